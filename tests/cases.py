@@ -1,0 +1,120 @@
+"""Seeded parity cases shared by the golden generator (oracle/gen_golden.py) and the tests.
+
+Every case is a deterministic PCM generator + encoder settings.  Expected outputs of the
+reference's libFLAC 1.4.3 binary for these cases are committed in tests/golden/encode_vectors.json.
+"""
+import os
+
+import numpy as np
+
+from pyflac_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _sines(n, ch, amp, seed, noise):
+    r = _rng(seed)
+    t = np.arange(n)[:, None]
+    f = 0.01 * (1 + np.arange(ch)) * (1 + 0.37 * np.arange(ch))
+    return (amp * np.sin(t * f) + r.integers(-noise, noise + 1, (n, ch))).astype(np.int64)
+
+
+def fixture_pcm(name):
+    """PCM of a reference test fixture, decoded from tests/golden/data/<name>.flac by the oracle."""
+    from oracle import oracle as O
+    with open(os.path.join(GOLDEN, 'data', name + '.flac'), 'rb') as f:
+        pcm, res = O.decode_stream(f.read())
+    return pcm, res.sample_rate, res.bps
+
+
+def make_pcm(spec):
+    """spec: dict(kind=..., ...) -> (int array [frames, ch], bps)."""
+    k = spec['kind']
+    if k == 'cfg1':
+        return synth.config1_sine(), 16
+    if k == 'cfg2':
+        return synth.config2_stereo16(spec['seconds'], spec.get('seed', 0)), 16
+    if k == 'hard16':
+        return synth.config2_hard16(spec['seconds'], spec.get('seed', 7)), 16
+    if k == 'cfg4':
+        return synth.config4_stereo24(spec['seconds'], spec.get('seed', 1)), 24
+    if k == 'cfg5':
+        return synth.config5_stream(spec['stream'], spec['seconds']), 16
+    if k == 'fixture':
+        pcm, _sr, bps = fixture_pcm(spec['name'])
+        return pcm, bps
+    if k == 'sines':
+        bps = spec['bps']
+        amp = (1 << (bps - 1)) - 1
+        return _sines(spec['n'], spec['ch'], amp * spec.get('level', 0.7), spec.get('seed', 3),
+                      max(amp // spec.get('snr', 30), 1)), bps
+    if k == 'noise':
+        bps = spec['bps']
+        r = _rng(spec.get('seed', 5))
+        return r.integers(-(1 << (bps - 1)), (1 << (bps - 1)), (spec['n'], spec['ch'])), bps
+    if k == 'zeros':
+        return np.zeros((spec['n'], spec['ch']), np.int64), spec['bps']
+    if k == 'const':
+        return np.full((spec['n'], spec['ch']), spec['value'], np.int64), spec['bps']
+    if k == 'wasted':
+        r = _rng(spec.get('seed', 9))
+        return r.integers(-2000, 2000, (spec['n'], spec['ch'])) << spec['shift'], spec['bps']
+    if k == 'lr_equal':
+        r = _rng(11)
+        a = r.integers(-20000, 20000, (spec['n'], 1))
+        return np.concatenate([a, a * spec.get('sign', 1)], axis=1), 16
+    if k == 'walk32':
+        r = _rng(13)
+        x = (np.cumsum(r.integers(-2 ** 27, 2 ** 27, spec['n'])) % 2 ** 31) | 1
+        return x.reshape(-1, 1), 32
+    raise KeyError(k)
+
+
+def as_int_array(pcm, bps):
+    """What pyFLAC hands to process(): int16 for 16-bit, else int32."""
+    pcm = np.asarray(pcm)
+    return pcm.astype(np.int16) if bps == 16 else pcm.astype(np.int32)
+
+
+# name -> (pcm spec, sample_rate, level, blocksize, streamable_subset)
+ENCODE_CASES = {
+    'cfg1_passthrough': ({'kind': 'cfg1'}, 44100, 5, 0, True),
+    'cfg2_2s_l5': ({'kind': 'cfg2', 'seconds': 2.0}, 48000, 5, 4096, True),
+    'cfg2_20s_l5': ({'kind': 'cfg2', 'seconds': 20.0}, 48000, 5, 4096, True),
+    'cfg4_1s_l8': ({'kind': 'cfg4', 'seconds': 1.0}, 96000, 8, 4096, True),
+    'cfg4_10s_l8': ({'kind': 'cfg4', 'seconds': 10.0}, 96000, 8, 4096, True),
+    'cfg4_1s_l5': ({'kind': 'cfg4', 'seconds': 1.0}, 96000, 5, 4096, True),
+    'cfg5_s0_2s': ({'kind': 'cfg5', 'stream': 0, 'seconds': 2.0}, 48000, 5, 4096, True),
+    'cfg5_s777_2s': ({'kind': 'cfg5', 'stream': 777, 'seconds': 2.0}, 48000, 5, 4096, True),
+    'fixture_mono_l5': ({'kind': 'fixture', 'name': 'mono'}, 44100, 5, 0, True),
+    'fixture_stereo_l5': ({'kind': 'fixture', 'name': 'stereo'}, 44100, 5, 0, True),
+    'fixture_stereo_l8': ({'kind': 'fixture', 'name': 'stereo'}, 44100, 8, 0, True),
+    'fixture_stereo_bs1024': ({'kind': 'fixture', 'name': 'stereo'}, 44100, 5, 1024, True),
+    'fixture_surround_l5': ({'kind': 'fixture', 'name': 'surround'}, 48000, 5, 0, True),
+    'fixture_32bit_l5': ({'kind': 'fixture', 'name': '32bit'}, 44100, 5, 0, True),
+    'noise16_st': ({'kind': 'noise', 'bps': 16, 'n': 9000, 'ch': 2}, 48000, 5, 4096, True),
+    'zeros16_mono': ({'kind': 'zeros', 'bps': 16, 'n': 5000, 'ch': 1}, 44100, 5, 0, True),
+    'const16_st': ({'kind': 'const', 'bps': 16, 'n': 8292, 'ch': 2, 'value': -5}, 48000, 5, 4096, True),
+    'wasted4_st': ({'kind': 'wasted', 'bps': 16, 'n': 8192, 'ch': 2, 'shift': 4}, 48000, 5, 4096, True),
+    'lr_equal': ({'kind': 'lr_equal', 'n': 8192}, 48000, 5, 4096, True),
+    'lr_opposite': ({'kind': 'lr_equal', 'n': 8192, 'sign': -1}, 48000, 5, 4096, True),
+    'sines24_l8_bs4608': ({'kind': 'sines', 'bps': 24, 'n': 12000, 'ch': 2}, 96000, 8, 4608, True),
+    'sines8_st': ({'kind': 'sines', 'bps': 8, 'n': 9000, 'ch': 2}, 22050, 8, 4096, True),
+    'sines12_st': ({'kind': 'sines', 'bps': 12, 'n': 9000, 'ch': 2}, 32000, 8, 4096, True),
+    'sines20_st': ({'kind': 'sines', 'bps': 20, 'n': 9000, 'ch': 2}, 96000, 8, 4096, True),
+    'sines16_ch3': ({'kind': 'sines', 'bps': 16, 'n': 6000, 'ch': 3, 'level': 0.1}, 48000, 5, 4096, True),
+    'sines16_ch8': ({'kind': 'sines', 'bps': 16, 'n': 6000, 'ch': 8, 'level': 0.1}, 48000, 5, 4096, True),
+    'sines16_bs16': ({'kind': 'sines', 'bps': 16, 'n': 55, 'ch': 2, 'level': 0.1}, 48000, 5, 16, True),
+    'sines16_bs1000': ({'kind': 'sines', 'bps': 16, 'n': 3007, 'ch': 2, 'level': 0.1}, 48000, 5, 1000, True),
+    'sines16_bs65535_lax': ({'kind': 'sines', 'bps': 16, 'n': 66312, 'ch': 2, 'level': 0.1}, 48000, 8, 65535, False),
+    'sines16_sr12345_lax': ({'kind': 'sines', 'bps': 16, 'n': 5000, 'ch': 1, 'level': 0.1}, 12345, 5, 1024, False),
+    'sines16_tail3': ({'kind': 'sines', 'bps': 16, 'n': 4099, 'ch': 2, 'level': 0.1}, 48000, 5, 4096, True),
+    'walk32_l8': ({'kind': 'walk32', 'n': 12288}, 44100, 8, 4096, True),
+}
+for _lv in range(9):
+    ENCODE_CASES['hard16_l%d' % _lv] = ({'kind': 'hard16', 'seconds': 1.0}, 48000, _lv, 0, True)
+    ENCODE_CASES['cfg2_1s_l%d' % _lv] = ({'kind': 'cfg2', 'seconds': 1.0, 'seed': 42}, 48000, _lv, 0, True)

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import json
+    from tests import cases
+    with open(os.path.join(cases.GOLDEN, 'encode_vectors.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def small_streams():
+    import numpy as np
+    from tests import cases
+    z = np.load(os.path.join(cases.GOLDEN, 'small_streams.npz'))
+    return {k: z[k].tobytes() for k in z.files}
