@@ -1,0 +1,489 @@
+/*
+ * flacgpu.h -- C ABI of libflacgpu.so, the MI355X-native FLAC core behind pyFLAC's API.
+ *
+ * Part 1 is the libFLAC entry-point subset that pyFLAC binds through cffi
+ * (reference: pyflac/builder/encoder.py:266-322 and pyflac/builder/decoder.py:387-475).  Names,
+ * signatures, enum values and callback contracts are those of libFLAC 1.4.3
+ * (pyflac/include/FLAC/stream_encoder.h, stream_decoder.h, format.h), so the reference can link
+ * against this library by changing only pyflac/builder/build_args.py:49-51.
+ *
+ * Part 2 is the batch extension the single-stream callback API cannot express: many blocks /
+ * many streams per launch with PCM and output resident in HBM ("Extensions").
+ *
+ * Plain C, no torch / HIP types in any signature; device buffers are passed as void* addresses.
+ */
+#ifndef FLACGPU_H
+#define FLACGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================== Part 1: libFLAC-compatible ABI */
+typedef int FLAC__bool;
+typedef uint8_t FLAC__byte;
+typedef int32_t FLAC__int32;
+typedef int64_t FLAC__int64;
+typedef uint32_t FLAC__uint32;
+typedef uint64_t FLAC__uint64;
+typedef uint16_t FLAC__uint16;
+typedef uint8_t FLAC__uint8;
+
+/* ---- encoder enums (pyflac/builder/encoder.py:51-106) */
+typedef enum {
+    FLAC__STREAM_ENCODER_OK = 0,
+    FLAC__STREAM_ENCODER_UNINITIALIZED,
+    FLAC__STREAM_ENCODER_OGG_ERROR,
+    FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR,
+    FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA,
+    FLAC__STREAM_ENCODER_CLIENT_ERROR,
+    FLAC__STREAM_ENCODER_IO_ERROR,
+    FLAC__STREAM_ENCODER_FRAMING_ERROR,
+    FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR
+} FLAC__StreamEncoderState;
+extern const char *const FLAC__StreamEncoderStateString[];
+
+typedef enum {
+    FLAC__STREAM_ENCODER_INIT_STATUS_OK = 0,
+    FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR,
+    FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION,
+    FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER,
+    FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE,
+    FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA,
+    FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED
+} FLAC__StreamEncoderInitStatus;
+extern const char *const FLAC__StreamEncoderInitStatusString[];
+
+typedef enum {
+    FLAC__STREAM_ENCODER_READ_STATUS_CONTINUE,
+    FLAC__STREAM_ENCODER_READ_STATUS_END_OF_STREAM,
+    FLAC__STREAM_ENCODER_READ_STATUS_ABORT,
+    FLAC__STREAM_ENCODER_READ_STATUS_UNSUPPORTED
+} FLAC__StreamEncoderReadStatus;
+typedef enum {
+    FLAC__STREAM_ENCODER_SEEK_STATUS_OK,
+    FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR,
+    FLAC__STREAM_ENCODER_SEEK_STATUS_UNSUPPORTED
+} FLAC__StreamEncoderSeekStatus;
+typedef enum {
+    FLAC__STREAM_ENCODER_TELL_STATUS_OK,
+    FLAC__STREAM_ENCODER_TELL_STATUS_ERROR,
+    FLAC__STREAM_ENCODER_TELL_STATUS_UNSUPPORTED
+} FLAC__StreamEncoderTellStatus;
+typedef enum {
+    FLAC__STREAM_ENCODER_WRITE_STATUS_OK = 0,
+    FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR
+} FLAC__StreamEncoderWriteStatus;
+
+/* Opaque two-pointer handles (pyflac/builder/encoder.py:109-114, decoder.py:139-144). */
+typedef struct {
+    struct FLAC__StreamEncoderProtected *protected_;
+    struct FLAC__StreamEncoderPrivate *private_;
+} FLAC__StreamEncoder;
+typedef struct {
+    struct FLAC__StreamDecoderProtected *protected_;
+    struct FLAC__StreamDecoderPrivate *private_;
+} FLAC__StreamDecoder;
+
+/* ---- metadata (pyflac/builder/encoder.py:117-248).  Only STREAMINFO is ever produced. */
+typedef enum {
+    FLAC__METADATA_TYPE_STREAMINFO = 0,
+    FLAC__METADATA_TYPE_PADDING = 1,
+    FLAC__METADATA_TYPE_APPLICATION = 2,
+    FLAC__METADATA_TYPE_SEEKTABLE = 3,
+    FLAC__METADATA_TYPE_VORBIS_COMMENT = 4,
+    FLAC__METADATA_TYPE_CUESHEET = 5,
+    FLAC__METADATA_TYPE_PICTURE = 6,
+    FLAC__METADATA_TYPE_UNDEFINED = 7,
+    FLAC__MAX_METADATA_TYPE = 126
+} FLAC__MetadataType;
+
+typedef struct {
+    uint32_t min_blocksize, max_blocksize;
+    uint32_t min_framesize, max_framesize;
+    uint32_t sample_rate;
+    uint32_t channels;
+    uint32_t bits_per_sample;
+    FLAC__uint64 total_samples;
+    FLAC__byte md5sum[16];
+} FLAC__StreamMetadata_StreamInfo;
+
+typedef struct {
+    FLAC__MetadataType type;
+    FLAC__bool is_last;
+    uint32_t length;
+    union {
+        FLAC__StreamMetadata_StreamInfo stream_info;
+        /* the largest member of libFLAC's union is the cue sheet (160 bytes on LP64) */
+        unsigned char reserve_[160];
+    } data;
+} FLAC__StreamMetadata;
+
+/* ---- encoder callbacks (pyflac/builder/encoder.py:251-256) */
+typedef FLAC__StreamEncoderReadStatus (*FLAC__StreamEncoderReadCallback)(const FLAC__StreamEncoder *encoder, FLAC__byte buffer[], size_t *bytes, void *client_data);
+typedef FLAC__StreamEncoderWriteStatus (*FLAC__StreamEncoderWriteCallback)(const FLAC__StreamEncoder *encoder, const FLAC__byte buffer[], size_t bytes, uint32_t samples, uint32_t current_frame, void *client_data);
+typedef FLAC__StreamEncoderSeekStatus (*FLAC__StreamEncoderSeekCallback)(const FLAC__StreamEncoder *encoder, FLAC__uint64 absolute_byte_offset, void *client_data);
+typedef FLAC__StreamEncoderTellStatus (*FLAC__StreamEncoderTellCallback)(const FLAC__StreamEncoder *encoder, FLAC__uint64 *absolute_byte_offset, void *client_data);
+typedef void (*FLAC__StreamEncoderMetadataCallback)(const FLAC__StreamEncoder *encoder, const FLAC__StreamMetadata *metadata, void *client_data);
+typedef void (*FLAC__StreamEncoderProgressCallback)(const FLAC__StreamEncoder *encoder, FLAC__uint64 bytes_written, FLAC__uint64 samples_written, uint32_t frames_written, uint32_t total_frames_estimate, void *client_data);
+
+/* ---- encoder functions (pyflac/builder/encoder.py:266-322) */
+FLAC__StreamEncoder *FLAC__stream_encoder_new(void);
+void FLAC__stream_encoder_delete(FLAC__StreamEncoder *encoder);
+
+FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_channels(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_bits_per_sample(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_sample_rate(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_blocksize(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_do_mid_side_stereo(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_loose_mid_side_stereo(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_apodization(FLAC__StreamEncoder *encoder, const char *specification);
+FLAC__bool FLAC__stream_encoder_set_max_lpc_order(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_qlp_coeff_precision(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_do_qlp_coeff_prec_search(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_do_exhaustive_model_search(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_min_residual_partition_order(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_max_residual_partition_order(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_rice_parameter_search_dist(FLAC__StreamEncoder *encoder, uint32_t value);
+FLAC__bool FLAC__stream_encoder_set_total_samples_estimate(FLAC__StreamEncoder *encoder, FLAC__uint64 value);
+FLAC__bool FLAC__stream_encoder_set_streamable_subset(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_limit_min_bitrate(FLAC__StreamEncoder *encoder, FLAC__bool value);
+/* exported by libFLAC 1.4.3 (stream_encoder.h) though not in pyFLAC's cdef; used by bench.py */
+FLAC__bool FLAC__stream_encoder_set_do_md5(FLAC__StreamEncoder *encoder, FLAC__bool value);
+
+FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *encoder);
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *encoder);
+void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *encoder, FLAC__uint64 *absolute_sample, uint32_t *frame_number, uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got);
+FLAC__bool FLAC__stream_encoder_get_verify(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_streamable_subset(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_channels(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_bits_per_sample(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_sample_rate(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_blocksize(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_mid_side_stereo(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_loose_mid_side_stereo(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_max_lpc_order(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_qlp_coeff_precision(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_qlp_coeff_prec_search(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_escape_coding(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_exhaustive_model_search(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_min_residual_partition_order(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_max_residual_partition_order(const FLAC__StreamEncoder *encoder);
+uint32_t FLAC__stream_encoder_get_rice_parameter_search_dist(const FLAC__StreamEncoder *encoder);
+FLAC__uint64 FLAC__stream_encoder_get_total_samples_estimate(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_limit_min_bitrate(const FLAC__StreamEncoder *encoder);
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *encoder, FLAC__StreamEncoderWriteCallback write_callback, FLAC__StreamEncoderSeekCallback seek_callback, FLAC__StreamEncoderTellCallback tell_callback, FLAC__StreamEncoderMetadataCallback metadata_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamEncoder *encoder, FLAC__StreamEncoderReadCallback read_callback, FLAC__StreamEncoderWriteCallback write_callback, FLAC__StreamEncoderSeekCallback seek_callback, FLAC__StreamEncoderTellCallback tell_callback, FLAC__StreamEncoderMetadataCallback metadata_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_FILE(FLAC__StreamEncoder *encoder, FILE *file, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_FILE(FLAC__StreamEncoder *encoder, FILE *file, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder *encoder, const char *filename, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_file(FLAC__StreamEncoder *encoder, const char *filename, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *encoder, const FLAC__int32 *const buffer[], uint32_t samples);
+FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *encoder, const FLAC__int32 buffer[], uint32_t samples);
+
+/* ---- decoder enums (pyflac/builder/decoder.py:49-136) */
+typedef enum {
+    FLAC__STREAM_DECODER_SEARCH_FOR_METADATA = 0,
+    FLAC__STREAM_DECODER_READ_METADATA,
+    FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC,
+    FLAC__STREAM_DECODER_READ_FRAME,
+    FLAC__STREAM_DECODER_END_OF_STREAM,
+    FLAC__STREAM_DECODER_OGG_ERROR,
+    FLAC__STREAM_DECODER_SEEK_ERROR,
+    FLAC__STREAM_DECODER_ABORTED,
+    FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR,
+    FLAC__STREAM_DECODER_UNINITIALIZED
+} FLAC__StreamDecoderState;
+extern const char *const FLAC__StreamDecoderStateString[];
+
+typedef enum {
+    FLAC__STREAM_DECODER_INIT_STATUS_OK = 0,
+    FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER,
+    FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS,
+    FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR,
+    FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE,
+    FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED
+} FLAC__StreamDecoderInitStatus;
+extern const char *const FLAC__StreamDecoderInitStatusString[];
+
+typedef enum {
+    FLAC__STREAM_DECODER_READ_STATUS_CONTINUE,
+    FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM,
+    FLAC__STREAM_DECODER_READ_STATUS_ABORT
+} FLAC__StreamDecoderReadStatus;
+typedef enum {
+    FLAC__STREAM_DECODER_SEEK_STATUS_OK,
+    FLAC__STREAM_DECODER_SEEK_STATUS_ERROR,
+    FLAC__STREAM_DECODER_SEEK_STATUS_UNSUPPORTED
+} FLAC__StreamDecoderSeekStatus;
+typedef enum {
+    FLAC__STREAM_DECODER_TELL_STATUS_OK,
+    FLAC__STREAM_DECODER_TELL_STATUS_ERROR,
+    FLAC__STREAM_DECODER_TELL_STATUS_UNSUPPORTED
+} FLAC__StreamDecoderTellStatus;
+typedef enum {
+    FLAC__STREAM_DECODER_LENGTH_STATUS_OK,
+    FLAC__STREAM_DECODER_LENGTH_STATUS_ERROR,
+    FLAC__STREAM_DECODER_LENGTH_STATUS_UNSUPPORTED
+} FLAC__StreamDecoderLengthStatus;
+typedef enum {
+    FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE,
+    FLAC__STREAM_DECODER_WRITE_STATUS_ABORT
+} FLAC__StreamDecoderWriteStatus;
+typedef enum {
+    FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC,
+    FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER,
+    FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH,
+    FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM,
+    FLAC__STREAM_DECODER_ERROR_STATUS_BAD_METADATA
+} FLAC__StreamDecoderErrorStatus;
+extern const char *const FLAC__StreamDecoderErrorStatusString[];
+
+typedef enum {
+    FLAC__FRAME_NUMBER_TYPE_FRAME_NUMBER,
+    FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER
+} FLAC__FrameNumberType;
+typedef enum {
+    FLAC__CHANNEL_ASSIGNMENT_INDEPENDENT = 0,
+    FLAC__CHANNEL_ASSIGNMENT_LEFT_SIDE = 1,
+    FLAC__CHANNEL_ASSIGNMENT_RIGHT_SIDE = 2,
+    FLAC__CHANNEL_ASSIGNMENT_MID_SIDE = 3
+} FLAC__ChannelAssignment;
+typedef enum {
+    FLAC__SUBFRAME_TYPE_CONSTANT = 0,
+    FLAC__SUBFRAME_TYPE_VERBATIM = 1,
+    FLAC__SUBFRAME_TYPE_FIXED = 2,
+    FLAC__SUBFRAME_TYPE_LPC = 3
+} FLAC__SubframeType;
+typedef enum {
+    FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE = 0,
+    FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 = 1
+} FLAC__EntropyCodingMethodType;
+
+/* ---- FLAC__Frame (pyflac/builder/decoder.py:146-231).  pyFLAC reads only
+ * header.{blocksize,sample_rate,channels,bits_per_sample} (pyflac/decoder.py:500-524); the subframe
+ * records are filled with type / order / wasted bits, residual pointers are NULL. */
+typedef struct {
+    uint32_t blocksize;
+    uint32_t sample_rate;
+    uint32_t channels;
+    FLAC__ChannelAssignment channel_assignment;
+    uint32_t bits_per_sample;
+    FLAC__FrameNumberType number_type;
+    union {
+        FLAC__uint32 frame_number;
+        FLAC__uint64 sample_number;
+    } number;
+    FLAC__uint8 crc;
+} FLAC__FrameHeader;
+
+typedef struct {
+    uint32_t *parameters;
+    uint32_t *raw_bits;
+    uint32_t capacity_by_order;
+} FLAC__EntropyCodingMethod_PartitionedRiceContents;
+typedef struct {
+    uint32_t order;
+    const FLAC__EntropyCodingMethod_PartitionedRiceContents *contents;
+} FLAC__EntropyCodingMethod_PartitionedRice;
+typedef struct {
+    FLAC__EntropyCodingMethodType type;
+    union {
+        FLAC__EntropyCodingMethod_PartitionedRice partitioned_rice;
+    } data;
+} FLAC__EntropyCodingMethod;
+typedef struct {
+    FLAC__int64 value;
+} FLAC__Subframe_Constant;
+typedef enum {
+    FLAC__VERBATIM_SUBFRAME_DATA_TYPE_INT32 = 0,
+    FLAC__VERBATIM_SUBFRAME_DATA_TYPE_INT64 = 1
+} FLAC__VerbatimSubframeDataType;
+typedef struct {
+    union {
+        const FLAC__int32 *int32;
+        const FLAC__int64 *int64;
+    } data;
+    FLAC__VerbatimSubframeDataType data_type;
+} FLAC__Subframe_Verbatim;
+typedef struct {
+    FLAC__EntropyCodingMethod entropy_coding_method;
+    uint32_t order;
+    FLAC__int64 warmup[4];
+    const FLAC__int32 *residual;
+} FLAC__Subframe_Fixed;
+typedef struct {
+    FLAC__EntropyCodingMethod entropy_coding_method;
+    uint32_t order;
+    uint32_t qlp_coeff_precision;
+    int quantization_level;
+    FLAC__int32 qlp_coeff[32];
+    FLAC__int64 warmup[32];
+    const FLAC__int32 *residual;
+} FLAC__Subframe_LPC;
+typedef struct {
+    FLAC__SubframeType type;
+    union {
+        FLAC__Subframe_Constant constant;
+        FLAC__Subframe_Fixed fixed;
+        FLAC__Subframe_LPC lpc;
+        FLAC__Subframe_Verbatim verbatim;
+    } data;
+    uint32_t wasted_bits;
+} FLAC__Subframe;
+typedef struct {
+    FLAC__uint16 crc;
+} FLAC__FrameFooter;
+typedef struct {
+    FLAC__FrameHeader header;
+    FLAC__Subframe subframes[8];
+    FLAC__FrameFooter footer;
+} FLAC__Frame;
+
+/* ---- decoder callbacks (pyflac/builder/decoder.py:368-375) */
+typedef FLAC__StreamDecoderReadStatus (*FLAC__StreamDecoderReadCallback)(const FLAC__StreamDecoder *decoder, FLAC__byte buffer[], size_t *bytes, void *client_data);
+typedef FLAC__StreamDecoderSeekStatus (*FLAC__StreamDecoderSeekCallback)(const FLAC__StreamDecoder *decoder, FLAC__uint64 absolute_byte_offset, void *client_data);
+typedef FLAC__StreamDecoderTellStatus (*FLAC__StreamDecoderTellCallback)(const FLAC__StreamDecoder *decoder, FLAC__uint64 *absolute_byte_offset, void *client_data);
+typedef FLAC__StreamDecoderLengthStatus (*FLAC__StreamDecoderLengthCallback)(const FLAC__StreamDecoder *decoder, FLAC__uint64 *stream_length, void *client_data);
+typedef FLAC__bool (*FLAC__StreamDecoderEofCallback)(const FLAC__StreamDecoder *decoder, void *client_data);
+typedef FLAC__StreamDecoderWriteStatus (*FLAC__StreamDecoderWriteCallback)(const FLAC__StreamDecoder *decoder, const FLAC__Frame *frame, const FLAC__int32 *const buffer[], void *client_data);
+typedef void (*FLAC__StreamDecoderMetadataCallback)(const FLAC__StreamDecoder *decoder, const FLAC__StreamMetadata *metadata, void *client_data);
+typedef void (*FLAC__StreamDecoderErrorCallback)(const FLAC__StreamDecoder *decoder, FLAC__StreamDecoderErrorStatus status, void *client_data);
+
+/* ---- decoder functions (pyflac/builder/decoder.py:387-475) */
+FLAC__StreamDecoder *FLAC__stream_decoder_new(void);
+void FLAC__stream_decoder_delete(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *decoder, FLAC__bool value);
+FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *decoder, FLAC__MetadataType type);
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_application(FLAC__StreamDecoder *decoder, const FLAC__byte id[4]);
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *decoder, FLAC__MetadataType type);
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_application(FLAC__StreamDecoder *decoder, const FLAC__byte id[4]);
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *decoder);
+FLAC__StreamDecoderState FLAC__stream_decoder_get_state(const FLAC__StreamDecoder *decoder);
+const char *FLAC__stream_decoder_get_resolved_state_string(const FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_get_md5_checking(const FLAC__StreamDecoder *decoder);
+FLAC__uint64 FLAC__stream_decoder_get_total_samples(const FLAC__StreamDecoder *decoder);
+uint32_t FLAC__stream_decoder_get_channels(const FLAC__StreamDecoder *decoder);
+FLAC__ChannelAssignment FLAC__stream_decoder_get_channel_assignment(const FLAC__StreamDecoder *decoder);
+uint32_t FLAC__stream_decoder_get_bits_per_sample(const FLAC__StreamDecoder *decoder);
+uint32_t FLAC__stream_decoder_get_sample_rate(const FLAC__StreamDecoder *decoder);
+uint32_t FLAC__stream_decoder_get_blocksize(const FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_get_decode_position(const FLAC__StreamDecoder *decoder, FLAC__uint64 *position);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_stream(FLAC__StreamDecoder *decoder, FLAC__StreamDecoderReadCallback read_callback, FLAC__StreamDecoderSeekCallback seek_callback, FLAC__StreamDecoderTellCallback tell_callback, FLAC__StreamDecoderLengthCallback length_callback, FLAC__StreamDecoderEofCallback eof_callback, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_stream(FLAC__StreamDecoder *decoder, FLAC__StreamDecoderReadCallback read_callback, FLAC__StreamDecoderSeekCallback seek_callback, FLAC__StreamDecoderTellCallback tell_callback, FLAC__StreamDecoderLengthCallback length_callback, FLAC__StreamDecoderEofCallback eof_callback, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_FILE(FLAC__StreamDecoder *decoder, FILE *file, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_FILE(FLAC__StreamDecoder *decoder, FILE *file, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder *decoder, const char *filename, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_file(FLAC__StreamDecoder *decoder, const char *filename, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_process_single(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_process_until_end_of_metadata(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_process_until_end_of_stream(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_skip_single_frame(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *decoder, FLAC__uint64 sample);
+
+extern const char *FLAC__VERSION_STRING;
+extern const char *FLAC__VENDOR_STRING;
+
+/* ===================================================================== Part 2: batch extension */
+typedef struct flacgpu_ctx flacgpu_ctx;
+
+/* Encoder settings after level/blocksize resolution (what FLAC__stream_encoder_set_compression_level
+ * + init_stream establish; stream_encoder.h:845-853). */
+typedef struct {
+    uint32_t channels, bits_per_sample, sample_rate, blocksize;
+    uint32_t do_mid_side, loose_mid_side;
+    uint32_t max_lpc_order, qlp_coeff_precision;
+    uint32_t min_partition_order, max_partition_order;
+    uint32_t apod_parts;          /* 0 = tukey(0.5); n >= 2 = subdivide_tukey(n) */
+    uint32_t streamable_subset;
+} flacgpu_settings;
+
+/* Returns a FLAC__StreamEncoderInitStatus value (0 = OK). */
+int flacgpu_settings_from_level(flacgpu_settings *s, uint32_t level, uint32_t channels, uint32_t bits_per_sample,
+                                uint32_t sample_rate, uint32_t blocksize, int streamable_subset);
+
+int flacgpu_device_count(void);
+flacgpu_ctx *flacgpu_ctx_create(int device);           /* NULL on failure; see flacgpu_last_error() */
+void flacgpu_ctx_destroy(flacgpu_ctx *ctx);
+const char *flacgpu_last_error(void);
+
+/* One stream of a batch: `nsamples` inter-channel samples starting at sample index `pcm_offset` of the
+ * device PCM buffer; frames are numbered from first_frame. */
+typedef struct {
+    uint64_t pcm_offset;
+    uint64_t nsamples;
+    uint32_t first_frame;
+    uint32_t reserved;
+} flacgpu_stream_desc;
+
+typedef struct {
+    uint32_t nblocks;             /* frames produced */
+    uint32_t error_flags;         /* OR of per-block FG_ERR_* bits; 0 = ok */
+    uint64_t total_bytes;         /* bytes written to d_out */
+    float encode_kernel_ms;       /* HIP-event time of the frame-encode kernel */
+    float total_gpu_ms;           /* HIP-event time of the whole enqueue (encode + compaction) */
+} flacgpu_encode_stats;
+
+/* Encode every block of every stream.  d_pcm: device address of interleaved PCM (int32, or int16 when
+ * pcm_is_i16).  d_out receives the frames back to back in (stream, block) order; d_frame_offsets
+ * (device, nblocks+1 uint64) their byte offsets.  Blocks are settings->blocksize long, the last block of a
+ * stream may be shorter.  Synchronous: returns when the GPU work is complete.  0 on success. */
+int flacgpu_encode_streams(flacgpu_ctx *ctx, const flacgpu_settings *settings, const void *d_pcm, int pcm_is_i16,
+                           const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_capacity,
+                           void *d_frame_offsets, flacgpu_encode_stats *stats);
+
+/* Upper bound of the encoded size of the given batch (for sizing d_out). */
+uint64_t flacgpu_encode_bound(const flacgpu_settings *settings, const flacgpu_stream_desc *streams, uint32_t nstreams,
+                              uint32_t *nblocks);
+
+/* Debug: per-block analysis records of the last flacgpu_encode_streams call made with
+ * flacgpu_set_debug(ctx, 1).  Layout: FgDebugRec (pyflac_amd/csrc/fg_types.h). */
+void flacgpu_set_debug(flacgpu_ctx *ctx, int on);
+int flacgpu_copy_debug(flacgpu_ctx *ctx, void *host_dst, uint32_t first_block, uint32_t nblocks);
+int flacgpu_copy_block_results(flacgpu_ctx *ctx, void *host_dst, uint32_t nblocks);
+
+typedef struct {
+    uint32_t nframes;
+    uint32_t error_frames;        /* frames with CRC-16 mismatch or malformed contents */
+    uint64_t total_samples;       /* inter-channel samples written */
+    uint32_t channels, bits_per_sample, sample_rate, max_blocksize;
+    float decode_kernel_ms;
+    float total_gpu_ms;
+} flacgpu_decode_stats;
+
+/* Decode the audio frames of one FLAC stream held in device memory.  d_stream/len: the frame data (device);
+ * the frame index (h_frame_offsets: nframes+1 byte offsets into d_stream) comes from flacgpu_index_frames.
+ * d_pcm receives interleaved int32 (nsamples_total * channels).  0 on success. */
+int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *h_frame_offsets,
+                          uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
+                          uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
+
+/* Host-side frame indexer: parses metadata and frame headers of a complete FLAC stream in host memory and
+ * returns frame byte offsets (validated by header CRC-8 and chained by frame CRC-16).  Returns the number
+ * of frames, or a negative value on error. */
+int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uint64_t *frame_offsets, uint64_t capacity,
+                             FLAC__StreamMetadata_StreamInfo *streaminfo, uint64_t *audio_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLACGPU_H */

@@ -1,0 +1,190 @@
+"""ctypes loader for libflacgpu.so (the C-ABI boundary, include/flacgpu.h).
+
+The reference binds libFLAC through cffi API-mode modules generated from
+``pyflac/builder/encoder.py`` / ``pyflac/builder/decoder.py``; cffi is not available here, so the same
+entry points are bound with ctypes.  There is no fallback: if the HIP library is missing this module
+raises on import of the product classes.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libflacgpu.so')
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [('min_blocksize', C.c_uint32), ('max_blocksize', C.c_uint32),
+                ('min_framesize', C.c_uint32), ('max_framesize', C.c_uint32),
+                ('sample_rate', C.c_uint32), ('channels', C.c_uint32),
+                ('bits_per_sample', C.c_uint32), ('total_samples', C.c_uint64),
+                ('md5sum', C.c_uint8 * 16)]
+
+
+class _MetaData(C.Union):
+    _fields_ = [('stream_info', StreamInfo), ('reserve_', C.c_uint8 * 160)]
+
+
+class StreamMetadata(C.Structure):
+    _fields_ = [('type', C.c_int), ('is_last', C.c_int), ('length', C.c_uint32), ('data', _MetaData)]
+
+
+class _Number(C.Union):
+    _fields_ = [('frame_number', C.c_uint32), ('sample_number', C.c_uint64)]
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [('blocksize', C.c_uint32), ('sample_rate', C.c_uint32), ('channels', C.c_uint32),
+                ('channel_assignment', C.c_int), ('bits_per_sample', C.c_uint32),
+                ('number_type', C.c_int), ('number', _Number), ('crc', C.c_uint8)]
+
+
+class Frame(C.Structure):
+    # only the header is read on the Python side (pyflac/decoder.py:500-524)
+    _fields_ = [('header', FrameHeader)]
+
+
+class Settings(C.Structure):
+    _fields_ = [('channels', C.c_uint32), ('bits_per_sample', C.c_uint32), ('sample_rate', C.c_uint32),
+                ('blocksize', C.c_uint32), ('do_mid_side', C.c_uint32), ('loose_mid_side', C.c_uint32),
+                ('max_lpc_order', C.c_uint32), ('qlp_coeff_precision', C.c_uint32),
+                ('min_partition_order', C.c_uint32), ('max_partition_order', C.c_uint32),
+                ('apod_parts', C.c_uint32), ('streamable_subset', C.c_uint32)]
+
+
+class StreamDesc(C.Structure):
+    _fields_ = [('pcm_offset', C.c_uint64), ('nsamples', C.c_uint64), ('first_frame', C.c_uint32),
+                ('reserved', C.c_uint32)]
+
+
+class EncodeStats(C.Structure):
+    _fields_ = [('nblocks', C.c_uint32), ('error_flags', C.c_uint32), ('total_bytes', C.c_uint64),
+                ('encode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float)]
+
+
+class DecodeStats(C.Structure):
+    _fields_ = [('nframes', C.c_uint32), ('error_frames', C.c_uint32), ('total_samples', C.c_uint64),
+                ('channels', C.c_uint32), ('bits_per_sample', C.c_uint32), ('sample_rate', C.c_uint32),
+                ('max_blocksize', C.c_uint32), ('decode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float)]
+
+
+ENC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
+ENC_SEEK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)
+ENC_TELL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+ENC_META_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(StreamMetadata), C.c_void_p)
+ENC_PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p)
+DEC_READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.POINTER(C.c_size_t), C.c_void_p)
+DEC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Frame), C.POINTER(C.POINTER(C.c_int32)), C.c_void_p)
+DEC_META_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(StreamMetadata), C.c_void_p)
+DEC_ERROR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+ENCODER_FUNCTIONS = [
+    'new', 'delete', 'set_verify', 'set_channels', 'set_bits_per_sample', 'set_sample_rate',
+    'set_compression_level', 'set_blocksize', 'set_do_mid_side_stereo', 'set_loose_mid_side_stereo',
+    'set_apodization', 'set_max_lpc_order', 'set_qlp_coeff_precision', 'set_do_qlp_coeff_prec_search',
+    'set_do_exhaustive_model_search', 'set_min_residual_partition_order', 'set_max_residual_partition_order',
+    'set_rice_parameter_search_dist', 'set_total_samples_estimate', 'set_streamable_subset',
+    'set_limit_min_bitrate', 'get_state', 'get_resolved_state_string', 'get_verify_decoder_error_stats',
+    'get_verify', 'get_streamable_subset', 'get_channels', 'get_bits_per_sample', 'get_sample_rate',
+    'get_blocksize', 'get_do_mid_side_stereo', 'get_loose_mid_side_stereo', 'get_max_lpc_order',
+    'get_qlp_coeff_precision', 'get_do_qlp_coeff_prec_search', 'get_do_escape_coding',
+    'get_do_exhaustive_model_search', 'get_min_residual_partition_order', 'get_max_residual_partition_order',
+    'get_rice_parameter_search_dist', 'get_total_samples_estimate', 'get_limit_min_bitrate', 'init_stream',
+    'init_ogg_stream', 'init_FILE', 'init_ogg_FILE', 'init_file', 'init_ogg_file', 'finish', 'process',
+    'process_interleaved']
+DECODER_FUNCTIONS = [
+    'new', 'delete', 'set_md5_checking', 'set_metadata_respond', 'set_metadata_respond_application',
+    'set_metadata_respond_all', 'set_metadata_ignore', 'set_metadata_ignore_application',
+    'set_metadata_ignore_all', 'get_state', 'get_resolved_state_string', 'get_md5_checking',
+    'get_total_samples', 'get_channels', 'get_channel_assignment', 'get_bits_per_sample', 'get_sample_rate',
+    'get_blocksize', 'get_decode_position', 'init_stream', 'init_ogg_stream', 'init_FILE', 'init_ogg_FILE',
+    'init_file', 'init_ogg_file', 'finish', 'flush', 'reset', 'process_single',
+    'process_until_end_of_metadata', 'process_until_end_of_stream', 'skip_single_frame', 'seek_absolute']
+DATA_SYMBOLS = ['FLAC__StreamEncoderStateString', 'FLAC__StreamEncoderInitStatusString',
+                'FLAC__StreamDecoderStateString', 'FLAC__StreamDecoderInitStatusString',
+                'FLAC__StreamDecoderErrorStatusString']
+EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu_ctx_create', 'flacgpu_ctx_destroy',
+                 'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
+                 'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_index_frames']
+
+_lib = None
+
+
+def lib():
+    """Load libflacgpu.so and declare the signatures used from Python.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(there is no CPU fallback)' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.FLAC__stream_encoder_new.restype = vp
+    L.FLAC__stream_encoder_delete.argtypes = [vp]
+    L.FLAC__stream_encoder_delete.restype = None
+    for n in ('verify', 'channels', 'bits_per_sample', 'sample_rate', 'compression_level', 'blocksize',
+              'streamable_subset', 'limit_min_bitrate', 'do_md5'):
+        f = getattr(L, 'FLAC__stream_encoder_set_' + n)
+        f.argtypes = [vp, C.c_uint32]
+        f.restype = C.c_int
+    for n in ('verify', 'channels', 'bits_per_sample', 'sample_rate', 'blocksize', 'streamable_subset',
+              'limit_min_bitrate', 'state', 'max_lpc_order', 'qlp_coeff_precision',
+              'max_residual_partition_order', 'do_mid_side_stereo', 'loose_mid_side_stereo'):
+        f = getattr(L, 'FLAC__stream_encoder_get_' + n)
+        f.argtypes = [vp]
+        f.restype = C.c_uint32
+    L.FLAC__stream_encoder_init_stream.argtypes = [vp, ENC_WRITE_CB, ENC_SEEK_CB, ENC_TELL_CB, ENC_META_CB, vp]
+    L.FLAC__stream_encoder_init_stream.restype = C.c_int
+    L.FLAC__stream_encoder_init_file.argtypes = [vp, C.c_char_p, ENC_PROGRESS_CB, vp]
+    L.FLAC__stream_encoder_init_file.restype = C.c_int
+    L.FLAC__stream_encoder_process_interleaved.argtypes = [vp, vp, C.c_uint32]
+    L.FLAC__stream_encoder_process_interleaved.restype = C.c_int
+    L.FLAC__stream_encoder_finish.argtypes = [vp]
+    L.FLAC__stream_encoder_finish.restype = C.c_int
+    L.FLAC__stream_decoder_new.restype = vp
+    L.FLAC__stream_decoder_delete.argtypes = [vp]
+    L.FLAC__stream_decoder_delete.restype = None
+    L.FLAC__stream_decoder_get_state.argtypes = [vp]
+    L.FLAC__stream_decoder_get_state.restype = C.c_int
+    L.FLAC__stream_decoder_init_stream.argtypes = [vp, DEC_READ_CB, vp, vp, vp, vp, DEC_WRITE_CB, DEC_META_CB, DEC_ERROR_CB, vp]
+    L.FLAC__stream_decoder_init_stream.restype = C.c_int
+    L.FLAC__stream_decoder_init_file.argtypes = [vp, C.c_char_p, DEC_WRITE_CB, DEC_META_CB, DEC_ERROR_CB, vp]
+    L.FLAC__stream_decoder_init_file.restype = C.c_int
+    for n in ('finish', 'process_single', 'process_until_end_of_stream', 'process_until_end_of_metadata', 'flush', 'reset'):
+        f = getattr(L, 'FLAC__stream_decoder_' + n)
+        f.argtypes = [vp]
+        f.restype = C.c_int
+    L.flacgpu_settings_from_level.argtypes = [C.POINTER(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.flacgpu_settings_from_level.restype = C.c_int
+    L.flacgpu_device_count.restype = C.c_int
+    L.flacgpu_ctx_create.argtypes = [C.c_int]
+    L.flacgpu_ctx_create.restype = vp
+    L.flacgpu_ctx_destroy.argtypes = [vp]
+    L.flacgpu_ctx_destroy.restype = None
+    L.flacgpu_last_error.restype = C.c_char_p
+    L.flacgpu_encode_streams.argtypes = [vp, C.POINTER(Settings), vp, C.c_int, C.POINTER(StreamDesc), C.c_uint32, vp,
+                                         C.c_uint64, vp, C.POINTER(EncodeStats)]
+    L.flacgpu_encode_streams.restype = C.c_int
+    L.flacgpu_encode_bound.argtypes = [C.POINTER(Settings), C.POINTER(StreamDesc), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.flacgpu_encode_bound.restype = C.c_uint64
+    L.flacgpu_set_debug.argtypes = [vp, C.c_int]
+    L.flacgpu_set_debug.restype = None
+    L.flacgpu_copy_debug.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.flacgpu_copy_debug.restype = C.c_int
+    L.flacgpu_copy_block_results.argtypes = [vp, vp, C.c_uint32]
+    L.flacgpu_copy_block_results.restype = C.c_int
+    L.flacgpu_decode_frames.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp,
+                                        C.POINTER(DecodeStats)]
+    L.flacgpu_decode_frames.restype = C.c_int
+    L.flacgpu_index_frames.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(StreamInfo), C.POINTER(C.c_uint64)]
+    L.flacgpu_index_frames.restype = C.c_int64
+    _lib = L
+    return L
+
+
+def string_table(name, n):
+    return (C.c_char_p * n).in_dll(lib(), name)
+
+
+def last_error():
+    return (lib().flacgpu_last_error() or b'').decode()

@@ -1,0 +1,129 @@
+"""Batch (many blocks / many streams per launch) front end of libflacgpu, with PCM and output in HBM.
+
+This is the extension SURVEY.md section 8b asks for beyond the libFLAC ABI: pyFLAC's callback API hands one
+stream at a time to ``FLAC__stream_encoder_process_interleaved`` (``pyflac/encoder.py:115``); the batch entry
+points encode / decode any number of independent streams in one launch.  torch is used only to own device
+memory; the library itself takes raw device addresses.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class FlacGpuError(RuntimeError):
+    pass
+
+
+def settings(level=5, channels=2, bits_per_sample=16, sample_rate=48000, blocksize=0, streamable_subset=True):
+    s = _lib.Settings()
+    rc = _lib.lib().flacgpu_settings_from_level(C.byref(s), level, channels, bits_per_sample, sample_rate, blocksize,
+                                                1 if streamable_subset else 0)
+    if rc != 0:
+        raise FlacGpuError(_lib.string_table('FLAC__StreamEncoderInitStatusString', 14)[rc].decode())
+    return s
+
+
+class Context:
+    """One device context (stream, scratch buffers, tables).  One per process per GPU."""
+
+    def __init__(self, device=0):
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise FlacGpuError('no GPU visible: pyflac_amd has no CPU fallback')
+        self.device = device
+        self._h = L.flacgpu_ctx_create(device)
+        if not self._h:
+            raise FlacGpuError(_lib.last_error())
+
+    def close(self):
+        if self._h:
+            _lib.lib().flacgpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- encode
+    def encode(self, s, pcm, stream_lengths=None, out=None, offsets=None, debug=False):
+        """Encode device tensor ``pcm`` ([total_samples, channels] int32 or int16).
+
+        ``stream_lengths``: samples per stream (streams are laid back to back in ``pcm``); default one stream.
+        Returns ``(out_bytes_tensor[:total], frame_offsets_tensor[nblocks+1], EncodeStats)``.
+        """
+        L = _lib.lib()
+        assert pcm.is_cuda and pcm.is_contiguous()
+        is16 = pcm.dtype == torch.int16
+        assert is16 or pcm.dtype == torch.int32
+        total = pcm.shape[0]
+        if stream_lengths is None:
+            stream_lengths = [total]
+        descs = (_lib.StreamDesc * len(stream_lengths))()
+        pos = 0
+        for i, n in enumerate(stream_lengths):
+            descs[i].pcm_offset = pos
+            descs[i].nsamples = int(n)
+            descs[i].first_frame = 0
+            pos += int(n)
+        assert pos == total
+        nb = C.c_uint32(0)
+        bound = L.flacgpu_encode_bound(C.byref(s), descs, len(stream_lengths), C.byref(nb))
+        if out is None or out.numel() < bound:
+            out = torch.empty(max(int(bound), 1), dtype=torch.uint8, device=pcm.device)
+        if offsets is None or offsets.numel() < nb.value + 1:
+            offsets = torch.empty(nb.value + 1, dtype=torch.int64, device=pcm.device)
+        L.flacgpu_set_debug(self._h, 1 if debug else 0)
+        st = _lib.EncodeStats()
+        rc = L.flacgpu_encode_streams(self._h, C.byref(s), pcm.data_ptr(), 1 if is16 else 0, descs, len(stream_lengths),
+                                      out.data_ptr(), out.numel(), offsets.data_ptr(), C.byref(st))
+        if rc != 0:
+            raise FlacGpuError(_lib.last_error())
+        if st.error_flags:
+            raise FlacGpuError('encode error flags 0x%x' % st.error_flags)
+        return out, offsets[:st.nblocks + 1], st
+
+    def debug_records(self, first, n):
+        from .debug import DebugRec
+        buf = (DebugRec * n)()
+        if _lib.lib().flacgpu_copy_debug(self._h, buf, first, n) != 0:
+            raise FlacGpuError('no debug records')
+        return buf
+
+    # -- decode
+    def decode(self, stream, frame_offsets, channels, bits_per_sample, max_samples, out=None):
+        """Decode frames of a device-resident byte tensor.  ``frame_offsets``: host int64 array (nframes+1).
+
+        Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
+        """
+        L = _lib.lib()
+        assert stream.is_cuda and stream.dtype == torch.uint8
+        offs = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.uint64))
+        nframes = offs.size - 1
+        if out is None or out.numel() < max_samples * channels:
+            out = torch.empty((max(int(max_samples), 1), channels), dtype=torch.int32, device=stream.device)
+        status = np.zeros((max(nframes, 1), 2), np.uint32)
+        st = _lib.DecodeStats()
+        rc = L.flacgpu_decode_frames(self._h, stream.data_ptr(), stream.numel(), offs.ctypes.data, nframes, channels,
+                                     bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, C.byref(st))
+        if rc != 0:
+            raise FlacGpuError(_lib.last_error())
+        return out[:st.total_samples], status[:nframes], st
+
+
+def index_frames(data):
+    """Host frame index of a complete FLAC stream (bytes).  Returns (offsets uint64[nframes+1], StreamInfo)."""
+    L = _lib.lib()
+    buf = np.frombuffer(data, np.uint8)
+    cap = max(len(data) // 16 + 16, 64)
+    offs = np.zeros(cap, np.uint64)
+    si = _lib.StreamInfo()
+    audio = C.c_uint64(0)
+    n = L.flacgpu_index_frames(buf.ctypes.data, buf.size, offs.ctypes.data, cap, C.byref(si), C.byref(audio))
+    if n < 0:
+        raise FlacGpuError('not a FLAC stream')
+    return offs[:n + 1].copy(), si

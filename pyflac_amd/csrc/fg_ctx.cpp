@@ -1,0 +1,406 @@
+// fg_ctx.cpp -- device context, settings resolution, window tables, MD5/CRC and the batch encode entry
+// points of libflacgpu (Part 2 of include/flacgpu.h).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "fg_host.h"
+
+static thread_local std::string g_err;
+void fg_set_error(const std::string &msg) { g_err = msg; }
+extern "C" const char *flacgpu_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            fg_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return false;                                                                    \
+        }                                                                                    \
+    } while (0)
+
+bool DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap) return true;
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + 4095) & ~(size_t)4095;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) { fg_set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return false; }
+    if (p) (void)hipFree(p);
+    p = np; cap = want;
+    return true;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+}
+
+bool flacgpu_ctx::ensure_pinned(size_t bytes)
+{
+    if (bytes <= h_pin_cap) return true;
+    size_t want = std::max(bytes, h_pin_cap * 2);
+    void *np = nullptr;
+    if (hipHostMalloc(&np, want, hipHostMallocDefault) != hipSuccess) { fg_set_error("hipHostMalloc failed"); return false; }
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = np; h_pin_cap = want;
+    return true;
+}
+
+// ------------------------------------------------------------------ window tables
+// Generated on the host with the C library's cosf, exactly as libFLAC does; tests/golden/window_hashes.json
+// pins the tables so that a libm difference on another host is detected rather than silently encoded.
+void fg_tukey_window(float *w, int32_t L, float p)
+{
+    for (int32_t n = 0; n < L; n++) w[n] = 1.0f;
+    if (p <= 0.0f || p >= 1.0f) return;
+    const int32_t Np = (int32_t)(p / 2.0f * L) - 1;
+    if (Np > 0) {
+        for (int32_t n = 0; n <= Np; n++) {
+            w[n] = (float)(0.5f - 0.5f * cosf((float)(M_PI * n / Np)));
+            w[L - Np - 1 + n] = (float)(0.5f - 0.5f * cosf((float)(M_PI * (n + Np) / Np)));
+        }
+    }
+}
+
+uint32_t flacgpu_ctx::window_offset(uint32_t n, uint32_t parts)
+{
+    for (const WindowEntry &e : win_index)
+        if (e.n == n && e.parts == parts) return e.off;
+    WindowEntry e;
+    e.n = n; e.parts = parts; e.off = (uint32_t)h_windows.size();
+    h_windows.resize(h_windows.size() + ((n + 3) & ~3u));
+    const float p = parts >= 2 ? 0.5f / (float)(int32_t)parts : 0.5f;
+    fg_tukey_window(h_windows.data() + e.off, (int32_t)n, p);
+    win_index.push_back(e);
+    windows_dirty = true;
+    return e.off;
+}
+
+bool flacgpu_ctx::sync_windows()
+{
+    if (!windows_dirty) return true;
+    HIPCHK(hipStreamSynchronize(stream));
+    if (!windows.ensure(h_windows.size() * sizeof(float))) return false;
+    HIPCHK(hipMemcpyAsync(windows.p, h_windows.data(), h_windows.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    windows_dirty = false;
+    return true;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int flacgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static bool ctx_init(flacgpu_ctx *c, int device)
+{
+    c->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+    if (!c->crctab.ensure(1024 * sizeof(uint16_t))) return false;
+    if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return true;
+}
+
+extern "C" flacgpu_ctx *flacgpu_ctx_create(int device)
+{
+    if (flacgpu_device_count() <= 0) { fg_set_error("no HIP device available: libflacgpu has no CPU fallback"); return nullptr; }
+    flacgpu_ctx *c = new flacgpu_ctx();
+    if (!ctx_init(c, device)) { delete c; return nullptr; }
+    return c;
+}
+
+extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->descs, &c->slots, &c->results, &c->dbg, &c->crctab, &c->windows, &c->offsets, &c->scratch_pcm,
+                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch};
+    for (DevBuf *b : bufs) b->release();
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static std::mutex g_default_mu;
+static flacgpu_ctx *g_default = nullptr;
+flacgpu_ctx *fg_default_ctx()
+{
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        int dev = 0;
+        const char *env = getenv("FLACGPU_DEVICE");
+        if (env) dev = atoi(env);
+        g_default = flacgpu_ctx_create(dev);
+    }
+    return g_default;
+}
+
+// ------------------------------------------------------------------ settings (stream_encoder.h:845-853)
+extern "C" int flacgpu_settings_from_level(flacgpu_settings *s, uint32_t level, uint32_t channels, uint32_t bps,
+                                           uint32_t sample_rate, uint32_t blocksize, int subset)
+{
+    static const struct { uint32_t ms, loose, parts, order, minpo, maxpo; } L[9] = {
+        {0, 0, 0, 0, 0, 3}, {1, 1, 0, 0, 0, 3}, {1, 0, 0, 0, 0, 3}, {0, 0, 0, 6, 0, 4}, {1, 1, 0, 8, 0, 4},
+        {1, 0, 0, 8, 0, 5}, {1, 0, 2, 8, 0, 6}, {1, 0, 2, 12, 0, 6}, {1, 0, 3, 12, 0, 6}};
+    if (level > 8) level = 8;
+    memset(s, 0, sizeof *s);
+    s->channels = channels; s->bits_per_sample = bps; s->sample_rate = sample_rate; s->blocksize = blocksize;
+    s->do_mid_side = L[level].ms; s->loose_mid_side = L[level].loose; s->apod_parts = L[level].parts;
+    s->max_lpc_order = L[level].order; s->min_partition_order = L[level].minpo; s->max_partition_order = L[level].maxpo;
+    s->streamable_subset = subset ? 1 : 0;
+    s->qlp_coeff_precision = 0;
+    return fg_resolve_settings(s);
+}
+
+// The checks and defaults init_stream applies, in libFLAC's order; returns a
+// FLAC__StreamEncoderInitStatus value.
+int fg_resolve_settings(flacgpu_settings *s)
+{
+    if (s->channels == 0 || s->channels > 8) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS;
+    if (s->channels != 2) { s->do_mid_side = 0; s->loose_mid_side = 0; }
+    else if (!s->do_mid_side) s->loose_mid_side = 0;
+    const uint32_t bps = s->bits_per_sample;
+    if (bps < 4 || bps > 32) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE;
+    if (s->sample_rate > 1048575u) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE;
+    if (s->blocksize == 0) s->blocksize = s->max_lpc_order == 0 ? 1152 : 4096;
+    if (s->blocksize < 16 || s->blocksize > 65535) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE;
+    if (s->max_lpc_order > 32) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER;
+    if (s->blocksize < s->max_lpc_order) return FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER;
+    if (s->qlp_coeff_precision == 0) {
+        const uint32_t bs = s->blocksize;
+        uint32_t q;
+        if (bps < 16) { q = 2 + bps / 2; if (q < 5) q = 5; }
+        else if (bps == 16) q = bs <= 192 ? 7 : bs <= 384 ? 8 : bs <= 576 ? 9 : bs <= 1152 ? 10 : bs <= 2304 ? 11 : bs <= 4608 ? 12 : 13;
+        else q = bs <= 384 ? 13 : bs <= 1152 ? 14 : 15;
+        s->qlp_coeff_precision = q;
+    }
+    else if (s->qlp_coeff_precision < 5 || s->qlp_coeff_precision > 15)
+        return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION;
+    if (s->streamable_subset) {
+        const uint32_t bs = s->blocksize, sr = s->sample_rate;
+        if (bs > 16384 || (sr <= 48000 && bs > 4608)) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+        if (sr >= 65536 && !(sr % 1000 == 0 || sr % 10 == 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+        if (bps != 8 && bps != 12 && bps != 16 && bps != 20 && bps != 24 && bps != 32) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+        if (s->max_partition_order > 8) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+        if (sr <= 48000 && (bs > 4608 || s->max_lpc_order > 12)) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+    }
+    if (s->max_partition_order >= 16) s->max_partition_order = 15;
+    if (s->min_partition_order >= s->max_partition_order) s->min_partition_order = s->max_partition_order;
+    return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
+}
+
+// ------------------------------------------------------------------ launch parameters
+uint32_t fg_slot_bytes(const flacgpu_settings &s, uint32_t max_n)
+{
+    // a frame never exceeds its verbatim size by more than n/2 bits per subframe (+ parameters)
+    uint64_t per = ((uint64_t)max_n * (s.bits_per_sample + 2)) / 8 + 512;
+    uint64_t slot = 64 + (uint64_t)s.channels * per;
+    return (uint32_t)((slot + 255) & ~(uint64_t)255);
+}
+
+void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, bool debug, FgEncParams *P)
+{
+    memset(P, 0, sizeof *P);
+    P->channels = s.channels; P->bps = s.bits_per_sample; P->sample_rate = s.sample_rate; P->blocksize = s.blocksize;
+    P->do_mid_side = (s.channels == 2 && s.do_mid_side) ? 1 : 0;
+    P->max_lpc_order = s.max_lpc_order; P->qlp_precision = s.qlp_coeff_precision;
+    P->min_po = s.min_partition_order; P->max_po = s.max_partition_order;
+    P->apod_parts = s.apod_parts;
+    P->rice_limit = s.bits_per_sample > 16 ? 31 : 15;
+    P->slot_bytes = fg_slot_bytes(s, max_n);
+    P->sig_stride = (max_n + 3) & ~3u;
+    uint32_t nvec = 1;
+    if (s.apod_parts >= 2) for (uint32_t b = 2; b <= s.apod_parts; b++) nvec += (b == 2) ? 2 : 2 * b;
+    P->nvec = nvec;
+    P->pcm_i16 = pcm_i16 ? 1 : 0;
+    P->debug = debug ? 1 : 0;
+    const uint32_t mo = s.max_lpc_order ? s.max_lpc_order : 1;
+    uint32_t dbuf = 4 * (FG_DH + FG_DK) * 8;
+    const uint32_t lev = FG_MAX_CAND * nvec * mo * 12 + 64;
+    if (lev > dbuf) dbuf = lev;
+    P->lds_dbuf_bytes = (dbuf + 15) & ~15u;
+}
+
+// ------------------------------------------------------------------ batch encode
+extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgpu_stream_desc *streams, uint32_t nstreams,
+                                         uint32_t *nblocks)
+{
+    uint64_t nb = 0;
+    for (uint32_t i = 0; i < nstreams; i++) nb += (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+    if (nblocks) *nblocks = (uint32_t)nb;
+    return nb * fg_slot_bytes(*s, s->blocksize);
+}
+
+extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
+
+extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
+{
+    if (!c->dbg.p || first + n > c->last_nblocks) return -1;
+    (void)hipSetDevice(c->device);
+    return hipMemcpy(dst, (char *)c->dbg.p + (size_t)first * sizeof(FgDebugRec), (size_t)n * sizeof(FgDebugRec), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+
+extern "C" int flacgpu_copy_block_results(flacgpu_ctx *c, void *dst, uint32_t n)
+{
+    if (!c->results.p || n > c->last_nblocks) return -1;
+    (void)hipSetDevice(c->device);
+    return hipMemcpy(dst, c->results.p, (size_t)n * sizeof(FgBlockResult), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+
+static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const void *d_pcm, int pcm_is_i16,
+                                const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_cap,
+                                void *d_offsets, flacgpu_encode_stats *st)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (s->blocksize < 16 || s->blocksize > 65535) { fg_set_error("invalid blocksize"); return false; }
+    if (s->max_partition_order > 8) { fg_set_error("max_residual_partition_order > 8 is not supported by the GPU path"); return false; }
+    if (s->apod_parts > 3) { fg_set_error("subdivide_tukey parts > 3 is not supported by the GPU path"); return false; }
+    if (s->channels < 1 || s->channels > 8 || s->bits_per_sample < 4 || s->bits_per_sample > 32 || s->qlp_coeff_precision < 5 ||
+        s->qlp_coeff_precision > 15 || s->max_lpc_order > 32) {
+        fg_set_error("invalid encoder settings"); return false;
+    }
+    // block list
+    std::vector<FgBlockDesc> descs;
+    uint64_t nb = 0;
+    for (uint32_t i = 0; i < nstreams; i++) nb += (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+    descs.reserve(nb);
+    for (uint32_t i = 0; i < nstreams; i++) {
+        uint64_t pos = 0;
+        uint32_t fn = streams[i].first_frame;
+        while (pos < streams[i].nsamples) {
+            FgBlockDesc d;
+            const uint64_t left = streams[i].nsamples - pos;
+            d.pcm_off = streams[i].pcm_offset + pos;
+            d.n = (uint32_t)std::min<uint64_t>(left, s->blocksize);
+            d.frame_number = fn++;
+            d.win_off = s->max_lpc_order ? c->window_offset(d.n, s->apod_parts) : 0;
+            d.forced_ca = 0xFF;
+            descs.push_back(d);
+            pos += d.n;
+        }
+    }
+    const uint32_t nblocks = (uint32_t)descs.size();
+    memset(st, 0, sizeof *st);
+    st->nblocks = nblocks;
+    if (nblocks == 0) return true;
+    if (s->max_lpc_order == 0 && c->h_windows.empty()) c->window_offset(16, 0);
+    if (!c->sync_windows()) return false;
+    FgEncParams P;
+    fg_fill_params(*s, s->blocksize, pcm_is_i16 != 0, c->debug, &P);
+    if (fg_enc_lds_bytes(&P) > 160 * 1024) { fg_set_error("block too large for the LDS-staged encoder (blocksize * channels)"); return false; }
+    if (!c->descs.ensure((size_t)nblocks * sizeof(FgBlockDesc))) return false;
+    if (!c->slots.ensure((size_t)nblocks * P.slot_bytes)) return false;
+    if (!c->results.ensure((size_t)nblocks * sizeof(FgBlockResult))) return false;
+    if (!c->offsets.ensure(((size_t)nblocks + 2) * 8)) return false;
+    FgDebugRec *dbg = nullptr;
+    if (c->debug) {
+        if (!c->dbg.ensure((size_t)nblocks * sizeof(FgDebugRec))) return false;
+        HIPCHK(hipMemsetAsync(c->dbg.p, 0, (size_t)nblocks * sizeof(FgDebugRec), c->stream));
+        dbg = (FgDebugRec *)c->dbg.p;
+    }
+    HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+    // loose mid-side (levels 1, 4): the decision frames are independent of each other, the frames in between
+    // copy the decision.  First pass encodes the decision frames only.
+    if (P.do_mid_side && s->loose_mid_side) {
+        uint32_t period = (uint32_t)((double)s->sample_rate * 0.4 / (double)s->blocksize + 0.5);
+        if (period == 0) period = 1;
+        if (period > 1) {
+            std::vector<FgBlockDesc> dec;
+            std::vector<uint32_t> decidx;
+            size_t bi = 0;
+            for (uint32_t i = 0; i < nstreams; i++) {
+                const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+                for (uint64_t k = 0; k < cnt; k += period) { dec.push_back(descs[bi + k]); decidx.push_back((uint32_t)(bi + k)); }
+                bi += cnt;
+            }
+            // loose mode compares only independent vs mid/side on decision frames
+            HIPCHK(hipMemcpyAsync(c->descs.p, dec.data(), dec.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+            if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, (uint32_t)dec.size(),
+                                 (uint8_t *)c->slots.p, (FgBlockResult *)c->results.p, nullptr, (const uint16_t *)c->crctab.p, c->stream) != 0) {
+                fg_set_error("encode kernel launch failed"); return false;
+            }
+            std::vector<FgBlockResult> r(dec.size());
+            HIPCHK(hipMemcpyAsync(r.data(), c->results.p, dec.size() * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            bi = 0;
+            size_t di = 0;
+            for (uint32_t i = 0; i < nstreams; i++) {
+                const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+                for (uint64_t k = 0; k < cnt; k++) {
+                    if (k % period == 0) di = std::find(decidx.begin(), decidx.end(), (uint32_t)(bi + k)) - decidx.begin();
+                    const FgBlockResult &rr = r[di];
+                    const uint32_t ms = (rr.best_bits[2] + rr.best_bits[3]) < (rr.best_bits[0] + rr.best_bits[1]) ? 3u : 0u;
+                    descs[bi + k].forced_ca = ms;
+                }
+                bi += cnt;
+            }
+            HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+        }
+        else {
+            // period 1: every frame decides, but only between independent and mid/side: handled by forcing
+            // after a probe is unnecessary -- emulate by a probe pass as well for simplicity
+            std::vector<FgBlockResult> r(nblocks);
+            if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nblocks, (uint8_t *)c->slots.p,
+                                 (FgBlockResult *)c->results.p, nullptr, (const uint16_t *)c->crctab.p, c->stream) != 0) {
+                fg_set_error("encode kernel launch failed"); return false;
+            }
+            HIPCHK(hipMemcpyAsync(r.data(), c->results.p, (size_t)nblocks * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (uint32_t b = 0; b < nblocks; b++)
+                descs[b].forced_ca = (r[b].best_bits[2] + r[b].best_bits[3]) < (r[b].best_bits[0] + r[b].best_bits[1]) ? 3u : 0u;
+            HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nblocks, (uint8_t *)c->slots.p,
+                         (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {
+        fg_set_error("encode kernel launch failed"); return false;
+    }
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    // sizes -> offsets -> contiguous output
+    if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
+        fg_set_error("scan kernel launch failed"); return false;
+    }
+    unsigned long long tail[2] = {0, 0};   // total bytes, OR of error flags
+    HIPCHK(hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    st->total_bytes = tail[0];
+    st->error_flags = (uint32_t)tail[1];
+    c->last_nblocks = nblocks;
+    if (d_out) {
+        if (tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
+        if (fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
+                           (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream) != 0) {
+            fg_set_error("copy kernel launch failed"); return false;
+        }
+    }
+    if (d_offsets) HIPCHK(hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
+    return true;
+}
+
+extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s, const void *d_pcm, int pcm_is_i16,
+                                      const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_cap,
+                                      void *d_offsets, flacgpu_encode_stats *st)
+{
+    flacgpu_encode_stats local;
+    if (!st) st = &local;
+    if (!c) { fg_set_error("null context"); return -1; }
+    return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
+}

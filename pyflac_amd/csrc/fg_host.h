@@ -1,0 +1,87 @@
+// Host-side internals of libflacgpu (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fg_types.h"
+#include "flacgpu.h"
+
+// ---- kernel launchers (flac_enc_kernels.hip / flac_dec_kernels.hip)
+extern "C" {
+size_t fg_enc_lds_bytes(const FgEncParams *P);
+int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream);
+int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
+                     uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
+                     const uint16_t *d_crctab, hipStream_t stream);
+int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
+int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
+                   const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream);
+int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
+                          uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
+                          unsigned long long *d_totals, hipStream_t stream);
+int fg_launch_decode(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_pcm,
+                     FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
+                     hipStream_t stream);
+}
+
+void fg_set_error(const std::string &msg);
+
+// Grow-only device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes);
+    void release();
+};
+
+struct WindowEntry {
+    uint32_t n, parts;
+    uint32_t off;   // floats
+};
+
+struct flacgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu;
+    DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
+        dec_scratch;
+    std::vector<float> h_windows;
+    std::vector<WindowEntry> win_index;
+    bool windows_dirty = false;
+    bool debug = false;
+    uint32_t last_nblocks = 0;
+    // pinned staging for the stream (callback) API
+    void *h_pin = nullptr;
+    size_t h_pin_cap = 0;
+    bool ensure_pinned(size_t bytes);
+    uint32_t window_offset(uint32_t n, uint32_t parts);   // returns float offset, computing the table if new
+    bool sync_windows();
+};
+
+flacgpu_ctx *fg_default_ctx();   // lazily created context on the current/default device
+
+int fg_resolve_settings(flacgpu_settings *s);
+// settings helpers shared by the libFLAC-style encoder and the batch API
+void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, bool debug, FgEncParams *P);
+uint32_t fg_slot_bytes(const flacgpu_settings &s, uint32_t max_n);
+void fg_tukey_window(float *w, int32_t L, float p);
+
+// MD5 (RFC 1321) used for STREAMINFO
+struct FgMd5 {
+    uint32_t a, b, c, d;
+    uint64_t len;
+    uint8_t buf[64];
+    uint32_t fill;
+    void init();
+    void update(const uint8_t *p, size_t n);
+    void final(uint8_t out[16]);
+    void update_pcm(const int32_t *interleaved, uint64_t nvalues, uint32_t bps);
+};
+
+uint8_t fg_crc8(const uint8_t *p, size_t n);
+uint16_t fg_crc16(const uint8_t *p, size_t n);

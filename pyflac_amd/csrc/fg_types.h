@@ -1,0 +1,79 @@
+// Structures shared by the HIP kernels and the host side of libflacgpu.
+#pragma once
+#include <stdint.h>
+
+#define FG_MAX_ORDER 32
+#define FG_MAX_VEC 16    // autocorrelation vectors per candidate; subdivide_tukey(3) needs 9
+#define FG_MAX_CAND 4    // L, R, M, S
+#define FG_MAX_PARTS 256 // 2^8: FLAC__SUBSET_MAX_RICE_PARTITION_ORDER (format.h:151)
+#define FG_WINW 128      // bit-packer LDS window, 32-bit words
+#define FG_DH 32         // autocorrelation history entries kept in front of each chunk
+#define FG_DK 224        // autocorrelation chunk length (doubles per candidate)
+
+// Error bits reported per block.
+#define FG_ERR_RANGE 1u        // input sample outside the bits-per-sample range
+#define FG_ERR_SLOT 2u         // frame did not fit its output slot
+#define FG_ERR_SIDE33 4u       // 33-bit side channel (32-bit stereo input) not representable
+#define FG_ERR_INTERNAL 8u
+
+struct FgEncParams {
+    uint32_t channels, bps, sample_rate, blocksize;
+    uint32_t do_mid_side;
+    uint32_t max_lpc_order, qlp_precision, min_po, max_po;
+    uint32_t apod_parts;   // 0/1: one tukey window; >= 2: subdivide_tukey(parts)
+    uint32_t rice_limit;   // 15 (bps <= 16) or 31
+    uint32_t slot_bytes;   // output slot stride, multiple of 4
+    uint32_t sig_stride;   // int32 elements per staged channel in LDS
+    uint32_t nvec;         // autocorrelation vectors per candidate
+    uint32_t pcm_i16;      // input is interleaved int16 instead of int32
+    uint32_t debug;
+    uint32_t lds_dbuf_bytes;
+};
+
+struct FgBlockDesc {
+    uint64_t pcm_off;      // first inter-channel sample of the block in the PCM buffer
+    uint32_t n;            // samples per channel in this block
+    uint32_t frame_number;
+    uint32_t win_off;      // offset (floats) of this block length's window table
+    uint32_t forced_ca;    // 0xFF = choose; else 0 or 3 (loose mid-side follower frames)
+};
+
+struct FgBlockResult {
+    uint32_t bytes;
+    uint32_t ca;
+    uint32_t err;
+    uint32_t best_bits[4];
+    uint32_t reserved;
+};
+
+struct FgDebugCand {
+    uint32_t wasted, sbps;
+    uint64_t fixed_tot[5];
+    uint32_t fixed_guess, fixed_bits, nvec, pad0;
+    uint32_t lpc_guess[FG_MAX_VEC], lpc_bits[FG_MAX_VEC];
+    double autoc[FG_MAX_VEC][FG_MAX_ORDER + 1];
+    uint32_t type, order, precision;
+    int32_t shift;
+    int32_t qlp[FG_MAX_ORDER];
+    uint32_t rice_method, porder, bits, pad1;
+    uint32_t rice_params[FG_MAX_PARTS];
+};
+
+struct FgDebugRec {
+    FgDebugCand cand[FG_MAX_CAND];
+};
+
+// ---- decoder ----
+struct FgDecFrame {
+    uint64_t byte_off;     // frame start in the stream buffer
+    uint64_t out_off;      // first inter-channel sample of this frame in the output
+    uint32_t bytes;        // frame length including CRC-16
+    uint32_t n;            // block size
+    uint32_t hdr_bytes;    // header length including CRC-8
+    uint32_t channels, ca, bps;
+};
+
+struct FgDecResult {
+    uint32_t err;          // 0 ok, 1 malformed, 2 crc16 mismatch
+    uint32_t crc;
+};

@@ -1,0 +1,429 @@
+// flac_dec_kernels.hip -- MI355X (gfx950) FLAC frame decoder.
+//
+// Replaces the decode hot loop of libFLAC (read_subframe_*, read_residual_partitioned_rice_,
+// FLAC__fixed_restore_signal, FLAC__lpc_restore_signal, undo_channel_coding) that pyFLAC reaches
+// through FLAC__stream_decoder_process_until_end_of_stream / process_single
+// (reference: pyflac/decoder.py:196,294,388; algorithm: SURVEY.md Appendix B, rows D2-D5 of 8a).
+//
+// Rice decoding is serial in the bit position and the LPC recurrence has an arithmetic shift inside the
+// feedback (hard part 2), so the honest parallelism is one lane per frame:
+//   phase 1  lane = frame: bit reader over the frame's bytes, Rice decode + predictor restore of every
+//            subframe into a frame-planar scratch area (history ring in LDS, [tap][lane] layout);
+//   phase 2  the wave walks its 64 frames together: CRC-16 over the frame bytes (64 lanes over interleaved
+//            words), then wasted-bit/stereo undo and the coalesced store of the output samples.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fg_types.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+namespace {
+
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v ^= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        r = (r & 0x8000) ? (((r << 1) ^ 0x8005) & 0xFFFF) : ((r << 1) & 0xFFFF);
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+
+// Per-lane MSB-first bit reader over 32-bit big-endian words of the stream buffer.
+struct BitReader {
+    const uint8_t *base;    // frame start
+    uint32_t pos;           // bit position from base
+    uint32_t end;           // frame length in bits
+    uint32_t w_idx;         // cached word index
+    uint32_t w0, w1;        // cached big-endian words w_idx, w_idx+1
+    bool over;
+
+    __device__ __forceinline__ uint32_t load_be(uint32_t wi) const
+    {
+        // bytes beyond the frame are never needed for valid streams; clamp reads to the frame
+        const uint32_t b = wi * 4;
+        const uint32_t nbytes = (end + 7) >> 3;
+        uint32_t v = 0;
+        if (b + 4 <= nbytes) {
+            v = ((uint32_t)base[b] << 24) | ((uint32_t)base[b + 1] << 16) | ((uint32_t)base[b + 2] << 8) | base[b + 3];
+        }
+        else {
+            for (uint32_t k = 0; k < 4; k++) v = (v << 8) | ((b + k < nbytes) ? base[b + k] : 0);
+        }
+        return v;
+    }
+    __device__ __forceinline__ void init(const uint8_t *p, uint32_t start_bit, uint32_t end_bit)
+    {
+        base = p; pos = start_bit; end = end_bit; over = false;
+        w_idx = pos >> 5;
+        w0 = load_be(w_idx); w1 = load_be(w_idx + 1);
+    }
+    __device__ __forceinline__ uint32_t peek32()
+    {
+        const uint32_t wi = pos >> 5;
+        if (wi != w_idx) {
+            if (wi == w_idx + 1) { w0 = w1; w1 = load_be(wi + 1); }
+            else { w0 = load_be(wi); w1 = load_be(wi + 1); }
+            w_idx = wi;
+        }
+        const u64 v = ((u64)w0 << 32) | w1;
+        return (uint32_t)((v << (pos & 31)) >> 32);
+    }
+    __device__ __forceinline__ void skip(uint32_t n)
+    {
+        pos += n;
+        if (pos > end) over = true;
+    }
+    __device__ __forceinline__ uint32_t bits(uint32_t n)   // n <= 32
+    {
+        if (n == 0) return 0;
+        const uint32_t v = peek32() >> (32 - n);
+        skip(n);
+        return v;
+    }
+    __device__ __forceinline__ int32_t sbits(uint32_t n)   // n <= 32
+    {
+        if (n == 0) return 0;
+        const int32_t v = (int32_t)peek32() >> (32 - n);
+        skip(n);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t unary()
+    {
+        uint32_t z = 0;
+        for (;;) {
+            const uint32_t p = peek32();
+            if (p) { const uint32_t l = (uint32_t)__clz(p); z += l; skip(l + 1); return z; }
+            z += 32; skip(32);
+            if (over) return z;
+        }
+    }
+};
+
+__global__ void __launch_bounds__(64)
+fg_decode_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch, int32_t *out,
+                 FgDecResult *results, const uint16_t *crctab, uint32_t interleave)
+{
+    __shared__ int32_t ring[32 * 64];
+    __shared__ uint16_t crct[768];
+    __shared__ uint32_t mult[64];
+    __shared__ uint8_t wasted_s[64 * 8];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < 768; j += 64) crct[j] = crctab[j];
+    mult[lane] = crctab[768 + lane];
+    __syncthreads();
+
+    const uint32_t f = blockIdx.x * 64 + lane;
+    const bool valid = f < nframes;
+    FgDecFrame fr;
+    if (valid) fr = frames[f];
+    else { fr.byte_off = 0; fr.out_off = 0; fr.bytes = 0; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0; }
+    uint32_t err = 0;
+    const uint32_t n = fr.n, C = fr.channels;
+    int32_t *planar = scratch + fr.out_off * C;     // [C][n]
+
+    // ---------------------------------------------------------------- phase 1: lane = frame
+    if (valid && fr.bytes >= fr.hdr_bytes + 2) {
+        BitReader br;
+        br.init(stream + fr.byte_off, fr.hdr_bytes * 8, (fr.bytes - 2) * 8);
+        for (uint32_t ch = 0; ch < C && !err; ch++) {
+            uint32_t sb = fr.bps;
+            if ((fr.ca == 1 && ch == 1) || (fr.ca == 2 && ch == 0) || (fr.ca == 3 && ch == 1)) sb++;
+            const uint32_t hdr = br.bits(8);
+            uint32_t wasted = 0;
+            if (hdr & 0x80) { err = 1; break; }
+            if (hdr & 1) { wasted = br.unary() + 1; if (wasted >= sb) { err = 1; break; } sb -= wasted; }
+            wasted_s[lane * 8 + ch] = (uint8_t)wasted;
+            if (sb > 32) { err = 1; break; }          // 33-bit side channel: not supported
+            const uint32_t t = (hdr >> 1) & 0x3F;
+            int32_t *dst = planar + (size_t)ch * n;
+            if (t == 0) {
+                const int32_t v = br.sbits(sb);
+                for (uint32_t i = 0; i < n; i++) dst[i] = v;
+            }
+            else if (t == 1) {
+                for (uint32_t i = 0; i < n; i++) dst[i] = br.sbits(sb);
+            }
+            else if ((t >= 8 && t <= 12) || t >= 32) {
+                const bool lpc = t >= 32;
+                const uint32_t order = lpc ? (t & 31) + 1 : (t & 7);
+                if (order > n) { err = 1; break; }
+                int32_t q[32];
+                int32_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+                for (uint32_t i = 0; i < order; i++) {
+                    const int32_t v = br.sbits(sb);
+                    dst[i] = v;
+                    ring[(i & 31) * 64 + lane] = v;
+                    p4 = p3; p3 = p2; p2 = p1; p1 = v;
+                }
+                uint32_t prec = 0;
+                int shift = 0;
+                if (lpc) {
+                    prec = br.bits(4) + 1;
+                    if (prec == 16) { err = 1; break; }
+                    shift = br.sbits(5);
+                    if (shift < 0) { err = 1; break; }
+                    for (uint32_t j = 0; j < 32; j++) q[j] = (j < order) ? br.sbits(prec) : 0;
+                }
+                const uint32_t method = br.bits(2);
+                if (method > 1) { err = 1; break; }
+                const uint32_t po = br.bits(4);
+                const uint32_t plen = method ? 5 : 4, esc = method ? 31 : 15;
+                const uint32_t psz = n >> po;
+                if ((po > 0 && ((n & ((1u << po) - 1)) != 0 || psz < order)) || (po == 0 && n < order)) { err = 1; break; }
+                uint32_t left = 0, part = 0, k = 0, raw = 0;
+                bool is_esc = false;
+                // 64-bit accumulation is a safe universal choice
+                const bool narrow = lpc && (sb + prec + (32 - __clz(order)) <= 32);
+                for (uint32_t i = order; i < n; i++) {
+                    if (left == 0) {
+                        left = (part == 0) ? (psz - order) : psz;
+                        if (po == 0) left = n - order;
+                        part++;
+                        k = br.bits(plen);
+                        is_esc = (k == esc);
+                        if (is_esc) raw = br.bits(5);
+                        if (left == 0) { i--; continue; }
+                    }
+                    left--;
+                    int32_t r;
+                    if (is_esc) r = br.sbits(raw);
+                    else {
+                        const uint32_t p = br.peek32();
+                        uint32_t u;
+                        const uint32_t lz = p ? (uint32_t)__clz(p) : 32;
+                        if (lz + 1 + k <= 32) {
+                            const uint32_t rest = (lz + 1 < 32) ? (p << (lz + 1)) : 0;
+                            u = (lz << k) | (k ? (rest >> (32 - k)) : 0);
+                            br.skip(lz + 1 + k);
+                        }
+                        else {
+                            const uint32_t msb = br.unary();
+                            u = (msb << k) | br.bits(k);
+                        }
+                        r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+                    }
+                    int32_t v;
+                    if (!lpc) {
+                        switch (order) {
+                        case 0: v = r; break;
+                        case 1: v = r + p1; break;
+                        case 2: v = r + 2 * p1 - p2; break;
+                        case 3: v = r + 3 * p1 - 3 * p2 + p3; break;
+                        default: v = r + 4 * p1 - 6 * p2 + 4 * p3 - p4; break;
+                        }
+                        p4 = p3; p3 = p2; p2 = p1; p1 = v;
+                    }
+                    else if (narrow) {
+                        int32_t sum = 0;
+                        for (uint32_t j = 0; j < order; j++) sum += q[j] * ring[((i - 1 - j) & 31) * 64 + lane];
+                        v = r + (sum >> shift);
+                        ring[(i & 31) * 64 + lane] = v;
+                    }
+                    else {
+                        i64 sum = 0;
+                        for (uint32_t j = 0; j < order; j++) sum += (i64)q[j] * (i64)ring[((i - 1 - j) & 31) * 64 + lane];
+                        v = (int32_t)((i64)r + (sum >> shift));
+                        ring[(i & 31) * 64 + lane] = v;
+                    }
+                    dst[i] = v;
+                    if (br.over) { err = 1; break; }
+                }
+            }
+            else { err = 1; break; }
+            if (br.over) err = 1;
+        }
+        if (!err) {
+            // zero padding to the byte boundary must end exactly at the CRC-16
+            const uint32_t endbits = (br.pos + 7) & ~7u;
+            if (endbits != (fr.bytes - 2) * 8) err = 1;
+        }
+    }
+    else if (valid) err = 1;
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 2: the wave walks its frames together
+    const uint16_t *t0 = crct, *thi = crct + 256, *tlo = crct + 512;
+    for (int L = 0; L < 64; L++) {
+        const uint32_t fb = __shfl(fr.bytes, L), fn = __shfl(fr.n, L), fC = __shfl(fr.channels, L), fca = __shfl(fr.ca, L);
+        const uint32_t ferr = __shfl(err, L);
+        if (fb == 0) continue;
+        const u64 boff = ((u64)__shfl((uint32_t)(fr.byte_off >> 32), L) << 32) | __shfl((uint32_t)fr.byte_off, L);
+        const u64 ooff = ((u64)__shfl((uint32_t)(fr.out_off >> 32), L) << 32) | __shfl((uint32_t)fr.out_off, L);
+        const uint8_t *fp = stream + boff;
+        // CRC-16 of bytes [0, fb-2): lanes take interleaved 32-bit groups (front-padded), fold with x^(32k)
+        const uint32_t nbytes = fb - 2;
+        const uint32_t W = nbytes >> 2, tail = nbytes & 3;
+        const uint32_t pad = (64 - (W & 63)) & 63, T = (W + pad) >> 6;
+        uint32_t s = 0;
+        for (uint32_t t = 0; t < T; t++) {
+            const int qi = (int)(t * 64 + lane) - (int)pad;
+            uint32_t wv = 0;
+            if (qi >= 0) {
+                const uint8_t *p = fp + (size_t)qi * 4;
+                wv = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+            }
+            s = thi[s >> 8] ^ tlo[s & 0xFF];
+            uint32_t cw = 0;
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 24)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 16)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 8)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ wv) & 0xFF];
+            s ^= cw;
+        }
+        s = gf16_mul(s, mult[63 - lane]);
+        uint32_t crc = wave_xor(s);
+        for (uint32_t b = 0; b < tail; b++) crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ fp[W * 4 + b]) & 0xFF];
+        const uint32_t stored = ((uint32_t)fp[nbytes] << 8) | fp[nbytes + 1];
+        const bool crc_ok = (crc == stored);
+        uint32_t status = ferr ? 1u : (crc_ok ? 0u : 2u);
+        if (lane == 0) { results[blockIdx.x * 64 + L].err = status; results[blockIdx.x * 64 + L].crc = crc; }
+        // undo wasted bits and channel coding; bad frames are delivered as silence
+        const int32_t *pl = scratch + ooff * fC;
+        int32_t *o = out + ooff * fC;
+        uint32_t ws[8];
+        for (uint32_t c = 0; c < 8; c++) ws[c] = c < fC ? wasted_s[L * 8 + c] : 0;
+        for (uint32_t i = lane; i < fn; i += 64) {
+            int32_t v[8];
+            for (uint32_t c = 0; c < 8; c++) v[c] = (c < fC && status == 0) ? (int32_t)((uint32_t)pl[(size_t)c * fn + i] << ws[c]) : 0;
+            if (status == 0) {
+                if (fca == 1) v[1] = v[0] - v[1];
+                else if (fca == 2) v[0] = v[0] + v[1];
+                else if (fca == 3) {
+                    const i64 side = v[1];
+                    const i64 mid = (i64)(((u64)(i64)v[0]) << 1) | (side & 1);
+                    v[0] = (int32_t)((mid + side) >> 1);
+                    v[1] = (int32_t)((mid - side) >> 1);
+                }
+            }
+            for (uint32_t c = 0; c < 8; c++) {
+                if (c < fC) {
+                    if (interleave) o[(size_t)i * fC + c] = v[c];
+                    else o[(size_t)c * fn + i] = v[c];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- frame header parse (format.h:418-462)
+// lane = frame.  offsets[f] .. offsets[f+1] delimit the frame.  Fills FgDecFrame except out_off.
+__global__ void __launch_bounds__(256)
+fg_dec_headers_kernel(const uint8_t *stream, const u64 *offsets, uint32_t nframes, uint32_t si_channels, uint32_t si_bps,
+                      FgDecFrame *frames, FgDecResult *results)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    const uint8_t *p = stream + offsets[f];
+    const uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
+    FgDecFrame fr;
+    fr.byte_off = offsets[f]; fr.out_off = 0; fr.bytes = len; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0;
+    uint32_t bad = 0;
+    if (len < 7 || p[0] != 0xFF || (p[1] & 0xFE) != 0xF8) bad = 1;
+    uint32_t pos = 2, n = 0;
+    if (!bad) {
+        const uint32_t bsc = p[2] >> 4, src = p[2] & 15, cac = p[3] >> 4, bpc = (p[3] >> 1) & 7;
+        if (bsc == 0 || src == 15 || cac > 10 || bpc == 3 || (p[3] & 1)) bad = 1;
+        pos = 4;
+        // UTF-8 coded frame/sample number
+        uint32_t x = p[pos++], extra = 0;
+        if (!(x & 0x80)) extra = 0;
+        else if ((x & 0xE0) == 0xC0) extra = 1;
+        else if ((x & 0xF0) == 0xE0) extra = 2;
+        else if ((x & 0xF8) == 0xF0) extra = 3;
+        else if ((x & 0xFC) == 0xF8) extra = 4;
+        else if ((x & 0xFE) == 0xFC) extra = 5;
+        else if (x == 0xFE) extra = 6;
+        else bad = 1;
+        if (pos + extra + 4 > len) bad = 1;
+        if (!bad) {
+            for (uint32_t i = 0; i < extra; i++) if ((p[pos++] & 0xC0) != 0x80) bad = 1;
+            switch (bsc) {
+            case 1: n = 192; break;
+            case 2: case 3: case 4: case 5: n = 576u << (bsc - 2); break;
+            case 6: n = (uint32_t)p[pos] + 1; pos += 1; break;
+            case 7: n = (((uint32_t)p[pos] << 8) | p[pos + 1]) + 1; pos += 2; break;
+            default: n = 256u << (bsc - 8); break;
+            }
+            if (src == 12) pos += 1; else if (src == 13 || src == 14) pos += 2;
+            if (pos + 1 > len) bad = 1;
+        }
+        if (!bad) {
+            uint32_t c8 = 0;
+            for (uint32_t i = 0; i < pos; i++) {
+                c8 ^= p[i];
+                for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
+            }
+            if (c8 != p[pos]) bad = 1;
+            pos++;
+            const uint32_t BP[8] = {0, 8, 12, 0, 16, 20, 24, 32};
+            fr.bps = bpc ? BP[bpc] : si_bps;
+            if (cac < 8) { fr.channels = cac + 1; fr.ca = 0; } else { fr.channels = 2; fr.ca = cac - 7; }
+            if (si_channels && fr.channels != si_channels) bad = 1;
+            fr.n = n; fr.hdr_bytes = pos;
+        }
+    }
+    if (bad) { fr.n = 0; fr.channels = si_channels ? si_channels : 1; fr.bytes = 0; }
+    frames[f] = fr;
+    results[f].err = bad ? 1 : 0;
+    results[f].crc = 0;
+}
+
+// Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.
+__global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals)
+{
+    __shared__ u64 part[1024];
+    __shared__ uint32_t maxn;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t per = (nframes + nt - 1) / nt;
+    const uint32_t b0 = tid * per < nframes ? tid * per : nframes, b1 = (b0 + per) < nframes ? (b0 + per) : nframes;
+    if (tid == 0) maxn = 0;
+    __syncthreads();
+    u64 s = 0;
+    uint32_t m = 0;
+    for (uint32_t b = b0; b < b1; b++) { s += frames[b].n; m = frames[b].n > m ? frames[b].n : m; }
+    part[tid] = s;
+    atomicMax(&maxn, m);
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0;
+        for (uint32_t t = 0; t < nt; t++) { u64 v = part[t]; part[t] = run; run += v; }
+        totals[0] = run; totals[1] = maxn;
+    }
+    __syncthreads();
+    u64 run = part[tid];
+    for (uint32_t b = b0; b < b1; b++) { frames[b].out_off = run; run += frames[b].n; }
+}
+
+}  // namespace
+
+extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
+                                     uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
+                                     unsigned long long *d_totals, hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, d_offsets, nframes,
+                       si_channels, si_bps, d_frames, d_results);
+    hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fg_launch_decode(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_pcm,
+                                FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
+                                hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    const uint32_t nwg = (nframes + 63) / 64;
+    hipLaunchKernelGGL(fg_decode_kernel, dim3(nwg), dim3(64), 0, stream, d_stream, d_frames, nframes, d_scratch, d_pcm,
+                       d_results, d_crctab, interleave);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,1213 @@
+// flac_enc_kernels.hip -- MI355X (gfx950) FLAC frame encoder, one FLAC block per wavefront.
+//
+// Replaces the per-block hot loop of libFLAC's process_frame_/process_subframes_ that pyFLAC
+// reaches through FLAC__stream_encoder_process_interleaved (reference: pyflac/encoder.py:115;
+// algorithm: SURVEY.md Appendix A, rows L2-L13 of section 8a).  Output frames are bit-exact with
+// libFLAC 1.4.3 for the same settings.
+//
+// Mapping (wave64, block = one wavefront):
+//   * samples are staged once from HBM into LDS (planar int32, two channels at a time);
+//   * integer stages (wasted bits, fixed-predictor error sums, FIR residuals, Rice partition sums,
+//     bit packing) run lane = sample (i = 64*t + lane), LDS reads are conflict-free;
+//   * the order-sensitive double autocorrelation runs lane = (candidate, lag): one serial fp64
+//     FMA chain per lag, windowed samples pre-converted to double in LDS chunks;
+//   * Levinson-Durbin / order guess / quantiser run lane = (candidate, apodization vector);
+//   * the bit packer computes every code's length, wave-scans them into bit offsets, ORs the
+//     codes into a small LDS window and streams finished words to the frame's HBM slot;
+//   * CRC-16 is computed by 64 lanes over interleaved words and folded with x^(32k) multipliers.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile).  No fast-math: the
+// LPC analysis must round exactly like the x86-64 SSE2 double arithmetic of the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fg_types.h"
+
+#define FG_LN2 0.69314718055994530942
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+namespace {
+
+// ------------------------------------------------------------------ wave primitives
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_add(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ u64 wave_add64(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v ^= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ uint32_t ilog2_32(uint32_t v) { return 31u - (uint32_t)__clz(v); }
+__device__ __forceinline__ uint32_t ilog2_64(u64 v) { return 63u - (uint32_t)__clzll(v); }
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+__device__ __forceinline__ void lds_fence() { __syncthreads(); }
+
+// ------------------------------------------------------------------ CRC helpers (poly 0x8005 / 0x07)
+__device__ __forceinline__ uint32_t crc16_mulx(uint32_t a, int nbits)
+{
+    for (int i = 0; i < nbits; i++) a = (a & 0x8000) ? (((a << 1) ^ 0x8005) & 0xFFFF) : ((a << 1) & 0xFFFF);
+    return a;
+}
+__device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
+{
+    // a*b mod x^16+x^15+x^2+1
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        r = (r & 0x8000) ? (((r << 1) ^ 0x8005) & 0xFFFF) : ((r << 1) & 0xFFFF);
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------ per-wave encoder state
+struct Dec {            // decision for one candidate subframe (lives in LDS)
+    uint32_t type;      // 0 CONSTANT 1 VERBATIM 2 FIXED 3 LPC
+    uint32_t order, prec;
+    int32_t shift;
+    uint32_t porder, method, bits, wasted, sbps, pad;
+    int32_t q[FG_MAX_ORDER];
+    uint8_t k[FG_MAX_PARTS];
+};
+
+struct Enc {
+    // LDS regions
+    int32_t *s0, *s1;
+    double *dbuf;
+    double *autoc;
+    int32_t *qres;
+    uint32_t *lres;
+    u64 *sums;
+    uint8_t *tmpk;
+    uint32_t *win;
+    uint16_t *crct;
+    uint32_t *misc;
+    Dec *decs;
+    // uniform state
+    FgEncParams P;
+    const float *window;
+    int lane;
+    uint32_t n;
+    int mode;   // 0 independent channels, 1 L/R/M/S
+    int wide;   // 64-bit arithmetic for M/S derivation
+    int ncand;
+    uint32_t err;
+    // bit writer
+    uint32_t bitpos, wbase;
+    uint32_t *outw;
+    uint32_t slot_words;
+
+    __device__ __forceinline__ int32_t cval(int c, int32_t L, int32_t R, uint32_t w) const
+    {
+        if (mode == 0) return (c == 0 ? L : R) >> w;
+        if (c == 0) return L >> w;
+        if (c == 1) return R >> w;
+        if (!wide) return (c == 2 ? ((L + R) >> 1) : (L - R)) >> w;
+        i64 a = (c == 2) ? (((i64)L + (i64)R) >> 1) : ((i64)L - (i64)R);
+        return (int32_t)(a >> w);
+    }
+    __device__ __forceinline__ int32_t get(int c, uint32_t i, uint32_t w) const
+    {
+        int32_t L = 0, R = 0;
+        if (mode == 0) { if (c == 0) L = s0[i]; else R = s1[i]; }
+        else {
+            if (c != 1) L = s0[i];
+            if (c != 0) R = s1[i];
+        }
+        return cval(c, L, R, w);
+    }
+
+    // ---------------------------------------------------------------- staging
+    __device__ void stage(const void *pcm, u64 pcm_off, uint32_t ch0, uint32_t nch)
+    {
+        const uint32_t C = P.channels;
+        const i64 lo = -((i64)1 << (P.bps - 1)), hi = ((i64)1 << (P.bps - 1)) - 1;
+        uint32_t bad = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            for (uint32_t c = 0; c < nch; c++) {
+                int32_t v;
+                u64 idx = (pcm_off + i) * C + ch0 + c;
+                if (P.pcm_i16) v = ((const int16_t *)pcm)[idx];
+                else v = ((const int32_t *)pcm)[idx];
+                if ((i64)v < lo || (i64)v > hi) bad = 1;
+                (c == 0 ? s0 : s1)[i] = v;
+            }
+        }
+        if (__any(bad)) err |= FG_ERR_RANGE;
+        lds_fence();
+    }
+
+    // ---------------------------------------------------------------- wasted bits
+    __device__ void wasted_bits(uint32_t dbase)
+    {
+        for (int c = 0; c < ncand; c++) {
+            uint32_t orl = 0, orh = 0;
+            for (uint32_t i = lane; i < n; i += 64) {
+                if (mode == 1 && c == 3 && wide) {
+                    i64 s = (i64)s0[i] - (i64)s1[i];
+                    orl |= (uint32_t)s; orh |= (uint32_t)((u64)s >> 32);
+                }
+                else orl |= (uint32_t)get(c, i, 0);
+            }
+            orl = wave_or(orl); orh = wave_or(orh);
+            uint32_t w = 0;
+            if (orl) w = (uint32_t)__builtin_ctz(orl);
+            else if (orh) w = 32;
+            uint32_t nominal = P.bps + ((mode == 1 && c == 3) ? 1u : 0u);
+            if (w > nominal) w = nominal;
+            uint32_t sb = nominal - w;
+            if (sb > 32) { err |= FG_ERR_SIDE33; sb = 32; }
+            if (lane == 0) { decs[dbase + c].wasted = w; decs[dbase + c].sbps = sb; }
+        }
+        lds_fence();
+    }
+
+    // ---------------------------------------------------------------- fixed predictor sums (L4)
+    __device__ uint32_t fixed_sums(int c, uint32_t w, uint32_t sb, u64 tot[5], float rb[5])
+    {
+        u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        uint32_t order;
+        if (sb < 28) {
+            for (uint32_t i = 4 + lane; i < n; i += 64) {
+                int32_t v0 = get(c, i, w), v1 = get(c, i - 1, w), v2 = get(c, i - 2, w), v3 = get(c, i - 3, w),
+                        v4 = get(c, i - 4, w);
+                int32_t e1 = v0 - v1, d1 = v1 - v2, d2 = v2 - v3, d3 = v3 - v4;
+                int32_t e2 = e1 - d1, f2 = d1 - d2, g2 = d2 - d3;
+                int32_t e3 = e2 - f2, f3 = f2 - g2;
+                int32_t e4 = e3 - f3;
+                a0 += (uint32_t)abs(v0); a1 += (uint32_t)abs(e1); a2 += (uint32_t)abs(e2);
+                a3 += (uint32_t)abs(e3); a4 += (uint32_t)abs(e4);
+            }
+            tot[0] = wave_add64(a0); tot[1] = wave_add64(a1); tot[2] = wave_add64(a2);
+            tot[3] = wave_add64(a3); tot[4] = wave_add64(a4);
+            u64 m34 = tot[3] < tot[4] ? tot[3] : tot[4];
+            u64 m234 = tot[2] < m34 ? tot[2] : m34;
+            u64 m1234 = tot[1] < m234 ? tot[1] : m234;
+            if (tot[0] <= m1234) order = 0;
+            else if (tot[1] <= m234) order = 1;
+            else if (tot[2] <= m34) order = 2;
+            else if (tot[3] <= tot[4]) order = 3;
+            else order = 4;
+            const double len = (double)(n - 4);
+            for (int k = 0; k < 5; k++)
+                rb[k] = (float)((tot[k] > 0) ? log(FG_LN2 * (double)tot[k] / len) / FG_LN2 : 0.0);
+        }
+        else {
+            // sbps >= 28: libFLAC's _limit_residual variant (oracle/flac_oracle.c fixed_best_predictor)
+            uint32_t inv = 0;
+            for (uint32_t i = lane; i < n; i += 64) {
+                i64 v0 = get(c, i, w);
+                i64 v1 = i >= 1 ? (i64)get(c, i - 1, w) : 0, v2 = i >= 2 ? (i64)get(c, i - 2, w) : 0;
+                i64 v3 = i >= 3 ? (i64)get(c, i - 3, w) : 0, v4 = i >= 4 ? (i64)get(c, i - 4, w) : 0;
+                u64 e0 = (u64)(v0 < 0 ? -v0 : v0), e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+                i64 t;
+                if (i >= 1) { t = v0 - v1; e1 = (u64)(t < 0 ? -t : t); }
+                if (i >= 2) { t = v0 - 2 * v1 + v2; e2 = (u64)(t < 0 ? -t : t); }
+                if (i >= 3) { t = v0 - 3 * v1 + 3 * v2 - v3; e3 = (u64)(t < 0 ? -t : t); }
+                if (i >= 4) { t = v0 - 4 * v1 + 6 * v2 - 4 * v3 + v4; e4 = (u64)(t < 0 ? -t : t); }
+                a0 += e0; a1 += e1; a2 += e2; a3 += e3; a4 += e4;
+                if (e0 > 0x7FFFFFFFull) inv |= 1;
+                if (e1 > 0x7FFFFFFFull) inv |= 2;
+                if (e2 > 0x7FFFFFFFull) inv |= 4;
+                if (e3 > 0x7FFFFFFFull) inv |= 8;
+                if (e4 > 0x7FFFFFFFull) inv |= 16;
+            }
+            inv = wave_or(inv);
+            tot[0] = wave_add64(a0); tot[1] = wave_add64(a1); tot[2] = wave_add64(a2);
+            tot[3] = wave_add64(a3); tot[4] = wave_add64(a4);
+            u64 smallest = ~0ull;
+            order = 0;
+            const double len = (double)(n - 4);
+            for (int k = 4; k >= 0; k--) {
+                if (!((inv >> k) & 1) && tot[k] <= smallest) {
+                    order = (uint32_t)k; smallest = tot[k];
+                    rb[k] = (float)((tot[0] > 0) ? log(FG_LN2 * (double)tot[0] / len) / FG_LN2 : 0.0);
+                }
+                else rb[k] = 34.0f;
+            }
+        }
+        return order;
+    }
+
+    __device__ bool is_constant(int c, uint32_t w)
+    {
+        const int32_t x0 = get(c, 0, w);
+        uint32_t ne = 0;
+        for (uint32_t i = lane; i < n; i += 64) ne |= (get(c, i, w) != x0);
+        return !__any(ne);
+    }
+
+    // ---------------------------------------------------------------- autocorrelation (L5, L6)
+    // One vector for every candidate at once.  vec_len samples; if part == 0 the plain window over the
+    // whole block, else FLAC__lpc_window_data_partial(part_size = part, data_shift = sh).
+    __device__ void autocorr_vector(uint32_t dbase, uint32_t v, uint32_t vec_len, uint32_t part, uint32_t sh,
+                                    uint32_t mo, uint32_t LP)
+    {
+        const uint32_t mo1 = mo + 1;
+        const uint32_t cpp = 64 / LP;                // candidates per pass
+        const uint32_t DSTR = FG_DH + FG_DK;
+        for (uint32_t c0 = 0; c0 < (uint32_t)ncand; c0 += cpp) {
+            const uint32_t cl = lane / LP, l = lane % LP;   // candidate slot / lag of this lane
+            const uint32_t c = c0 + cl;
+            double acc = 0.0;
+            // zero the history
+            for (uint32_t j = lane; j < cpp * DSTR; j += 64)
+                if ((j % DSTR) < FG_DH) dbuf[j] = 0.0;
+            lds_fence();
+            for (uint32_t k0 = 0; k0 < vec_len; k0 += FG_DK) {
+                const uint32_t kn = (vec_len - k0) < FG_DK ? (vec_len - k0) : FG_DK;
+                for (uint32_t cc = 0; cc < cpp && c0 + cc < (uint32_t)ncand; cc++) {
+                    const uint32_t w = decs[dbase + c0 + cc].wasted;
+                    for (uint32_t j = lane; j < kn; j += 64) {
+                        const uint32_t i = k0 + j;
+                        float d;
+                        if (part == 0) d = (float)get(c0 + cc, i, w) * window[i];
+                        else if (i < part) d = (float)get(c0 + cc, sh + i, w) * window[i];
+                        else if (i < 2 * part) d = (float)get(c0 + cc, sh + i, w) * window[n - 2 * part + i];
+                        else d = 0.0f;
+                        dbuf[cc * DSTR + FG_DH + j] = (double)d;
+                    }
+                }
+                lds_fence();
+                if (c < (uint32_t)ncand && l < mo1) {
+                    const double *cur = dbuf + cl * DSTR + FG_DH;
+                    const double *hist = cur - l;
+                    for (uint32_t j = 0; j < kn; j++) acc = __builtin_fma(cur[j], hist[j], acc);
+                }
+                lds_fence();
+                // keep the last FG_DH entries as history for the next chunk
+                if (k0 + kn < vec_len) {
+                    double t[(64 / 16) * FG_DH / 64 + 1];
+                    int cnt = 0;
+                    for (uint32_t j = lane; j < cpp * FG_DH; j += 64)
+                        t[cnt++] = dbuf[(j / FG_DH) * DSTR + kn + (j % FG_DH)];
+                    lds_fence();
+                    cnt = 0;
+                    for (uint32_t j = lane; j < cpp * FG_DH; j += 64) dbuf[(j / FG_DH) * DSTR + (j % FG_DH)] = t[cnt++];
+                    lds_fence();
+                }
+            }
+            if (c < (uint32_t)ncand && l < mo1) autoc[(c * P.nvec + v) * (FG_MAX_ORDER + 1) + l] = acc;
+            lds_fence();
+        }
+    }
+
+    __device__ __forceinline__ double ebps(double e, double scale) const
+    {
+        if (e > 0.0) {
+            double b = 0.5 * log(scale * e) / FG_LN2;
+            return b >= 0.0 ? b : 0.0;
+        }
+        else if (e < 0.0) return 1e32;
+        return 0.0;
+    }
+
+    // ---------------------------------------------------------------- Levinson / order guess / quantise (L7-L9)
+    // lane = (candidate, vector).  Results: lres[idx] = order | prec<<8 | (shift&255)<<16 | ok<<24 | ran<<25,
+    // qres[idx*32+j].  Scratch (aliases dbuf): lpcw[mo][LS] doubles + lpf[mo][LS] floats.
+    __device__ void lpc_decide(uint32_t dbase, uint32_t nv, uint32_t mo, const uint32_t vflags[])
+    {
+        const uint32_t nidx = (uint32_t)ncand * P.nvec;
+        const uint32_t LS = nidx;
+        double *lpcw = dbuf;
+        float *lpf = (float *)(dbuf + (size_t)mo * LS);
+        const uint32_t idx = lane;
+        if (idx < nidx) {
+            const uint32_t c = idx / P.nvec, v = idx % P.nvec;
+            uint32_t vf = 0;
+            for (int cc = 0; cc < ncand; cc++) if ((uint32_t)cc == c) vf = vflags[cc];
+            const double *A = autoc + (c * P.nvec + v) * (FG_MAX_ORDER + 1);
+            bool on = v < nv && ((vf >> v) & 1);
+            if (on && A[0] == 0.0) on = false;
+            const uint32_t sb = decs[dbase + c].sbps;
+            const double a0 = on ? A[0] : 1.0;
+            const uint32_t overhead = sb + P.qlp_precision;
+            const double scale = 0.5 / (double)n;
+            double err = a0, bestb = 4294967295.0;
+            uint32_t besti = 0;
+            bool stopped = false;
+            for (uint32_t i = 0; i < mo; i++) {
+                double r = on ? -A[i + 1] : 0.0;
+                for (uint32_t j = 0; j < i; j++) r -= lpcw[j * LS + idx] * (on ? A[i - j] : 0.0);
+                r /= err;
+                lpcw[i * LS + idx] = r;
+                uint32_t j;
+                for (j = 0; j < (i >> 1); j++) {
+                    const double tmp = lpcw[j * LS + idx], t2 = lpcw[(i - 1 - j) * LS + idx];
+                    lpcw[j * LS + idx] = tmp + r * t2;
+                    lpcw[(i - 1 - j) * LS + idx] = t2 + r * tmp;
+                }
+                if (i & 1) { const double t = lpcw[j * LS + idx]; lpcw[j * LS + idx] = t + t * r; }
+                err *= (1.0 - r * r);
+                if (!stopped) {
+                    const uint32_t o = i + 1;
+                    const double bits = ebps(err, scale) * (double)(n - o) + (double)(o * overhead);
+                    if (bits < bestb) { besti = i; bestb = bits; }
+                    if (err == 0.0) stopped = true;
+                }
+            }
+            const uint32_t ostar = besti + 1;
+            // second pass: recompute the recursion and capture the coefficients of order ostar
+            double err2 = a0, err_at = 0.0;
+            for (uint32_t i = 0; i < ostar; i++) {
+                double r = on ? -A[i + 1] : 0.0;
+                for (uint32_t j = 0; j < i; j++) r -= lpcw[j * LS + idx] * (on ? A[i - j] : 0.0);
+                r /= err2;
+                lpcw[i * LS + idx] = r;
+                uint32_t j;
+                for (j = 0; j < (i >> 1); j++) {
+                    const double tmp = lpcw[j * LS + idx], t2 = lpcw[(i - 1 - j) * LS + idx];
+                    lpcw[j * LS + idx] = tmp + r * t2;
+                    lpcw[(i - 1 - j) * LS + idx] = t2 + r * tmp;
+                }
+                if (i & 1) { const double t = lpcw[j * LS + idx]; lpcw[j * LS + idx] = t + t * r; }
+                err2 *= (1.0 - r * r);
+            }
+            err_at = err2;
+            for (uint32_t jj = 0; jj < ostar; jj++) lpf[jj * LS + idx] = (float)(-lpcw[jj * LS + idx]);
+            uint32_t result = 0;
+            if (on) {
+                bool ok = !(ebps(err_at, 0.5 / (double)(n - ostar)) >= (double)sb);
+                uint32_t prec = P.qlp_precision;
+                if (sb <= 17) { const uint32_t lim = 32 - sb - ilog2_32(ostar); if (lim < prec) prec = lim; }
+                int shift = 0;
+                if (ok) {
+                    // FLAC__lpc_quantize_coefficients
+                    const int p1 = (int)prec - 1;
+                    const int32_t qmax = (1 << p1) - 1, qmin = -(1 << p1);
+                    double cmax = 0.0;
+                    for (uint32_t j = 0; j < ostar; j++) { const double d = fabs((double)lpf[j * LS + idx]); if (d > cmax) cmax = d; }
+                    if (cmax <= 0.0) ok = false;
+                    else {
+                        const int e = (int)((__double_as_longlong(cmax) >> 52) & 0x7FF) - 1022;  // frexp exponent
+                        shift = p1 - (e - 1) - 1;
+                        if (shift > 15) shift = 15;
+                        else if (shift < -16) ok = false;
+                    }
+                    if (ok) {
+                        double error = 0.0;
+                        const bool neg = shift < 0;
+                        const double mul = neg ? (double)(1 << (-shift)) : (double)(1 << shift);
+                        for (uint32_t j = 0; j < ostar; j++) {
+                            const double lpv = (double)lpf[j * LS + idx];
+                            error += neg ? lpv / mul : lpv * mul;
+                            const double rq = round(error);
+                            int32_t qv = (int32_t)(i64)rq;
+                            if (qv > qmax) qv = qmax; else if (qv < qmin) qv = qmin;
+                            error -= (double)qv;
+                            qres[idx * FG_MAX_ORDER + j] = qv;
+                        }
+                        if (neg) shift = 0;
+                    }
+                }
+                result = ostar | (prec << 8) | (((uint32_t)shift & 0xFF) << 16) | ((ok ? 1u : 0u) << 24) | (1u << 25);
+            }
+            lres[idx] = result;
+        }
+        lds_fence();
+    }
+
+    // ---------------------------------------------------------------- residual of one sample
+    // kind 0: fixed predictor of order `order`; kind 1: LPC with coefficients q (LDS), shift.
+    // Returns false through *ovf when the value does not fit int32 (libFLAC's _limit_residual guard).
+    __device__ __forceinline__ int32_t residual_at(int c, uint32_t w, uint32_t i, int kind, uint32_t order,
+                                                   const int32_t *q, int shift, bool narrow, uint32_t *ovf) const
+    {
+        if (kind == 0) {
+            int32_t v0 = get(c, i, w);
+            if (order == 0) return v0;
+            int32_t v1 = get(c, i - 1, w);
+            if (order == 1) return v0 - v1;
+            int32_t v2 = get(c, i - 2, w);
+            if (order == 2) return v0 - 2 * v1 + v2;
+            int32_t v3 = get(c, i - 3, w);
+            if (order == 3) return v0 - 3 * v1 + 3 * v2 - v3;
+            int32_t v4 = get(c, i - 4, w);
+            return v0 - 4 * v1 + 6 * v2 - 4 * v3 + v4;
+        }
+        if (narrow) {
+            int32_t sum = 0;
+            for (uint32_t j = 0; j < order; j++) sum += q[j] * get(c, i - 1 - j, w);
+            return get(c, i, w) - (sum >> shift);
+        }
+        i64 sum = 0;
+        for (uint32_t j = 0; j < order; j++) sum += (i64)q[j] * (i64)get(c, i - 1 - j, w);
+        i64 r = (i64)get(c, i, w) - (sum >> shift);
+        if (r <= (i64)INT32_MIN || r > (i64)INT32_MAX) *ovf = 1;
+        return (int32_t)r;
+    }
+
+    __device__ bool narrow_ok(uint32_t sb, uint32_t order, const int32_t *q) const
+    {
+        // FLAC__lpc_max_prediction_before_shift_bps(...) <= 32: the 32-bit sum cannot overflow
+        uint32_t s = 0;
+        for (uint32_t j = 0; j < order; j++) s += (uint32_t)abs(q[j]);
+        if (s == 0) s = 1;
+        return sb + (ilog2_32(s) + 2) <= 32;
+    }
+
+    // ---------------------------------------------------------------- partition sums at order pmax (L11)
+    __device__ bool partition_sums(int c, uint32_t w, uint32_t sb, int kind, uint32_t order, const int32_t *q,
+                                   int shift, uint32_t pmax)
+    {
+        const uint32_t parts = 1u << pmax, psz = n >> pmax;
+        const bool narrow = kind == 1 ? narrow_ok(sb, order, q) : true;
+        const bool wrap32 = (sb + 4) < (32 - ilog2_32(psz));
+        uint32_t ovf = 0;
+        if ((psz & 63) == 0) {
+            const uint32_t ipp = psz >> 6;      // iterations per partition
+            uint32_t t = 0;
+            for (uint32_t p = 0; p < parts; p++) {
+                u64 a = 0;
+                for (uint32_t k = 0; k < ipp; k++, t++) {
+                    const uint32_t i = (t << 6) + lane;
+                    if (i >= order) {
+                        int32_t r = residual_at(c, w, i, kind, order, q, shift, narrow, &ovf);
+                        a += (uint32_t)abs(r);
+                    }
+                }
+                a = wave_add64(a);
+                if (wrap32) a &= 0xFFFFFFFFull;
+                if (lane == 0) sums[p] = a;
+            }
+        }
+        else {
+            for (uint32_t p = lane; p < parts; p += 64) sums[p] = 0;
+            lds_fence();
+            const uint32_t inv = (uint32_t)(0xFFFFFFFFull / psz) + 1;   // exact for i, psz < 2^16
+            for (uint32_t i = lane; i < n; i += 64) {
+                if (i >= order) {
+                    int32_t r = residual_at(c, w, i, kind, order, q, shift, narrow, &ovf);
+                    uint32_t p = (uint32_t)(((u64)i * inv) >> 32);
+                    atomicAdd((unsigned long long *)&sums[p], (unsigned long long)(uint32_t)abs(r));
+                }
+            }
+            lds_fence();
+            if (wrap32) for (uint32_t p = lane; p < parts; p += 64) sums[p] &= 0xFFFFFFFFull;
+        }
+        lds_fence();
+        return !__any(ovf);
+    }
+
+    // ---------------------------------------------------------------- Rice parameter / partition order search (L11)
+    // Leaves the parameters of the best order in tmpk[]; returns estimated bits.
+    __device__ uint32_t rice_search(uint32_t order, uint32_t pmax, uint32_t pmin, uint32_t *best_po)
+    {
+        // lower levels by pairwise merge
+        uint32_t from = 0, to = 1u << pmax;
+        for (int po = (int)pmax - 1; po >= (int)pmin; po--) {
+            const uint32_t parts = 1u << po;
+            for (uint32_t p = lane; p < parts; p += 64) sums[to + p] = sums[from + 2 * p] + sums[from + 2 * p + 1];
+            from = to; to += parts;
+            lds_fence();
+        }
+        uint32_t best_bits = 0, bpo = 0, base = 0;
+        const uint32_t limit = P.rice_limit;
+        for (int po = (int)pmax; po >= (int)pmin; po--) {
+            const uint32_t parts = 1u << po;
+            const uint32_t pbase = n >> po;
+            const uint32_t divb = 0x40000u / pbase;
+            u64 total = 0;
+            uint32_t kk[FG_MAX_PARTS / 64];
+            int cnt = 0;
+            for (uint32_t p = lane; p < ((parts + 63) & ~63u); p += 64, cnt++) {
+                uint32_t k = 0;
+                if (p < parts) {
+                    uint32_t np = pbase, div = divb;
+                    if (p == 0) { np -= order; div = 0x40000u / np; }
+                    const u64 mean = sums[base + p];
+                    if (mean >= 2) {
+                        const u64 qv = ((mean - 1) * div) >> 18;
+                        if (qv != 0) k = ilog2_64(qv) + 1;
+                    }
+                    if (k >= limit) k = limit - 1;
+                    u64 pb = (u64)4 + (u64)(1 + k) * np + (k ? (mean >> (k - 1)) : (mean << 1)) - (np >> 1);
+                    if (pb > 0xFFFFFFFFull) pb = 0xFFFFFFFFull;
+                    total += pb;
+                }
+                kk[cnt] = k;
+            }
+            total = wave_add64(total) + 6;
+            const uint32_t bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+            if (best_bits == 0 || bits < best_bits) {
+                best_bits = bits; bpo = (uint32_t)po;
+                cnt = 0;
+                for (uint32_t p = lane; p < parts; p += 64, cnt++) tmpk[p] = (uint8_t)kk[cnt];
+            }
+            base += parts;
+            lds_fence();
+        }
+        *best_po = bpo;
+        return best_bits;
+    }
+
+    __device__ uint32_t limit_pmax(uint32_t pmax, uint32_t order) const
+    {
+        while (pmax > 0 && (n >> pmax) <= order) pmax--;
+        return pmax;
+    }
+
+    // Evaluate one predictor for candidate c; on a strict win, record it in decs[di].
+    __device__ void evaluate(int c, uint32_t di, int kind, uint32_t order, uint32_t prec, int shift,
+                             const int32_t *q, uint32_t pmax0, uint32_t pmin0, uint32_t *best_bits,
+                             uint32_t *out_bits)
+    {
+        const uint32_t w = decs[di].wasted, sb = decs[di].sbps;
+        uint32_t pmax = limit_pmax(pmax0, order);
+        uint32_t pmin = pmin0 < pmax ? pmin0 : pmax;
+        *out_bits = 0;
+        if (!partition_sums(c, w, sb, kind, order, q, shift, pmax)) return;
+        uint32_t bpo;
+        uint32_t rb = rice_search(order, pmax, pmin, &bpo);
+        uint32_t est = kind == 0 ? (8 + w + order * sb) : (8 + w + 4 + 5 + order * (prec + sb));
+        if (rb < 0xFFFFFFFFu - est) est += rb; else est = 0xFFFFFFFFu;
+        *out_bits = est;
+        if (est > 0 && est < *best_bits) {
+            *best_bits = est;
+            Dec *d = &decs[di];
+            if (lane == 0) {
+                d->type = kind == 0 ? 2 : 3; d->order = order; d->prec = prec; d->shift = shift;
+                d->porder = bpo; d->bits = est;
+            }
+            if (kind == 1 && (uint32_t)lane < order) d->q[lane] = q[lane];
+            uint32_t anyhi = 0;
+            for (uint32_t p = lane; p < (1u << bpo); p += 64) { d->k[p] = tmpk[p]; anyhi |= tmpk[p] >= 15; }
+            anyhi = __any(anyhi);
+            if (lane == 0) d->method = anyhi ? 1 : 0;
+        }
+        lds_fence();
+    }
+
+    // ---------------------------------------------------------------- analysis of the staged group (A.5)
+    __device__ void analyse(uint32_t dbase, FgDebugRec *dbg)
+    {
+        const uint32_t pmax_blk = [&] { uint32_t o = 0, b = n; while (!(b & 1)) { o++; b >>= 1; } return o < 15 ? o : 15; }();
+        uint32_t pmax0 = pmax_blk < P.max_po ? pmax_blk : P.max_po;
+        uint32_t pmin0 = P.min_po < pmax0 ? P.min_po : pmax0;
+        wasted_bits(dbase);
+        uint32_t best[FG_MAX_CAND], guess[FG_MAX_CAND], fixed_ok[FG_MAX_CAND], is_const[FG_MAX_CAND];
+        uint32_t vflags[FG_MAX_CAND];
+        bool any_lpc = false;
+        for (int c = 0; c < ncand; c++) {
+            const uint32_t w = decs[dbase + c].wasted, sb = decs[dbase + c].sbps;
+            u64 vb = (u64)8 + w + (u64)n * sb;
+            best[c] = vb < 0xFFFFFFFFull ? (uint32_t)vb : 0xFFFFFFFFu;
+            if (lane == 0) { decs[dbase + c].type = 1; decs[dbase + c].bits = best[c]; decs[dbase + c].order = 0; }
+            guess[c] = 0; fixed_ok[c] = 0; is_const[c] = 0; vflags[c] = 0;
+            if (n > 4) {
+                u64 tot[5];
+                float rb[5];
+                guess[c] = fixed_sums(c, w, sb, tot, rb);
+                if (dbg && lane == 0) {
+                    for (int k = 0; k < 5; k++) dbg->cand[c].fixed_tot[k] = tot[k];
+                    dbg->cand[c].fixed_guess = guess[c];
+                }
+                if (rb[1] == 0.0f && is_constant(c, w)) {
+                    is_const[c] = 1;
+                    uint32_t cb = 8 + w + sb;
+                    if (cb < best[c]) { best[c] = cb; if (lane == 0) { decs[dbase + c].type = 0; decs[dbase + c].bits = cb; } }
+                }
+                else {
+                    uint32_t fo = guess[c];
+                    if (fo >= n) fo = n - 1;
+                    guess[c] = fo;
+                    fixed_ok[c] = !(rb[fo] >= (float)sb);
+                    if (P.max_lpc_order > 0) { vflags[c] = 0xFFFFu; any_lpc = true; }
+                }
+            }
+        }
+        lds_fence();
+        // fixed predictor evaluation (comes before LPC in libFLAC's candidate order)
+        for (int c = 0; c < ncand; c++) {
+            if (!fixed_ok[c]) continue;
+            uint32_t ob;
+            evaluate(c, dbase + c, 0, guess[c], 0, 0, nullptr, pmax0, pmin0, &best[c], &ob);
+            if (dbg && lane == 0) dbg->cand[c].fixed_bits = ob;
+        }
+        // LPC
+        uint32_t nv = 0;
+        if (any_lpc) {
+            const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+            if (mo > 0) {
+                const uint32_t LP = (mo + 1) <= 16 ? 16 : ((mo + 1) <= 32 ? 32 : 64);
+                autocorr_vector(dbase, 0, n, 0, 0, mo, LP);
+                nv = 1;
+                if (P.apod_parts >= 2) {
+                    for (uint32_t b = 2; b <= P.apod_parts; b++) {
+                        const uint32_t cmax = (b == 2) ? 2 : 2 * b - 1;
+                        for (uint32_t cc = 0; cc <= cmax; cc += (b == 2 ? 2 : 1)) {
+                            if (n / b <= 32) continue;      // no vector at all for this depth
+                            if (!(cc & 1)) autocorr_vector(dbase, nv, n / b, n / b / 2, (cc / 2 * n) / b, mo, LP);
+                            else {
+                                // punch-out: root - previous partial for lags < mo; lag mo keeps the partial (upstream quirk)
+                                const uint32_t total = (uint32_t)ncand * (mo + 1);
+                                for (uint32_t j = lane; j < total; j += 64) {
+                                    const uint32_t c = j / (mo + 1), l = j % (mo + 1);
+                                    double *base = autoc + c * P.nvec * (FG_MAX_ORDER + 1);
+                                    const double prev = base[(nv - 1) * (FG_MAX_ORDER + 1) + l];
+                                    base[nv * (FG_MAX_ORDER + 1) + l] = (l < mo) ? base[l] - prev : prev;
+                                }
+                                lds_fence();
+                            }
+                            nv++;
+                        }
+                    }
+                }
+                if (dbg) {
+                    for (uint32_t j = lane; j < (uint32_t)ncand * nv * (mo + 1); j += 64) {
+                        const uint32_t c = j / (nv * (mo + 1)), r = j % (nv * (mo + 1)), v = r / (mo + 1), l = r % (mo + 1);
+                        dbg->cand[c].autoc[v][l] = autoc[(c * P.nvec + v) * (FG_MAX_ORDER + 1) + l];
+                    }
+                    if (lane < ncand) dbg->cand[lane].nvec = nv;
+                }
+                lpc_decide(dbase, nv, mo, vflags);
+                for (int c = 0; c < ncand; c++) {
+                    if (!vflags[c]) continue;
+                    for (uint32_t v = 0; v < nv; v++) {
+                        const uint32_t idx = (uint32_t)c * P.nvec + v;
+                        const uint32_t r = lres[idx];
+                        const uint32_t o = r & 0xFF, prec = (r >> 8) & 0xFF;
+                        const int shift = (int)(int8_t)((r >> 16) & 0xFF);
+                        uint32_t ob = 0;
+                        if (dbg && lane == 0) dbg->cand[c].lpc_guess[v] = (r >> 25) & 1 ? o : 0;
+                        if ((r >> 24) & 1) evaluate(c, dbase + c, 1, o, prec, shift, qres + idx * FG_MAX_ORDER, pmax0, pmin0, &best[c], &ob);
+                        if (dbg && lane == 0) dbg->cand[c].lpc_bits[v] = ob;
+                    }
+                }
+            }
+        }
+        lds_fence();
+    }
+
+    // ---------------------------------------------------------------- bit writer
+    __device__ void bw_init(uint32_t *out, uint32_t words)
+    {
+        outw = out; slot_words = words; bitpos = 0; wbase = 0;
+        for (uint32_t j = lane; j < FG_WINW + 2; j += 64) win[j] = 0;
+        lds_fence();
+    }
+    // Flush every complete word below bit position `newpos`; window keeps the partial word.
+    __device__ void bw_flush(uint32_t newpos)
+    {
+        uint32_t nfull = (newpos >> 5) - wbase;
+        if (nfull == 0) return;
+        if (wbase + nfull > slot_words) { err |= FG_ERR_SLOT; nfull = slot_words > wbase ? slot_words - wbase : 0; }
+        for (uint32_t j = lane; j < nfull; j += 64) outw[wbase + j] = bswap32(win[j]);
+        const uint32_t carry = ((newpos >> 5) - wbase) < FG_WINW + 2 ? win[(newpos >> 5) - wbase] : 0;
+        lds_fence();
+        for (uint32_t j = lane; j < FG_WINW + 2; j += 64) win[j] = 0;
+        lds_fence();
+        if (lane == 0) win[0] = carry;
+        wbase = newpos >> 5;
+        lds_fence();
+    }
+    __device__ __forceinline__ void bw_or(uint32_t pos, uint32_t val, uint32_t vbits)
+    {
+        // place the low `vbits` bits of val at absolute bit position pos (MSB first)
+        const uint32_t rel = pos - (wbase << 5);
+        const uint32_t word = rel >> 5, sh = rel & 31;
+        const u64 x = (u64)val << (64 - sh - vbits);
+        atomicOr(&win[word], (uint32_t)(x >> 32));
+        const uint32_t lo = (uint32_t)x;
+        if (lo) atomicOr(&win[word + 1], lo);
+    }
+    // Skip z zero bits (uniform).
+    __device__ void bw_zeros(uint32_t z)
+    {
+        while (((bitpos + z) >> 5) - wbase >= FG_WINW) {
+            const uint32_t np = (wbase + FG_WINW) << 5;
+            z -= np - bitpos;
+            bitpos = np;
+            bw_flush(np);
+        }
+        bitpos += z;
+    }
+    // One packing round.  Every lane may contribute a prefix field (pv, pb bits, pb <= 32) followed by a
+    // code of nb bits whose low vb bits are val and whose leading nb - vb bits are zero (vb <= 32).
+    __device__ void bw_round(uint32_t pv, uint32_t pb, uint32_t val, uint32_t vb, uint32_t nb)
+    {
+        const uint32_t mine = pb + nb;
+        const uint32_t incl = wave_incl_scan(mine, lane);
+        const uint32_t total = bcast(incl, 63);
+        if (total == 0) return;
+        // 32-bit bit positions: a frame is far below 2^32 bits; guard the scan against wrap anyway
+        const uint32_t anybig = __any(nb > (1u << 26));
+        if (!anybig && (bitpos & 31) + total <= 32u * FG_WINW) {
+            const uint32_t off = bitpos + incl - mine;
+            if (pb) bw_or(off, pv, pb);
+            if (vb) bw_or(off + pb + nb - vb, val, vb);
+            lds_fence();
+            bitpos += total;
+            bw_flush(bitpos);
+        }
+        else {
+            // rare: a round that does not fit the window (very long unary runs); serialise the lanes
+            for (int L = 0; L < 64; L++) {
+                const uint32_t lpv = bcast(pv, L), lpb = bcast(pb, L), lval = bcast(val, L), lvb = bcast(vb, L),
+                               lnb = bcast(nb, L);
+                if (lpb) {
+                    if (lane == 0) bw_or(bitpos, lpv, lpb);
+                    lds_fence();
+                    bitpos += lpb;
+                    bw_flush(bitpos);
+                }
+                if (lnb) {
+                    bw_zeros(lnb - lvb);
+                    bw_flush(bitpos);
+                    if (lvb) {
+                        if (lane == 0) bw_or(bitpos, lval, lvb);
+                        lds_fence();
+                        bitpos += lvb;
+                        bw_flush(bitpos);
+                    }
+                }
+            }
+        }
+    }
+    __device__ void bw_put(uint32_t val, uint32_t bits)   // uniform single field, bits <= 32
+    {
+        bw_round(0, 0, lane == 0 ? (bits < 32 ? (val & ((1u << bits) - 1)) : val) : 0, lane == 0 ? bits : 0,
+                 lane == 0 ? bits : 0);
+    }
+    // Flush everything including the partial last word (zero padded); the partial word stays in the
+    // window so later fields can still be ORed in (it is simply stored again, as a superset).
+    __device__ void bw_flush_all()
+    {
+        bw_flush(bitpos);
+        if ((bitpos & 31) && lane == 0) {
+            if (wbase < slot_words) outw[wbase] = bswap32(win[0]);
+            else err |= FG_ERR_SLOT;
+        }
+        err = wave_or(err);
+    }
+
+    // ---------------------------------------------------------------- frame header (A.8)
+    __device__ void write_header(uint32_t ca, uint32_t frame_number)
+    {
+        uint8_t *hb = (uint8_t *)misc;      // header bytes assembled by lane 0
+        uint32_t hl = 0;
+        if (lane == 0) {
+            uint32_t u, bs_hint = 0, sr_hint = 0;
+            hb[hl++] = 0xFF; hb[hl++] = 0xF8;
+            switch (n) {
+            case 192: u = 1; break; case 576: u = 2; break; case 1152: u = 3; break; case 2304: u = 4; break;
+            case 4608: u = 5; break; case 256: u = 8; break; case 512: u = 9; break; case 1024: u = 10; break;
+            case 2048: u = 11; break; case 4096: u = 12; break; case 8192: u = 13; break; case 16384: u = 14; break;
+            case 32768: u = 15; break;
+            default: bs_hint = u = (n <= 0x100) ? 6 : 7; break;
+            }
+            uint32_t b2 = u << 4;
+            const uint32_t sr = P.sample_rate;
+            switch (sr) {
+            case 88200: u = 1; break; case 176400: u = 2; break; case 192000: u = 3; break; case 8000: u = 4; break;
+            case 16000: u = 5; break; case 22050: u = 6; break; case 24000: u = 7; break; case 32000: u = 8; break;
+            case 44100: u = 9; break; case 48000: u = 10; break; case 96000: u = 11; break;
+            default:
+                if (sr <= 255000 && sr % 1000 == 0) sr_hint = u = 12;
+                else if (sr <= 655350 && sr % 10 == 0) sr_hint = u = 14;
+                else if (sr <= 0xffff) sr_hint = u = 13;
+                else u = 0;
+                break;
+            }
+            hb[hl++] = (uint8_t)(b2 | u);
+            switch (ca) { case 0: u = P.channels - 1; break; case 1: u = 8; break; case 2: u = 9; break; default: u = 10; break; }
+            uint32_t b3 = u << 4;
+            switch (P.bps) { case 8: u = 1; break; case 12: u = 2; break; case 16: u = 4; break; case 20: u = 5; break;
+                             case 24: u = 6; break; case 32: u = 7; break; default: u = 0; break; }
+            hb[hl++] = (uint8_t)(b3 | (u << 1));
+            const uint32_t v = frame_number;
+            if (v < 0x80) hb[hl++] = (uint8_t)v;
+            else if (v < 0x800) { hb[hl++] = 0xC0 | (v >> 6); hb[hl++] = 0x80 | (v & 0x3F); }
+            else if (v < 0x10000) { hb[hl++] = 0xE0 | (v >> 12); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            else if (v < 0x200000) { hb[hl++] = 0xF0 | (v >> 18); hb[hl++] = 0x80 | ((v >> 12) & 0x3F); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            else if (v < 0x4000000) { hb[hl++] = 0xF8 | (v >> 24); hb[hl++] = 0x80 | ((v >> 18) & 0x3F); hb[hl++] = 0x80 | ((v >> 12) & 0x3F); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            else { hb[hl++] = 0xFC | (v >> 30); hb[hl++] = 0x80 | ((v >> 24) & 0x3F); hb[hl++] = 0x80 | ((v >> 18) & 0x3F); hb[hl++] = 0x80 | ((v >> 12) & 0x3F); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            if (bs_hint == 6) hb[hl++] = (uint8_t)(n - 1);
+            else if (bs_hint == 7) { hb[hl++] = (uint8_t)((n - 1) >> 8); hb[hl++] = (uint8_t)(n - 1); }
+            if (sr_hint == 12) hb[hl++] = (uint8_t)(sr / 1000);
+            else if (sr_hint == 13) { hb[hl++] = (uint8_t)(sr >> 8); hb[hl++] = (uint8_t)sr; }
+            else if (sr_hint == 14) { hb[hl++] = (uint8_t)((sr / 10) >> 8); hb[hl++] = (uint8_t)(sr / 10); }
+            uint32_t c8 = 0;
+            for (uint32_t i = 0; i < hl; i++) {
+                c8 ^= hb[i];
+                for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
+            }
+            hb[hl++] = (uint8_t)c8;
+        }
+        hl = bcast(hl, 0);
+        lds_fence();
+        const uint32_t v = (uint32_t)lane < hl ? hb[lane] : 0, b = (uint32_t)lane < hl ? 8 : 0;
+        lds_fence();
+        bw_round(0, 0, v, b, b);
+    }
+
+    // ---------------------------------------------------------------- one subframe (A.8)
+    __device__ void write_subframe(int c, uint32_t di)
+    {
+        const Dec *d = &decs[di];
+        const uint32_t type = d->type, order = d->order, w = d->wasted, sb = d->sbps;
+        const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
+        uint32_t hdr;
+        switch (type) {
+        case 0: hdr = 0x00; break;
+        case 1: hdr = 0x02; break;
+        case 2: hdr = 0x10 | (order << 1); break;
+        default: hdr = 0x40 | ((order - 1) << 1); break;
+        }
+        bw_put(hdr | (w ? 1 : 0), 8);
+        if (w) {
+            // unary: w-1 zeros then a one
+            const uint32_t nb = lane == 0 ? w : 0;
+            bw_round(0, 0, lane == 0 ? 1 : 0, lane == 0 ? 1 : 0, nb);
+        }
+        if (type == 0) { bw_put((uint32_t)get(c, 0, w) & mask, sb); return; }
+        if (type == 1) {
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool on = i < n;
+                bw_round(0, 0, on ? ((uint32_t)get(c, i, w) & mask) : 0, on ? sb : 0, on ? sb : 0);
+            }
+            return;
+        }
+        {   // warm-up samples
+            const bool on = (uint32_t)lane < order;
+            bw_round(0, 0, on ? ((uint32_t)get(c, lane, w) & mask) : 0, on ? sb : 0, on ? sb : 0);
+        }
+        const int32_t *q = d->q;
+        const int shift = d->shift;
+        if (type == 3) {
+            const uint32_t prec = d->prec;
+            // lane 0: precision-1 (4 bits) as prefix + shift (5 bits); lanes 1..order: coefficients
+            uint32_t pv = 0, pb = 0, val = 0, vb = 0;
+            if (lane == 0) { pv = prec - 1; pb = 4; val = (uint32_t)shift & 31; vb = 5; }
+            else if ((uint32_t)lane <= order) { val = (uint32_t)q[lane - 1] & ((1u << prec) - 1); vb = prec; }
+            bw_round(pv, pb, val, vb, vb);
+        }
+        const uint32_t po = d->porder, method = d->method;
+        bw_put((method << 4) | po, 6);
+        const uint32_t plen = method ? 5 : 4;
+        const uint32_t psz = n >> po;
+        const uint32_t inv = psz ? (uint32_t)(0xFFFFFFFFull / psz) + 1 : 0;
+        const int kind = type == 2 ? 0 : 1;
+        const bool narrow = kind == 1 ? narrow_ok(sb, order, q) : true;
+        uint32_t ovf = 0;
+        for (uint32_t i0 = (order / 64) * 64; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint32_t pv = 0, pb = 0, val = 0, vb = 0, nb = 0;
+            if (i < n && i >= order) {
+                const int32_t r = residual_at(c, w, i, kind, order, q, shift, narrow, &ovf);
+                const uint32_t p = po ? (uint32_t)(((u64)i * inv) >> 32) : 0;
+                const uint32_t k = d->k[p];
+                const uint32_t u = ((uint32_t)r << 1) ^ (uint32_t)(r >> 31);
+                const uint32_t msb = u >> k;
+                val = (1u << k) | (u & ((1u << k) - 1));
+                vb = k + 1;
+                nb = msb + 1 + k;
+                const uint32_t pstart = p == 0 ? order : p * psz;
+                if (i == pstart) { pv = k; pb = plen; }
+            }
+            bw_round(pv, pb, val, vb, nb);
+        }
+    }
+
+    // ---------------------------------------------------------------- frame footer: pad + CRC-16
+    __device__ uint32_t finish_frame()
+    {
+        if (bitpos & 7) bitpos += 8 - (bitpos & 7);
+        bw_flush(bitpos);
+        bw_flush_all();
+        __threadfence_block();
+        const uint32_t nbytes = bitpos >> 3;
+        const uint32_t W = nbytes >> 2, tail = nbytes & 3;
+        // lanes take words q = 64*t + lane - pad (front padded with zero words: no effect, CRC init is 0)
+        const uint32_t pad = (64 - (W & 63)) & 63, T = (W + pad) >> 6;
+        uint32_t s = 0;
+        const uint16_t *t0 = crct, *thi = crct + 256, *tlo = crct + 512;
+        for (uint32_t t = 0; t < T; t++) {
+            const int qi = (int)(t * 64 + lane) - (int)pad;
+            uint32_t wv = 0;
+            if (qi >= 0) wv = bswap32(__builtin_nontemporal_load(&outw[qi]));
+            // state * x^2048  (+) crc of the 4 bytes
+            s = thi[s >> 8] ^ tlo[s & 0xFF];
+            uint32_t cw = 0;
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 24)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 16)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 8)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ wv) & 0xFF];
+            s ^= cw;
+        }
+        // fold: lane's polynomial is followed by (63 - lane) words
+        const uint32_t mult = misc[64 + (63 - lane)];
+        s = gf16_mul(s, mult);
+        uint32_t crc = wave_xor(s);
+        if (tail) {
+            const uint32_t wv = W < slot_words ? bswap32(__builtin_nontemporal_load(&outw[W])) : 0;
+            for (uint32_t b = 0; b < tail; b++)
+                crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ (wv >> (24 - 8 * b))) & 0xFF];
+        }
+        bw_put(crc, 16);
+        bw_flush_all();
+        return bitpos >> 3;
+    }
+};
+
+// x^(32*k) mod P for k = 0..63 and the three CRC tables are generated once per launch by fg_crc_tables.
+__global__ void fg_crc_tables_kernel(uint16_t *tab)
+{
+    const int i = threadIdx.x;   // 256 threads
+    uint32_t c = (uint32_t)i << 8;
+    for (int b = 0; b < 8; b++) c = (c & 0x8000) ? (((c << 1) ^ 0x8005) & 0xFFFF) : ((c << 1) & 0xFFFF);
+    tab[i] = (uint16_t)c;                                       // standard table: (i * x^8) * x^8 ... = crc of byte i
+    // multiply by x^2048: high-byte and low-byte contribution tables
+    tab[256 + i] = (uint16_t)crc16_mulx((uint32_t)i << 8, 2048);
+    tab[512 + i] = (uint16_t)crc16_mulx((uint32_t)i, 2048);
+    if (i < 64) tab[768 + i] = (uint16_t)crc16_mulx(1, 32 * i);  // x^(32 i)
+}
+
+__global__ void __launch_bounds__(64)
+fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, uint8_t *out,
+                 FgBlockResult *results, FgDebugRec *dbg, const uint16_t *crctab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FgBlockDesc d = descs[blockIdx.x];
+    Enc e;
+    e.P = P;
+    e.lane = threadIdx.x;
+    e.n = d.n;
+    e.err = 0;
+    e.window = windows + d.win_off;
+    // ---- LDS carve (all offsets multiples of 16)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
+    e.s0 = (int32_t *)carve((size_t)P.sig_stride * 4);
+    e.s1 = (int32_t *)carve((size_t)P.sig_stride * 4);
+    e.dbuf = (double *)carve(P.lds_dbuf_bytes);
+    e.autoc = (double *)carve((size_t)FG_MAX_CAND * P.nvec * (FG_MAX_ORDER + 1) * 8);
+    e.qres = (int32_t *)carve((size_t)FG_MAX_CAND * P.nvec * FG_MAX_ORDER * 4);
+    e.lres = (uint32_t *)carve((size_t)FG_MAX_CAND * P.nvec * 4);
+    e.sums = (u64 *)carve((size_t)(2u << P.max_po) * 8);
+    e.tmpk = (uint8_t *)carve(FG_MAX_PARTS);
+    e.win = (uint32_t *)carve((FG_WINW + 2) * 4);
+    e.crct = (uint16_t *)carve(768 * 2);
+    e.misc = (uint32_t *)carve(128 * 4);
+    e.decs = (Dec *)carve(sizeof(Dec) * 8);
+    for (int j = e.lane; j < 768; j += 64) e.crct[j] = crctab[j];
+    e.misc[64 + e.lane] = crctab[768 + e.lane];
+    lds_fence();
+
+    const uint32_t C = P.channels;
+    e.wide = P.bps > 30;
+    FgDebugRec *mydbg = dbg ? dbg + blockIdx.x : nullptr;
+    uint32_t ca = 0;
+    uint32_t sub_c[8], sub_d[8];
+    uint32_t nsub = C;
+    if (C == 2 && P.do_mid_side) {
+        e.mode = 1; e.ncand = 4;
+        e.stage(pcm, d.pcm_off, 0, 2);
+        e.analyse(0, mydbg);
+        uint32_t b0 = e.decs[0].bits, b1 = e.decs[1].bits, b2 = e.decs[2].bits, b3 = e.decs[3].bits;
+        if (d.forced_ca != 0xFF) ca = d.forced_ca;
+        else {
+            uint32_t bits[4] = {b0 + b1, b0 + b3, b1 + b3, b2 + b3};
+            uint32_t mn = bits[0];
+            for (uint32_t k = 1; k <= 3; k++) if (bits[k] < mn) { mn = bits[k]; ca = k; }
+        }
+        switch (ca) { case 0: sub_c[0] = 0; sub_c[1] = 1; break; case 1: sub_c[0] = 0; sub_c[1] = 3; break;
+                      case 2: sub_c[0] = 3; sub_c[1] = 1; break; default: sub_c[0] = 2; sub_c[1] = 3; break; }
+        sub_d[0] = sub_c[0]; sub_d[1] = sub_c[1];
+        if (e.lane == 0) {
+            FgBlockResult *r = &results[blockIdx.x];
+            r->best_bits[0] = b0; r->best_bits[1] = b1; r->best_bits[2] = b2; r->best_bits[3] = b3;
+        }
+    }
+    else {
+        e.mode = 0;
+        for (uint32_t ch0 = 0; ch0 < C; ch0 += 2) {
+            const uint32_t nch = (C - ch0) < 2 ? (C - ch0) : 2;
+            e.ncand = (int)nch;
+            e.stage(pcm, d.pcm_off, ch0, nch);
+            e.analyse(ch0, (mydbg && ch0 == 0) ? mydbg : nullptr);
+        }
+        for (uint32_t ch = 0; ch < C; ch++) { sub_c[ch] = ch & 1; sub_d[ch] = ch; }
+        if (e.lane == 0) {
+            FgBlockResult *r = &results[blockIdx.x];
+            for (uint32_t k = 0; k < 4; k++) r->best_bits[k] = k < C ? e.decs[k].bits : 0;
+        }
+    }
+    if (mydbg && e.lane < 4 && e.lane < ((C == 2 && P.do_mid_side) ? 4 : (C < 2 ? C : 2))) {
+        const Dec *dd = &e.decs[e.lane];
+        FgDebugCand *dc = &mydbg->cand[e.lane];
+        dc->wasted = dd->wasted; dc->sbps = dd->sbps; dc->type = dd->type; dc->order = dd->type >= 2 ? dd->order : 0;
+        dc->precision = dd->type == 3 ? dd->prec : 0; dc->shift = dd->type == 3 ? dd->shift : 0;
+        dc->bits = dd->bits; dc->porder = dd->type >= 2 ? dd->porder : 0; dc->rice_method = dd->type >= 2 ? dd->method : 0;
+        for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (dd->type == 3 && j < dd->order) ? dd->q[j] : 0;
+        for (uint32_t j = 0; j < FG_MAX_PARTS; j++) dc->rice_params[j] = (dd->type >= 2 && j < (1u << dd->porder)) ? dd->k[j] : 0;
+    }
+    // ---- pack
+    e.bw_init((uint32_t *)(out + (size_t)blockIdx.x * P.slot_bytes), P.slot_bytes / 4);
+    e.write_header(ca, d.frame_number);
+    uint32_t staged_group = (C <= 2) ? 0 : 0xFFFFFFFFu;
+    for (uint32_t sidx = 0; sidx < nsub; sidx++) {
+        if (e.mode == 0 && C > 2) {
+            const uint32_t g = sidx / 2;
+            if (g != staged_group) {
+                const uint32_t ch0 = g * 2, nch = (C - ch0) < 2 ? (C - ch0) : 2;
+                e.stage(pcm, d.pcm_off, ch0, nch);
+                staged_group = g;
+            }
+        }
+        e.write_subframe((int)sub_c[sidx], sub_d[sidx]);
+    }
+    const uint32_t bytes = e.finish_frame();
+    if (e.lane == 0) {
+        FgBlockResult *r = &results[blockIdx.x];
+        r->bytes = bytes; r->ca = ca; r->err = e.err; r->reserved = 0;
+    }
+}
+
+// ------------------------------------------------------------------ compaction: slots -> contiguous stream
+// offsets[b] = sum of bytes of blocks < b (exclusive), offsets[nblocks] = total, offsets[nblocks+1] = OR of errors.
+__global__ void fg_scan_sizes_kernel(const FgBlockResult *results, uint32_t nblocks, u64 *offsets)
+{
+    __shared__ u64 part[1024];
+    __shared__ uint32_t errs;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t per = (nblocks + nt - 1) / nt;
+    const uint32_t b0 = tid * per < nblocks ? tid * per : nblocks, b1 = (b0 + per) < nblocks ? (b0 + per) : nblocks;
+    u64 s = 0;
+    uint32_t e = 0;
+    if (tid == 0) errs = 0;
+    __syncthreads();
+    for (uint32_t b = b0; b < b1; b++) { s += results[b].bytes; e |= results[b].err; }
+    part[tid] = s;
+    if (e) atomicOr(&errs, e);
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0;
+        for (uint32_t t = 0; t < nt; t++) { u64 v = part[t]; part[t] = run; run += v; }
+        offsets[nblocks] = run;
+        offsets[nblocks + 1] = errs;
+    }
+    __syncthreads();
+    u64 run = part[tid];
+    for (uint32_t b = b0; b < b1; b++) { offsets[b] = run; run += results[b].bytes; }
+}
+
+__global__ void __launch_bounds__(256)
+fg_compact_kernel(const uint8_t *slots, uint32_t slot_bytes, const FgBlockResult *results, const u64 *offsets,
+                  uint8_t *dst)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t nb = results[b].bytes;
+    const uint8_t *src = slots + (size_t)b * slot_bytes;
+    uint8_t *d = dst + offsets[b];
+    // head bytes up to a 4-byte boundary of dst, then word copies with a funnel shift on the source
+    const uint32_t mis = (uint32_t)((uintptr_t)d & 3);
+    const uint32_t head = mis ? (4 - mis) : 0;
+    const uint32_t h = head < nb ? head : nb;
+    if (threadIdx.x < h) d[threadIdx.x] = src[threadIdx.x];
+    const uint32_t nw = (nb - h) >> 2;
+    const uint32_t *sw = (const uint32_t *)src;   // slot is 4-byte aligned
+    uint32_t *dw = (uint32_t *)(d + h);
+    const uint32_t shb = h * 8;                   // source byte offset h (0..3) -> bit shift
+    for (uint32_t j = threadIdx.x; j < nw; j += 256) {
+        uint32_t lo = sw[j], v;
+        if (shb == 0) v = lo;
+        else { uint32_t hi = sw[j + 1]; v = (lo >> shb) | (hi << (32 - shb)); }
+        dw[j] = v;
+    }
+    const uint32_t done = h + nw * 4;
+    if (threadIdx.x < nb - done) d[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host-callable launchers (C ABI, used by flacgpu_api.cpp)
+extern "C" {
+
+size_t fg_enc_lds_bytes(const FgEncParams *P)
+{
+    size_t off = 0;
+    auto add = [&](size_t b) { off += (b + 15) & ~(size_t)15; };
+    add((size_t)P->sig_stride * 4);
+    add((size_t)P->sig_stride * 4);
+    add(P->lds_dbuf_bytes);
+    add((size_t)FG_MAX_CAND * P->nvec * (FG_MAX_ORDER + 1) * 8);
+    add((size_t)FG_MAX_CAND * P->nvec * FG_MAX_ORDER * 4);
+    add((size_t)FG_MAX_CAND * P->nvec * 4);
+    add((size_t)(2u << P->max_po) * 8);
+    add(FG_MAX_PARTS);
+    add((FG_WINW + 2) * 4);
+    add(768 * 2);
+    add(128 * 4);
+    add(sizeof(Dec) * 8);
+    return off;
+}
+
+int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_crc_tables_kernel, dim3(1), dim3(256), 0, stream, d_tab);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
+                     uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
+                     const uint16_t *d_crctab, hipStream_t stream)
+{
+    if (nblocks == 0) return 0;
+    const size_t lds = fg_enc_lds_bytes(P);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)fg_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(fg_encode_kernel, dim3(nblocks), dim3(64), lds, stream, d_pcm, d_descs, d_windows, *P, d_slots,
+                       d_results, d_dbg, d_crctab);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream)
+{
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, nblocks, d_offsets);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
+                   const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream)
+{
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(fg_compact_kernel, dim3(nblocks), dim3(256), 0, stream, d_slots, slot_bytes, d_results, d_offsets, d_dst);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,741 @@
+// flacgpu_dec_api.cpp -- the libFLAC stream-decoder entry points pyFLAC binds
+// (reference: pyflac/builder/decoder.py:387-475), backed by the HIP frame decoder, plus the batch decode
+// entry points of include/flacgpu.h.
+//
+// Host responsibilities: pulling bytes through the read callback,
+// metadata parsing, locating frame boundaries (sync code + header CRC-8, confirmed by the frame CRC-16),
+// delivering frames in order through the write callback and reporting errors.  All subframe decoding, CRC-16
+// checking and channel reconstruction runs on the GPU; there is no CPU decode fallback.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "fg_host.h"
+
+extern "C" {
+const char *const FLAC__StreamDecoderStateString[] = {
+    "FLAC__STREAM_DECODER_SEARCH_FOR_METADATA", "FLAC__STREAM_DECODER_READ_METADATA", "FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC",
+    "FLAC__STREAM_DECODER_READ_FRAME", "FLAC__STREAM_DECODER_END_OF_STREAM", "FLAC__STREAM_DECODER_OGG_ERROR",
+    "FLAC__STREAM_DECODER_SEEK_ERROR", "FLAC__STREAM_DECODER_ABORTED", "FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR",
+    "FLAC__STREAM_DECODER_UNINITIALIZED"};
+const char *const FLAC__StreamDecoderInitStatusString[] = {
+    "FLAC__STREAM_DECODER_INIT_STATUS_OK", "FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER",
+    "FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS", "FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR",
+    "FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE", "FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED"};
+const char *const FLAC__StreamDecoderErrorStatusString[] = {
+    "FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC", "FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER",
+    "FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH", "FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM",
+    "FLAC__STREAM_DECODER_ERROR_STATUS_BAD_METADATA"};
+}
+
+#define HIPOK(call) ((call) == hipSuccess)
+
+// ------------------------------------------------------------------ frame header parsing on the host
+namespace {
+
+struct HostHeader {
+    uint32_t n, sample_rate, channels, ca, bps, hdr_bytes, variable;
+    uint64_t number;
+};
+
+// Returns true when p[0..avail) starts with a syntactically valid frame header whose CRC-8 matches.
+bool parse_header(const uint8_t *p, size_t avail, const FLAC__StreamMetadata_StreamInfo *si, HostHeader *h)
+{
+    if (avail < 6 || p[0] != 0xFF || (p[1] & 0xFE) != 0xF8) return false;
+    const uint32_t bsc = p[2] >> 4, src = p[2] & 15, cac = p[3] >> 4, bpc = (p[3] >> 1) & 7;
+    if (bsc == 0 || src == 15 || cac > 10 || bpc == 3 || (p[3] & 1)) return false;
+    size_t pos = 4;
+    uint32_t x = p[pos++], extra;
+    uint64_t num;
+    if (!(x & 0x80)) { num = x; extra = 0; }
+    else if ((x & 0xE0) == 0xC0) { num = x & 0x1F; extra = 1; }
+    else if ((x & 0xF0) == 0xE0) { num = x & 0x0F; extra = 2; }
+    else if ((x & 0xF8) == 0xF0) { num = x & 0x07; extra = 3; }
+    else if ((x & 0xFC) == 0xF8) { num = x & 0x03; extra = 4; }
+    else if ((x & 0xFE) == 0xFC) { num = x & 0x01; extra = 5; }
+    else if (x == 0xFE) { num = 0; extra = 6; }
+    else return false;
+    if (pos + extra + 5 > avail + 0 && pos + extra >= avail) return false;
+    for (uint32_t i = 0; i < extra; i++) {
+        if (pos >= avail || (p[pos] & 0xC0) != 0x80) return false;
+        num = (num << 6) | (p[pos++] & 0x3F);
+    }
+    uint32_t n;
+    switch (bsc) {
+    case 1: n = 192; break;
+    case 2: case 3: case 4: case 5: n = 576u << (bsc - 2); break;
+    case 6: if (pos + 1 > avail) return false; n = (uint32_t)p[pos] + 1; pos += 1; break;
+    case 7: if (pos + 2 > avail) return false; n = (((uint32_t)p[pos] << 8) | p[pos + 1]) + 1; pos += 2; break;
+    default: n = 256u << (bsc - 8); break;
+    }
+    static const uint32_t SR[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
+    uint32_t sr = si ? si->sample_rate : 0;
+    if (src >= 1 && src <= 11) sr = SR[src];
+    else if (src == 12) { if (pos + 1 > avail) return false; sr = (uint32_t)p[pos] * 1000; pos += 1; }
+    else if (src == 13) { if (pos + 2 > avail) return false; sr = ((uint32_t)p[pos] << 8) | p[pos + 1]; pos += 2; }
+    else if (src == 14) { if (pos + 2 > avail) return false; sr = (((uint32_t)p[pos] << 8) | p[pos + 1]) * 10; pos += 2; }
+    if (pos + 1 > avail) return false;
+    if (fg_crc8(p, pos) != p[pos]) return false;
+    pos++;
+    static const uint32_t BP[8] = {0, 8, 12, 0, 16, 20, 24, 32};
+    h->n = n; h->sample_rate = sr; h->bps = bpc ? BP[bpc] : (si ? si->bits_per_sample : 0);
+    if (cac < 8) { h->channels = cac + 1; h->ca = 0; } else { h->channels = 2; h->ca = cac - 7; }
+    h->hdr_bytes = (uint32_t)pos; h->variable = p[1] & 1; h->number = num;
+    if (si && si->channels && h->channels != si->channels) return false;
+    if (si && si->bits_per_sample && h->bps != si->bits_per_sample) return false;
+    return true;
+}
+
+// Parse "fLaC" + metadata blocks.  Returns bytes consumed (audio offset), 0 if more data is needed,
+// -1 on a malformed stream.
+int64_t parse_metadata(const uint8_t *d, uint64_t len, FLAC__StreamMetadata_StreamInfo *si, bool *have_si)
+{
+    if (len < 4) return 0;
+    if (memcmp(d, "fLaC", 4)) return -1;
+    uint64_t pos = 4;
+    for (;;) {
+        if (pos + 4 > len) return 0;
+        const uint32_t last = d[pos] >> 7, type = d[pos] & 0x7F;
+        const uint32_t l = ((uint32_t)d[pos + 1] << 16) | ((uint32_t)d[pos + 2] << 8) | d[pos + 3];
+        if (pos + 4 + l > len) return 0;
+        if (type == 0 && l >= 34) {
+            const uint8_t *s = d + pos + 4;
+            si->min_blocksize = (s[0] << 8) | s[1]; si->max_blocksize = (s[2] << 8) | s[3];
+            si->min_framesize = (s[4] << 16) | (s[5] << 8) | s[6];
+            si->max_framesize = (s[7] << 16) | (s[8] << 8) | s[9];
+            si->sample_rate = ((uint32_t)s[10] << 12) | ((uint32_t)s[11] << 4) | (s[12] >> 4);
+            si->channels = ((s[12] >> 1) & 7) + 1;
+            si->bits_per_sample = ((((uint32_t)s[12] & 1) << 4) | (s[13] >> 4)) + 1;
+            si->total_samples = ((uint64_t)(s[13] & 15) << 32) | ((uint64_t)s[14] << 24) | ((uint64_t)s[15] << 16) |
+                                ((uint64_t)s[16] << 8) | s[17];
+            memcpy(si->md5sum, s + 18, 16);
+            *have_si = true;
+        }
+        pos += 4 + l;
+        if (last) break;
+    }
+    return (int64_t)pos;
+}
+
+// Incremental frame indexer over a growing byte buffer.  A frame [a, b) is accepted when a valid header
+// starts at a, and either a valid header starts at b or b is the end of the stream, and the CRC-16 over
+// [a, b) (stored CRC included) is zero.
+struct Indexer {
+    uint64_t frame_start = 0;     // start of the frame being delimited (valid header already confirmed)
+    bool in_frame = false;
+    uint64_t scan = 0;            // next byte to examine
+    uint16_t crc = 0;             // running CRC-16 over [frame_start, scan)
+    std::vector<uint64_t> bounds; // accepted frame boundaries: frames are [bounds[i], bounds[i+1])
+    std::vector<uint32_t> errors; // FLAC__StreamDecoderErrorStatus to report, in stream order
+    std::vector<uint64_t> error_pos;
+
+    // Examine data[0..len).  `final` = no more data will arrive.
+    void feed(const uint8_t *d, uint64_t len, bool final, const FLAC__StreamMetadata_StreamInfo *si)
+    {
+        static uint16_t tab[256];
+        static bool tab_ok = false;
+        if (!tab_ok) {
+            for (int i = 0; i < 256; i++) {
+                uint16_t c = (uint16_t)(i << 8);
+                for (int b = 0; b < 8; b++) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1));
+                tab[i] = c;
+            }
+            tab_ok = true;
+        }
+        HostHeader h;
+        while (scan < len) {
+            if (!in_frame) {
+                // search for a frame start
+                if (d[scan] == 0xFF && scan + 1 < len && (d[scan + 1] & 0xFE) == 0xF8) {
+                    if (len - scan < 16 && !final) return;             // need the whole header
+                    if (parse_header(d + scan, len - scan, si, &h)) {
+                        in_frame = true; frame_start = scan; crc = 0;
+                        if (bounds.empty() || bounds.back() != scan) {
+                            bounds.push_back(scan);
+                        }
+                        // consume the header bytes
+                        for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan + i]]);
+                        scan += h.hdr_bytes;
+                        continue;
+                    }
+                }
+                else if (d[scan] == 0xFF && scan + 1 >= len && !final) return;
+                if (errors.empty() || error_pos.back() + 1 != scan || errors.back() != FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC) {
+                    errors.push_back(FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC);
+                    error_pos.push_back(scan);
+                }
+                else error_pos.back() = scan;
+                scan++;
+                continue;
+            }
+            // inside a frame: a boundary candidate is a position where the running CRC is zero and a valid header follows
+            if (crc == 0 && scan >= frame_start + 9 && d[scan] == 0xFF) {
+                if (scan + 1 >= len && !final) return;
+                if (scan + 1 < len && (d[scan + 1] & 0xFE) == 0xF8) {
+                    if (len - scan < 16 && !final) return;
+                    if (parse_header(d + scan, len - scan, si, &h)) {
+                        bounds.push_back(scan);       // closes the current frame, opens the next
+                        frame_start = scan; crc = 0;
+                        for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan + i]]);
+                        scan += h.hdr_bytes;
+                        continue;
+                    }
+                }
+            }
+            crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan]]);
+            scan++;
+        }
+        if (final && in_frame) {
+            // last frame ends at the end of the data (its CRC is checked on the GPU like every other frame)
+            bounds.push_back(len);
+            in_frame = false;
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uint64_t *frame_offsets, uint64_t capacity,
+                                        FLAC__StreamMetadata_StreamInfo *streaminfo, uint64_t *audio_offset)
+{
+    FLAC__StreamMetadata_StreamInfo si;
+    memset(&si, 0, sizeof si);
+    bool have = false;
+    const int64_t a = parse_metadata(stream, len, &si, &have);
+    if (a <= 0) return -1;
+    if (streaminfo) *streaminfo = si;
+    if (audio_offset) *audio_offset = (uint64_t)a;
+    Indexer ix;
+    ix.feed(stream + a, len - a, true, have ? &si : nullptr);
+    const uint64_t nfr = ix.bounds.size() > 0 ? ix.bounds.size() - 1 : 0;
+    if (frame_offsets) {
+        if (ix.bounds.size() > capacity) return -2;
+        for (size_t i = 0; i < ix.bounds.size(); i++) frame_offsets[i] = ix.bounds[i] + (uint64_t)a;
+    }
+    return (int64_t)nfr;
+}
+
+// ------------------------------------------------------------------ batch decode of device-resident frames
+static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
+                               uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
+                               FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)len;
+    memset(st, 0, sizeof *st);
+    if (!HIPOK(hipSetDevice(c->device))) { fg_set_error("hipSetDevice failed"); return false; }
+    st->nframes = nframes;
+    if (nframes == 0) return true;
+    if (channels_hint == 0) { fg_set_error("channel count required"); return false; }
+    const uint32_t npad = (nframes + 63) & ~63u;
+    if (!c->dec_frames.ensure((size_t)npad * sizeof(FgDecFrame)) || !c->dec_results.ensure((size_t)npad * sizeof(FgDecResult)) ||
+        !c->offsets.ensure(((size_t)nframes + 4) * 8))
+        return false;
+    unsigned long long *d_off = (unsigned long long *)c->offsets.p;
+    unsigned long long *d_tot = d_off + nframes + 1;
+    if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, hipMemcpyHostToDevice, c->stream))) { fg_set_error("H2D offsets failed"); return false; }
+    if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
+    if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
+                              (FgDecResult *)c->dec_results.p, d_tot, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
+    unsigned long long tot[2] = {0, 0};
+    if (!HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+        fg_set_error("header pass failed"); return false;
+    }
+    st->total_samples = tot[0];
+    st->max_blocksize = (uint32_t)tot[1];
+    const uint32_t C = channels_hint ? channels_hint : 2;
+    if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
+    if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4)) return false;
+    if (!HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
+    if (fg_launch_decode((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)d_pcm,
+                         (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, (int32_t *)c->dec_scratch.p,
+                         interleave ? 1u : 0u, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+    if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
+    std::vector<FgDecResult> res(nframes);
+    if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
+    if (h_frames) {
+        h_frames->resize(nframes);
+        if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
+    }
+    if (!HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < nframes; i++) if (res[i].err) bad++;
+    st->error_frames = bad;
+    st->channels = C; st->bits_per_sample = bps_hint;
+    if (h_status) memcpy(h_status, res.data(), (size_t)nframes * sizeof(FgDecResult));
+    return true;
+}
+
+extern "C" int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *h_frame_offsets,
+                                     uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
+                                     uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats)
+{
+    flacgpu_decode_stats local;
+    if (!stats) stats = &local;
+    if (!ctx) { fg_set_error("null context"); return -1; }
+    return decode_frames_impl(ctx, d_stream, len, h_frame_offsets, nframes, channels_hint, bps_hint, d_pcm, pcm_capacity_samples, 1,
+                              (FgDecResult *)h_frame_status, nullptr, stats) ? 0 : -1;
+}
+
+// ------------------------------------------------------------------ libFLAC-style stream decoder
+namespace {
+
+struct DecImpl {
+    FLAC__StreamDecoder pub;
+    FLAC__StreamDecoderState state;
+    FLAC__bool md5_checking;
+    FLAC__StreamDecoderReadCallback read_cb;
+    FLAC__StreamDecoderWriteCallback write_cb;
+    FLAC__StreamDecoderMetadataCallback meta_cb;
+    FLAC__StreamDecoderErrorCallback error_cb;
+    void *client;
+    FILE *file;
+    bool own_file;
+    bool respond_streaminfo;
+    flacgpu_ctx *ctx;
+    // stream state
+    std::vector<uint8_t> buf;       // bytes not yet consumed (from `base` on)
+    uint64_t consumed_total;        // stream offset of buf[0]
+    bool eof;
+    bool have_meta, have_si;
+    FLAC__StreamMetadata_StreamInfo si;
+    Indexer ix;
+    size_t errors_reported;
+    uint64_t frames_delivered_bound;  // index into ix.bounds of the next frame to decode
+    uint64_t samples_decoded;
+    // decoded frames waiting for delivery
+    std::vector<int32_t> pcm;         // frame-planar
+    std::vector<FgDecFrame> frames;
+    std::vector<FgDecResult> status;
+    size_t next_frame;
+    uint32_t last_blocksize, last_ca;
+    DevBuf d_stream, d_pcm;
+};
+
+inline DecImpl *impl(FLAC__StreamDecoder *d) { return reinterpret_cast<DecImpl *>(d); }
+inline const DecImpl *impl(const FLAC__StreamDecoder *d) { return reinterpret_cast<const DecImpl *>(d); }
+
+void reset_stream(DecImpl *d)
+{
+    d->buf.clear(); d->consumed_total = 0; d->eof = false; d->have_meta = false; d->have_si = false;
+    memset(&d->si, 0, sizeof d->si);
+    d->ix = Indexer();
+    d->errors_reported = 0; d->frames_delivered_bound = 0; d->samples_decoded = 0;
+    d->pcm.clear(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->last_blocksize = 0; d->last_ca = 0;
+}
+
+// Pull more bytes.  Returns false on abort.  Sets d->eof at end of stream.  `short_read` reports that the
+// callback returned fewer bytes than requested (everything currently available has been delivered).
+bool pull(DecImpl *d, bool *short_read)
+{
+    const size_t want = 1 << 16;
+    const size_t old = d->buf.size();
+    d->buf.resize(old + want);
+    size_t got = want;
+    *short_read = true;
+    if (d->file) {
+        got = fread(d->buf.data() + old, 1, want, d->file);
+        d->buf.resize(old + got);
+        if (got == 0) d->eof = true;
+        *short_read = false;
+        return true;
+    }
+    const FLAC__StreamDecoderReadStatus rs = d->read_cb(&d->pub, d->buf.data() + old, &got, d->client);
+    if (rs == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { d->buf.resize(old); d->state = FLAC__STREAM_DECODER_ABORTED; return false; }
+    if (got > want) got = want;
+    d->buf.resize(old + got);
+    if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || (got == 0 && rs != FLAC__STREAM_DECODER_READ_STATUS_CONTINUE)) d->eof = true;
+    if (got == 0 && rs == FLAC__STREAM_DECODER_READ_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return false; }  // contract violation
+    *short_read = got < want;
+    return true;
+}
+
+void report_errors(DecImpl *d)
+{
+    while (d->errors_reported < d->ix.errors.size()) {
+        if (d->error_cb) d->error_cb(&d->pub, (FLAC__StreamDecoderErrorStatus)d->ix.errors[d->errors_reported], d->client);
+        d->errors_reported++;
+    }
+}
+
+bool ensure_metadata(DecImpl *d)
+{
+    while (!d->have_meta) {
+        const int64_t a = parse_metadata(d->buf.data(), d->buf.size(), &d->si, &d->have_si);
+        if (a < 0) {
+            // libFLAC keeps searching for "fLaC" and reports LOST_SYNC; a stream that never shows it ends in error
+            if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
+            d->buf.clear();
+            if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
+            if (d->state == FLAC__STREAM_DECODER_ABORTED) return false;
+            bool sr;
+            if (!pull(d, &sr)) return false;
+            if (d->eof && d->buf.empty()) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
+            continue;
+        }
+        if (a == 0) {
+            if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
+            bool sr;
+            if (!pull(d, &sr)) return false;
+            continue;
+        }
+        d->have_meta = true;
+        d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+        if (d->meta_cb && d->have_si && d->respond_streaminfo) {
+            FLAC__StreamMetadata m;
+            memset(&m, 0, sizeof m);
+            m.type = FLAC__METADATA_TYPE_STREAMINFO; m.is_last = 0; m.length = 34;
+            m.data.stream_info = d->si;
+            d->meta_cb(&d->pub, &m, d->client);
+        }
+        d->buf.erase(d->buf.begin(), d->buf.begin() + a);
+        d->consumed_total += (uint64_t)a;
+    }
+    return true;
+}
+
+// Decode every complete frame currently delimited in d->buf on the GPU and queue them for delivery.
+bool decode_available(DecImpl *d)
+{
+    const size_t nb = d->ix.bounds.size();
+    if (nb < 2 || d->frames_delivered_bound + 1 >= nb) return true;
+    const uint32_t nframes = (uint32_t)(nb - 1 - d->frames_delivered_bound);
+    const uint64_t first = d->ix.bounds[d->frames_delivered_bound], last = d->ix.bounds[nb - 1];
+    flacgpu_ctx *c = d->ctx;
+    (void)hipSetDevice(c->device);
+    std::vector<uint64_t> offs(nframes + 1);
+    for (uint32_t i = 0; i <= nframes; i++) offs[i] = d->ix.bounds[d->frames_delivered_bound + i] - first;
+    if (!d->d_stream.ensure((size_t)(last - first) + 64)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+    if (!HIPOK(hipMemcpy(d->d_stream.p, d->buf.data() + first, (size_t)(last - first), hipMemcpyHostToDevice))) {
+        d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
+    }
+    const uint32_t C = d->have_si ? d->si.channels : 0;
+    // upper bound of the sample count: 65535 per frame is wasteful; use the STREAMINFO max block size when known
+    uint64_t cap = (uint64_t)nframes * ((d->have_si && d->si.max_blocksize) ? d->si.max_blocksize : 65535);
+    const uint32_t Cb = C ? C : 8;
+    if (!d->d_pcm.ensure((size_t)cap * Cb * 4)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+    flacgpu_decode_stats st;
+    std::vector<FgDecResult> status(nframes);
+    std::vector<FgDecFrame> frames;
+    if (!decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
+                            cap, 0, status.data(), &frames, &st)) {
+        d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
+    }
+    d->pcm.resize((size_t)st.total_samples * (C ? C : 2));
+    if (st.total_samples && !HIPOK(hipMemcpy(d->pcm.data(), d->d_pcm.p, d->pcm.size() * 4, hipMemcpyDeviceToHost))) {
+        d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
+    }
+    d->frames.swap(frames);
+    d->status.swap(status);
+    d->next_frame = 0;
+    d->frames_delivered_bound = nb - 1;
+    return true;
+}
+
+// Deliver one queued frame.  Returns false when the client aborted.
+bool deliver_one(DecImpl *d)
+{
+    const FgDecFrame &fr = d->frames[d->next_frame];
+    const FgDecResult &rs = d->status[d->next_frame];
+    d->next_frame++;
+    if (rs.err == 1) {
+        // header or contents malformed: libFLAC reports and resynchronises without delivering a frame
+        if (d->error_cb) d->error_cb(&d->pub, fr.n ? FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC : FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER, d->client);
+        if (!fr.n) return true;
+    }
+    else if (rs.err == 2) {
+        if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, d->client);
+    }
+    if (rs.err == 1) return true;
+    FLAC__Frame f;
+    memset(&f, 0, sizeof f);
+    f.header.blocksize = fr.n;
+    f.header.sample_rate = d->si.sample_rate;
+    f.header.channels = fr.channels;
+    f.header.channel_assignment = (FLAC__ChannelAssignment)fr.ca;
+    f.header.bits_per_sample = fr.bps;
+    f.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
+    f.header.number.sample_number = d->samples_decoded;
+    f.footer.crc = (FLAC__uint16)rs.crc;
+    const int32_t *chan[8];
+    for (uint32_t c = 0; c < 8; c++) chan[c] = c < fr.channels ? d->pcm.data() + (size_t)fr.out_off * fr.channels + (size_t)c * fr.n : nullptr;
+    d->last_blocksize = fr.n; d->last_ca = fr.ca;
+    d->samples_decoded += fr.n;
+    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+    if (d->write_cb(&d->pub, &f, chan, d->client) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) {
+        d->state = FLAC__STREAM_DECODER_ABORTED;
+        return false;
+    }
+    return true;
+}
+
+// Make progress: after this call either at least one frame is queued, or the stream has ended / aborted.
+bool fill_queue(DecImpl *d)
+{
+    for (;;) {
+        if (d->next_frame < d->frames.size()) return true;
+        if (!ensure_metadata(d)) return false;
+        // drop the bytes of delivered frames
+        if (d->frames_delivered_bound > 0 && !d->ix.bounds.empty()) {
+            const uint64_t cut = d->ix.bounds[d->frames_delivered_bound];
+            if (cut > 0) {
+                d->buf.erase(d->buf.begin(), d->buf.begin() + (size_t)cut);
+                d->consumed_total += cut;
+                std::vector<uint64_t> nbnd;
+                for (size_t i = d->frames_delivered_bound; i < d->ix.bounds.size(); i++) nbnd.push_back(d->ix.bounds[i] - cut);
+                d->ix.bounds.swap(nbnd);
+                d->ix.scan -= cut; d->ix.frame_start -= cut;
+                for (auto &p : d->ix.error_pos) p = p >= cut ? p - cut : 0;
+                d->frames_delivered_bound = 0;
+            }
+        }
+        d->frames.clear(); d->status.clear(); d->next_frame = 0;
+        d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr);
+        report_errors(d);
+        if (d->ix.bounds.size() >= 2 && d->frames_delivered_bound + 1 < d->ix.bounds.size()) {
+            if (!decode_available(d)) return false;
+            if (!d->frames.empty()) return true;
+        }
+        if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
+        // need more data; keep pulling while the callback keeps filling the request (drains what is available)
+        bool short_read = false;
+        if (!pull(d, &short_read)) return false;
+        while (!short_read && !d->eof && d->buf.size() < (64u << 20)) {
+            if (!pull(d, &short_read)) return false;
+        }
+    }
+}
+
+FLAC__StreamDecoderInitStatus init_common(DecImpl *d)
+{
+    d->ctx = fg_default_ctx();
+    if (!d->ctx) return FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR;
+    reset_stream(d);
+    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_METADATA;
+    return FLAC__STREAM_DECODER_INIT_STATUS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
+{
+    DecImpl *d = new DecImpl();
+    d->pub.protected_ = nullptr; d->pub.private_ = nullptr;
+    d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
+    d->md5_checking = 0; d->read_cb = nullptr; d->write_cb = nullptr; d->meta_cb = nullptr; d->error_cb = nullptr;
+    d->client = nullptr; d->file = nullptr; d->own_file = false; d->respond_streaminfo = true; d->ctx = nullptr;
+    reset_stream(d);
+    return &d->pub;
+}
+
+void FLAC__stream_decoder_delete(FLAC__StreamDecoder *dec)
+{
+    if (!dec) return;
+    DecImpl *d = impl(dec);
+    if (d->file && d->own_file) fclose(d->file);
+    if (d->ctx) (void)hipSetDevice(d->ctx->device);
+    d->d_stream.release(); d->d_pcm.release();
+    delete d;
+}
+
+FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *dec, FLAC__bool value)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    d->md5_checking = value;
+    return 1;
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *dec, FLAC__MetadataType type)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    if (type == FLAC__METADATA_TYPE_STREAMINFO) d->respond_streaminfo = true;
+    return 1;
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_application(FLAC__StreamDecoder *dec, const FLAC__byte[4]) { return impl(dec)->state == FLAC__STREAM_DECODER_UNINITIALIZED; }
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    d->respond_streaminfo = true;
+    return 1;
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *dec, FLAC__MetadataType type)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    if (type == FLAC__METADATA_TYPE_STREAMINFO) d->respond_streaminfo = false;
+    return 1;
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_application(FLAC__StreamDecoder *dec, const FLAC__byte[4]) { return impl(dec)->state == FLAC__STREAM_DECODER_UNINITIALIZED; }
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    d->respond_streaminfo = false;
+    return 1;
+}
+
+FLAC__StreamDecoderState FLAC__stream_decoder_get_state(const FLAC__StreamDecoder *dec) { return impl(dec)->state; }
+const char *FLAC__stream_decoder_get_resolved_state_string(const FLAC__StreamDecoder *dec) { return FLAC__StreamDecoderStateString[impl(dec)->state]; }
+FLAC__bool FLAC__stream_decoder_get_md5_checking(const FLAC__StreamDecoder *dec) { return impl(dec)->md5_checking; }
+FLAC__uint64 FLAC__stream_decoder_get_total_samples(const FLAC__StreamDecoder *dec) { return impl(dec)->have_si ? impl(dec)->si.total_samples : 0; }
+uint32_t FLAC__stream_decoder_get_channels(const FLAC__StreamDecoder *dec) { return impl(dec)->si.channels; }
+FLAC__ChannelAssignment FLAC__stream_decoder_get_channel_assignment(const FLAC__StreamDecoder *dec) { return (FLAC__ChannelAssignment)impl(dec)->last_ca; }
+uint32_t FLAC__stream_decoder_get_bits_per_sample(const FLAC__StreamDecoder *dec) { return impl(dec)->si.bits_per_sample; }
+uint32_t FLAC__stream_decoder_get_sample_rate(const FLAC__StreamDecoder *dec) { return impl(dec)->si.sample_rate; }
+uint32_t FLAC__stream_decoder_get_blocksize(const FLAC__StreamDecoder *dec) { return impl(dec)->last_blocksize; }
+FLAC__bool FLAC__stream_decoder_get_decode_position(const FLAC__StreamDecoder *dec, FLAC__uint64 *position)
+{
+    const DecImpl *d = impl(dec);
+    if (!position || !d->file) return 0;
+    *position = d->consumed_total;
+    return 1;
+}
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_stream(FLAC__StreamDecoder *dec, FLAC__StreamDecoderReadCallback read_callback,
+                                                               FLAC__StreamDecoderSeekCallback seek_callback, FLAC__StreamDecoderTellCallback tell_callback,
+                                                               FLAC__StreamDecoderLengthCallback length_callback, FLAC__StreamDecoderEofCallback eof_callback,
+                                                               FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback,
+                                                               FLAC__StreamDecoderErrorCallback error_callback, void *client_data)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+    if (!read_callback || !write_callback || !error_callback || (seek_callback && (!tell_callback || !length_callback || !eof_callback)))
+        return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+    d->read_cb = read_callback; d->write_cb = write_callback; d->meta_cb = metadata_callback; d->error_cb = error_callback;
+    d->client = client_data; d->file = nullptr; d->own_file = false;
+    return init_common(d);
+}
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_stream(FLAC__StreamDecoder *, FLAC__StreamDecoderReadCallback, FLAC__StreamDecoderSeekCallback,
+                                                                   FLAC__StreamDecoderTellCallback, FLAC__StreamDecoderLengthCallback, FLAC__StreamDecoderEofCallback,
+                                                                   FLAC__StreamDecoderWriteCallback, FLAC__StreamDecoderMetadataCallback,
+                                                                   FLAC__StreamDecoderErrorCallback, void *)
+{
+    return FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_FILE(FLAC__StreamDecoder *dec, FILE *file, FLAC__StreamDecoderWriteCallback write_callback,
+                                                             FLAC__StreamDecoderMetadataCallback metadata_callback,
+                                                             FLAC__StreamDecoderErrorCallback error_callback, void *client_data)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+    if (!file || !write_callback || !error_callback) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+    d->read_cb = nullptr; d->write_cb = write_callback; d->meta_cb = metadata_callback; d->error_cb = error_callback;
+    d->client = client_data; d->file = file; d->own_file = false;
+    return init_common(d);
+}
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_FILE(FLAC__StreamDecoder *, FILE *, FLAC__StreamDecoderWriteCallback,
+                                                                 FLAC__StreamDecoderMetadataCallback, FLAC__StreamDecoderErrorCallback, void *)
+{
+    return FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder *dec, const char *filename, FLAC__StreamDecoderWriteCallback write_callback,
+                                                             FLAC__StreamDecoderMetadataCallback metadata_callback,
+                                                             FLAC__StreamDecoderErrorCallback error_callback, void *client_data)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+    if (!write_callback || !error_callback) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+    FILE *f = filename ? fopen(filename, "rb") : stdin;
+    if (!f) return FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE;
+    const FLAC__StreamDecoderInitStatus rc = FLAC__stream_decoder_init_FILE(dec, f, write_callback, metadata_callback, error_callback, client_data);
+    if (rc == FLAC__STREAM_DECODER_INIT_STATUS_OK) d->own_file = (f != stdin);
+    else if (f != stdin) fclose(f);
+    return rc;
+}
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_file(FLAC__StreamDecoder *, const char *, FLAC__StreamDecoderWriteCallback,
+                                                                 FLAC__StreamDecoderMetadataCallback, FLAC__StreamDecoderErrorCallback, void *)
+{
+    return FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+
+FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 1;
+    if (d->file) { if (d->own_file) fclose(d->file); d->file = nullptr; }
+    reset_stream(d);
+    d->md5_checking = 0; d->respond_streaminfo = true;
+    d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
+    return 1;
+}
+FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    d->buf.clear(); d->ix = Indexer(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
+    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+    return 1;
+}
+FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    if (d->file) { if (fseek(d->file, 0, SEEK_SET) != 0) return 0; }
+    reset_stream(d);
+    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_METADATA;
+    return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_process_single(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    if (d->state == FLAC__STREAM_DECODER_END_OF_STREAM) return 1;
+    if (d->state == FLAC__STREAM_DECODER_ABORTED) return 0;
+    if (!d->have_meta) {
+        if (!ensure_metadata(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
+        return 1;                                    // one call consumes the metadata, like libFLAC
+    }
+    if (!fill_queue(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
+    return deliver_one(d) ? 1 : 0;
+}
+
+FLAC__bool FLAC__stream_decoder_process_until_end_of_metadata(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    if (d->have_meta) return 1;
+    if (!ensure_metadata(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
+    return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_process_until_end_of_stream(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    for (;;) {
+        if (d->state == FLAC__STREAM_DECODER_END_OF_STREAM) return 1;
+        if (d->state == FLAC__STREAM_DECODER_ABORTED) return 0;
+        if (!fill_queue(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
+        while (d->next_frame < d->frames.size())
+            if (!deliver_one(d)) return 0;
+    }
+}
+
+FLAC__bool FLAC__stream_decoder_skip_single_frame(FLAC__StreamDecoder *dec)
+{
+    DecImpl *d = impl(dec);
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    if (!d->have_meta) return FLAC__stream_decoder_process_single(dec);
+    if (!fill_queue(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
+    d->samples_decoded += d->frames[d->next_frame].n;
+    d->next_frame++;
+    return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *dec, FLAC__uint64)
+{
+    // pyFLAC declares but never calls seek; without seek callbacks libFLAC fails the same way
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) d->state = FLAC__STREAM_DECODER_SEEK_ERROR;
+    return 0;
+}
+
+}  // extern "C"

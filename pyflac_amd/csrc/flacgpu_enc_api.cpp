@@ -1,0 +1,598 @@
+// flacgpu_enc_api.cpp -- the libFLAC stream-encoder entry points pyFLAC binds
+// (reference: pyflac/builder/encoder.py:266-322), backed by the HIP frame encoder.
+//
+// Host responsibilities: input buffering with libFLAC's
+// blocksize+1 look-ahead, the fLaC/STREAMINFO/VORBIS_COMMENT header, frame-size statistics, MD5 of the
+// raw PCM, callback delivery in stream order.  Every frame byte is produced on the GPU; there is no CPU
+// fallback: without a HIP device init_stream/init_file fail with ENCODER_ERROR.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+
+#include "fg_host.h"
+
+extern "C" {
+const char *FLAC__VERSION_STRING = "1.4.3";
+const char *FLAC__VENDOR_STRING = "reference libFLAC 1.4.3 20230623";   // byte-exact VORBIS_COMMENT parity
+
+const char *const FLAC__StreamEncoderStateString[] = {
+    "FLAC__STREAM_ENCODER_OK", "FLAC__STREAM_ENCODER_UNINITIALIZED", "FLAC__STREAM_ENCODER_OGG_ERROR",
+    "FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR", "FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA",
+    "FLAC__STREAM_ENCODER_CLIENT_ERROR", "FLAC__STREAM_ENCODER_IO_ERROR", "FLAC__STREAM_ENCODER_FRAMING_ERROR",
+    "FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR"};
+const char *const FLAC__StreamEncoderInitStatusString[] = {
+    "FLAC__STREAM_ENCODER_INIT_STATUS_OK", "FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR",
+    "FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS",
+    "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE",
+    "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE",
+    "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION",
+    "FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE",
+    "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA", "FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED"};
+}
+
+// ------------------------------------------------------------------ MD5 / CRC on the host
+static const uint32_t MD5_K[64] = {
+    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+    0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+    0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+    0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+    0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+    0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+    0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+    0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+static const uint8_t MD5_S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9,
+                                  14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
+                                  4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+static void md5_block(FgMd5 *m, const uint8_t *p)
+{
+    uint32_t w[16];
+    memcpy(w, p, 64);   // little-endian host
+    uint32_t a = m->a, b = m->b, c = m->c, d = m->d;
+    for (uint32_t i = 0; i < 64; i++) {
+        uint32_t f, g;
+        if (i < 16) { f = (b & c) | (~b & d); g = i; }
+        else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+        else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+        else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+        const uint32_t t = a + f + MD5_K[i] + w[g];
+        a = d; d = c; c = b;
+        b = b + ((t << MD5_S[i]) | (t >> (32 - MD5_S[i])));
+    }
+    m->a += a; m->b += b; m->c += c; m->d += d;
+}
+void FgMd5::init() { a = 0x67452301; b = 0xefcdab89; c = 0x98badcfe; d = 0x10325476; len = 0; fill = 0; }
+void FgMd5::update(const uint8_t *p, size_t n)
+{
+    len += n;
+    if (fill) {
+        size_t k = std::min<size_t>(64 - fill, n);
+        memcpy(buf + fill, p, k);
+        fill += (uint32_t)k; p += k; n -= k;
+        if (fill == 64) { md5_block(this, buf); fill = 0; }
+    }
+    while (n >= 64) { md5_block(this, p); p += 64; n -= 64; }
+    if (n) { memcpy(buf, p, n); fill = (uint32_t)n; }
+}
+void FgMd5::final(uint8_t out[16])
+{
+    const uint64_t bits = len * 8;
+    uint8_t pad[72];
+    memset(pad, 0, sizeof pad);
+    pad[0] = 0x80;
+    const size_t padlen = (fill < 56) ? (56 - fill) : (120 - fill);
+    update(pad, padlen);
+    uint8_t l[8];
+    for (int i = 0; i < 8; i++) l[i] = (uint8_t)(bits >> (8 * i));
+    update(l, 8);
+    const uint32_t v[4] = {a, b, c, d};
+    memcpy(out, v, 16);
+}
+void FgMd5::update_pcm(const int32_t *x, uint64_t nvalues, uint32_t bps)
+{
+    // little-endian, (bps+7)/8 bytes per sample, interleaved
+    const uint32_t bytes = (bps + 7) / 8;
+    uint8_t tmp[4096 + 8];
+    size_t f = 0;
+    if (bytes == 2) {
+        for (uint64_t i = 0; i < nvalues; i++) {
+            const uint32_t v = (uint32_t)x[i];
+            tmp[f] = (uint8_t)v; tmp[f + 1] = (uint8_t)(v >> 8); f += 2;
+            if (f >= 4096) { update(tmp, f); f = 0; }
+        }
+    }
+    else {
+        for (uint64_t i = 0; i < nvalues; i++) {
+            const uint32_t v = (uint32_t)x[i];
+            for (uint32_t b = 0; b < bytes; b++) tmp[f++] = (uint8_t)(v >> (8 * b));
+            if (f >= 4096) { update(tmp, f); f = 0; }
+        }
+    }
+    update(tmp, f);
+}
+
+static uint8_t g_crc8[256];
+static uint16_t g_crc16[256];
+static std::once_flag g_crc_once;
+static void crc_tables()
+{
+    for (int i = 0; i < 256; i++) {
+        uint8_t c = (uint8_t)i;
+        for (int b = 0; b < 8; b++) c = (uint8_t)((c & 0x80) ? ((c << 1) ^ 0x07) : (c << 1));
+        g_crc8[i] = c;
+        uint16_t d = (uint16_t)(i << 8);
+        for (int b = 0; b < 8; b++) d = (uint16_t)((d & 0x8000) ? ((d << 1) ^ 0x8005) : (d << 1));
+        g_crc16[i] = d;
+    }
+}
+uint8_t fg_crc8(const uint8_t *p, size_t n)
+{
+    std::call_once(g_crc_once, crc_tables);
+    uint8_t c = 0;
+    while (n--) c = g_crc8[c ^ *p++];
+    return c;
+}
+uint16_t fg_crc16(const uint8_t *p, size_t n)
+{
+    std::call_once(g_crc_once, crc_tables);
+    uint16_t c = 0;
+    while (n--) c = (uint16_t)((c << 8) ^ g_crc16[(c >> 8) ^ *p++]);
+    return c;
+}
+
+// ------------------------------------------------------------------ encoder object
+namespace {
+
+struct EncImpl {
+    FLAC__StreamEncoder pub;   // must be first: the handle pyFLAC holds points here
+    FLAC__StreamEncoderState state;
+    // settings as the setters leave them
+    FLAC__bool verify, streamable_subset, do_md5, limit_min_bitrate;
+    uint32_t channels, bps, sample_rate, blocksize;
+    FLAC__bool do_mid_side, loose_mid_side;
+    uint32_t apod_parts;
+    bool apod_supported;
+    uint32_t max_lpc_order, qlp_precision;
+    FLAC__bool prec_search, escape_coding, exhaustive;
+    uint32_t min_po, max_po, rice_dist;
+    uint64_t total_estimate;
+    // run state
+    flacgpu_settings s;
+    flacgpu_ctx *ctx;
+    FLAC__StreamEncoderWriteCallback write_cb;
+    FLAC__StreamEncoderSeekCallback seek_cb;
+    FLAC__StreamEncoderTellCallback tell_cb;
+    FLAC__StreamEncoderMetadataCallback meta_cb;
+    FLAC__StreamEncoderProgressCallback progress_cb;
+    void *client;
+    FILE *file;
+    bool own_file;
+    uint64_t bytes_written;
+    std::vector<int32_t> pending;   // interleaved samples not yet encoded
+    uint32_t frame_number;
+    uint64_t samples_done;
+    uint32_t min_frame, max_frame;
+    FgMd5 md5;
+    std::vector<uint8_t> hbuf;      // host copy of encoded frames
+    std::vector<uint64_t> hoffs;
+    DevBuf d_pcm, d_out, d_offs;    // per-encoder device staging
+};
+
+void set_defaults(EncImpl *e)
+{
+    e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1; e->limit_min_bitrate = 0;
+    e->channels = 2; e->bps = 16; e->sample_rate = 44100; e->blocksize = 0;
+    e->total_estimate = 0;
+    e->prec_search = 0; e->escape_coding = 0; e->exhaustive = 0; e->rice_dist = 0; e->qlp_precision = 0;
+    e->apod_supported = true;
+    // compression level 5 (stream_encoder.h:850)
+    e->do_mid_side = 1; e->loose_mid_side = 0; e->apod_parts = 0; e->max_lpc_order = 8; e->min_po = 0; e->max_po = 5;
+    e->write_cb = nullptr; e->seek_cb = nullptr; e->tell_cb = nullptr; e->meta_cb = nullptr; e->progress_cb = nullptr;
+    e->client = nullptr; e->file = nullptr; e->own_file = false;
+}
+
+inline EncImpl *impl(FLAC__StreamEncoder *e) { return reinterpret_cast<EncImpl *>(e); }
+inline const EncImpl *impl(const FLAC__StreamEncoder *e) { return reinterpret_cast<const EncImpl *>(e); }
+
+bool emit(EncImpl *e, const uint8_t *p, size_t n, uint32_t samples, uint32_t frame)
+{
+    if (e->file) {
+        if (fwrite(p, 1, n, e->file) != n) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return false; }
+    }
+    else if (e->write_cb(&e->pub, p, n, samples, frame, e->client) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) {
+        e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+        return false;
+    }
+    e->bytes_written += n;
+    return true;
+}
+
+size_t build_header(const EncImpl *e, uint8_t *out, uint32_t minf, uint32_t maxf, uint64_t total, const uint8_t *md5)
+{
+    // fLaC + STREAMINFO (format.h:536-557) + VORBIS_COMMENT with the vendor string only
+    const flacgpu_settings &s = e->s;
+    uint8_t *p = out;
+    memcpy(p, "fLaC", 4); p += 4;
+    *p++ = 0x00; *p++ = 0; *p++ = 0; *p++ = 34;
+    *p++ = (uint8_t)(s.blocksize >> 8); *p++ = (uint8_t)s.blocksize;
+    *p++ = (uint8_t)(s.blocksize >> 8); *p++ = (uint8_t)s.blocksize;
+    *p++ = (uint8_t)(minf >> 16); *p++ = (uint8_t)(minf >> 8); *p++ = (uint8_t)minf;
+    *p++ = (uint8_t)(maxf >> 16); *p++ = (uint8_t)(maxf >> 8); *p++ = (uint8_t)maxf;
+    const uint64_t v = ((uint64_t)s.sample_rate << 44) | ((uint64_t)(s.channels - 1) << 41) |
+                       ((uint64_t)(s.bits_per_sample - 1) << 36) | (total & 0xFFFFFFFFFull);
+    for (int i = 7; i >= 0; i--) *p++ = (uint8_t)(v >> (8 * i));
+    if (md5) memcpy(p, md5, 16); else memset(p, 0, 16);
+    p += 16;
+    const uint32_t vl = (uint32_t)strlen(FLAC__VENDOR_STRING);
+    *p++ = 0x84; *p++ = 0; *p++ = 0; *p++ = (uint8_t)(8 + vl);
+    *p++ = (uint8_t)vl; *p++ = (uint8_t)(vl >> 8); *p++ = (uint8_t)(vl >> 16); *p++ = (uint8_t)(vl >> 24);
+    memcpy(p, FLAC__VENDOR_STRING, vl); p += vl;
+    memset(p, 0, 4); p += 4;
+    return (size_t)(p - out);
+}
+
+FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
+{
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+    flacgpu_settings &s = e->s;
+    memset(&s, 0, sizeof s);
+    s.channels = e->channels; s.bits_per_sample = e->bps; s.sample_rate = e->sample_rate; s.blocksize = e->blocksize;
+    s.do_mid_side = e->do_mid_side; s.loose_mid_side = e->loose_mid_side; s.max_lpc_order = e->max_lpc_order;
+    s.qlp_coeff_precision = e->qlp_precision; s.min_partition_order = e->min_po; s.max_partition_order = e->max_po;
+    s.apod_parts = e->apod_parts; s.streamable_subset = e->streamable_subset;
+    const int rc = fg_resolve_settings(&s);
+    if (rc != 0) return (FLAC__StreamEncoderInitStatus)rc;
+    // settings libFLAC accepts but this GPU core does not implement are refused loudly (out of scope)
+    if (e->prec_search || e->exhaustive || e->escape_coding || !e->apod_supported || s.max_partition_order > 8 || s.apod_parts > 3) {
+        fg_set_error("setting not supported by the GPU encoder");
+        return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+    }
+    e->ctx = fg_default_ctx();
+    if (!e->ctx) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+    FgEncParams P;
+    fg_fill_params(s, s.blocksize, false, false, &P);
+    if (fg_enc_lds_bytes(&P) > 160 * 1024) {
+        fg_set_error("blocksize too large for the LDS-staged GPU encoder");
+        return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+    }
+    e->blocksize = s.blocksize; e->qlp_precision = s.qlp_coeff_precision; e->do_mid_side = s.do_mid_side;
+    e->loose_mid_side = s.loose_mid_side; e->min_po = s.min_partition_order; e->max_po = s.max_partition_order;
+    e->pending.clear();
+    e->frame_number = 0; e->samples_done = 0; e->min_frame = 0; e->max_frame = 0; e->bytes_written = 0;
+    e->md5.init();
+    e->state = FLAC__STREAM_ENCODER_OK;
+    // three metadata writes: "fLaC", STREAMINFO, VORBIS_COMMENT (stream_encoder.h:1484-1486)
+    uint8_t hdr[128];
+    const size_t hl = build_header(e, hdr, 0, 0, 0, nullptr);
+    if (!emit(e, hdr, 4, 0, 0) || !emit(e, hdr + 4, 38, 0, 0) || !emit(e, hdr + 42, hl - 42, 0, 0)) {
+        e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+        return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+    }
+    return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
+}
+
+// Encode `nblocks_full` complete blocks (and, if last, the remaining partial block) from e->pending.
+bool encode_pending(EncImpl *e, bool flush_all)
+{
+    const uint32_t C = e->s.channels, bs = e->s.blocksize;
+    const uint64_t have = e->pending.size() / C;
+    uint64_t take;
+    if (flush_all) take = have;
+    else take = have >= 1 ? ((have - 1) / bs) * bs : 0;   // libFLAC emits a frame once blocksize+1 samples are buffered
+    if (take == 0) return true;
+    flacgpu_ctx *c = e->ctx;
+    (void)hipSetDevice(c->device);
+    const size_t pcm_bytes = (size_t)take * C * 4;
+    flacgpu_stream_desc sd;
+    sd.pcm_offset = 0; sd.nsamples = take; sd.first_frame = e->frame_number; sd.reserved = 0;
+    uint32_t nblocks = 0;
+    const uint64_t bound = flacgpu_encode_bound(&e->s, &sd, 1, &nblocks);
+    if (!e->d_pcm.ensure(pcm_bytes) || !e->d_out.ensure(bound) || !e->d_offs.ensure(((size_t)nblocks + 1) * 8)) {
+        e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false;
+    }
+    if (hipMemcpy(e->d_pcm.p, e->pending.data(), pcm_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false;
+    }
+    // MD5 of the consumed PCM on a helper thread while the GPU encodes
+    std::thread md5t;
+    if (e->do_md5) md5t = std::thread([&] { e->md5.update_pcm(e->pending.data(), take * C, e->s.bits_per_sample); });
+    flacgpu_encode_stats st;
+    const int rc = flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, e->d_out.p, e->d_out.cap, e->d_offs.p, &st);
+    bool ok = rc == 0;
+    if (ok && st.error_flags) {
+        ok = false;
+        e->state = (st.error_flags & FG_ERR_RANGE) ? FLAC__STREAM_ENCODER_CLIENT_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+        if (st.error_flags & FG_ERR_SIDE33) fg_set_error("32-bit stereo input needs a 33-bit side channel: not supported");
+    }
+    else if (!ok) e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
+    if (ok) {
+        e->hbuf.resize(st.total_bytes);
+        e->hoffs.resize((size_t)st.nblocks + 1);
+        if (hipMemcpy(e->hbuf.data(), e->d_out.p, st.total_bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(e->hoffs.data(), e->d_offs.p, ((size_t)st.nblocks + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            ok = false; e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR;
+        }
+    }
+    if (md5t.joinable()) md5t.join();
+    if (!ok) return false;
+    uint64_t pos = 0;
+    for (uint32_t b = 0; b < st.nblocks; b++) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(bs, take - pos);
+        const uint32_t fb = (uint32_t)(e->hoffs[b + 1] - e->hoffs[b]);
+        if (!emit(e, e->hbuf.data() + e->hoffs[b], fb, n, e->frame_number)) return false;
+        if (e->min_frame == 0 || fb < e->min_frame) e->min_frame = fb;
+        if (fb > e->max_frame) e->max_frame = fb;
+        e->frame_number++;
+        e->samples_done += n;
+        pos += n;
+        if (e->progress_cb) {
+            const uint32_t est = e->total_estimate ? (uint32_t)((e->total_estimate + bs - 1) / bs) : 0;
+            e->progress_cb(&e->pub, e->bytes_written, e->samples_done, e->frame_number, est, e->client);
+        }
+    }
+    e->pending.erase(e->pending.begin(), e->pending.begin() + (size_t)take * C);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
+{
+    EncImpl *e = new EncImpl();
+    e->pub.protected_ = nullptr; e->pub.private_ = nullptr;
+    e->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
+    e->ctx = nullptr;
+    set_defaults(e);
+    return &e->pub;
+}
+
+void FLAC__stream_encoder_delete(FLAC__StreamEncoder *enc)
+{
+    if (!enc) return;
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) {
+        // tolerate un-finished instances (GC finaliser, any thread): drop buffered data silently
+        if (e->file && e->own_file) fclose(e->file);
+    }
+    if (e->ctx) (void)hipSetDevice(e->ctx->device);
+    e->d_pcm.release(); e->d_out.release(); e->d_offs.release();
+    delete e;
+}
+
+#define SETTER(name, field, type)                                                            \
+    FLAC__bool FLAC__stream_encoder_set_##name(FLAC__StreamEncoder *enc, type value)          \
+    {                                                                                         \
+        EncImpl *e = impl(enc);                                                               \
+        if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;                         \
+        e->field = value;                                                                     \
+        return 1;                                                                             \
+    }
+SETTER(verify, verify, FLAC__bool)
+SETTER(channels, channels, uint32_t)
+SETTER(bits_per_sample, bps, uint32_t)
+SETTER(sample_rate, sample_rate, uint32_t)
+SETTER(blocksize, blocksize, uint32_t)
+SETTER(do_mid_side_stereo, do_mid_side, FLAC__bool)
+SETTER(loose_mid_side_stereo, loose_mid_side, FLAC__bool)
+SETTER(max_lpc_order, max_lpc_order, uint32_t)
+SETTER(qlp_coeff_precision, qlp_precision, uint32_t)
+SETTER(do_qlp_coeff_prec_search, prec_search, FLAC__bool)
+SETTER(do_exhaustive_model_search, exhaustive, FLAC__bool)
+SETTER(min_residual_partition_order, min_po, uint32_t)
+SETTER(max_residual_partition_order, max_po, uint32_t)
+SETTER(rice_parameter_search_dist, rice_dist, uint32_t)
+SETTER(streamable_subset, streamable_subset, FLAC__bool)
+SETTER(limit_min_bitrate, limit_min_bitrate, FLAC__bool)
+SETTER(do_md5, do_md5, FLAC__bool)
+
+FLAC__bool FLAC__stream_encoder_set_total_samples_estimate(FLAC__StreamEncoder *enc, FLAC__uint64 value)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+    e->total_estimate = value < ((1ull << 36) - 1) ? value : ((1ull << 36) - 1);
+    return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *enc, uint32_t value)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+    flacgpu_settings s;
+    flacgpu_settings_from_level(&s, value, 2, 16, 44100, 4096, 0);   // only the preset columns are used
+    static const uint32_t parts[9] = {0, 0, 0, 0, 0, 0, 2, 2, 3};
+    static const uint32_t ms[9] = {0, 1, 1, 0, 1, 1, 1, 1, 1}, loose[9] = {0, 1, 0, 0, 1, 0, 0, 0, 0};
+    const uint32_t lv = value > 8 ? 8 : value;
+    e->do_mid_side = ms[lv]; e->loose_mid_side = loose[lv]; e->apod_parts = parts[lv]; e->apod_supported = true;
+    e->max_lpc_order = s.max_lpc_order; e->qlp_precision = 0; e->prec_search = 0; e->escape_coding = 0; e->exhaustive = 0;
+    e->min_po = 0;
+    static const uint32_t maxpo[9] = {3, 3, 3, 4, 4, 5, 6, 6, 6};
+    e->max_po = maxpo[lv];
+    e->rice_dist = 0;
+    return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_set_apodization(FLAC__StreamEncoder *enc, const char *spec)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+    // the level presets only use tukey(5e-1) and subdivide_tukey(N); anything else is refused at init
+    if (!spec) return 0;
+    if (!strcmp(spec, "tukey(5e-1)") || !strcmp(spec, "tukey(0.5)")) { e->apod_parts = 0; e->apod_supported = true; }
+    else if (!strncmp(spec, "subdivide_tukey(", 16)) {
+        const int n = atoi(spec + 16);
+        e->apod_parts = (n >= 2) ? (uint32_t)n : 0;
+        e->apod_supported = n >= 1 && strchr(spec, '/') == nullptr && strchr(spec, ';') == nullptr;
+    }
+    else e->apod_supported = false;
+    return 1;
+}
+
+FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *enc) { return impl(enc)->state; }
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *enc)
+{
+    return FLAC__StreamEncoderStateString[impl(enc)->state];
+}
+void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *, FLAC__uint64 *absolute_sample, uint32_t *frame_number,
+                                                         uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got)
+{
+    if (absolute_sample) *absolute_sample = 0;
+    if (frame_number) *frame_number = 0;
+    if (channel) *channel = 0;
+    if (sample) *sample = 0;
+    if (expected) *expected = 0;
+    if (got) *got = 0;
+}
+#define GETTER(name, field, type) \
+    type FLAC__stream_encoder_get_##name(const FLAC__StreamEncoder *enc) { return (type)impl(enc)->field; }
+GETTER(verify, verify, FLAC__bool)
+GETTER(streamable_subset, streamable_subset, FLAC__bool)
+GETTER(channels, channels, uint32_t)
+GETTER(bits_per_sample, bps, uint32_t)
+GETTER(sample_rate, sample_rate, uint32_t)
+GETTER(blocksize, blocksize, uint32_t)
+GETTER(do_mid_side_stereo, do_mid_side, FLAC__bool)
+GETTER(loose_mid_side_stereo, loose_mid_side, FLAC__bool)
+GETTER(max_lpc_order, max_lpc_order, uint32_t)
+GETTER(qlp_coeff_precision, qlp_precision, uint32_t)
+GETTER(do_qlp_coeff_prec_search, prec_search, FLAC__bool)
+GETTER(do_escape_coding, escape_coding, FLAC__bool)
+GETTER(do_exhaustive_model_search, exhaustive, FLAC__bool)
+GETTER(min_residual_partition_order, min_po, uint32_t)
+GETTER(max_residual_partition_order, max_po, uint32_t)
+GETTER(rice_parameter_search_dist, rice_dist, uint32_t)
+GETTER(total_samples_estimate, total_estimate, FLAC__uint64)
+GETTER(limit_min_bitrate, limit_min_bitrate, FLAC__bool)
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *enc, FLAC__StreamEncoderWriteCallback write_callback,
+                                                               FLAC__StreamEncoderSeekCallback seek_callback,
+                                                               FLAC__StreamEncoderTellCallback tell_callback,
+                                                               FLAC__StreamEncoderMetadataCallback metadata_callback, void *client_data)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+    if (!write_callback || (seek_callback && !tell_callback)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS;
+    e->write_cb = write_callback; e->seek_cb = seek_callback; e->tell_cb = tell_callback; e->meta_cb = metadata_callback;
+    e->progress_cb = nullptr; e->client = client_data; e->file = nullptr; e->own_file = false;
+    return init_common(e);
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamEncoder *, FLAC__StreamEncoderReadCallback, FLAC__StreamEncoderWriteCallback,
+                                                                   FLAC__StreamEncoderSeekCallback, FLAC__StreamEncoderTellCallback,
+                                                                   FLAC__StreamEncoderMetadataCallback, void *)
+{
+    return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;   // as the reference build: FLAC_API_SUPPORTS_OGG_FLAC == 0
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_FILE(FLAC__StreamEncoder *enc, FILE *file, FLAC__StreamEncoderProgressCallback progress_callback,
+                                                             void *client_data)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+    if (!file) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+    e->write_cb = nullptr; e->seek_cb = nullptr; e->tell_cb = nullptr; e->meta_cb = nullptr;
+    e->progress_cb = progress_callback; e->client = client_data; e->file = file; e->own_file = false;
+    FLAC__StreamEncoderInitStatus rc = init_common(e);
+    if (rc != FLAC__STREAM_ENCODER_INIT_STATUS_OK) e->file = nullptr;
+    return rc;
+}
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_FILE(FLAC__StreamEncoder *, FILE *, FLAC__StreamEncoderProgressCallback, void *)
+{
+    return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder *enc, const char *filename,
+                                                             FLAC__StreamEncoderProgressCallback progress_callback, void *client_data)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+    FILE *f = filename ? fopen(filename, "w+b") : stdout;
+    if (!f) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+    FLAC__StreamEncoderInitStatus rc = FLAC__stream_encoder_init_FILE(enc, f, progress_callback, client_data);
+    if (rc == FLAC__STREAM_ENCODER_INIT_STATUS_OK) e->own_file = (f != stdout);
+    else if (f != stdout) fclose(f);
+    return rc;
+}
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_file(FLAC__StreamEncoder *, const char *, FLAC__StreamEncoderProgressCallback, void *)
+{
+    return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+
+FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *enc, const FLAC__int32 buffer[], uint32_t samples)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_OK) return 0;
+    const size_t nv = (size_t)samples * e->s.channels;
+    e->pending.insert(e->pending.end(), buffer, buffer + nv);
+    return encode_pending(e, false) ? 1 : 0;
+}
+
+FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *enc, const FLAC__int32 *const buffer[], uint32_t samples)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_OK) return 0;
+    const uint32_t C = e->s.channels;
+    const size_t base = e->pending.size();
+    e->pending.resize(base + (size_t)samples * C);
+    for (uint32_t i = 0; i < samples; i++)
+        for (uint32_t c = 0; c < C; c++) e->pending[base + (size_t)i * C + c] = buffer[c][i];
+    return encode_pending(e, false) ? 1 : 0;
+}
+
+FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *enc)
+{
+    EncImpl *e = impl(enc);
+    if (e->state == FLAC__STREAM_ENCODER_UNINITIALIZED) return 1;
+    bool error = false;
+    if (e->state == FLAC__STREAM_ENCODER_OK) {
+        if (!e->pending.empty() && !encode_pending(e, true)) error = true;
+    }
+    if (e->state == FLAC__STREAM_ENCODER_OK || !error) {
+        uint8_t md5[16];
+        memset(md5, 0, sizeof md5);
+        if (e->do_md5) e->md5.final(md5);
+        uint8_t hdr[128];
+        build_header(e, hdr, e->min_frame, e->max_frame, e->samples_done, md5);
+        if (e->file) {
+            // rewrite STREAMINFO in place (file and stream outputs differ only in these bytes)
+            if (fseek(e->file, 8, SEEK_SET) == 0) {
+                if (fwrite(hdr + 8, 1, 34, e->file) != 34) error = true;
+                fseek(e->file, 0, SEEK_END);
+            }
+        }
+        else if (e->seek_cb && e->state == FLAC__STREAM_ENCODER_OK) {
+            // libFLAC's update_metadata_: MD5 (offset 26), total samples (offset 21, 5 bytes, keeping the
+            // bits-per-sample nibble), min/max frame size (offset 12), each a seek + write
+            struct { uint64_t off; size_t len; } pieces[3] = {{26, 16}, {21, 5}, {12, 6}};
+            for (int i = 0; i < 3 && !error; i++) {
+                if (e->seek_cb(&e->pub, pieces[i].off, e->client) != FLAC__STREAM_ENCODER_SEEK_STATUS_OK) { error = true; break; }
+                if (e->write_cb(&e->pub, hdr + pieces[i].off, pieces[i].len, 0, 0, e->client) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) error = true;
+            }
+            if (error) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+        }
+        if (e->meta_cb && e->state == FLAC__STREAM_ENCODER_OK) {
+            FLAC__StreamMetadata m;
+            memset(&m, 0, sizeof m);
+            m.type = FLAC__METADATA_TYPE_STREAMINFO; m.is_last = 0; m.length = 34;
+            FLAC__StreamMetadata_StreamInfo &si = m.data.stream_info;
+            si.min_blocksize = si.max_blocksize = e->s.blocksize;
+            si.min_framesize = e->min_frame; si.max_framesize = e->max_frame;
+            si.sample_rate = e->s.sample_rate; si.channels = e->s.channels; si.bits_per_sample = e->s.bits_per_sample;
+            si.total_samples = e->samples_done;
+            memcpy(si.md5sum, md5, 16);
+            e->meta_cb(&e->pub, &m, e->client);
+        }
+    }
+    if (e->file) {
+        if (e->own_file) fclose(e->file); else fflush(e->file);
+        e->file = nullptr;
+    }
+    const bool failed = error || (e->state != FLAC__STREAM_ENCODER_OK);
+    e->pending.clear(); e->pending.shrink_to_fit();
+    set_defaults(e);                         // finish resets every setting (stream_encoder.h:225-227)
+    e->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
+    return failed ? 0 : 1;
+}
+
+}  // extern "C"

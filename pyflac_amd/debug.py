@@ -1,0 +1,16 @@
+"""ctypes mirror of FgDebugRec (pyflac_amd/csrc/fg_types.h) for stage-level parity tests."""
+import ctypes as C
+
+
+class DebugCand(C.Structure):
+    _fields_ = [('wasted', C.c_uint32), ('sbps', C.c_uint32), ('fixed_tot', C.c_uint64 * 5),
+                ('fixed_guess', C.c_uint32), ('fixed_bits', C.c_uint32), ('nvec', C.c_uint32), ('pad0', C.c_uint32),
+                ('lpc_guess', C.c_uint32 * 16), ('lpc_bits', C.c_uint32 * 16),
+                ('autoc', (C.c_double * 33) * 16), ('type', C.c_uint32), ('order', C.c_uint32),
+                ('precision', C.c_uint32), ('shift', C.c_int32), ('qlp', C.c_int32 * 32),
+                ('rice_method', C.c_uint32), ('porder', C.c_uint32), ('bits', C.c_uint32), ('pad1', C.c_uint32),
+                ('rice_params', C.c_uint32 * 256)]
+
+
+class DebugRec(C.Structure):
+    _fields_ = [('cand', DebugCand * 4)]
