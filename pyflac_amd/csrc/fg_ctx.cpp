@@ -226,6 +226,7 @@ void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, boo
     P->nvec = nvec;
     P->pcm_i16 = pcm_i16 ? 1 : 0;
     P->debug = debug ? 1 : 0;
+    if (getenv("FLACGPU_STOP")) P->debug = 100 + atoi(getenv("FLACGPU_STOP"));
     const uint32_t mo = s.max_lpc_order ? s.max_lpc_order : 1;
     uint32_t dbuf = 4 * (FG_DH + FG_DK) * 8;
     const uint32_t lev = FG_MAX_CAND * nvec * mo * 12 + 64;
@@ -288,6 +289,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             d.frame_number = fn++;
             d.win_off = s->max_lpc_order ? c->window_offset(d.n, s->apod_parts) : 0;
             d.forced_ca = 0xFF;
+            d.out_slot = (uint32_t)descs.size();
+            d.reserved = 0;
             descs.push_back(d);
             pos += d.n;
         }
@@ -323,7 +326,11 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             size_t bi = 0;
             for (uint32_t i = 0; i < nstreams; i++) {
                 const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
-                for (uint64_t k = 0; k < cnt; k += period) { dec.push_back(descs[bi + k]); decidx.push_back((uint32_t)(bi + k)); }
+                for (uint64_t k = 0; k < cnt; k += period) {
+                    FgBlockDesc pd = descs[bi + k];
+                    pd.out_slot = (uint32_t)dec.size();
+                    dec.push_back(pd); decidx.push_back((uint32_t)(bi + k));
+                }
                 bi += cnt;
             }
             // loose mode compares only independent vs mid/side on decision frames
@@ -364,8 +371,37 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
         }
     }
+    // blocks the specialised kernel covers go first, the rest to the generic kernel (same bytes either way)
+    uint32_t nfast = 0;
+    {
+        const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
+        std::vector<FgBlockDesc> ordered;
+        ordered.reserve(nblocks);
+        std::vector<FgBlockDesc> slow;
+        for (const FgBlockDesc &d : descs) {
+            bool fast = cfg_fast && d.n >= 64 && (d.n & 63) == 0;
+            if (fast) {
+                uint32_t pm = 0, b = d.n;
+                while (!(b & 1)) { pm++; b >>= 1; }
+                if (pm > s->max_partition_order) pm = s->max_partition_order;
+                if (((d.n >> pm) & 63) != 0) fast = false;
+            }
+            if (fast) ordered.push_back(d); else slow.push_back(d);
+        }
+        nfast = (uint32_t)ordered.size();
+        ordered.insert(ordered.end(), slow.begin(), slow.end());
+        descs.swap(ordered);
+        HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nblocks, (uint8_t *)c->slots.p,
+    if (nfast) {
+        const int rc = fg_launch_encode_fast(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nfast, (uint8_t *)c->slots.p,
+                                             (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream);
+        if (rc == -1) nfast = 0;
+        else if (rc != 0) { fg_set_error("fast encode kernel launch failed"); return false; }
+    }
+    if (nblocks > nfast &&
+        fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + nfast, (const float *)c->windows.p, &P, nblocks - nfast, (uint8_t *)c->slots.p,
                          (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {
         fg_set_error("encode kernel launch failed"); return false;
     }

@@ -1,0 +1,85 @@
+// fg_dev.h -- wave64 device primitives shared by the gfx950 FLAC kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+namespace fgdev {
+
+// DPP controls (gfx9): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+
+// Inclusive prefix sum over the 64 lanes (6 DPP adds, no LDS traffic).
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
+{
+    x += dpp0<0x111>(x);
+    x += dpp0<0x112>(x);
+    x += dpp0<0x114>(x);
+    x += dpp0<0x118>(x);
+    x += dpp0<0x142, 0xA, 0xF, false>(x);   // lane 15 of rows 0,2 -> rows 1,3
+    x += dpp0<0x143, 0xC, 0xF, false>(x);   // lane 31 -> rows 2,3
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(x), 63);
+}
+__device__ __forceinline__ uint32_t wave_or32(uint32_t x)
+{
+    x |= dpp0<0x111>(x);
+    x |= dpp0<0x112>(x);
+    x |= dpp0<0x114>(x);
+    x |= dpp0<0x118>(x);
+    x |= dpp0<0x142, 0xA, 0xF, false>(x);
+    x |= dpp0<0x143, 0xC, 0xF, false>(x);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_xor32(uint32_t x)
+{
+    x ^= dpp0<0x111>(x);
+    x ^= dpp0<0x112>(x);
+    x ^= dpp0<0x114>(x);
+    x ^= dpp0<0x118>(x);
+    x ^= dpp0<0x142, 0xA, 0xF, false>(x);
+    x ^= dpp0<0x143, 0xC, 0xF, false>(x);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// 64-bit sum via three limb sums (each limb sum stays below 2^32)
+__device__ __forceinline__ u64 wave_sum64(u64 v)
+{
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const u64 a = wave_sum(lo & 0xFFFF), b = wave_sum(lo >> 16), c = wave_sum(hi & 0xFFFFFF), d = wave_sum(hi >> 24);
+    return a + (b << 16) + (c << 32) + (d << 56);
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint32_t ilog2_32(uint32_t v) { return 31u - (uint32_t)__clz(v); }
+__device__ __forceinline__ uint32_t ilog2_64(u64 v) { return 63u - (uint32_t)__clzll(v); }
+
+// LDS operations of one wave execute in issue order, so a cross-lane read-after-write through LDS needs
+// no wait -- only a barrier against compiler reordering.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
+{
+    // a*b mod x^16+x^15+x^2+1 (CRC-16 polynomial 0x8005)
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        r = (r & 0x8000) ? (((r << 1) ^ 0x8005) & 0xFFFF) : ((r << 1) & 0xFFFF);
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+
+}  // namespace fgdev

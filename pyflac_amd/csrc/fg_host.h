@@ -17,6 +17,10 @@ int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream);
 int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
                      uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
                      const uint16_t *d_crctab, hipStream_t stream);
+size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo);
+int fg_launch_encode_fast(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
+                          uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
+                          const uint16_t *d_crctab, hipStream_t stream);
 int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
                    const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream);

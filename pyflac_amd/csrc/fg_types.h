@@ -36,6 +36,8 @@ struct FgBlockDesc {
     uint32_t frame_number;
     uint32_t win_off;      // offset (floats) of this block length's window table
     uint32_t forced_ca;    // 0xFF = choose; else 0 or 3 (loose mid-side follower frames)
+    uint32_t out_slot;     // index of the output slot / result / debug record of this block
+    uint32_t reserved;
 };
 
 struct FgBlockResult {
@@ -61,6 +63,7 @@ struct FgDebugCand {
 
 struct FgDebugRec {
     FgDebugCand cand[FG_MAX_CAND];
+    uint64_t t[16];    // clock64() stamps at stage boundaries
 };
 
 // ---- decoder ----

@@ -502,11 +502,11 @@ struct Enc {
         else {
             for (uint32_t p = lane; p < parts; p += 64) sums[p] = 0;
             lds_fence();
-            const uint32_t inv = (uint32_t)(0xFFFFFFFFull / psz) + 1;   // exact for i, psz < 2^16
+            const uint32_t inv = psz > 1 ? (uint32_t)(0xFFFFFFFFull / psz) + 1 : 0;   // exact for i, psz < 2^16
             for (uint32_t i = lane; i < n; i += 64) {
                 if (i >= order) {
                     int32_t r = residual_at(c, w, i, kind, order, q, shift, narrow, &ovf);
-                    uint32_t p = (uint32_t)(((u64)i * inv) >> 32);
+                    uint32_t p = psz > 1 ? (uint32_t)(((u64)i * inv) >> 32) : i;
                     atomicAdd((unsigned long long *)&sums[p], (unsigned long long)(uint32_t)abs(r));
                 }
             }
@@ -607,8 +607,14 @@ struct Enc {
     }
 
     // ---------------------------------------------------------------- analysis of the staged group (A.5)
+    __device__ __forceinline__ void stamp(FgDebugRec *dbg, int k) const
+    {
+        if (dbg && lane == 0) dbg->t[k] = clock64();
+    }
+
     __device__ void analyse(uint32_t dbase, FgDebugRec *dbg)
     {
+        stamp(dbg, 1);
         const uint32_t pmax_blk = [&] { uint32_t o = 0, b = n; while (!(b & 1)) { o++; b >>= 1; } return o < 15 ? o : 15; }();
         uint32_t pmax0 = pmax_blk < P.max_po ? pmax_blk : P.max_po;
         uint32_t pmin0 = P.min_po < pmax0 ? P.min_po : pmax0;
@@ -645,6 +651,7 @@ struct Enc {
             }
         }
         lds_fence();
+        stamp(dbg, 2);
         // fixed predictor evaluation (comes before LPC in libFLAC's candidate order)
         for (int c = 0; c < ncand; c++) {
             if (!fixed_ok[c]) continue;
@@ -653,6 +660,7 @@ struct Enc {
             if (dbg && lane == 0) dbg->cand[c].fixed_bits = ob;
         }
         // LPC
+        stamp(dbg, 3);
         uint32_t nv = 0;
         if (any_lpc) {
             const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
@@ -688,7 +696,9 @@ struct Enc {
                     }
                     if (lane < ncand) dbg->cand[lane].nvec = nv;
                 }
+                stamp(dbg, 4);
                 lpc_decide(dbase, nv, mo, vflags);
+                stamp(dbg, 5);
                 for (int c = 0; c < ncand; c++) {
                     if (!vflags[c]) continue;
                     for (uint32_t v = 0; v < nv; v++) {
@@ -705,6 +715,7 @@ struct Enc {
             }
         }
         lds_fence();
+        stamp(dbg, 6);
     }
 
     // ---------------------------------------------------------------- bit writer
@@ -915,7 +926,7 @@ struct Enc {
         bw_put((method << 4) | po, 6);
         const uint32_t plen = method ? 5 : 4;
         const uint32_t psz = n >> po;
-        const uint32_t inv = psz ? (uint32_t)(0xFFFFFFFFull / psz) + 1 : 0;
+        const uint32_t inv = psz > 1 ? (uint32_t)(0xFFFFFFFFull / psz) + 1 : 0;
         const int kind = type == 2 ? 0 : 1;
         const bool narrow = kind == 1 ? narrow_ok(sb, order, q) : true;
         uint32_t ovf = 0;
@@ -924,7 +935,7 @@ struct Enc {
             uint32_t pv = 0, pb = 0, val = 0, vb = 0, nb = 0;
             if (i < n && i >= order) {
                 const int32_t r = residual_at(c, w, i, kind, order, q, shift, narrow, &ovf);
-                const uint32_t p = po ? (uint32_t)(((u64)i * inv) >> 32) : 0;
+                const uint32_t p = po ? (psz > 1 ? (uint32_t)(((u64)i * inv) >> 32) : i) : 0;
                 const uint32_t k = d->k[p];
                 const uint32_t u = ((uint32_t)r << 1) ^ (uint32_t)(r >> 31);
                 const uint32_t msb = u >> k;
@@ -1025,7 +1036,8 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
 
     const uint32_t C = P.channels;
     e.wide = P.bps > 30;
-    FgDebugRec *mydbg = dbg ? dbg + blockIdx.x : nullptr;
+    FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
+    e.stamp(mydbg, 0);
     uint32_t ca = 0;
     uint32_t sub_c[8], sub_d[8];
     uint32_t nsub = C;
@@ -1044,7 +1056,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
                       case 2: sub_c[0] = 3; sub_c[1] = 1; break; default: sub_c[0] = 2; sub_c[1] = 3; break; }
         sub_d[0] = sub_c[0]; sub_d[1] = sub_c[1];
         if (e.lane == 0) {
-            FgBlockResult *r = &results[blockIdx.x];
+            FgBlockResult *r = &results[d.out_slot];
             r->best_bits[0] = b0; r->best_bits[1] = b1; r->best_bits[2] = b2; r->best_bits[3] = b3;
         }
     }
@@ -1058,7 +1070,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
         }
         for (uint32_t ch = 0; ch < C; ch++) { sub_c[ch] = ch & 1; sub_d[ch] = ch; }
         if (e.lane == 0) {
-            FgBlockResult *r = &results[blockIdx.x];
+            FgBlockResult *r = &results[d.out_slot];
             for (uint32_t k = 0; k < 4; k++) r->best_bits[k] = k < C ? e.decs[k].bits : 0;
         }
     }
@@ -1072,7 +1084,8 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
         for (uint32_t j = 0; j < FG_MAX_PARTS; j++) dc->rice_params[j] = (dd->type >= 2 && j < (1u << dd->porder)) ? dd->k[j] : 0;
     }
     // ---- pack
-    e.bw_init((uint32_t *)(out + (size_t)blockIdx.x * P.slot_bytes), P.slot_bytes / 4);
+    e.bw_init((uint32_t *)(out + (size_t)d.out_slot * P.slot_bytes), P.slot_bytes / 4);
+    e.stamp(mydbg, 7);
     e.write_header(ca, d.frame_number);
     uint32_t staged_group = (C <= 2) ? 0 : 0xFFFFFFFFu;
     for (uint32_t sidx = 0; sidx < nsub; sidx++) {
@@ -1086,9 +1099,11 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
         }
         e.write_subframe((int)sub_c[sidx], sub_d[sidx]);
     }
+    e.stamp(mydbg, 8);
     const uint32_t bytes = e.finish_frame();
+    e.stamp(mydbg, 9);
     if (e.lane == 0) {
-        FgBlockResult *r = &results[blockIdx.x];
+        FgBlockResult *r = &results[d.out_slot];
         r->bytes = bytes; r->ca = ca; r->err = e.err; r->reserved = 0;
     }
 }

@@ -13,4 +13,4 @@ class DebugCand(C.Structure):
 
 
 class DebugRec(C.Structure):
-    _fields_ = [('cand', DebugCand * 4)]
+    _fields_ = [('cand', DebugCand * 4), ('t', C.c_uint64 * 16)]

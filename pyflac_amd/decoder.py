@@ -1,0 +1,253 @@
+"""pyFLAC-compatible decoder classes over libflacgpu (HIP).
+
+Mirror of ``pyflac/decoder.py`` (reference): `StreamDecoder` (background thread + deque + Event protocol,
+pyflac/decoder.py:116-241), `FileDecoder` (:244-313), `OneShotDecoder` (:316-391) and the callback
+trampolines (:394-549), bound with ctypes instead of cffi.
+"""
+import ctypes as C
+from collections import deque
+from enum import Enum
+import logging
+from pathlib import Path
+import tempfile
+import threading
+import time
+from typing import Callable, Tuple
+
+import numpy as np
+
+from . import _lib
+from . import wav
+
+_L = _lib.lib()
+
+
+class DecoderState(Enum):
+    """The decoder state as a Python enumeration (pyflac/decoder.py:30-46)."""
+    SEARCH_FOR_METADATA = 0
+    READ_METADATA = 1
+    SEARCH_FOR_FRAME_SYNC = 2
+    READ_FRAME = 3
+    END_OF_STREAM = 4
+    OGG_ERROR = 5
+    SEEK_ERROR = 6
+    ABORTED = 7
+    MEMORY_ALLOCATION_ERROR = 8
+    UNINITIALIZED = 9
+
+    def __str__(self):
+        return _lib.string_table('FLAC__StreamDecoderStateString', 10)[self.value].decode()
+
+
+class DecoderInitException(Exception):
+    """Raised if initialisation fails for a `StreamDecoder` or a `FileDecoder`."""
+    def __init__(self, code):
+        self.code = code
+
+    def __str__(self):
+        return _lib.string_table('FLAC__StreamDecoderInitStatusString', 6)[self.code].decode()
+
+
+class DecoderProcessException(Exception):
+    """Raised if an error occurs during the processing of audio data."""
+    pass
+
+
+class _Decoder:
+    """Generic decoder: handles interaction with the C library (pyflac/decoder.py:73-113)."""
+
+    def __init__(self):
+        self._error = None
+        self._decoder = _L.FLAC__stream_decoder_new()
+        self.logger = logging.getLogger(__name__)
+        self._make_trampolines()
+
+    def __del__(self):
+        dec = getattr(self, '_decoder', None)
+        if dec:
+            _L.FLAC__stream_decoder_delete(dec)
+            self._decoder = None
+
+    def finish(self):
+        _L.FLAC__stream_decoder_finish(self._decoder)
+
+    @property
+    def state(self) -> DecoderState:
+        return DecoderState(_L.FLAC__stream_decoder_get_state(self._decoder))
+
+    def process(self):
+        raise NotImplementedError
+
+    # -- trampolines (pyflac/decoder.py:394-549)
+    def _make_trampolines(self):
+        def _read(_dec, byte_buffer, num_bytes, _client):
+            try:
+                # wait until there is something in the buffer, an error occurred, or finish() was called
+                self._event.wait()
+                if self._error:
+                    return 2   # ABORT
+                if self._done:
+                    num_bytes[0] = 0
+                    return 1   # END_OF_STREAM
+                data = bytes()
+                maximum_bytes = int(num_bytes[0])
+                self._lock.acquire()
+                try:
+                    if len(self._buffer[0]) <= maximum_bytes:
+                        data = self._buffer.popleft()
+                        maximum_bytes -= len(data)
+                    if len(self._buffer) > 0 and len(self._buffer[0]) > maximum_bytes:
+                        data += self._buffer[0][0:maximum_bytes]
+                        self._buffer[0] = self._buffer[0][maximum_bytes:]
+                    if len(self._buffer) == 0 or (len(self._buffer) > 0 and len(self._buffer[0]) == 0):
+                        self._event.clear()
+                finally:
+                    self._lock.release()
+                actual_bytes = len(data)
+                num_bytes[0] = actual_bytes
+                C.memmove(byte_buffer, data, actual_bytes)
+                return 0   # CONTINUE
+            except Exception:   # noqa: BLE001  (def_extern(error=ABORT) in the reference)
+                return 2
+
+        def _write(_dec, frame, buffer, _client):
+            try:
+                h = frame.contents.header
+                if h.bits_per_sample not in (16, 32) and not getattr(self, '_allow_any_bps', False):
+                    raise ValueError('Only int16/int32 data type is supported')
+                channels = []
+                for ch in range(0, h.channels):
+                    npbuffer = np.ctypeslib.as_array(buffer[ch], shape=(h.blocksize,))
+                    if h.bits_per_sample == 16:
+                        channels.append(npbuffer.astype(np.int16))
+                    else:
+                        channels.append(npbuffer.copy())
+                output = np.column_stack(channels)
+                self.write_callback(output, int(h.sample_rate), int(h.channels), int(h.blocksize))
+                return 0   # CONTINUE
+            except Exception:   # noqa: BLE001  (def_extern(error=ABORT) in the reference)
+                return 1
+
+        def _error(_dec, status, _client):
+            message = _lib.string_table('FLAC__StreamDecoderErrorStatusString', 5)[status].decode()
+            self.logger.error(f'Error in libFLAC decoder: {message}')
+            self._error = message
+            ev = getattr(self, '_event', None)
+            if ev is not None:
+                ev.set()
+
+        self._c_read = _lib.DEC_READ_CB(_read)
+        self._c_write = _lib.DEC_WRITE_CB(_write)
+        self._c_error = _lib.DEC_ERROR_CB(_error)
+        self._c_meta_null = C.cast(None, _lib.DEC_META_CB)
+
+    def _init_stream(self):
+        rc = _L.FLAC__stream_decoder_init_stream(self._decoder, self._c_read, None, None, None, None, self._c_write,
+                                                 self._c_meta_null, self._c_error, None)
+        if rc != 0:
+            raise DecoderInitException(rc)
+
+
+class StreamDecoder(_Decoder):
+    """Converts a stream of FLAC bytes back to raw audio (pyflac/decoder.py:116-241).
+
+    Data goes in through `process` (non-blocking); blocks come back through
+    ``write_callback(audio: ndarray[blocksize, channels], sample_rate, num_channels, num_samples)`` on a
+    background thread.  `finish` must be called at the end.
+    """
+
+    def __init__(self, write_callback: Callable[[np.ndarray, int, int, int], None]):
+        super().__init__()
+        self._done = False
+        self._buffer = deque()
+        self._event = threading.Event()
+        self._lock = threading.Lock()
+        self.write_callback = write_callback
+        self._init_stream()
+        self._thread = threading.Thread(target=self._process)
+        self._thread.daemon = True
+        self._thread.start()
+
+    def _process(self):
+        if not _L.FLAC__stream_decoder_process_until_end_of_stream(self._decoder):
+            self._error = 'A fatal read, write, or memory allocation error occurred'
+
+    def process(self, data: bytes):
+        """Hand some FLAC bytes to the decoder (non-blocking)."""
+        self._lock.acquire()
+        self._buffer.append(data)
+        self._lock.release()
+        self._event.set()
+
+    def finish(self):
+        """Drain the buffer, stop the thread, reset the decoder.
+
+        Raises:
+            DecoderProcessException: if any fatal read, write, or memory allocation error occurred.
+        """
+        while self._thread.is_alive() and self._error is None and len(self._buffer) > 0:
+            time.sleep(0.01)
+        self._done = True
+        self._event.set()
+        self._thread.join()
+        super().finish()
+        if self._error:
+            raise DecoderProcessException(self._error)
+
+
+class FileDecoder(_Decoder):
+    """Reads a FLAC file and writes a WAV file (pyflac/decoder.py:244-313)."""
+
+    def __init__(self, input_file: Path, output_file: Path = None):
+        super().__init__()
+        self.__output = None
+        self.__bits = None
+        self.write_callback = self._write_callback
+        if output_file:
+            self.__output_file = output_file
+        else:
+            self.__tmp = tempfile.NamedTemporaryFile(suffix='.wav')
+            self.__output_file = Path(self.__tmp.name)
+        rc = _L.FLAC__stream_decoder_init_file(self._decoder, str(input_file).encode('utf-8'), self._c_write,
+                                               self._c_meta_null, self._c_error, None)
+        if rc != 0:
+            raise DecoderInitException(rc)
+
+    def process(self) -> Tuple[np.ndarray, int]:
+        """Decode the file.  Returns (audio ndarray[frames, channels], sample_rate).
+
+        Raises:
+            DecoderProcessException: if any fatal read, write, or memory allocation error occurred.
+        """
+        result = _L.FLAC__stream_decoder_process_until_end_of_stream(self._decoder)
+        if self.state != DecoderState.END_OF_STREAM and not result:
+            raise DecoderProcessException(str(self.state))
+        self.finish()
+        if self.__output:
+            self.__output.close()
+            data, info = wav.read(str(self.__output_file))
+            return data, info.samplerate
+
+    def _write_callback(self, data: np.ndarray, sample_rate: int, num_channels: int, num_samples: int):
+        if self.__output is None:
+            self.__output = wav.WavWriter(self.__output_file, sample_rate, num_channels, data.dtype.itemsize * 8)
+        self.__output.write(data)
+
+
+class OneShotDecoder(_Decoder):
+    """Decodes one buffer of FLAC bytes, blocking, no thread (pyflac/decoder.py:316-391)."""
+
+    def __init__(self, write_callback: Callable[[np.ndarray, int, int, int], None], buffer: bytes):
+        super().__init__()
+        self._done = False
+        self._buffer = deque()
+        self._buffer.append(buffer)
+        self._event = threading.Event()
+        self._event.set()
+        self._lock = threading.Lock()
+        self.write_callback = write_callback
+        self._init_stream()
+        while len(self._buffer) > 0:
+            _L.FLAC__stream_decoder_process_single(self._decoder)
+        self._done = True
+        super().finish()

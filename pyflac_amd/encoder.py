@@ -1,0 +1,318 @@
+"""pyFLAC-compatible encoder classes over libflacgpu (HIP).
+
+Mirror of ``pyflac/encoder.py`` (reference): same class names, constructor arguments, callback signatures,
+exceptions and error behaviour; the cffi ``_lib``/``_ffi`` pair is replaced by ctypes over the C-ABI library
+(cffi is not available in this image).  One extension: ``bits_per_sample`` can be given explicitly, because
+the reference infers it from the dtype (``pyflac/encoder.py:109``) and so cannot express 24-bit input.
+"""
+import ctypes as C
+from enum import Enum
+import logging
+from pathlib import Path
+import tempfile
+from typing import Callable
+
+import numpy as np
+
+from . import _lib
+from . import wav
+
+_L = _lib.lib()
+
+
+class EncoderState(Enum):
+    """The encoder state as a Python enumeration (pyflac/encoder.py:27-42)."""
+    OK = 0
+    UNINITIALIZED = 1
+    OGG_ERROR = 2
+    VERIFY_DECODER_ERROR = 3
+    VERIFY_MISMATCH_IN_AUDIO_DATA = 4
+    CLIENT_ERROR = 5
+    IO_ERROR = 6
+    FRAMING_ERROR = 7
+    MEMORY_ALLOCATION_ERROR = 8
+
+    def __str__(self):
+        return _lib.string_table('FLAC__StreamEncoderStateString', 9)[self.value].decode()
+
+
+class EncoderInitException(Exception):
+    """Raised if initialisation fails for a `StreamEncoder` or a `FileEncoder` (pyflac/encoder.py:45-54)."""
+    def __init__(self, code):
+        self.code = code
+
+    def __str__(self):
+        return _lib.string_table('FLAC__StreamEncoderInitStatusString', 14)[self.code].decode()
+
+
+class EncoderProcessException(Exception):
+    """Raised if an error occurs during the processing of audio data."""
+    pass
+
+
+def stream_header_bytes(settings, min_framesize=0, max_framesize=0, total_samples=0, md5=None):
+    """The 86-byte fLaC + STREAMINFO + VORBIS_COMMENT header for resolved batch settings."""
+    s = settings
+    b = bytearray(b'fLaC')
+    b += bytes([0, 0, 0, 34])
+    b += int(s.blocksize).to_bytes(2, 'big') * 2
+    b += int(min_framesize).to_bytes(3, 'big') + int(max_framesize).to_bytes(3, 'big')
+    v = (s.sample_rate << 44) | ((s.channels - 1) << 41) | ((s.bits_per_sample - 1) << 36) | (total_samples & 0xFFFFFFFFF)
+    b += v.to_bytes(8, 'big')
+    b += bytes(md5) if md5 else bytes(16)
+    vendor = C.c_char_p.in_dll(_L, 'FLAC__VENDOR_STRING').value
+    b += bytes([0x84, 0, 0, 8 + len(vendor)]) + len(vendor).to_bytes(4, 'little') + vendor + bytes(4)
+    return bytes(b)
+
+
+class _Encoder:
+    """Generic encoder: handles interaction with the C library (pyflac/encoder.py:65-231)."""
+
+    def __init__(self):
+        self._initialised = False
+        self._encoder = _L.FLAC__stream_encoder_new()
+        self._explicit_bps = None
+        self.logger = logging.getLogger(__name__)
+
+    def __del__(self):
+        enc = getattr(self, '_encoder', None)
+        if enc:
+            _L.FLAC__stream_encoder_delete(enc)
+            self._encoder = None
+
+    def _init(self):
+        raise NotImplementedError
+
+    # -- Processing
+    def process(self, samples: np.ndarray):
+        """Process some samples (pyflac/encoder.py:86-119).
+
+        Raises:
+            TypeError: if a numpy array of samples is not provided
+            EncoderProcessException: if an error occurs when processing the samples
+        """
+        if not isinstance(samples, np.ndarray):
+            raise TypeError('Processing only supports numpy arrays')
+
+        if not self._initialised:
+            try:
+                self._channels = samples.shape[1]
+            except IndexError:
+                self._channels = 1
+            self._bits_per_sample = self._explicit_bps or samples.dtype.itemsize * 8
+            self._init()
+
+        samples = np.ascontiguousarray(samples).astype(np.int32)
+        result = _L.FLAC__stream_encoder_process_interleaved(self._encoder, samples.ctypes.data, len(samples))
+        if not result:
+            raise EncoderProcessException(str(self.state))
+
+    def finish(self) -> bool:
+        """Flush the encoder, reset its settings, return it to UNINITIALIZED (pyflac/encoder.py:121-132)."""
+        return bool(_L.FLAC__stream_encoder_finish(self._encoder))
+
+    # -- State
+    @property
+    def state(self) -> EncoderState:
+        return EncoderState(_L.FLAC__stream_encoder_get_state(self._encoder))
+
+    # -- Getters & Setters (pyflac/encoder.py:145-231)
+    @property
+    def _verify(self) -> bool:
+        return bool(_L.FLAC__stream_encoder_get_verify(self._encoder))
+
+    @_verify.setter
+    def _verify(self, value: bool):
+        _L.FLAC__stream_encoder_set_verify(self._encoder, bool(value))
+
+    @property
+    def _channels(self) -> int:
+        return _L.FLAC__stream_encoder_get_channels(self._encoder)
+
+    @_channels.setter
+    def _channels(self, value: int):
+        _L.FLAC__stream_encoder_set_channels(self._encoder, value)
+
+    @property
+    def _bits_per_sample(self) -> int:
+        return _L.FLAC__stream_encoder_get_bits_per_sample(self._encoder)
+
+    @_bits_per_sample.setter
+    def _bits_per_sample(self, value: int):
+        _L.FLAC__stream_encoder_set_bits_per_sample(self._encoder, value)
+
+    @property
+    def _sample_rate(self) -> int:
+        return _L.FLAC__stream_encoder_get_sample_rate(self._encoder)
+
+    @_sample_rate.setter
+    def _sample_rate(self, value: int):
+        _L.FLAC__stream_encoder_set_sample_rate(self._encoder, value)
+
+    @property
+    def _blocksize(self) -> int:
+        return _L.FLAC__stream_encoder_get_blocksize(self._encoder)
+
+    @_blocksize.setter
+    def _blocksize(self, value: int):
+        _L.FLAC__stream_encoder_set_blocksize(self._encoder, value)
+
+    @property
+    def _compression_level(self) -> int:
+        raise NotImplementedError
+
+    @_compression_level.setter
+    def _compression_level(self, value: int):
+        _L.FLAC__stream_encoder_set_compression_level(self._encoder, value)
+
+    @property
+    def _streamable_subset(self) -> bool:
+        return bool(_L.FLAC__stream_encoder_get_streamable_subset(self._encoder))
+
+    @_streamable_subset.setter
+    def _streamable_subset(self, value: bool):
+        _L.FLAC__stream_encoder_set_streamable_subset(self._encoder, bool(value))
+
+    @property
+    def _limit_min_bitrate(self) -> bool:
+        return bool(_L.FLAC__stream_encoder_get_limit_min_bitrate(self._encoder))
+
+    @_limit_min_bitrate.setter
+    def _limit_min_bitrate(self, value: bool):
+        _L.FLAC__stream_encoder_set_limit_min_bitrate(self._encoder, bool(value))
+
+
+class StreamEncoder(_Encoder):
+    """Real-time style stream encoder (pyflac/encoder.py:234-330).
+
+    Raw audio goes in through `process`; compressed chunks come back through
+    ``write_callback(buffer: bytes, num_bytes, num_samples, current_frame)``.
+    """
+
+    def __init__(self,
+                 sample_rate: int,
+                 write_callback: Callable[[bytes, int, int, int], None],
+                 seek_callback: Callable[[int], None] = None,
+                 tell_callback: Callable[[], int] = None,
+                 metadata_callback: Callable[[int], None] = None,
+                 compression_level: int = 5,
+                 blocksize: int = 0,
+                 streamable_subset: bool = True,
+                 verify: bool = False,
+                 limit_min_bitrate: bool = False,
+                 bits_per_sample: int = None):
+        super().__init__()
+        self.write_callback = write_callback
+        self.seek_callback = seek_callback
+        self.tell_callback = tell_callback
+        self.metadata_callback = metadata_callback
+        self._explicit_bps = bits_per_sample
+
+        self._sample_rate = sample_rate
+        self._blocksize = blocksize
+        self._compression_level = compression_level
+        self._streamable_subset = streamable_subset
+        self._verify = verify
+        self._limit_min_bitrate = limit_min_bitrate
+        self._callback_error = None
+
+        # trampolines (pyflac/encoder.py:429-483): exceptions become the abort status
+        def _write(_enc, byte_buffer, num_bytes, num_samples, current_frame, _client):
+            try:
+                buffer = C.string_at(byte_buffer, num_bytes)
+                self.write_callback(buffer, num_bytes, num_samples, current_frame)
+                return 0
+            except Exception as exc:   # noqa: BLE001
+                self._callback_error = exc
+                return 1
+
+        def _seek(_enc, offset, _client):
+            try:
+                self.seek_callback(offset)
+                return 0
+            except Exception as exc:   # noqa: BLE001
+                self._callback_error = exc
+                return 1
+
+        def _tell(_enc, poffset, _client):
+            try:
+                poffset[0] = self.tell_callback()
+                return 0
+            except Exception as exc:   # noqa: BLE001
+                self._callback_error = exc
+                return 1
+
+        def _meta(_enc, metadata, _client):
+            try:
+                self.metadata_callback(metadata.contents)
+            except Exception as exc:   # noqa: BLE001
+                self._callback_error = exc
+
+        self._c_write = _lib.ENC_WRITE_CB(_write)
+        self._c_seek = _lib.ENC_SEEK_CB(_seek)
+        self._c_tell = _lib.ENC_TELL_CB(_tell)
+        self._c_meta = _lib.ENC_META_CB(_meta)
+
+    def _init(self):
+        null = C.cast(None, C.c_void_p)
+        rc = _L.FLAC__stream_encoder_init_stream(
+            self._encoder,
+            self._c_write,
+            self._c_seek if self.seek_callback else C.cast(null, _lib.ENC_SEEK_CB),
+            self._c_tell if self.tell_callback else C.cast(null, _lib.ENC_TELL_CB),
+            self._c_meta if self.metadata_callback else C.cast(null, _lib.ENC_META_CB),
+            None)
+        if rc != 0:
+            raise EncoderInitException(rc)
+        self._initialised = True
+
+
+class FileEncoder(_Encoder):
+    """Reads a WAV file and writes a FLAC file (pyflac/encoder.py:333-426).
+
+    The input WAV must be PCM_16 or PCM_32, as in the reference.
+    """
+
+    def __init__(self,
+                 input_file: Path,
+                 output_file: Path = None,
+                 compression_level: int = 5,
+                 blocksize: int = 0,
+                 streamable_subset: bool = True,
+                 verify: bool = False):
+        super().__init__()
+        info = wav.info(str(input_file))
+        if info.subtype not in ('PCM_16', 'PCM_32'):
+            raise ValueError(f'WAV input data type must be either PCM_16 or PCM_32: Got {info.subtype}')
+        self.__raw_audio, wi = wav.read(str(input_file))
+        sample_rate = wi.samplerate
+        if output_file:
+            self.__output_file = output_file
+        else:
+            self.__tmp = tempfile.NamedTemporaryFile(suffix='.flac')
+            self.__output_file = Path(self.__tmp.name)
+
+        self._sample_rate = sample_rate
+        self._blocksize = blocksize
+        self._compression_level = compression_level
+        self._streamable_subset = streamable_subset
+        self._verify = verify
+
+        def _progress(_enc, bytes_written, samples_written, frames_written, total_frames_estimate, _client):
+            self.logger.debug(f'{frames_written} frames written')
+
+        self._c_progress = _lib.ENC_PROGRESS_CB(_progress)
+
+    def _init(self):
+        rc = _L.FLAC__stream_encoder_init_file(self._encoder, str(self.__output_file).encode('utf-8'),
+                                               self._c_progress, None)
+        if rc != 0:
+            raise EncoderInitException(rc)
+        self._initialised = True
+
+    def process(self) -> bytes:
+        """Encode the WAV file; returns the FLAC bytes."""
+        super().process(self.__raw_audio)
+        self.finish()
+        with open(self.__output_file, 'rb') as f:
+            return f.read()

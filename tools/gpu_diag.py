@@ -21,13 +21,27 @@ def compare_case(ctx, name, pcm, bps, sr, level, bs, subset=True, verbose=True, 
     try:
         out, offs, st = ctx.encode(s, t, debug=True)
     except Exception as e:
-        print('%-22s EXC %s' % (name, e)); return False
+        import ctypes as C
+        from pyflac_amd import _lib
+        res = np.zeros((8, 8), np.uint32)
+        _lib.lib().flacgpu_copy_block_results(ctx._h, res.ctypes.data, min(8, (a32.shape[0] + cfg.blocksize - 1) // cfg.blocksize))
+        print('%-22s EXC %s\n%s' % (name, e, res)); return False
     torch.cuda.synchronize()
     ob = out[:st.total_bytes].cpu().numpy().tobytes()
     oo = offs.cpu().numpy()
     ok = ob == ref[86:]
     print('%-22s %s  frames=%d bytes=%d/%d kernel=%.3fms' % (name, 'OK' if ok else 'MISMATCH', st.nblocks, len(ob), len(ref) - 86, st.encode_kernel_ms))
-    if ok or not verbose:
+    if ok:
+        dec, status, dst = ctx.decode(out[:st.total_bytes], oo, ch, bps, a32.shape[0])
+        dok = bool(status[:, 0].max() == 0) and dec.shape[0] == a32.shape[0] and bool(torch.equal(dec, t))
+        if not dok:
+            bad = np.nonzero(status[:, 0])[0]
+            print('   DECODE MISMATCH status-bad frames %s, kernel=%.3fms' % (bad[:8], dst.decode_kernel_ms))
+            if dec.shape[0] == a32.shape[0]:
+                d = (dec != t).any(dim=1).nonzero()[:4].flatten().tolist()
+                print('   first differing samples', d, [dec[i].tolist() for i in d], [t[i].tolist() for i in d])
+        return ok and dok
+    if not verbose:
         return ok
     pos = 86
     nshow = 0
