@@ -104,6 +104,8 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     c->device = device;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     if (!c->crctab.ensure(1024 * sizeof(uint16_t))) return false;
     if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
@@ -129,6 +131,8 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -220,7 +224,7 @@ void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, boo
     P->apod_parts = s.apod_parts;
     P->rice_limit = s.bits_per_sample > 16 ? 31 : 15;
     P->slot_bytes = fg_slot_bytes(s, max_n);
-    P->sig_stride = (max_n + 3) & ~3u;
+    P->sig_stride = (max_n + 7) & ~7u;
     uint32_t nvec = 1;
     if (s.apod_parts >= 2) for (uint32_t b = 2; b <= s.apod_parts; b++) nvec += (b == 2) ? 2 : 2 * b;
     P->nvec = nvec;
@@ -394,16 +398,27 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    const bool side = nfast > 0 && nblocks > nfast;     // overlap the few generic blocks with the fast launch
+    if (side) {
+        HIPCHK(hipEventRecord(c->evx[0], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
+    }
     if (nfast) {
         const int rc = fg_launch_encode_fast(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nfast, (uint8_t *)c->slots.p,
                                              (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream);
         if (rc == -1) nfast = 0;
         else if (rc != 0) { fg_set_error("fast encode kernel launch failed"); return false; }
     }
-    if (nblocks > nfast &&
-        fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + nfast, (const float *)c->windows.p, &P, nblocks - nfast, (uint8_t *)c->slots.p,
-                         (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {
-        fg_set_error("encode kernel launch failed"); return false;
+    if (nblocks > nfast) {
+        hipStream_t ss = (side && nfast) ? c->stream2 : c->stream;
+        if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + nfast, (const float *)c->windows.p, &P, nblocks - nfast, (uint8_t *)c->slots.p,
+                             (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, ss) != 0) {
+            fg_set_error("encode kernel launch failed"); return false;
+        }
+        if (ss == c->stream2) {
+            HIPCHK(hipEventRecord(c->evx[1], c->stream2));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->evx[1], 0));
+        }
     }
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     // sizes -> offsets -> contiguous output

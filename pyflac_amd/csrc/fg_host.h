@@ -27,9 +27,13 @@ int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockRes
 int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
                           uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
                           unsigned long long *d_totals, hipStream_t stream);
-int fg_launch_decode(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_pcm,
-                     FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
-                     hipStream_t stream);
+int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
+                          int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
+                          hipStream_t stream);
+int fg_launch_decode_fast(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_scratch,
+                          FgDecResult *d_results, int wide, hipStream_t stream);
+int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, const int32_t *d_scratch,
+                            int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, uint32_t interleave, hipStream_t stream);
 }
 
 void fg_set_error(const std::string &msg);
@@ -50,6 +54,8 @@ struct WindowEntry {
 struct flacgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
+    hipEvent_t evx[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,

@@ -8,7 +8,7 @@
 #define FG_MAX_PARTS 256 // 2^8: FLAC__SUBSET_MAX_RICE_PARTITION_ORDER (format.h:151)
 #define FG_WINW 128      // bit-packer LDS window, 32-bit words
 #define FG_DH 32         // autocorrelation history entries kept in front of each chunk
-#define FG_DK 224        // autocorrelation chunk length (doubles per candidate)
+#define FG_DK 96          // autocorrelation chunk length (doubles per candidate)
 
 // Error bits reported per block.
 #define FG_ERR_RANGE 1u        // input sample outside the bits-per-sample range

@@ -109,9 +109,11 @@ struct BitReader {
     }
 };
 
+// Generic (slow) decoder: any predictor order up to 32.  Used only for the frames the register-resident
+// decoder below flags with status 3; frame_list maps the launch's lanes to frame indices.
 __global__ void __launch_bounds__(64)
-fg_decode_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch, int32_t *out,
-                 FgDecResult *results, const uint16_t *crctab, uint32_t interleave)
+fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const uint32_t *frame_list, uint32_t nframes,
+                      int32_t *scratch, int32_t *out, FgDecResult *results_all, const uint16_t *crctab, uint32_t interleave)
 {
     __shared__ int32_t ring[32 * 64];
     __shared__ uint16_t crct[768];
@@ -122,10 +124,11 @@ fg_decode_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfram
     mult[lane] = crctab[768 + lane];
     __syncthreads();
 
-    const uint32_t f = blockIdx.x * 64 + lane;
-    const bool valid = f < nframes;
+    const uint32_t fl = blockIdx.x * 64 + lane;
+    const bool valid = fl < nframes;
+    const uint32_t f = valid ? frame_list[fl] : 0;
     FgDecFrame fr;
-    if (valid) fr = frames[f];
+    if (valid) fr = frames_all[f];
     else { fr.byte_off = 0; fr.out_off = 0; fr.bytes = 0; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0; }
     uint32_t err = 0;
     const uint32_t n = fr.n, C = fr.channels;
@@ -286,7 +289,8 @@ fg_decode_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfram
         const uint32_t stored = ((uint32_t)fp[nbytes] << 8) | fp[nbytes + 1];
         const bool crc_ok = (crc == stored);
         uint32_t status = ferr ? 1u : (crc_ok ? 0u : 2u);
-        if (lane == 0) { results[blockIdx.x * 64 + L].err = status; results[blockIdx.x * 64 + L].crc = crc; }
+        const uint32_t fidx = __shfl(f, L);
+        if (lane == 0) { results_all[fidx].err = status; results_all[fidx].crc = crc; }
         // undo wasted bits and channel coding; bad frames are delivered as silence
         const int32_t *pl = scratch + ooff * fC;
         int32_t *o = out + ooff * fC;
@@ -417,13 +421,13 @@ extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned lon
     return (int)hipGetLastError();
 }
 
-extern "C" int fg_launch_decode(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_pcm,
-                                FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
-                                hipStream_t stream)
+extern "C" int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
+                                     int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch,
+                                     uint32_t interleave, hipStream_t stream)
 {
-    if (nframes == 0) return 0;
-    const uint32_t nwg = (nframes + 63) / 64;
-    hipLaunchKernelGGL(fg_decode_kernel, dim3(nwg), dim3(64), 0, stream, d_stream, d_frames, nframes, d_scratch, d_pcm,
+    if (nlist == 0) return 0;
+    const uint32_t nwg = (nlist + 63) / 64;
+    hipLaunchKernelGGL(fg_decode_slow_kernel, dim3(nwg), dim3(64), 0, stream, d_stream, d_frames, d_frame_list, nlist, d_scratch, d_pcm,
                        d_results, d_crctab, interleave);
     return (int)hipGetLastError();
 }

@@ -15,12 +15,13 @@ FG_DECL(ms_o8) FG_DECL(ms_o12) FG_DECL(st_o8) FG_DECL(st_o12) FG_DECL(mono_o8) F
 
 size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo)
 {
+    const size_t sb = P->bps > 16 ? 4 : 2;   // staged sample size
     const int NC = ms ? 4 : nch;
     const int MQ = maxo > 0 ? maxo : 1;
     size_t off = 0;
     auto add = [&](size_t b) { off += (b + 15) & ~(size_t)15; };
-    add((size_t)(P->sig_stride + FG_PADF) * 4);
-    add(nch == 2 ? (size_t)(P->sig_stride + FG_PADF) * 4 : 16);
+    add((size_t)(P->sig_stride + FG_PADF) * sb);
+    add(nch == 2 ? (size_t)(P->sig_stride + FG_PADF) * sb : 16);
     add(P->lds_dbuf_bytes);
     add((size_t)NC * P->nvec * (maxo + 1) * 8);
     add((size_t)NC * P->nvec * MQ * 4);

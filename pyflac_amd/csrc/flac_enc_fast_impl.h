@@ -33,9 +33,11 @@ template <bool MS, int NCH, int MAXO, bool ACC64>
 struct Fast {
     static constexpr int NC = MS ? 4 : NCH;
     typedef typename std::conditional<ACC64, u64, uint32_t>::type sum_t;
+    // bits-per-sample <= 16 (the !ACC64 shapes): samples are staged as int16, halving the LDS footprint
+    typedef typename std::conditional<ACC64, int32_t, int16_t>::type samp_t;
 
     // LDS
-    LDS int32_t *sL, *sR;
+    LDS samp_t *sL, *sR;
     LDS double *dbuf;
     LDS double *autoc;   // [NC][nvec][MAXO+1]
     LDS int32_t *qres;   // [NC*nvec][MAXO]
@@ -77,7 +79,7 @@ struct Fast {
         const int32_t lim = (int32_t)(pp->bps - 1);
         uint32_t bad = 0;
         if (lane < FG_PADF) { sL[lane] = 0; if (NCH == 2) sR[lane] = 0; }
-        LDS int32_t *dl = sL + FG_PADF, *dr = sR + FG_PADF;
+        LDS samp_t *dl = sL + FG_PADF, *dr = sR + FG_PADF;
         for (uint32_t i0 = 0; i0 < n; i0 += 256) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -93,8 +95,8 @@ struct Fast {
                         else a = ((const int32_t *)pcm)[pcm_off + i];
                     }
                     if (pp->bps < 32) bad |= (uint32_t)(((a ^ (a >> 31)) >> lim) | ((b ^ (b >> 31)) >> lim));
-                    dl[i] = a;
-                    if (NCH == 2) dr[i] = b;
+                    dl[i] = (samp_t)a;
+                    if (NCH == 2) dr[i] = (samp_t)b;
                 }
             }
         }
@@ -115,7 +117,7 @@ struct Fast {
 #pragma unroll
             for (int k = 0; k < 5; k++) acc[c][k] = 0;
         }
-        const LDS int32_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
+        const LDS samp_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
         for (uint32_t i = lane; i < n; i += 64) {
             int32_t l[5], r[5];
 #pragma unroll
@@ -156,7 +158,7 @@ struct Fast {
     __device__ __forceinline__ void fixed_sums_one(u64 tot[5])
     {
         u64 acc[5] = {0, 0, 0, 0, 0};
-        const LDS int32_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
+        const LDS samp_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
         for (uint32_t i = 4 + lane; i < n; i += 64) {
             int32_t v[5];
 #pragma unroll
@@ -175,7 +177,7 @@ struct Fast {
     template <int C>
     __device__ __forceinline__ bool is_constant()
     {
-        const LDS int32_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
+        const LDS samp_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
         const int32_t x0 = cv<C>(pl[0], (NCH == 2) ? pr[0] : 0);
         uint32_t ne = 0;
         for (uint32_t i = lane; i < n; i += 64) ne |= (cv<C>(pl[i], (NCH == 2) ? pr[i] : 0) != x0);
@@ -188,7 +190,7 @@ struct Fast {
     {
         const uint32_t DSTR = FG_DH + FG_DK;
         const uint32_t cl = lane >> 4, l = lane & 15;
-        const LDS int32_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
+        const LDS samp_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
         double acc = 0.0;
         for (uint32_t j = lane; j < NC * FG_DH; j += 64) dbuf[(j / FG_DH) * DSTR + (j % FG_DH)] = 0.0;
         wave_lds_fence();
@@ -389,7 +391,7 @@ struct Fast {
                               uint32_t pmax, sum_t psum[NC], uint32_t *ovfmask)
     {
         const uint32_t psz = n >> pmax, ipp = psz >> 6, parts = 1u << pmax;
-        const LDS int32_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
+        const LDS samp_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
         uint32_t ovf[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) { psum[c] = 0; ovf[c] = 0; }
@@ -639,7 +641,7 @@ struct Fast {
     {
         const uint32_t type = d_type[C], order = d_order[C], w = wst[C], sb = sbp[C];
         const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
-        const LDS int32_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
+        const LDS samp_t *pl = sL + FG_PADF, *pr = sR + FG_PADF;
         uint32_t hdr;
         switch (type) {
         case 0: hdr = 0x00; break;
@@ -770,8 +772,8 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     size_t off = 0;
     LDS unsigned char *lbase = (LDS unsigned char *)smem;
     auto carve = [&](size_t bytes) __attribute__((always_inline)) { LDS unsigned char *p = lbase + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    e.sL = (LDS int32_t *)carve((size_t)(P.sig_stride + FG_PADF) * 4);
-    e.sR = (LDS int32_t *)carve(NCH == 2 ? (size_t)(P.sig_stride + FG_PADF) * 4 : 16);
+    e.sL = (LDS typename F::samp_t *)carve((size_t)(P.sig_stride + FG_PADF) * sizeof(typename F::samp_t));
+    e.sR = (LDS typename F::samp_t *)carve(NCH == 2 ? (size_t)(P.sig_stride + FG_PADF) * sizeof(typename F::samp_t) : 16);
     e.dbuf = (LDS double *)carve(P.lds_dbuf_bytes);
     e.autoc = (LDS double *)carve((size_t)NC * P.nvec * (MAXO + 1) * 8);
     e.qres = (LDS int32_t *)carve((size_t)NC * P.nvec * MQ * 4);

@@ -248,9 +248,11 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
     if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4)) return false;
     if (!HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
-    if (fg_launch_decode((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)d_pcm,
-                         (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, (int32_t *)c->dec_scratch.p,
-                         interleave ? 1u : 0u, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+    if (fg_launch_decode_fast((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+                              (FgDecResult *)c->dec_results.p, bps_hint > 16 ? 1 : 0, c->stream) != 0 ||
+        fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (const int32_t *)c->dec_scratch.p,
+                                (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, interleave ? 1u : 0u,
+                                c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
     if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
     std::vector<FgDecResult> res(nframes);
     if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
@@ -259,6 +261,20 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
     }
     if (!HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    {
+        // frames outside the register-resident decoder's envelope (predictor order > 12, ...) go through the generic kernel
+        std::vector<uint32_t> redo;
+        for (uint32_t i = 0; i < nframes; i++) if (res[i].err == 3) redo.push_back(i);
+        if (!redo.empty()) {
+            if (!c->descs.ensure(redo.size() * 4)) return false;
+            if (!HIPOK(hipMemcpyAsync(c->descs.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, c->stream))) return false;
+            if (fg_launch_decode_slow((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, (const uint32_t *)c->descs.p, (uint32_t)redo.size(),
+                                      (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, (int32_t *)c->dec_scratch.p,
+                                      interleave ? 1u : 0u, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+            if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream)) ||
+                !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+        }
+    }
     (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);
     uint32_t bad = 0;
