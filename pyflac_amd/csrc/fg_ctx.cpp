@@ -307,7 +307,12 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (!c->sync_windows()) return false;
     FgEncParams P;
     fg_fill_params(*s, s->blocksize, pcm_is_i16 != 0, c->debug, &P);
-    if (fg_enc_lds_bytes(&P) > 160 * 1024) { fg_set_error("block too large for the LDS-staged encoder (blocksize * channels)"); return false; }
+    if (fg_enc_lds_bytes(&P) > 64 * 1024) {
+        // large blocks: the generic kernel reads the PCM in place instead of staging it in LDS
+        if (pcm_is_i16) { fg_set_error("int16 ingest needs blocks that fit LDS"); return false; }
+        P.sig_stride = 0;
+        if (fg_enc_lds_bytes(&P) > 160 * 1024) { fg_set_error("settings need more LDS than the device has"); return false; }
+    }
     if (!c->descs.ensure((size_t)nblocks * sizeof(FgBlockDesc))) return false;
     if (!c->slots.ensure((size_t)nblocks * P.slot_bytes)) return false;
     if (!c->results.ensure((size_t)nblocks * sizeof(FgBlockResult))) return false;
@@ -378,7 +383,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // blocks the specialised kernel covers go first, the rest to the generic kernel (same bytes either way)
     uint32_t nfast = 0;
     {
-        const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
+        const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
         std::vector<FgBlockDesc> ordered;
         ordered.reserve(nblocks);
         std::vector<FgBlockDesc> slow;

@@ -146,15 +146,23 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
             if (hdr & 0x80) { err = 1; break; }
             if (hdr & 1) { wasted = br.unary() + 1; if (wasted >= sb) { err = 1; break; } sb -= wasted; }
             wasted_s[lane * 8 + ch] = (uint8_t)wasted;
-            if (sb > 32) { err = 1; break; }          // 33-bit side channel: not supported
+            if (sb > 33) { err = 1; break; }
+            const bool s33 = sb == 33;   // 33-bit side subframe: fields are read as sign + 32 bits and must fit int32
             const uint32_t t = (hdr >> 1) & 0x3F;
             int32_t *dst = planar + (size_t)ch * n;
+            auto sample = [&]() -> int32_t {
+                if (!s33) return br.sbits(sb);
+                const uint32_t sgn = br.bits(1);
+                const int32_t lo = (int32_t)br.bits(32);
+                if ((sgn != 0) != (lo < 0)) err = 1;     // does not fit int32
+                return lo;
+            };
             if (t == 0) {
-                const int32_t v = br.sbits(sb);
+                const int32_t v = sample();
                 for (uint32_t i = 0; i < n; i++) dst[i] = v;
             }
             else if (t == 1) {
-                for (uint32_t i = 0; i < n; i++) dst[i] = br.sbits(sb);
+                for (uint32_t i = 0; i < n; i++) dst[i] = sample();
             }
             else if ((t >= 8 && t <= 12) || t >= 32) {
                 const bool lpc = t >= 32;
@@ -163,7 +171,7 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                 int32_t q[32];
                 int32_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
                 for (uint32_t i = 0; i < order; i++) {
-                    const int32_t v = br.sbits(sb);
+                    const int32_t v = sample();
                     dst[i] = v;
                     ring[(i & 31) * 64 + lane] = v;
                     p4 = p3; p3 = p2; p2 = p1; p1 = v;
@@ -187,6 +195,7 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                 bool is_esc = false;
                 // 64-bit accumulation is a safe universal choice
                 const bool narrow = lpc && (sb + prec + (32 - __clz(order)) <= 32);
+                const bool fixwide = !lpc && sb + order > 32;
                 for (uint32_t i = order; i < n; i++) {
                     if (left == 0) {
                         left = (part == 0) ? (psz - order) : psz;
@@ -217,12 +226,14 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                     }
                     int32_t v;
                     if (!lpc) {
+                        // two's-complement wrap-around is exact whenever the true value fits int32
+                        (void)fixwide;
                         switch (order) {
                         case 0: v = r; break;
-                        case 1: v = r + p1; break;
-                        case 2: v = r + 2 * p1 - p2; break;
-                        case 3: v = r + 3 * p1 - 3 * p2 + p3; break;
-                        default: v = r + 4 * p1 - 6 * p2 + 4 * p3 - p4; break;
+                        case 1: v = (int32_t)((uint32_t)r + (uint32_t)p1); break;
+                        case 2: v = (int32_t)((uint32_t)r + 2u * (uint32_t)p1 - (uint32_t)p2); break;
+                        case 3: v = (int32_t)((uint32_t)r + 3u * (uint32_t)p1 - 3u * (uint32_t)p2 + (uint32_t)p3); break;
+                        default: v = (int32_t)((uint32_t)r + 4u * (uint32_t)p1 - 6u * (uint32_t)p2 + 4u * (uint32_t)p3 - (uint32_t)p4); break;
                         }
                         p4 = p3; p3 = p2; p2 = p1; p1 = v;
                     }

@@ -101,6 +101,7 @@ struct Dec {            // decision for one candidate subframe (lives in LDS)
 struct Enc {
     // LDS regions
     int32_t *s0, *s1;
+    uint32_t sstr;      // element stride of s0/s1: 1 when staged in LDS, channels when read straight from the PCM buffer
     double *dbuf;
     double *autoc;
     int32_t *qres;
@@ -137,10 +138,11 @@ struct Enc {
     __device__ __forceinline__ int32_t get(int c, uint32_t i, uint32_t w) const
     {
         int32_t L = 0, R = 0;
-        if (mode == 0) { if (c == 0) L = s0[i]; else R = s1[i]; }
+        const size_t j = (size_t)i * sstr;
+        if (mode == 0) { if (c == 0) L = s0[j]; else R = s1[j]; }
         else {
-            if (c != 1) L = s0[i];
-            if (c != 0) R = s1[i];
+            if (c != 1) L = s0[j];
+            if (c != 0) R = s1[j];
         }
         return cval(c, L, R, w);
     }
@@ -151,6 +153,16 @@ struct Enc {
         const uint32_t C = P.channels;
         const i64 lo = -((i64)1 << (P.bps - 1)), hi = ((i64)1 << (P.bps - 1)) - 1;
         uint32_t bad = 0;
+        if (P.sig_stride == 0) {
+            // block too large for LDS: read the interleaved int32 PCM in place (host guarantees !pcm_i16)
+            int32_t *base = (int32_t *)pcm + (pcm_off * C + ch0);
+            s0 = base; s1 = base + (nch > 1 ? 1 : 0); sstr = C;
+            for (uint32_t i = lane; i < n; i += 64)
+                for (uint32_t c = 0; c < nch; c++) { const int32_t v = base[(size_t)i * C + c]; if ((i64)v < lo || (i64)v > hi) bad = 1; }
+            if (__any(bad)) err |= FG_ERR_RANGE;
+            return;
+        }
+        sstr = 1;
         for (uint32_t i = lane; i < n; i += 64) {
             for (uint32_t c = 0; c < nch; c++) {
                 int32_t v;
@@ -169,11 +181,12 @@ struct Enc {
     __device__ void wasted_bits(uint32_t dbase)
     {
         for (int c = 0; c < ncand; c++) {
-            uint32_t orl = 0, orh = 0;
+            uint32_t orl = 0, orh = 0, nofit = 0;
             for (uint32_t i = lane; i < n; i += 64) {
                 if (mode == 1 && c == 3 && wide) {
-                    i64 s = (i64)s0[i] - (i64)s1[i];
+                    i64 s = (i64)s0[(size_t)i * sstr] - (i64)s1[(size_t)i * sstr];
                     orl |= (uint32_t)s; orh |= (uint32_t)((u64)s >> 32);
+                    if (s != (i64)(int32_t)s) nofit = 1;
                 }
                 else orl |= (uint32_t)get(c, i, 0);
             }
@@ -184,7 +197,9 @@ struct Enc {
             uint32_t nominal = P.bps + ((mode == 1 && c == 3) ? 1u : 0u);
             if (w > nominal) w = nominal;
             uint32_t sb = nominal - w;
-            if (sb > 32) { err |= FG_ERR_SIDE33; sb = 32; }
+            // a 33-bit side subframe is representable here as long as every value (after the wasted-bit shift)
+            // still fits int32; genuinely 33-bit values are refused
+            if (sb > 32 && __any(nofit)) { err |= FG_ERR_SIDE33; sb = 32; }
             if (lane == 0) { decs[dbase + c].wasted = w; decs[dbase + c].sbps = sb; }
         }
         lds_fence();
@@ -899,18 +914,27 @@ struct Enc {
             const uint32_t nb = lane == 0 ? w : 0;
             bw_round(0, 0, lane == 0 ? 1 : 0, lane == 0 ? 1 : 0, nb);
         }
-        if (type == 0) { bw_put((uint32_t)get(c, 0, w) & mask, sb); return; }
+        // a sample field is sb bits wide; sb == 33 is sent as its sign bit followed by 32 bits
+        const uint32_t sb_lo = sb > 32 ? 32 : sb, sb_hi = sb > 32 ? 1 : 0;
+        if (type == 0) {
+            const int32_t v = get(c, 0, w);
+            bw_round(lane == 0 ? (uint32_t)(v < 0) : 0, lane == 0 ? sb_hi : 0, lane == 0 ? ((uint32_t)v & mask) : 0, lane == 0 ? sb_lo : 0,
+                     lane == 0 ? sb_lo : 0);
+            return;
+        }
         if (type == 1) {
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                 const uint32_t i = i0 + lane;
                 const bool on = i < n;
-                bw_round(0, 0, on ? ((uint32_t)get(c, i, w) & mask) : 0, on ? sb : 0, on ? sb : 0);
+                const int32_t v = on ? get(c, i, w) : 0;
+                bw_round(on ? (uint32_t)(v < 0) : 0, on ? sb_hi : 0, on ? ((uint32_t)v & mask) : 0, on ? sb_lo : 0, on ? sb_lo : 0);
             }
             return;
         }
         {   // warm-up samples
             const bool on = (uint32_t)lane < order;
-            bw_round(0, 0, on ? ((uint32_t)get(c, lane, w) & mask) : 0, on ? sb : 0, on ? sb : 0);
+            const int32_t v = on ? get(c, lane, w) : 0;
+            bw_round(on ? (uint32_t)(v < 0) : 0, on ? sb_hi : 0, on ? ((uint32_t)v & mask) : 0, on ? sb_lo : 0, on ? sb_lo : 0);
         }
         const int32_t *q = d->q;
         const int shift = d->shift;
@@ -1020,6 +1044,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
     auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
     e.s0 = (int32_t *)carve((size_t)P.sig_stride * 4);
     e.s1 = (int32_t *)carve((size_t)P.sig_stride * 4);
+    e.sstr = 1;
     e.dbuf = (double *)carve(P.lds_dbuf_bytes);
     e.autoc = (double *)carve((size_t)FG_MAX_CAND * P.nvec * (FG_MAX_ORDER + 1) * 8);
     e.qres = (int32_t *)carve((size_t)FG_MAX_CAND * P.nvec * FG_MAX_ORDER * 4);

@@ -252,8 +252,9 @@ FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
     if (!e->ctx) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
     FgEncParams P;
     fg_fill_params(s, s.blocksize, false, false, &P);
+    P.sig_stride = 0;   // worst case: samples read in place
     if (fg_enc_lds_bytes(&P) > 160 * 1024) {
-        fg_set_error("blocksize too large for the LDS-staged GPU encoder");
+        fg_set_error("settings need more LDS than the device has");
         return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
     }
     e->blocksize = s.blocksize; e->qlp_precision = s.qlp_coeff_precision; e->do_mid_side = s.do_mid_side;

@@ -250,4 +250,9 @@ class OneShotDecoder(_Decoder):
         while len(self._buffer) > 0:
             _L.FLAC__stream_decoder_process_single(self._decoder)
         self._done = True
+        self._event.set()
+        # The reference stops here (pyflac/decoder.py:387-391), which drops the frames libFLAC still holds in its
+        # read buffer.  This library reads in larger units, so the remainder is drained explicitly: every frame of
+        # the buffer is delivered.
+        _L.FLAC__stream_decoder_process_until_end_of_stream(self._decoder)
         super().finish()

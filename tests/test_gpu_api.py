@@ -1,0 +1,204 @@
+"""The pyFLAC-compatible classes over the GPU library.  These mirror the reference's own suites
+(tests/test_encoder.py, tests/test_decoder.py: callbacks fire, exception types and messages) and add the
+bit-exactness the reference only asserts in examples/passthrough.py:76."""
+import os
+import pathlib
+import tempfile
+import time
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+DEFAULT_SAMPLE_RATE = 44100
+DEFAULT_BLOCKSIZE = 1024
+
+
+@pytest.fixture(scope='module')
+def wavs():
+    """WAV inputs rebuilt from the reference's FLAC fixtures (the WAVs themselves are not copied)."""
+    from pyflac_amd import wav
+    d = tempfile.mkdtemp()
+    out = {}
+    for name in ('mono', 'stereo', 'surround', '32bit'):
+        pcm, sr, bps = cases.fixture_pcm(name)
+        p = pathlib.Path(d) / (name + '.wav')
+        wav.write(p, cases.as_int_array(pcm, bps), sr)
+        out[name] = (p, pcm, sr, bps)
+    return out
+
+
+class TestStreamEncoder:
+    def _mk(self, **kw):
+        import pyflac_amd
+        self.calls = []
+        args = dict(sample_rate=DEFAULT_SAMPLE_RATE, blocksize=DEFAULT_BLOCKSIZE, verify=True,
+                    write_callback=lambda b, n, s, f: self.calls.append((b, n, s, f)))
+        args.update(kw)
+        return pyflac_amd.StreamEncoder(**args)
+
+    def test_state_and_type_error(self):
+        import pyflac_amd
+        enc = self._mk()
+        assert enc.state == pyflac_amd.EncoderState.UNINITIALIZED
+        assert str(enc.state) == 'FLAC__STREAM_ENCODER_UNINITIALIZED'
+        with pytest.raises(TypeError):
+            enc.process([1, 2, 3, 4])
+
+    @pytest.mark.parametrize('kw,regex', [
+        (dict(sample_rate=2000000), 'INVALID_SAMPLE_RATE'), (dict(blocksize=1000000), 'INVALID_BLOCK_SIZE'),
+        (dict(blocksize=65535), 'NOT_STREAMABLE'),
+        (dict(seek_callback=lambda off: None), 'INVALID_CALLBACKS')])
+    def test_init_errors(self, kw, regex):
+        import pyflac_amd
+        enc = self._mk(**kw)
+        with pytest.raises(pyflac_amd.EncoderInitException, match=regex):
+            enc.process(np.zeros((100, 2), np.int16))
+
+    def test_lax_blocksize_ok(self):
+        enc = self._mk(blocksize=65535, streamable_subset=False)
+        enc.process(np.zeros((70000, 2), np.int16))
+        assert enc.finish()
+        assert self.calls
+
+    @pytest.mark.parametrize('shape,dtype', [((DEFAULT_BLOCKSIZE * 3 + 7,), np.int16), ((DEFAULT_BLOCKSIZE * 3, 2), np.int16),
+                                             ((DEFAULT_BLOCKSIZE * 2, 2), np.int32)])
+    def test_process_shapes(self, shape, dtype):
+        """Like the reference's tests: rand() in [0,1) truncates to zeros -> CONSTANT subframes."""
+        enc = self._mk()
+        enc.process(np.random.rand(*shape).astype(dtype))
+        assert enc.finish()
+        assert len(self.calls) >= 4 and self.calls[0][0] == b'fLaC'
+
+    def test_seek_tell_metadata_callbacks(self):
+        pos = [0]
+        seeks, metas = [], []
+
+        def w(b, n, s, f):
+            pos[0] += n
+        enc = self._mk(write_callback=w, seek_callback=lambda off: seeks.append(off) or pos.__setitem__(0, off),
+                       tell_callback=lambda: pos[0], metadata_callback=lambda m: metas.append(int(m.data.stream_info.total_samples)))
+        x = (3000 * np.sin(np.arange(5000) * 0.05)).astype(np.int16)
+        enc.process(x)
+        assert enc.finish()
+        assert seeks and metas == [5000]
+
+    def test_callback_sequence_and_bytes_match_libflac(self, golden, small_streams):
+        """the exact callback sequence of config 1, byte for byte."""
+        import pyflac_amd
+        pcm, _ = cases.make_pcm({'kind': 'cfg1'})
+        calls = []
+        enc = pyflac_amd.StreamEncoder(44100, lambda b, n, s, f: calls.append((b, n, s, f)), compression_level=5, blocksize=0)
+        for i in range(0, len(pcm), 3000):     # output must not depend on how process() calls are chunked
+            enc.process(pcm[i:i + 3000])
+        assert enc.finish()
+        g = golden['cfg1_passthrough']
+        assert [[c[1], c[2], c[3]] for c in calls] == g['callbacks']
+        assert b''.join(c[0] for c in calls) == small_streams['cfg1_passthrough']
+
+    def test_look_ahead_of_one_sample(self):
+        """libFLAC emits a frame only once blocksize+1 samples are buffered."""
+        enc = self._mk(blocksize=1024)
+        enc.process(np.zeros((2048, 1), np.int16))
+        assert len(self.calls) == 3 + 1
+        enc.process(np.zeros((1, 1), np.int16))
+        assert len(self.calls) == 3 + 2
+        assert enc.finish()
+
+    def test_24_bit_extension(self):
+        import pyflac_amd
+        from oracle import oracle as O
+        pcm, bps = cases.make_pcm({'kind': 'cfg4', 'seconds': 0.3})
+        chunks = []
+        enc = pyflac_amd.StreamEncoder(96000, lambda b, n, s, f: chunks.append(b), compression_level=8, blocksize=4096, bits_per_sample=24)
+        enc.process(pcm)
+        assert enc.finish()
+        cfg, _ = O.config(8, 2, 24, 96000, 4096)
+        want, _sizes = O.encode_stream(cfg, pcm)
+        assert b''.join(chunks) == want
+
+
+class TestPassthrough:
+    def test_encoder_to_decoder(self):
+        """BASELINE config 1 (examples/passthrough.py): every decoded block equals the input slice."""
+        import pyflac_amd
+        pcm, _ = cases.make_pcm({'kind': 'cfg1'})
+        blocks = []
+        dec = pyflac_amd.StreamDecoder(lambda a, sr, ch, n: blocks.append((a, sr, ch, n)))
+        enc = pyflac_amd.StreamEncoder(44100, lambda b, n, s, f: dec.process(b))
+        enc.process(pcm)
+        enc.finish()
+        dec.finish()
+        got = np.concatenate([b[0] for b in blocks], axis=0)
+        assert got.dtype == np.int16 and np.array_equal(got, pcm)
+        assert all(b[1] == 44100 and b[2] == 1 for b in blocks) and [b[3] for b in blocks] == [4096] * 10 + [3140]
+
+
+class TestFileEncoderDecoder:
+    @pytest.mark.parametrize('name', ['mono', 'stereo', 'surround', '32bit'])
+    def test_file_round_trip(self, wavs, golden, name):
+        import hashlib
+        import pyflac_amd
+        p, pcm, sr, bps = wavs[name]
+        out = pathlib.Path(tempfile.mkdtemp()) / 'o.flac'
+        enc = pyflac_amd.FileEncoder(p, out, blocksize=0, verify=True)
+        data = enc.process()
+        assert data is not None and data[:4] == b'fLaC'
+        assert hashlib.sha256(data).hexdigest() == golden['fixture_%s_l5' % name]['file_sha256']
+        dec = pyflac_amd.FileDecoder(out)
+        audio, rate = dec.process()
+        assert rate == sr and np.array_equal(audio.astype(np.int64), np.asarray(pcm).reshape(audio.shape))
+
+    def test_missing_input_raises(self):
+        import pyflac_amd
+        with pytest.raises(pyflac_amd.DecoderInitException, match='ERROR_OPENING_FILE'):
+            pyflac_amd.FileDecoder(pathlib.Path('/nonexistent/file.flac'))
+
+    def test_8bit_raises(self):
+        """bits-per-sample other than 16/32 raise through the Python API (pyflac/decoder.py:502-503)."""
+        import pyflac_amd
+        dec = pyflac_amd.FileDecoder(pathlib.Path(cases.GOLDEN) / 'data' / '8bit.flac')
+        with pytest.raises(pyflac_amd.DecoderProcessException):
+            dec.process()
+
+
+class TestStreamDecoder:
+    def _data(self):
+        with open(os.path.join(cases.GOLDEN, 'data', 'stereo.flac'), 'rb') as f:
+            return f.read()
+
+    def test_random_bytes_raise(self):
+        import pyflac_amd
+        dec = pyflac_amd.StreamDecoder(lambda *a: None)
+        dec.process(os.urandom(100000))
+        time.sleep(0.2)
+        with pytest.raises(pyflac_amd.DecoderProcessException):
+            dec.finish()
+
+    @pytest.mark.parametrize('chunk', [None, 1024])
+    def test_decode_stereo(self, chunk):
+        import pyflac_amd
+        from oracle import oracle as O
+        data = self._data()
+        want, _ = O.decode_stream(data)
+        blocks = []
+        dec = pyflac_amd.StreamDecoder(lambda a, sr, ch, n: blocks.append(a))
+        if chunk is None:
+            dec.process(data)
+        else:
+            for i in range(0, len(data), chunk):
+                dec.process(data[i:i + chunk])
+        dec.finish()
+        assert np.array_equal(np.concatenate(blocks), want)
+
+    def test_one_shot(self):
+        import pyflac_amd
+        from oracle import oracle as O
+        data = self._data()
+        want, _ = O.decode_stream(data)
+        blocks = []
+        pyflac_amd.OneShotDecoder(lambda a, sr, ch, n: blocks.append(a), data)
+        assert np.array_equal(np.concatenate(blocks), want)

@@ -1,0 +1,65 @@
+"""GPU parity tests of the decoder: reference fixtures, golden libFLAC streams, error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from pyflac_amd import batch
+    return batch.Context(0)
+
+
+def _decode(ctx, data):
+    import torch
+    from pyflac_amd import batch
+    offs, si = batch.index_frames(data)
+    buf = torch.frombuffer(bytearray(data) + bytearray(64), dtype=torch.uint8).cuda()
+    cap = (len(offs) - 1) * max(si.max_blocksize, 16)
+    pcm, status, st = ctx.decode(buf, offs, si.channels, si.bits_per_sample, cap)
+    return pcm.cpu().numpy(), status, si
+
+
+@pytest.mark.parametrize('name', ['mono', 'stereo', 'surround', '32bit', '8bit'])
+def test_reference_fixtures(ctx, name):
+    """tests/data/*.flac of the reference (libFLAC 1.3.3 / 1.4.2 output) decode to the oracle's PCM; the
+    STREAMINFO MD5 pins the PCM for the four pairs the reference ships WAVs for."""
+    from oracle import oracle as O
+    with open(os.path.join(cases.GOLDEN, 'data', name + '.flac'), 'rb') as f:
+        data = f.read()
+    want, res = O.decode_stream(data)
+    got, status, si = _decode(ctx, data)
+    assert int(status[:, 0].max()) == 0
+    assert np.array_equal(got, want)
+    if name != '8bit':
+        assert O.md5_pcm(got, si.bits_per_sample) == bytes(si.md5sum)
+
+
+def test_golden_streams(ctx, small_streams):
+    """Streams produced by the reference's libFLAC 1.4.3 binary (tests/golden/small_streams.npz)."""
+    for name, data in sorted(small_streams.items()):
+        pcm, bps = cases.make_pcm(cases.ENCODE_CASES[name][0])
+        got, status, si = _decode(ctx, data)
+        assert int(status[:, 0].max()) == 0, name
+        assert np.array_equal(got, np.asarray(pcm).astype(np.int32).reshape(got.shape)), name
+
+
+def test_crc_mismatch_gives_silence_and_flag(ctx, small_streams):
+    data = bytearray(small_streams['cfg1_passthrough'])
+    from pyflac_amd import batch
+    offs, _si = batch.index_frames(bytes(data))
+    # corrupt one byte in the middle of frame 3 (index built from the intact stream)
+    data[int(offs[3]) + 40] ^= 0x10
+    import torch
+    buf = torch.frombuffer(data + bytearray(64), dtype=torch.uint8).cuda()
+    pcm, status, st = ctx.decode(buf, offs, 1, 16, 11 * 4096)
+    pcm = pcm.cpu().numpy()
+    assert status[3, 0] != 0 and (status[np.arange(len(status)) != 3, 0] == 0).all()
+    assert not pcm[3 * 4096:4 * 4096].any()
+    want, _ = cases.make_pcm({'kind': 'cfg1'})
+    assert np.array_equal(pcm[:3 * 4096, 0], want[:3 * 4096, 0])
