@@ -433,8 +433,28 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     unsigned long long tail[2] = {0, 0};   // total bytes, OR of error flags
     HIPCHK(hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if ((uint32_t)tail[1] & FG_ERR_REDO) {
+        // blocks the specialised kernel declined (wasted bits): encode them with the generic kernel and rescan
+        std::vector<FgBlockResult> r(nblocks);
+        HIPCHK(hipMemcpyAsync(r.data(), c->results.p, (size_t)nblocks * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<FgBlockDesc> redo;
+        for (uint32_t i = 0; i < nfast; i++) if (r[descs[i].out_slot].err & FG_ERR_REDO) redo.push_back(descs[i]);
+        if (!redo.empty()) {
+            HIPCHK(hipMemcpyAsync(c->descs.p, redo.data(), redo.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+            if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, (uint32_t)redo.size(), (uint8_t *)c->slots.p,
+                                 (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {
+                fg_set_error("encode kernel launch failed"); return false;
+            }
+            if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
+                fg_set_error("scan kernel launch failed"); return false;
+            }
+            HIPCHK(hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
     st->total_bytes = tail[0];
-    st->error_flags = (uint32_t)tail[1];
+    st->error_flags = (uint32_t)tail[1] & ~FG_ERR_REDO;
     c->last_nblocks = nblocks;
     if (d_out) {
         if (tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }

@@ -15,6 +15,7 @@
 #define FG_ERR_SLOT 2u         // frame did not fit its output slot
 #define FG_ERR_SIDE33 4u       // 33-bit side channel (32-bit stereo input) not representable
 #define FG_ERR_INTERNAL 8u
+#define FG_ERR_REDO 16u         // not an error: the specialised kernel hands this block to the generic kernel
 
 struct FgEncParams {
     uint32_t channels, bps, sample_rate, blocksize;

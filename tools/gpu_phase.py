@@ -5,7 +5,7 @@ import numpy as np, torch
 from pyflac_amd import batch, synth, _lib
 
 ctx = batch.Context(0)
-for level, secs in ((5, 2.0), (8, 2.0), (5, 120.0)):
+for level, secs in ((5, 2.0), (8, 2.0), (5, 600.0)):
     pcm = synth.config2_stereo16(secs, 0)
     t = torch.from_numpy(pcm.astype(np.int32)).cuda()
     s = batch.settings(level, 2, 16, 48000, 4096)
@@ -15,7 +15,8 @@ for level, secs in ((5, 2.0), (8, 2.0), (5, 120.0)):
     recs = ctx.debug_records(0, min(nb, 2000))
     T = np.array([[r.t[k] for k in range(10)] for r in recs], dtype=np.float64)
     d = np.diff(T, axis=1)
-    names = ['stage', 'wasted+fixedsums', 'fixed eval', 'autocorr', 'lpc_decide', 'lpc eval', 'choose', 'pack', 'crc/finish']
+    names = ['stage', 'sums+baseline', '-', 'autocorr', 'lpc_decide', 'eval(fixed+lpc)', 'choose', 'pack', 'crc/finish']
+    T[:, 3] = T[:, 2]
     tot = (T[:, 9] - T[:, 0]).mean()
     print('level %d, %d blocks, kernel %.3f ms; mean clock64 ticks per stage:' % (level, nb, st.encode_kernel_ms))
     for k, nme in enumerate(names):

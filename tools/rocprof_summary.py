@@ -26,7 +26,7 @@ for f in find('*counter_collection.csv'):
             acc[k][row.get('Counter_Name', '?')].append(float(row.get('Counter_Value', 0)))
     print(os.path.relpath(f, root))
     for k, d in acc.items():
-        if 'encode' not in k and 'decode' not in k:
+        if 'fg_' not in k:
             continue
         print('  ', k[:90])
         for c, v in sorted(d.items()):
