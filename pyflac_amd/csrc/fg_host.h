@@ -30,10 +30,12 @@ int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_o
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
-int fg_launch_decode_fast(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_scratch,
-                          FgDecResult *d_results, int wide, hipStream_t stream);
-int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, const int32_t *d_scratch,
-                            int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, uint32_t interleave, hipStream_t stream);
+int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
+                          int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
+                          hipStream_t stream);
+int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels,
+                            const int32_t *d_scratch, const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results,
+                            const uint16_t *d_crctab, uint32_t interleave, int wide, unsigned long long *d_prof, hipStream_t stream);
 }
 
 void fg_set_error(const std::string &msg);
@@ -59,7 +61,7 @@ struct flacgpu_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch;
+        dec_scratch, dec_subs, dec_prof;
     std::vector<float> h_windows;
     std::vector<WindowEntry> win_index;
     bool windows_dirty = false;

@@ -77,6 +77,15 @@ struct FgDecFrame {
     uint32_t channels, ca, bps;
 };
 
+// Per-subframe predictor description handed from the parse kernel to the restore kernel.
+struct FgDecSub {
+    uint32_t order;        // samples stored verbatim at the start of the subframe (0 for CONSTANT / VERBATIM)
+    int32_t shift;
+    uint32_t wasted;
+    uint32_t flags;
+    int32_t q[12];         // FIR coefficients (quantised LPC, or the binomial coefficients of a fixed predictor)
+};
+
 struct FgDecResult {
     uint32_t err;          // 0 ok, 1 malformed, 2 crc16 mismatch
     uint32_t crc;

@@ -1,14 +1,21 @@
-// flac_dec_fast.hip -- register-resident FLAC frame decoder for gfx950 (the common shapes).
+// flac_dec_fast.hip -- FLAC frame decoder for gfx950 (the common shapes), split by the two serial recurrences of the format:
 //
-//   fg_dec_frames_kernel   lane = frame.  Per-lane bit reader with two words of register prefetch; Rice decode;
-//                          fixed and LPC restoration unified as an FIR over a register shift history with up
-//                          to 12 taps (coefficients and history in VGPRs, no LDS, no scratch).  Writes
-//                          frame-planar samples (wasted bits already undone).  Frames using features outside
-//                          this kernel (predictor order > 12, > 32-bit subframes) are flagged status 3 and
-//                          redone by fg_decode_slow_kernel (flac_dec_kernels.hip).
+//   fg_dec_rice_kernel     lane = frame: the bit-serial part.  Each lane walks its frame with a register bit window fed by a
+//                          four-word prefetch queue, parses the subframe headers and delimits the Rice codes.  Per code it only
+//                          finds the code length (count-leading-zeros + k) and parks the 32-bit window in an LDS tile; the wave
+//                          then turns a whole tile of windows into residuals in parallel (quotient/remainder split, zig-zag undo)
+//                          and writes it to the residual plane with coalesced stores.  The number of frames per wave is a launch
+//                          parameter: a single stream has few thousand frames, so waves are kept narrow to spread the serial
+//                          chains over all SIMDs; large batches use all 64 lanes.
 //   fg_dec_crc_kernel      wave = frame: CRC-16 over the frame bytes, 64 lanes over interleaved 32-bit groups.
-//   fg_dec_finish_kernel   workgroup = frame: stereo undo + interleave (or planar copy), zeros for bad frames
-//                          (libFLAC delivers silence on a CRC mismatch).
+//   fg_dec_restore_kernel  lane = (frame, channel): the prediction recurrence.  Residual tiles come in through LDS with coalesced
+//                          loads; fixed and LPC restoration are one FIR over a register history of up to 12 samples addressed
+//                          statically (the loop is unrolled by the history length, no register moves); the finished tile is
+//                          written back with the stereo decorrelation undone and the channels interleaved (or frame-planar),
+//                          zeros for frames that failed (libFLAC delivers silence on a CRC mismatch).
+//
+// Frames using features outside these kernels (predictor order > 12, > 32-bit subframes) are flagged status 3 and redone by
+// fg_decode_slow_kernel (flac_dec_kernels.hip).
 //
 // Reference path replaced: read_subframe_*, read_residual_partitioned_rice_, FLAC__fixed_restore_signal,
 // FLAC__lpc_restore_signal, undo_channel_coding inside libFLAC.
@@ -21,47 +28,100 @@
 using namespace fgdev;
 
 #define FG_DMAXO 12
+#define FG_TS 64            // residual tile of the parse kernel (samples per lane)
+#define FG_TSTR 65          // its LDS row stride (words)
 
 namespace {
 
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
 
-// MSB-first bit reader.  Invariant between calls: avail >= 32, so peek() always returns 32 valid bits.
-struct FastBR {
-    const uint32_t *wp;   // next word to prefetch
-    u64 acc;              // left-aligned bit window
-    uint32_t avail;       // valid bits in acc
-    uint32_t pre0, pre1;  // prefetched words (already big-endian swapped)
-    uint32_t pos;         // bits consumed from the frame start
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t > v ? t : v; }
+    return v;
+}
 
-    __device__ __forceinline__ void init(const uint8_t *base, uint32_t start_bit)
+// MSB-first bit reader.  The window is w0, w1 with w2 (byte-swapped) and w3 (raw, just requested from LDS) queued behind; `s` in
+// [0, 31] is 32 minus the bit offset into w0 (offset 1..32), so peek() is one v_alignbit and always returns 32 valid
+// bits, and consuming up to 32 bits advances by at most one word.  The stream reaches the lane through a private ring
+// of 16-byte groups in LDS:
+//   * HBM -> registers: every lane loads the next few aligned groups of its own frame at the start of a residual tile
+//     (issue()), with wave-uniform control flow, and parks them in the ring one tile later (land()) -- the memory
+//     latency is covered by a whole tile of parsing and never sits inside the per-code loop;
+//   * ring -> window: one ds_read per 32 bits consumed, one word ahead of its use.
+// Groups are aligned to 16 bytes in memory, so a load never straddles a page and the group that holds the last stream
+// byte is the last one touched (indices are clamped to it).  consume() checks that the ring holds the next word and
+// fetches synchronously if not (headers, escapes, very long codes); consume_fast() relies on the tile-start
+// guarantee of FG_RAHEAD groups, enough for a tile of codes of at most 32 bits.
+typedef uint32_t fg_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) fg_u32x4 *FgGroupPtr;
+#define FG_RG 64                      // ring capacity in groups (1 KiB per lane)
+#define FG_RSTR (FG_RG * 4)           // ring row stride in words
+#define FG_RAHEAD 20                  // groups guaranteed ahead of the read position at a tile start
+#define FG_RCAP 40                    // never hold more than this many groups ahead
+#define FG_PF 8                       // groups fetched per lane and tile
+
+struct BitRdState { uint32_t w0, w1, w2, w3, s, wb; };
+
+struct BitRd {
+    FgGroupPtr fg;          // group that holds the first byte of the frame
+    uint32_t glim;          // last loadable group index relative to fg
+    uint32_t skip0;         // bit offset of the frame start inside fg[0]
+    uint32_t *ring;         // this lane's ring (LDS, 512-byte aligned)
+    uint32_t w0, w1, w2, w3, s;
+    uint32_t wb;            // byte offset (relative to fg) of the next word to read from the ring; w3 = word wb/4 - 1
+    uint32_t H;             // groups below H are in the ring (or already consumed)
+    uint32_t pfH, pfn;      // groups [pfH, pfH + pfn) are in flight
+    fg_u32x4 pf[FG_PF];
+
+    __device__ __forceinline__ fg_u32x4 ldgroup(uint32_t g) const { return fg[g < glim ? g : glim]; }
+    __device__ __forceinline__ void selfload()
     {
-        const uintptr_t a = (uintptr_t)base + (start_bit >> 3);
-        const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
-        const uint32_t skip = (uint32_t)(a & 3) * 8 + (start_bit & 7);
-        const uint32_t w0 = be32(w[0]), w1 = be32(w[1]);
-        pre0 = be32(w[2]); pre1 = be32(w[3]);
-        wp = w + 4;
-        acc = (((u64)w0 << 32) | w1) << skip;
-        avail = 64 - skip;
-        pos = start_bit;
-        if (avail < 32) refill();
+        const fg_u32x4 v = ldgroup(H);
+        *(fg_u32x4 *)&ring[(H & (FG_RG - 1)) * 4] = v;
+        H++;
     }
-    __device__ __forceinline__ void refill()
+    __device__ __forceinline__ uint32_t ringword() const { return *(const uint32_t *)((const char *)ring + (wb & (FG_RG * 16 - 1))); }
+    __device__ __forceinline__ void save(BitRdState &t) const { t.w0 = w0; t.w1 = w1; t.w2 = w2; t.w3 = w3; t.s = s; t.wb = wb; }
+    __device__ __forceinline__ void restore(const BitRdState &t) { w0 = t.w0; w1 = t.w1; w2 = t.w2; w3 = t.w3; s = t.s; wb = t.wb; }
+    __device__ __forceinline__ uint32_t fetch()
     {
-        acc |= (u64)pre0 << (32 - avail);
-        avail += 32;
-        pre0 = pre1;
-        pre1 = be32(*wp);
-        wp++;
+        while ((wb >> 4) >= H) selfload();
+        const uint32_t x = ringword();
+        wb += 4;
+        return x;
     }
-    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)(acc >> 32); }
+    __device__ __forceinline__ void init(FgGroupPtr frame_group, uint32_t group_limit, uint32_t frame_bit0, uint32_t start_bit, uint32_t *lds_ring)
+    {
+        fg = frame_group; glim = group_limit; skip0 = frame_bit0; ring = lds_ring;
+        const uint32_t b = frame_bit0 + start_bit;
+        const uint32_t w = b >> 5, sk = b & 31;
+        wb = w * 4; H = w >> 2; pfH = H; pfn = 0;
+        w0 = 0;
+        if (sk) w0 = be32(fetch());
+        w1 = be32(fetch());
+        w2 = be32(fetch());
+        w3 = fetch();
+        s = (32 - sk) & 31;
+    }
+    // bits consumed since the frame start
+    __device__ __forceinline__ uint32_t pos() const { return 8u * wb - 96u - s - skip0; }
+    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w0, w1, s); }
     __device__ __forceinline__ void consume(uint32_t n)   // n <= 32
     {
-        acc = (n < 32) ? (acc << n) : (acc << 31) << 1;
-        avail -= n;
-        pos += n;
-        if (avail < 32) refill();
+        s -= n;
+        if ((int32_t)s < 0) { s += 32; w0 = w1; w1 = w2; w2 = be32(w3); w3 = fetch(); }
+    }
+    // straight-line variant for the per-code loop (no availability check, see FG_RAHEAD)
+    __device__ __forceinline__ void consume_fast(uint32_t n)
+    {
+        s -= n;
+        const bool adv = (int32_t)s < 0;
+        s &= 31;
+        w0 = adv ? w1 : w0;
+        w1 = adv ? w2 : w1;
+        if (adv) { w2 = be32(w3); w3 = ringword(); wb += 4; }
     }
     __device__ __forceinline__ uint32_t bits(uint32_t n)   // n <= 32
     {
@@ -84,140 +144,264 @@ struct FastBR {
             const uint32_t p = peek();
             if (p) { const uint32_t l = (uint32_t)__clz(p); z += l; consume(l + 1); return z; }
             z += 32; consume(32);
-            if (pos > limit_bits) return z;
+            if (pos() > limit_bits) return z;
         }
+    }
+    // tile start, step 1: park the groups requested one tile ago
+    __device__ __forceinline__ void land()
+    {
+#pragma unroll
+        for (int t = 0; t < FG_PF; t++) {
+            const uint32_t g = pfH + t;
+            if ((uint32_t)t < pfn && g >= H) *(fg_u32x4 *)&ring[(g & (FG_RG - 1)) * 4] = pf[t];
+        }
+        if (pfH + pfn > H) H = pfH + pfn;
+        pfn = 0;
+    }
+    // tile start, step 2 (lanes that will parse): guarantee the look-ahead, then request the next groups
+    __device__ __forceinline__ void issue(bool on)
+    {
+        const uint32_t cg = wb >> 4;
+        if (on) while (H < cg + FG_RAHEAD) selfload();
+        pfH = H;
+        pfn = 0;
+        if (on && H < cg + FG_RCAP) { pfn = cg + FG_RCAP - H; if (pfn > FG_PF) pfn = FG_PF; }
+#pragma unroll
+        for (int t = 0; t < FG_PF; t++) if ((uint32_t)t < pfn) pf[t] = ldgroup(H + t);
     }
 };
 
-template <bool WIDE>
+__device__ __forceinline__ int32_t unzig(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
+
+// ------------------------------------------------------------------------------------------------ parse
+// Tile protocol (LDS): tile[row][col] holds either a finished value or the 32-bit window at the start of a Rice code
+// ("window form": leading zeros = quotient, then the stop bit, then k remainder bits).  rowk[row] = k when the tile is in
+// window form, 0xFF when every entry is a finished value, 0xFE when the subframe is CONSTANT (value in rowc[row]);
+// a 64-bit mask marks entries of a window-form tile that are finished values anyway.  The per-row facts stay in the
+// registers of the owning lane; the flush reads them with v_readlane (rows are visited in wave-uniform order).
 __global__ void __launch_bounds__(64)
-fg_dec_frames_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch, FgDecResult *results)
+fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
+                   int32_t *scratch, FgDecSub *subs, FgDecResult *results, u64 *prof)
 {
-    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= nframes) return;
-    const FgDecFrame fr = frames[f];
-    if (fr.bytes == 0) return;                        // header already rejected
+    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
+    uint32_t *rings = dsm;                       // G rows of FG_RSTR words
+    uint32_t *tile = dsm + G * FG_RSTR;          // G rows of FG_TSTR words
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x * G + lane;
+    const bool mine = (uint32_t)lane < G && f < nframes;
+    FgDecFrame fr;
+    fr.byte_off = 0; fr.out_off = 0; fr.bytes = 0; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0;
+    if (mine) fr = frames[f];
+    const bool accepted = mine && fr.bytes != 0;          // the header pass rejects frames by zeroing `bytes`
+    bool alive = accepted;
     uint32_t err = 0;
+    if (alive && fr.bytes < fr.hdr_bytes + 2) { err = 1; alive = false; }
     const uint32_t n = fr.n, C = fr.channels;
-    int32_t *planar = scratch + fr.out_off * C;
-    if (fr.bytes < fr.hdr_bytes + 2) { results[f].err = 1; return; }
-    const uint32_t end_bits = (fr.bytes - 2) * 8;
-    FastBR br;
-    br.init(stream + fr.byte_off, fr.hdr_bytes * 8);
-    for (uint32_t ch = 0; ch < C && !err; ch++) {
-        uint32_t sb = fr.bps;
-        if ((fr.ca == 1 && ch == 1) || (fr.ca == 2 && ch == 0) || (fr.ca == 3 && ch == 1)) sb++;
-        const uint32_t hdr = br.bits(8);
-        uint32_t wasted = 0;
-        if (hdr & 0x80) { err = 1; break; }
-        if (hdr & 1) { wasted = br.unary(end_bits) + 1; if (wasted >= sb) { err = 1; break; } sb -= wasted; }
-        if (sb > 32) { err = 3; break; }
-        const uint32_t t = (hdr >> 1) & 0x3F;
-        int32_t *dst = planar + (size_t)ch * n;
-        // mode 0 constant, 1 verbatim, 2 predicted
-        uint32_t mode, order = 0;
-        if (t == 0) mode = 0;
-        else if (t == 1) mode = 1;
-        else if (t >= 8 && t <= 12) { mode = 2; order = t & 7; }
-        else if (t >= 32) { mode = 2; order = (t & 31) + 1; }
-        else { err = 1; break; }
-        if (order > n) { err = 1; break; }
-        if (order > FG_DMAXO) { err = 3; break; }
-        if (mode == 0) {
-            const int32_t v = (int32_t)((uint32_t)br.sbits(sb) << wasted);
-            for (uint32_t i = 0; i < n; i++) dst[i] = v;
-            continue;
-        }
-        if (mode == 1) {
-            for (uint32_t i = 0; i < n; i++) dst[i] = (int32_t)((uint32_t)br.sbits(sb) << wasted);
-            if (br.pos > end_bits) err = 1;
-            continue;
-        }
-        // predicted: warm-up, coefficients, Rice-coded residual
-        int32_t h[FG_DMAXO], q[FG_DMAXO];
-#pragma unroll
-        for (int j = 0; j < FG_DMAXO; j++) { h[j] = 0; q[j] = 0; }
-        for (uint32_t i = 0; i < order; i++) {
-            const int32_t v = br.sbits(sb);
-            dst[i] = (int32_t)((uint32_t)v << wasted);
-#pragma unroll
-            for (int j = FG_DMAXO - 1; j > 0; j--) h[j] = h[j - 1];
-            h[0] = v;
-        }
-        int shift = 0;
-        if (t >= 32) {
-            const uint32_t prec = br.bits(4) + 1;
-            if (prec == 16) { err = 1; break; }
-            shift = br.sbits(5);
-            if (shift < 0) { err = 1; break; }
-#pragma unroll
-            for (int j = 0; j < FG_DMAXO; j++) if ((uint32_t)j < order) q[j] = br.sbits(prec);
-        }
-        else {
-            // fixed predictor of order k as FIR with binomial coefficients
-            const int32_t FX[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
-#pragma unroll
-            for (int j = 0; j < 4; j++) q[j] = (order == 0) ? 0 : (order == 1) ? FX[1][j] : (order == 2) ? FX[2][j] : (order == 3) ? FX[3][j] : FX[4][j];
-        }
-        const uint32_t method = br.bits(2);
-        if (method > 1) { err = 1; break; }
-        const uint32_t po = br.bits(4);
-        const uint32_t plen = method ? 5 : 4, esc = method ? 31 : 15;
-        const uint32_t psz = n >> po;
-        if ((po > 0 && ((n & ((1u << po) - 1)) != 0 || psz < order)) || (po == 0 && n < order)) { err = 1; break; }
-        uint32_t left = 0, part = 0, k = 0, raw = 0;
-        bool is_esc = false;
-        for (uint32_t i = order; i < n; i++) {
-            while (left == 0) {
-                left = (po == 0) ? (n - order) : ((part == 0) ? (psz - order) : psz);
-                part++;
-                k = br.bits(plen);
-                is_esc = (k == esc);
-                if (is_esc) raw = br.bits(5);
-            }
-            left--;
-            int32_t r;
-            if (is_esc) r = br.sbits(raw);
-            else {
-                const uint32_t p = br.peek();
-                const uint32_t lz = p ? (uint32_t)__clz(p) : 32;
-                uint32_t u;
-                if (lz + 1 + k <= 32) {
-                    const uint32_t rest = (lz + 1 < 32) ? (p << (lz + 1)) : 0;
-                    u = (lz << k) | (k ? (rest >> (32 - k)) : 0);
-                    br.consume(lz + 1 + k);
-                }
+    const uint32_t Cmax = wave_max32(alive ? C : 0), nmax = wave_max32(alive ? n : 0);
+    const uint32_t end_bits = alive ? (fr.bytes - 2) * 8 : 0;
+    BitRd br;
+    br.fg = nullptr; br.glim = 0; br.skip0 = 0; br.ring = rings; br.w0 = 0; br.w1 = 0; br.w2 = 0; br.w3 = 0; br.s = 0; br.wb = 12; br.H = 0;
+    br.pfH = 0; br.pfn = 0;
+    if (alive) {
+        const uintptr_t sa = (uintptr_t)stream;
+        const FgGroupPtr gbase = (FgGroupPtr)(sa & ~(uintptr_t)15);
+        const u64 mis = (u64)(sa & 15);
+        const u64 total_groups = (mis + stream_len + 15) >> 4;
+        const u64 fb = mis + fr.byte_off;
+        const u64 g0 = fb >> 4;
+        const u64 room = total_groups > g0 ? total_groups - g0 - 1 : 0;
+        br.init(gbase + g0, room > 0x0FFFFFF0ull ? 0x0FFFFFF0u : (uint32_t)room, (uint32_t)(fb & 15) * 8, fr.hdr_bytes * 8,
+                rings + lane * FG_RSTR);
+    }
+
+    u64 tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? clock64() : 0;
+#define FG_TICK(i) do { if (prof) { const u64 now_ = clock64(); tp[i] += now_ - tlast; tlast = now_; } } while (0)
+    FG_TICK(0);
+    for (uint32_t ch = 0; ch < Cmax; ch++) {
+        // ---------------- subframe header (per lane)
+        uint32_t kind = 0;              // 0 idle (constant / dead), 1 Rice-coded residual, 2 verbatim
+        uint32_t order = 0, sb = 0, k = 0, raw = 0, po = 0, psz = 0, plen = 4, escv = 15, pend = 0, part = 0;
+        u64 mask0 = 0;
+        uint32_t cval = 0;
+        bool is_esc = false, aligned = false, isconst = false;
+        const bool on = alive && ch < C;
+        if (on) {
+            FgDecSub *sd = &subs[(size_t)f * C + ch];
+            sb = fr.bps;
+            if ((fr.ca == 1 && ch == 1) || (fr.ca == 2 && ch == 0) || (fr.ca == 3 && ch == 1)) sb++;
+            const uint32_t hdr = br.bits(8);
+            uint32_t wasted = 0;
+            if (hdr & 0x80) err = 1;
+            if (!err && (hdr & 1)) { wasted = br.unary(end_bits) + 1; if (wasted >= sb) err = 1; else sb -= wasted; }
+            if (!err && sb > (narrow ? 24u : 32u)) err = 3;
+            const uint32_t t = (hdr >> 1) & 0x3F;
+            uint32_t mode = 0;
+            if (t == 0) mode = 0;
+            else if (t == 1) mode = 1;
+            else if (t >= 8 && t <= 12) { mode = 2; order = t & 7; }
+            else if (t >= 32) { mode = 2; order = (t & 31) + 1; }
+            else if (!err) err = 1;
+            if (!err && order > n) err = 1;
+            if (!err && order > FG_DMAXO) err = 3;
+            int shift = 0;
+            if (!err) {
+                if (mode == 0) { isconst = true; cval = (uint32_t)br.sbits(sb); order = 0; }
+                else if (mode == 1) { kind = 2; order = 0; }
                 else {
-                    const uint32_t msb = br.unary(end_bits);
-                    u = (msb << k) | br.bits(k);
+                    for (uint32_t i = 0; i < order; i++) tile[lane * FG_TSTR + i] = (uint32_t)br.sbits(sb);
+                    mask0 = ((u64)1 << order) - 1;      // order <= 12 here
+                    if (t >= 32) {
+                        const uint32_t prec = br.bits(4) + 1;
+                        if (prec == 16) err = 1;
+                        shift = br.sbits(5);
+                        if (shift < 0) err = 1;
+                        // the 32-bit restore is exact only under libFLAC's own width rule (lpc.c: bps + precision + ilog2(order) <= 32)
+                        if (!err && narrow && sb + prec + ilog2_32(order) > 32) err = 3;
+                        if (!err) for (uint32_t j = 0; j < order; j++) sd->q[j] = br.sbits(prec);
+                    }
+                    else {
+                        // fixed predictor of order k as FIR with binomial coefficients
+                        const int32_t c0 = (int32_t)order, c1 = order < 2 ? 0 : (order == 2 ? -1 : order == 3 ? -3 : -6);
+                        const int32_t c2 = order < 3 ? 0 : (order == 3 ? 1 : 4), c3 = order < 4 ? 0 : -1;
+                        sd->q[0] = c0; sd->q[1] = c1; sd->q[2] = c2; sd->q[3] = c3;
+                    }
+                    if (!err) {
+                        const uint32_t method = br.bits(2);
+                        if (method > 1) err = 1;
+                        po = br.bits(4);
+                        plen = method ? 5 : 4; escv = method ? 31 : 15;
+                        psz = n >> po;
+                        if ((po > 0 && ((n & ((1u << po) - 1)) != 0 || psz < order)) || (po == 0 && n < order)) err = 1;
+                        aligned = po == 0 || (psz % FG_TS) == 0;
+                        pend = order;
+                        kind = 1;
+                    }
                 }
-                r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
             }
-            int32_t v;
-            if (!WIDE) {
-                int32_t sum = 0;
-#pragma unroll
-                for (int j = 0; j < FG_DMAXO; j++) sum += q[j] * h[j];
-                v = r + (sum >> shift);
+            if (err) { alive = false; kind = 0; isconst = false; }
+            else { sd->order = order; sd->shift = shift; sd->wasted = wasted; sd->flags = 0; }
+        }
+        uint32_t rn = (on && !err) ? n : 0;                       // samples this lane's row contributes
+        const u64 roff = fr.out_off * C + (u64)ch * n;
+        const uint32_t start = order;
+        FG_TICK(1);
+
+        // ---------------- residual tiles
+        for (uint32_t i0 = 0; i0 < nmax; i0 += FG_TS) {
+            const bool act = alive && kind != 0 && i0 < n;
+            uint32_t tk = 0xFF;
+            u64 tmask = (i0 == 0) ? mask0 : 0;
+            bool fastlane = false;
+            if (act && kind == 1 && aligned && i0 > 0 && i0 + FG_TS <= n) {
+                while (i0 >= pend) {
+                    k = br.bits(plen);
+                    is_esc = (k == escv);
+                    if (is_esc) raw = br.bits(5);
+                    part++;
+                    pend = po == 0 ? n : part * psz;
+                }
+                fastlane = !is_esc;
             }
-            else {
-                i64 sum = 0;
+            if (__any(act)) {
+                br.land();
+                br.issue(act);
+                FG_TICK(2);
+                if (act) {
+                    uint32_t *row = &tile[lane * FG_TSTR];
+                    uint32_t ii = 0;
+                    if (!__any(!fastlane)) {
+                        // every parsing lane sits inside one Rice partition for the whole tile: delimit the codes only
+                        // (straight-line code).  A code that does not fit the window (rare) voids the attempt: the
+                        // reader is rewound and the general loop below decodes the tile.
+                        BitRdState keep;
+                        br.save(keep);
+                        const uint32_t kp1 = k + 1;
+                        uint32_t maxlen = 0;
 #pragma unroll
-                for (int j = 0; j < FG_DMAXO; j++) sum += (i64)q[j] * (i64)h[j];
-                v = (int32_t)((i64)r + (sum >> shift));
+                        for (uint32_t jj = 0; jj < FG_TS; jj++) {
+                            const uint32_t p = br.peek();
+                            const uint32_t len = (uint32_t)__clz(p) + kp1;
+                            maxlen = len > maxlen ? len : maxlen;
+                            row[jj] = p;
+                            br.consume_fast(len);
+                        }
+                        if (__any(maxlen > 32)) br.restore(keep);
+                        else { tk = k; ii = FG_TS; }
+                    }
+                    for (; ii < FG_TS; ii++) {
+                        const uint32_t i = i0 + ii;
+                        if (i < start || i >= n) continue;
+                        int32_t v;
+                        if (kind == 2) v = br.sbits(sb);
+                        else {
+                            while (i >= pend) {
+                                k = br.bits(plen);
+                                is_esc = (k == escv);
+                                if (is_esc) raw = br.bits(5);
+                                part++;
+                                pend = po == 0 ? n : part * psz;
+                            }
+                            if (is_esc) v = br.sbits(raw);
+                            else {
+                                const uint32_t p = br.peek();
+                                const uint32_t lz = (uint32_t)__clz(p);
+                                uint32_t u;
+                                if (lz + 1 + k <= 32) {
+                                    const uint32_t rest = (p << lz) << 1;
+                                    u = (lz << k) | (k ? (rest >> (32 - k)) : 0);
+                                    br.consume(lz + 1 + k);
+                                }
+                                else {
+                                    const uint32_t msb = br.unary(end_bits);
+                                    u = (msb << k) | br.bits(k);
+                                }
+                                v = unzig(u);
+                            }
+                        }
+                        row[ii] = (uint32_t)v;
+                        tmask |= (u64)1 << ii;
+                    }
+                }
             }
-#pragma unroll
-            for (int j = FG_DMAXO - 1; j > 0; j--) h[j] = h[j - 1];
-            h[0] = v;
-            dst[i] = (int32_t)((uint32_t)v << wasted);
-            if (br.pos > end_bits) { err = 1; break; }
+            FG_TICK(3);
+            if (isconst) tk = 0xFE;
+            wave_lds_fence();
+            // ---- cooperative flush: one row per pass, lane = column; the row's facts come from its lane's registers
+            for (uint32_t r = 0; r < G; r++) {
+                const uint32_t rn_s = rl(rn, (int)r);
+                if (i0 >= rn_s) continue;
+                const uint32_t kk = rl(tk, (int)r);
+                const u64 off_s = ((u64)rl((uint32_t)(roff >> 32), (int)r) << 32) | rl((uint32_t)roff, (int)r);
+                const uint32_t i = i0 + (uint32_t)lane;
+                uint32_t val;
+                if (kk == 0xFE) val = rl(cval, (int)r);
+                else {
+                    val = tile[r * FG_TSTR + lane];
+                    if (kk != 0xFF) {
+                        const uint32_t mlo = rl((uint32_t)tmask, (int)r), mhi = rl((uint32_t)(tmask >> 32), (int)r);
+                        const uint32_t done = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1;
+                        const uint32_t lz = (uint32_t)__clz(val);
+                        const uint32_t rest = (val << lz) << 1;
+                        const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                        val = done ? val : (uint32_t)unzig(u);
+                    }
+                }
+                if (i < rn_s) scratch[off_s + i] = (int32_t)val;
+            }
+            wave_lds_fence();
+            if (act && br.pos() > end_bits) { err = 1; alive = false; rn = 0; }
+            FG_TICK(4);
         }
     }
-    if (!err) {
-        const uint32_t endb = (br.pos + 7) & ~7u;
-        if (endb != end_bits) err = 1;
+    if (accepted) {
+        if (!err) {
+            const uint32_t endb = (br.pos() + 7) & ~7u;
+            if (endb != end_bits) err = 1;
+        }
+        results[f].err = err;
     }
-    results[f].err = err;
+    if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t)blockIdx.x * 8 + i] = tp[i];
+#undef FG_TICK
 }
 
 // CRC-16 (poly 0x8005, init 0) of frame bytes [0, bytes-2), compared with the stored big-endian CRC.
@@ -282,64 +466,258 @@ fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfra
     }
 }
 
-// Stereo undo + interleave.  One workgroup per frame.
-__global__ void __launch_bounds__(256)
-fg_dec_finish_kernel(const FgDecFrame *frames, uint32_t nframes, const int32_t *scratch, int32_t *out, const FgDecResult *results,
-                     uint32_t interleave)
+
+// ------------------------------------------------------------------------------------------------ restore
+#define FG_TR 192           // samples per tile and chain: a multiple of both history lengths (8 and 12) and of the pass width
+#define FG_TRS 196          // LDS row stride in words (16-byte aligned rows, rows of neighbouring lanes on different banks)
+#define FG_TP 64            // columns moved per I/O pass (lane = column)
+#define FG_RROWS 32         // chains per wave at most (one prefetch register per row)
+
+// MAXO steps of s[i] = r[i] + ((sum_j q[j] * s[i-1-j]) >> shift).  Sample i lives in history slot i mod MAXO, so every
+// register index below is a compile-time constant.  GATE: the group may still contain warm-up samples (i < order).
+template <int MAXO, bool WIDE, bool GATE>
+__device__ __forceinline__ void restore_group(int32_t (&h)[FG_DMAXO], const int32_t (&q)[FG_DMAXO], int shift, uint32_t order,
+                                              uint32_t ibase, uint32_t *rowp)
 {
-    const uint32_t f = blockIdx.x;
-    if (f >= nframes) return;
-    const FgDecFrame fr = frames[f];
-    if (fr.bytes == 0 || fr.n == 0) return;
-    const uint32_t status = results[f].err;
-    const uint32_t n = fr.n, C = fr.channels, ca = fr.ca;
-    const int32_t *pl = scratch + fr.out_off * C;
-    int32_t *o = out + fr.out_off * C;
-    if (C == 2) {
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            int32_t a = 0, b = 0;
-            if (status == 0) {
-                a = pl[i]; b = pl[n + i];
-                if (ca == 1) b = a - b;
-                else if (ca == 2) a = a + b;
-                else if (ca == 3) {
-                    const i64 side = b;
-                    const i64 mid = (i64)(((u64)(i64)a) << 1) | (side & 1);
-                    a = (int32_t)((mid + side) >> 1);
-                    b = (int32_t)((mid - side) >> 1);
+    int32_t r[MAXO];
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4) {
+        const uint4 t = *(const uint4 *)(rowp + u);
+        r[u] = (int32_t)t.x; r[u + 1] = (int32_t)t.y; r[u + 2] = (int32_t)t.z; r[u + 3] = (int32_t)t.w;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u++) {
+        int32_t pred;
+        if (!WIDE) {
+            int32_t sum = 0;
+#pragma unroll
+            for (int j = MAXO - 1; j >= 0; j--) sum += __mul24(q[j], h[(u - 1 - j + 2 * MAXO) % MAXO]);
+            pred = sum >> shift;
+        }
+        else {
+            i64 sum = 0;
+#pragma unroll
+            for (int j = MAXO - 1; j >= 0; j--) sum += (i64)q[j] * (i64)h[(u - 1 - j + 2 * MAXO) % MAXO];
+            pred = (int32_t)(sum >> shift);
+        }
+        int32_t v = r[u] + pred;
+        if (GATE) v = (ibase + (uint32_t)u >= order) ? v : r[u];
+        h[u] = v;
+        r[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4) *(uint4 *)(rowp + u) = make_uint4((uint32_t)r[u], (uint32_t)r[u + 1], (uint32_t)r[u + 2], (uint32_t)r[u + 3]);
+}
+
+// groups [g0, g1) of the current tile
+template <int MAXO, bool WIDE>
+__device__ __forceinline__ void restore_range(int32_t (&h)[FG_DMAXO], const int32_t (&q)[FG_DMAXO], int shift, uint32_t order,
+                                              bool first_tile, uint32_t g0, uint32_t g1, uint32_t *rowp)
+{
+    for (uint32_t g = g0; g < g1; g++) {
+        if (first_tile && g * MAXO < FG_DMAXO) restore_group<MAXO, WIDE, true>(h, q, shift, order, g * MAXO, rowp + g * MAXO);
+        else restore_group<MAXO, WIDE, false>(h, q, shift, order, 0, rowp + g * MAXO);
+    }
+}
+
+// lane = chain = (frame, channel); G frames per wave, G * C <= FG_RROWS.
+//
+// A tile is moved in three passes of 64 columns.  Per pass the wave loads one register per chain (coalesced, the row's
+// base address and length come from the owning lane with v_readlane), parks it in LDS one phase later, and the phase in
+// between restores a third of the previous data -- HBM latency hides behind the recurrence:
+//   phase 0: land(t,0)  issue(t,1)    restore groups of columns   0.. 63
+//   phase 1: land(t,1)  issue(t,2)    restore groups of columns  64..127   write out pass 0
+//   phase 2: land(t,2)  issue(t+1,0)  restore the rest                     write out passes 1, 2
+// (group boundaries of the 12-tap variant do not fall on pass boundaries; each phase restores the groups that are
+// complete, which is why pass p is written out one phase later.)
+template <bool WIDE>
+__global__ void __launch_bounds__(64)
+fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
+                      int32_t *out, const FgDecResult *results, uint32_t interleave, u64 *prof)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];     // rows of FG_TRS words: chains (rounded up to 8) + 1 spare
+    const int lane = threadIdx.x;
+    const uint32_t chains = G * C;
+    const uint32_t fi = (uint32_t)lane / C, ch = (uint32_t)lane % C;
+    const uint32_t f = blockIdx.x * G + fi;
+    const bool mine = (uint32_t)lane < chains && f < nframes;
+    uint32_t n = 0, status = 1, ca = 0;
+    u64 out_off = 0;
+    if (mine) {
+        const FgDecFrame fr = frames[f];
+        if (fr.bytes != 0 && fr.channels == C) { n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off; }
+    }
+    const bool ok = mine && n != 0 && status == 0;
+    int32_t q[FG_DMAXO], h[FG_DMAXO];
+#pragma unroll
+    for (int j = 0; j < FG_DMAXO; j++) { q[j] = 0; h[j] = 0; }
+    uint32_t order = 0, wasted = 0;
+    int shift = 0;
+    if (ok) {
+        const FgDecSub *sd = &subs[(size_t)f * C + ch];
+        order = sd->order; shift = sd->shift; wasted = sd->wasted;
+#pragma unroll
+        for (int j = 0; j < FG_DMAXO; j++) if ((uint32_t)j < order) q[j] = sd->q[j];
+    }
+    // row facts, read by the I/O passes with v_readlane
+    const uint32_t n_in = ok ? n : 0;                                   // residuals to load
+    const uint32_t n_out = (mine && status != 3) ? n : 0;               // samples to write (status 3: the generic kernel writes)
+    const u64 plane = ok ? out_off * C + (u64)ch * n : 0;               // this chain's residual plane in `scratch`
+    const uint32_t nmax = wave_max32(n_out);
+    const bool big = __any(ok && order > 8);
+    // idle lanes run the recurrence on a spare row behind the real ones
+    uint32_t *rowp = &tile[((uint32_t)lane < chains ? (uint32_t)lane : ((chains + 7) & ~7u)) * FG_TRS];
+    uint32_t pf[FG_RROWS];
+    u64 tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? clock64() : 0;
+#define FG_TICK(i) do { if (prof) { const u64 now_ = clock64(); tp[i] += now_ - tlast; tlast = now_; } } while (0)
+
+    // rows are handled in blocks of eight (no per-row guards, so the loads of a pass stay back to back); rows past
+    // `chains` belong to idle lanes, whose plane is element 0 of the scratch buffer
+    const uint32_t nr8 = (chains + 7) >> 3;
+    auto issue8 = [&](int r0, uint32_t i) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t rn = rl(n_in, r0 + r);
+            const u64 base = ((u64)rl((uint32_t)(plane >> 32), r0 + r) << 32) | rl((uint32_t)plane, r0 + r);
+            pf[r0 + r] = (uint32_t)scratch[base + (i < rn ? i : 0)];
+        }
+    };
+    auto issue = [&](uint32_t i0, uint32_t p) {
+        const uint32_t i = i0 + p * FG_TP + (uint32_t)lane;
+        issue8(0, i);
+        if (nr8 > 1) issue8(8, i);
+        if (nr8 > 2) issue8(16, i);
+        if (nr8 > 3) issue8(24, i);
+    };
+    auto land8 = [&](int r0, uint32_t p) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) tile[(r0 + r) * FG_TRS + p * FG_TP + lane] = pf[r0 + r];
+    };
+    auto land = [&](uint32_t p) {
+        land8(0, p);
+        if (nr8 > 1) land8(8, p);
+        if (nr8 > 2) land8(16, p);
+        if (nr8 > 3) land8(24, p);
+        wave_lds_fence();
+    };
+    auto writeout = [&](uint32_t i0, uint32_t p) {
+        const uint32_t col = p * FG_TP + (uint32_t)lane, i = i0 + col;
+        if (C == 2) {
+            for (uint32_t g = 0; g < G; g++) {
+                const int r0 = (int)(2 * g);
+                const uint32_t rn = rl(n_out, r0);
+                if (i0 + p * FG_TP >= rn) continue;
+                const uint32_t okr = rl(n_in, r0), cc = rl(ca, r0), wa = rl(wasted, r0), wb = rl(wasted, r0 + 1);
+                const u64 oo = ((u64)rl((uint32_t)(out_off >> 32), r0) << 32) | rl((uint32_t)out_off, r0);
+                int32_t a = 0, b = 0;
+                if (okr) {
+                    a = (int32_t)(tile[r0 * FG_TRS + col] << wa);
+                    b = (int32_t)(tile[(r0 + 1) * FG_TRS + col] << wb);
+                    if (cc == 1) b = a - b;
+                    else if (cc == 2) a = a + b;
+                    else if (cc == 3) {
+                        const i64 side = b;
+                        const i64 mid = (i64)(((u64)(i64)a) << 1) | (side & 1);
+                        a = (int32_t)((mid + side) >> 1);
+                        b = (int32_t)((mid - side) >> 1);
+                    }
+                }
+                if (i < rn) {
+                    int32_t *o = out + oo * 2;
+                    if (interleave) ((int2 *)o)[i] = make_int2(a, b);
+                    else { o[i] = a; o[rn + i] = b; }
                 }
             }
-            if (interleave) ((int2 *)o)[i] = make_int2(a, b);
-            else { o[i] = a; o[n + i] = b; }
         }
-    }
-    else {
-        for (uint32_t j = threadIdx.x; j < n * C; j += 256) {
-            const uint32_t c = j / n, i = j % n;
-            const int32_t v = status == 0 ? pl[j] : 0;
-            if (interleave) o[(size_t)i * C + c] = v; else o[j] = v;
+        else {
+            for (uint32_t r = 0; r < chains; r++) {
+                const uint32_t rn = rl(n_out, (int)r);
+                if (i0 + p * FG_TP >= rn) continue;
+                const uint32_t okr = rl(n_in, (int)r), wa = rl(wasted, (int)r);
+                const u64 oo = ((u64)rl((uint32_t)(out_off >> 32), (int)r) << 32) | rl((uint32_t)out_off, (int)r);
+                const int32_t v = okr ? (int32_t)(tile[r * FG_TRS + col] << wa) : 0;
+                if (i < rn) {
+                    int32_t *o = out + oo * C;
+                    if (interleave) o[(size_t)i * C + (r % C)] = v;
+                    else o[(size_t)(r % C) * rn + i] = v;
+                }
+            }
         }
+    };
+    const uint32_t ng = big ? FG_TR / 12 : FG_TR / 8;
+    const uint32_t ga = big ? 5 : 8, gb = big ? 10 : 16;       // groups that are complete after passes 0 and 1 have landed
+
+    issue(0, 0);
+    for (uint32_t i0 = 0; i0 < nmax; i0 += FG_TR) {
+        const bool first = i0 == 0;
+        FG_TICK(0);
+        land(0); issue(i0, 1);
+        FG_TICK(1);
+        if (big) restore_range<12, WIDE>(h, q, shift, order, first, 0, ga, rowp); else restore_range<8, WIDE>(h, q, shift, order, first, 0, ga, rowp);
+        FG_TICK(2);
+        land(1); issue(i0, 2);
+        FG_TICK(1);
+        if (big) restore_range<12, WIDE>(h, q, shift, order, first, ga, gb, rowp); else restore_range<8, WIDE>(h, q, shift, order, first, ga, gb, rowp);
+        wave_lds_fence();
+        FG_TICK(2);
+        writeout(i0, 0);
+        FG_TICK(3);
+        land(2); issue(i0 + FG_TR, 0);
+        FG_TICK(1);
+        if (big) restore_range<12, WIDE>(h, q, shift, order, first, gb, ng, rowp); else restore_range<8, WIDE>(h, q, shift, order, first, gb, ng, rowp);
+        wave_lds_fence();
+        FG_TICK(2);
+        writeout(i0, 1);
+        writeout(i0, 2);
+        wave_lds_fence();
+        FG_TICK(3);
     }
+    if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t)blockIdx.x * 8 + i] = tp[i];
+#undef FG_TICK
 }
 
 }  // namespace
 
-extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, int32_t *d_scratch,
-                                     FgDecResult *d_results, int wide, hipStream_t stream)
+// Frames per wave: narrow waves while the launch cannot fill the SIMDs (the kernels are chains of dependent work per lane),
+// full waves for large batches.
+static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t simds = (uint32_t)cus * 4;
+    uint32_t g = (nframes + simds - 1) / simds;
+    const uint32_t gmax = 64 / per_frame_lanes;
+    if (g < 1) g = 1;
+    if (g > gmax) g = gmax;
+    return g;
+}
+
+extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
+                                     int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
+                                     hipStream_t stream)
 {
     if (nframes == 0) return 0;
-    const uint32_t nwg = (nframes + 63) / 64;
-    if (wide) hipLaunchKernelGGL(fg_dec_frames_kernel<true>, dim3(nwg), dim3(64), 0, stream, d_stream, d_frames, nframes, d_scratch, d_results);
-    else hipLaunchKernelGGL(fg_dec_frames_kernel<false>, dim3(nwg), dim3(64), 0, stream, d_stream, d_frames, nframes, d_scratch, d_results);
+    uint32_t G = fg_dec_group(nframes, 1);
+    if (G > 32) G = 32;     // LDS per wave grows with G (ring + tile rows); 32 keeps several waves per CU
+    const size_t lds = (size_t)G * (FG_RSTR + FG_TSTR) * 4;
+    hipLaunchKernelGGL(fg_dec_rice_kernel, dim3((nframes + G - 1) / G), dim3(64), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G,
+                       wide ? 0u : 1u, d_scratch, d_subs, d_results, d_prof);
     return (int)hipGetLastError();
 }
 
-extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, const int32_t *d_scratch,
-                                       int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, uint32_t interleave,
-                                       hipStream_t stream)
+extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels,
+                                       const int32_t *d_scratch, const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results,
+                                       const uint16_t *d_crctab, uint32_t interleave, int wide, unsigned long long *d_prof, hipStream_t stream)
 {
     if (nframes == 0) return 0;
     hipLaunchKernelGGL(fg_dec_crc_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_stream, d_frames, nframes, d_results, d_crctab);
-    hipLaunchKernelGGL(fg_dec_finish_kernel, dim3(nframes), dim3(256), 0, stream, d_frames, nframes, d_scratch, d_pcm, d_results, interleave);
+    const uint32_t C = channels ? channels : 1;
+    uint32_t G = fg_dec_group(nframes, C);
+    if (G * C > FG_RROWS) G = FG_RROWS / C;
+    if (G < 1) return -1;
+    const dim3 grid((nframes + G - 1) / G);
+    const size_t lds = (size_t)(((G * C + 7) & ~7u) + 1) * FG_TRS * 4;
+    if (wide) hipLaunchKernelGGL(fg_dec_restore_kernel<true>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
+    else hipLaunchKernelGGL(fg_dec_restore_kernel<false>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
     return (int)hipGetLastError();
 }

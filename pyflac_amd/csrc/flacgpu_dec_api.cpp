@@ -222,7 +222,6 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st)
 {
     std::lock_guard<std::mutex> lk(c->mu);
-    (void)len;
     memset(st, 0, sizeof *st);
     if (!HIPOK(hipSetDevice(c->device))) { fg_set_error("hipSetDevice failed"); return false; }
     st->nframes = nframes;
@@ -246,13 +245,24 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     st->max_blocksize = (uint32_t)tot[1];
     const uint32_t C = channels_hint ? channels_hint : 2;
     if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
-    if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4)) return false;
+    if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4) || !c->dec_subs.ensure((size_t)npad * C * sizeof(FgDecSub)))
+        return false;
     if (!HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
-    if (fg_launch_decode_fast((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                              (FgDecResult *)c->dec_results.p, bps_hint > 16 ? 1 : 0, c->stream) != 0 ||
-        fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (const int32_t *)c->dec_scratch.p,
-                                (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, interleave ? 1u : 0u,
-                                c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+    const int wide = (bps_hint == 0 || bps_hint > 16) ? 1 : 0;
+    // FLACGPU_DEC_PROF=1: per-wave clock64() totals of the kernel stages, averaged and printed to stderr (tuning aid)
+    static const bool want_prof = getenv("FLACGPU_DEC_PROF") != nullptr;
+    unsigned long long *d_prof = nullptr;
+    if (want_prof && c->dec_prof.ensure((size_t)npad * 2 * 8 * 8)) {
+        d_prof = (unsigned long long *)c->dec_prof.p;
+        (void)hipMemsetAsync(d_prof, 0, (size_t)npad * 2 * 8 * 8, c->stream);
+    }
+    if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+                              (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, c->stream) != 0 ||
+        fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
+                                (const FgDecSub *)c->dec_subs.p, (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p,
+                                (const uint16_t *)c->crctab.p, interleave ? 1u : 0u, wide, d_prof ? d_prof + (size_t)npad * 8 : nullptr, c->stream) != 0) {
+        fg_set_error("decode kernel launch failed"); return false;
+    }
     if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
     std::vector<FgDecResult> res(nframes);
     if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
@@ -273,6 +283,23 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                       interleave ? 1u : 0u, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
             if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream)) ||
                 !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+        }
+    }
+    if (d_prof) {
+        std::vector<unsigned long long> hp((size_t)npad * 16);
+        if (HIPOK(hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost))) {
+            for (int kk = 0; kk < 2; kk++) {
+                double sum[8] = {0}; size_t nw = 0;
+                for (size_t w = 0; w < npad; w++) {
+                    const unsigned long long *r = &hp[((size_t)kk * npad + w) * 8];
+                    unsigned long long tot = 0; for (int i = 0; i < 8; i++) tot += r[i];
+                    if (!tot) continue;
+                    nw++; for (int i = 0; i < 8; i++) sum[i] += (double)r[i];
+                }
+                fprintf(stderr, "[flacgpu dec prof] kernel %d: %zu waves; mean ticks/wave:", kk, nw);
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", nw ? sum[i] / nw : 0.0);
+                fprintf(stderr, "\n");
+            }
         }
     }
     (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
