@@ -388,12 +388,13 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         ordered.reserve(nblocks);
         std::vector<FgBlockDesc> slow;
         for (const FgBlockDesc &d : descs) {
-            bool fast = cfg_fast && d.n >= 64 && (d.n & 63) == 0;
+            // lane = segment of n/64 samples: at least the predictor history per lane, partitions no finer than a lane
+            bool fast = cfg_fast && d.n >= 64 * 12 && (d.n & 63) == 0;
             if (fast) {
                 uint32_t pm = 0, b = d.n;
                 while (!(b & 1)) { pm++; b >>= 1; }
                 if (pm > s->max_partition_order) pm = s->max_partition_order;
-                if (((d.n >> pm) & 63) != 0) fast = false;
+                if (pm > 6) fast = false;
             }
             if (fast) ordered.push_back(d); else slow.push_back(d);
         }

@@ -29,7 +29,7 @@ using namespace fgdev;
 
 #define FG_DMAXO 12
 #define FG_TS 64            // residual tile of the parse kernel (samples per lane)
-#define FG_TSTR 65          // its LDS row stride (words)
+#define FG_TSTR 68          // its LDS row stride (words): 16-byte aligned rows, neighbouring lanes 4 banks apart
 
 namespace {
 
@@ -315,19 +315,43 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                         // reader is rewound and the general loop below decodes the tile.
                         BitRdState keep;
                         br.save(keep);
+                        // Per code: lz = leading zeros of the window, length = lz + k + 1.  The dependent chain is kept
+                        // short: the word advance is decided by comparing lz with (s - k - 1), prepared one code earlier.
                         const uint32_t kp1 = k + 1;
-                        uint32_t maxlen = 0;
+                        uint32_t lzmax = 0;
+                        uint32_t w0 = br.w0, w1 = br.w1, w2 = br.w2, w3 = br.w3, wb = br.wb;
+                        uint32_t sm = br.s;
+                        int32_t smk = (int32_t)(sm - kp1);
+                        const char *rbase = (const char *)br.ring;
 #pragma unroll
-                        for (uint32_t jj = 0; jj < FG_TS; jj++) {
-                            const uint32_t p = br.peek();
-                            const uint32_t len = (uint32_t)__clz(p) + kp1;
-                            maxlen = len > maxlen ? len : maxlen;
-                            row[jj] = p;
-                            br.consume_fast(len);
+                        for (uint32_t jj = 0; jj < FG_TS; jj += 4) {
+                            uint32_t pw[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const uint32_t p = __builtin_amdgcn_alignbit(w0, w1, sm);
+                                uint32_t lz;
+                                asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(p));       // 0xFFFFFFFF for an all-zero window
+                                pw[u] = p;
+                                const bool adv = smk < (int32_t)lz;
+                                lzmax = lz > lzmax ? lz : lzmax;
+                                sm = (uint32_t)(smk - (int32_t)lz) & 31;
+                                smk = (int32_t)(sm - kp1);
+                                w0 = adv ? w1 : w0;
+                                w1 = adv ? w2 : w1;
+                                if (adv) {
+                                    w2 = be32(w3);
+                                    w3 = *(const uint32_t *)(rbase + (wb & (FG_RG * 16 - 1)));
+                                    wb += 4;
+                                }
+                            }
+                            *(uint4 *)(row + jj) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
                         }
-                        if (__any(maxlen > 32)) br.restore(keep);
-                        else { tk = k; ii = FG_TS; }
+                        // a code longer than the window (or an all-zero window) voids the attempt
+                        if (__any(lzmax > 32 - kp1)) br.restore(keep);
+                        else { br.w0 = w0; br.w1 = w1; br.w2 = w2; br.w3 = w3; br.wb = wb; br.s = sm; }
+                        if (!__any(lzmax > 32 - kp1)) { tk = k; ii = FG_TS; tp[5]++; } else tp[6]++;
                     }
+                    if (ii < FG_TS) tp[7]++;
                     for (; ii < FG_TS; ii++) {
                         const uint32_t i = i0 + ii;
                         if (i < start || i >= n) continue;

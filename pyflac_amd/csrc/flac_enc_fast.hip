@@ -5,7 +5,8 @@
 
 #include "fg_types.h"
 
-#define FG_PADF 32
+#define FGS_FBW 1024
+#define FGS_DSTR 168
 
 extern "C" {
 
@@ -21,14 +22,14 @@ size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo)
     const int MQ = maxo > 0 ? maxo : 1;
     size_t off = 0;
     auto add = [&](size_t b) { off += (b + 15) & ~(size_t)15; };
-    add((size_t)(P->sig_stride + FG_PADF) * sb);
-    add(nch == 2 ? (size_t)(P->sig_stride + FG_PADF) * sb : 16);
-    add(P->lds_dbuf_bytes);
+    add((size_t)(P->sig_stride + 256) * sb);
+    add(nch == 2 ? (size_t)(P->sig_stride + 256) * sb : 16);
+    add(P->lds_dbuf_bytes > (size_t)NC * FGS_DSTR * 8 ? P->lds_dbuf_bytes : (size_t)NC * FGS_DSTR * 8);
     add((size_t)NC * P->nvec * (maxo + 1) * 8);
     add((size_t)NC * P->nvec * MQ * 4);
     add((size_t)NC * P->nvec * 4);
     add((size_t)NC * MQ * 4);
-    add((FG_WINW + 2) * 4);
+    add((FGS_FBW + 2) * 4);
     add(768 * 2);
     add(128 * 4);
     return off;

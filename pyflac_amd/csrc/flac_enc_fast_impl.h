@@ -1,18 +1,23 @@
 // flac_enc_fast_impl.h -- specialised one-block-per-wavefront FLAC frame encoder for the common shapes:
-// 1 or 2 channels, block length a multiple of 64 whose finest Rice partition is a multiple of 64 samples
-// (4096 at partition order <= 6), max LPC order <= 12, bits-per-sample <= 24.  Everything else goes to
-// the generic kernel in flac_enc_kernels.hip; both produce identical bytes (tests/test_gpu_encode.py).
+// 1 or 2 channels, block length a multiple of 64 with at least MAXO samples per lane, Rice partition order <= 6,
+// max LPC order <= 12, bits-per-sample <= 24.  Everything else goes to the generic kernel in flac_enc_kernels.hip;
+// both produce identical bytes (tests/test_gpu_encode.py).
 //
 // Same algorithm and stage order as the generic kernel; what changes is the mapping:
-//   * compile-time candidate set (L,R,M,S / L,R / mono) -- no per-sample branches in the analysis passes;
-//   * every pass handles all candidates at once from one set of LDS loads;
-//   * fixed and LPC predictors share one FIR evaluation pass (a fixed predictor of order k is the FIR with
-//     binomial coefficients and shift 0), coefficients live in SGPRs;
-//   * reductions and prefix sums use DPP row shifts / broadcasts instead of LDS shuffles;
-//   * Rice partition sums, parameters and bit estimates live in registers, lane = partition;
+//   * lane = segment.  Lane i owns the n/64 consecutive samples [i*seg, (i+1)*seg) of every channel.  The analysis
+//     passes (fixed-predictor error sums, FIR residual of every predictor candidate) and the two packing passes walk
+//     the segment serially with the predictor history in registers, addressed statically (the loop is unrolled by the
+//     history length), so a pass costs one LDS read per sample and channel instead of one per tap;
+//   * a lane's |residual| total is the Rice partition sum of the finest partition order (or a power-of-two fraction
+//     of it), so the partition sums need no wave reductions, only pairwise merges;
+//   * packing: one pass gives every lane the exact bit length of its segment, one prefix sum gives its start, and a
+//     second pass ORs the codes straight into an LDS window at that position -- no per-sample wave scans, no
+//     divergent word emission; the window is written out coalesced, the CRC-16 advances with it;
+//   * compile-time candidate set (L,R,M,S / L,R / mono), predictor coefficients in SGPRs (wave-uniform);
+//   * the autocorrelation keeps libFLAC's order-preserving fp64 chains (lane = candidate x lag): one LDS read per step,
+//     the lag-0 operand comes from a DPP row broadcast inside the FMA;
 //   * LDS accesses of the single wave are ordered by issue, so stages are separated by compiler fences only;
-//   * wave-uniform state (bit position, decisions) is kept in plain locals so it stays in SGPRs and every
-//     branch on it is a scalar branch.
+//     wave-uniform state (bit position, decisions) is kept in plain locals so it stays in SGPRs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,11 +28,14 @@
 #include "fg_types.h"
 
 #define FG_LN2 0.69314718055994530942
-#define FG_PADF 32   // zero samples kept in front of each staged channel (>= max order)
-// LDS arrays are addressed through address_space(3) pointers: ds_* instructions, and no FLAT aperture checks
-// on the (possibly negative) sample offsets.
+// LDS arrays are addressed through address_space(3) pointers: ds_* instructions, no FLAT aperture checks.
 #define LDS __attribute__((address_space(3)))
 #define FGI __device__ __forceinline__
+
+#define FGS_FBW 1024      // frame-bit window, 32-bit words
+#define FGS_DH 32         // autocorrelation: history doubles kept in front of each chunk
+#define FGS_DK 128        // autocorrelation: chunk length
+#define FGS_DSTR 168      // doubles per candidate row (history + chunk + bank skew)
 
 using namespace fgdev;
 
@@ -37,141 +45,39 @@ template <bool ACC64> struct FastTypes {
     typedef typename std::conditional<ACC64, u64, uint32_t>::type sum_t;
     // bits-per-sample <= 16 (the !ACC64 shapes): samples are staged as int16, halving the LDS footprint
     typedef typename std::conditional<ACC64, int32_t, int16_t>::type samp_t;
+    // elements of skew between the rows of neighbouring lanes (rows stay 8-byte aligned, bank-conflict free)
+    static constexpr uint32_t PADE = ACC64 ? 2 : 4;
 };
 
-// Constants of one block (written once).
-template <bool ACC64> struct FastCtx {
-    typedef typename FastTypes<ACC64>::samp_t samp_t;
-    const LDS samp_t *pl, *pr;   // staged samples (after the zero padding)
-    LDS double *dbuf;
-    LDS double *autoc;
-    LDS int32_t *qres;
-    LDS uint32_t *lres;
-    LDS int32_t *bestq;
-    LDS uint32_t *win;
-    LDS uint16_t *crct;
-    LDS uint32_t *misc;
-    const float *window;
-    int lane;
-    uint32_t n, nvec;
-};
-
-// Bit writer state (wave-uniform).
-struct FastBW {
-    uint32_t bitpos, wbase, err, slot_words;
-    uint32_t *outw;
-};
-
-template <bool MS, int C> FGI int32_t fcv(int32_t L, int32_t R, uint32_t w)
+// candidate value from the two channel samples
+template <bool MS, int C> FGI int32_t fcv(int32_t L, int32_t R)
 {
-    if (!MS) return (C == 0 ? L : R) >> w;
-    if (C == 0) return L >> w;
-    if (C == 1) return R >> w;
-    if (C == 2) return ((L + R) >> 1) >> w;
-    return (L - R) >> w;
-}
-// runtime (wave-uniform) candidate index
-template <bool MS> FGI int32_t fcv_rt(uint32_t c, int32_t L, int32_t R, uint32_t w)
-{
-    int32_t v;
-    if (!MS) v = c == 0 ? L : R;
-    else v = c == 0 ? L : c == 1 ? R : c == 2 ? ((L + R) >> 1) : (L - R);
-    return v >> w;
+    if (!MS) return C == 0 ? L : R;
+    if (C == 0) return L;
+    if (C == 1) return R;
+    if (C == 2) return (L + R) >> 1;
+    return L - R;
 }
 
-// ------------------------------------------------------------------ bit writer (LDS window -> HBM slot)
-FGI void bw_flush(FastBW &b, LDS uint32_t *win, int lane, uint32_t newpos)
+FGI uint32_t fabs32(int32_t v) { return (uint32_t)(v < 0 ? -v : v); }
+
+// sum_j q[j] * h[(u - 1 - j) mod MAXO] with 24-bit multiplies: one v_mad_i32_i24 per tap, coefficient from an SGPR.
+// (History slot of sample s is s mod MAXO; u is the slot of the sample being predicted, a compile-time constant after
+// unrolling.)
+template <int MAXO> FGI int32_t fir24(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
 {
-    const uint32_t nfull = (newpos >> 5) - b.wbase;
-    if (nfull == 0) return;
-    if (b.wbase + nfull > b.slot_words) { b.err |= FG_ERR_SLOT; b.wbase += nfull; return; }
-    if (nfull < 64) {
-        const uint32_t v = win[lane];
-        if ((uint32_t)lane < nfull) b.outw[b.wbase + lane] = __builtin_bswap32(v);
-        const uint32_t carry = rl(v, (int)nfull);
-        wave_lds_fence();
-        if ((uint32_t)lane <= nfull) win[lane] = (lane == 0) ? carry : 0;
-    }
-    else {
-        for (uint32_t j = lane; j < nfull; j += 64) b.outw[b.wbase + j] = __builtin_bswap32(win[j]);
-        const uint32_t carry = win[nfull];
-        wave_lds_fence();
-        for (uint32_t j = lane; j < FG_WINW + 2; j += 64) win[j] = 0;
-        wave_lds_fence();
-        if (lane == 0) win[0] = carry;
-    }
-    b.wbase += nfull;
-    wave_lds_fence();
+    int32_t sm = 0;
+#pragma unroll
+    for (int j = MAXO - 1; j >= 0; j--)
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(sm) : "s"(q[j]), "v"(h[(u - 1 - j + 2 * MAXO) % MAXO]));
+    return sm;
 }
-FGI void bw_or(const FastBW &b, LDS uint32_t *win, uint32_t pos, uint32_t val, uint32_t vbits)
+template <int MAXO> FGI i64 fir64(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
 {
-    const uint32_t rel = pos - (b.wbase << 5);
-    const uint32_t word = rel >> 5, sh = rel & 31;
-    const u64 x = (u64)val << (64 - sh - vbits);
-    __hip_atomic_fetch_or(&win[word], (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    const uint32_t lo = (uint32_t)x;
-    if (lo) __hip_atomic_fetch_or(&win[word + 1], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-// rare: a round that does not fit the window (very long unary runs); serialise the lanes
-FGI void bw_round_slow(FastBW &b, LDS uint32_t *win, int lane, uint32_t pv, uint32_t pb, uint32_t val, uint32_t vb, uint32_t nb)
-{
-    for (int L = 0; L < 64; L++) {
-        const uint32_t lpv = rl(pv, L), lpb = rl(pb, L), lval = rl(val, L), lvb = rl(vb, L), lnb = rl(nb, L);
-        if (lpb) {
-            if (lane == 0) bw_or(b, win, b.bitpos, lpv, lpb);
-            wave_lds_fence();
-            b.bitpos += lpb;
-            bw_flush(b, win, lane, b.bitpos);
-        }
-        if (lnb) {
-            uint32_t z = lnb - lvb;
-            while (((b.bitpos + z) >> 5) - b.wbase >= FG_WINW) {
-                const uint32_t np = (b.wbase + FG_WINW) << 5;
-                z -= np - b.bitpos;
-                b.bitpos = np;
-                bw_flush(b, win, lane, np);
-            }
-            b.bitpos += z;
-            bw_flush(b, win, lane, b.bitpos);
-            if (lvb) {
-                if (lane == 0) bw_or(b, win, b.bitpos, lval, lvb);
-                wave_lds_fence();
-                b.bitpos += lvb;
-                bw_flush(b, win, lane, b.bitpos);
-            }
-        }
-    }
-}
-// One packing round: every lane may contribute a prefix field (pv, pb bits) followed by a code of nb bits whose
-// low vb bits are val and whose leading nb - vb bits are zero (pb, vb <= 32).
-FGI void bw_round(FastBW &b, LDS uint32_t *win, int lane, uint32_t pv, uint32_t pb, uint32_t val, uint32_t vb, uint32_t nb)
-{
-    const uint32_t mine = pb + nb;
-    const uint32_t incl = wave_scan_add(mine);
-    const uint32_t total = rl(incl, 63);
-    if (total == 0) return;
-    const bool anybig = __any(nb > (1u << 20));
-    if (!anybig && (b.bitpos & 31) + total <= 32u * FG_WINW) {
-        const uint32_t off = b.bitpos + incl - mine;
-        if (pb) bw_or(b, win, off, pv, pb);
-        if (vb) bw_or(b, win, off + pb + nb - vb, val, vb);
-        wave_lds_fence();
-        b.bitpos += total;
-        bw_flush(b, win, lane, b.bitpos);
-    }
-    else bw_round_slow(b, win, lane, pv, pb, val, vb, nb);
-}
-FGI void bw_put(FastBW &b, LDS uint32_t *win, int lane, uint32_t val, uint32_t bits)
-{
-    bw_round(b, win, lane, 0, 0, lane == 0 ? (bits < 32 ? (val & ((1u << bits) - 1)) : val) : 0, lane == 0 ? bits : 0, lane == 0 ? bits : 0);
-}
-FGI void bw_flush_all(FastBW &b, LDS uint32_t *win, int lane)
-{
-    bw_flush(b, win, lane, b.bitpos);
-    if ((b.bitpos & 31) && lane == 0) {
-        if (b.wbase < b.slot_words) b.outw[b.wbase] = __builtin_bswap32(win[0]);
-    }
-    if ((b.bitpos & 31) && b.wbase >= b.slot_words) b.err |= FG_ERR_SLOT;
+    i64 sm = 0;
+#pragma unroll
+    for (int j = MAXO - 1; j >= 0; j--) sm += (i64)q[j] * (i64)h[(u - 1 - j + 2 * MAXO) % MAXO];
+    return sm;
 }
 
 FGI double f_ebps(double e, double scale)
@@ -184,6 +90,66 @@ FGI double f_ebps(double e, double scale)
     return 0.0;
 }
 
+// ------------------------------------------------------------------ frame-bit window (LDS) -> HBM slot, CRC-16 alongside
+// Bits are ORed into a zeroed window of FGS_FBW words that starts at absolute word `wbase` of the frame.  flush() writes
+// the complete words out (big-endian) and advances the per-lane CRC state: lane l owns the words l, l+64, l+128, ... of the
+// frame, so its state is  state * x^2048 + crc(word)  whenever it meets its next word, whatever the flush boundaries.
+struct FrameBits {
+    LDS uint32_t *w;
+    const LDS uint16_t *t0, *thi, *tlo;
+    uint32_t *outw;
+    uint32_t wbase, slot_words, err;
+    uint32_t crc;          // per lane
+};
+
+// OR `vbits` bits (val < 2^vbits, vbits in [0, 32]) into the window at absolute bit position `pos`
+FGI void fb_or(const FrameBits &b, uint32_t pos, uint32_t val, uint32_t vbits)
+{
+    // value left-aligned at bit `sh` of a 64-bit big-endian pair: x = val << (64 - sh - vbits)
+    const uint32_t rel = pos - (b.wbase << 5);
+    const uint32_t word = rel >> 5, sh = rel & 31;
+    const u64 x = (u64)val << ((64 - sh - vbits) & 63);
+    __hip_atomic_fetch_or(&b.w[word], (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(&b.w[word + 1], (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// write out the complete words below bit position `upto`
+FGI void fb_flush(FrameBits &b, int lane, uint32_t upto)
+{
+    const uint32_t wend = upto >> 5;
+    if (wend <= b.wbase) return;
+    const uint32_t nfull = wend - b.wbase;
+    if (wend > b.slot_words) { b.err |= FG_ERR_SLOT; }
+    wave_lds_fence();
+    for (uint32_t row = b.wbase & ~63u; row < wend; row += 64) {
+        const uint32_t wi = row + (uint32_t)lane;
+        if (wi >= b.wbase && wi < wend) {
+            const uint32_t v = b.w[wi - b.wbase];
+            if (wi < b.slot_words) b.outw[wi] = __builtin_bswap32(v);
+            uint32_t s = b.crc;
+            s = b.thi[s >> 8] ^ b.tlo[s & 0xFF];
+            uint32_t cw = b.t0[v >> 24];
+            cw = ((cw << 8) & 0xFFFF) ^ b.t0[((cw >> 8) ^ (v >> 16)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ b.t0[((cw >> 8) ^ (v >> 8)) & 0xFF];
+            cw = ((cw << 8) & 0xFFFF) ^ b.t0[((cw >> 8) ^ v) & 0xFF];
+            b.crc = s ^ cw;
+        }
+    }
+    const uint32_t carry = b.w[nfull];
+    wave_lds_fence();
+    for (uint32_t j = lane; j <= nfull + 1 && j < FGS_FBW + 2; j += 64) b.w[j] = 0;
+    wave_lds_fence();
+    if (lane == 0) b.w[0] = carry;
+    b.wbase = wend;
+    wave_lds_fence();
+}
+
+// make room for `bits` more bits after position `bitpos`
+FGI void fb_reserve(FrameBits &b, int lane, uint32_t bitpos, uint32_t bits)
+{
+    if (bitpos + bits - (b.wbase << 5) > 32u * FGS_FBW - 64u) fb_flush(b, lane, bitpos);
+}
+
 // ------------------------------------------------------------------ the kernel
 template <bool MS, int NCH, int MAXO, bool ACC64>
 __global__ void __launch_bounds__(64)
@@ -193,42 +159,45 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     constexpr int NC = MS ? 4 : NCH;
     typedef typename FastTypes<ACC64>::sum_t sum_t;
     typedef typename FastTypes<ACC64>::samp_t samp_t;
+    constexpr uint32_t PADE = FastTypes<ACC64>::PADE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FgBlockDesc d = descs[blockIdx.x];
     const int lane = threadIdx.x;
     const uint32_t n = d.n;
+    const uint32_t seg = n >> 6;                    // samples per lane
+    const uint32_t rstr = seg + PADE;               // LDS row stride (elements)
     // ---- LDS carve
     LDS unsigned char *lbase = (LDS unsigned char *)smem;
     uint32_t off = 0;
 #define FG_CARVE(type, bytes) (LDS type *)(lbase + off); off += (uint32_t)(((bytes) + 15) & ~15u)
-    LDS samp_t *sL = FG_CARVE(samp_t, (P.sig_stride + FG_PADF) * sizeof(samp_t));
-    LDS samp_t *sR = FG_CARVE(samp_t, NCH == 2 ? (P.sig_stride + FG_PADF) * sizeof(samp_t) : 16);
-    FastCtx<ACC64> k;
-    k.pl = sL + FG_PADF; k.pr = sR + FG_PADF;
-    k.dbuf = FG_CARVE(double, P.lds_dbuf_bytes);
-    k.autoc = FG_CARVE(double, NC * P.nvec * (MAXO + 1) * 8);
-    k.qres = FG_CARVE(int32_t, NC * P.nvec * MAXO * 4);
-    k.lres = FG_CARVE(uint32_t, NC * P.nvec * 4);
-    k.bestq = FG_CARVE(int32_t, NC * MAXO * 4);
-    k.win = FG_CARVE(uint32_t, (FG_WINW + 2) * 4);
-    k.crct = FG_CARVE(uint16_t, 768 * 2);
-    k.misc = FG_CARVE(uint32_t, 128 * 4);
+    LDS samp_t *sL = FG_CARVE(samp_t, (P.sig_stride + 256) * sizeof(samp_t));      // 64 rows, up to 4 elements of skew each
+    LDS samp_t *sR = FG_CARVE(samp_t, NCH == 2 ? (P.sig_stride + 256) * sizeof(samp_t) : 16);
+    LDS double *dbuf = FG_CARVE(double, P.lds_dbuf_bytes > NC * FGS_DSTR * 8 ? P.lds_dbuf_bytes : NC * FGS_DSTR * 8);
+    LDS double *autoc = FG_CARVE(double, NC * P.nvec * (MAXO + 1) * 8);
+    LDS int32_t *qres = FG_CARVE(int32_t, NC * P.nvec * MAXO * 4);
+    LDS uint32_t *lres = FG_CARVE(uint32_t, NC * P.nvec * 4);
+    LDS int32_t *bestq = FG_CARVE(int32_t, NC * MAXO * 4);
+    LDS uint32_t *fbw = FG_CARVE(uint32_t, (FGS_FBW + 2) * 4);
+    LDS uint16_t *crct = FG_CARVE(uint16_t, 768 * 2);
+    LDS uint32_t *misc = FG_CARVE(uint32_t, 128 * 4);
 #undef FG_CARVE
-    k.window = windows + d.win_off;
-    k.lane = lane; k.n = n; k.nvec = P.nvec;
-    for (int j = lane; j < 768; j += 64) k.crct[j] = crctab[j];
-    k.misc[64 + lane] = crctab[768 + lane];
+    const float *window = windows + d.win_off;
+    for (int j = lane; j < 768; j += 64) crct[j] = crctab[j];
+    misc[64 + lane] = crctab[768 + lane];
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
 #define FG_STAMP(i) do { if (mydbg && lane == 0) mydbg->t[i] = clock64(); } while (0)
     FG_STAMP(0);
     uint32_t err = 0;
+    // rows of this lane and of its left neighbour (history)
+    const LDS samp_t *rowL = sL + (uint32_t)lane * rstr, *rowR = sR + (uint32_t)lane * rstr;
+    // g -> LDS element index: g + (g / seg) * PADE, the division by a reciprocal (exact for g < 2^16, seg <= 1024)
+    const uint32_t magic = 0xFFFFFFFFu / seg + 1;
+#define FG_SADDR(g) ((g) + __umulhi((g), magic) * PADE)
 
-    // ================================================================ stage: HBM -> LDS (coalesced)
+    // ================================================================ stage: HBM -> LDS (coalesced reads, lane-segment rows)
     {
         const int32_t lim = (int32_t)(P.bps - 1);
         uint32_t bad = 0;
-        if (lane < FG_PADF) { sL[lane] = 0; if (NCH == 2) sR[lane] = 0; }
-        LDS samp_t *dl = sL + FG_PADF, *dr = sR + FG_PADF;
         for (uint32_t i0 = 0; i0 < n; i0 += 256) {
             int32_t a[4], b[4];
 #pragma unroll
@@ -251,8 +220,9 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 const uint32_t i = i0 + u * 64 + lane;
                 if (i < n) {
                     if (P.bps < 32) bad |= (uint32_t)(((a[u] ^ (a[u] >> 31)) >> lim) | ((b[u] ^ (b[u] >> 31)) >> lim));
-                    dl[i] = (samp_t)a[u];
-                    if (NCH == 2) dr[i] = (samp_t)b[u];
+                    const uint32_t ad = FG_SADDR(i);
+                    sL[ad] = (samp_t)a[u];
+                    if (NCH == 2) sR[ad] = (samp_t)b[u];
                 }
             }
         }
@@ -272,33 +242,32 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     {
         sum_t acc[NC][5];
         uint32_t orv[NC];
+        int32_t p1[NC], q1[NC], q2[NC], q3[NC];       // previous value and previous 1st..3rd differences
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            orv[c] = 0;
+            orv[c] = 0; p1[c] = 0; q1[c] = 0; q2[c] = 0; q3[c] = 0;
 #pragma unroll
             for (int kk = 0; kk < 5; kk++) acc[c][kk] = 0;
         }
-        for (uint32_t i = lane; i < n; i += 64) {
-            int32_t l[5], r[5];
-#pragma unroll
-            for (int kk = 0; kk < 5; kk++) { l[kk] = k.pl[(int)i - kk]; r[kk] = (NCH == 2) ? k.pr[(int)i - kk] : 0; }
-            const bool on = i >= 4;
+        // prime the differences with the four samples in front of the segment (zeros in front of the block), then walk
+#pragma unroll 1
+        for (int s = -4; s < (int)seg; s++) {
+            int32_t l = 0, r = 0;
+            if (s >= 0) { l = rowL[s]; r = (NCH == 2) ? rowR[s] : 0; }
+            else if (lane > 0) { l = rowL[(int)seg + s - (int)rstr]; r = (NCH == 2) ? rowR[(int)seg + s - (int)rstr] : 0; }
+            // the sums run over samples 4 .. n-1 (libFLAC hands fixed.c the signal shifted by the maximum fixed order)
+            const bool on = s >= 0 && (lane > 0 || s >= 4);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                int32_t v[5];
-#pragma unroll
-                for (int kk = 0; kk < 5; kk++) {
-                    if (!MS) v[kk] = (c == 0) ? l[kk] : r[kk];
-                    else v[kk] = (c == 0) ? l[kk] : (c == 1) ? r[kk] : (c == 2) ? ((l[kk] + r[kk]) >> 1) : (l[kk] - r[kk]);
-                }
-                orv[c] |= (uint32_t)v[0];
-                const int32_t e1 = v[0] - v[1], d1 = v[1] - v[2], d2 = v[2] - v[3], d3 = v[3] - v[4];
-                const int32_t e2 = e1 - d1, f2 = d1 - d2, g2 = d2 - d3;
-                const int32_t e3 = e2 - f2, f3 = f2 - g2;
-                const int32_t e4 = e3 - f3;
+                int32_t v;
+                if (!MS) v = (c == 0) ? l : r;
+                else v = (c == 0) ? l : (c == 1) ? r : (c == 2) ? ((l + r) >> 1) : (l - r);
+                const int32_t e1 = v - p1[c], e2 = e1 - q1[c], e3 = e2 - q2[c], e4 = e3 - q3[c];
+                p1[c] = v; q1[c] = e1; q2[c] = e2; q3[c] = e3;
+                if (s >= 0) orv[c] |= (uint32_t)v;
                 if (on) {
-                    acc[c][0] += (uint32_t)abs(v[0]); acc[c][1] += (uint32_t)abs(e1); acc[c][2] += (uint32_t)abs(e2);
-                    acc[c][3] += (uint32_t)abs(e3); acc[c][4] += (uint32_t)abs(e4);
+                    acc[c][0] += fabs32(v); acc[c][1] += fabs32(e1); acc[c][2] += fabs32(e2);
+                    acc[c][3] += fabs32(e3); acc[c][4] += fabs32(e4);
                 }
             }
         }
@@ -326,25 +295,6 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 return;
             }
         }
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (false) {
-                u64 a5[5] = {0, 0, 0, 0, 0};
-                for (uint32_t i = 4 + lane; i < n; i += 64) {
-                    int32_t v[5];
-#pragma unroll
-                    for (int kk = 0; kk < 5; kk++) v[kk] = fcv_rt<MS>((uint32_t)c, k.pl[(int)i - kk], (NCH == 2) ? k.pr[(int)i - kk] : 0, wst[c]);
-                    const int32_t e1 = v[0] - v[1], d1 = v[1] - v[2], d2 = v[2] - v[3], d3 = v[3] - v[4];
-                    const int32_t e2 = e1 - d1, f2 = d1 - d2, g2 = d2 - d3;
-                    const int32_t e3 = e2 - f2, f3 = f2 - g2;
-                    const int32_t e4 = e3 - f3;
-                    a5[0] += (uint32_t)abs(v[0]); a5[1] += (uint32_t)abs(e1); a5[2] += (uint32_t)abs(e2);
-                    a5[3] += (uint32_t)abs(e3); a5[4] += (uint32_t)abs(e4);
-                }
-#pragma unroll
-                for (int kk = 0; kk < 5; kk++) tot[c][kk] = wave_sum64(a5[kk]);
-            }
-        }
     }
 
     // ---- per-candidate baseline: verbatim / constant, fixed order guess
@@ -354,8 +304,8 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     uint32_t fixed_mask = 0, lpc_mask = 0;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        const uint32_t w = wst[c], sb = sbp[c];
-        const u64 vb = (u64)8 + w + (u64)n * sb;
+        const uint32_t sb = sbp[c];
+        const u64 vb = (u64)8 + (u64)n * sb;
         best[c] = vb < 0xFFFFFFFFull ? (uint32_t)vb : 0xFFFFFFFFu;
         d_type[c] = 1; d_order[c] = 0; d_prec[c] = 0; d_shift[c] = 0; d_porder[c] = 0; d_method[c] = 0; d_k[c] = 0;
         const u64 m34 = tot[c][3] < tot[c][4] ? tot[c][3] : tot[c][4];
@@ -373,9 +323,15 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         const float rbg = (float)((tg > 0) ? log(FG_LN2 * (double)tg / len) / FG_LN2 : 0.0);
         bool constant = false;
         if (tot[c][1] == 0) {
-            const int32_t x0 = fcv_rt<MS>((uint32_t)c, k.pl[0], (NCH == 2) ? k.pr[0] : 0, w);
+            const int32_t l0 = sL[0], r0 = (NCH == 2) ? sR[0] : 0;
+            const int32_t x0 = !MS ? (c == 0 ? l0 : r0) : (c == 0 ? l0 : c == 1 ? r0 : c == 2 ? ((l0 + r0) >> 1) : (l0 - r0));
             uint32_t ne = 0;
-            for (uint32_t i = lane; i < n; i += 64) ne |= (fcv_rt<MS>((uint32_t)c, k.pl[i], (NCH == 2) ? k.pr[i] : 0, w) != x0);
+#pragma unroll 1
+            for (uint32_t s = 0; s < seg; s++) {
+                const int32_t l = rowL[s], r = (NCH == 2) ? rowR[s] : 0;
+                const int32_t x = !MS ? (c == 0 ? l : r) : (c == 0 ? l : c == 1 ? r : c == 2 ? ((l + r) >> 1) : (l - r));
+                ne |= (x != x0);
+            }
             constant = !__any(ne != 0);
         }
         if (mydbg && lane == 0) {
@@ -383,7 +339,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             mydbg->cand[c].fixed_guess = g;
         }
         if (constant) {
-            const uint32_t cb = 8 + w + sb;
+            const uint32_t cb = 8 + sb;
             if (cb < best[c]) { best[c] = cb; d_type[c] = 0; }
         }
         else {
@@ -394,14 +350,15 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     FG_STAMP(2);
 
     // ================================================================ autocorrelation vectors (order-preserving fp64 chains)
+    // lane = candidate row (16 lanes) x lag.  Per chunk of FGS_DK samples the windowed signal of every candidate is staged
+    // as doubles (with FGS_DH history entries in front); the chain then needs one LDS read per step: lane (c, l) reads
+    // d[j - l], the d[j] operand is lane (c, 0)'s own value, broadcast inside the FMA (DPP row_newbcast:0).
     uint32_t nv = 0;
     const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
     if (lpc_mask && MAXO > 0 && mo > 0) {
-        const uint32_t DSTR = FG_DH + FG_DK;
         const uint32_t cl = lane >> 4, l = lane & 15;
         const bool on = cl < (uint32_t)NC && l <= mo;
-        const LDS double *cur = k.dbuf + (on ? cl : 0) * DSTR + FG_DH;
-        const LDS double *hist = cur - (on ? l : 0);
+        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGS_DSTR + FGS_DH - (on ? l : 0);
         // vector schedule of apply_apodization_ (tukey: one; subdivide_tukey(parts): whole, then per depth b the
         // partial windows at even c and the punch-outs at odd c)
         uint32_t vb_ = 1, vc_ = 0;
@@ -416,57 +373,79 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
             if (!skip && !punch) {
                 double acc = 0.0;
-                for (uint32_t j = lane; j < NC * FG_DH; j += 64) k.dbuf[(j / FG_DH) * DSTR + (j % FG_DH)] = 0.0;
+                for (uint32_t j = lane; j < NC * FGS_DH; j += 64) dbuf[(j / FGS_DH) * FGS_DSTR + (j % FGS_DH)] = 0.0;
                 wave_lds_fence();
-                for (uint32_t k0 = 0; k0 < vec_len; k0 += FG_DK) {
-                    const uint32_t kn = (vec_len - k0) < FG_DK ? (vec_len - k0) : FG_DK;
-                    for (uint32_t j = lane; j < kn; j += 64) {
-                        const uint32_t i = k0 + j;
-                        float wv;
-                        uint32_t si;
-                        bool zero = false;
-                        if (part == 0) { wv = k.window[i]; si = i; }
-                        else if (i < part) { wv = k.window[i]; si = sh + i; }
-                        else if (i < 2 * part) { wv = k.window[n - 2 * part + i]; si = sh + i; }
-                        else { wv = 0.0f; si = 0; zero = true; }
-                        const int32_t L = k.pl[si], R = (NCH == 2) ? k.pr[si] : 0;
+                // window values of the first chunk
+                float wv[FGS_DK / 64];
+                uint32_t si[FGS_DK / 64];
+                auto fetch = [&](uint32_t k0) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int c = 0; c < NC; c++) {
-                            const int32_t x = fcv_rt<MS>((uint32_t)c, L, R, 0);
-                            const float dd = zero ? 0.0f : (float)x * wv;
-                            k.dbuf[c * DSTR + FG_DH + j] = (double)dd;
+                    for (int u = 0; u < FGS_DK / 64; u++) {
+                        const uint32_t i = k0 + u * 64 + lane;
+                        float w = 0.0f;
+                        uint32_t s_ = 0;
+                        if (i < vec_len) {
+                            if (part == 0) { w = window[i]; s_ = i; }
+                            else if (i < part) { w = window[i]; s_ = sh + i; }
+                            else if (i < 2 * part) { w = window[n - 2 * part + i]; s_ = sh + i; }
+                        }
+                        wv[u] = w; si[u] = s_;
+                    }
+                };
+                fetch(0);
+                for (uint32_t k0 = 0; k0 < vec_len; k0 += FGS_DK) {
+                    const uint32_t kn = (vec_len - k0) < FGS_DK ? (vec_len - k0) : FGS_DK;
+#pragma unroll
+                    for (int u = 0; u < FGS_DK / 64; u++) {
+                        const uint32_t j = u * 64 + lane;
+                        if (j < kn) {
+                            const uint32_t ad = FG_SADDR(si[u]);
+                            const int32_t L = sL[ad], R = (NCH == 2) ? sR[ad] : 0;
+                            const bool zero = part != 0 && (k0 + j) >= 2 * part;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) {
+                                const int32_t x = !MS ? (c == 0 ? L : R) : (c == 0 ? L : c == 1 ? R : c == 2 ? ((L + R) >> 1) : (L - R));
+                                const float dd = zero ? 0.0f : (float)x * wv[u];
+                                dbuf[c * FGS_DSTR + FGS_DH + j] = (double)dd;
+                            }
                         }
                     }
+                    if (k0 + FGS_DK < vec_len) fetch(k0 + FGS_DK);       // next chunk's window values travel during the chain
                     wave_lds_fence();
                     if (on) {
                         uint32_t j = 0;
-                        for (; j + 8 <= kn; j += 8) {
-                            double a[8], b[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) { a[u] = cur[j + u]; b[u] = hist[j + u]; }
-#pragma unroll
-                            for (int u = 0; u < 8; u++) acc = __builtin_fma(a[u], b[u], acc);
+                        for (; j + 4 <= kn; j += 4) {
+                            const double h0 = hist[j], h1 = hist[j + 1], h2 = hist[j + 2], h3 = hist[j + 3];
+                            asm volatile("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                         "v_fmac_f64_dpp %0, %2, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                         "v_fmac_f64_dpp %0, %3, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                         "v_fmac_f64_dpp %0, %4, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf"
+                                         : "+v"(acc) : "v"(h0), "v"(h1), "v"(h2), "v"(h3));
                         }
-                        for (; j < kn; j++) acc = __builtin_fma(cur[j], hist[j], acc);
+                        for (; j < kn; j++) {
+                            const double h0 = hist[j];
+                            asm volatile("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
+                        }
                     }
                     wave_lds_fence();
                     if (k0 + kn < vec_len) {
-                        double t[(NC * FG_DH + 63) / 64];
+                        // the last FGS_DH entries of the chunk become the history of the next one
+                        double t[(NC * FGS_DH + 63) / 64];
 #pragma unroll
-                        for (int u = 0; u < (NC * FG_DH + 63) / 64; u++) {
+                        for (int u = 0; u < (NC * FGS_DH + 63) / 64; u++) {
                             const uint32_t j = u * 64 + lane;
-                            t[u] = (j < NC * FG_DH) ? k.dbuf[(j / FG_DH) * DSTR + FG_DK + (j % FG_DH)] : 0.0;
+                            t[u] = (j < NC * FGS_DH) ? dbuf[(j / FGS_DH) * FGS_DSTR + FGS_DK + (j % FGS_DH)] : 0.0;
                         }
                         wave_lds_fence();
 #pragma unroll
-                        for (int u = 0; u < (NC * FG_DH + 63) / 64; u++) {
+                        for (int u = 0; u < (NC * FGS_DH + 63) / 64; u++) {
                             const uint32_t j = u * 64 + lane;
-                            if (j < NC * FG_DH) k.dbuf[(j / FG_DH) * DSTR + (j % FG_DH)] = t[u];
+                            if (j < NC * FGS_DH) dbuf[(j / FGS_DH) * FGS_DSTR + (j % FGS_DH)] = t[u];
                         }
                         wave_lds_fence();
                     }
                 }
-                if (on) k.autoc[(cl * P.nvec + nv) * (MAXO + 1) + l] = acc;
+                if (on) autoc[(cl * P.nvec + nv) * (MAXO + 1) + l] = acc;
                 wave_lds_fence();
             }
             else if (punch) {
@@ -474,7 +453,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 const uint32_t total = (uint32_t)NC * (mo + 1);
                 for (uint32_t j = lane; j < total; j += 64) {
                     const uint32_t c = j / (mo + 1), ll = j % (mo + 1);
-                    LDS double *base = k.autoc + c * P.nvec * (MAXO + 1);
+                    LDS double *base = autoc + c * P.nvec * (MAXO + 1);
                     const double prev = base[(nv - 1) * (MAXO + 1) + ll];
                     base[nv * (MAXO + 1) + ll] = (ll < mo) ? base[ll] - prev : prev;
                 }
@@ -494,7 +473,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         if (mydbg) {
             for (uint32_t j = lane; j < (uint32_t)NC * nv * (mo + 1); j += 64) {
                 const uint32_t c = j / (nv * (mo + 1)), r = j % (nv * (mo + 1)), v = r / (mo + 1), ll = r % (mo + 1);
-                mydbg->cand[c].autoc[v][ll] = k.autoc[(c * P.nvec + v) * (MAXO + 1) + ll];
+                mydbg->cand[c].autoc[v][ll] = autoc[(c * P.nvec + v) * (MAXO + 1) + ll];
             }
             if (lane < NC) mydbg->cand[lane].nvec = nv;
         }
@@ -506,12 +485,12 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     if (nv > 0) {
         const uint32_t nidx = (uint32_t)NC * P.nvec;
         const uint32_t LS = nidx;
-        LDS double *lpcw = k.dbuf;
-        LDS float *lpf = (LDS float *)(k.dbuf + (size_t)mo * LS);
+        LDS double *lpcw = dbuf;
+        LDS float *lpf = (LDS float *)(dbuf + (size_t)mo * LS);
         const uint32_t idx = lane;
         if (idx < nidx) {
             const uint32_t c = idx / P.nvec, v = idx % P.nvec;
-            const LDS double *A = k.autoc + (c * P.nvec + v) * (MAXO + 1);
+            const LDS double *A = autoc + (c * P.nvec + v) * (MAXO + 1);
             bool on = v < nv && ((lpc_mask >> c) & 1);
             if (on && A[0] == 0.0) on = false;
             uint32_t sb = sbp[0];
@@ -561,7 +540,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
             for (uint32_t jj = 0; jj < ostar; jj++) lpf[jj * LS + idx] = (float)(-lpcw[jj * LS + idx]);
             uint32_t result = 0;
-            for (uint32_t j = 0; j < (uint32_t)MAXO; j++) k.qres[idx * MAXO + j] = 0;
+            for (uint32_t j = 0; j < (uint32_t)MAXO; j++) qres[idx * MAXO + j] = 0;
             if (on) {
                 bool ok = !(f_ebps(err2, 0.5 / (double)(n - ostar)) >= (double)sb);
                 uint32_t prec = P.qlp_precision;
@@ -590,23 +569,25 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                             int32_t qv = (int32_t)(i64)rq;
                             if (qv > qmax) qv = qmax; else if (qv < qmin) qv = qmin;
                             error -= (double)qv;
-                            k.qres[idx * MAXO + j] = qv;
+                            qres[idx * MAXO + j] = qv;
                         }
                         if (neg) shift = 0;
                     }
                 }
                 result = ostar | (prec << 8) | (((uint32_t)shift & 0xFF) << 16) | ((ok ? 1u : 0u) << 24) | (1u << 25);
             }
-            k.lres[idx] = result;
+            lres[idx] = result;
         }
         wave_lds_fence();
     }
     FG_STAMP(5);
 
-    // ================================================================ evaluation of the predictors: pass 0 = fixed, then
-    // one pass per autocorrelation vector.  Each pass: FIR residual of every enabled candidate, |r| partition sums,
-    // Rice parameter / partition order search, strict-< update of the best (libFLAC's candidate order).
-    const uint32_t psz0 = n >> pmax0, ipp0 = psz0 >> 6, parts0 = 1u << pmax0;
+    // ================================================================ evaluation of the predictors: pass 0 = fixed, then one
+    // pass per autocorrelation vector.  Each pass: every lane runs the FIR of every candidate over its segment (history in
+    // registers, coefficients in SGPRs); its |residual| total is a partition sum.  Then the Rice parameter / partition
+    // order search (lane = partition) and the strict-< update of the best (libFLAC's candidate order).
+    const uint32_t parts0 = 1u << pmax0;
+#pragma unroll 1
     for (uint32_t pass = 0; pass < 1 + nv; pass++) {
         uint32_t order[NC], prec[NC], emask = 0;
         int32_t q[NC][MAXO];
@@ -631,73 +612,87 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const uint32_t idx = (uint32_t)c * P.nvec + v;
-                const uint32_t r = rfl(k.lres[idx]);
+                const uint32_t r = rfl(lres[idx]);
                 order[c] = r & 0xFF; prec[c] = (r >> 8) & 0xFF; shift[c] = (int)(int8_t)((r >> 16) & 0xFF);
                 if (((lpc_mask >> c) & 1) && ((r >> 24) & 1)) emask |= 1u << c;
                 if (order[c] == 0) order[c] = 1;
 #pragma unroll
-                for (int j = 0; j < MAXO; j++) q[c][j] = (int32_t)rfl((uint32_t)k.qres[idx * MAXO + j]);
+                for (int j = 0; j < MAXO; j++) q[c][j] = (int32_t)rfl((uint32_t)qres[idx * MAXO + j]);
                 if (mydbg && lane == 0) mydbg->cand[c].lpc_guess[v] = ((r >> 25) & 1) ? (r & 0xFF) : 0;
             }
             if (!emask) continue;
         }
-        // ---- residual partition sums, lane p = partition p
+        // ---- FIR over the segment
         sum_t psum[NC];
         uint32_t ovf[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) { psum[c] = 0; ovf[c] = 0; }
         {
-            uint32_t t = 0;
-            for (uint32_t p = 0; p < parts0; p++) {
-                sum_t a[NC];
+            int32_t h[NC][MAXO];
 #pragma unroll
-                for (int c = 0; c < NC; c++) a[c] = 0;
-                for (uint32_t kk = 0; kk < ipp0; kk++, t++) {
-                    const int i = (int)((t << 6) + lane);
-                    int32_t l[MAXO + 1], r[MAXO + 1];
+            for (int c = 0; c < NC; c++) { psum[c] = 0; ovf[c] = 0; }
+            // history: the MAXO samples in front of the segment; sample (s - 1 - j) lives in slot (s - 1 - j) mod MAXO
 #pragma unroll
-                    for (int j = 0; j <= MAXO; j++) { l[j] = k.pl[i - j]; r[j] = (NCH == 2) ? k.pr[i - j] : 0; }
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        if (!((emask >> c) & 1)) continue;
-                        int32_t res;
-                        const int32_t x0 = fcv_rt<MS>((uint32_t)c, l[0], r[0], 0);
-                        if (!ACC64) {
-                            int32_t s = 0;
-#pragma unroll
-                            for (int j = 0; j < MAXO; j++) s += __mul24(q[c][j], fcv_rt<MS>((uint32_t)c, l[j + 1], r[j + 1], 0));
-                            res = x0 - (s >> shift[c]);
-                        }
-                        else {
-                            i64 s = 0;
-#pragma unroll
-                            for (int j = 0; j < MAXO; j++) s += (i64)q[c][j] * (i64)fcv_rt<MS>((uint32_t)c, l[j + 1], r[j + 1], 0);
-                            const i64 rr = (i64)x0 - (s >> shift[c]);
-                            if (rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) ovf[c] = 1;
-                            res = (int32_t)rr;
-                        }
-                        if ((uint32_t)i >= order[c]) a[c] += (uint32_t)abs(res);
-                    }
-                }
+            for (int j = 0; j < MAXO; j++) {
+                int32_t l = 0, r = 0;
+                if (lane > 0) { l = rowL[(int)seg - 1 - j - (int)rstr]; r = (NCH == 2) ? rowR[(int)seg - 1 - j - (int)rstr] : 0; }
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    if (!((emask >> c) & 1)) continue;
-                    sum_t tt;
-                    if (ACC64) tt = (sum_t)wave_sum64((u64)a[c]);
-                    else tt = (sum_t)wave_sum((uint32_t)a[c]);
-                    if ((uint32_t)lane == p) psum[c] = tt;
+                    const int32_t x = !MS ? (c == 0 ? l : r) : (c == 0 ? l : c == 1 ? r : c == 2 ? ((l + r) >> 1) : (l - r));
+                    h[c][(MAXO - 1 - j) % MAXO] = x;
                 }
             }
+            auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
+                const int32_t l = rowL[s], r = (NCH == 2) ? rowR[s] : 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const int32_t x = !MS ? (c == 0 ? l : r) : (c == 0 ? l : c == 1 ? r : c == 2 ? ((l + r) >> 1) : (l - r));
+                    int32_t res;
+                    if (!ACC64) res = x - (fir24<MAXO>(q[c], h[c], u) >> shift[c]);
+                    else {
+                        const i64 rr = (i64)x - (fir64<MAXO>(q[c], h[c], u) >> shift[c]);
+                        if (rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) ovf[c] = 1;
+                        res = (int32_t)rr;
+                    }
+                    h[c][u] = x;
+                    // warm-up samples (the first `order` of the block, all in lane 0) are not residuals
+                    if (!guard || lane > 0 || s >= order[c]) psum[c] += fabs32(res);
+                }
+            };
+            uint32_t s0 = 0;
+            // first group: may contain warm-up samples
+            if (seg >= (uint32_t)MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, (uint32_t)u, true);
+                s0 = MAXO;
+            }
+#pragma unroll 1
+            for (; s0 + MAXO <= seg; s0 += MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
         }
-        // ---- Rice search per candidate
+        // ---- Rice search per candidate (lane p = partition p of the finest order)
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             if (!((emask >> c) & 1)) continue;
             uint32_t est = 0;
             if (!(ACC64 && __any(ovf[c] != 0))) {
                 const uint32_t limit = P.rice_limit, sb = sbp[c];
+                const uint32_t psz0 = n >> pmax0;
                 const bool wrap32 = (sb + 4) < (32 - ilog2_32(psz0));
                 u64 s = (u64)psum[c];
+                // 64 segments -> 2^pmax0 partitions: merge neighbours (6 - pmax0) times
+                for (uint32_t m = 6; m > pmax0; m--) {
+                    const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
+                    const int src = (lane * 2) & 63;
+                    u64 s0_ = (uint32_t)__shfl((int)lo, src), s1_ = (uint32_t)__shfl((int)lo, src + 1);
+                    if (ACC64) {
+                        s0_ |= (u64)(uint32_t)__shfl((int)hi, src) << 32;
+                        s1_ |= (u64)(uint32_t)__shfl((int)hi, src + 1) << 32;
+                    }
+                    s = ((uint32_t)lane < (1u << (m - 1))) ? s0_ + s1_ : 0;
+                }
                 if (wrap32) s &= 0xFFFFFFFFull;
                 uint32_t best_bits = 0, bpo = 0, kb = 0;
                 for (int po = (int)pmax0; po >= (int)pmin0; po--) {
@@ -723,22 +718,22 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                         // merge pairs: lane p <- s[2p] + s[2p+1]
                         const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
                         const int src = (lane * 2) & 63;
-                        u64 s0 = (uint32_t)__shfl((int)lo, src), s1 = (uint32_t)__shfl((int)lo, src + 1);
+                        u64 s0_ = (uint32_t)__shfl((int)lo, src), s1_ = (uint32_t)__shfl((int)lo, src + 1);
                         if (__any(hi != 0)) {
-                            s0 |= (u64)(uint32_t)__shfl((int)hi, src) << 32;
-                            s1 |= (u64)(uint32_t)__shfl((int)hi, src + 1) << 32;
+                            s0_ |= (u64)(uint32_t)__shfl((int)hi, src) << 32;
+                            s1_ |= (u64)(uint32_t)__shfl((int)hi, src + 1) << 32;
                         }
-                        s = ((uint32_t)lane < (parts >> 1)) ? s0 + s1 : 0;
+                        s = ((uint32_t)lane < (parts >> 1)) ? s0_ + s1_ : 0;
                     }
                 }
-                est = kind == 0 ? (8 + wst[c] + order[c] * sb) : (8 + wst[c] + 4 + 5 + order[c] * (prec[c] + sb));
+                est = kind == 0 ? (8 + order[c] * sb) : (8 + 4 + 5 + order[c] * (prec[c] + sb));
                 if (best_bits < 0xFFFFFFFFu - est) est += best_bits; else est = 0xFFFFFFFFu;
                 if (est > 0 && est < best[c]) {
                     best[c] = est;
                     d_type[c] = kind == 0 ? 2 : 3; d_order[c] = order[c]; d_prec[c] = prec[c]; d_shift[c] = shift[c];
                     d_porder[c] = bpo; d_k[c] = kb;
                     d_method[c] = __any(((uint32_t)lane < (1u << bpo)) && kb >= 15) ? 1 : 0;
-                    if (kind == 1 && lane < MAXO) k.bestq[c * MAXO + lane] = k.qres[((uint32_t)c * P.nvec + (pass - 1)) * MAXO + lane];
+                    if (kind == 1 && lane < MAXO) bestq[c * MAXO + lane] = qres[((uint32_t)c * P.nvec + (pass - 1)) * MAXO + lane];
                 }
             }
             if (mydbg && lane == 0) {
@@ -773,7 +768,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 dc->wasted = wst[c]; dc->sbps = sbp[c]; dc->type = d_type[c]; dc->order = d_type[c] >= 2 ? d_order[c] : 0;
                 dc->precision = d_type[c] == 3 ? d_prec[c] : 0; dc->shift = d_type[c] == 3 ? d_shift[c] : 0;
                 dc->bits = best[c]; dc->porder = d_type[c] >= 2 ? d_porder[c] : 0; dc->rice_method = d_type[c] >= 2 ? d_method[c] : 0;
-                for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (d_type[c] == 3 && j < d_order[c] && j < (uint32_t)MAXO) ? k.bestq[c * MAXO + j] : 0;
+                for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (d_type[c] == 3 && j < d_order[c] && j < (uint32_t)MAXO) ? bestq[c * MAXO + j] : 0;
             }
             if (d_type[c] >= 2 && (uint32_t)lane < (1u << d_porder[c])) mydbg->cand[c].rice_params[lane] = d_k[c];
         }
@@ -781,13 +776,17 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     FG_STAMP(7);
 
     // ================================================================ pack: header, subframes, padding, CRC-16
-    FastBW bw;
-    bw.outw = (uint32_t *)(out + (size_t)d.out_slot * P.slot_bytes);
-    bw.slot_words = P.slot_bytes / 4; bw.bitpos = 0; bw.wbase = 0; bw.err = 0;
-    for (uint32_t j = lane; j < FG_WINW + 2; j += 64) k.win[j] = 0;
+    u64 tacc[4] = {0, 0, 0, 0}, tl_ = mydbg ? clock64() : 0;
+#define FG_TACC(i) do { if (mydbg) { const u64 n_ = clock64(); tacc[i] += n_ - tl_; tl_ = n_; } } while (0)
+    FrameBits fb;
+    fb.w = fbw; fb.t0 = crct; fb.thi = crct + 256; fb.tlo = crct + 512;
+    fb.outw = (uint32_t *)(out + (size_t)d.out_slot * P.slot_bytes);
+    fb.slot_words = P.slot_bytes / 4; fb.wbase = 0; fb.err = 0; fb.crc = 0;
+    uint32_t bitpos = 0;
+    for (uint32_t j = lane; j < FGS_FBW + 2; j += 64) fbw[j] = 0;
     wave_lds_fence();
     {   // frame header: assembled by lane 0 in LDS, emitted one byte per lane
-        LDS uint8_t *hb = (LDS uint8_t *)k.misc;
+        LDS uint8_t *hb = (LDS uint8_t *)misc;
         uint32_t hl = 0;
         if (lane == 0) {
             uint32_t u, bs_hint = 0, sr_hint = 0;
@@ -841,18 +840,20 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         wave_lds_fence();
         const uint32_t v = (uint32_t)lane < hl ? hb[lane] : 0, b = (uint32_t)lane < hl ? 8 : 0;
         wave_lds_fence();
-        bw_round(bw, k.win, lane, 0, 0, v, b, b);
+        fb_or(fb, (uint32_t)lane * 8, v, b);
+        bitpos = hl * 8;
+        wave_lds_fence();
     }
+#pragma unroll 1
     for (uint32_t si = 0; si < (uint32_t)NCH; si++) {
         const uint32_t c = MS ? (si == 0 ? sub0 : sub1) : si;
         // select the decision of candidate c (wave-uniform)
-        uint32_t type = d_type[0], order = d_order[0], w = wst[0], sb = sbp[0], prec = d_prec[0], po = d_porder[0], method = d_method[0],
-                 kv = d_k[0];
+        uint32_t type = d_type[0], order = d_order[0], sb = sbp[0], prec = d_prec[0], po = d_porder[0], method = d_method[0], kv = d_k[0];
         int shift = d_shift[0];
 #pragma unroll
         for (int cc = 1; cc < NC; cc++)
             if (c == (uint32_t)cc) {
-                type = d_type[cc]; order = d_order[cc]; w = wst[cc]; sb = sbp[cc]; prec = d_prec[cc]; po = d_porder[cc]; method = d_method[cc];
+                type = d_type[cc]; order = d_order[cc]; sb = sbp[cc]; prec = d_prec[cc]; po = d_porder[cc]; method = d_method[cc];
                 kv = d_k[cc]; shift = d_shift[cc];
             }
         const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
@@ -863,120 +864,215 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         case 2: hdr = 0x10 | (order << 1); break;
         default: hdr = 0x40 | ((order - 1) << 1); break;
         }
-        // ---- one round for everything in front of the residual: lane 0 = subframe header byte (+ wasted-bits unary),
-        // lanes 1..order = warm-up samples, then precision/shift, coefficients, coding method + partition order
+        auto cand = [&](int32_t l, int32_t r) -> int32_t {
+            if (!MS) return c == 0 ? l : r;
+            return c == 0 ? l : c == 1 ? r : c == 2 ? ((l + r) >> 1) : (l - r);
+        };
+        // ---- everything in front of the residual: lane 0 = subframe header byte, lanes 1..order = warm-up samples, then
+        // precision/shift, coefficients, coding method + partition order; positions from one prefix sum
         {
-            uint32_t pv = 0, pb = 0, val = 0, vb = 0, nb = 0;
+            uint32_t pv = 0, pb = 0, val = 0, vb = 0;
             const bool pred = type >= 2;
-            const uint32_t nw = type == 0 ? 1 : (pred ? order : 0);   // sample fields in this round
-            if (lane == 0) { pv = hdr | (w ? 1 : 0); pb = 8; if (w) { val = 1; vb = 1; nb = w; } }
+            const uint32_t nw = type == 0 ? 1 : (pred ? order : 0);   // sample fields
+            if (lane == 0) { pv = hdr; pb = 8; }
             else if ((uint32_t)lane <= nw) {
-                val = (uint32_t)fcv_rt<MS>(c, k.pl[lane - 1], (NCH == 2) ? k.pr[lane - 1] : 0, w) & mask; vb = sb; nb = sb;
+                const uint32_t g = (uint32_t)lane - 1;                 // sample index (inside segment 0: order <= MAXO <= seg)
+                val = (uint32_t)cand(sL[g], (NCH == 2) ? sR[g] : 0) & mask; vb = sb;
             }
-            else if (type == 3 && (uint32_t)lane == order + 1) { pv = prec - 1; pb = 4; val = (uint32_t)shift & 31; vb = 5; nb = 5; }
-            else if (type == 3 && (uint32_t)lane <= 2 * order + 1) {
-                val = (uint32_t)k.bestq[c * MAXO + (lane - order - 2)] & ((1u << prec) - 1); vb = prec; nb = prec;
-            }
-            else if (pred && (uint32_t)lane == (type == 3 ? 2 * order + 2 : order + 1)) { val = (method << 4) | po; vb = 6; nb = 6; }
-            bw_round(bw, k.win, lane, pv, pb, val, vb, nb);
+            else if (type == 3 && (uint32_t)lane == order + 1) { pv = prec - 1; pb = 4; val = (uint32_t)shift & 31; vb = 5; }
+            else if (type == 3 && (uint32_t)lane <= 2 * order + 1) { val = (uint32_t)bestq[c * MAXO + (lane - order - 2)] & ((1u << prec) - 1); vb = prec; }
+            else if (pred && (uint32_t)lane == (type == 3 ? 2 * order + 2 : order + 1)) { val = (method << 4) | po; vb = 6; }
+            const uint32_t mine = pb + vb;
+            const uint32_t incl = wave_scan_add(mine);
+            const uint32_t total = rl(incl, 63);
+            fb_reserve(fb, lane, bitpos, total);
+            const uint32_t o = bitpos + incl - mine;
+            fb_or(fb, o, pv, pb);
+            fb_or(fb, o + pb, val, vb);
+            bitpos += total;
+            wave_lds_fence();
         }
-        if (type == 1) {
-            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                bw_round(bw, k.win, lane, 0, 0, (uint32_t)fcv_rt<MS>(c, k.pl[i], (NCH == 2) ? k.pr[i] : 0, w) & mask, sb, sb);
-            }
+        if (type == 0) continue;
+        // ---- body: pass A = exact bit length of every lane's segment, prefix sum = its start, pass B = OR the codes in
+        int32_t q[MAXO];
+        if (type == 3) {
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rfl((uint32_t)bestq[c * MAXO + j]);
         }
-        else if (type >= 2) {
-            int32_t q[MAXO];
-            if (type == 3) {
+        else {
+            const uint32_t g = type == 2 ? order : 0;
+            const int32_t c0 = g == 0 ? 0 : (int32_t)g, c1 = g < 2 ? 0 : (g == 2 ? -1 : g == 3 ? -3 : -6);
+            const int32_t c2 = g < 3 ? 0 : (g == 3 ? 1 : 4), c3 = g < 4 ? 0 : -1;
 #pragma unroll
-                for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rfl((uint32_t)k.bestq[c * MAXO + j]);
+            for (int j = 0; j < MAXO; j++) q[j] = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : 0;
+            shift = 0;
+        }
+        const uint32_t plen = method ? 5 : 4;
+        const uint32_t lpp = 64u >> po;                                  // lanes per partition
+        const uint32_t kr = type >= 2 ? (uint32_t)__shfl((int)kv, (int)((uint32_t)lane / lpp)) : 0;     // this lane's Rice parameter
+        const bool pstart = type >= 2 && ((uint32_t)lane % lpp) == 0;
+        const uint32_t skip = (type >= 2 && lane == 0) ? order : 0;      // warm-up samples are not coded
+        // one walk over the segment; EMIT = false: returns the bit length, EMIT = true: writes the codes from bit `p0` on
+        // CC = candidate, VERB = verbatim subframe, EMIT: all compile-time, so the per-sample loop has no control flow
+        auto walk_t = [&](auto CC, auto VERB, auto EMIT, auto ATOM, uint32_t p0, bool inrange) __attribute__((always_inline)) -> uint32_t {
+            constexpr int C_ = decltype(CC)::value;
+            constexpr bool verb = decltype(VERB)::value, emit = decltype(EMIT)::value, atom = decltype(ATOM)::value;
+            int32_t h[MAXO];
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) {
+                int32_t x = 0;
+                if (lane > 0) x = fcv<MS, C_>(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                h[(MAXO - 1 - j) % MAXO] = x;
             }
-            else {
-                const uint32_t g = order;
-                const int32_t c0 = g == 0 ? 0 : (int32_t)g, c1 = g < 2 ? 0 : (g == 2 ? -1 : g == 3 ? -3 : -6);
-                const int32_t c2 = g < 3 ? 0 : (g == 3 ? 1 : 4), c3 = g < 4 ? 0 : -1;
-#pragma unroll
-                for (int j = 0; j < MAXO; j++) q[j] = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : 0;
-                shift = 0;
+            uint32_t pos = p0, len = 0;
+            // Emission without LDS atomics (they run at about one lane per clock on this hardware).  A lane's bits are
+            // consecutive, so it keeps the word it is filling in a register (`cur`, window word `cw`) and stores it when
+            // it moves on; the word it ends in is shared with the next lane and is merged after the walk.  The stores
+            // are unconditional: a lane that has nothing to store writes to a scratch word of its own.
+            // This needs every lane to span at least a word (no three lanes in one word): true for 32 or more samples
+            // per lane; shorter segments (atom) OR their bits into the window with LDS atomics instead.
+            LDS uint32_t *const dummy = misc + lane;             // misc[0..63]: header bytes earlier, free by now
+            uint32_t cw = (p0 >> 5) - fb.wbase;
+            uint32_t cur = (emit && !atom && inrange) ? fb.w[cw] : 0;
+            auto put = [&](uint32_t at, uint32_t val, uint32_t vb) __attribute__((always_inline)) {
+                if (atom) { fb_or(fb, inrange ? at : (fb.wbase << 5), inrange ? val : 0, vb); return; }
+                const uint32_t rel = at - (fb.wbase << 5);
+                const uint32_t wi = rel >> 5, sh = rel & 31;
+                const u64 x = (u64)val << ((64 - sh - vb) & 63);
+                const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+                const bool moved = inrange && wi != cw;
+                *(moved ? fb.w + cw : dummy) = cur;
+                cur = moved ? hi : (cur | hi);
+                cw = wi;
+                const bool spill = inrange && lo != 0;
+                *(spill ? fb.w + cw : dummy) = cur;
+                cur = spill ? lo : cur;
+                cw += spill ? 1u : 0u;
+            };
+            if (pstart) {
+                if (emit) put(pos, kr, plen);
+                pos += plen; len += plen;
             }
-            const uint32_t plen = method ? 5 : 4;
-            const uint32_t psz = n >> po, ipp = psz >> 6;
-            uint32_t t = 0;
-            for (uint32_t p = 0; p < (1u << po); p++) {
-                const uint32_t kr = rl(kv, (int)p);
-                for (uint32_t kk = 0; kk < ipp; kk++, t++) {
-                    const int i = (int)((t << 6) + lane);
-                    int32_t xw[MAXO + 1];
-#pragma unroll
-                    for (int j = 0; j <= MAXO; j++) xw[j] = fcv_rt<MS>(c, k.pl[i - j], (NCH == 2) ? k.pr[i - j] : 0, 0);
-                    int32_t r;
-                    if (!ACC64) {
-                        int32_t s = 0;
-#pragma unroll
-                        for (int j = 0; j < MAXO; j++) s += __mul24(q[j], xw[j + 1]);
-                        r = xw[0] - (s >> shift);
-                    }
-                    else {
-                        i64 s = 0;
-#pragma unroll
-                        for (int j = 0; j < MAXO; j++) s += (i64)q[j] * (i64)xw[j + 1];
-                        r = (int32_t)((i64)xw[0] - (s >> shift));
-                    }
-                    uint32_t pv = 0, pb = 0, val = 0, vb = 0, nb = 0;
-                    if ((uint32_t)i >= order) {
-                        const uint32_t u = ((uint32_t)r << 1) ^ (uint32_t)(r >> 31);
-                        val = (1u << kr) | (u & ((1u << kr) - 1));
-                        vb = kr + 1;
-                        nb = (u >> kr) + 1 + kr;
-                        if (kk == 0 && (uint32_t)i == (p == 0 ? order : p * psz)) { pv = kr; pb = plen; }
-                    }
-                    bw_round(bw, k.win, lane, pv, pb, val, vb, nb);
+            const uint32_t kmask = (1u << kr) - 1, kone = 1u << kr;
+            auto step = [&](int u, uint32_t s) __attribute__((always_inline)) {
+                const int32_t x = fcv<MS, C_>(rowL[s], (NCH == 2) ? rowR[s] : 0);
+                uint32_t val, vb, lead;
+                if (verb) { val = (uint32_t)x & mask; vb = sb; lead = 0; }
+                else {
+                    int32_t res;
+                    if (!ACC64) res = x - (fir24<MAXO>(q, h, u) >> shift);
+                    else res = (int32_t)((i64)x - (fir64<MAXO>(q, h, u) >> shift));
+                    h[u] = x;
+                    const uint32_t uu = ((uint32_t)res << 1) ^ (uint32_t)(res >> 31);
+                    lead = uu >> kr;
+                    val = kone | (uu & kmask);
+                    vb = kr + 1;
                 }
+                const bool coded = s >= skip;
+                if (emit) put(coded ? pos + lead : pos, coded ? val : 0, coded ? vb : 0);     // warm-up samples: nothing, in place
+                const uint32_t cl_ = coded ? lead + vb : 0;
+                pos += cl_; len += cl_;
+            };
+            uint32_t s0 = 0;
+#pragma unroll 1
+            for (; s0 + MAXO <= seg; s0 += MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, s0 + u);
             }
+#pragma unroll
+            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u);
+            if (emit && !atom) {
+                // the last word of every lane: no other lane of the group ends in it (each lane spans at least a word)
+                wave_lds_fence();
+                if (inrange) fb.w[cw] |= cur;
+                wave_lds_fence();
+            }
+            return len;
+        };
+        auto walk_c = [&](auto CC, bool emit, uint32_t p0, bool inrange) __attribute__((always_inline)) -> uint32_t {
+            typedef std::integral_constant<bool, true> T;
+            typedef std::integral_constant<bool, false> F;
+            if (!emit) return type == 1 ? walk_t(CC, T(), F(), F(), p0, inrange) : walk_t(CC, F(), F(), F(), p0, inrange);
+            if (seg < 32) return type == 1 ? walk_t(CC, T(), T(), T(), p0, inrange) : walk_t(CC, F(), T(), T(), p0, inrange);
+            return type == 1 ? walk_t(CC, T(), T(), F(), p0, inrange) : walk_t(CC, F(), T(), F(), p0, inrange);
+        };
+        auto walk = [&](bool emit, uint32_t p0, bool inrange) __attribute__((always_inline)) -> uint32_t {
+            if (NC == 1 || c == 0) return walk_c(std::integral_constant<int, 0>(), emit, p0, inrange);
+            if (NC == 2 || c == 1) return walk_c(std::integral_constant<int, (NC > 1 ? 1 : 0)>(), emit, p0, inrange);
+            if (c == 2) return walk_c(std::integral_constant<int, (NC > 2 ? 2 : 0)>(), emit, p0, inrange);
+            return walk_c(std::integral_constant<int, (NC > 3 ? 3 : 0)>(), emit, p0, inrange);
+        };
+        FG_TACC(0);
+        const uint32_t mylen = walk(false, 0, false);
+        FG_TACC(1);
+        if (__any(mylen > (1u << 24))) { fb.err |= FG_ERR_REDO; break; }       // absurd code lengths: the generic kernel copes
+        const uint32_t incl = wave_scan_add(mylen);
+        const uint32_t mystart = bitpos + incl - mylen, myend = bitpos + incl;
+        const uint32_t subend = bitpos + rl(incl, 63);
+        // lanes are emitted in ascending groups that fit the window
+        uint32_t a = 0;
+        bool failed = false;
+#pragma unroll 1
+        while (a < 64) {
+            fb_flush(fb, lane, rl(mystart, (int)a));
+            const uint32_t cap = (fb.wbase << 5) + 32u * FGS_FBW - 64u;
+            const uint64_t fits = __ballot((uint32_t)lane >= a && myend <= cap);
+            // lanes a .. b-1 fit (ends are ascending, so the fitting lanes form a prefix of a..63)
+            const uint64_t shifted = fits >> a;
+            const uint32_t cnt = (~shifted) ? (uint32_t)__builtin_ctzll(~shifted) : 64u - a;
+            if (cnt == 0) { failed = true; break; }
+            const uint32_t b = a + cnt;
+            FG_TACC(0);
+            (void)walk(true, mystart, (uint32_t)lane >= a && (uint32_t)lane < b);
+            wave_lds_fence();
+            FG_TACC(2);
+            a = b;
         }
+        if (failed) { fb.err |= FG_ERR_REDO; break; }
+        bitpos = subend;
     }
+    FG_TACC(0);
     FG_STAMP(8);
-    // ---- zero-pad to a byte, CRC-16 over the whole frame (64 lanes over interleaved words), append
-    if (bw.bitpos & 7) bw.bitpos += 8 - (bw.bitpos & 7);
-    bw_flush(bw, k.win, lane, bw.bitpos);
-    bw_flush_all(bw, k.win, lane);
-    __threadfence_block();
-    {
-        const uint32_t nbytes = bw.bitpos >> 3;
-        const uint32_t W = nbytes >> 2, tail = nbytes & 3;
-        const uint32_t pad = (64 - (W & 63)) & 63, T = (W + pad) >> 6;
-        uint32_t s = 0;
-        const LDS uint16_t *t0 = k.crct, *thi = k.crct + 256, *tlo = k.crct + 512;
-        for (uint32_t t = 0; t < T; t++) {
-            const int qi = (int)(t * 64 + lane) - (int)pad;
-            uint32_t wv = 0;
-            if (qi >= 0) wv = __builtin_bswap32(__builtin_nontemporal_load(&bw.outw[qi]));
-            s = thi[s >> 8] ^ tlo[s & 0xFF];
-            uint32_t cw = 0;
-            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 24)) & 0xFF];
-            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 16)) & 0xFF];
-            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 8)) & 0xFF];
-            cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ wv) & 0xFF];
-            s ^= cw;
+    if (mydbg && lane == 0) { mydbg->t[10] = tacc[0]; mydbg->t[11] = tacc[1]; mydbg->t[12] = tacc[2]; }
+    if (fb.err & FG_ERR_REDO) {
+        if (lane == 0) {
+            FgBlockResult *r = &results[d.out_slot];
+            r->bytes = 0; r->ca = 0; r->err = FG_ERR_REDO; r->reserved = 3;
         }
-        s = gf16_mul(s, k.misc[64 + (63 - lane)]);
+        return;
+    }
+    // ---- zero-pad to a byte, CRC-16 over the whole frame, append
+    if (bitpos & 7) bitpos += 8 - (bitpos & 7);
+    fb_flush(fb, lane, bitpos);
+    {
+        const uint32_t nbytes = bitpos >> 3;
+        const uint32_t W = nbytes >> 2, tail = nbytes & 3;
+        // lane l holds the CRC state of the words l, l+64, ...; its last word is dist = (W - 1 - l) mod 64 words from the end
+        uint32_t s = 0;
+        if ((uint32_t)lane < W) s = gf16_mul(fb.crc, misc[64 + ((W - 1 - (uint32_t)lane) & 63)]);
         uint32_t crc = wave_xor32(s);
         if (tail) {
-            const uint32_t wv = W < bw.slot_words ? __builtin_bswap32(__builtin_nontemporal_load(&bw.outw[W])) : 0;
-            for (uint32_t b = 0; b < tail; b++) crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ (wv >> (24 - 8 * b))) & 0xFF];
+            const uint32_t wv = rfl(fbw[0]);
+            for (uint32_t b = 0; b < tail; b++) crc = ((crc << 8) & 0xFFFF) ^ crct[((crc >> 8) ^ (wv >> (24 - 8 * b))) & 0xFF];
         }
-        bw_put(bw, k.win, lane, crc, 16);
-        bw_flush_all(bw, k.win, lane);
+        if (lane == 0) fb_or(fb, bitpos, crc, 16);
+        bitpos += 16;
+        wave_lds_fence();
+        fb_flush(fb, lane, bitpos);
+        if ((bitpos & 31) && lane == 0) {
+            if (fb.wbase < fb.slot_words) fb.outw[fb.wbase] = __builtin_bswap32(fbw[0]);
+        }
+        if ((bitpos & 31) && fb.wbase >= fb.slot_words) fb.err |= FG_ERR_SLOT;
     }
     FG_STAMP(9);
     if (lane == 0) {
         FgBlockResult *r = &results[d.out_slot];
-        r->bytes = bw.bitpos >> 3; r->ca = ca; r->err = err | bw.err; r->reserved = 1;
+        r->bytes = bitpos >> 3; r->ca = ca; r->err = err | fb.err; r->reserved = 1;
 #pragma unroll
         for (int c = 0; c < 4; c++) r->best_bits[c] = c < NC ? best[c < NC ? c : 0] : 0;
     }
 #undef FG_STAMP
+#undef FG_SADDR
 }
 
 }  // namespace
