@@ -389,7 +389,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         std::vector<FgBlockDesc> slow;
         for (const FgBlockDesc &d : descs) {
             // lane = segment of n/64 samples: at least the predictor history per lane, partitions no finer than a lane
-            bool fast = cfg_fast && d.n >= 64 * 12 && (d.n & 63) == 0;
+            bool fast = cfg_fast && d.n >= 64 * 16 && (d.n & 63) == 0;    // more samples per lane than any predictor order
             if (fast) {
                 uint32_t pm = 0, b = d.n;
                 while (!(b & 1)) { pm++; b >>= 1; }

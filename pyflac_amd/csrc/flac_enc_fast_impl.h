@@ -172,12 +172,16 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 #define FG_CARVE(type, bytes) (LDS type *)(lbase + off); off += (uint32_t)(((bytes) + 15) & ~15u)
     LDS samp_t *sL = FG_CARVE(samp_t, (P.sig_stride + 256) * sizeof(samp_t));      // 64 rows, up to 4 elements of skew each
     LDS samp_t *sR = FG_CARVE(samp_t, NCH == 2 ? (P.sig_stride + 256) * sizeof(samp_t) : 16);
-    LDS double *dbuf = FG_CARVE(double, P.lds_dbuf_bytes > NC * FGS_DSTR * 8 ? P.lds_dbuf_bytes : NC * FGS_DSTR * 8);
+    // the analysis scratch (autocorrelation staging, Levinson-Durbin work space) and the frame-bit window of the packing
+    // stage are never live together: one region
+    uint32_t ubytes = P.lds_dbuf_bytes > NC * FGS_DSTR * 8 ? P.lds_dbuf_bytes : NC * FGS_DSTR * 8;
+    if (ubytes < (FGS_FBW + 2) * 4) ubytes = (FGS_FBW + 2) * 4;
+    LDS double *dbuf = FG_CARVE(double, ubytes);
+    LDS uint32_t *fbw = (LDS uint32_t *)dbuf;
     LDS double *autoc = FG_CARVE(double, NC * P.nvec * (MAXO + 1) * 8);
     LDS int32_t *qres = FG_CARVE(int32_t, NC * P.nvec * MAXO * 4);
     LDS uint32_t *lres = FG_CARVE(uint32_t, NC * P.nvec * 4);
     LDS int32_t *bestq = FG_CARVE(int32_t, NC * MAXO * 4);
-    LDS uint32_t *fbw = FG_CARVE(uint32_t, (FGS_FBW + 2) * 4);
     LDS uint16_t *crct = FG_CARVE(uint16_t, 768 * 2);
     LDS uint32_t *misc = FG_CARVE(uint32_t, 128 * 4);
 #undef FG_CARVE
@@ -413,19 +417,30 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                     if (k0 + FGS_DK < vec_len) fetch(k0 + FGS_DK);       // next chunk's window values travel during the chain
                     wave_lds_fence();
                     if (on) {
+                        // four steps per group; the operands of the next two groups are requested before the FMAs of the
+                        // current one so that the LDS latency overlaps the dependent chain (reads past the chunk stay
+                        // inside the row and are not used)
+#define FG_FMAC4(h) asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
+                        "v_fmac_f64_dpp %0, %2, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
+                        "v_fmac_f64_dpp %0, %3, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
+                        "v_fmac_f64_dpp %0, %4, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf"                 \
+                        : "+v"(acc) : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]))
+#define FG_LOAD4(h, j0) do { h[0] = hist[(j0)]; h[1] = hist[(j0) + 1]; h[2] = hist[(j0) + 2]; h[3] = hist[(j0) + 3]; } while (0)
+                        double ha[4], hb[4], hc[4];
                         uint32_t j = 0;
-                        for (; j + 4 <= kn; j += 4) {
-                            const double h0 = hist[j], h1 = hist[j + 1], h2 = hist[j + 2], h3 = hist[j + 3];
-                            asm volatile("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                                         "v_fmac_f64_dpp %0, %2, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                                         "v_fmac_f64_dpp %0, %3, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                                         "v_fmac_f64_dpp %0, %4, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf"
-                                         : "+v"(acc) : "v"(h0), "v"(h1), "v"(h2), "v"(h3));
+                        FG_LOAD4(ha, 0); FG_LOAD4(hb, 4);
+                        for (; j + 12 <= kn; j += 12) {
+                            FG_LOAD4(hc, j + 8);  FG_FMAC4(ha);
+                            FG_LOAD4(ha, j + 12); FG_FMAC4(hb);
+                            FG_LOAD4(hb, j + 16); FG_FMAC4(hc);
                         }
+                        if (j + 4 <= kn) { FG_FMAC4(ha); j += 4; if (j + 4 <= kn) { FG_FMAC4(hb); j += 4; } }
                         for (; j < kn; j++) {
                             const double h0 = hist[j];
-                            asm volatile("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
+                            asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
                         }
+#undef FG_FMAC4
+#undef FG_LOAD4
                     }
                     wave_lds_fence();
                     if (k0 + kn < vec_len) {
@@ -587,6 +602,8 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     // registers, coefficients in SGPRs); its |residual| total is a partition sum.  Then the Rice parameter / partition
     // order search (lane = partition) and the strict-< update of the best (libFLAC's candidate order).
     const uint32_t parts0 = 1u << pmax0;
+    u64 te_fir = 0, te_search = 0, te_setup = 0, te_l = mydbg ? clock64() : 0;
+#define FG_TE(acc) do { if (mydbg) { const u64 n_ = clock64(); acc += n_ - te_l; te_l = n_; } } while (0)
 #pragma unroll 1
     for (uint32_t pass = 0; pass < 1 + nv; pass++) {
         uint32_t order[NC], prec[NC], emask = 0;
@@ -622,6 +639,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
             if (!emask) continue;
         }
+        FG_TE(te_setup);
         // ---- FIR over the segment
         sum_t psum[NC];
         uint32_t ovf[NC];
@@ -672,34 +690,66 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 #pragma unroll
             for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
         }
-        // ---- Rice search per candidate (lane p = partition p of the finest order)
+        FG_TE(te_fir);
+        // ---- Rice parameter / partition order search, all candidates side by side.  The sums stay where they are:
+        // at partition order po, partition p lives in lane p * (64 >> po); going one order down adds the neighbour
+        // 2^(5-po) lanes up (DPP row shift inside a 16-lane row, a permute across rows).
+        {
+            u64 sv[NC];
+            uint32_t best_bits[NC], bpo[NC], kb[NC];
+            bool dead[NC];
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (!((emask >> c) & 1)) continue;
-            uint32_t est = 0;
-            if (!(ACC64 && __any(ovf[c] != 0))) {
-                const uint32_t limit = P.rice_limit, sb = sbp[c];
-                const uint32_t psz0 = n >> pmax0;
-                const bool wrap32 = (sb + 4) < (32 - ilog2_32(psz0));
-                u64 s = (u64)psum[c];
-                // 64 segments -> 2^pmax0 partitions: merge neighbours (6 - pmax0) times
-                for (uint32_t m = 6; m > pmax0; m--) {
-                    const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
-                    const int src = (lane * 2) & 63;
-                    u64 s0_ = (uint32_t)__shfl((int)lo, src), s1_ = (uint32_t)__shfl((int)lo, src + 1);
-                    if (ACC64) {
-                        s0_ |= (u64)(uint32_t)__shfl((int)hi, src) << 32;
-                        s1_ |= (u64)(uint32_t)__shfl((int)hi, src + 1) << 32;
-                    }
-                    s = ((uint32_t)lane < (1u << (m - 1))) ? s0_ + s1_ : 0;
+            for (int c = 0; c < NC; c++) {
+                sv[c] = (u64)psum[c]; best_bits[c] = 0; bpo[c] = 0; kb[c] = 0;
+                dead[c] = ACC64 && __any(ovf[c] != 0);
+            }
+            // lane + dist for dist = 1, 2, 4, 8 (zero past the end of the row), 16, 32
+            auto up = [&](uint32_t v, uint32_t t) __attribute__((always_inline)) -> uint32_t {
+                switch (t) {
+                case 0: return dpp0<0x101>(v);
+                case 1: return dpp0<0x102>(v);
+                case 2: return dpp0<0x104>(v);
+                case 3: return dpp0<0x108>(v);
+                case 4: return (uint32_t)__shfl((int)v, (lane + 16) & 63);
+                default: return (uint32_t)__shfl((int)v, (lane + 32) & 63);
                 }
-                if (wrap32) s &= 0xFFFFFFFFull;
-                uint32_t best_bits = 0, bpo = 0, kb = 0;
-                for (int po = (int)pmax0; po >= (int)pmin0; po--) {
-                    const uint32_t parts = 1u << po;
-                    const uint32_t pbase = n >> po;
-                    uint32_t np = pbase, dv = 0x40000u / pbase;
-                    if (lane == 0) { np -= order[c]; dv = 0x40000u / np; }
+            };
+            auto merge = [&](uint32_t t) __attribute__((always_inline)) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    u64 o = up((uint32_t)sv[c], t);
+                    if (ACC64) o |= (u64)up((uint32_t)(sv[c] >> 32), t) << 32;
+                    sv[c] += o;
+                }
+            };
+            for (uint32_t m = 6; m > pmax0; m--) merge(6 - m);
+            const uint32_t psz0 = n >> pmax0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const bool wrap32 = (sbp[c] + 4) < (32 - ilog2_32(psz0));
+                if (wrap32) sv[c] &= 0xFFFFFFFFull;
+            }
+            const uint32_t limit = P.rice_limit;
+            for (int po = (int)pmax0; po >= (int)pmin0; po--) {
+                const uint32_t stride = 64u >> po;
+                const bool valid = ((uint32_t)lane & (stride - 1)) == 0;
+                const uint32_t pbase = n >> po;
+                // 0x40000 / x for x < 2^16 through the reciprocal, corrected to the exact quotient
+                auto div18 = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+                    uint32_t qd = (uint32_t)(262144.0f * __builtin_amdgcn_rcpf((float)x));
+                    const int32_t r = (int32_t)(0x40000u - qd * x);
+                    if (r < 0) qd--;
+                    else if ((uint32_t)r >= x) qd++;
+                    return qd;
+                };
+                const uint32_t dv_all = div18(pbase);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const u64 s = sv[c];
+                    uint32_t np = pbase, dv = dv_all;
+                    if (lane == 0) np -= order[c];
+                    const uint32_t dv0 = div18(pbase - order[c]);
+                    if (lane == 0) dv = dv0;
                     uint32_t kr = 0;
                     if (s >= 2) {
                         const u64 qv = ((s - 1) * dv) >> 18;
@@ -708,41 +758,40 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                     if (kr >= limit) kr = limit - 1;
                     u64 pb = (u64)4 + (u64)(1 + kr) * np + (kr ? (s >> (kr - 1)) : (s << 1)) - (np >> 1);
                     if (pb > 0xFFFFFFFFull) pb = 0xFFFFFFFFull;
-                    if ((uint32_t)lane >= parts) pb = 0;
+                    if (!valid) pb = 0;
                     u64 total;
                     if (__any(pb >> 25)) total = wave_sum64(pb) + 6;
                     else total = (u64)wave_sum((uint32_t)pb) + 6;
                     const uint32_t bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
-                    if (best_bits == 0 || bits < best_bits) { best_bits = bits; bpo = (uint32_t)po; kb = kr; }
-                    if (po > (int)pmin0) {
-                        // merge pairs: lane p <- s[2p] + s[2p+1]
-                        const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
-                        const int src = (lane * 2) & 63;
-                        u64 s0_ = (uint32_t)__shfl((int)lo, src), s1_ = (uint32_t)__shfl((int)lo, src + 1);
-                        if (__any(hi != 0)) {
-                            s0_ |= (u64)(uint32_t)__shfl((int)hi, src) << 32;
-                            s1_ |= (u64)(uint32_t)__shfl((int)hi, src + 1) << 32;
-                        }
-                        s = ((uint32_t)lane < (parts >> 1)) ? s0_ + s1_ : 0;
+                    if (best_bits[c] == 0 || bits < best_bits[c]) { best_bits[c] = bits; bpo[c] = (uint32_t)po; kb[c] = kr; }
+                }
+                if (po > (int)pmin0) merge(6 - (uint32_t)po);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                uint32_t est = 0;
+                if (((emask >> c) & 1) && !dead[c]) {
+                    const uint32_t sb = sbp[c];
+                    est = kind == 0 ? (8 + order[c] * sb) : (8 + 4 + 5 + order[c] * (prec[c] + sb));
+                    if (best_bits[c] < 0xFFFFFFFFu - est) est += best_bits[c]; else est = 0xFFFFFFFFu;
+                    if (est > 0 && est < best[c]) {
+                        best[c] = est;
+                        d_type[c] = kind == 0 ? 2 : 3; d_order[c] = order[c]; d_prec[c] = prec[c]; d_shift[c] = shift[c];
+                        d_porder[c] = bpo[c]; d_k[c] = kb[c];          // parameter of partition p in lane p * (64 >> order)
+                        d_method[c] = __any((((uint32_t)lane & ((64u >> bpo[c]) - 1)) == 0) && kb[c] >= 15) ? 1 : 0;
+                        if (kind == 1 && lane < MAXO) bestq[c * MAXO + lane] = qres[((uint32_t)c * P.nvec + (pass - 1)) * MAXO + lane];
                     }
                 }
-                est = kind == 0 ? (8 + order[c] * sb) : (8 + 4 + 5 + order[c] * (prec[c] + sb));
-                if (best_bits < 0xFFFFFFFFu - est) est += best_bits; else est = 0xFFFFFFFFu;
-                if (est > 0 && est < best[c]) {
-                    best[c] = est;
-                    d_type[c] = kind == 0 ? 2 : 3; d_order[c] = order[c]; d_prec[c] = prec[c]; d_shift[c] = shift[c];
-                    d_porder[c] = bpo; d_k[c] = kb;
-                    d_method[c] = __any(((uint32_t)lane < (1u << bpo)) && kb >= 15) ? 1 : 0;
-                    if (kind == 1 && lane < MAXO) bestq[c * MAXO + lane] = qres[((uint32_t)c * P.nvec + (pass - 1)) * MAXO + lane];
+                if (mydbg && lane == 0 && ((emask >> c) & 1)) {
+                    if (kind == 0) mydbg->cand[c].fixed_bits = est;
+                    else mydbg->cand[c].lpc_bits[pass - 1] = est;
                 }
-            }
-            if (mydbg && lane == 0) {
-                if (kind == 0) mydbg->cand[c].fixed_bits = est;
-                else mydbg->cand[c].lpc_bits[pass - 1] = est;
             }
         }
         wave_lds_fence();
     }
+    FG_TE(te_search);
+    if (mydbg && lane == 0) { mydbg->t[13] = te_fir; mydbg->t[14] = te_search; mydbg->t[15] = te_setup; }
     FG_STAMP(6);
 
     // ================================================================ channel assignment
@@ -770,7 +819,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 dc->bits = best[c]; dc->porder = d_type[c] >= 2 ? d_porder[c] : 0; dc->rice_method = d_type[c] >= 2 ? d_method[c] : 0;
                 for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (d_type[c] == 3 && j < d_order[c] && j < (uint32_t)MAXO) ? bestq[c * MAXO + j] : 0;
             }
-            if (d_type[c] >= 2 && (uint32_t)lane < (1u << d_porder[c])) mydbg->cand[c].rice_params[lane] = d_k[c];
+            if (d_type[c] >= 2 && ((uint32_t)lane & ((64u >> d_porder[c]) - 1)) == 0) mydbg->cand[c].rice_params[(uint32_t)lane >> (6 - d_porder[c])] = d_k[c];
         }
     }
     FG_STAMP(7);
@@ -909,7 +958,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         }
         const uint32_t plen = method ? 5 : 4;
         const uint32_t lpp = 64u >> po;                                  // lanes per partition
-        const uint32_t kr = type >= 2 ? (uint32_t)__shfl((int)kv, (int)((uint32_t)lane / lpp)) : 0;     // this lane's Rice parameter
+        const uint32_t kr = type >= 2 ? (uint32_t)__shfl((int)kv, (int)((uint32_t)lane & ~(lpp - 1))) : 0;   // this lane's Rice parameter
         const bool pstart = type >= 2 && ((uint32_t)lane % lpp) == 0;
         const uint32_t skip = (type >= 2 && lane == 0) ? order : 0;      // warm-up samples are not coded
         // one walk over the segment; EMIT = false: returns the bit length, EMIT = true: writes the codes from bit `p0` on

@@ -22,8 +22,8 @@ for level, secs in ((5, 2.0), (5, 600.0)):
     for k, nme in enumerate(names):
         print('   %-18s %10.0f  (%.1f%%)' % (nme, d[:, k].mean(), 100 * d[:, k].mean() / tot))
     print('   total %.0f' % tot)
-    X = np.array([[r.t[k] for k in range(10, 13)] for r in recs], dtype=np.float64).mean(axis=0)
-    print('   pack split: other %.0f  passA %.0f  passB %.0f' % (X[0], X[1], X[2]))
+    X = np.array([[r.t[k] for k in range(10, 16)] for r in recs], dtype=np.float64).mean(axis=0)
+    print('   pack split: other %.0f  passA %.0f  passB %.0f;  eval split: fir %.0f  search %.0f  setup %.0f' % (X[0], X[1], X[2], X[3], X[4], X[5]))
 import pyflac_amd
 try:
     enc = pyflac_amd.StreamEncoder(48000, lambda b, n, s, f: None, compression_level=5, blocksize=4096)
