@@ -21,6 +21,7 @@
 // FLAC__lpc_restore_signal, undo_channel_coding inside libFLAC.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fg_dev.h"
 #include "fg_types.h"
@@ -59,7 +60,7 @@ typedef const __attribute__((address_space(1))) fg_u32x4 *FgGroupPtr;
 #define FG_RG 64                      // ring capacity in groups (1 KiB per lane)
 #define FG_RSTR (FG_RG * 4)           // ring row stride in words
 #define FG_RAHEAD 20                  // groups guaranteed ahead of the read position at a tile start
-#define FG_RCAP 40                    // never hold more than this many groups ahead
+#define FG_RCAP 52                    // never hold more than this many groups ahead
 #define FG_PF 8                       // groups fetched per lane and tile
 
 struct BitRdState { uint32_t w0, w1, w2, w3, s, wb; };
@@ -72,7 +73,8 @@ struct BitRd {
     uint32_t w0, w1, w2, w3, s;
     uint32_t wb;            // byte offset (relative to fg) of the next word to read from the ring; w3 = word wb/4 - 1
     uint32_t H;             // groups below H are in the ring (or already consumed)
-    uint32_t pfH, pfn;      // groups [pfH, pfH + pfn) are in flight
+    uint32_t pfH, pfn;      // groups [pfH, pfH + FG_PF) are in flight, the first pfn of them count
+    bool pfvalid;
     fg_u32x4 pf[FG_PF];
 
     __device__ __forceinline__ fg_u32x4 ldgroup(uint32_t g) const { return fg[g < glim ? g : glim]; }
@@ -97,7 +99,7 @@ struct BitRd {
         fg = frame_group; glim = group_limit; skip0 = frame_bit0; ring = lds_ring;
         const uint32_t b = frame_bit0 + start_bit;
         const uint32_t w = b >> 5, sk = b & 31;
-        wb = w * 4; H = w >> 2; pfH = H; pfn = 0;
+        wb = w * 4; H = w >> 2; pfH = H; pfn = 0; pfvalid = false;
         w0 = 0;
         if (sk) w0 = be32(fetch());
         w1 = be32(fetch());
@@ -147,27 +149,39 @@ struct BitRd {
             if (pos() > limit_bits) return z;
         }
     }
-    // tile start, step 1: park the groups requested one tile ago
+    // tile start, step 1: park the groups requested one tile ago.  Every lane parks all FG_PF registers: ring slots of
+    // groups that are not valid yet are free, and a group that is already there is rewritten with the same bytes.
     __device__ __forceinline__ void land()
     {
+        if (fg && pfvalid) {       // lanes without a frame own no ring; nothing was requested before the first tile
 #pragma unroll
-        for (int t = 0; t < FG_PF; t++) {
-            const uint32_t g = pfH + t;
-            if ((uint32_t)t < pfn && g >= H) *(fg_u32x4 *)&ring[(g & (FG_RG - 1)) * 4] = pf[t];
+            for (int t = 0; t < FG_PF; t++) *(fg_u32x4 *)&ring[((pfH + t) & (FG_RG - 1)) * 4] = pf[t];
         }
-        if (pfH + pfn > H) H = pfH + pfn;
+        const uint32_t h2 = pfH + pfn;
+        H = h2 > H ? h2 : H;
         pfn = 0;
     }
-    // tile start, step 2 (lanes that will parse): guarantee the look-ahead, then request the next groups
+    // tile start, step 2: guarantee the look-ahead of the lanes that will parse, then request the next FG_PF groups
+    // (straight-line code: one address, FG_PF loads; a lane that is far enough ahead simply does not count them)
     __device__ __forceinline__ void issue(bool on)
     {
         const uint32_t cg = wb >> 4;
-        if (on) while (H < cg + FG_RAHEAD) selfload();
-        pfH = H;
-        pfn = 0;
-        if (on && H < cg + FG_RCAP) { pfn = cg + FG_RCAP - H; if (pfn > FG_PF) pfn = FG_PF; }
+        if (__any(on && H < cg + FG_RAHEAD)) { if (on) while (H < cg + FG_RAHEAD) selfload(); }
+        // start of the batch, pulled back at the very end of the stream so that every load stays inside it
+        const uint32_t last = glim >= FG_PF - 1 ? glim - (FG_PF - 1) : 0;
+        pfH = H < last ? H : last;
+        pfn = (on && H + FG_PF <= cg + FG_RCAP) ? FG_PF : 0;
+        if (!fg) return;
+        pfvalid = true;
+        if (glim >= FG_PF - 1) {
+            const FgGroupPtr src = fg + pfH;
 #pragma unroll
-        for (int t = 0; t < FG_PF; t++) if ((uint32_t)t < pfn) pf[t] = ldgroup(H + t);
+            for (int t = 0; t < FG_PF; t++) pf[t] = src[t];
+        }
+        else {
+#pragma unroll
+            for (int t = 0; t < FG_PF; t++) pf[t] = ldgroup(pfH + t);
+        }
     }
 };
 
@@ -201,7 +215,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
     const uint32_t end_bits = alive ? (fr.bytes - 2) * 8 : 0;
     BitRd br;
     br.fg = nullptr; br.glim = 0; br.skip0 = 0; br.ring = rings; br.w0 = 0; br.w1 = 0; br.w2 = 0; br.w3 = 0; br.s = 0; br.wb = 12; br.H = 0;
-    br.pfH = 0; br.pfn = 0;
+    br.pfH = 0; br.pfn = 0; br.pfvalid = false;
     if (alive) {
         const uintptr_t sa = (uintptr_t)stream;
         const FgGroupPtr gbase = (FgGroupPtr)(sa & ~(uintptr_t)15);
@@ -319,7 +333,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                         // short: the word advance is decided by comparing lz with (s - k - 1), prepared one code earlier.
                         const uint32_t kp1 = k + 1;
                         uint32_t lzmax = 0;
-                        uint32_t w0 = br.w0, w1 = br.w1, w2 = br.w2, w3 = br.w3, wb = br.wb;
+                        uint32_t w0 = br.w0, w1 = br.w1, w2 = br.w2, w3 = br.w3, wb = br.wb - 4;      // wb: ring offset of w3's word
                         uint32_t sm = br.s;
                         int32_t smk = (int32_t)(sm - kp1);
                         const char *rbase = (const char *)br.ring;
@@ -336,19 +350,20 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                                 lzmax = lz > lzmax ? lz : lzmax;
                                 sm = (uint32_t)(smk - (int32_t)lz) & 31;
                                 smk = (int32_t)(sm - kp1);
+                                // word advance as selects, the queue tail re-read every code (same word when nothing
+                                // moved): no EXEC-mask region in the loop, which costs more than these few selects
+                                const uint32_t nx = be32(w3);
                                 w0 = adv ? w1 : w0;
                                 w1 = adv ? w2 : w1;
-                                if (adv) {
-                                    w2 = be32(w3);
-                                    w3 = *(const uint32_t *)(rbase + (wb & (FG_RG * 16 - 1)));
-                                    wb += 4;
-                                }
+                                w2 = adv ? nx : w2;
+                                wb += adv ? 4u : 0u;
+                                w3 = *(const uint32_t *)(rbase + (wb & (FG_RG * 16 - 1)));
                             }
                             *(uint4 *)(row + jj) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
                         }
                         // a code longer than the window (or an all-zero window) voids the attempt
                         if (__any(lzmax > 32 - kp1)) br.restore(keep);
-                        else { br.w0 = w0; br.w1 = w1; br.w2 = w2; br.w3 = w3; br.wb = wb; br.s = sm; }
+                        else { br.w0 = w0; br.w1 = w1; br.w2 = w2; br.w3 = w3; br.wb = wb + 4; br.s = sm; }
                         if (!__any(lzmax > 32 - kp1)) { tk = k; ii = FG_TS; tp[5]++; } else tp[6]++;
                     }
                     if (ii < FG_TS) tp[7]++;
@@ -391,26 +406,45 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
             if (isconst) tk = 0xFE;
             wave_lds_fence();
             // ---- cooperative flush: one row per pass, lane = column; the row's facts come from its lane's registers
-            for (uint32_t r = 0; r < G; r++) {
-                const uint32_t rn_s = rl(rn, (int)r);
-                if (i0 >= rn_s) continue;
-                const uint32_t kk = rl(tk, (int)r);
-                const u64 off_s = ((u64)rl((uint32_t)(roff >> 32), (int)r) << 32) | rl((uint32_t)roff, (int)r);
-                const uint32_t i = i0 + (uint32_t)lane;
-                uint32_t val;
-                if (kk == 0xFE) val = rl(cval, (int)r);
-                else {
-                    val = tile[r * FG_TSTR + lane];
-                    if (kk != 0xFF) {
-                        const uint32_t mlo = rl((uint32_t)tmask, (int)r), mhi = rl((uint32_t)(tmask >> 32), (int)r);
-                        const uint32_t done = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1;
-                        const uint32_t lz = (uint32_t)__clz(val);
-                        const uint32_t rest = (val << lz) << 1;
-                        const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
-                        val = done ? val : (uint32_t)unzig(u);
-                    }
+            const uint32_t meta = (rn << 8) | tk;                      // block sizes are below 2^16
+            const uint32_t icol = i0 + (uint32_t)lane;
+            if (!__any((uint32_t)lane < G && rn > i0 && (tk >= 0xFE || tmask != 0))) {
+                // common case: every row is a full tile of code windows; the next row's entry is requested early
+                uint32_t vnext = tile[lane];
+                for (uint32_t r = 0; r < G; r++) {
+                    const uint32_t val = vnext;
+                    if (r + 1 < G) vnext = tile[(r + 1) * FG_TSTR + lane];
+                    const uint32_t m = rl(meta, (int)r), rn_s = m >> 8, kk = m & 0xFF;
+                    if (i0 >= rn_s) continue;
+                    const u64 off_s = ((u64)rl((uint32_t)(roff >> 32), (int)r) << 32) | rl((uint32_t)roff, (int)r);
+                    const uint32_t lz = (uint32_t)__clz(val);
+                    const uint32_t rest = (val << lz) << 1;
+                    const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                    const int32_t res = unzig(u);
+                    if (i0 + FG_TS <= rn_s) scratch[off_s + icol] = res;
+                    else if (icol < rn_s) scratch[off_s + icol] = res;
                 }
-                if (i < rn_s) scratch[off_s + i] = (int32_t)val;
+            }
+            else {
+                for (uint32_t r = 0; r < G; r++) {
+                    const uint32_t m = rl(meta, (int)r), rn_s = m >> 8, kk = m & 0xFF;
+                    if (i0 >= rn_s) continue;
+                    const u64 off_s = ((u64)rl((uint32_t)(roff >> 32), (int)r) << 32) | rl((uint32_t)roff, (int)r);
+                    uint32_t val;
+                    if (kk == 0xFE) val = rl(cval, (int)r);
+                    else {
+                        val = tile[r * FG_TSTR + lane];
+                        if (kk != 0xFF) {
+                            const uint32_t mlo = rl((uint32_t)tmask, (int)r), mhi = rl((uint32_t)(tmask >> 32), (int)r);
+                            const uint32_t done = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1;
+                            const uint32_t lz = (uint32_t)__clz(val);
+                            const uint32_t rest = (val << lz) << 1;
+                            const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                            val = done ? val : (uint32_t)unzig(u);
+                        }
+                    }
+                    if (icol < rn_s) scratch[off_s + icol] = (int32_t)val;
+                }
             }
             wave_lds_fence();
             if (act && br.pos() > end_bits) { err = 1; alive = false; rn = 0; }
@@ -704,11 +738,12 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
 
 // Frames per wave: narrow waves while the launch cannot fill the SIMDs (the kernels are chains of dependent work per lane),
 // full waves for large batches.
-static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes)
+static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes, uint32_t waves_per_simd)
 {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t simds = (uint32_t)cus * 4;
+    uint32_t simds = (uint32_t)cus * 4 * waves_per_simd;
+    if (getenv("FLACGPU_DEC_WPS")) simds = (uint32_t)cus * 4 * (uint32_t)atoi(getenv("FLACGPU_DEC_WPS"));
     uint32_t g = (nframes + simds - 1) / simds;
     const uint32_t gmax = 64 / per_frame_lanes;
     if (g < 1) g = 1;
@@ -721,7 +756,7 @@ extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_le
                                      hipStream_t stream)
 {
     if (nframes == 0) return 0;
-    uint32_t G = fg_dec_group(nframes, 1);
+    uint32_t G = fg_dec_group(nframes, 1, 2);
     if (G > 32) G = 32;     // LDS per wave grows with G (ring + tile rows); 32 keeps several waves per CU
     const size_t lds = (size_t)G * (FG_RSTR + FG_TSTR) * 4;
     hipLaunchKernelGGL(fg_dec_rice_kernel, dim3((nframes + G - 1) / G), dim3(64), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G,
@@ -736,7 +771,7 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
     if (nframes == 0) return 0;
     hipLaunchKernelGGL(fg_dec_crc_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_stream, d_frames, nframes, d_results, d_crctab);
     const uint32_t C = channels ? channels : 1;
-    uint32_t G = fg_dec_group(nframes, C);
+    uint32_t G = fg_dec_group(nframes, C, 1);
     if (G * C > FG_RROWS) G = FG_RROWS / C;
     if (G < 1) return -1;
     const dim3 grid((nframes + G - 1) / G);

@@ -144,6 +144,84 @@ BENCH_BEGIN(k_valu_sgpr_operand)
     asm volatile(".rept " STR(REP) "\n v_mul_i32_i24 %0, %1, %0\n .endr" : "+v"(a) : "s"(s));
 BENCH_END
 
+// the per-code step of the decoder's delimiting loop (see flac_dec_fast.hip), as compiled
+BENCH_BEGIN(k_rice_step_v1)
+    uint32_t w0 = a, w1 = b, w2 = c, w3 = d, sm = 5, smk = 3, lz, p, wb = threadIdx.x * 4, u0, u1;
+    asm volatile(".rept " STR(REP) "\n"
+        "v_alignbit_b32 %[p], %[w0], %[w1], %[sm]\n"
+        "v_ffbh_u32 %[lz], %[p]\n"
+        "v_and_b32 %[lz], 15, %[lz]\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "s_and_saveexec_b64 s[20:21], vcc\n"
+        "s_cbranch_execz 6\n"
+        "v_and_b32 %[t0], 0x3ff, %[wb]\n"
+        "v_perm_b32 %[t1], 0, %[w3], %[sel]\n"
+        "ds_read_b32 %[w3], %[t0]\n"
+        "v_add_u32 %[wb], 4, %[wb]\n"
+        "v_mov_b32 %[w2], %[t1]\n"
+        "s_nop 0\n"
+        "s_or_b64 exec, exec, s[20:21]\n"
+        "v_sub_u32 %[sm], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[sm]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "v_cndmask_b32 %[w1], %[w1], %[w2], vcc\n"
+        ".endr\n s_waitcnt lgkmcnt(0)"
+        : [w0]"+v"(w0), [w1]"+v"(w1), [w2]"+v"(w2), [w3]"+v"(w3), [sm]"+v"(sm), [smk]"+v"(smk), [lz]"=&v"(lz), [p]"=&v"(p), [wb]"+v"(wb), [t0]"=&v"(u0), [t1]"=&v"(u1)
+        : [sel]"s"(0x00010203u), [kp1]"v"(11u) : "vcc", "s20", "s21", "memory");
+    a = w0 + w1 + w2 + w3 + sm;
+BENCH_END
+
+// same without the skip branch
+BENCH_BEGIN(k_rice_step_v2)
+    uint32_t w0 = a, w1 = b, w2 = c, w3 = d, sm = 5, smk = 3, lz, p, wb = threadIdx.x * 4, u0, u1;
+    asm volatile(".rept " STR(REP) "\n"
+        "v_alignbit_b32 %[p], %[w0], %[w1], %[sm]\n"
+        "v_ffbh_u32 %[lz], %[p]\n"
+        "v_and_b32 %[lz], 15, %[lz]\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "s_and_saveexec_b64 s[20:21], vcc\n"
+        "v_and_b32 %[t0], 0x3ff, %[wb]\n"
+        "v_perm_b32 %[t1], 0, %[w3], %[sel]\n"
+        "ds_read_b32 %[w3], %[t0]\n"
+        "v_add_u32 %[wb], 4, %[wb]\n"
+        "v_mov_b32 %[w2], %[t1]\n"
+        "s_or_b64 exec, exec, s[20:21]\n"
+        "v_sub_u32 %[sm], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[sm]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "v_cndmask_b32 %[w1], %[w1], %[w2], vcc\n"
+        ".endr\n s_waitcnt lgkmcnt(0)"
+        : [w0]"+v"(w0), [w1]"+v"(w1), [w2]"+v"(w2), [w3]"+v"(w3), [sm]"+v"(sm), [smk]"+v"(smk), [lz]"=&v"(lz), [p]"=&v"(p), [wb]"+v"(wb), [t0]"=&v"(u0), [t1]"=&v"(u1)
+        : [sel]"s"(0x00010203u), [kp1]"v"(11u) : "vcc", "s20", "s21", "memory");
+    a = w0 + w1 + w2 + w3 + sm;
+BENCH_END
+
+// no EXEC changes at all: the queue advance as selects, the LDS read unconditional (address selected)
+BENCH_BEGIN(k_rice_step_v3)
+    uint32_t w0 = a, w1 = b, w2 = c, w3 = d, sm = 5, smk = 3, lz, p, wb = threadIdx.x * 4, u0, u1;
+    asm volatile(".rept " STR(REP) "\n"
+        "v_alignbit_b32 %[p], %[w0], %[w1], %[sm]\n"
+        "v_ffbh_u32 %[lz], %[p]\n"
+        "v_and_b32 %[lz], 15, %[lz]\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "v_perm_b32 %[t1], 0, %[w3], %[sel]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "v_cndmask_b32 %[w1], %[w1], %[w2], vcc\n"
+        "v_cndmask_b32 %[w2], %[w2], %[t1], vcc\n"
+        "v_addc_co_u32 %[wb], vcc, %[wb], %[wb], vcc\n"
+        "v_and_b32 %[t0], 0x3fc, %[wb]\n"
+        "ds_read_b32 %[w3], %[t0]\n"
+        "v_sub_u32 %[sm], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[sm]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        ".endr\n s_waitcnt lgkmcnt(0)"
+        : [w0]"+v"(w0), [w1]"+v"(w1), [w2]"+v"(w2), [w3]"+v"(w3), [sm]"+v"(sm), [smk]"+v"(smk), [lz]"=&v"(lz), [p]"=&v"(p), [wb]"+v"(wb), [t0]"=&v"(u0), [t1]"=&v"(u1)
+        : [sel]"s"(0x00010203u), [kp1]"v"(11u) : "vcc", "memory");
+    a = w0 + w1 + w2 + w3 + sm;
+BENCH_END
+
 BENCH_BEGIN(k_dpp_dep)
     asm volatile(".rept " STR(REP) "\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n .endr" : "+v"(a));
 BENCH_END
@@ -200,6 +278,8 @@ int main()
         {"ds_or_b32 back to back", k_lds_or_nowait, 1}, {"ds_or_b32 pair scattered (x2)", k_lds_or_pair_scattered, 2},
         {"ds_read_u16 back to back (stride 136B)", k_lds_read_u16_nowait, 1}, {"v_writelane + v_readlane (x2)", k_writelane_readlane, 2},
         {"v_mul_i32_i24 with SGPR operand", k_valu_sgpr_operand, 1},
+        {"rice step v1 (saveexec + skip branch)", k_rice_step_v1, 1}, {"rice step v2 (saveexec, no branch)", k_rice_step_v2, 1},
+        {"rice step v3 (selects, unconditional LDS read)", k_rice_step_v3, 1},
         {"dependent DPP v_add row_shr", k_dpp_dep, 1}, {"loop: v_add + s_sub + s_cmp + s_cbranch (x4)", k_loop_branch, 4},
     };
     for (int nwg : {1, 1280}) {
