@@ -66,10 +66,30 @@ FGI uint32_t fabs32(int32_t v) { return (uint32_t)(v < 0 ? -v : v); }
 // unrolling.)
 template <int MAXO> FGI int32_t fir24(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
 {
+    // one asm statement for the whole sum: the hazard recogniser pads every inline-asm statement with s_nop
     int32_t sm = 0;
-#pragma unroll
-    for (int j = MAXO - 1; j >= 0; j--)
-        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(sm) : "s"(q[j]), "v"(h[(u - 1 - j + 2 * MAXO) % MAXO]));
+#define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
+    if (MAXO == 8) {
+        asm("v_mad_i32_i24 %0, %1, %9, %0\n\tv_mad_i32_i24 %0, %2, %10, %0\n\tv_mad_i32_i24 %0, %3, %11, %0\n\t"
+            "v_mad_i32_i24 %0, %4, %12, %0\n\tv_mad_i32_i24 %0, %5, %13, %0\n\tv_mad_i32_i24 %0, %6, %14, %0\n\t"
+            "v_mad_i32_i24 %0, %7, %15, %0\n\tv_mad_i32_i24 %0, %8, %16, %0"
+            : "+v"(sm)
+            : "v"(q[7 % MAXO]), "v"(q[6 % MAXO]), "v"(q[5 % MAXO]), "v"(q[4 % MAXO]), "v"(q[3 % MAXO]), "v"(q[2 % MAXO]), "v"(q[1 % MAXO]), "v"(q[0]),
+              "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+    else {
+        asm("v_mad_i32_i24 %0, %1, %7, %0\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
+            "v_mad_i32_i24 %0, %4, %10, %0\n\tv_mad_i32_i24 %0, %5, %11, %0\n\tv_mad_i32_i24 %0, %6, %12, %0"
+            : "+v"(sm)
+            : "v"(q[11 % MAXO]), "v"(q[10 % MAXO]), "v"(q[9 % MAXO]), "v"(q[8 % MAXO]), "v"(q[7 % MAXO]), "v"(q[6 % MAXO]),
+              "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
+        asm("v_mad_i32_i24 %0, %1, %7, %0\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
+            "v_mad_i32_i24 %0, %4, %10, %0\n\tv_mad_i32_i24 %0, %5, %11, %0\n\tv_mad_i32_i24 %0, %6, %12, %0"
+            : "+v"(sm)
+            : "v"(q[5 % MAXO]), "v"(q[4 % MAXO]), "v"(q[3 % MAXO]), "v"(q[2 % MAXO]), "v"(q[1 % MAXO]), "v"(q[0]),
+              "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+#undef FG_H
     return sm;
 }
 template <int MAXO> FGI i64 fir64(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
@@ -241,26 +261,29 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     const uint32_t pmin0 = P.min_po < pmax0 ? P.min_po : pmax0;
 
     // ================================================================ wasted bits + fixed-predictor error sums (one pass)
+    // The per-lane sums double as the Rice partition sums of the fixed predictors (the order-k residual IS the k-th
+    // difference), so the fixed predictor needs no FIR pass later: facc = sums over the lane's samples from sample 4 on
+    // (what libFLAC's order guess uses), fwarm = the part of samples 0..3 that belongs to the order-k residual (s >= k).
     uint32_t wst[NC], sbp[NC];
     u64 tot[NC][5];
+    sum_t facc[NC][5], fwarm[NC][5];
     {
-        sum_t acc[NC][5];
         uint32_t orv[NC];
         int32_t p1[NC], q1[NC], q2[NC], q3[NC];       // previous value and previous 1st..3rd differences
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             orv[c] = 0; p1[c] = 0; q1[c] = 0; q2[c] = 0; q3[c] = 0;
 #pragma unroll
-            for (int kk = 0; kk < 5; kk++) acc[c][kk] = 0;
+            for (int kk = 0; kk < 5; kk++) { facc[c][kk] = 0; fwarm[c][kk] = 0; }
         }
-        // prime the differences with the four samples in front of the segment (zeros in front of the block), then walk
-#pragma unroll 1
-        for (int s = -4; s < (int)seg; s++) {
+        // head: prime the differences with the four samples in front of the segment (zeros in front of the block), then
+        // samples 0..3, which only lanes > 0 add to the sums (libFLAC hands fixed.c the signal shifted by the maximum
+        // fixed order, so the sums of the block start at sample 4)
+#pragma unroll
+        for (int s = -4; s < 4; s++) {
             int32_t l = 0, r = 0;
             if (s >= 0) { l = rowL[s]; r = (NCH == 2) ? rowR[s] : 0; }
             else if (lane > 0) { l = rowL[(int)seg + s - (int)rstr]; r = (NCH == 2) ? rowR[(int)seg + s - (int)rstr] : 0; }
-            // the sums run over samples 4 .. n-1 (libFLAC hands fixed.c the signal shifted by the maximum fixed order)
-            const bool on = s >= 0 && (lane > 0 || s >= 4);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 int32_t v;
@@ -268,11 +291,30 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 else v = (c == 0) ? l : (c == 1) ? r : (c == 2) ? ((l + r) >> 1) : (l - r);
                 const int32_t e1 = v - p1[c], e2 = e1 - q1[c], e3 = e2 - q2[c], e4 = e3 - q3[c];
                 p1[c] = v; q1[c] = e1; q2[c] = e2; q3[c] = e3;
-                if (s >= 0) orv[c] |= (uint32_t)v;
-                if (on) {
-                    acc[c][0] += fabs32(v); acc[c][1] += fabs32(e1); acc[c][2] += fabs32(e2);
-                    acc[c][3] += fabs32(e3); acc[c][4] += fabs32(e4);
+                if (s >= 0) {
+                    orv[c] |= (uint32_t)v;
+                    const uint32_t ab[5] = {fabs32(v), fabs32(e1), fabs32(e2), fabs32(e3), fabs32(e4)};
+#pragma unroll
+                    for (int kk = 0; kk < 5; kk++) {
+                        facc[c][kk] += (lane > 0) ? ab[kk] : 0u;
+                        if (s >= kk) fwarm[c][kk] += ab[kk];
+                    }
                 }
+            }
+        }
+#pragma unroll 1
+        for (int s = 4; s < (int)seg; s++) {
+            const int32_t l = rowL[s], r = (NCH == 2) ? rowR[s] : 0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                int32_t v;
+                if (!MS) v = (c == 0) ? l : r;
+                else v = (c == 0) ? l : (c == 1) ? r : (c == 2) ? ((l + r) >> 1) : (l - r);
+                const int32_t e1 = v - p1[c], e2 = e1 - q1[c], e3 = e2 - q2[c], e4 = e3 - q3[c];
+                p1[c] = v; q1[c] = e1; q2[c] = e2; q3[c] = e3;
+                orv[c] |= (uint32_t)v;
+                facc[c][0] += fabs32(v); facc[c][1] += fabs32(e1); facc[c][2] += fabs32(e2);
+                facc[c][3] += fabs32(e3); facc[c][4] += fabs32(e4);
             }
         }
 #pragma unroll
@@ -283,7 +325,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             if (w > nominal) w = nominal;
             wst[c] = w; sbp[c] = nominal - w;
 #pragma unroll
-            for (int kk = 0; kk < 5; kk++) tot[c][kk] = ACC64 ? wave_sum64((u64)acc[c][kk]) : (u64)wave_sum((uint32_t)acc[c][kk]);
+            for (int kk = 0; kk < 5; kk++) tot[c][kk] = ACC64 ? wave_sum64((u64)facc[c][kk]) : (u64)wave_sum((uint32_t)facc[c][kk]);
         }
         // Blocks in which some candidate has wasted bits (all samples share trailing zero bits: rare) are handed
         // to the generic kernel: every hot loop below then works on unshifted samples.
@@ -626,24 +668,46 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         }
         else {
             const uint32_t v = pass - 1;
+            // one LDS read brings every coefficient of the pass (lane = candidate * MAXO + tap), another the result words;
+            // the wave-uniform copies come from v_readlane
+            const uint32_t lc = (uint32_t)lane / MAXO, lj = (uint32_t)lane % MAXO;
+            const int32_t qall = (lc < (uint32_t)NC) ? qres[(lc * P.nvec + v) * MAXO + lj] : 0;
+            const uint32_t rall = ((uint32_t)lane < (uint32_t)NC) ? lres[(uint32_t)lane * P.nvec + v] : 0;
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const uint32_t idx = (uint32_t)c * P.nvec + v;
-                const uint32_t r = rfl(lres[idx]);
+                const uint32_t r = rl(rall, c);
                 order[c] = r & 0xFF; prec[c] = (r >> 8) & 0xFF; shift[c] = (int)(int8_t)((r >> 16) & 0xFF);
                 if (((lpc_mask >> c) & 1) && ((r >> 24) & 1)) emask |= 1u << c;
                 if (order[c] == 0) order[c] = 1;
 #pragma unroll
-                for (int j = 0; j < MAXO; j++) q[c][j] = (int32_t)rfl((uint32_t)qres[idx * MAXO + j]);
+                for (int j = 0; j < MAXO; j++) q[c][j] = (int32_t)rl((uint32_t)qall, c * MAXO + j);
                 if (mydbg && lane == 0) mydbg->cand[c].lpc_guess[v] = ((r >> 25) & 1) ? (r & 0xFF) : 0;
             }
             if (!emask) continue;
         }
         FG_TE(te_setup);
-        // ---- FIR over the segment
+        FG_TE(te_setup);
         sum_t psum[NC];
         uint32_t ovf[NC];
-        {
+        if (pass == 0) {
+            // fixed predictor of order g: the lane's partition sum is its sum of |g-th differences|, lane 0 adds the part
+            // of samples g..3
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const uint32_t g = guess[c];
+                sum_t a = g == 0 ? facc[c][0] : g == 1 ? facc[c][1] : g == 2 ? facc[c][2] : g == 3 ? facc[c][3] : facc[c][4];
+                const sum_t w = g == 0 ? fwarm[c][0] : g == 1 ? fwarm[c][1] : g == 2 ? fwarm[c][2] : g == 3 ? fwarm[c][3] : fwarm[c][4];
+                if (lane == 0) a += w;
+                psum[c] = a; ovf[c] = 0;
+            }
+        }
+        else {
+            // ---- FIR over the segment.  The coefficients live in VGPRs (pinned by an opaque asm): 32 wave-uniform values
+            // plus the rest of the uniform state overflow the SGPR file.
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) asm volatile("" : "+v"(q[c][j]));
             int32_t h[NC][MAXO];
 #pragma unroll
             for (int c = 0; c < NC; c++) { psum[c] = 0; ovf[c] = 0; }
@@ -730,43 +794,67 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 if (wrap32) sv[c] &= 0xFFFFFFFFull;
             }
             const uint32_t limit = P.rice_limit;
-            for (int po = (int)pmax0; po >= (int)pmin0; po--) {
-                const uint32_t stride = 64u >> po;
+            // 0x40000 / x for x < 2^16 through the reciprocal, corrected to the exact quotient
+            auto div18 = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+                uint32_t qd = (uint32_t)(262144.0f * __builtin_amdgcn_rcpf((float)x));
+                const int32_t r = (int32_t)(0x40000u - qd * x);
+                if (r < 0) qd--;
+                else if ((uint32_t)r >= x) qd++;
+                return qd;
+            };
+            const bool lane0 = lane == 0;
+            // one partition order; PO is a compile-time constant so that the lane stride and the DPP shifts are immediates
+            auto po_step = [&](auto PO) __attribute__((always_inline)) {
+                constexpr int po = decltype(PO)::value;
+                if (po > (int)pmax0 || po < (int)pmin0) return;
+                constexpr uint32_t stride = 64u >> po;
                 const bool valid = ((uint32_t)lane & (stride - 1)) == 0;
                 const uint32_t pbase = n >> po;
-                // 0x40000 / x for x < 2^16 through the reciprocal, corrected to the exact quotient
-                auto div18 = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
-                    uint32_t qd = (uint32_t)(262144.0f * __builtin_amdgcn_rcpf((float)x));
-                    const int32_t r = (int32_t)(0x40000u - qd * x);
-                    if (r < 0) qd--;
-                    else if ((uint32_t)r >= x) qd++;
-                    return qd;
-                };
                 const uint32_t dv_all = div18(pbase);
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    const u64 s = sv[c];
-                    uint32_t np = pbase, dv = dv_all;
-                    if (lane == 0) np -= order[c];
+                    const uint32_t np = lane0 ? pbase - order[c] : pbase;
                     const uint32_t dv0 = div18(pbase - order[c]);
-                    if (lane == 0) dv = dv0;
-                    uint32_t kr = 0;
-                    if (s >= 2) {
-                        const u64 qv = ((s - 1) * dv) >> 18;
-                        if (qv != 0) kr = ilog2_64(qv) + 1;
+                    const uint32_t dv = lane0 ? dv0 : dv_all;
+                    uint32_t kr, bits;
+                    if (!ACC64) {
+                        // sums below 2^31 (16-bit input): 32-bit arithmetic, one 64-bit product
+                        const uint32_t s32 = (uint32_t)sv[c];
+                        const uint32_t s1 = (s32 > 1 ? s32 : 1) - 1;
+                        const uint32_t qv = (uint32_t)(((u64)s1 * dv) >> 18);
+                        kr = qv ? 32 - (uint32_t)__builtin_clz(qv) : 0;
+                        if (kr >= limit) kr = limit - 1;
+                        uint32_t pb = 4 + (1 + kr) * np + ((s32 << 1) >> kr) - (np >> 1);
+                        if (!valid) pb = 0;
+                        u64 total;
+                        if (__any(pb >> 25)) total = wave_sum64((u64)pb) + 6;
+                        else total = (u64)wave_sum(pb) + 6;
+                        bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
                     }
-                    if (kr >= limit) kr = limit - 1;
-                    u64 pb = (u64)4 + (u64)(1 + kr) * np + (kr ? (s >> (kr - 1)) : (s << 1)) - (np >> 1);
-                    if (pb > 0xFFFFFFFFull) pb = 0xFFFFFFFFull;
-                    if (!valid) pb = 0;
-                    u64 total;
-                    if (__any(pb >> 25)) total = wave_sum64(pb) + 6;
-                    else total = (u64)wave_sum((uint32_t)pb) + 6;
-                    const uint32_t bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+                    else {
+                        const u64 s = sv[c];
+                        kr = 0;
+                        if (s >= 2) {
+                            const u64 qv = ((s - 1) * dv) >> 18;
+                            if (qv != 0) kr = ilog2_64(qv) + 1;
+                        }
+                        if (kr >= limit) kr = limit - 1;
+                        u64 pb = (u64)4 + (u64)(1 + kr) * np + (kr ? (s >> (kr - 1)) : (s << 1)) - (np >> 1);
+                        if (pb > 0xFFFFFFFFull) pb = 0xFFFFFFFFull;
+                        if (!valid) pb = 0;
+                        u64 total;
+                        if (__any(pb >> 25)) total = wave_sum64(pb) + 6;
+                        else total = (u64)wave_sum((uint32_t)pb) + 6;
+                        bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+                    }
                     if (best_bits[c] == 0 || bits < best_bits[c]) { best_bits[c] = bits; bpo[c] = (uint32_t)po; kb[c] = kr; }
                 }
                 if (po > (int)pmin0) merge(6 - (uint32_t)po);
-            }
+            };
+            po_step(std::integral_constant<int, 6>()); po_step(std::integral_constant<int, 5>());
+            po_step(std::integral_constant<int, 4>()); po_step(std::integral_constant<int, 3>());
+            po_step(std::integral_constant<int, 2>()); po_step(std::integral_constant<int, 1>());
+            po_step(std::integral_constant<int, 0>());
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 uint32_t est = 0;
