@@ -70,6 +70,25 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Exclusive prefix sum of one u64 per thread over a workgroup of up to 1024 threads (wave scans through shuffles, then the
+// wave totals through LDS).  `wtot` holds one entry per wave (16); returns the prefix, *total gets the grand total.
+__device__ __forceinline__ u64 block_scan_excl_u64(u64 v, u64 *wtot, u64 *total)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    u64 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d);
+        if ((int)lane >= d) inc += ((u64)hi << 32) | lo;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    u64 base = 0, all = 0;
+    for (uint32_t w = 0; w < nw; w++) { const u64 t = wtot[w]; if (w < wave) base += t; all += t; }
+    *total = all;
+    return base + inc - v;
+}
+
 __device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
 {
     // a*b mod x^16+x^15+x^2+1 (CRC-16 polynomial 0x8005)

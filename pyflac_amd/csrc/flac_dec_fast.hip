@@ -409,20 +409,30 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
             const uint32_t meta = (rn << 8) | tk;                      // block sizes are below 2^16
             const uint32_t icol = i0 + (uint32_t)lane;
             if (!__any((uint32_t)lane < G && rn > i0 && (tk >= 0xFE || tmask != 0))) {
-                // common case: every row is a full tile of code windows; the next row's entry is requested early
-                uint32_t vnext = tile[lane];
-                for (uint32_t r = 0; r < G; r++) {
-                    const uint32_t val = vnext;
-                    if (r + 1 < G) vnext = tile[(r + 1) * FG_TSTR + lane];
-                    const uint32_t m = rl(meta, (int)r), rn_s = m >> 8, kk = m & 0xFF;
-                    if (i0 >= rn_s) continue;
-                    const u64 off_s = ((u64)rl((uint32_t)(roff >> 32), (int)r) << 32) | rl((uint32_t)roff, (int)r);
-                    const uint32_t lz = (uint32_t)__clz(val);
-                    const uint32_t rest = (val << lz) << 1;
-                    const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
-                    const int32_t res = unzig(u);
-                    if (i0 + FG_TS <= rn_s) scratch[off_s + icol] = res;
-                    else if (icol < rn_s) scratch[off_s + icol] = res;
+                // common case: every row is a full tile of code windows.  Four rows per pass: 16 lanes per row, four
+                // entries per lane (one 16-byte LDS read, one 16-byte store); the row facts reach the lanes by permute.
+                const uint32_t rsub = (uint32_t)lane >> 4, q4 = ((uint32_t)lane & 15) * 4;
+                for (uint32_t r0 = 0; r0 < G; r0 += 4) {
+                    const uint32_t r = r0 + rsub;
+                    const int src = (int)(r < G ? r : 0);
+                    const uint32_t m = (uint32_t)__shfl((int)meta, src);
+                    const uint32_t rn_r = r < G ? (m >> 8) : 0, kk = m & 0xFF;
+                    const u64 off_r = ((u64)(uint32_t)__shfl((int)(uint32_t)(roff >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)roff, src);
+                    if (i0 + q4 < rn_r) {
+                        const uint4 pw = *(const uint4 *)&tile[r * FG_TSTR + q4];
+                        const uint32_t p4[4] = {pw.x, pw.y, pw.z, pw.w};
+                        int32_t res[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const uint32_t lz = (uint32_t)__clz(p4[e]);
+                            const uint32_t rest = (p4[e] << lz) << 1;
+                            const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                            res[e] = unzig(u);
+                        }
+                        int32_t *dst = scratch + off_r + i0 + q4;
+                        if ((((uintptr_t)dst) & 15) == 0) *(int4 *)dst = make_int4(res[0], res[1], res[2], res[3]);
+                        else { dst[0] = res[0]; dst[1] = res[1]; dst[2] = res[2]; dst[3] = res[3]; }
+                    }
                 }
             }
             else {
@@ -593,7 +603,7 @@ __global__ void __launch_bounds__(64)
 fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
                       int32_t *out, const FgDecResult *results, uint32_t interleave, u64 *prof)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];     // rows of FG_TRS words: chains (rounded up to 8) + 1 spare
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];     // rows of FG_TRS words: chains (rounded up to 16) + 1 spare
     const int lane = threadIdx.x;
     const uint32_t chains = G * C;
     const uint32_t fi = (uint32_t)lane / C, ch = (uint32_t)lane % C;
@@ -623,16 +633,42 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
     const u64 plane = ok ? out_off * C + (u64)ch * n : 0;               // this chain's residual plane in `scratch`
     const uint32_t nmax = wave_max32(n_out);
     const bool big = __any(ok && order > 8);
+    const bool scratch_aligned = (((uintptr_t)scratch) & 15) == 0, out_aligned = (((uintptr_t)out) & 15) == 0;
     // idle lanes run the recurrence on a spare row behind the real ones
-    uint32_t *rowp = &tile[((uint32_t)lane < chains ? (uint32_t)lane : ((chains + 7) & ~7u)) * FG_TRS];
-    uint32_t pf[FG_RROWS];
+    uint32_t *rowp = &tile[((uint32_t)lane < chains ? (uint32_t)lane : ((chains + 15) & ~15u)) * FG_TRS];
     u64 tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? clock64() : 0;
 #define FG_TICK(i) do { if (prof) { const u64 now_ = clock64(); tp[i] += now_ - tlast; tlast = now_; } } while (0)
 
-    // rows are handled in blocks of eight (no per-row guards, so the loads of a pass stay back to back); rows past
-    // `chains` belong to idle lanes, whose plane is element 0 of the scratch buffer
+    // ---- tile I/O.  Fast form (whole 64-column pass inside every row, 16-byte aligned planes): lane = (row, quarter) for
+    // the residuals in (four 16-byte loads per lane and round of 16 rows), lane = (frame, eighth) for the samples out
+    // (16-byte LDS reads and stores); the row / frame facts sit in per-lane registers, fetched once by permute.
+    // General form (tails, odd block sizes, other channel counts): one row per step, lane = column, facts by v_readlane.
+    const uint32_t nrnd = (chains + 15) >> 4;                            // rounds of 16 rows (1 or 2)
+    uint32_t l_rn[2], f_rn[2], f_ok[2], f_ca[2], f_wa[2], f_wb[2];
+    u64 l_base[2], f_oo[2];
+    bool planes_aligned = true;
+#pragma unroll
+    for (int R = 0; R < 2; R++) {
+        const int row = R * 16 + (lane >> 2);
+        l_rn[R] = (uint32_t)__shfl((int)n_in, row);
+        l_base[R] = ((u64)(uint32_t)__shfl((int)(uint32_t)(plane >> 32), row) << 32) | (uint32_t)__shfl((int)(uint32_t)plane, row);
+        const int fl = 2 * (R * 8 + (lane >> 3));                        // lane of the frame's first chain (stereo)
+        f_rn[R] = (uint32_t)__shfl((int)n_out, fl & 63);
+        f_ok[R] = (uint32_t)__shfl((int)n_in, fl & 63);
+        f_ca[R] = (uint32_t)__shfl((int)ca, fl & 63);
+        f_wa[R] = (uint32_t)__shfl((int)wasted, fl & 63);
+        f_wb[R] = (uint32_t)__shfl((int)wasted, (fl + 1) & 63);
+        f_oo[R] = ((u64)(uint32_t)__shfl((int)(uint32_t)(out_off >> 32), fl & 63) << 32) | (uint32_t)__shfl((int)(uint32_t)out_off, fl & 63);
+        if (R * 8 + (lane >> 3) >= (int)G) { f_rn[R] = 0; f_ok[R] = 0; }
+    }
+    planes_aligned = !__any(((plane & 3) != 0 && n_in != 0) || ((out_off & 1) != 0 && n_out != 0) || ((n & 3) != 0 && n_out != 0));
+    const uint32_t nmin_in = ~wave_max32(~(n_in ? n_in : 0xFFFFFFFFu));   // shortest row that is loaded at all
+    const uint32_t nmin_out = ~wave_max32(~(n_out ? n_out : 0xFFFFFFFFu));
+    fg_u32x4 pfv[2][4];
+    uint32_t pf[FG_RROWS];
+    bool pfvec = false;
     const uint32_t nr8 = (chains + 7) >> 3;
-    auto issue8 = [&](int r0, uint32_t i) {
+    auto issue8 = [&](int r0, uint32_t i) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t rn = rl(n_in, r0 + r);
@@ -640,25 +676,93 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
             pf[r0 + r] = (uint32_t)scratch[base + (i < rn ? i : 0)];
         }
     };
-    auto issue = [&](uint32_t i0, uint32_t p) {
-        const uint32_t i = i0 + p * FG_TP + (uint32_t)lane;
-        issue8(0, i);
-        if (nr8 > 1) issue8(8, i);
-        if (nr8 > 2) issue8(16, i);
-        if (nr8 > 3) issue8(24, i);
+    auto issue = [&](uint32_t i0, uint32_t p) __attribute__((always_inline)) {
+        const uint32_t c0 = i0 + p * FG_TP;
+        pfvec = planes_aligned && scratch_aligned && c0 + FG_TP <= nmin_in;
+        if (pfvec) {
+            const uint32_t i = c0 + ((uint32_t)lane & 3) * 16;
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                if ((uint32_t)R < nrnd) {
+                    const fg_u32x4 *src = (const fg_u32x4 *)(scratch + l_base[R] + (l_rn[R] ? i : 0));
+#pragma unroll
+                    for (int t = 0; t < 4; t++) pfv[R][t] = src[t];
+                }
+            }
+        }
+        else {
+            const uint32_t i = c0 + (uint32_t)lane;
+            issue8(0, i);
+            if (nr8 > 1) issue8(8, i);
+            if (nr8 > 2) issue8(16, i);
+            if (nr8 > 3) issue8(24, i);
+        }
     };
-    auto land8 = [&](int r0, uint32_t p) {
+    auto land8 = [&](int r0, uint32_t p) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 8; r++) tile[(r0 + r) * FG_TRS + p * FG_TP + lane] = pf[r0 + r];
     };
-    auto land = [&](uint32_t p) {
-        land8(0, p);
-        if (nr8 > 1) land8(8, p);
-        if (nr8 > 2) land8(16, p);
-        if (nr8 > 3) land8(24, p);
+    auto land = [&](uint32_t p) __attribute__((always_inline)) {
+        if (pfvec) {
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                if ((uint32_t)R < nrnd) {
+                    fg_u32x4 *dst = (fg_u32x4 *)&tile[(R * 16 + (lane >> 2)) * FG_TRS + p * FG_TP + (lane & 3) * 16];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) dst[t] = pfv[R][t];
+                }
+            }
+        }
+        else {
+            land8(0, p);
+            if (nr8 > 1) land8(8, p);
+            if (nr8 > 2) land8(16, p);
+            if (nr8 > 3) land8(24, p);
+        }
         wave_lds_fence();
     };
-    auto writeout = [&](uint32_t i0, uint32_t p) {
+    auto writeout = [&](uint32_t i0, uint32_t p) __attribute__((always_inline)) {
+        const uint32_t c0 = i0 + p * FG_TP;
+        if (C == 2 && planes_aligned && out_aligned && c0 + FG_TP <= nmin_out) {
+            const uint32_t colb = p * FG_TP + ((uint32_t)lane & 7) * 8;
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                if ((uint32_t)(R * 8) < G && f_rn[R] != 0) {
+                    const uint32_t r0 = 2 * (R * 8 + ((uint32_t)lane >> 3));
+                    const uint32_t i = i0 + colb;
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        int32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+                        if (f_ok[R]) {
+                            const uint4 ta = *(const uint4 *)&tile[r0 * FG_TRS + colb + 4 * hh];
+                            const uint4 tb = *(const uint4 *)&tile[(r0 + 1) * FG_TRS + colb + 4 * hh];
+                            const uint32_t xa[4] = {ta.x, ta.y, ta.z, ta.w}, xb[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                int32_t av = (int32_t)(xa[e] << f_wa[R]), bv = (int32_t)(xb[e] << f_wb[R]);
+                                const uint32_t cc = f_ca[R];
+                                const i64 side = bv;
+                                const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
+                                const int32_t ma = (int32_t)((mid + side) >> 1), mb = (int32_t)((mid - side) >> 1);
+                                a[e] = cc == 2 ? av + bv : cc == 3 ? ma : av;
+                                b[e] = cc == 1 ? av - bv : cc == 3 ? mb : bv;
+                            }
+                        }
+                        int32_t *o = out + f_oo[R] * 2;
+                        if (interleave) {
+                            int4 *d = (int4 *)(o + (size_t)(i + 4 * hh) * 2);
+                            d[0] = make_int4(a[0], b[0], a[1], b[1]);
+                            d[1] = make_int4(a[2], b[2], a[3], b[3]);
+                        }
+                        else {
+                            *(int4 *)(o + i + 4 * hh) = make_int4(a[0], a[1], a[2], a[3]);
+                            *(int4 *)(o + f_rn[R] + i + 4 * hh) = make_int4(b[0], b[1], b[2], b[3]);
+                        }
+                    }
+                }
+            }
+            return;
+        }
         const uint32_t col = p * FG_TP + (uint32_t)lane, i = i0 + col;
         if (C == 2) {
             for (uint32_t g = 0; g < G; g++) {
@@ -775,7 +879,7 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
     if (G * C > FG_RROWS) G = FG_RROWS / C;
     if (G < 1) return -1;
     const dim3 grid((nframes + G - 1) / G);
-    const size_t lds = (size_t)(((G * C + 7) & ~7u) + 1) * FG_TRS * 4;
+    const size_t lds = (size_t)(((G * C + 15) & ~15u) + 1) * FG_TRS * 4;      // rounds of 16 rows + the spare row
     if (wide) hipLaunchKernelGGL(fg_dec_restore_kernel<true>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
     else hipLaunchKernelGGL(fg_dec_restore_kernel<false>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
     return (int)hipGetLastError();

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fg_dev.h"
 #include "fg_types.h"
 
 typedef unsigned long long u64;
@@ -396,7 +397,7 @@ fg_dec_headers_kernel(const uint8_t *stream, const u64 *offsets, uint32_t nframe
 // Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.
 __global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals)
 {
-    __shared__ u64 part[1024];
+    __shared__ u64 wtot[16];
     __shared__ uint32_t maxn;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t per = (nframes + nt - 1) / nt;
@@ -406,16 +407,10 @@ __global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *to
     u64 s = 0;
     uint32_t m = 0;
     for (uint32_t b = b0; b < b1; b++) { s += frames[b].n; m = frames[b].n > m ? frames[b].n : m; }
-    part[tid] = s;
     atomicMax(&maxn, m);
-    __syncthreads();
-    if (tid == 0) {
-        u64 run = 0;
-        for (uint32_t t = 0; t < nt; t++) { u64 v = part[t]; part[t] = run; run += v; }
-        totals[0] = run; totals[1] = maxn;
-    }
-    __syncthreads();
-    u64 run = part[tid];
+    u64 total;
+    u64 run = fgdev::block_scan_excl_u64(s, wtot, &total);
+    if (tid == 0) { totals[0] = total; totals[1] = maxn; }
     for (uint32_t b = b0; b < b1; b++) { frames[b].out_off = run; run += frames[b].n; }
 }
 

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fg_dev.h"
 #include "fg_types.h"
 
 #define FG_LN2 0.69314718055994530942
@@ -1137,7 +1138,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
 // offsets[b] = sum of bytes of blocks < b (exclusive), offsets[nblocks] = total, offsets[nblocks+1] = OR of errors.
 __global__ void fg_scan_sizes_kernel(const FgBlockResult *results, uint32_t nblocks, u64 *offsets)
 {
-    __shared__ u64 part[1024];
+    __shared__ u64 wtot[16];
     __shared__ uint32_t errs;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t per = (nblocks + nt - 1) / nt;
@@ -1147,17 +1148,10 @@ __global__ void fg_scan_sizes_kernel(const FgBlockResult *results, uint32_t nblo
     if (tid == 0) errs = 0;
     __syncthreads();
     for (uint32_t b = b0; b < b1; b++) { s += results[b].bytes; e |= results[b].err; }
-    part[tid] = s;
     if (e) atomicOr(&errs, e);
-    __syncthreads();
-    if (tid == 0) {
-        u64 run = 0;
-        for (uint32_t t = 0; t < nt; t++) { u64 v = part[t]; part[t] = run; run += v; }
-        offsets[nblocks] = run;
-        offsets[nblocks + 1] = errs;
-    }
-    __syncthreads();
-    u64 run = part[tid];
+    u64 total;
+    u64 run = fgdev::block_scan_excl_u64(s, wtot, &total);
+    if (tid == 0) { offsets[nblocks] = total; offsets[nblocks + 1] = errs; }
     for (uint32_t b = b0; b < b1; b++) { offsets[b] = run; run += results[b].bytes; }
 }
 

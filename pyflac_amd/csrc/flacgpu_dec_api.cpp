@@ -245,7 +245,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     st->max_blocksize = (uint32_t)tot[1];
     const uint32_t C = channels_hint ? channels_hint : 2;
     if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
-    if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4) || !c->dec_subs.ensure((size_t)npad * C * sizeof(FgDecSub)))
+    if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4 + 256) || !c->dec_subs.ensure((size_t)npad * C * sizeof(FgDecSub)))
         return false;
     if (!HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
     const int wide = (bps_hint == 0 || bps_hint > 16) ? 1 : 0;
