@@ -59,6 +59,20 @@ def cpu_baseline(pcm16, level, sr, budget_s=12.0):
             'wall_s': round(time.perf_counter() - t0, 1)}
 
 
+def pmc_traffic(args, est):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json, written by
+    tools/rocprof_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command); None when the file does
+    not describe this workload."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fh:
+            t = json.load(fh)
+        if t.get('blocks') == int(est.nblocks) and t.get('level') == args.level and t.get('kernel') == 'fg_encode_fast_kernel':
+            return int(t['traffic_bytes_per_launch'])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -163,8 +177,8 @@ def main():
             'encode_kernel_msamples_per_s': round(chsamples / (enc_k * 1e-3) / 1e6, 1),
             'decode_kernel_msamples_per_s': round(chsamples / (dec_k * 1e-3) / 1e6, 1),
             'encode_kernel_ms': round(enc_k, 3), 'decode_kernel_ms': round(dec_k, 3),
-            'roofline': {'bound': 'hbm', 'kernel': 'fg_encode_kernel', 'achieved': round(achieved, 2), 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': round(achieved / 8000.0, 5), 'traffic': None,
+            'roofline': {'bound': 'hbm', 'kernel': 'fg_encode_fast_kernel', 'achieved': round(achieved, 2), 'peak': 8000.0,
+                         'unit': 'GB/s', 'frac': round(achieved / 8000.0, 5), 'traffic': pmc_traffic(args, est),
                          'algorithmic_bytes_per_launch': int(alg_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -63,3 +63,21 @@ def test_crc_mismatch_gives_silence_and_flag(ctx, small_streams):
     assert not pcm[3 * 4096:4 * 4096].any()
     want, _ = cases.make_pcm({'kind': 'cfg1'})
     assert np.array_equal(pcm[:3 * 4096, 0], want[:3 * 4096, 0])
+
+
+@pytest.mark.parametrize('wps,seconds,ch', [('1', 330.0, 2), ('2', 330.0, 2), ('1', 200.0, 1), ('8', 40.0, 2)])
+def test_frames_per_wave_shapes(ctx, monkeypatch, wps, seconds, ch):
+    """The parse / restore kernels pack several frames into a wave when a launch has many frames (FLACGPU_DEC_WPS sets
+    the target waves per SIMD): decode of a long stream must stay the identity for every packing (here 1..8 frames per
+    wave), including the short last frame."""
+    import torch
+    from pyflac_amd import batch, synth
+    monkeypatch.setenv('FLACGPU_DEC_WPS', wps)
+    pcm = synth.config2_stereo16(seconds, 3)[:, :ch].copy()
+    pcm = pcm[:len(pcm) - 777]                                   # ragged tail frame
+    t = torch.from_numpy(pcm.astype(np.int32)).cuda()
+    s = batch.settings(5, ch, 16, 48000, 4096)
+    out, offs, st = ctx.encode(s, t)
+    dec, status, _dst = ctx.decode(out[:st.total_bytes], offs.cpu().numpy(), ch, 16, len(pcm))
+    assert int(status[:, 0].max()) == 0
+    assert torch.equal(dec.reshape(-1, ch), t)
