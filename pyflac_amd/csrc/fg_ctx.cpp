@@ -323,10 +323,20 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         HIPCHK(hipMemsetAsync(c->dbg.p, 0, (size_t)nblocks * sizeof(FgDebugRec), c->stream));
         dbg = (FgDebugRec *)c->dbg.p;
     }
-    HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+    // the block list goes to the device once per distinct layout (repeated calls with the same streams skip the copy)
+    auto upload_descs = [&]() -> bool {
+        const size_t bytes = (size_t)nblocks * sizeof(FgBlockDesc);
+        if (c->dev_descs_ptr == c->descs.p && c->dev_descs.size() == descs.size() && memcmp(c->dev_descs.data(), descs.data(), bytes) == 0) return true;
+        if (hipMemcpyAsync(c->descs.p, descs.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { fg_set_error("H2D of the block list failed"); return false; }
+        // the pageable copy is staged before the call returns, so the vector may be reused; remember what is there
+        c->dev_descs = descs;
+        c->dev_descs_ptr = c->descs.p;
+        return true;
+    };
     // loose mid-side (levels 1, 4): the decision frames are independent of each other, the frames in between
     // copy the decision.  First pass encodes the decision frames only.
     if (P.do_mid_side && s->loose_mid_side) {
+        if (!upload_descs()) return false;
         uint32_t period = (uint32_t)((double)s->sample_rate * 0.4 / (double)s->blocksize + 0.5);
         if (period == 0) period = 1;
         if (period > 1) {
@@ -343,6 +353,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
                 bi += cnt;
             }
             // loose mode compares only independent vs mid/side on decision frames
+            c->dev_descs.clear();
             HIPCHK(hipMemcpyAsync(c->descs.p, dec.data(), dec.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
             if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, (uint32_t)dec.size(),
                                  (uint8_t *)c->slots.p, (FgBlockResult *)c->results.p, nullptr, (const uint16_t *)c->crctab.p, c->stream) != 0) {
@@ -363,7 +374,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
                 }
                 bi += cnt;
             }
-            HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+            if (!upload_descs()) return false;
         }
         else {
             // period 1: every frame decides, but only between independent and mid/side: handled by forcing
@@ -377,7 +388,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             HIPCHK(hipStreamSynchronize(c->stream));
             for (uint32_t b = 0; b < nblocks; b++)
                 descs[b].forced_ca = (r[b].best_bits[2] + r[b].best_bits[3]) < (r[b].best_bits[0] + r[b].best_bits[1]) ? 3u : 0u;
-            HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+            if (!upload_descs()) return false;
         }
     }
     // blocks the specialised kernel covers go first, the rest to the generic kernel (same bytes either way)
@@ -401,7 +412,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         nfast = (uint32_t)ordered.size();
         ordered.insert(ordered.end(), slow.begin(), slow.end());
         descs.swap(ordered);
-        HIPCHK(hipMemcpyAsync(c->descs.p, descs.data(), (size_t)nblocks * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+        if (!upload_descs()) return false;
     }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const bool side = nfast > 0 && nblocks > nfast;     // overlap the few generic blocks with the fast launch
@@ -442,6 +453,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         std::vector<FgBlockDesc> redo;
         for (uint32_t i = 0; i < nfast; i++) if (r[descs[i].out_slot].err & FG_ERR_REDO) redo.push_back(descs[i]);
         if (!redo.empty()) {
+            c->dev_descs.clear();
             HIPCHK(hipMemcpyAsync(c->descs.p, redo.data(), redo.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
             if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, (uint32_t)redo.size(), (uint8_t *)c->slots.p,
                                  (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {

@@ -33,6 +33,8 @@ int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, c
 int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                           int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
                           hipStream_t stream);
+int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
+                         const uint16_t *d_crctab, hipStream_t stream);
 int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels,
                             const int32_t *d_scratch, const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results,
                             const uint16_t *d_crctab, uint32_t interleave, int wide, unsigned long long *d_prof, hipStream_t stream);
@@ -62,6 +64,8 @@ struct flacgpu_ctx {
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
         dec_scratch, dec_subs, dec_prof;
+    std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`
+    const void *dev_descs_ptr = nullptr;
     std::vector<float> h_windows;
     std::vector<WindowEntry> win_index;
     bool windows_dirty = false;

@@ -529,8 +529,8 @@ fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfra
     for (uint32_t b = 0; b < tail; b++) crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ fp[hb + W * 4 + b]) & 0xFF];
     const uint32_t stored = ((uint32_t)fp[nbytes] << 8) | fp[nbytes + 1];
     if (lane == 0) {
-        results[f].crc = crc;
-        if (results[f].err == 0 && crc != stored) results[f].err = 2;
+        // runs beside the parse kernel (which owns `err`): the mismatch travels in bit 31, the restore kernel merges it
+        results[f].crc = crc | (crc != stored ? 0x80000000u : 0u);
     }
 }
 
@@ -601,7 +601,7 @@ __device__ __forceinline__ void restore_range(int32_t (&h)[FG_DMAXO], const int3
 template <bool WIDE>
 __global__ void __launch_bounds__(64)
 fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
-                      int32_t *out, const FgDecResult *results, uint32_t interleave, u64 *prof)
+                      int32_t *out, FgDecResult *results, uint32_t interleave, u64 *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];     // rows of FG_TRS words: chains (rounded up to 16) + 1 spare
     const int lane = threadIdx.x;
@@ -613,7 +613,12 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
     u64 out_off = 0;
     if (mine) {
         const FgDecFrame fr = frames[f];
-        if (fr.bytes != 0 && fr.channels == C) { n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off; }
+        if (fr.bytes != 0 && fr.channels == C) {
+            n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off;
+            const uint32_t cw = results[f].crc;
+            if (status == 0 && (cw & 0x80000000u)) status = 2;          // CRC-16 mismatch (fg_dec_crc_kernel)
+            if (ch == 0) { results[f].err = status; results[f].crc = cw & 0xFFFFu; }
+        }
     }
     const bool ok = mine && n != 0 && status == 0;
     int32_t q[FG_DMAXO], h[FG_DMAXO];
@@ -873,7 +878,6 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
                                        const uint16_t *d_crctab, uint32_t interleave, int wide, unsigned long long *d_prof, hipStream_t stream)
 {
     if (nframes == 0) return 0;
-    hipLaunchKernelGGL(fg_dec_crc_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_stream, d_frames, nframes, d_results, d_crctab);
     const uint32_t C = channels ? channels : 1;
     uint32_t G = fg_dec_group(nframes, C, 1);
     if (G * C > FG_RROWS) G = FG_RROWS / C;
@@ -882,5 +886,14 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
     const size_t lds = (size_t)(((G * C + 15) & ~15u) + 1) * FG_TRS * 4;      // rounds of 16 rows + the spare row
     if (wide) hipLaunchKernelGGL(fg_dec_restore_kernel<true>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
     else hipLaunchKernelGGL(fg_dec_restore_kernel<false>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
+    return (int)hipGetLastError();
+}
+
+// CRC-16 of every frame; independent of the parse kernel, so the caller may run it on a second stream beside it
+extern "C" int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
+                                    const uint16_t *d_crctab, hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    hipLaunchKernelGGL(fg_dec_crc_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_stream, d_frames, nframes, d_results, d_crctab);
     return (int)hipGetLastError();
 }

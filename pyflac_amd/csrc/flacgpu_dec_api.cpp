@@ -256,9 +256,17 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         d_prof = (unsigned long long *)c->dec_prof.p;
         (void)hipMemsetAsync(d_prof, 0, (size_t)npad * 2 * 8 * 8, c->stream);
     }
+    // the CRC-16 pass only needs the stream and the frame table: it runs on the side stream beside the parse kernel
+    bool forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
+    if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
+                             (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+    if (forked && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
     if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                              (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, c->stream) != 0 ||
-        fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
+                              (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, c->stream) != 0) {
+        fg_set_error("decode kernel launch failed"); return false;
+    }
+    if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+    if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
                                 (const FgDecSub *)c->dec_subs.p, (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p,
                                 (const uint16_t *)c->crctab.p, interleave ? 1u : 0u, wide, d_prof ? d_prof + (size_t)npad * 8 : nullptr, c->stream) != 0) {
         fg_set_error("decode kernel launch failed"); return false;
