@@ -222,7 +222,37 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     {
         const int32_t lim = (int32_t)(P.bps - 1);
         uint32_t bad = 0;
-        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        uint32_t istart = 0;
+        if (NCH == 2 && !P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (((uintptr_t)pcm) & 15) == 0) {
+            // int32 stereo, 16-byte aligned: two inter-channel samples per lane and load, eight loads in flight; the pair
+            // lands in one LDS row (even index, even row length) and is stored as one word per channel when staged as int16
+            const int4 *src = (const int4 *)((const int2 *)pcm + d.pcm_off);
+            for (uint32_t j0 = 0; j0 < n / 2; j0 += 512) {
+                int4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    v[u] = make_int4(0, 0, 0, 0);
+                    if (j < n / 2) v[u] = src[j];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    if (j < n / 2) {
+                        const int32_t l0 = v[u].x, r0 = v[u].y, l1 = v[u].z, r1 = v[u].w;
+                        if (P.bps < 32) bad |= (uint32_t)(((l0 ^ (l0 >> 31)) >> lim) | ((r0 ^ (r0 >> 31)) >> lim) | ((l1 ^ (l1 >> 31)) >> lim) | ((r1 ^ (r1 >> 31)) >> lim));
+                        const uint32_t ad = FG_SADDR(2 * j);
+                        if (sizeof(samp_t) == 2) {
+                            *(LDS uint32_t *)(sL + ad) = ((uint32_t)l0 & 0xFFFFu) | ((uint32_t)l1 << 16);
+                            *(LDS uint32_t *)(sR + ad) = ((uint32_t)r0 & 0xFFFFu) | ((uint32_t)r1 << 16);
+                        }
+                        else { sL[ad] = (samp_t)l0; sL[ad + 1] = (samp_t)l1; sR[ad] = (samp_t)r0; sR[ad + 1] = (samp_t)r1; }
+                    }
+                }
+            }
+            istart = n;
+        }
+        for (uint32_t i0 = istart; i0 < n; i0 += 256) {
             int32_t a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {

@@ -16,12 +16,13 @@ for level, secs in ((5, 2.0), (5, 600.0)):
     T = np.array([[r.t[k] for k in range(10)] for r in recs], dtype=np.float64)
     d = np.diff(T, axis=1)
     names = ['stage', 'sums+baseline', '-', 'autocorr', 'lpc_decide', 'eval(fixed+lpc)', 'choose', 'pack', 'crc/finish']
+    chain = T[:, 3].mean()
     T[:, 3] = T[:, 2]
     tot = (T[:, 9] - T[:, 0]).mean()
     print('level %d, %d blocks, kernel %.3f ms; mean clock64 ticks per stage:' % (level, nb, st.encode_kernel_ms))
     for k, nme in enumerate(names):
         print('   %-18s %10.0f  (%.1f%%)' % (nme, d[:, k].mean(), 100 * d[:, k].mean() / tot))
-    print('   total %.0f' % tot)
+    print('   total %.0f   (autocorr: chain part %.0f)' % (tot, chain))
     X = np.array([[r.t[k] for k in range(10, 16)] for r in recs], dtype=np.float64).mean(axis=0)
     print('   pack split: other %.0f  passA %.0f  passB %.0f;  eval split: fir %.0f  search %.0f  setup %.0f' % (X[0], X[1], X[2], X[3], X[4], X[5]))
 import pyflac_amd

@@ -222,6 +222,17 @@ BENCH_BEGIN(k_rice_step_v3)
     a = w0 + w1 + w2 + w3 + sm;
 BENCH_END
 
+BENCH_BEGIN(k_fmac64_dpp)
+    asm volatile(".rept " STR(REP) "\n v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n .endr" : "+v"(fa) : "v"(fb));
+BENCH_END
+
+BENCH_BEGIN(k_fma64_bcast_movs)
+    uint32_t lo = a, hi = b, tl, th;
+    // stands for: broadcast both halves, then a plain FMA on the pair (here fb twice, the moves are independent of it)
+    asm volatile(".rept " STR(REP) "\n v_mov_b32_dpp %1, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n v_fma_f64 %0, %5, %5, %0\n .endr" : "+v"(fa), "=&v"(tl), "=&v"(th) : "v"(lo), "v"(hi), "v"(fb));
+    a += tl + th;
+BENCH_END
+
 BENCH_BEGIN(k_dpp_dep)
     asm volatile(".rept " STR(REP) "\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n .endr" : "+v"(a));
 BENCH_END
@@ -278,6 +289,7 @@ int main()
         {"ds_or_b32 back to back", k_lds_or_nowait, 1}, {"ds_or_b32 pair scattered (x2)", k_lds_or_pair_scattered, 2},
         {"ds_read_u16 back to back (stride 136B)", k_lds_read_u16_nowait, 1}, {"v_writelane + v_readlane (x2)", k_writelane_readlane, 2},
         {"v_mul_i32_i24 with SGPR operand", k_valu_sgpr_operand, 1},
+        {"dependent v_fmac_f64_dpp row_newbcast", k_fmac64_dpp, 1}, {"2 x v_mov_b32_dpp + v_fma_f64 (x3)", k_fma64_bcast_movs, 3},
         {"rice step v1 (saveexec + skip branch)", k_rice_step_v1, 1}, {"rice step v2 (saveexec, no branch)", k_rice_step_v2, 1},
         {"rice step v3 (selects, unconditional LDS read)", k_rice_step_v3, 1},
         {"dependent DPP v_add row_shr", k_dpp_dep, 1}, {"loop: v_add + s_sub + s_cmp + s_cbranch (x4)", k_loop_branch, 4},
