@@ -107,7 +107,7 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-    if (!c->crctab.ensure(1024 * sizeof(uint16_t))) return false;
+    if (!c->crctab.ensure(2048 * sizeof(uint16_t))) return false;
     if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
     HIPCHK(hipStreamSynchronize(c->stream));
     return true;

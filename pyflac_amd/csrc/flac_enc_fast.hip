@@ -40,7 +40,7 @@ size_t fg_wave_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo)
     add(NC * MQ * 4);
     add(NC * 64 * 4);
     add(NC * 32);
-    add(768 * 2);
+    add(1536 * 2);
     add(64 * 4);
     add(64 * NC * 4);
     add(72 * 4);
@@ -65,7 +65,7 @@ size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo)
     add((size_t)NC * P->nvec * MQ * 4);
     add((size_t)NC * P->nvec * 4);
     add((size_t)NC * MQ * 4);
-    add(768 * 2);
+    add(1536 * 2);
     add(128 * 4);
     return off;
 }

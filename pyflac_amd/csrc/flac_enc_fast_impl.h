@@ -116,7 +116,7 @@ FGI double f_ebps(double e, double scale)
 // frame, so its state is  state * x^2048 + crc(word)  whenever it meets its next word, whatever the flush boundaries.
 struct FrameBits {
     LDS uint32_t *w;
-    const LDS uint16_t *t0, *thi, *tlo;
+    const LDS uint16_t *t0, *thi, *tlo, *t1, *t2, *t3;      // byte table, x^2048 multiply tables, slicing tables
     uint32_t *outw;
     uint32_t wbase, slot_words, err;
     uint32_t crc;          // per lane
@@ -148,11 +148,8 @@ FGI void fb_flush(FrameBits &b, int lane, uint32_t upto)
             if (wi < b.slot_words) b.outw[wi] = __builtin_bswap32(v);
             uint32_t s = b.crc;
             s = b.thi[s >> 8] ^ b.tlo[s & 0xFF];
-            uint32_t cw = b.t0[v >> 24];
-            cw = ((cw << 8) & 0xFFFF) ^ b.t0[((cw >> 8) ^ (v >> 16)) & 0xFF];
-            cw = ((cw << 8) & 0xFFFF) ^ b.t0[((cw >> 8) ^ (v >> 8)) & 0xFF];
-            cw = ((cw << 8) & 0xFFFF) ^ b.t0[((cw >> 8) ^ v) & 0xFF];
-            b.crc = s ^ cw;
+            // crc of the word by slicing: four independent look-ups (byte followed by 3, 2, 1, 0 zero bytes)
+            b.crc = s ^ b.t3[v >> 24] ^ b.t2[(v >> 16) & 0xFF] ^ b.t1[(v >> 8) & 0xFF] ^ b.t0[v & 0xFF];
         }
     }
     const uint32_t carry = b.w[nfull];
@@ -202,11 +199,11 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     LDS int32_t *qres = FG_CARVE(int32_t, NC * P.nvec * MAXO * 4);
     LDS uint32_t *lres = FG_CARVE(uint32_t, NC * P.nvec * 4);
     LDS int32_t *bestq = FG_CARVE(int32_t, NC * MAXO * 4);
-    LDS uint16_t *crct = FG_CARVE(uint16_t, 768 * 2);
+    LDS uint16_t *crct = FG_CARVE(uint16_t, 1536 * 2);
     LDS uint32_t *misc = FG_CARVE(uint32_t, 128 * 4);
 #undef FG_CARVE
     const float *window = windows + d.win_off;
-    for (int j = lane; j < 768; j += 64) crct[j] = crctab[j];
+    for (int j = lane; j < 768; j += 64) { crct[j] = crctab[j]; crct[768 + j] = crctab[1024 + j]; }
     misc[64 + lane] = crctab[768 + lane];
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
 #define FG_STAMP(i) do { if (mydbg && lane == 0) mydbg->t[i] = clock64(); } while (0)
@@ -569,17 +566,24 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 
     // ================================================================ Levinson-Durbin, order guess, quantiser
     // lane = candidate * nvec + vector.  lres[idx] = order | prec<<8 | (shift&255)<<16 | ok<<24 | ran<<25
+    // The recursion runs in registers (loops unrolled to the compile-time maximum order, guarded by the run-time one);
+    // the coefficient set of the best order so far is kept aside instead of being recomputed afterwards (same operations
+    // in the same order as lpc.c, so the same doubles).
     if (nv > 0) {
         const uint32_t nidx = (uint32_t)NC * P.nvec;
-        const uint32_t LS = nidx;
-        LDS double *lpcw = dbuf;
-        LDS float *lpf = (LDS float *)(dbuf + (size_t)mo * LS);
         const uint32_t idx = lane;
         if (idx < nidx) {
             const uint32_t c = idx / P.nvec, v = idx % P.nvec;
-            const LDS double *A = autoc + (c * P.nvec + v) * (MAXO + 1);
+            const LDS double *Ap = autoc + (c * P.nvec + v) * (MAXO + 1);
             bool on = v < nv && ((lpc_mask >> c) & 1);
+            double A[MAXO + 1];
+#pragma unroll
+            for (int j = 0; j <= MAXO; j++) A[j] = ((uint32_t)j <= mo) ? Ap[j] : 0.0;
             if (on && A[0] == 0.0) on = false;
+            if (!on) {
+#pragma unroll
+                for (int j = 0; j <= MAXO; j++) A[j] = 0.0;
+            }
             uint32_t sb = sbp[0];
 #pragma unroll
             for (int cc = 1; cc < NC; cc++) if (c == (uint32_t)cc) sb = sbp[cc];
@@ -587,45 +591,49 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             const uint32_t overhead = sb + P.qlp_precision;
             const double scale = 0.5 / (double)n;
             double er = a0, bestb = 4294967295.0;
+            double lp[MAXO], keep[MAXO], err2 = a0;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) { lp[j] = 0.0; keep[j] = 0.0; }
             uint32_t besti = 0;
-            bool stopped = false;
-            for (uint32_t i = 0; i < mo; i++) {
-                double r = on ? -A[i + 1] : 0.0;
-                for (uint32_t j = 0; j < i; j++) r -= lpcw[j * LS + idx] * (on ? A[i - j] : 0.0);
-                r /= er;
-                lpcw[i * LS + idx] = r;
-                uint32_t j;
-                for (j = 0; j < (i >> 1); j++) {
-                    const double tmp = lpcw[j * LS + idx], t2 = lpcw[(i - 1 - j) * LS + idx];
-                    lpcw[j * LS + idx] = tmp + r * t2;
-                    lpcw[(i - 1 - j) * LS + idx] = t2 + r * tmp;
-                }
-                if (i & 1) { const double t = lpcw[j * LS + idx]; lpcw[j * LS + idx] = t + t * r; }
-                er *= (1.0 - r * r);
-                if (!stopped) {
-                    const uint32_t o = i + 1;
-                    const double bits = f_ebps(er, scale) * (double)(n - o) + (double)(o * overhead);
-                    if (bits < bestb) { besti = i; bestb = bits; }
-                    if (er == 0.0) stopped = true;
+            bool stopped = false, have = false;
+#pragma unroll
+            for (int i = 0; i < MAXO; i++) {
+                if ((uint32_t)i < mo) {
+                    double r = -A[i + 1];
+#pragma unroll
+                    for (int j = 0; j < i; j++) r -= lp[j] * A[i - j];
+                    r /= er;
+                    lp[i] = r;
+#pragma unroll
+                    for (int j = 0; j < (i >> 1); j++) {
+                        const double tmp = lp[j], t2 = lp[i - 1 - j];
+                        lp[j] = tmp + r * t2;
+                        lp[i - 1 - j] = t2 + r * tmp;
+                    }
+                    if (i & 1) { const double t = lp[i >> 1]; lp[i >> 1] = t + t * r; }
+                    er *= (1.0 - r * r);
+                    bool better = false;
+                    if (!stopped) {
+                        const uint32_t o = i + 1;
+                        const double bits = f_ebps(er, scale) * (double)(n - o) + (double)(o * overhead);
+                        if (bits < bestb) { besti = i; bestb = bits; better = true; }
+                        if (er == 0.0) stopped = true;
+                    }
+                    // order 1 is what remains when no order improves on the initial bound (besti stays 0)
+                    if (better || !have) {
+                        if (better || i == 0) {
+#pragma unroll
+                            for (int j = 0; j <= i; j++) keep[j] = lp[j];
+                            err2 = er;
+                        }
+                        have = true;
+                    }
                 }
             }
             const uint32_t ostar = besti + 1;
-            double err2 = a0;
-            for (uint32_t i = 0; i < ostar; i++) {
-                double r = on ? -A[i + 1] : 0.0;
-                for (uint32_t j = 0; j < i; j++) r -= lpcw[j * LS + idx] * (on ? A[i - j] : 0.0);
-                r /= err2;
-                lpcw[i * LS + idx] = r;
-                uint32_t j;
-                for (j = 0; j < (i >> 1); j++) {
-                    const double tmp = lpcw[j * LS + idx], t2 = lpcw[(i - 1 - j) * LS + idx];
-                    lpcw[j * LS + idx] = tmp + r * t2;
-                    lpcw[(i - 1 - j) * LS + idx] = t2 + r * tmp;
-                }
-                if (i & 1) { const double t = lpcw[j * LS + idx]; lpcw[j * LS + idx] = t + t * r; }
-                err2 *= (1.0 - r * r);
-            }
-            for (uint32_t jj = 0; jj < ostar; jj++) lpf[jj * LS + idx] = (float)(-lpcw[jj * LS + idx]);
+            float lpf[MAXO];
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) lpf[j] = (float)(-keep[j]);
             uint32_t result = 0;
             for (uint32_t j = 0; j < (uint32_t)MAXO; j++) qres[idx * MAXO + j] = 0;
             if (on) {
@@ -637,7 +645,8 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                     const int p1 = (int)prec - 1;
                     const int32_t qmax = (1 << p1) - 1, qmin = -(1 << p1);
                     double cmax = 0.0;
-                    for (uint32_t j = 0; j < ostar; j++) { const double dd = fabs((double)lpf[j * LS + idx]); if (dd > cmax) cmax = dd; }
+#pragma unroll
+                    for (int j = 0; j < MAXO; j++) if ((uint32_t)j < ostar) { const double dd = fabs((double)lpf[j]); if (dd > cmax) cmax = dd; }
                     if (cmax <= 0.0) ok = false;
                     else {
                         const int e = (int)((__double_as_longlong(cmax) >> 52) & 0x7FF) - 1022;
@@ -649,14 +658,17 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                         double error = 0.0;
                         const bool neg = shift < 0;
                         const double mul = neg ? (double)(1 << (-shift)) : (double)(1 << shift);
-                        for (uint32_t j = 0; j < ostar; j++) {
-                            const double lpv = (double)lpf[j * LS + idx];
-                            error += neg ? lpv / mul : lpv * mul;
-                            const double rq = round(error);
-                            int32_t qv = (int32_t)(i64)rq;
-                            if (qv > qmax) qv = qmax; else if (qv < qmin) qv = qmin;
-                            error -= (double)qv;
-                            qres[idx * MAXO + j] = qv;
+#pragma unroll
+                        for (int j = 0; j < MAXO; j++) {
+                            if ((uint32_t)j < ostar) {
+                                const double lpv = (double)lpf[j];
+                                error += neg ? lpv / mul : lpv * mul;
+                                const double rq = round(error);
+                                int32_t qv = (int32_t)(i64)rq;
+                                if (qv > qmax) qv = qmax; else if (qv < qmin) qv = qmin;
+                                error -= (double)qv;
+                                qres[idx * MAXO + j] = qv;
+                            }
                         }
                         if (neg) shift = 0;
                     }
@@ -946,7 +958,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     u64 tacc[4] = {0, 0, 0, 0}, tl_ = mydbg ? clock64() : 0;
 #define FG_TACC(i) do { if (mydbg) { const u64 n_ = clock64(); tacc[i] += n_ - tl_; tl_ = n_; } } while (0)
     FrameBits fb;
-    fb.w = fbw; fb.t0 = crct; fb.thi = crct + 256; fb.tlo = crct + 512;
+    fb.w = fbw; fb.t0 = crct; fb.thi = crct + 256; fb.tlo = crct + 512; fb.t1 = crct + 768; fb.t2 = crct + 1024; fb.t3 = crct + 1280;
     fb.outw = (uint32_t *)(out + (size_t)d.out_slot * P.slot_bytes);
     fb.slot_words = P.slot_bytes / 4; fb.wbase = 0; fb.err = 0; fb.crc = 0;
     uint32_t bitpos = 0;
@@ -1081,9 +1093,11 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         const uint32_t skip = (type >= 2 && lane == 0) ? order : 0;      // warm-up samples are not coded
         // one walk over the segment; EMIT = false: returns the bit length, EMIT = true: writes the codes from bit `p0` on
         // CC = candidate, VERB = verbatim subframe, EMIT: all compile-time, so the per-sample loop has no control flow
-        auto walk_t = [&](auto CC, auto VERB, auto EMIT, auto ATOM, uint32_t p0, bool inrange) __attribute__((always_inline)) -> uint32_t {
+        // ALLF: every lane belongs to the group being emitted (the whole subframe fits the window: the common case)
+        auto walk_t = [&](auto CC, auto VERB, auto EMIT, auto ATOM, auto ALLF, uint32_t p0, bool inrange_) __attribute__((always_inline)) -> uint32_t {
             constexpr int C_ = decltype(CC)::value;
             constexpr bool verb = decltype(VERB)::value, emit = decltype(EMIT)::value, atom = decltype(ATOM)::value;
+            const bool inrange = decltype(ALLF)::value ? true : inrange_;
             int32_t h[MAXO];
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
@@ -1121,7 +1135,8 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 pos += plen; len += plen;
             }
             const uint32_t kmask = (1u << kr) - 1, kone = 1u << kr;
-            auto step = [&](int u, uint32_t s) __attribute__((always_inline)) {
+            // guard: the step may be one of the warm-up samples (the first `order` of the block, all in lane 0's first group)
+            auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
                 const int32_t x = fcv<MS, C_>(rowL[s], (NCH == 2) ? rowR[s] : 0);
                 uint32_t val, vb, lead;
                 if (verb) { val = (uint32_t)x & mask; vb = sb; lead = 0; }
@@ -1135,19 +1150,30 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                     val = kone | (uu & kmask);
                     vb = kr + 1;
                 }
-                const bool coded = s >= skip;
-                if (emit) put(coded ? pos + lead : pos, coded ? val : 0, coded ? vb : 0);     // warm-up samples: nothing, in place
-                const uint32_t cl_ = coded ? lead + vb : 0;
-                pos += cl_; len += cl_;
+                if (guard) {
+                    const bool coded = s >= skip;
+                    if (emit) put(coded ? pos + lead : pos, coded ? val : 0, coded ? vb : 0);     // warm-up samples: nothing, in place
+                    const uint32_t cl_ = coded ? lead + vb : 0;
+                    pos += cl_; len += cl_;
+                }
+                else {
+                    if (emit) put(pos + lead, val, vb);
+                    pos += lead + vb; len += lead + vb;
+                }
             };
             uint32_t s0 = 0;
+            if (seg >= (uint32_t)MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, (uint32_t)u, true);
+                s0 = MAXO;
+            }
 #pragma unroll 1
             for (; s0 + MAXO <= seg; s0 += MAXO) {
 #pragma unroll
-                for (int u = 0; u < MAXO; u++) step(u, s0 + u);
+                for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
             }
 #pragma unroll
-            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u);
+            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
             if (emit && !atom) {
                 // the last word of every lane: no other lane of the group ends in it (each lane spans at least a word)
                 wave_lds_fence();
@@ -1156,21 +1182,22 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
             return len;
         };
-        auto walk_c = [&](auto CC, bool emit, uint32_t p0, bool inrange) __attribute__((always_inline)) -> uint32_t {
+        auto walk_c = [&](auto CC, bool emit, uint32_t p0, bool inrange, bool all) __attribute__((always_inline)) -> uint32_t {
             typedef std::integral_constant<bool, true> T;
             typedef std::integral_constant<bool, false> F;
-            if (!emit) return type == 1 ? walk_t(CC, T(), F(), F(), p0, inrange) : walk_t(CC, F(), F(), F(), p0, inrange);
-            if (seg < 32) return type == 1 ? walk_t(CC, T(), T(), T(), p0, inrange) : walk_t(CC, F(), T(), T(), p0, inrange);
-            return type == 1 ? walk_t(CC, T(), T(), F(), p0, inrange) : walk_t(CC, F(), T(), F(), p0, inrange);
+            if (!emit) return type == 1 ? walk_t(CC, T(), F(), F(), F(), p0, inrange) : walk_t(CC, F(), F(), F(), F(), p0, inrange);
+            if (seg < 32) return type == 1 ? walk_t(CC, T(), T(), T(), F(), p0, inrange) : walk_t(CC, F(), T(), T(), F(), p0, inrange);
+            if (all) return type == 1 ? walk_t(CC, T(), T(), F(), T(), p0, true) : walk_t(CC, F(), T(), F(), T(), p0, true);
+            return type == 1 ? walk_t(CC, T(), T(), F(), F(), p0, inrange) : walk_t(CC, F(), T(), F(), F(), p0, inrange);
         };
-        auto walk = [&](bool emit, uint32_t p0, bool inrange) __attribute__((always_inline)) -> uint32_t {
-            if (NC == 1 || c == 0) return walk_c(std::integral_constant<int, 0>(), emit, p0, inrange);
-            if (NC == 2 || c == 1) return walk_c(std::integral_constant<int, (NC > 1 ? 1 : 0)>(), emit, p0, inrange);
-            if (c == 2) return walk_c(std::integral_constant<int, (NC > 2 ? 2 : 0)>(), emit, p0, inrange);
-            return walk_c(std::integral_constant<int, (NC > 3 ? 3 : 0)>(), emit, p0, inrange);
+        auto walk = [&](bool emit, uint32_t p0, bool inrange, bool all) __attribute__((always_inline)) -> uint32_t {
+            if (NC == 1 || c == 0) return walk_c(std::integral_constant<int, 0>(), emit, p0, inrange, all);
+            if (NC == 2 || c == 1) return walk_c(std::integral_constant<int, (NC > 1 ? 1 : 0)>(), emit, p0, inrange, all);
+            if (c == 2) return walk_c(std::integral_constant<int, (NC > 2 ? 2 : 0)>(), emit, p0, inrange, all);
+            return walk_c(std::integral_constant<int, (NC > 3 ? 3 : 0)>(), emit, p0, inrange, all);
         };
         FG_TACC(0);
-        const uint32_t mylen = walk(false, 0, false);
+        const uint32_t mylen = walk(false, 0, false, false);
         FG_TACC(1);
         if (__any(mylen > (1u << 24))) { fb.err |= FG_ERR_REDO; break; }       // absurd code lengths: the generic kernel copes
         const uint32_t incl = wave_scan_add(mylen);
@@ -1190,7 +1217,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             if (cnt == 0) { failed = true; break; }
             const uint32_t b = a + cnt;
             FG_TACC(0);
-            (void)walk(true, mystart, (uint32_t)lane >= a && (uint32_t)lane < b);
+            (void)walk(true, mystart, (uint32_t)lane >= a && (uint32_t)lane < b, a == 0 && b == 64);
             wave_lds_fence();
             FG_TACC(2);
             a = b;

@@ -1026,6 +1026,10 @@ __global__ void fg_crc_tables_kernel(uint16_t *tab)
     tab[256 + i] = (uint16_t)crc16_mulx((uint32_t)i << 8, 2048);
     tab[512 + i] = (uint16_t)crc16_mulx((uint32_t)i, 2048);
     if (i < 64) tab[768 + i] = (uint16_t)crc16_mulx(1, 32 * i);  // x^(32 i)
+    // slicing tables: crc of byte i followed by 1, 2, 3 zero bytes (a 32-bit word then needs four independent look-ups)
+    tab[1024 + i] = (uint16_t)crc16_mulx(c, 8);
+    tab[1280 + i] = (uint16_t)crc16_mulx(c, 16);
+    tab[1536 + i] = (uint16_t)crc16_mulx(c, 24);
 }
 
 __global__ void __launch_bounds__(64)

@@ -56,7 +56,7 @@ fg_encode_wave_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     LDS int32_t *bestq = FG_CARVE(int32_t, NC * MAXO * 4);
     LDS uint32_t *dk = FG_CARVE(uint32_t, NC * 64 * 4);                 // Rice parameters of the best predictor, per lane
     LDS WaveDecision *dec = FG_CARVE(WaveDecision, NC * sizeof(WaveDecision));
-    LDS uint16_t *crct = FG_CARVE(uint16_t, 768 * 2);
+    LDS uint16_t *crct = FG_CARVE(uint16_t, 1536 * 2);
     LDS uint32_t *mult = FG_CARVE(uint32_t, 64 * 4);                    // x^(32 j) mod P, j = 0..63
     LDS uint32_t *scrw = FG_CARVE(uint32_t, NT * 4);                    // one scratch word per thread (parked stores)
     LDS uint32_t *hand = FG_CARVE(uint32_t, 72 * 4);                    // wave 0 -> wave 1: CRC lane states, tail word, positions
@@ -64,7 +64,7 @@ fg_encode_wave_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     LDS uint32_t *flags = FG_CARVE(uint32_t, 16);
 #undef FG_CARVE
     const float *window = windows + d.win_off;
-    for (int j = tid; j < 768; j += NT) crct[j] = crctab[j];
+    for (int j = tid; j < 768; j += NT) { crct[j] = crctab[j]; crct[768 + j] = crctab[1024 + j]; }
     if (tid < 64) mult[tid] = crctab[768 + tid];
     if (tid == 0) { flags[0] = 0; flags[1] = 0; }
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
@@ -614,7 +614,7 @@ fg_encode_wave_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     const uint32_t pc = MS ? (si == 0 ? sub0 : sub1) : (packer ? si : 0);     // candidate this wave packs
     FrameBits fb;
     fb.w = (LDS uint32_t *)(ureg + (packer ? si : 0) * ((FGS_FBW + 2) * 4));
-    fb.t0 = crct; fb.thi = crct + 256; fb.tlo = crct + 512;
+    fb.t0 = crct; fb.thi = crct + 256; fb.tlo = crct + 512; fb.t1 = crct + 768; fb.t2 = crct + 1024; fb.t3 = crct + 1280;
     fb.outw = (uint32_t *)(out + (size_t)d.out_slot * P.slot_bytes);
     fb.slot_words = P.slot_bytes / 4; fb.wbase = 0; fb.err = 0; fb.crc = 0;
     uint32_t bitpos = 0;
