@@ -56,16 +56,15 @@ size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo)
     const int MQ = maxo > 0 ? maxo : 1;
     size_t off = 0;
     auto add = [&](size_t b) { off += (b + 15) & ~(size_t)15; };
-    add((size_t)(P->sig_stride + 256) * sb);
-    add(nch == 2 ? (size_t)(P->sig_stride + 256) * sb : 16);
+    add((size_t)(P->sig_stride + 128) * sb);
+    add(nch == 2 ? (size_t)(P->sig_stride + 128) * sb : 16);
     size_t ubytes = P->lds_dbuf_bytes > (size_t)NC * FGS_DSTR * 8 ? P->lds_dbuf_bytes : (size_t)NC * FGS_DSTR * 8;
-    if (ubytes < (FGS_FBW + 2) * 4) ubytes = (FGS_FBW + 2) * 4;
+    if (ubytes < (FGS_FBW + 2) * 4 + 8 + 1536 * 2) ubytes = (FGS_FBW + 2) * 4 + 8 + 1536 * 2;
     add(ubytes);
     add((size_t)NC * P->nvec * (maxo + 1) * 8);
     add((size_t)NC * P->nvec * MQ * 4);
     add((size_t)NC * P->nvec * 4);
     add((size_t)NC * MQ * 4);
-    add(1536 * 2);
     add(128 * 4);
     return off;
 }

@@ -45,8 +45,8 @@ template <bool ACC64> struct FastTypes {
     typedef typename std::conditional<ACC64, u64, uint32_t>::type sum_t;
     // bits-per-sample <= 16 (the !ACC64 shapes): samples are staged as int16, halving the LDS footprint
     typedef typename std::conditional<ACC64, int32_t, int16_t>::type samp_t;
-    // elements of skew between the rows of neighbouring lanes (rows stay 8-byte aligned, bank-conflict free)
-    static constexpr uint32_t PADE = ACC64 ? 2 : 4;
+    // elements of skew between the rows of neighbouring lanes (rows stay 4-byte aligned; 33 / 66 words of stride: no bank conflicts)
+    static constexpr uint32_t PADE = 2;
 };
 
 // candidate value from the two channel samples
@@ -187,23 +187,23 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     LDS unsigned char *lbase = (LDS unsigned char *)smem;
     uint32_t off = 0;
 #define FG_CARVE(type, bytes) (LDS type *)(lbase + off); off += (uint32_t)(((bytes) + 15) & ~15u)
-    LDS samp_t *sL = FG_CARVE(samp_t, (P.sig_stride + 256) * sizeof(samp_t));      // 64 rows, up to 4 elements of skew each
-    LDS samp_t *sR = FG_CARVE(samp_t, NCH == 2 ? (P.sig_stride + 256) * sizeof(samp_t) : 16);
-    // the analysis scratch (autocorrelation staging, Levinson-Durbin work space) and the frame-bit window of the packing
-    // stage are never live together: one region
+    LDS samp_t *sL = FG_CARVE(samp_t, (P.sig_stride + 128) * sizeof(samp_t));      // 64 rows, 2 elements of skew each
+    LDS samp_t *sR = FG_CARVE(samp_t, NCH == 2 ? (P.sig_stride + 128) * sizeof(samp_t) : 16);
+    // the analysis scratch (autocorrelation staging rows) and what only the packing stage needs (frame-bit window, CRC
+    // tables) are never live together: one region.  (LDS is handed out in coarse granules on this part: the kernel must
+    // stay under 25.6 KB to keep six blocks per CU.)
     uint32_t ubytes = P.lds_dbuf_bytes > NC * FGS_DSTR * 8 ? P.lds_dbuf_bytes : NC * FGS_DSTR * 8;
-    if (ubytes < (FGS_FBW + 2) * 4) ubytes = (FGS_FBW + 2) * 4;
+    if (ubytes < (FGS_FBW + 2) * 4 + 8 + 1536 * 2) ubytes = (FGS_FBW + 2) * 4 + 8 + 1536 * 2;
     LDS double *dbuf = FG_CARVE(double, ubytes);
     LDS uint32_t *fbw = (LDS uint32_t *)dbuf;
+    LDS uint16_t *crct = (LDS uint16_t *)(fbw + FGS_FBW + 4);
     LDS double *autoc = FG_CARVE(double, NC * P.nvec * (MAXO + 1) * 8);
     LDS int32_t *qres = FG_CARVE(int32_t, NC * P.nvec * MAXO * 4);
     LDS uint32_t *lres = FG_CARVE(uint32_t, NC * P.nvec * 4);
     LDS int32_t *bestq = FG_CARVE(int32_t, NC * MAXO * 4);
-    LDS uint16_t *crct = FG_CARVE(uint16_t, 1536 * 2);
     LDS uint32_t *misc = FG_CARVE(uint32_t, 128 * 4);
 #undef FG_CARVE
     const float *window = windows + d.win_off;
-    for (int j = lane; j < 768; j += 64) { crct[j] = crctab[j]; crct[768 + j] = crctab[1024 + j]; }
     misc[64 + lane] = crctab[768 + lane];
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
 #define FG_STAMP(i) do { if (mydbg && lane == 0) mydbg->t[i] = clock64(); } while (0)
@@ -963,6 +963,11 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     fb.slot_words = P.slot_bytes / 4; fb.wbase = 0; fb.err = 0; fb.crc = 0;
     uint32_t bitpos = 0;
     for (uint32_t j = lane; j < FGS_FBW + 2; j += 64) fbw[j] = 0;
+    // the CRC tables move in now (their LDS belonged to the analysis until here): byte table + x^2048 tables, slicing tables
+    for (int j = lane; j < 384; j += 64) {
+        ((LDS uint32_t *)crct)[j] = ((const uint32_t *)crctab)[j];
+        ((LDS uint32_t *)crct)[384 + j] = ((const uint32_t *)crctab)[512 + j];
+    }
     wave_lds_fence();
     {   // frame header: assembled by lane 0 in LDS, emitted one byte per lane
         LDS uint8_t *hb = (LDS uint8_t *)misc;
