@@ -7,6 +7,7 @@
 
 #define FGS_FBW 1024
 #define FGS_DSTR 168
+#define FGS_CSTR 136
 
 extern "C" {
 
@@ -58,8 +59,8 @@ size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo)
     auto add = [&](size_t b) { off += (b + 15) & ~(size_t)15; };
     add((size_t)(P->sig_stride + 128) * sb);
     add(nch == 2 ? (size_t)(P->sig_stride + 128) * sb : 16);
-    size_t ubytes = P->lds_dbuf_bytes > (size_t)NC * FGS_DSTR * 8 ? P->lds_dbuf_bytes : (size_t)NC * FGS_DSTR * 8;
-    if (ubytes < (FGS_FBW + 2) * 4 + 8 + 1536 * 2) ubytes = (FGS_FBW + 2) * 4 + 8 + 1536 * 2;
+    size_t ubytes = (size_t)NC * FGS_CSTR * 8;
+    if (ubytes < (FGS_FBW + 2) * 4) ubytes = (FGS_FBW + 2) * 4;
     add(ubytes);
     add((size_t)NC * P->nvec * (maxo + 1) * 8);
     add((size_t)NC * P->nvec * MQ * 4);

@@ -34,8 +34,10 @@
 
 #define FGS_FBW 1024      // frame-bit window, 32-bit words
 #define FGS_DH 32         // autocorrelation: history doubles kept in front of each chunk
-#define FGS_DK 128        // autocorrelation: chunk length
-#define FGS_DSTR 168      // doubles per candidate row (history + chunk + bank skew)
+#define FGS_DK 128        // autocorrelation: chunk length                                   [wave-per-candidate kernel]
+#define FGS_DSTR 168      // doubles per candidate row (history + chunk + bank skew)          [wave-per-candidate kernel]
+#define FGS_CK 96         // single-wave kernel: chunk length (LDS is the occupancy limit there)
+#define FGS_CSTR 136      // doubles per row: 32 history + 96 + read-ahead slack; 272 words = 16 banks of skew
 
 using namespace fgdev;
 
@@ -114,9 +116,13 @@ FGI double f_ebps(double e, double scale)
 // Bits are ORed into a zeroed window of FGS_FBW words that starts at absolute word `wbase` of the frame.  flush() writes
 // the complete words out (big-endian) and advances the per-lane CRC state: lane l owns the words l, l+64, l+128, ... of the
 // frame, so its state is  state * x^2048 + crc(word)  whenever it meets its next word, whatever the flush boundaries.
+// where the CRC tables of a kernel live: global memory for the single-wave kernel, LDS for the wave-per-candidate one
+#ifndef FG_CRCT
+#define FG_CRCT
+#endif
 struct FrameBits {
     LDS uint32_t *w;
-    const LDS uint16_t *t0, *thi, *tlo, *t1, *t2, *t3;      // byte table, x^2048 multiply tables, slicing tables
+    const FG_CRCT uint16_t *t0, *thi, *tlo, *t1, *t2, *t3;      // byte table, x^2048 multiply tables, slicing tables
     uint32_t *outw;
     uint32_t wbase, slot_words, err;
     uint32_t crc;          // per lane
@@ -189,14 +195,14 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 #define FG_CARVE(type, bytes) (LDS type *)(lbase + off); off += (uint32_t)(((bytes) + 15) & ~15u)
     LDS samp_t *sL = FG_CARVE(samp_t, (P.sig_stride + 128) * sizeof(samp_t));      // 64 rows, 2 elements of skew each
     LDS samp_t *sR = FG_CARVE(samp_t, NCH == 2 ? (P.sig_stride + 128) * sizeof(samp_t) : 16);
-    // the analysis scratch (autocorrelation staging rows) and what only the packing stage needs (frame-bit window, CRC
-    // tables) are never live together: one region.  (LDS is handed out in coarse granules on this part: the kernel must
-    // stay under 25.6 KB to keep six blocks per CU.)
-    uint32_t ubytes = P.lds_dbuf_bytes > NC * FGS_DSTR * 8 ? P.lds_dbuf_bytes : NC * FGS_DSTR * 8;
-    if (ubytes < (FGS_FBW + 2) * 4 + 8 + 1536 * 2) ubytes = (FGS_FBW + 2) * 4 + 8 + 1536 * 2;
+    // the analysis scratch (autocorrelation staging rows) and the frame-bit window of the packing stage are never live
+    // together: one region.  LDS is the occupancy limit (it is handed out in 1280-byte granules; 18 granules = 7 blocks
+    // per CU), so the CRC tables are read from global memory (3 KB, L1-resident) instead of being copied in.
+    uint32_t ubytes = NC * FGS_CSTR * 8;
+    if (ubytes < (FGS_FBW + 2) * 4) ubytes = (FGS_FBW + 2) * 4;
     LDS double *dbuf = FG_CARVE(double, ubytes);
     LDS uint32_t *fbw = (LDS uint32_t *)dbuf;
-    LDS uint16_t *crct = (LDS uint16_t *)(fbw + FGS_FBW + 4);
+    const uint16_t *crct = crctab;          // [0,256) byte table, [256,768) x^2048 tables, [1024,1792) slicing tables
     LDS double *autoc = FG_CARVE(double, NC * P.nvec * (MAXO + 1) * 8);
     LDS int32_t *qres = FG_CARVE(int32_t, NC * P.nvec * MAXO * 4);
     LDS uint32_t *lres = FG_CARVE(uint32_t, NC * P.nvec * 4);
@@ -423,7 +429,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     FG_STAMP(2);
 
     // ================================================================ autocorrelation vectors (order-preserving fp64 chains)
-    // lane = candidate row (16 lanes) x lag.  Per chunk of FGS_DK samples the windowed signal of every candidate is staged
+    // lane = candidate row (16 lanes) x lag.  Per chunk of FGS_CK samples the windowed signal of every candidate is staged
     // as doubles (with FGS_DH history entries in front); the chain then needs one LDS read per step: lane (c, l) reads
     // d[j - l], the d[j] operand is lane (c, 0)'s own value, broadcast inside the FMA (DPP row_newbcast:0).
     uint32_t nv = 0;
@@ -431,7 +437,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     if (lpc_mask && MAXO > 0 && mo > 0) {
         const uint32_t cl = lane >> 4, l = lane & 15;
         const bool on = cl < (uint32_t)NC && l <= mo;
-        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGS_DSTR + FGS_DH - (on ? l : 0);
+        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGS_CSTR + FGS_DH - (on ? l : 0);
         // vector schedule of apply_apodization_ (tukey: one; subdivide_tukey(parts): whole, then per depth b the
         // partial windows at even c and the punch-outs at odd c)
         uint32_t vb_ = 1, vc_ = 0;
@@ -446,18 +452,18 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
             if (!skip && !punch) {
                 double acc = 0.0;
-                for (uint32_t j = lane; j < NC * FGS_DH; j += 64) dbuf[(j / FGS_DH) * FGS_DSTR + (j % FGS_DH)] = 0.0;
+                for (uint32_t j = lane; j < NC * FGS_DH; j += 64) dbuf[(j / FGS_DH) * FGS_CSTR + (j % FGS_DH)] = 0.0;
                 wave_lds_fence();
                 // window values of the first chunk
-                float wv[FGS_DK / 64];
-                uint32_t si[FGS_DK / 64];
+                float wv[(FGS_CK + 63) / 64];
+                uint32_t si[(FGS_CK + 63) / 64];
                 auto fetch = [&](uint32_t k0) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int u = 0; u < FGS_DK / 64; u++) {
+                    for (int u = 0; u < (FGS_CK + 63) / 64; u++) {
                         const uint32_t i = k0 + u * 64 + lane;
                         float w = 0.0f;
                         uint32_t s_ = 0;
-                        if (i < vec_len) {
+                        if (i < vec_len && (uint32_t)(u * 64 + lane) < FGS_CK) {
                             if (part == 0) { w = window[i]; s_ = i; }
                             else if (i < part) { w = window[i]; s_ = sh + i; }
                             else if (i < 2 * part) { w = window[n - 2 * part + i]; s_ = sh + i; }
@@ -466,10 +472,10 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                     }
                 };
                 fetch(0);
-                for (uint32_t k0 = 0; k0 < vec_len; k0 += FGS_DK) {
-                    const uint32_t kn = (vec_len - k0) < FGS_DK ? (vec_len - k0) : FGS_DK;
+                for (uint32_t k0 = 0; k0 < vec_len; k0 += FGS_CK) {
+                    const uint32_t kn = (vec_len - k0) < FGS_CK ? (vec_len - k0) : FGS_CK;
 #pragma unroll
-                    for (int u = 0; u < FGS_DK / 64; u++) {
+                    for (int u = 0; u < (FGS_CK + 63) / 64; u++) {
                         const uint32_t j = u * 64 + lane;
                         if (j < kn) {
                             const uint32_t ad = FG_SADDR(si[u]);
@@ -479,11 +485,11 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                             for (int c = 0; c < NC; c++) {
                                 const int32_t x = !MS ? (c == 0 ? L : R) : (c == 0 ? L : c == 1 ? R : c == 2 ? ((L + R) >> 1) : (L - R));
                                 const float dd = zero ? 0.0f : (float)x * wv[u];
-                                dbuf[c * FGS_DSTR + FGS_DH + j] = (double)dd;
+                                dbuf[c * FGS_CSTR + FGS_DH + j] = (double)dd;
                             }
                         }
                     }
-                    if (k0 + FGS_DK < vec_len) fetch(k0 + FGS_DK);       // next chunk's window values travel during the chain
+                    if (k0 + FGS_CK < vec_len) fetch(k0 + FGS_CK);       // next chunk's window values travel during the chain
                     wave_lds_fence();
                     if (on) {
                         // four steps per group; the operands of the next two groups are requested before the FMAs of the
@@ -518,13 +524,13 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 #pragma unroll
                         for (int u = 0; u < (NC * FGS_DH + 63) / 64; u++) {
                             const uint32_t j = u * 64 + lane;
-                            t[u] = (j < NC * FGS_DH) ? dbuf[(j / FGS_DH) * FGS_DSTR + FGS_DK + (j % FGS_DH)] : 0.0;
+                            t[u] = (j < NC * FGS_DH) ? dbuf[(j / FGS_DH) * FGS_CSTR + FGS_CK + (j % FGS_DH)] : 0.0;
                         }
                         wave_lds_fence();
 #pragma unroll
                         for (int u = 0; u < (NC * FGS_DH + 63) / 64; u++) {
                             const uint32_t j = u * 64 + lane;
-                            if (j < NC * FGS_DH) dbuf[(j / FGS_DH) * FGS_DSTR + (j % FGS_DH)] = t[u];
+                            if (j < NC * FGS_DH) dbuf[(j / FGS_DH) * FGS_CSTR + (j % FGS_DH)] = t[u];
                         }
                         wave_lds_fence();
                     }
@@ -958,16 +964,15 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     u64 tacc[4] = {0, 0, 0, 0}, tl_ = mydbg ? clock64() : 0;
 #define FG_TACC(i) do { if (mydbg) { const u64 n_ = clock64(); tacc[i] += n_ - tl_; tl_ = n_; } } while (0)
     FrameBits fb;
-    fb.w = fbw; fb.t0 = crct; fb.thi = crct + 256; fb.tlo = crct + 512; fb.t1 = crct + 768; fb.t2 = crct + 1024; fb.t3 = crct + 1280;
+    // (the cast only matters where this header is included with LDS-resident tables, i.e. never for this kernel)
+#define FG_TP(x) ((const FG_CRCT uint16_t *)(uintptr_t)(x))
+    fb.w = fbw; fb.t0 = FG_TP(crct); fb.thi = FG_TP(crct + 256); fb.tlo = FG_TP(crct + 512);
+    fb.t1 = FG_TP(crct + 1024); fb.t2 = FG_TP(crct + 1280); fb.t3 = FG_TP(crct + 1536);
+#undef FG_TP
     fb.outw = (uint32_t *)(out + (size_t)d.out_slot * P.slot_bytes);
     fb.slot_words = P.slot_bytes / 4; fb.wbase = 0; fb.err = 0; fb.crc = 0;
     uint32_t bitpos = 0;
     for (uint32_t j = lane; j < FGS_FBW + 2; j += 64) fbw[j] = 0;
-    // the CRC tables move in now (their LDS belonged to the analysis until here): byte table + x^2048 tables, slicing tables
-    for (int j = lane; j < 384; j += 64) {
-        ((LDS uint32_t *)crct)[j] = ((const uint32_t *)crctab)[j];
-        ((LDS uint32_t *)crct)[384 + j] = ((const uint32_t *)crctab)[512 + j];
-    }
     wave_lds_fence();
     {   // frame header: assembled by lane 0 in LDS, emitted one byte per lane
         LDS uint8_t *hb = (LDS uint8_t *)misc;

@@ -9,6 +9,7 @@
 // Four waves per block share the staged samples, so a CU holds four times the wavefronts for the same LDS, and the
 // per-block latency drops to that of one candidate.
 #pragma once
+#define FG_CRCT __attribute__((address_space(3)))
 #include "flac_enc_fast_impl.h"
 
 namespace {
