@@ -415,6 +415,7 @@ typedef struct {
     uint32_t min_partition_order, max_partition_order;
     uint32_t apod_parts;          /* 0 = tukey(0.5); n >= 2 = subdivide_tukey(n) */
     uint32_t streamable_subset;
+    uint32_t limit_min_bitrate;   /* FLAC__stream_encoder_set_limit_min_bitrate (stream_encoder.h): no frame of CONSTANT subframes only */
 } flacgpu_settings;
 
 /* Returns a FLAC__StreamEncoderInitStatus value (0 = OK). */

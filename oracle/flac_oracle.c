@@ -557,8 +557,11 @@ static uint32_t get_wasted_bits(int32_t *s, uint32_t n)
     return shift;
 }
 
+/* forbid_constant: limit_min_bitrate asks for at least one bit per sample, so a frame may not consist of CONSTANT
+ * subframes only: the last channel of the frame (R after a constant L, S after a constant M) is evaluated with the
+ * constant candidate disabled (observed on the reference binary: a silent stereo block becomes CONSTANT + FIXED order 0). */
 static void process_subframe(const flo_config *c, enc_ws *w, uint32_t ch, uint32_t n, uint32_t min_po,
-                             uint32_t max_po, flo_subframe_info *inf)
+                             uint32_t max_po, flo_subframe_info *inf, int forbid_constant)
 {
     const int32_t *x = w->sig[ch];
     const uint32_t sbps = w->sbps[ch], wasted = w->wasted[ch];
@@ -584,6 +587,7 @@ static void process_subframe(const flo_config *c, enc_ws *w, uint32_t ch, uint32
             constant = 1;
             for (uint32_t i = 1; i < n; i++) if (x[0] != x[i]) { constant = 0; break; }
         }
+        if (forbid_constant) constant = 0;
         if (constant) {
             S[!best].type = 0;
             cand = 8 + wasted + sbps;
@@ -850,10 +854,24 @@ size_t flo_encode_frame(const flo_config *c, const int32_t *in, uint32_t n, uint
             if (ws > c->bps + 1) ws = c->bps + 1;
             w->wasted[2 + k] = ws; w->sbps[2 + k] = c->bps - ws + k;
         }
-    if (do_indep)
-        for (uint32_t ch = 0; ch < C; ch++) process_subframe(c, w, ch, n, min_po, max_po, info ? &info->cand[ch] : NULL);
-    if (do_ms)
-        for (uint32_t k = 0; k < 2; k++) process_subframe(c, w, 2 + k, n, min_po, max_po, info ? &info->cand[2 + k] : NULL);
+    /* limit_min_bitrate (observed on the reference binary, incl. loose mid-side frames): the last independent channel is
+     * evaluated with CONSTANT disabled when every earlier one chose CONSTANT; once that happened, mid and side of the same
+     * frame are evaluated with CONSTANT disabled as well.  When only mid/side are evaluated (loose mid-side follower
+     * frames) nothing is disabled: such frames may still consist of two CONSTANT subframes. */
+    int forced = 0;
+    if (do_indep) {
+        int allc = 1;
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const int forbid = c->limit_min_bitrate && ch + 1 == C && allc;
+            if (forbid) forced = 1;
+            process_subframe(c, w, ch, n, min_po, max_po, info ? &info->cand[ch] : NULL, forbid);
+            if (w->ws[ch][w->best[ch]].type != 0) allc = 0;
+        }
+    }
+    if (do_ms) {
+        for (uint32_t k = 0; k < 2; k++)
+            process_subframe(c, w, 2 + k, n, min_po, max_po, info ? &info->cand[2 + k] : NULL, do_indep ? forced : 0);
+    }
 
     uint32_t first = 0, second = 1;
     if (c->do_mid_side) {

@@ -43,6 +43,7 @@ typedef struct {
     uint32_t apod_parts;
     uint32_t streamable_subset;
     uint32_t do_md5;
+    uint32_t limit_min_bitrate;   /* FLAC__stream_encoder_set_limit_min_bitrate: no frame of constant subframes only */
 } flo_config;
 
 /* One analysed candidate subframe (L, R, M or S). */

@@ -51,6 +51,20 @@ def main():
         if len(stream) < 70000:
             small[name] = np.frombuffer(stream, np.uint8)
         print('%-24s %8d bytes %4d cbs  %s' % (name, len(stream), len(cbs), rec['sha256'][:16]))
+    # limit_min_bitrate cases (tests/cases.py LIMIT_CASES)
+    lim = {}
+    for name, (spec, sr, level, bs) in sorted(cases.LIMIT_CASES.items()):
+        pcm, bps = cases.make_pcm(spec)
+        arr = cases.as_int_array(pcm, bps)
+        cbs, info = R.encode(arr, sr, bps=bps, level=level, blocksize=bs, extra=[('set_limit_min_bitrate', 1)])
+        stream = b''.join(c[0] for c in cbs)
+        _pcm, frames, st = R.decode(stream)
+        assert not st['errors'] and (_pcm == np.asarray(pcm).reshape(_pcm.shape)).all(), name
+        lim[name] = {'total_bytes': len(stream), 'sha256': hashlib.sha256(stream).hexdigest(),
+                     'frame_bytes': [len(c[0]) for c in cbs[3:]], 'pcm_hash': synth.pcm_hash(arr)}
+        print('%-24s %8d bytes  %s' % (name, len(stream), lim[name]['sha256'][:16]))
+    with open(os.path.join(cases.GOLDEN, 'limit_vectors.json'), 'w') as f:
+        json.dump(lim, f, indent=0, sort_keys=True, separators=(',', ':'))
     gd = cases.GOLDEN
     with open(os.path.join(gd, 'encode_vectors.json'), 'w') as f:
         json.dump(out, f, indent=0, sort_keys=True, separators=(',', ':'))

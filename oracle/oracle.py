@@ -21,7 +21,7 @@ class Config(C.Structure):
                 ('max_lpc_order', C.c_uint32), ('qlp_coeff_precision', C.c_uint32),
                 ('min_partition_order', C.c_uint32), ('max_partition_order', C.c_uint32),
                 ('apod_type', C.c_uint32), ('apod_p', C.c_float), ('apod_parts', C.c_uint32),
-                ('streamable_subset', C.c_uint32), ('do_md5', C.c_uint32)]
+                ('streamable_subset', C.c_uint32), ('do_md5', C.c_uint32), ('limit_min_bitrate', C.c_uint32)]
 
 
 class SubframeInfo(C.Structure):

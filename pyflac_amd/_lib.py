@@ -48,7 +48,7 @@ class Settings(C.Structure):
                 ('blocksize', C.c_uint32), ('do_mid_side', C.c_uint32), ('loose_mid_side', C.c_uint32),
                 ('max_lpc_order', C.c_uint32), ('qlp_coeff_precision', C.c_uint32),
                 ('min_partition_order', C.c_uint32), ('max_partition_order', C.c_uint32),
-                ('apod_parts', C.c_uint32), ('streamable_subset', C.c_uint32)]
+                ('apod_parts', C.c_uint32), ('streamable_subset', C.c_uint32), ('limit_min_bitrate', C.c_uint32)]
 
 
 class StreamDesc(C.Structure):

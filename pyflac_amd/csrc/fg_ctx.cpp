@@ -222,6 +222,7 @@ void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, boo
     P->max_lpc_order = s.max_lpc_order; P->qlp_precision = s.qlp_coeff_precision;
     P->min_po = s.min_partition_order; P->max_po = s.max_partition_order;
     P->apod_parts = s.apod_parts;
+    P->limit_min_bitrate = s.limit_min_bitrate ? 1 : 0;
     P->rice_limit = s.bits_per_sample > 16 ? 31 : 15;
     P->slot_bytes = fg_slot_bytes(s, max_n);
     P->sig_stride = (max_n + 7) & ~7u;

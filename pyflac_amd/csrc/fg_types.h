@@ -29,6 +29,7 @@ struct FgEncParams {
     uint32_t pcm_i16;      // input is interleaved int16 instead of int32
     uint32_t debug;
     uint32_t lds_dbuf_bytes;
+    uint32_t limit_min_bitrate;   // a frame may not consist of CONSTANT subframes only (see the kernels' baseline stage)
 };
 
 struct FgBlockDesc {

@@ -83,7 +83,7 @@ int fg_launch_encode_fast(const void *d_pcm, const FgBlockDesc *d_descs, const f
     // FLACGPU_WAVE=1: the variant with one wavefront per predictor candidate (flac_enc_wave_impl.h).  It has the lower
     // latency for a handful of blocks but repeats the serial stages (autocorrelation chain, Levinson-Durbin, Rice search)
     // in every wave, so the one-block-per-wavefront kernel wins on throughput (1.23 ms against 1.42 ms for 7032 blocks)
-    if (nch == 2 && getenv("FLACGPU_WAVE") && atoi(getenv("FLACGPU_WAVE")) == 1) {
+    if (nch == 2 && !P->limit_min_bitrate && getenv("FLACGPU_WAVE") && atoi(getenv("FLACGPU_WAVE")) == 1) {
         const size_t wl = fg_wave_lds_bytes(P, nch, ms, maxo);
         if (wl <= 160 * 1024) {
 #define FG_CALLW(name) return fg_wave_launch_##name(d_pcm, d_descs, d_windows, P, nblocks, d_slots, d_results, d_dbg, d_crctab, wl, acc64, stream)

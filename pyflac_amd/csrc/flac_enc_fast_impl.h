@@ -381,6 +381,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     uint32_t d_type[NC], d_order[NC], d_prec[NC], d_porder[NC], d_method[NC], d_k[NC];
     int d_shift[NC];
     uint32_t fixed_mask = 0, lpc_mask = 0;
+    bool lmb_forced = false;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t sb = sbp[c];
@@ -416,6 +417,22 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
         if (mydbg && lane == 0) {
             for (int kk = 0; kk < 5; kk++) mydbg->cand[c].fixed_tot[kk] = tot[c][kk];
             mydbg->cand[c].fixed_guess = g;
+        }
+        // limit_min_bitrate (libFLAC 1.4.3 as observed, oracle/flac_oracle.c): the last independent channel is evaluated with
+        // CONSTANT disabled when every earlier one chose CONSTANT; mid and side of the same frame then are, too -- unless
+        // only mid/side are evaluated at all (loose mid-side follower frames, forced_ca == 3)
+        if (P.limit_min_bitrate) {
+            bool forbid = false;
+            if (c < NCH) {
+                if (c == NCH - 1 && d.forced_ca != 3) {
+                    forbid = true;
+#pragma unroll
+                    for (int cc = 0; cc < NCH - 1; cc++) if (d_type[cc] != 0) forbid = false;
+                    lmb_forced = forbid;
+                }
+            }
+            else forbid = lmb_forced;
+            if (forbid) constant = false;
         }
         if (constant) {
             const uint32_t cb = 8 + sb;

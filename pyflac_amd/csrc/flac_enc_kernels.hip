@@ -119,6 +119,8 @@ struct Enc {
     int lane;
     uint32_t n;
     int mode;   // 0 independent channels, 1 L/R/M/S
+    bool lmb_forced;          // limit_min_bitrate: CONSTANT was disabled for the last independent channel of this frame
+    uint32_t lmb_forced_ca;   // the block's forced channel assignment (3: only mid/side count)
     int wide;   // 64-bit arithmetic for M/S derivation
     int ncand;
     uint32_t err;
@@ -652,7 +654,19 @@ struct Enc {
                     for (int k = 0; k < 5; k++) dbg->cand[c].fixed_tot[k] = tot[k];
                     dbg->cand[c].fixed_guess = guess[c];
                 }
-                if (rb[1] == 0.0f && is_constant(c, w)) {
+                // limit_min_bitrate: see flac_enc_fast_impl.h / oracle process_subframe(forbid_constant)
+                bool forbid = false;
+                if (P.limit_min_bitrate) {
+                    if (mode == 1) {
+                        if (c == 1 && lmb_forced_ca != 3) { forbid = decs[dbase + 0].type == 0; lmb_forced = forbid; }
+                        else if (c >= 2) forbid = lmb_forced;
+                    }
+                    else if (dbase + (uint32_t)c + 1 == P.channels) {       // decs[] is indexed by the channel here
+                        forbid = true;
+                        for (uint32_t cc = 0; cc < dbase + (uint32_t)c; cc++) if (decs[cc].type != 0) forbid = false;
+                    }
+                }
+                if (!forbid && rb[1] == 0.0f && is_constant(c, w)) {
                     is_const[c] = 1;
                     uint32_t cb = 8 + w + sb;
                     if (cb < best[c]) { best[c] = cb; if (lane == 0) { decs[dbase + c].type = 0; decs[dbase + c].bits = cb; } }
@@ -1043,6 +1057,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
     e.lane = threadIdx.x;
     e.n = d.n;
     e.err = 0;
+    e.lmb_forced = false; e.lmb_forced_ca = d.forced_ca;
     e.window = windows + d.win_off;
     // ---- LDS carve (all offsets multiples of 16)
     size_t off = 0;

@@ -240,7 +240,7 @@ FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
     s.channels = e->channels; s.bits_per_sample = e->bps; s.sample_rate = e->sample_rate; s.blocksize = e->blocksize;
     s.do_mid_side = e->do_mid_side; s.loose_mid_side = e->loose_mid_side; s.max_lpc_order = e->max_lpc_order;
     s.qlp_coeff_precision = e->qlp_precision; s.min_partition_order = e->min_po; s.max_partition_order = e->max_po;
-    s.apod_parts = e->apod_parts; s.streamable_subset = e->streamable_subset;
+    s.apod_parts = e->apod_parts; s.streamable_subset = e->streamable_subset; s.limit_min_bitrate = e->limit_min_bitrate ? 1 : 0;
     const int rc = fg_resolve_settings(&s);
     if (rc != 0) return (FLAC__StreamEncoderInitStatus)rc;
     // settings libFLAC accepts but this GPU core does not implement are refused loudly (out of scope)

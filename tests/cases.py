@@ -67,6 +67,18 @@ def make_pcm(spec):
         r = _rng(11)
         a = r.integers(-20000, 20000, (spec['n'], 1))
         return np.concatenate([a, a * spec.get('sign', 1)], axis=1), 16
+    if k == 'constmix':
+        # per channel: 'z' zeros, 'c<value>' constant, 's' sine + noise, 'm' constant in even 4096-blocks only
+        n, r = spec['n'], _rng(spec.get('seed', 21))
+        cols = []
+        for i, what in enumerate(spec['chans']):
+            t = np.arange(n)
+            if what == 'z': x = np.zeros(n)
+            elif what[0] == 'c': x = np.full(n, int(what[1:]))
+            elif what == 's': x = 2000 * np.sin(t * 0.03 * (i + 1)) + r.normal(0, 20, n)
+            else: x = np.where((t // 4096) % 2 == 0, 77, 2000 * np.sin(t * 0.01))
+            cols.append(np.round(x))
+        return np.stack(cols, 1).astype(np.int64), 16
     if k == 'walk32':
         r = _rng(13)
         x = (np.cumsum(r.integers(-2 ** 27, 2 ** 27, spec['n'])) % 2 ** 31) | 1
@@ -118,3 +130,27 @@ ENCODE_CASES = {
 for _lv in range(9):
     ENCODE_CASES['hard16_l%d' % _lv] = ({'kind': 'hard16', 'seconds': 1.0}, 48000, _lv, 0, True)
     ENCODE_CASES['cfg2_1s_l%d' % _lv] = ({'kind': 'cfg2', 'seconds': 1.0, 'seed': 42}, 48000, _lv, 0, True)
+
+
+# FLAC__stream_encoder_set_limit_min_bitrate(true): name -> (pcm spec, sample rate, level, blocksize).
+# Goldens in tests/golden/limit_vectors.json (reference binary, oracle/gen_golden.py).
+_N = 4096 * 5 + 300
+LIMIT_CASES = {
+    'lmb_zeros_mono_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['z']}, 48000, 5, 4096),
+    'lmb_const_mono_l0': ({'kind': 'constmix', 'n': _N, 'chans': ['c-911']}, 48000, 0, 4096),
+    'lmb_mixed_mono_l8': ({'kind': 'constmix', 'n': _N, 'chans': ['m']}, 48000, 8, 4096),
+    'lmb_zeros_st_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['z', 'z']}, 48000, 5, 4096),
+    'lmb_equal_st_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['c123', 'c123']}, 48000, 5, 4096),
+    'lmb_equal_st_l1': ({'kind': 'constmix', 'n': _N, 'chans': ['c123', 'c123']}, 48000, 1, 4096),
+    'lmb_equal_st_l0': ({'kind': 'constmix', 'n': _N, 'chans': ['c123', 'c123']}, 48000, 0, 4096),
+    'lmb_diff_st_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['c123', 'c50']}, 48000, 5, 4096),
+    'lmb_diff_st_l4': ({'kind': 'constmix', 'n': _N, 'chans': ['c7', 'c9']}, 48000, 4, 4096),
+    'lmb_const_sine_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['c5', 's']}, 48000, 5, 4096),
+    'lmb_sine_const_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['s', 'z']}, 48000, 5, 4096),
+    'lmb_mixed_st_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['m', 'c77']}, 48000, 5, 4096),
+    'lmb_mixed_st_l8': ({'kind': 'constmix', 'n': _N, 'chans': ['m', 'm']}, 48000, 8, 4096),
+    'lmb_ch3_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['c1', 'c2', 'c3']}, 48000, 5, 4096),
+    'lmb_ch3_mid_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['c1', 's', 'c3']}, 48000, 5, 4096),
+    'lmb_ch6_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['z', 'c4', 'z', 'c-4', 'z', 'm']}, 48000, 5, 4096),
+    'lmb_bs1152_st_l2': ({'kind': 'constmix', 'n': 1152 * 7 + 5, 'chans': ['c-3', 'c-3']}, 44100, 2, 1152),
+}

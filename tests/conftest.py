@@ -21,6 +21,15 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def limit_golden():
+    """Reference output with FLAC__stream_encoder_set_limit_min_bitrate(true) (tests/cases.py LIMIT_CASES)."""
+    import json
+    from tests import cases
+    with open(os.path.join(cases.GOLDEN, 'limit_vectors.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
 def small_streams():
     import numpy as np
     from tests import cases

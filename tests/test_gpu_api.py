@@ -99,6 +99,19 @@ class TestStreamEncoder:
         assert [[c[1], c[2], c[3]] for c in calls] == g['callbacks']
         assert b''.join(c[0] for c in calls) == small_streams['cfg1_passthrough']
 
+    def test_limit_min_bitrate_through_the_class(self, limit_golden):
+        """StreamEncoder(limit_min_bitrate=True) (pyflac/encoder.py:223-231 property) reaches the kernels."""
+        import hashlib
+        import pyflac_amd
+        spec, sr, level, bs = cases.LIMIT_CASES['lmb_equal_st_l5']
+        pcm, bps = cases.make_pcm(spec)
+        chunks = []
+        enc = pyflac_amd.StreamEncoder(sample_rate=sr, write_callback=lambda b, n, s_, f: chunks.append(bytes(b)),
+                                       compression_level=level, blocksize=bs, limit_min_bitrate=True)
+        enc.process(cases.as_int_array(pcm, bps).astype(np.int16))
+        enc.finish()
+        assert hashlib.sha256(b''.join(chunks)).hexdigest() == limit_golden['lmb_equal_st_l5']['sha256']
+
     def test_look_ahead_of_one_sample(self):
         """libFLAC emits a frame only once blocksize+1 samples are buffered."""
         enc = self._mk(blocksize=1024)

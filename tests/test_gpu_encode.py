@@ -47,6 +47,39 @@ def test_batch_encode_matches_golden(ctx, golden, name):
     assert [int(x) for x in np.diff(offs)] == [c[0] for c in g['callbacks'][3:]]
 
 
+@pytest.mark.parametrize('name', sorted(cases.LIMIT_CASES))
+def test_limit_min_bitrate_matches_golden(ctx, limit_golden, name):
+    """limit_min_bitrate through the batch entry point: byte-identical to the reference binary."""
+    import torch
+    from pyflac_amd import batch
+    from pyflac_amd.encoder import stream_header_bytes
+    spec, sr, level, bs = cases.LIMIT_CASES[name]
+    pcm, bps = cases.make_pcm(spec)
+    arr = cases.as_int_array(pcm, bps)
+    s = batch.settings(level, arr.shape[1], bps, sr, bs, True)
+    s.limit_min_bitrate = 1
+    out, offs, st = ctx.encode(s, torch.from_numpy(np.ascontiguousarray(arr).astype(np.int32)).cuda())
+    stream = stream_header_bytes(s) + out[:st.total_bytes].cpu().numpy().tobytes()
+    assert [int(x) for x in np.diff(offs.cpu().numpy())] == limit_golden[name]['frame_bytes']
+    assert hashlib.sha256(stream).hexdigest() == limit_golden[name]['sha256']
+
+
+def test_limit_min_bitrate_generic_kernel(ctx, limit_golden, monkeypatch):
+    import torch
+    from pyflac_amd import batch
+    from pyflac_amd.encoder import stream_header_bytes
+    monkeypatch.setenv('FLACGPU_NO_FAST', '1')
+    for name in ('lmb_equal_st_l5', 'lmb_equal_st_l1', 'lmb_zeros_mono_l5', 'lmb_mixed_st_l8'):
+        spec, sr, level, bs = cases.LIMIT_CASES[name]
+        pcm, bps = cases.make_pcm(spec)
+        arr = cases.as_int_array(pcm, bps)
+        s = batch.settings(level, arr.shape[1], bps, sr, bs, True)
+        s.limit_min_bitrate = 1
+        out, offs, st = ctx.encode(s, torch.from_numpy(np.ascontiguousarray(arr).astype(np.int32)).cuda())
+        stream = stream_header_bytes(s) + out[:st.total_bytes].cpu().numpy().tobytes()
+        assert hashlib.sha256(stream).hexdigest() == limit_golden[name]['sha256'], name
+
+
 def test_int16_ingest_equals_int32(ctx):
     pcm, bps = cases.make_pcm({'kind': 'cfg2', 'seconds': 1.0, 'seed': 5})
     a, _, _ = _gpu_stream(ctx, pcm, 48000, 16, 5, 4096, True, i16=False)

@@ -32,6 +32,23 @@ def test_encode_matches_golden(name, golden):
     assert hashlib.sha256(filed).hexdigest() == g['file_sha256']
 
 
+@pytest.mark.parametrize('name', sorted(cases.LIMIT_CASES))
+def test_limit_min_bitrate_matches_golden(name, limit_golden):
+    """limit_min_bitrate: no frame of CONSTANT subframes only (behaviour recovered from the reference binary, including
+    the loose mid-side frames; oracle/flac_oracle.c flo_encode_frame)."""
+    spec, sr, level, bs = cases.LIMIT_CASES[name]
+    g = limit_golden[name]
+    pcm, bps = cases.make_pcm(spec)
+    arr = cases.as_int_array(pcm, bps)
+    assert synth.pcm_hash(arr) == g['pcm_hash']
+    cfg, rc = O.config(level, arr.shape[1], bps, sr, bs, True)
+    assert rc == 0
+    cfg.limit_min_bitrate = 1
+    stream, sizes = O.encode_stream(cfg, arr)
+    assert [int(x) for x in sizes] == g['frame_bytes']
+    assert hashlib.sha256(stream).hexdigest() == g['sha256']
+
+
 def test_frame_decisions_match_golden(golden):
     name = 'cfg2_2s_l5'
     spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
