@@ -140,6 +140,8 @@ def lib():
     L.FLAC__stream_encoder_process_interleaved.argtypes = [vp, vp, C.c_uint32]
     L.FLAC__stream_encoder_process_interleaved.restype = C.c_int
     L.FLAC__stream_encoder_finish.argtypes = [vp]
+    L.FLAC__stream_encoder_get_verify_decoder_error_stats.argtypes = [vp] + [vp] * 6
+    L.FLAC__stream_encoder_get_verify_decoder_error_stats.restype = None
     L.FLAC__stream_encoder_finish.restype = C.c_int
     L.FLAC__stream_decoder_new.restype = vp
     L.FLAC__stream_decoder_delete.argtypes = [vp]

@@ -33,6 +33,7 @@ int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, c
 int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                           int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
                           hipStream_t stream);
+int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream);
 int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
                          const uint16_t *d_crctab, hipStream_t stream);
 int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels,

@@ -414,7 +414,28 @@ __global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *to
     for (uint32_t b = b0; b < b1; b++) { frames[b].out_off = run; run += frames[b].n; }
 }
 
+// First index at which two int32 arrays differ (0xFFFFFFFFFFFFFFFF if none): the encoder's verify pass compares what the
+// decoder made of the fresh frames with the PCM that went in.
+__global__ void __launch_bounds__(256)
+fg_compare_kernel(const int32_t *a, const int32_t *b, u64 n, unsigned long long *first)
+{
+    u64 best = ~(u64)0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        if (a[i] != b[i]) { best = i; break; }
+    if (best != ~(u64)0) atomicMin(first, (unsigned long long)best);
+}
+
 }  // namespace
+
+extern "C" int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream)
+{
+    if (hipMemsetAsync(d_first, 0xFF, 8, stream) != hipSuccess) return -1;
+    if (n == 0) return 0;
+    uint64_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(fg_compare_kernel, dim3((uint32_t)nb), dim3(256), 0, stream, d_a, d_b, (u64)n, d_first);
+    return (int)hipGetLastError();
+}
 
 extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
                                      uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,

@@ -177,11 +177,15 @@ struct EncImpl {
     std::vector<uint8_t> hbuf;      // host copy of encoded frames
     std::vector<uint64_t> hoffs;
     DevBuf d_pcm, d_out, d_offs;    // per-encoder device staging
+    DevBuf d_verify;                // verify: decoded PCM + the first-mismatch word
+    // verify: where the round trip differed (FLAC__stream_encoder_get_verify_decoder_error_stats)
+    uint64_t v_abs_sample; uint32_t v_frame, v_channel, v_sample; int32_t v_expected, v_got;
 };
 
 void set_defaults(EncImpl *e)
 {
     e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1; e->limit_min_bitrate = 0;
+    e->v_abs_sample = 0; e->v_frame = 0; e->v_channel = 0; e->v_sample = 0; e->v_expected = 0; e->v_got = 0;
     e->channels = 2; e->bps = 16; e->sample_rate = 44100; e->blocksize = 0;
     e->total_estimate = 0;
     e->prec_search = 0; e->escape_coding = 0; e->exhaustive = 0; e->rice_dist = 0; e->qlp_precision = 0;
@@ -315,6 +319,37 @@ bool encode_pending(EncImpl *e, bool flush_all)
             ok = false; e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR;
         }
     }
+    // verify (stream_encoder.h: FLAC__stream_encoder_set_verify): decode the fresh frames on the GPU and compare with the
+    // PCM that went in, before anything is handed to the write callback
+    if (ok && e->verify && st.nblocks) {
+        flacgpu_decode_stats dst;
+        std::vector<uint32_t> fstat((size_t)st.nblocks * 2);
+        const uint64_t nvals = take * C;
+        if (!e->d_verify.ensure((size_t)nvals * 4 + 64)) { ok = false; e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; }
+        else if (flacgpu_decode_frames(c, e->d_out.p, st.total_bytes, (const uint64_t *)e->hoffs.data(), st.nblocks, C, e->s.bits_per_sample,
+                                       e->d_verify.p, take, fstat.data(), &dst) != 0 || dst.error_frames != 0 || dst.total_samples != take) {
+            ok = false; e->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR;
+        }
+        else {
+            unsigned long long *d_first = (unsigned long long *)((char *)e->d_verify.p + (((size_t)nvals * 4 + 15) & ~(size_t)15));
+            unsigned long long first = 0;
+            // FLACGPU_VERIFY_SELFTEST: disturb the reference copy so that the mismatch path can be exercised by a test
+            if (getenv("FLACGPU_VERIFY_SELFTEST")) { const int32_t poison = e->pending[0] ^ 0x55; (void)hipMemcpy(e->d_pcm.p, &poison, 4, hipMemcpyHostToDevice); }
+            if (fg_launch_compare((const int32_t *)e->d_verify.p, (const int32_t *)e->d_pcm.p, nvals, d_first, c->stream) != 0 ||
+                hipMemcpyAsync(&first, d_first, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { ok = false; e->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR; }
+            else if (first != ~0ull) {
+                int32_t got = 0, want = 0;
+                (void)hipMemcpy(&got, (const int32_t *)e->d_verify.p + first, 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&want, (const int32_t *)e->d_pcm.p + first, 4, hipMemcpyDeviceToHost);
+                const uint64_t fr = first / C;
+                e->v_abs_sample = e->samples_done + fr; e->v_frame = e->frame_number + (uint32_t)(fr / bs);
+                e->v_channel = (uint32_t)(first % C); e->v_sample = (uint32_t)(fr % bs);
+                e->v_expected = want; e->v_got = got;
+                ok = false; e->state = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA;
+            }
+        }
+    }
     if (md5t.joinable()) md5t.join();
     if (!ok) return false;
     uint64_t pos = 0;
@@ -359,7 +394,7 @@ void FLAC__stream_encoder_delete(FLAC__StreamEncoder *enc)
         if (e->file && e->own_file) fclose(e->file);
     }
     if (e->ctx) (void)hipSetDevice(e->ctx->device);
-    e->d_pcm.release(); e->d_out.release(); e->d_offs.release();
+    e->d_pcm.release(); e->d_out.release(); e->d_offs.release(); e->d_verify.release();
     delete e;
 }
 
@@ -436,15 +471,16 @@ const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEnc
 {
     return FLAC__StreamEncoderStateString[impl(enc)->state];
 }
-void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *, FLAC__uint64 *absolute_sample, uint32_t *frame_number,
+void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *enc, FLAC__uint64 *absolute_sample, uint32_t *frame_number,
                                                          uint32_t *channel, uint32_t *sample, FLAC__int32 *expected, FLAC__int32 *got)
 {
-    if (absolute_sample) *absolute_sample = 0;
-    if (frame_number) *frame_number = 0;
-    if (channel) *channel = 0;
-    if (sample) *sample = 0;
-    if (expected) *expected = 0;
-    if (got) *got = 0;
+    const EncImpl *e = impl(enc);
+    if (absolute_sample) *absolute_sample = e->v_abs_sample;
+    if (frame_number) *frame_number = e->v_frame;
+    if (channel) *channel = e->v_channel;
+    if (sample) *sample = e->v_sample;
+    if (expected) *expected = e->v_expected;
+    if (got) *got = e->v_got;
 }
 #define GETTER(name, field, type) \
     type FLAC__stream_encoder_get_##name(const FLAC__StreamEncoder *enc) { return (type)impl(enc)->field; }

@@ -112,6 +112,28 @@ class TestStreamEncoder:
         enc.finish()
         assert hashlib.sha256(b''.join(chunks)).hexdigest() == limit_golden['lmb_equal_st_l5']['sha256']
 
+    def test_verify_runs_and_reports_a_mismatch(self, monkeypatch):
+        """verify=True decodes every frame on the GPU and compares it with the input (libFLAC's verify mode); with the
+        self-test hook disturbing the comparison copy the encoder must stop in VERIFY_MISMATCH_IN_AUDIO_DATA."""
+        import pyflac_amd
+        from pyflac_amd import _lib
+        import ctypes as C
+        pcm = cases.make_pcm({'kind': 'cfg2', 'seconds': 0.5, 'seed': 2})[0]
+        enc = self._mk(sample_rate=48000, blocksize=4096, verify=True)
+        enc.process(pcm)
+        assert enc.finish() and len(self.calls) > 3
+        monkeypatch.setenv('FLACGPU_VERIFY_SELFTEST', '1')
+        enc = self._mk(sample_rate=48000, blocksize=4096, verify=True)
+        with pytest.raises(pyflac_amd.EncoderProcessException, match='VERIFY_MISMATCH_IN_AUDIO_DATA'):
+            enc.process(pcm)
+            enc.finish()
+        a, fr, ch, sm = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        ex, got = C.c_int32(), C.c_int32()
+        _lib.lib().FLAC__stream_encoder_get_verify_decoder_error_stats(enc._encoder, C.byref(a), C.byref(fr), C.byref(ch),
+                                                                      C.byref(sm), C.byref(ex), C.byref(got))
+        assert (a.value, fr.value, ch.value, sm.value) == (0, 0, 0, 0)
+        assert got.value == int(pcm[0, 0]) and ex.value == (int(pcm[0, 0]) ^ 0x55)
+
     def test_look_ahead_of_one_sample(self):
         """libFLAC emits a frame only once blocksize+1 samples are buffered."""
         enc = self._mk(blocksize=1024)
