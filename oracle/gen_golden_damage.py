@@ -1,0 +1,41 @@
+"""Generate tests/golden/damage_vectors.json: how the reference's libFLAC 1.4.3 binary decodes damaged streams.
+
+Run in the build container only (needs /root/reference):  python -m oracle.gen_golden_damage
+Each case of tests/cases.py DAMAGE_CASES names a committed stream and a list of edits (byte flips, deletions,
+insertions, truncation).  The vector records what pyFLAC's callbacks (pyflac/decoder.py:257-313) would see from the
+bundled library for the edited stream: the error-callback status sequence and, per delivered frame, its sample number,
+block size and a hash of the samples.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import libflac_ref as R  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def main():
+    out = {}
+    for name in sorted(cases.DAMAGE_CASES):
+        data = cases.damaged_stream(name)
+        pcm, frames, st = R.decode(data)
+        pos = 0
+        fr = []
+        for f in frames:
+            blk = pcm[pos:pos + f['blocksize']]
+            pos += f['blocksize']
+            fr.append([int(f['sample_number']), int(f['blocksize']),
+                       hashlib.sha256(np.ascontiguousarray(blk, np.int32).tobytes()).hexdigest()[:16]])
+        out[name] = {'errors': [int(e) for e in st['errors']], 'frames': fr, 'state': int(st['state'])}
+        print('%-28s frames %3d errors %s' % (name, len(fr), out[name]['errors']))
+    with open(os.path.join(cases.GOLDEN, 'damage_vectors.json'), 'w') as f:
+        json.dump(out, f, indent=0, sort_keys=True, separators=(',', ':'))
+
+
+if __name__ == '__main__':
+    main()

@@ -88,6 +88,8 @@ struct FgDecSub {
 };
 
 struct FgDecResult {
-    uint32_t err;          // 0 ok, 1 malformed, 2 crc16 mismatch
+    uint32_t err;          // 0 ok, 1 malformed (bad header / reserved or inconsistent fields), 2 crc16 mismatch,
+                           // 4 contents parse but do not end at the frame boundary (damaged residual or truncation),
+                           // 5 contents parse but the padding bits before the CRC-16 are not zero
     uint32_t crc;
 };

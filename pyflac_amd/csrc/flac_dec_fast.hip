@@ -457,14 +457,16 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                 }
             }
             wave_lds_fence();
-            if (act && br.pos() > end_bits) { err = 1; alive = false; rn = 0; }
+            if (act && br.pos() > end_bits) { err = 4; alive = false; rn = 0; }
             FG_TICK(4);
         }
     }
     if (accepted) {
         if (!err) {
             const uint32_t endb = (br.pos() + 7) & ~7u;
-            if (endb != end_bits) err = 1;
+            const uint32_t padb = endb - br.pos();
+            if (endb != end_bits) err = 4;
+            if (padb && (br.peek() >> (32 - padb)) != 0) err = 5;      // libFLAC read_zero_padding_: lost sync
         }
         results[f].err = err;
     }

@@ -251,16 +251,18 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                         ring[(i & 31) * 64 + lane] = v;
                     }
                     dst[i] = v;
-                    if (br.over) { err = 1; break; }
+                    if (br.over) { err = 4; break; }
                 }
             }
             else { err = 1; break; }
-            if (br.over) err = 1;
+            if (br.over) err = 4;
         }
         if (!err) {
             // zero padding to the byte boundary must end exactly at the CRC-16
             const uint32_t endbits = (br.pos + 7) & ~7u;
-            if (endbits != (fr.bytes - 2) * 8) err = 1;
+            const uint32_t padb = endbits - br.pos;
+            if (endbits != (fr.bytes - 2) * 8) err = 4;
+            if (padb && (br.peek32() >> (32 - padb)) != 0) err = 5;     // libFLAC read_zero_padding_: lost sync
         }
     }
     else if (valid) err = 1;
@@ -300,7 +302,7 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
         for (uint32_t b = 0; b < tail; b++) crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ fp[W * 4 + b]) & 0xFF];
         const uint32_t stored = ((uint32_t)fp[nbytes] << 8) | fp[nbytes + 1];
         const bool crc_ok = (crc == stored);
-        uint32_t status = ferr ? 1u : (crc_ok ? 0u : 2u);
+        uint32_t status = ferr ? ferr : (crc_ok ? 0u : 2u);
         const uint32_t fidx = __shfl(f, L);
         if (lane == 0) { results_all[fidx].err = status; results_all[fidx].crc = crc; }
         // undo wasted bits and channel coding; bad frames are delivered as silence

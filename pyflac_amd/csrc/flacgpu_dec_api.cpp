@@ -126,10 +126,21 @@ struct Indexer {
     bool in_frame = false;
     uint64_t scan = 0;            // next byte to examine
     uint16_t crc = 0;             // running CRC-16 over [frame_start, scan)
+    uint64_t max_len = 0;         // longest a frame with the current header can be (anything longer is damaged)
+    uint64_t cur_number = 0;      // frame / sample number of the frame being delimited
+    uint32_t cur_n = 0, cur_variable = 0;
+    bool tail_checked = false;    // the resync search already ran over the final, damaged frame
     std::vector<uint64_t> bounds; // accepted frame boundaries: frames are [bounds[i], bounds[i+1])
     std::vector<uint32_t> errors; // FLAC__StreamDecoderErrorStatus to report, in stream order
     std::vector<uint64_t> error_pos;
 
+    void open_frame(const HostHeader &h)
+    {
+        // verbatim subframes (one extra bit for a side channel) + subframe headers with a long wasted-bits unary + footer
+        const uint64_t bps = h.bps ? h.bps : 32;
+        max_len = h.hdr_bytes + (uint64_t)h.channels * (((uint64_t)h.n * (bps + 1) + 7) / 8 + 8) + 2 + 16;
+        cur_number = h.number; cur_n = h.n; cur_variable = h.variable;
+    }
     // Examine data[0..len).  `final` = no more data will arrive.
     void feed(const uint8_t *d, uint64_t len, bool final, const FLAC__StreamMetadata_StreamInfo *si)
     {
@@ -144,13 +155,19 @@ struct Indexer {
             tab_ok = true;
         }
         HostHeader h;
-        while (scan < len) {
+        for (;;) {
+            // A frame longer than its header allows, or one that reaches the end of the data without a clean CRC-16,
+            // is damaged: resynchronise (below).
+            const bool at_end = scan >= len;
+            const bool want_resync = in_frame && ((scan - frame_start > max_len) || (at_end && final && crc != 0 && !tail_checked));
+            if (at_end && !want_resync) break;
             if (!in_frame) {
                 // search for a frame start
                 if (d[scan] == 0xFF && scan + 1 < len && (d[scan + 1] & 0xFE) == 0xF8) {
                     if (len - scan < 16 && !final) return;             // need the whole header
                     if (parse_header(d + scan, len - scan, si, &h)) {
                         in_frame = true; frame_start = scan; crc = 0;
+                        open_frame(h);
                         if (bounds.empty() || bounds.back() != scan) {
                             bounds.push_back(scan);
                         }
@@ -170,18 +187,60 @@ struct Indexer {
                 continue;
             }
             // inside a frame: a boundary candidate is a position where the running CRC is zero and a valid header follows
-            if (crc == 0 && scan >= frame_start + 9 && d[scan] == 0xFF) {
+            if (!at_end && crc == 0 && scan >= frame_start + 9 && d[scan] == 0xFF) {
                 if (scan + 1 >= len && !final) return;
                 if (scan + 1 < len && (d[scan + 1] & 0xFE) == 0xF8) {
                     if (len - scan < 16 && !final) return;
                     if (parse_header(d + scan, len - scan, si, &h)) {
                         bounds.push_back(scan);       // closes the current frame, opens the next
                         frame_start = scan; crc = 0;
+                        open_frame(h);
                         for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan + i]]);
                         scan += h.hdr_bytes;
                         continue;
                     }
                 }
+            }
+            // Resynchronisation: no position with a clean CRC-16 inside the longest possible frame means the frame is
+            // damaged.  It is cut at the next header that continues the numbering (the GPU pass then reports the CRC
+            // mismatch and delivers silence for it, like libFLAC) instead of swallowing the frames behind it.
+            if (want_resync) {
+                uint64_t p2 = frame_start + 2;
+                bool found = false, starved = false;
+                for (; p2 + 1 < len; p2++) {
+                    if (d[p2] != 0xFF || (d[p2 + 1] & 0xFE) != 0xF8) continue;
+                    if (len - p2 < 16 && !final) { starved = true; break; }
+                    if (!parse_header(d + p2, len - p2, si, &h)) continue;
+                    const uint64_t step = cur_variable ? cur_n : 1;
+                    if (h.variable == cur_variable && h.number >= cur_number + step && h.number <= cur_number + 64 * step) { found = true; break; }
+                }
+                if (starved || (!found && !final)) return;          // wait for more data (scan stays, the test repeats)
+                if (found) {
+                    // The damage may sit in the NEXT frame's header only, with this frame intact: look for the end of
+                    // an intact frame (running CRC-16 zero) before p2, preferring one followed by a sync code.  The
+                    // bytes between it and p2 become a frame of their own, which the GPU pass rejects (bad header).
+                    // A wrong guess costs nothing: the parse kernel rejects a frame whose contents do not end at its
+                    // boundary.
+                    uint16_t c2 = 0;
+                    uint64_t cut_sync = 0, cut_any = 0;
+                    for (uint64_t e = frame_start; e < p2; e++) {
+                        c2 = (uint16_t)((c2 << 8) ^ tab[(c2 >> 8) ^ d[e]]);
+                        if (c2 == 0 && e + 1 >= frame_start + 9 && e + 1 < p2 && e + 1 - frame_start <= max_len) {
+                            cut_any = e + 1;
+                            if (!cut_sync && d[e + 1] == 0xFF && e + 2 < len && (d[e + 2] & 0xFC) == 0xF8) cut_sync = e + 1;
+                        }
+                    }
+                    const uint64_t cut = cut_sync ? cut_sync : cut_any;
+                    if (cut) bounds.push_back(cut);
+                    bounds.push_back(p2);
+                    frame_start = p2; crc = 0; open_frame(h);
+                    for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[p2 + i]]);
+                    scan = p2 + h.hdr_bytes;
+                    continue;
+                }
+                tail_checked = true;   // final and nothing follows: the damaged frame runs to the end of the data
+                scan = len;
+                continue;
             }
             crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan]]);
             scan++;
@@ -363,6 +422,11 @@ struct DecImpl {
     std::vector<FgDecResult> status;
     size_t next_frame;
     uint32_t last_blocksize, last_ca;
+    uint64_t first_pos;               // offset in buf of the first queued frame
+    uint32_t fixed_blocksize;         // block size of a fixed-blocksize stream without a usable STREAMINFO
+    FLAC__FrameHeader last_hdr;       // header of the last delivered frame (gap filling)
+    bool last_set;
+    std::vector<int32_t> silence;
     DevBuf d_stream, d_pcm;
 };
 
@@ -376,6 +440,7 @@ void reset_stream(DecImpl *d)
     d->ix = Indexer();
     d->errors_reported = 0; d->frames_delivered_bound = 0; d->samples_decoded = 0;
     d->pcm.clear(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->last_blocksize = 0; d->last_ca = 0;
+    d->first_pos = 0; d->fixed_blocksize = 0; d->last_set = false; memset(&d->last_hdr, 0, sizeof d->last_hdr);
 }
 
 // Pull more bytes.  Returns false on abort.  Sets d->eof at end of stream.  `short_read` reports that the
@@ -482,45 +547,102 @@ bool decode_available(DecImpl *d)
     d->frames.swap(frames);
     d->status.swap(status);
     d->next_frame = 0;
+    d->first_pos = first;
     d->frames_delivered_bound = nb - 1;
     return true;
 }
 
-// Deliver one queued frame.  Returns false when the client aborted.
-bool deliver_one(DecImpl *d)
+// Hand one frame to the write callback.  Returns false when the client aborted.
+bool write_frame(DecImpl *d, const FLAC__Frame &f, const int32_t *const chan[])
 {
-    const FgDecFrame &fr = d->frames[d->next_frame];
-    const FgDecResult &rs = d->status[d->next_frame];
-    d->next_frame++;
-    if (rs.err == 1) {
-        // header or contents malformed: libFLAC reports and resynchronises without delivering a frame
-        if (d->error_cb) d->error_cb(&d->pub, fr.n ? FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC : FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER, d->client);
-        if (!fr.n) return true;
-    }
-    else if (rs.err == 2) {
-        if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, d->client);
-    }
-    if (rs.err == 1) return true;
-    FLAC__Frame f;
-    memset(&f, 0, sizeof f);
-    f.header.blocksize = fr.n;
-    f.header.sample_rate = d->si.sample_rate;
-    f.header.channels = fr.channels;
-    f.header.channel_assignment = (FLAC__ChannelAssignment)fr.ca;
-    f.header.bits_per_sample = fr.bps;
-    f.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
-    f.header.number.sample_number = d->samples_decoded;
-    f.footer.crc = (FLAC__uint16)rs.crc;
-    const int32_t *chan[8];
-    for (uint32_t c = 0; c < 8; c++) chan[c] = c < fr.channels ? d->pcm.data() + (size_t)fr.out_off * fr.channels + (size_t)c * fr.n : nullptr;
-    d->last_blocksize = fr.n; d->last_ca = fr.ca;
-    d->samples_decoded += fr.n;
     d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
     if (d->write_cb(&d->pub, &f, chan, d->client) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) {
         d->state = FLAC__STREAM_DECODER_ABORTED;
         return false;
     }
     return true;
+}
+
+// Deliver one queued frame.  Returns false when the client aborted.
+//
+// Damage handling follows what clients of libFLAC 1.4.3 observe (tests/golden/damage_vectors.json, recorded from the
+// reference's binary): a frame that fails its CRC-16 or does not parse is reported through the error callback and NOT
+// delivered; when the next good frame's sample number shows a gap behind the last delivered frame, frames of silence
+// with the last frame's header fill it (at most 5 s / 50 frames, only between frames of the same format), so the time
+// line is kept.  Nothing is filled before the first delivered frame or after the last one.
+bool deliver_one(DecImpl *d)
+{
+    const FgDecFrame &fr = d->frames[d->next_frame];
+    const FgDecResult &rs = d->status[d->next_frame];
+    d->next_frame++;
+    const uint64_t fpos = d->first_pos + fr.byte_off;
+    if (rs.err == 1 || rs.err == 5) {
+        // header or contents malformed: a region that starts with a sync code was tried as a header first
+        const bool synced = fpos + 1 < d->buf.size() && d->buf[fpos] == 0xFF && (d->buf[fpos + 1] & 0xFE) == 0xF8;
+        if (d->error_cb && !fr.n && synced) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER, d->client);
+        if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
+        return true;
+    }
+    if (rs.err == 4 && d->eof && fpos + fr.bytes >= d->buf.size()) return true;     // cut short by the end of the stream: libFLAC just ends
+    if (rs.err == 2 || rs.err == 4) {
+        // (a frame whose residual is damaged still parses to some end, where libFLAC finds a CRC-16 that does not match)
+        // libFLAC re-searches from just behind the damaged frame's sync code, which reports a loss of sync as well
+        if (d->error_cb) {
+            d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, d->client);
+            d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
+        }
+        return true;
+    }
+    FLAC__Frame f;
+    memset(&f, 0, sizeof f);
+    f.header.blocksize = fr.n;
+    f.header.sample_rate = d->si.sample_rate;
+    // the sample number comes from the frame's own header (it stays right across frames lost to damage)
+    HostHeader hh;
+    uint64_t number = d->samples_decoded;
+    if (fpos < d->buf.size() && parse_header(d->buf.data() + fpos, d->buf.size() - fpos, d->have_si ? &d->si : nullptr, &hh)) {
+        if (hh.sample_rate) f.header.sample_rate = hh.sample_rate;
+        if (hh.variable) number = hh.number;
+        else {
+            const uint32_t fixed = (d->have_si && d->si.min_blocksize == d->si.max_blocksize && d->si.min_blocksize) ? d->si.min_blocksize
+                                   : (d->fixed_blocksize ? d->fixed_blocksize : fr.n);
+            if (!d->fixed_blocksize) d->fixed_blocksize = fixed;
+            number = hh.number * (uint64_t)fixed;
+        }
+    }
+    f.header.channels = fr.channels;
+    f.header.channel_assignment = (FLAC__ChannelAssignment)fr.ca;
+    f.header.bits_per_sample = fr.bps;
+    f.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
+    f.header.number.sample_number = number;
+    f.footer.crc = (FLAC__uint16)rs.crc;
+    if (d->last_set && d->last_hdr.number.sample_number + d->last_hdr.blocksize < number &&
+        d->last_hdr.sample_rate == f.header.sample_rate && d->last_hdr.channels == f.header.channels &&
+        d->last_hdr.bits_per_sample == f.header.bits_per_sample && d->last_hdr.blocksize >= 16) {
+        uint64_t need = number - (d->last_hdr.number.sample_number + d->last_hdr.blocksize);
+        FLAC__Frame e;
+        memset(&e, 0, sizeof e);
+        e.header = d->last_hdr;
+        if (need > 5ull * e.header.sample_rate) need = 5ull * e.header.sample_rate;
+        if (need > 50ull * e.header.blocksize) need = 50ull * e.header.blocksize;
+        d->silence.assign(e.header.blocksize, 0);
+        const int32_t *zc[8];
+        for (uint32_t c = 0; c < 8; c++) zc[c] = c < e.header.channels ? d->silence.data() : nullptr;
+        for (uint32_t c = 0; c < e.header.channels; c++) e.subframes[c].type = FLAC__SUBFRAME_TYPE_CONSTANT;
+        while (need) {
+            e.header.number.sample_number += e.header.blocksize;
+            if (need < e.header.blocksize) e.header.blocksize = (uint32_t)need;
+            need -= e.header.blocksize;
+            d->samples_decoded = e.header.number.sample_number + e.header.blocksize;
+            if (!write_frame(d, e, zc)) return false;
+        }
+    }
+    const int32_t *chan[8];
+    for (uint32_t c = 0; c < 8; c++) chan[c] = c < fr.channels ? d->pcm.data() + (size_t)fr.out_off * fr.channels + (size_t)c * fr.n : nullptr;
+    d->last_blocksize = fr.n; d->last_ca = fr.ca;
+    d->last_hdr = f.header; d->last_set = true;
+    d->samples_decoded = number + fr.n;
+    return write_frame(d, f, chan);
 }
 
 // Make progress: after this call either at least one frame is queued, or the stream has ended / aborted.

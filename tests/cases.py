@@ -154,3 +154,45 @@ LIMIT_CASES = {
     'lmb_ch6_l5': ({'kind': 'constmix', 'n': _N, 'chans': ['z', 'c4', 'z', 'c-4', 'z', 'm']}, 48000, 5, 4096),
     'lmb_bs1152_st_l2': ({'kind': 'constmix', 'n': 1152 * 7 + 5, 'chans': ['c-3', 'c-3']}, 44100, 2, 1152),
 }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Damaged streams (decoder resynchronisation).  name -> (fixture stream under golden/data, edits applied in order).
+# Edits use absolute byte positions of the ORIGINAL stream (they are applied back to front so they do not shift each
+# other): ('flip', pos, xor) | ('del', pos, count) | ('ins', pos, count, seed) | ('trunc', length).
+# stereo.flac frames start at 8304, 15616, 21301, 26619, 31110, 35345, 39273, 43054, ...; mono.flac at 8304, 10663,
+# 12641, 14513, 15930, 17235, 18551, 19536, ...
+DAMAGE_CASES = {
+    'body_flip':            ('stereo', [('flip', 21301 + 900, 0x10)]),
+    'body_flip_two_frames': ('stereo', [('flip', 15616 + 77, 0x01), ('flip', 35345 + 2000, 0x80)]),
+    'body_flip_adjacent':   ('stereo', [('flip', 21301 + 900, 0x10), ('flip', 26619 + 50, 0x04)]),
+    'crc16_flip':           ('stereo', [('flip', 26619 - 1, 0x01)]),
+    'header_blocksize':     ('stereo', [('flip', 26619 + 2, 0x10)]),
+    'header_sync':          ('stereo', [('flip', 26619, 0x0F)]),
+    'header_crc8':          ('mono', [('flip', 12641 + 5, 0xFF)]),
+    'delete_in_body':       ('stereo', [('del', 31110 + 1000, 37)]),
+    'delete_header':        ('mono', [('del', 14513, 8)]),
+    'insert_in_body':       ('stereo', [('ins', 35345 + 300, 501, 5)]),
+    'insert_between':       ('mono', [('ins', 15930, 3000, 6)]),
+    'truncated':            ('stereo', [('trunc', 43054 + 1234)]),
+    'truncated_at_frame':   ('mono', [('trunc', 18551)]),
+    'first_frame_body':     ('mono', [('flip', 8304 + 100, 0x20)]),
+    'last_frame_body':      ('mono', [('flip', 20964 - 100, 0x02)]),
+    'many_flips':           ('stereo', [('flip', p, 0x40) for p in range(9000, 73000, 9001)]),
+}
+
+
+def damaged_stream(name):
+    src, edits = DAMAGE_CASES[name]
+    with open(os.path.join(GOLDEN, 'data', src + '.flac'), 'rb') as f:
+        data = bytearray(f.read())
+    for e in sorted(edits, key=lambda e: -e[1]):
+        if e[0] == 'flip':
+            data[e[1]] ^= e[2]
+        elif e[0] == 'del':
+            del data[e[1]:e[1] + e[2]]
+        elif e[0] == 'ins':
+            data[e[1]:e[1]] = _rng(e[3]).integers(0, 256, e[2], dtype=np.uint8).tobytes()
+        elif e[0] == 'trunc':
+            del data[e[1]:]
+    return bytes(data)

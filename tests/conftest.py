@@ -21,6 +21,15 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def damage_golden():
+    """What clients of the reference's libFLAC 1.4.3 see for damaged streams (tests/cases.py DAMAGE_CASES)."""
+    import json
+    from tests import cases
+    with open(os.path.join(cases.GOLDEN, 'damage_vectors.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
 def limit_golden():
     """Reference output with FLAC__stream_encoder_set_limit_min_bitrate(true) (tests/cases.py LIMIT_CASES)."""
     import json

@@ -94,3 +94,39 @@ def test_no_cpu_fallback_without_gpu(L):
     assert not L.flacgpu_ctx_create(0)
     from pyflac_amd import _lib
     assert 'no CPU fallback' in _lib.last_error()
+
+
+@pytest.mark.parametrize('name', sorted(__import__('tests.cases', fromlist=['x']).DAMAGE_CASES))
+def test_frame_index_resynchronises_after_damage(L, name):
+    """Host frame index (flacgpu_index_frames) of the damaged streams of tests/cases.py: every frame whose header
+    survived is still delimited at its own start, so one damaged frame never swallows the frames behind it."""
+    import numpy as np
+    from tests import cases
+    from pyflac_amd import batch
+    src, edits = cases.DAMAGE_CASES[name]
+    with open(os.path.join(cases.GOLDEN, 'data', src + '.flac'), 'rb') as f:
+        clean = f.read()
+    offs, _ = batch.index_frames(clean)
+    got, _ = batch.index_frames(cases.damaged_stream(name))
+    got = set(int(x) for x in got)
+
+    def moved(p):
+        q = p
+        for e in edits:
+            if e[0] == 'del' and e[1] < p:
+                q -= e[2]
+            elif e[0] == 'ins' and e[1] <= p:
+                q += e[2]
+        return q
+
+    def header_hit(p):
+        for e in edits:
+            if e[0] == 'trunc' and p + 16 > e[1]:
+                return True
+            if e[0] in ('flip', 'del') and p <= e[1] < p + 16:
+                return True
+        return False
+
+    kept = [moved(int(p)) for p in offs[:-1] if not header_hit(int(p))]
+    assert len(kept) >= len(offs) - 3 or any(e[0] == 'trunc' for e in edits) or name == 'many_flips'
+    assert all(p in got for p in kept), sorted(set(kept) - got)
