@@ -4,7 +4,8 @@ Run in the build container only (needs /root/reference):  python -m oracle.gen_g
 Each case of tests/cases.py DAMAGE_CASES names a committed stream and a list of edits (byte flips, deletions,
 insertions, truncation).  The vector records what pyFLAC's callbacks (pyflac/decoder.py:257-313) would see from the
 bundled library for the edited stream: the error-callback status sequence and, per delivered frame, its sample number,
-block size and a hash of the samples.
+block size and a hash of the samples.  The `__md5__` entry records what FLAC__stream_decoder_finish returns with MD5
+checking enabled (tests/cases.py MD5_CASES).
 """
 import hashlib
 import json
@@ -33,6 +34,12 @@ def main():
                        hashlib.sha256(np.ascontiguousarray(blk, np.int32).tobytes()).hexdigest()[:16]])
         out[name] = {'errors': [int(e) for e in st['errors']], 'frames': fr, 'state': int(st['state'])}
         print('%-28s frames %3d errors %s' % (name, len(fr), out[name]['errors']))
+    md5 = {}
+    for name in sorted(cases.MD5_CASES):
+        _pcm, frames, st = R.decode(cases.md5_stream(name), md5_checking=cases.MD5_CASES[name][2])
+        md5[name] = {'finish': st['finish'], 'frames': len(frames), 'errors': [int(e) for e in st['errors']]}
+        print('%-28s %s' % (name, md5[name]))
+    out['__md5__'] = md5
     with open(os.path.join(cases.GOLDEN, 'damage_vectors.json'), 'w') as f:
         json.dump(out, f, indent=0, sort_keys=True, separators=(',', ':'))
 

@@ -257,7 +257,7 @@ def _subframe_info(sf, blocksize):
     return d
 
 
-def decode(data, read_size=8192, want_frames=True):
+def decode(data, read_size=8192, want_frames=True, md5_checking=False):
     """Decode a FLAC byte string.  Returns ``(pcm[frames, ch] int32, frames, errors)``."""
     L = lib()
     dec = C.c_void_p(L.FLAC__stream_decoder_new())
@@ -295,12 +295,14 @@ def decode(data, read_size=8192, want_frames=True):
         errors.append(status)
 
     rcb, wcb, ecb = DEC_READ_CB(_r), DEC_WRITE_CB(_w), DEC_ERROR_CB(_e)
+    if md5_checking:
+        assert L.FLAC__stream_decoder_set_md5_checking(dec, 1)
     rc = L.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb,
                                             None, ecb, None)
     assert rc == 0, rc
     ok = L.FLAC__stream_decoder_process_until_end_of_stream(dec)
     state = L.FLAC__stream_decoder_get_state(dec)
-    L.FLAC__stream_decoder_finish(dec)
+    fin = L.FLAC__stream_decoder_finish(dec)
     L.FLAC__stream_decoder_delete(dec)
     pcm = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, 1), np.int32)
-    return pcm, frames, {'errors': errors, 'ok': bool(ok), 'state': state}
+    return pcm, frames, {'errors': errors, 'ok': bool(ok), 'state': state, 'finish': bool(fin)}

@@ -425,6 +425,9 @@ struct DecImpl {
     uint64_t first_pos;               // offset in buf of the first queued frame
     uint32_t fixed_blocksize;         // block size of a fixed-blocksize stream without a usable STREAMINFO
     FLAC__FrameHeader last_hdr;       // header of the last delivered frame (gap filling)
+    bool do_md5;                      // MD5 checking still meaningful for this stream (libFLAC do_md5_checking)
+    FgMd5 md5;
+    std::vector<int32_t> md5_tmp;
     bool last_set;
     std::vector<int32_t> silence;
     DevBuf d_stream, d_pcm;
@@ -440,6 +443,7 @@ void reset_stream(DecImpl *d)
     d->ix = Indexer();
     d->errors_reported = 0; d->frames_delivered_bound = 0; d->samples_decoded = 0;
     d->pcm.clear(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->last_blocksize = 0; d->last_ca = 0;
+    d->do_md5 = d->md5_checking != 0; d->md5.init();
     d->first_pos = 0; d->fixed_blocksize = 0; d->last_set = false; memset(&d->last_hdr, 0, sizeof d->last_hdr);
 }
 
@@ -556,6 +560,18 @@ bool decode_available(DecImpl *d)
 bool write_frame(DecImpl *d, const FLAC__Frame &f, const int32_t *const chan[])
 {
     d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+    if (!d->have_si) d->do_md5 = false;
+    if (d->do_md5) {
+        // signature input: interleaved, little-endian, (bps+7)/8 bytes per sample (format.h:549 md5sum)
+        const uint32_t C = f.header.channels, n = f.header.blocksize;
+        d->md5_tmp.resize((size_t)n * C);
+        for (uint32_t c = 0; c < C; c++) {
+            const int32_t *src = chan[c];
+            int32_t *dst = d->md5_tmp.data() + c;
+            for (uint32_t i = 0; i < n; i++) dst[(size_t)i * C] = src[i];
+        }
+        d->md5.update_pcm(d->md5_tmp.data(), (uint64_t)n * C, f.header.bits_per_sample);
+    }
     if (d->write_cb(&d->pub, &f, chan, d->client) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) {
         d->state = FLAC__STREAM_DECODER_ABORTED;
         return false;
@@ -833,16 +849,27 @@ FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *dec)
     DecImpl *d = impl(dec);
     if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 1;
     if (d->file) { if (d->own_file) fclose(d->file); d->file = nullptr; }
+    // stream_decoder.h:1339-1348: false when MD5 checking is on, a STREAMINFO with a non-zero signature was read and
+    // the signature of the delivered samples differs
+    FLAC__bool md5_ok = 1;
+    if (d->do_md5 && d->have_si) {
+        static const uint8_t zero[16] = {0};
+        uint8_t got[16];
+        d->md5.final(got);
+        if (memcmp(d->si.md5sum, zero, 16) != 0 && memcmp(d->si.md5sum, got, 16) != 0) md5_ok = 0;
+    }
+    d->md5_checking = 0;
     reset_stream(d);
-    d->md5_checking = 0; d->respond_streaminfo = true;
+    d->respond_streaminfo = true;
     d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
-    return 1;
+    return md5_ok;
 }
 FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *dec)
 {
     DecImpl *d = impl(dec);
     if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
     d->buf.clear(); d->ix = Indexer(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
+    d->do_md5 = false;       // stream_decoder.h:1357-1359: a flush turns MD5 checking off
     d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
     return 1;
 }

@@ -7,7 +7,7 @@ import hashlib
 import numpy as np
 
 
-def decode(data, read_size=8192):
+def decode(data, read_size=8192, md5_checking=False):
     from pyflac_amd import _lib
     L = _lib.lib()
     dec = C.c_void_p(L.FLAC__stream_decoder_new())
@@ -36,10 +36,12 @@ def decode(data, read_size=8192):
         errors.append(int(status))
 
     rcb, wcb, ecb = _lib.DEC_READ_CB(_r), _lib.DEC_WRITE_CB(_w), _lib.DEC_ERROR_CB(_e)
+    if md5_checking:
+        assert L.FLAC__stream_decoder_set_md5_checking(dec, 1)
     rc = L.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb, C.cast(None, _lib.DEC_META_CB), ecb, None)
     assert rc == 0, rc
     ok = L.FLAC__stream_decoder_process_until_end_of_stream(dec)
     state = L.FLAC__stream_decoder_get_state(dec)
-    L.FLAC__stream_decoder_finish(dec)
+    fin = L.FLAC__stream_decoder_finish(dec)
     L.FLAC__stream_decoder_delete(dec)
-    return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'blocks': blocks}
+    return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'blocks': blocks, 'finish': bool(fin)}

@@ -196,3 +196,32 @@ def damaged_stream(name):
         elif e[0] == 'trunc':
             del data[e[1]:]
     return bytes(data)
+
+
+# MD5 checking on decode (FLAC__stream_decoder_set_md5_checking): name -> (damage case or fixture, STREAMINFO md5 edit,
+# checking enabled).  The signature sits at bytes 26..41 of a stream whose STREAMINFO is the first block.
+MD5_CASES = {
+    'clean_checked':      ('stereo', None, True),
+    'clean_mono_checked': ('mono', None, True),
+    'clean_32bit':        ('32bit', None, True),
+    'clean_surround':     ('surround', None, True),
+    'tampered_checked':   ('stereo', 'flip', True),
+    'tampered_unchecked': ('stereo', 'flip', False),
+    'zero_signature':     ('stereo', 'zero', True),
+    'damaged_checked':    ('body_flip', None, True),
+    'truncated_checked':  ('truncated', None, True),
+}
+
+
+def md5_stream(name):
+    src, edit, _on = MD5_CASES[name]
+    if src in DAMAGE_CASES:
+        data = bytearray(damaged_stream(src))
+    else:
+        with open(os.path.join(GOLDEN, 'data', src + '.flac'), 'rb') as f:
+            data = bytearray(f.read())
+    if edit == 'flip':
+        data[30] ^= 0x55
+    elif edit == 'zero':
+        data[26:42] = bytes(16)
+    return bytes(data)

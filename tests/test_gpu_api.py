@@ -279,3 +279,16 @@ class TestDamagedStreams:
             assert got['errors'][0] == want['errors'][0], (got['errors'], want['errors'])
         if name in self.EXACT:
             assert got['frames'] == want['frames'] and got['errors'] == want['errors']
+
+
+class TestMd5Checking:
+    """FLAC__stream_decoder_set_md5_checking: what FLAC__stream_decoder_finish returns, against
+    the reference binary's answers recorded in tests/golden/damage_vectors.json['__md5__']."""
+
+    @pytest.mark.parametrize('name', sorted(cases.MD5_CASES))
+    def test_finish_result(self, damage_golden, name):
+        from tests import abi_decode
+        want = damage_golden['__md5__'][name]
+        got = abi_decode.decode(cases.md5_stream(name), md5_checking=cases.MD5_CASES[name][2])
+        assert got['finish'] == want['finish']
+        assert len(got['frames']) == want['frames'] and got['errors'] == want['errors']
