@@ -478,6 +478,12 @@ int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, 
                           uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
                           uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
 
+/* The same with the frame index already in device memory (d_frame_offsets: nframes+1 uint64 byte offsets), e.g. the
+ * offsets flacgpu_encode_streams wrote: no host round trip of the index. */
+int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *d_frame_offsets,
+                              uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
+                              uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
+
 /* Host-side frame indexer: parses metadata and frame headers of a complete FLAC stream in host memory and
  * returns frame byte offsets (validated by header CRC-8 and chained by frame CRC-16).  Returns the number
  * of frames, or a negative value on error. */

@@ -96,20 +96,28 @@ class Context:
 
     # -- decode
     def decode(self, stream, frame_offsets, channels, bits_per_sample, max_samples, out=None):
-        """Decode frames of a device-resident byte tensor.  ``frame_offsets``: host int64 array (nframes+1).
+        """Decode frames of a device-resident byte tensor.  ``frame_offsets``: host int64 array (nframes+1), or a
+        device int64 tensor (the index stays in HBM).
 
         Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
         """
         L = _lib.lib()
         assert stream.is_cuda and stream.dtype == torch.uint8
-        offs = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.uint64))
-        nframes = offs.size - 1
+        on_dev = isinstance(frame_offsets, torch.Tensor) and frame_offsets.is_cuda
+        if on_dev:
+            # the index stays in HBM (e.g. the offsets tensor encode() returned)
+            assert frame_offsets.dtype in (torch.int64, torch.uint64) and frame_offsets.is_contiguous()
+            nframes = frame_offsets.numel() - 1
+        else:
+            offs = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.uint64))
+            nframes = offs.size - 1
         if out is None or out.numel() < max_samples * channels:
             out = torch.empty((max(int(max_samples), 1), channels), dtype=torch.int32, device=stream.device)
         status = np.zeros((max(nframes, 1), 2), np.uint32)
         st = _lib.DecodeStats()
-        rc = L.flacgpu_decode_frames(self._h, stream.data_ptr(), stream.numel(), offs.ctypes.data, nframes, channels,
-                                     bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, C.byref(st))
+        fn = L.flacgpu_decode_frames_dev if on_dev else L.flacgpu_decode_frames
+        rc = fn(self._h, stream.data_ptr(), stream.numel(), frame_offsets.data_ptr() if on_dev else offs.ctypes.data, nframes,
+                channels, bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, C.byref(st))
         if rc != 0:
             raise FlacGpuError(_lib.last_error())
         return out[:st.total_samples], status[:nframes], st

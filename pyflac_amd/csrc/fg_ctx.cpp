@@ -50,6 +50,17 @@ bool flacgpu_ctx::ensure_pinned(size_t bytes)
     return true;
 }
 
+bool flacgpu_ctx::ensure_pinned_res(size_t bytes)
+{
+    if (bytes <= h_res_cap) return true;
+    size_t want = std::max(bytes, h_res_cap * 2);
+    void *np = nullptr;
+    if (hipHostMalloc(&np, want, hipHostMallocDefault) != hipSuccess) { fg_set_error("hipHostMalloc failed"); return false; }
+    if (h_res) (void)hipHostFree(h_res);
+    h_res = np; h_res_cap = want;
+    return true;
+}
+
 // ------------------------------------------------------------------ window tables
 // Generated on the host with the C library's cosf, exactly as libFLAC does; tests/golden/window_hashes.json
 // pins the tables so that a libm difference on another host is detected rather than silently encoded.
@@ -130,6 +141,7 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
                       &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_res) (void)hipHostFree(c->h_res);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -443,7 +455,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
         fg_set_error("scan kernel launch failed"); return false;
     }
-    unsigned long long tail[2] = {0, 0};   // total bytes, OR of error flags
+    if (!c->ensure_pinned_res(64)) return false;
+    unsigned long long *tail = (unsigned long long *)c->h_res;   // total bytes, OR of error flags
+    tail[0] = tail[1] = 0;
     HIPCHK(hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((uint32_t)tail[1] & FG_ERR_REDO) {

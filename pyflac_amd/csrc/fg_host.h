@@ -76,6 +76,10 @@ struct flacgpu_ctx {
     void *h_pin = nullptr;
     size_t h_pin_cap = 0;
     bool ensure_pinned(size_t bytes);
+    // pinned landing area for the small device-to-host reads of the batch calls (totals, per-frame status)
+    void *h_res = nullptr;
+    size_t h_res_cap = 0;
+    bool ensure_pinned_res(size_t bytes);
     uint32_t window_offset(uint32_t n, uint32_t parts);   // returns float offset, computing the table if new
     bool sync_windows();
 };

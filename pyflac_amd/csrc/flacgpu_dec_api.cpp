@@ -255,6 +255,10 @@ struct Indexer {
 
 }  // namespace
 
+extern "C" int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *d_frame_offsets,
+                                         uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
+                                         uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
+
 extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uint64_t *frame_offsets, uint64_t capacity,
                                         FLAC__StreamMetadata_StreamInfo *streaminfo, uint64_t *audio_offset)
 {
@@ -278,7 +282,8 @@ extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uin
 // ------------------------------------------------------------------ batch decode of device-resident frames
 static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
                                uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
-                               FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st)
+                               FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
+                               bool offsets_on_device = false)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     memset(st, 0, sizeof *st);
@@ -292,11 +297,13 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         return false;
     unsigned long long *d_off = (unsigned long long *)c->offsets.p;
     unsigned long long *d_tot = d_off + nframes + 1;
-    if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, hipMemcpyHostToDevice, c->stream))) { fg_set_error("H2D offsets failed"); return false; }
+    if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
     if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                               (FgDecResult *)c->dec_results.p, d_tot, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
-    unsigned long long tot[2] = {0, 0};
+    if (!c->ensure_pinned_res(64 + (size_t)nframes * sizeof(FgDecResult))) return false;
+    unsigned long long *tot = (unsigned long long *)c->h_res;
+    tot[0] = tot[1] = 0;
     if (!HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
         fg_set_error("header pass failed"); return false;
     }
@@ -331,8 +338,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         fg_set_error("decode kernel launch failed"); return false;
     }
     if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
-    std::vector<FgDecResult> res(nframes);
-    if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
+    FgDecResult *res = (FgDecResult *)((char *)c->h_res + 64);
+    if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
     if (h_frames) {
         h_frames->resize(nframes);
         if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
@@ -348,7 +355,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             if (fg_launch_decode_slow((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, (const uint32_t *)c->descs.p, (uint32_t)redo.size(),
                                       (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, (int32_t *)c->dec_scratch.p,
                                       interleave ? 1u : 0u, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
-            if (!HIPOK(hipMemcpyAsync(res.data(), c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream)) ||
+            if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream)) ||
                 !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
         }
     }
@@ -375,8 +382,19 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     for (uint32_t i = 0; i < nframes; i++) if (res[i].err) bad++;
     st->error_frames = bad;
     st->channels = C; st->bits_per_sample = bps_hint;
-    if (h_status) memcpy(h_status, res.data(), (size_t)nframes * sizeof(FgDecResult));
+    if (h_status) memcpy(h_status, res, (size_t)nframes * sizeof(FgDecResult));
     return true;
+}
+
+extern "C" int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *d_frame_offsets,
+                                         uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
+                                         uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats)
+{
+    flacgpu_decode_stats local;
+    if (!stats) stats = &local;
+    if (!ctx) { fg_set_error("null context"); return -1; }
+    return decode_frames_impl(ctx, d_stream, len, d_frame_offsets, nframes, channels_hint, bps_hint, d_pcm, pcm_capacity_samples, 1,
+                              (FgDecResult *)h_frame_status, nullptr, stats, true) ? 0 : -1;
 }
 
 extern "C" int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *h_frame_offsets,

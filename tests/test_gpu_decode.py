@@ -81,3 +81,18 @@ def test_frames_per_wave_shapes(ctx, monkeypatch, wps, seconds, ch):
     dec, status, _dst = ctx.decode(out[:st.total_bytes], offs.cpu().numpy(), ch, 16, len(pcm))
     assert int(status[:, 0].max()) == 0
     assert torch.equal(dec.reshape(-1, ch), t)
+
+
+def test_device_resident_frame_index(ctx):
+    """flacgpu_decode_frames_dev: the frame index the encoder wrote is consumed from HBM; same result as the host index."""
+    import torch
+    from pyflac_amd import batch, synth
+    pcm = synth.config2_stereo16(3.0, 5)
+    t = torch.from_numpy(pcm.astype(np.int32)).cuda()
+    s = batch.settings(5, 2, 16, 48000, 4096)
+    out, offs, st = ctx.encode(s, t)
+    assert offs.is_cuda
+    a, sa, _ = ctx.decode(out[:st.total_bytes], offs, 2, 16, len(pcm))
+    b, sb, _ = ctx.decode(out[:st.total_bytes], offs.cpu().numpy(), 2, 16, len(pcm))
+    assert int(sa[:, 0].max()) == 0 and np.array_equal(sa, sb)
+    assert torch.equal(a, b) and torch.equal(a.reshape(-1, 2), t)
