@@ -361,7 +361,7 @@ typedef struct {
     sub_t ws[FLO_MAX_CHANNELS][2];
     int best[FLO_MAX_CHANNELS];
     uint32_t best_bits[FLO_MAX_CHANNELS];
-    int32_t *sig[FLO_MAX_CHANNELS];
+    int64_t *sig[FLO_MAX_CHANNELS];   /* int64: the side channel of a 32-bit stream needs 33 bits (integer_signal_33bit_side) */
     uint32_t wasted[FLO_MAX_CHANNELS], sbps[FLO_MAX_CHANNELS];
     uint64_t *sums;           /* partition sums for all orders: 2<<15 */
     uint32_t *tmp_params;     /* 1<<15 */
@@ -464,20 +464,58 @@ static uint32_t find_best_partition_order(enc_ws *w, const int32_t *res, uint32_
 }
 
 /* ------------------------------------------------------------------ fixed predictor */
-static uint32_t fixed_best_predictor(const int32_t *x, uint32_t n, uint32_t sbps, float rbps[5], uint64_t tot[5])
+/* The reference binary (x86-64, AVX2 dispatch) computes the error sums of the "wide" and "limit_residual" variants with
+ * FLAC__fixed_compute_best_predictor_wide_intrin_avx2 / _limit_residual_intrin_avx2: four lanes walk data_len/4 samples
+ * each.  The lanes' histories are taken at j*(data_len/4), but the lanes START at data_len/4, (2*data_len)/4 and
+ * (3*data_len)/4; the data_len%4 samples behind the lanes are ignored by the _wide routine and added by a scalar loop in
+ * the _limit_residual routine.  When data_len is a multiple of four this
+ * is the exact sum; otherwise lanes 2 and 3 start one or two samples late against their history and the sums differ
+ * from the plain C loop (which the same library uses on CPUs without AVX2).  Recovered from the disassembly of the
+ * reference binary and pinned by tools/fuzz_oracle_vs_ref.py; sums are what pyFLAC users on x86-64 get. */
+static void avx2_lane_sums(const int64_t *d, uint32_t len, uint64_t t[5], int over[5])
+{
+    const uint32_t q = len / 4;
+    const uint32_t start[4] = {0, len >> 2, len >> 1, (3 * len) >> 2};
+    if (len < 4) return;
+    for (int j = 0; j < 4; j++) {
+        const int64_t *h = d + (size_t)j * q;
+        int64_t p0 = h[-1], p1 = h[-1] - h[-2], p2 = p1 - (h[-2] - h[-3]), p3 = p2 - (h[-2] - 2 * h[-3] + h[-4]);
+        for (uint32_t i = 0; i < q; i++) {
+            const int64_t e0 = d[start[j] + i], e1 = e0 - p0, e2 = e1 - p1, e3 = e2 - p2, e4 = e3 - p3;
+            const int64_t e[5] = {e0, e1, e2, e3, e4};
+            for (int k = 0; k < 5; k++) {
+                const uint64_t a = (uint64_t)(e[k] < 0 ? -e[k] : e[k]);
+                t[k] += a;
+                if (a > 0x7FFFFFFF) over[k] = 1;
+            }
+            p3 = e3; p2 = e2; p1 = e1; p0 = e0;
+        }
+    }
+}
+
+static uint32_t fixed_best_predictor(const int64_t *x, uint32_t n, uint32_t sbps, float rbps[5], uint64_t tot[5])
 {
     /* x points at the start of the block */
     uint32_t order;
     if (sbps < 28) {
         uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-        const int32_t *d = x + 4;
+        const int64_t *d = x + 4;
         const uint32_t len = n - 4;
-        for (int i = 0; i < (int)len; i++) {
-            int32_t e0 = d[i], e1 = d[i] - d[i - 1], e2 = d[i] - 2 * d[i - 1] + d[i - 2];
-            int32_t e3 = d[i] - 3 * d[i - 1] + 3 * d[i - 2] - d[i - 3];
-            int32_t e4 = d[i] - 4 * d[i - 1] + 6 * d[i - 2] - 4 * d[i - 3] + d[i - 4];
-            t0 += (uint32_t)abs(e0); t1 += (uint32_t)abs(e1); t2 += (uint32_t)abs(e2);
-            t3 += (uint32_t)abs(e3); t4 += (uint32_t)abs(e4);
+        /* stream_encoder.c process_subframe_: 32-bit accumulators while sbps + ilog2((blocksize-4)*17) < 32, else _wide */
+        if (sbps + ilog2_32(len * 17) < 32) {
+            for (int i = 0; i < (int)len; i++) {
+                int32_t e0 = (int32_t)d[i], e1 = (int32_t)(d[i] - d[i - 1]), e2 = (int32_t)(d[i] - 2 * d[i - 1] + d[i - 2]);
+                int32_t e3 = (int32_t)(d[i] - 3 * d[i - 1] + 3 * d[i - 2] - d[i - 3]);
+                int32_t e4 = (int32_t)(d[i] - 4 * d[i - 1] + 6 * d[i - 2] - 4 * d[i - 3] + d[i - 4]);
+                t0 += (uint32_t)abs(e0); t1 += (uint32_t)abs(e1); t2 += (uint32_t)abs(e2);
+                t3 += (uint32_t)abs(e3); t4 += (uint32_t)abs(e4);
+            }
+        }
+        else {
+            uint64_t t[5] = {0, 0, 0, 0, 0};
+            int over[5] = {0, 0, 0, 0, 0};
+            avx2_lane_sums(d, len, t, over);
+            t0 = t[0]; t1 = t[1]; t2 = t[2]; t3 = t[3]; t4 = t[4];
         }
         tot[0] = t0; tot[1] = t1; tot[2] = t2; tot[3] = t3; tot[4] = t4;
 #define MIN2(a, b) ((a) < (b) ? (a) : (b))
@@ -490,27 +528,33 @@ static uint32_t fixed_best_predictor(const int32_t *x, uint32_t n, uint32_t sbps
             rbps[k] = (float)((tot[k] > 0) ? log(M_LN2 * (double)tot[k] / (double)len) / M_LN2 : 0.0);
     }
     else {
-        /* _limit_residual variant [upstream-recall, SURVEY A.5 footnote] */
+        /* _limit_residual variants: the sums include the four warm-up positions (i = -4..-1), and an order whose
+         * residual would not fit int32 is disqualified.  sbps <= 32: the AVX2 lanes above; sbps == 33 (side channel
+         * of a 32-bit stream): FLAC__fixed_compute_best_predictor_limit_residual_33bit, plain C, every sample. */
         uint64_t t[5] = {0, 0, 0, 0, 0}, smallest = UINT64_MAX;
-        int valid[5] = {1, 1, 1, 1, 1};
-        const int32_t *d = x + 4;
+        int over[5] = {0, 0, 0, 0, 0};
+        const int64_t *d = x + 4;
         const uint32_t len = n - 4;
         for (int i = -4; i < (int)len; i++) {
             uint64_t e[5];
+            /* sbps <= 32: the scalar parts of the AVX2 routine are the warm-up positions and the len%4 samples at the
+             * end (which the shifted lanes may already have counted once) */
+            if (sbps <= 32 && i >= 0 && i < (int)(len & ~3u)) continue;
             e[0] = (uint64_t)llabs((long long)d[i]);
             e[1] = (i > -4) ? (uint64_t)llabs((long long)d[i] - d[i - 1]) : 0;
             e[2] = (i > -3) ? (uint64_t)llabs((long long)d[i] - 2 * (long long)d[i - 1] + d[i - 2]) : 0;
             e[3] = (i > -2) ? (uint64_t)llabs((long long)d[i] - 3 * (long long)d[i - 1] + 3 * (long long)d[i - 2] - d[i - 3]) : 0;
             e[4] = (i > -1) ? (uint64_t)llabs((long long)d[i] - 4 * (long long)d[i - 1] + 6 * (long long)d[i - 2] - 4 * (long long)d[i - 3] + d[i - 4]) : 0;
-            for (int k = 0; k < 5; k++) { t[k] += e[k]; if (e[k] > 0x7FFFFFFF) valid[k] = 0; }
+            for (int k = 0; k < 5; k++) { t[k] += e[k]; if (e[k] > 0x7FFFFFFF) over[k] = 1; }
         }
+        if (sbps <= 32) avx2_lane_sums(d, len, t, over);
         /* Observed on the reference binary (true 32-bit probes, tests/test_oracle_vs_reference.py):
          * ties go to the lowest order, a non-zero constant signal is NOT flagged constant and an
          * all-zero one is; i.e. the per-order estimate is derived from total_error_0 for every order. */
         order = 0;
         for (int k = 4; k >= 0; k--) {
             tot[k] = t[k];
-            if (valid[k] && t[k] <= smallest) {
+            if (!over[k] && t[k] <= smallest) {
                 order = (uint32_t)k; smallest = t[k];
                 rbps[k] = (float)((t[0] > 0) ? log(M_LN2 * (double)t[0] / (double)len) / M_LN2 : 0.0);
             }
@@ -520,25 +564,26 @@ static uint32_t fixed_best_predictor(const int32_t *x, uint32_t n, uint32_t sbps
     return order;
 }
 
-static void fixed_residual(const int32_t *x, uint32_t n, uint32_t order, int32_t *r)
+static void fixed_residual(const int64_t *x, uint32_t n, uint32_t order, int32_t *r)
 {
-    /* x points at sample `order`; n residual samples */
+    /* x points at sample `order`; n residual samples.  The chosen order's residual fits int32 (guarded above for
+     * sbps >= 28), so the truncation equals libFLAC's int32 / _wide / _wide_33bit variants. */
     switch (order) {
-    case 0: memcpy(r, x, sizeof(int32_t) * n); break;
-    case 1: for (int i = 0; i < (int)n; i++) r[i] = x[i] - x[i - 1]; break;
-    case 2: for (int i = 0; i < (int)n; i++) r[i] = x[i] - 2 * x[i - 1] + x[i - 2]; break;
-    case 3: for (int i = 0; i < (int)n; i++) r[i] = x[i] - 3 * x[i - 1] + 3 * x[i - 2] - x[i - 3]; break;
-    default: for (int i = 0; i < (int)n; i++) r[i] = x[i] - 4 * x[i - 1] + 6 * x[i - 2] - 4 * x[i - 3] + x[i - 4]; break;
+    case 0: for (int i = 0; i < (int)n; i++) r[i] = (int32_t)x[i]; break;
+    case 1: for (int i = 0; i < (int)n; i++) r[i] = (int32_t)(x[i] - x[i - 1]); break;
+    case 2: for (int i = 0; i < (int)n; i++) r[i] = (int32_t)(x[i] - 2 * x[i - 1] + x[i - 2]); break;
+    case 3: for (int i = 0; i < (int)n; i++) r[i] = (int32_t)(x[i] - 3 * x[i - 1] + 3 * x[i - 2] - x[i - 3]); break;
+    default: for (int i = 0; i < (int)n; i++) r[i] = (int32_t)(x[i] - 4 * x[i - 1] + 6 * x[i - 2] - 4 * x[i - 3] + x[i - 4]); break;
     }
 }
 
 /* returns 0 if a residual does not fit int32 (the _limit_residual guard) */
-static int lpc_residual(const int32_t *x, uint32_t n, const int32_t *q, uint32_t order, int shift, int32_t *r)
+static int lpc_residual(const int64_t *x, uint32_t n, const int32_t *q, uint32_t order, int shift, int32_t *r)
 {
     for (int i = 0; i < (int)n; i++) {
         int64_t sum = 0;
-        for (uint32_t j = 0; j < order; j++) sum += (int64_t)q[j] * (int64_t)x[i - 1 - (int)j];
-        int64_t v = (int64_t)x[i] - (sum >> shift);
+        for (uint32_t j = 0; j < order; j++) sum += (int64_t)q[j] * x[i - 1 - (int)j];
+        int64_t v = x[i] - (sum >> shift);
         if (v <= INT32_MIN || v > INT32_MAX) return 0;
         r[i] = (int32_t)v;
     }
@@ -546,12 +591,14 @@ static int lpc_residual(const int32_t *x, uint32_t n, const int32_t *q, uint32_t
 }
 
 /* ------------------------------------------------------------------ per candidate subframe */
-static uint32_t get_wasted_bits(int32_t *s, uint32_t n)
+/* wide: get_wasted_bits_wide_ (the 33-bit side channel of a 32-bit stream): an all-zero signal reports one wasted bit,
+ * which moves it to the 32-bit subframe path. */
+static uint32_t get_wasted_bits(int64_t *s, uint32_t n, int wide)
 {
     uint32_t i, shift;
-    int32_t x = 0;
+    int64_t x = 0;
     for (i = 0; i < n && !(x & 1); i++) x |= s[i];
-    if (x == 0) shift = 0;
+    if (x == 0) shift = wide ? 1 : 0;
     else for (shift = 0; !(x & 1); shift++) x >>= 1;
     if (shift > 0) for (i = 0; i < n; i++) s[i] >>= shift;
     return shift;
@@ -563,7 +610,7 @@ static uint32_t get_wasted_bits(int32_t *s, uint32_t n)
 static void process_subframe(const flo_config *c, enc_ws *w, uint32_t ch, uint32_t n, uint32_t min_po,
                              uint32_t max_po, flo_subframe_info *inf, int forbid_constant)
 {
-    const int32_t *x = w->sig[ch];
+    const int64_t *x = w->sig[ch];
     const uint32_t sbps = w->sbps[ch], wasted = w->wasted[ch];
     const uint32_t limit = c->bps > 16 ? 31 : 15; /* rice parameter limit, SURVEY A.1 */
     int best = 0;
@@ -699,7 +746,7 @@ static void process_subframe(const flo_config *c, enc_ws *w, uint32_t ch, uint32
 }
 
 /* ------------------------------------------------------------------ bitstream */
-static void write_subframe(bw_t *b, const sub_t *s, const int32_t *x, uint32_t n, uint32_t sbps, uint32_t wasted)
+static void write_subframe(bw_t *b, const sub_t *s, const int64_t *x, uint32_t n, uint32_t sbps, uint32_t wasted)
 {
     uint32_t hdr;
     switch (s->type) {
@@ -710,9 +757,9 @@ static void write_subframe(bw_t *b, const sub_t *s, const int32_t *x, uint32_t n
     }
     bw_bits(b, hdr | (wasted ? 1 : 0), 8);
     if (wasted) bw_unary(b, wasted - 1);
-    if (s->type == 0) { bw_bits64(b, (uint64_t)(int64_t)x[0], sbps); return; }
-    if (s->type == 1) { for (uint32_t i = 0; i < n; i++) bw_bits64(b, (uint64_t)(int64_t)x[i], sbps); return; }
-    for (uint32_t i = 0; i < s->order; i++) bw_bits64(b, (uint64_t)(int64_t)x[i], sbps);
+    if (s->type == 0) { bw_bits64(b, (uint64_t)x[0], sbps); return; }
+    if (s->type == 1) { for (uint32_t i = 0; i < n; i++) bw_bits64(b, (uint64_t)x[i], sbps); return; }
+    for (uint32_t i = 0; i < s->order; i++) bw_bits64(b, (uint64_t)x[i], sbps);
     if (s->type == 3) {
         bw_bits(b, s->precision - 1, 4);
         bw_bits(b, (uint32_t)s->shift, 5);
@@ -790,7 +837,7 @@ static enc_ws *get_ws(const flo_config *c, uint32_t n)
     w = (enc_ws *)calloc(1, sizeof *w);
     w->n = n < 4096 ? 4096 : n;
     for (int ch = 0; ch < FLO_MAX_CHANNELS; ch++) {
-        w->sig[ch] = (int32_t *)malloc(sizeof(int32_t) * (w->n + 8));
+        w->sig[ch] = (int64_t *)malloc(sizeof(int64_t) * (w->n + 8));
         for (int k = 0; k < 2; k++) {
             w->ws[ch][k].params = (uint32_t *)malloc(sizeof(uint32_t) << 15);
             w->ws[ch][k].residual = (int32_t *)malloc(sizeof(int32_t) * (w->n + 8));
@@ -827,7 +874,6 @@ size_t flo_encode_frame(const flo_config *c, const int32_t *in, uint32_t n, uint
         }
         else { do_indep = 1; do_ms = 1; }
     }
-    if (do_ms && c->bps == 32) return 0; /* 33-bit side channel: not restated (flac_oracle.h) */
     if (info) { memset(info, 0, sizeof *info); info->blocksize = n; }
 
     for (uint32_t ch = 0; ch < C; ch++)
@@ -844,13 +890,13 @@ size_t flo_encode_frame(const flo_config *c, const int32_t *in, uint32_t n, uint
 
     if (do_indep)
         for (uint32_t ch = 0; ch < C; ch++) {
-            uint32_t ws = get_wasted_bits(w->sig[ch], n);
+            uint32_t ws = get_wasted_bits(w->sig[ch], n, 0);
             if (ws > c->bps) ws = c->bps;
             w->wasted[ch] = ws; w->sbps[ch] = c->bps - ws;
         }
     if (do_ms)
         for (uint32_t k = 0; k < 2; k++) {
-            uint32_t ws = get_wasted_bits(w->sig[2 + k], n);
+            uint32_t ws = get_wasted_bits(w->sig[2 + k], n, k == 1 && c->bps == 32);
             if (ws > c->bps + 1) ws = c->bps + 1;
             w->wasted[2 + k] = ws; w->sbps[2 + k] = c->bps - ws + k;
         }
