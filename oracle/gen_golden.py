@@ -63,6 +63,26 @@ def main():
         lim[name] = {'total_bytes': len(stream), 'sha256': hashlib.sha256(stream).hexdigest(),
                      'frame_bytes': [len(c[0]) for c in cbs[3:]], 'pcm_hash': synth.pcm_hash(arr)}
         print('%-24s %8d bytes  %s' % (name, len(stream), lim[name]['sha256'][:16]))
+    # seeded random corpus (tests/fuzzgen.py): settings, sample formats and signal families well outside the named cases,
+    # incl. 32-bit stereo (33-bit side channel) and ragged blocks above 16 bit (the binary's AVX2 fixed-predictor sums)
+    from tests import fuzzgen
+    fz = {}
+    for seed in range(fuzzgen.GOLDEN_SEEDS):
+        c = fuzzgen.case(seed)
+        arr = c['pcm'].astype(np.int16 if c['bps'] == 16 else np.int32)
+        extra = []
+        if not c['subset']:
+            extra.append(('set_streamable_subset', 0))
+        if c['limit_min_bitrate']:
+            extra.append(('set_limit_min_bitrate', 1))
+        cbs, info = R.encode(arr, c['sr'], bps=c['bps'], level=c['level'], blocksize=c['bs'], extra=extra or None)
+        stream = b''.join(x[0] for x in cbs)
+        fz[str(seed)] = {'init_status': int(info['init_status']), 'total_bytes': len(stream),
+                         'sha256': hashlib.sha256(stream).hexdigest() if not info['init_status'] else '',
+                         'pcm_hash': synth.pcm_hash(c['pcm'].astype(np.int32))}
+    with open(os.path.join(cases.GOLDEN, 'fuzz_vectors.json'), 'w') as f:
+        json.dump(fz, f, indent=0, sort_keys=True, separators=(',', ':'))
+    print('fuzz corpus: %d cases' % len(fz))
     with open(os.path.join(cases.GOLDEN, 'limit_vectors.json'), 'w') as f:
         json.dump(lim, f, indent=0, sort_keys=True, separators=(',', ':'))
     gd = cases.GOLDEN

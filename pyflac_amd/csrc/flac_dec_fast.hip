@@ -748,7 +748,8 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
                             for (int e = 0; e < 4; e++) {
                                 int32_t av = (int32_t)(xa[e] << f_wa[R]), bv = (int32_t)(xb[e] << f_wb[R]);
                                 const uint32_t cc = f_ca[R];
-                                const i64 side = bv;
+                                // (32-bit streams: a side channel with wasted bits is a 33-bit value once shifted back)
+                                const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)xb[e] << f_wb[R]) : (i64)bv;
                                 const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
                                 const int32_t ma = (int32_t)((mid + side) >> 1), mb = (int32_t)((mid - side) >> 1);
                                 a[e] = cc == 2 ? av + bv : cc == 3 ? ma : av;
@@ -785,7 +786,7 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
                     if (cc == 1) b = a - b;
                     else if (cc == 2) a = a + b;
                     else if (cc == 3) {
-                        const i64 side = b;
+                        const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)tile[(r0 + 1) * FG_TRS + col] << wb) : (i64)b;
                         const i64 mid = (i64)(((u64)(i64)a) << 1) | (side & 1);
                         a = (int32_t)((mid + side) >> 1);
                         b = (int32_t)((mid - side) >> 1);

@@ -117,6 +117,7 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                       int32_t *scratch, int32_t *out, FgDecResult *results_all, const uint16_t *crctab, uint32_t interleave)
 {
     __shared__ int32_t ring[32 * 64];
+    __shared__ int32_t ring_hi[32 * 64];      // bit 32 and up of the history of a 33-bit side subframe
     __shared__ uint16_t crct[768];
     __shared__ uint32_t mult[64];
     __shared__ uint8_t wasted_s[64 * 8];
@@ -148,33 +149,48 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
             if (hdr & 1) { wasted = br.unary() + 1; if (wasted >= sb) { err = 1; break; } sb -= wasted; }
             wasted_s[lane * 8 + ch] = (uint8_t)wasted;
             if (sb > 33) { err = 1; break; }
-            const bool s33 = sb == 33;   // 33-bit side subframe: fields are read as sign + 32 bits and must fit int32
+            // 33-bit side subframe (the side channel of a 32-bit stream): values are carried in 64 bits.  Left/side and
+            // right/side only need the low word (the other channel is recovered in wrapping 32-bit arithmetic and fits);
+            // mid/side needs bit 32, so the stereo pair is resolved right here, sample by sample, and the frame is handed to
+            // phase 2 as two independent channels.
+            const bool s33 = sb == 33;
+            const bool ms33 = s33 && fr.ca == 3 && ch == 1;
+            const uint32_t wmid = ms33 ? wasted_s[lane * 8 + 0] : 0;
             const uint32_t t = (hdr >> 1) & 0x3F;
             int32_t *dst = planar + (size_t)ch * n;
-            auto sample = [&]() -> int32_t {
-                if (!s33) return br.sbits(sb);
+            auto sample = [&]() -> i64 {
+                if (!s33) return (i64)br.sbits(sb);
                 const uint32_t sgn = br.bits(1);
-                const int32_t lo = (int32_t)br.bits(32);
-                if ((sgn != 0) != (lo < 0)) err = 1;     // does not fit int32
-                return lo;
+                const uint32_t lo = br.bits(32);
+                return (i64)(((u64)(sgn ? 0xFFFFFFFFu : 0u) << 32) | lo);
+            };
+            auto store = [&](uint32_t i, i64 v) {
+                if (ms33) {
+                    const i64 m = (i64)planar[i] << wmid;
+                    const i64 mid2 = (i64)((u64)m << 1) | (v & 1);
+                    planar[i] = (int32_t)((mid2 + v) >> 1);
+                    dst[i] = (int32_t)((mid2 - v) >> 1);
+                }
+                else dst[i] = (int32_t)v;
             };
             if (t == 0) {
-                const int32_t v = sample();
-                for (uint32_t i = 0; i < n; i++) dst[i] = v;
+                const i64 v = sample();
+                for (uint32_t i = 0; i < n; i++) store(i, v);
             }
             else if (t == 1) {
-                for (uint32_t i = 0; i < n; i++) dst[i] = sample();
+                for (uint32_t i = 0; i < n; i++) store(i, sample());
             }
             else if ((t >= 8 && t <= 12) || t >= 32) {
                 const bool lpc = t >= 32;
                 const uint32_t order = lpc ? (t & 31) + 1 : (t & 7);
                 if (order > n) { err = 1; break; }
                 int32_t q[32];
-                int32_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+                i64 p1 = 0, p2 = 0, p3 = 0, p4 = 0;
                 for (uint32_t i = 0; i < order; i++) {
-                    const int32_t v = sample();
-                    dst[i] = v;
-                    ring[(i & 31) * 64 + lane] = v;
+                    const i64 v = sample();
+                    store(i, v);
+                    ring[(i & 31) * 64 + lane] = (int32_t)v;
+                    if (s33) ring_hi[(i & 31) * 64 + lane] = (int32_t)(v >> 32);
                     p4 = p3; p3 = p2; p2 = p1; p1 = v;
                 }
                 uint32_t prec = 0;
@@ -225,8 +241,30 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                         }
                         r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
                     }
-                    int32_t v;
-                    if (!lpc) {
+                    i64 v;
+                    if (s33) {
+                        if (!lpc) {
+                            switch (order) {
+                            case 0: v = r; break;
+                            case 1: v = (i64)r + p1; break;
+                            case 2: v = (i64)r + 2 * p1 - p2; break;
+                            case 3: v = (i64)r + 3 * p1 - 3 * p2 + p3; break;
+                            default: v = (i64)r + 4 * p1 - 6 * p2 + 4 * p3 - p4; break;
+                            }
+                            p4 = p3; p3 = p2; p2 = p1; p1 = v;
+                        }
+                        else {
+                            i64 sum = 0;
+                            for (uint32_t j = 0; j < order; j++) {
+                                const uint32_t sl = ((i - 1 - j) & 31) * 64 + lane;
+                                sum += (i64)q[j] * (i64)(((u64)(uint32_t)ring_hi[sl] << 32) | (uint32_t)ring[sl]);
+                            }
+                            v = (i64)r + (sum >> shift);
+                            ring[(i & 31) * 64 + lane] = (int32_t)v;
+                            ring_hi[(i & 31) * 64 + lane] = (int32_t)(v >> 32);
+                        }
+                    }
+                    else if (!lpc) {
                         // two's-complement wrap-around is exact whenever the true value fits int32
                         (void)fixwide;
                         switch (order) {
@@ -236,26 +274,27 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                         case 3: v = (int32_t)((uint32_t)r + 3u * (uint32_t)p1 - 3u * (uint32_t)p2 + (uint32_t)p3); break;
                         default: v = (int32_t)((uint32_t)r + 4u * (uint32_t)p1 - 6u * (uint32_t)p2 + 4u * (uint32_t)p3 - (uint32_t)p4); break;
                         }
-                        p4 = p3; p3 = p2; p2 = p1; p1 = v;
+                        p4 = p3; p3 = p2; p2 = p1; p1 = (int32_t)v;
                     }
                     else if (narrow) {
                         int32_t sum = 0;
                         for (uint32_t j = 0; j < order; j++) sum += q[j] * ring[((i - 1 - j) & 31) * 64 + lane];
                         v = r + (sum >> shift);
-                        ring[(i & 31) * 64 + lane] = v;
+                        ring[(i & 31) * 64 + lane] = (int32_t)v;
                     }
                     else {
                         i64 sum = 0;
                         for (uint32_t j = 0; j < order; j++) sum += (i64)q[j] * (i64)ring[((i - 1 - j) & 31) * 64 + lane];
                         v = (int32_t)((i64)r + (sum >> shift));
-                        ring[(i & 31) * 64 + lane] = v;
+                        ring[(i & 31) * 64 + lane] = (int32_t)v;
                     }
-                    dst[i] = v;
+                    store(i, v);
                     if (br.over) { err = 4; break; }
                 }
             }
             else { err = 1; break; }
             if (br.over) err = 4;
+            if (ms33) { wasted_s[lane * 8 + 0] = 0; fr.ca = 0; }      // already left / right
         }
         if (!err) {
             // zero padding to the byte boundary must end exactly at the CRC-16
@@ -317,7 +356,7 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
                 if (fca == 1) v[1] = v[0] - v[1];
                 else if (fca == 2) v[0] = v[0] + v[1];
                 else if (fca == 3) {
-                    const i64 side = v[1];
+                    const i64 side = (i64)((u64)(i64)pl[(size_t)fn + i] << ws[1]);     // 33 bits in a 32-bit stream
                     const i64 mid = (i64)(((u64)(i64)v[0]) << 1) | (side & 1);
                     v[0] = (int32_t)((mid + side) >> 1);
                     v[1] = (int32_t)((mid - side) >> 1);

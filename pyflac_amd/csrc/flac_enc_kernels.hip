@@ -150,6 +150,19 @@ struct Enc {
         return cval(c, L, R, w);
     }
 
+    // The side channel of a 32-bit stream has 33 bits (libFLAC's integer_signal_33bit_side).  It is never stored: the exact
+    // value is L - R in 64-bit arithmetic wherever it is needed.  is33: the candidate is that channel with no wasted bits
+    // (with wasted bits the shifted values fit int32 and take the ordinary path, get_wasted_bits_wide_).
+    __device__ __forceinline__ bool is33(int c, uint32_t w) const { return mode == 1 && c == 3 && wide && w == 0; }
+    __device__ __forceinline__ i64 get64(int c, uint32_t i, uint32_t w) const
+    {
+        if (mode == 1 && c == 3 && wide) {
+            const size_t j = (size_t)i * sstr;
+            return ((i64)s0[j] - (i64)s1[j]) >> w;
+        }
+        return (i64)get(c, i, w);
+    }
+
     // ---------------------------------------------------------------- staging
     __device__ void stage(const void *pcm, u64 pcm_off, uint32_t ch0, uint32_t nch)
     {
@@ -184,12 +197,12 @@ struct Enc {
     __device__ void wasted_bits(uint32_t dbase)
     {
         for (int c = 0; c < ncand; c++) {
-            uint32_t orl = 0, orh = 0, nofit = 0;
+            uint32_t orl = 0, orh = 0;
+            const bool side33 = mode == 1 && c == 3 && wide;
             for (uint32_t i = lane; i < n; i += 64) {
-                if (mode == 1 && c == 3 && wide) {
+                if (side33) {
                     i64 s = (i64)s0[(size_t)i * sstr] - (i64)s1[(size_t)i * sstr];
                     orl |= (uint32_t)s; orh |= (uint32_t)((u64)s >> 32);
-                    if (s != (i64)(int32_t)s) nofit = 1;
                 }
                 else orl |= (uint32_t)get(c, i, 0);
             }
@@ -197,32 +210,61 @@ struct Enc {
             uint32_t w = 0;
             if (orl) w = (uint32_t)__builtin_ctz(orl);
             else if (orh) w = 32;
+            else if (side33) w = 1;        // get_wasted_bits_wide_: an all-zero 33-bit signal reports one wasted bit
             uint32_t nominal = P.bps + ((mode == 1 && c == 3) ? 1u : 0u);
             if (w > nominal) w = nominal;
             uint32_t sb = nominal - w;
-            // a 33-bit side subframe is representable here as long as every value (after the wasted-bit shift)
-            // still fits int32; genuinely 33-bit values are refused
-            if (sb > 32 && __any(nofit)) { err |= FG_ERR_SIDE33; sb = 32; }
             if (lane == 0) { decs[dbase + c].wasted = w; decs[dbase + c].sbps = sb; }
         }
         lds_fence();
     }
 
     // ---------------------------------------------------------------- fixed predictor sums (L4)
+    // Error sums the way the reference binary's AVX2 routines take them (oracle/flac_oracle.c avx2_lane_sums): four lanes
+    // of len/4 samples whose histories sit at j*(len/4) while the lanes start at (j*len)/4.  Only called when len is not a
+    // multiple of four (otherwise this is the plain sum).  d(i) = sample 4+i of the block.
+    __device__ void lane_sums(int c, uint32_t w, uint32_t len, u64 a[5], uint32_t *inv)
+    {
+        const uint32_t q = len >> 2;
+        for (uint32_t idx = lane; idx < 4 * q; idx += 64) {
+            const uint32_t j = idx / q, i = idx - j * q;
+            const uint32_t hb = 4 + j * q, st = 4 + ((j * len) >> 2);
+            i64 v[5];
+            for (uint32_t m = 0; m < 5; m++) v[m] = i >= m ? get64(c, st + i - m, w) : get64(c, hb + i - m, w);
+            const i64 e[5] = {v[0], v[0] - v[1], v[0] - 2 * v[1] + v[2], v[0] - 3 * v[1] + 3 * v[2] - v[3],
+                              v[0] - 4 * v[1] + 6 * v[2] - 4 * v[3] + v[4]};
+            for (int k = 0; k < 5; k++) {
+                const u64 m = (u64)(e[k] < 0 ? -e[k] : e[k]);
+                a[k] += m;
+                if (m > 0x7FFFFFFFull) *inv |= 1u << k;
+            }
+        }
+    }
+
     __device__ uint32_t fixed_sums(int c, uint32_t w, uint32_t sb, u64 tot[5], float rb[5])
     {
         u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         uint32_t order;
+        const uint32_t len = n - 4;
         if (sb < 28) {
-            for (uint32_t i = 4 + lane; i < n; i += 64) {
-                int32_t v0 = get(c, i, w), v1 = get(c, i - 1, w), v2 = get(c, i - 2, w), v3 = get(c, i - 3, w),
-                        v4 = get(c, i - 4, w);
-                int32_t e1 = v0 - v1, d1 = v1 - v2, d2 = v2 - v3, d3 = v3 - v4;
-                int32_t e2 = e1 - d1, f2 = d1 - d2, g2 = d2 - d3;
-                int32_t e3 = e2 - f2, f3 = f2 - g2;
-                int32_t e4 = e3 - f3;
-                a0 += (uint32_t)abs(v0); a1 += (uint32_t)abs(e1); a2 += (uint32_t)abs(e2);
-                a3 += (uint32_t)abs(e3); a4 += (uint32_t)abs(e4);
+            // 32-bit accumulators (exact) while sb + ilog2((n-4)*17) < 32, else the _wide routine: AVX2 lanes, no remainder
+            if ((len & 3) == 0 || sb + ilog2_32(len * 17) < 32) {
+                for (uint32_t i = 4 + lane; i < n; i += 64) {
+                    int32_t v0 = get(c, i, w), v1 = get(c, i - 1, w), v2 = get(c, i - 2, w), v3 = get(c, i - 3, w),
+                            v4 = get(c, i - 4, w);
+                    int32_t e1 = v0 - v1, d1 = v1 - v2, d2 = v2 - v3, d3 = v3 - v4;
+                    int32_t e2 = e1 - d1, f2 = d1 - d2, g2 = d2 - d3;
+                    int32_t e3 = e2 - f2, f3 = f2 - g2;
+                    int32_t e4 = e3 - f3;
+                    a0 += (uint32_t)abs(v0); a1 += (uint32_t)abs(e1); a2 += (uint32_t)abs(e2);
+                    a3 += (uint32_t)abs(e3); a4 += (uint32_t)abs(e4);
+                }
+            }
+            else {
+                u64 a[5] = {0, 0, 0, 0, 0};
+                uint32_t inv = 0;
+                lane_sums(c, w, len, a, &inv);
+                a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3]; a4 = a[4];
             }
             tot[0] = wave_add64(a0); tot[1] = wave_add64(a1); tot[2] = wave_add64(a2);
             tot[3] = wave_add64(a3); tot[4] = wave_add64(a4);
@@ -234,17 +276,21 @@ struct Enc {
             else if (tot[2] <= m34) order = 2;
             else if (tot[3] <= tot[4]) order = 3;
             else order = 4;
-            const double len = (double)(n - 4);
+            const double dlen = (double)len;
             for (int k = 0; k < 5; k++)
-                rb[k] = (float)((tot[k] > 0) ? log(FG_LN2 * (double)tot[k] / len) / FG_LN2 : 0.0);
+                rb[k] = (float)((tot[k] > 0) ? log(FG_LN2 * (double)tot[k] / dlen) / FG_LN2 : 0.0);
         }
         else {
-            // sbps >= 28: libFLAC's _limit_residual variant (oracle/flac_oracle.c fixed_best_predictor)
+            // sbps >= 28: libFLAC's _limit_residual variants (oracle/flac_oracle.c fixed_best_predictor).  33 bit: plain
+            // sums over every sample.  <= 32 bit: warm-up positions + AVX2 lanes + the len%4 samples at the end.
             uint32_t inv = 0;
+            const bool lanes = sb <= 32 && (len & 3) != 0;
+            const uint32_t tail0 = 4 + (len & ~3u);
             for (uint32_t i = lane; i < n; i += 64) {
-                i64 v0 = get(c, i, w);
-                i64 v1 = i >= 1 ? (i64)get(c, i - 1, w) : 0, v2 = i >= 2 ? (i64)get(c, i - 2, w) : 0;
-                i64 v3 = i >= 3 ? (i64)get(c, i - 3, w) : 0, v4 = i >= 4 ? (i64)get(c, i - 4, w) : 0;
+                if (lanes && i >= 4 && i < tail0) continue;
+                i64 v0 = get64(c, i, w);
+                i64 v1 = i >= 1 ? get64(c, i - 1, w) : 0, v2 = i >= 2 ? get64(c, i - 2, w) : 0;
+                i64 v3 = i >= 3 ? get64(c, i - 3, w) : 0, v4 = i >= 4 ? get64(c, i - 4, w) : 0;
                 u64 e0 = (u64)(v0 < 0 ? -v0 : v0), e1 = 0, e2 = 0, e3 = 0, e4 = 0;
                 i64 t;
                 if (i >= 1) { t = v0 - v1; e1 = (u64)(t < 0 ? -t : t); }
@@ -258,16 +304,21 @@ struct Enc {
                 if (e3 > 0x7FFFFFFFull) inv |= 8;
                 if (e4 > 0x7FFFFFFFull) inv |= 16;
             }
+            if (lanes) {
+                u64 a[5] = {0, 0, 0, 0, 0};
+                lane_sums(c, w, len, a, &inv);
+                a0 += a[0]; a1 += a[1]; a2 += a[2]; a3 += a[3]; a4 += a[4];
+            }
             inv = wave_or(inv);
             tot[0] = wave_add64(a0); tot[1] = wave_add64(a1); tot[2] = wave_add64(a2);
             tot[3] = wave_add64(a3); tot[4] = wave_add64(a4);
             u64 smallest = ~0ull;
             order = 0;
-            const double len = (double)(n - 4);
+            const double dlen = (double)len;
             for (int k = 4; k >= 0; k--) {
                 if (!((inv >> k) & 1) && tot[k] <= smallest) {
                     order = (uint32_t)k; smallest = tot[k];
-                    rb[k] = (float)((tot[0] > 0) ? log(FG_LN2 * (double)tot[0] / len) / FG_LN2 : 0.0);
+                    rb[k] = (float)((tot[0] > 0) ? log(FG_LN2 * (double)tot[0] / dlen) / FG_LN2 : 0.0);
                 }
                 else rb[k] = 34.0f;
             }
@@ -277,9 +328,9 @@ struct Enc {
 
     __device__ bool is_constant(int c, uint32_t w)
     {
-        const int32_t x0 = get(c, 0, w);
+        const i64 x0 = get64(c, 0, w);
         uint32_t ne = 0;
-        for (uint32_t i = lane; i < n; i += 64) ne |= (get(c, i, w) != x0);
+        for (uint32_t i = lane; i < n; i += 64) ne |= (get64(c, i, w) != x0);
         return !__any(ne);
     }
 
@@ -307,9 +358,11 @@ struct Enc {
                     for (uint32_t j = lane; j < kn; j += 64) {
                         const uint32_t i = k0 + j;
                         float d;
-                        if (part == 0) d = (float)get(c0 + cc, i, w) * window[i];
-                        else if (i < part) d = (float)get(c0 + cc, sh + i, w) * window[i];
-                        else if (i < 2 * part) d = (float)get(c0 + cc, sh + i, w) * window[n - 2 * part + i];
+                        // (float)int64 for the 33-bit side channel: FLAC__lpc_window_data_wide
+                        const bool w33 = is33((int)(c0 + cc), w);
+                        if (part == 0) d = (w33 ? (float)get64(c0 + cc, i, w) : (float)get(c0 + cc, i, w)) * window[i];
+                        else if (i < part) d = (w33 ? (float)get64(c0 + cc, sh + i, w) : (float)get(c0 + cc, sh + i, w)) * window[i];
+                        else if (i < 2 * part) d = (w33 ? (float)get64(c0 + cc, sh + i, w) : (float)get(c0 + cc, sh + i, w)) * window[n - 2 * part + i];
                         else d = 0.0f;
                         dbuf[cc * DSTR + FG_DH + j] = (double)d;
                     }
@@ -459,6 +512,25 @@ struct Enc {
     __device__ __forceinline__ int32_t residual_at(int c, uint32_t w, uint32_t i, int kind, uint32_t order,
                                                    const int32_t *q, int shift, bool narrow, uint32_t *ovf) const
     {
+        if (is33(c, w)) {
+            // 33-bit side channel: 64-bit arithmetic (_wide_33bit / _limit_residual_33bit); a chosen predictor's residual fits
+            // int32 (fixed: guarded by the order guess; LPC: guarded here)
+            i64 r;
+            if (kind == 0) {
+                const i64 v0 = get64(c, i, w);
+                if (order == 0) r = v0;
+                else if (order == 1) r = v0 - get64(c, i - 1, w);
+                else if (order == 2) r = v0 - 2 * get64(c, i - 1, w) + get64(c, i - 2, w);
+                else if (order == 3) r = v0 - 3 * get64(c, i - 1, w) + 3 * get64(c, i - 2, w) - get64(c, i - 3, w);
+                else r = v0 - 4 * get64(c, i - 1, w) + 6 * get64(c, i - 2, w) - 4 * get64(c, i - 3, w) + get64(c, i - 4, w);
+                return (int32_t)r;
+            }
+            i64 sum = 0;
+            for (uint32_t j = 0; j < order; j++) sum += (i64)q[j] * get64(c, i - 1 - j, w);
+            r = get64(c, i, w) - (sum >> shift);
+            if (r <= (i64)INT32_MIN || r > (i64)INT32_MAX) *ovf = 1;
+            return (int32_t)r;
+        }
         if (kind == 0) {
             int32_t v0 = get(c, i, w);
             if (order == 0) return v0;
@@ -932,7 +1004,7 @@ struct Enc {
         // a sample field is sb bits wide; sb == 33 is sent as its sign bit followed by 32 bits
         const uint32_t sb_lo = sb > 32 ? 32 : sb, sb_hi = sb > 32 ? 1 : 0;
         if (type == 0) {
-            const int32_t v = get(c, 0, w);
+            const i64 v = get64(c, 0, w);
             bw_round(lane == 0 ? (uint32_t)(v < 0) : 0, lane == 0 ? sb_hi : 0, lane == 0 ? ((uint32_t)v & mask) : 0, lane == 0 ? sb_lo : 0,
                      lane == 0 ? sb_lo : 0);
             return;
@@ -941,14 +1013,14 @@ struct Enc {
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                 const uint32_t i = i0 + lane;
                 const bool on = i < n;
-                const int32_t v = on ? get(c, i, w) : 0;
+                const i64 v = on ? get64(c, i, w) : 0;
                 bw_round(on ? (uint32_t)(v < 0) : 0, on ? sb_hi : 0, on ? ((uint32_t)v & mask) : 0, on ? sb_lo : 0, on ? sb_lo : 0);
             }
             return;
         }
         {   // warm-up samples
             const bool on = (uint32_t)lane < order;
-            const int32_t v = on ? get(c, lane, w) : 0;
+            const i64 v = on ? get64(c, lane, w) : 0;
             bw_round(on ? (uint32_t)(v < 0) : 0, on ? sb_hi : 0, on ? ((uint32_t)v & mask) : 0, on ? sb_lo : 0, on ? sb_lo : 0);
         }
         const int32_t *q = d->q;

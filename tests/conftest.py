@@ -30,6 +30,15 @@ def damage_golden():
 
 
 @pytest.fixture(scope='session')
+def fuzz_golden():
+    """Reference hashes of the seeded random corpus (tests/fuzzgen.py seeds 0..GOLDEN_SEEDS-1; oracle/gen_golden.py)."""
+    import json
+    from tests import cases
+    with open(os.path.join(cases.GOLDEN, 'fuzz_vectors.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
 def limit_golden():
     """Reference output with FLAC__stream_encoder_set_limit_min_bitrate(true) (tests/cases.py LIMIT_CASES)."""
     import json

@@ -47,6 +47,32 @@ def test_batch_encode_matches_golden(ctx, golden, name):
     assert [int(x) for x in np.diff(offs)] == [c[0] for c in g['callbacks'][3:]]
 
 
+@pytest.mark.parametrize('chunk', range(6))
+def test_fuzz_corpus_matches_reference_hashes(ctx, fuzz_golden, chunk):
+    """Seeded random corpus (tests/fuzzgen.py; hashes recorded from the reference binary): the batch encoder is
+    byte-identical and the decoder returns the input, for 1-8 channels, 8-32 bit (32-bit stereo = 33-bit side channel),
+    every level, odd block sizes, ragged tails, limit_min_bitrate and non-subset settings."""
+    import torch
+    from pyflac_amd import batch
+    from pyflac_amd.encoder import stream_header_bytes
+    from tests import fuzzgen
+    for seed in range(chunk * 40, chunk * 40 + 40):
+        g = fuzz_golden[str(seed)]
+        c = fuzzgen.case(seed)
+        if g['init_status']:
+            with pytest.raises(batch.FlacGpuError):
+                batch.settings(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+            continue
+        s = batch.settings(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+        s.limit_min_bitrate = 1 if c['limit_min_bitrate'] else 0
+        t = torch.from_numpy(np.ascontiguousarray(c['pcm'].astype(np.int32))).cuda()
+        out, offs, st = ctx.encode(s, t)
+        stream = stream_header_bytes(s) + out[:st.total_bytes].cpu().numpy().tobytes()
+        assert len(stream) == g['total_bytes'] and hashlib.sha256(stream).hexdigest() == g['sha256'], seed
+        dec, status, _ = ctx.decode(out[:st.total_bytes], offs, c['ch'], c['bps'], len(c['pcm']))
+        assert int(status[:, 0].max()) == 0 and torch.equal(dec.reshape(-1, c['ch']), t), seed
+
+
 @pytest.mark.parametrize('name', sorted(cases.LIMIT_CASES))
 def test_limit_min_bitrate_matches_golden(ctx, limit_golden, name):
     """limit_min_bitrate through the batch entry point: byte-identical to the reference binary."""

@@ -51,6 +51,28 @@ def test_random_corpus(seed):
     _check(x, int(r.choice([44100, 48000, 96000, 22050])), bps, level, bs)
 
 
+@pytest.mark.parametrize('chunk', range(4))
+def test_fuzz_corpus_beyond_the_golden_seeds(chunk):
+    """tests/fuzzgen.py seeds past the ones with committed hashes (tools/fuzz_oracle_vs_ref.py runs thousands)."""
+    from tests import fuzzgen
+    for seed in range(fuzzgen.GOLDEN_SEEDS + chunk * 50, fuzzgen.GOLDEN_SEEDS + chunk * 50 + 50):
+        c = fuzzgen.case(seed)
+        arr = c['pcm'].astype(np.int16 if c['bps'] == 16 else np.int32)
+        extra = []
+        if not c['subset']:
+            extra.append(('set_streamable_subset', 0))
+        if c['limit_min_bitrate']:
+            extra.append(('set_limit_min_bitrate', 1))
+        cbs, info = R.encode(arr, c['sr'], bps=c['bps'], level=c['level'], blocksize=c['bs'], extra=extra or None)
+        cfg, rc = O.config(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+        assert rc == info['init_status'], seed
+        if rc:
+            continue
+        cfg.limit_min_bitrate = 1 if c['limit_min_bitrate'] else 0
+        mine, _ = O.encode_stream(cfg, arr)
+        assert mine == b''.join(x[0] for x in cbs), seed
+
+
 @pytest.mark.parametrize('status_case', [
     (5, 2, 16, 2000000, 0, True), (5, 2, 16, 44100, 1000000, True), (5, 2, 16, 44100, 65535, True),
     (5, 2, 16, 44100, 65535, False), (5, 9, 16, 44100, 0, True), (5, 2, 3, 44100, 0, True),
