@@ -156,6 +156,33 @@ class TestStreamEncoder:
         assert b''.join(chunks) == want
 
 
+    def test_int32_stereo_full_scale(self):
+        """pyFLAC's int32 path (pyflac/encoder.py:109: int32 input -> 32 bps): full-scale stereo has a 33-bit side channel.
+        With verify on; stream equals the oracle's, and the decoder returns the int32 input."""
+        import pyflac_amd
+        from oracle import oracle as O
+        r = np.random.default_rng(33)
+        n = 4 * 4096 + 1234
+        t = np.arange(n)[:, None]
+        x = 2.0e9 * np.sin(t * np.array([0.01, 0.013])) + r.normal(0, 5e7, (n, 2))
+        x[4096:8192, 1] = -x[4096:8192, 0]                        # anti-phase: side = 2L, 33 bits once its wasted bit is restored
+        x[8192:12288, 1] = -x[8192:12288, 0] + r.integers(-3, 4, 4096)   # anti-phase + noise: a side channel with all 33 bits
+        x[12288:, 1] = x[12288:, 0] + r.integers(-3, 4, n - 12288) * 2
+        pcm = np.clip(np.round(x), -2**31, 2**31 - 1).astype(np.int32)
+        chunks, blocks = [], []
+        enc = pyflac_amd.StreamEncoder(48000, lambda b, nb, s, f: chunks.append(b), compression_level=5, blocksize=4096, verify=True)
+        enc.process(pcm)
+        assert enc.finish()
+        cfg, _ = O.config(5, 2, 32, 48000, 4096)
+        want, _sizes = O.encode_stream(cfg, pcm)
+        assert b''.join(chunks) == want
+        dec = pyflac_amd.StreamDecoder(lambda a, sr, ch, ns: blocks.append(a))
+        dec.process(b''.join(chunks))
+        dec.finish()
+        got = np.concatenate(blocks, axis=0)
+        assert got.dtype == np.int32 and np.array_equal(got, pcm)
+
+
 class TestPassthrough:
     def test_encoder_to_decoder(self):
         """BASELINE config 1 (examples/passthrough.py): every decoded block equals the input slice."""
