@@ -30,6 +30,16 @@ def damage_golden():
 
 
 @pytest.fixture(scope='session')
+def handmade_streams():
+    """Streams outside any encoder's repertoire with the PCM the reference binary decoded from them
+    (oracle/gen_golden_handmade.py): name -> (stream bytes, pcm int32[n, ch])."""
+    import numpy as np
+    from tests import cases
+    z = np.load(os.path.join(cases.GOLDEN, 'handmade_streams.npz'))
+    return {k[:-5]: (z[k].tobytes(), z[k[:-5] + '.pcm']) for k in z.files if k.endswith('.flac')}
+
+
+@pytest.fixture(scope='session')
 def fuzz_golden():
     """Reference hashes of the seeded random corpus (tests/fuzzgen.py seeds 0..GOLDEN_SEEDS-1; oracle/gen_golden.py)."""
     import json

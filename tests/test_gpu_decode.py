@@ -96,3 +96,22 @@ def test_device_resident_frame_index(ctx):
     b, sb, _ = ctx.decode(out[:st.total_bytes], offs.cpu().numpy(), 2, 16, len(pcm))
     assert int(sa[:, 0].max()) == 0 and np.array_equal(sa, sb)
     assert torch.equal(a, b) and torch.equal(a.reshape(-1, 2), t)
+
+
+@pytest.mark.parametrize('name', ['eight_ch', 'escape16', 'rice2_24', 'side33', 'variable'])
+def test_handmade_streams(ctx, name, handmade_streams):
+    """Streams no libFLAC encoder writes (escape-coded partitions under both coding methods, partition order 8, LPC
+    order 32 / 15-bit coefficients / shift 0, variable block sizes with every header form and 36-bit sample numbers,
+    wasted bits, 8 channels, 33-bit side channels): same PCM as the reference binary, through the batch entry point and
+    through the FLAC__stream_decoder_* callbacks."""
+    import torch
+    from pyflac_amd import batch
+    from tests import abi_decode
+    data, pcm = handmade_streams[name]
+    offs, si = batch.index_frames(data)
+    buf = torch.frombuffer(bytearray(data) + bytearray(64), dtype=torch.uint8).cuda()
+    got, status, st = ctx.decode(buf, offs, si.channels, si.bits_per_sample, len(pcm))
+    assert int(status[:, 0].max()) == 0
+    assert np.array_equal(got.cpu().numpy().reshape(pcm.shape), pcm)
+    res = abi_decode.decode(data)
+    assert not res['errors'] and np.array_equal(np.concatenate(res['blocks']).reshape(pcm.shape), pcm)

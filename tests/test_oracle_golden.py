@@ -135,3 +135,13 @@ def test_crc_known_answers():
 def test_md5_known_answer():
     a = np.frombuffer(b'ab', np.int16).reshape(1, 1)
     assert O.md5_pcm(a, 16).hex() == hashlib.md5(b'ab').hexdigest()
+
+
+@pytest.mark.parametrize('name', ['eight_ch', 'escape16', 'rice2_24', 'side33', 'variable'])
+def test_decoder_on_handmade_streams(name, handmade_streams):
+    """Escape-coded partitions, RICE2, partition order 8, LPC order 32, variable block sizes and every header form,
+    33-bit side channels: the oracle decoder returns what the reference binary returned."""
+    data, pcm = handmade_streams[name]
+    out, res = O.decode_stream(data)
+    assert res.n_errors == 0
+    assert np.array_equal(out.reshape(pcm.shape), pcm)
