@@ -214,6 +214,29 @@ class TestFileEncoderDecoder:
         audio, rate = dec.process()
         assert rate == sr and np.array_equal(audio.astype(np.int64), np.asarray(pcm).reshape(audio.shape))
 
+    def test_command_line(self, wavs, golden):
+        """python -m pyflac_amd (the reference's `pyflac` tool, pyflac/__main__.py:35-56): WAV -> FLAC -> WAV by file magic,
+        default output names, and the reference's inverted -v flag."""
+        import hashlib
+        import shutil
+        from pyflac_amd import __main__ as cli
+        from pyflac_amd import wav
+        p, pcm, sr, bps = wavs['stereo']
+        d = pathlib.Path(tempfile.mkdtemp())
+        src = d / 'clip.wav'
+        shutil.copy(p, src)
+        assert cli.parse([str(src)]).verify is True and cli.parse([str(src), '-v']).verify is False
+        assert cli.main([str(src)]) == 0
+        flac = d / 'clip.flac'
+        assert hashlib.sha256(flac.read_bytes()).hexdigest() == golden['fixture_stereo_l5']['file_sha256']
+        assert cli.main([str(flac), '-o', str(d / 'back.wav')]) == 0
+        audio, winfo = wav.read(d / 'back.wav')
+        assert winfo.samplerate == sr and np.array_equal(np.asarray(audio).astype(np.int64), np.asarray(pcm).reshape(np.asarray(audio).shape))
+        junk = d / 'junk.bin'
+        junk.write_bytes(b'OggS' + bytes(60))
+        with pytest.raises(ValueError):
+            cli.main([str(junk)])
+
     def test_missing_input_raises(self):
         import pyflac_amd
         with pytest.raises(pyflac_amd.DecoderInitException, match='ERROR_OPENING_FILE'):
