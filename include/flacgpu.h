@@ -96,7 +96,9 @@ typedef struct {
     struct FLAC__StreamDecoderPrivate *private_;
 } FLAC__StreamDecoder;
 
-/* ---- metadata (pyflac/builder/encoder.py:117-248).  Only STREAMINFO is ever produced. */
+/* ---- metadata (pyflac/builder/encoder.py:117-248, format.h:506-880).  The encoder produces STREAMINFO (and the vendor
+ * VORBIS_COMMENT in the stream header); the decoder parses every block type and hands the ones the client asked for
+ * (FLAC__stream_decoder_set_metadata_respond*) to the metadata callback.  Field order and types are the ABI. */
 typedef enum {
     FLAC__METADATA_TYPE_STREAMINFO = 0,
     FLAC__METADATA_TYPE_PADDING = 1,
@@ -119,14 +121,87 @@ typedef struct {
     FLAC__byte md5sum[16];
 } FLAC__StreamMetadata_StreamInfo;
 
+typedef struct { int dummy; } FLAC__StreamMetadata_Padding;
+
+typedef struct {
+    FLAC__byte id[4];
+    FLAC__byte *data;                  /* length - 4 bytes */
+} FLAC__StreamMetadata_Application;
+
+typedef struct {
+    FLAC__uint64 sample_number;
+    FLAC__uint64 stream_offset;
+    uint32_t frame_samples;
+} FLAC__StreamMetadata_SeekPoint;
+
+typedef struct {
+    uint32_t num_points;
+    FLAC__StreamMetadata_SeekPoint *points;
+} FLAC__StreamMetadata_SeekTable;
+
+typedef struct {
+    FLAC__uint32 length;
+    FLAC__byte *entry;                 /* NUL-terminated copy of the length bytes */
+} FLAC__StreamMetadata_VorbisComment_Entry;
+
+typedef struct {
+    FLAC__StreamMetadata_VorbisComment_Entry vendor_string;
+    FLAC__uint32 num_comments;
+    FLAC__StreamMetadata_VorbisComment_Entry *comments;
+} FLAC__StreamMetadata_VorbisComment;
+
+typedef struct {
+    FLAC__uint64 offset;
+    FLAC__byte number;
+} FLAC__StreamMetadata_CueSheet_Index;
+
+typedef struct {
+    FLAC__uint64 offset;
+    FLAC__byte number;
+    char isrc[13];
+    uint32_t type : 1;
+    uint32_t pre_emphasis : 1;
+    FLAC__byte num_indices;
+    FLAC__StreamMetadata_CueSheet_Index *indices;
+} FLAC__StreamMetadata_CueSheet_Track;
+
+typedef struct {
+    char media_catalog_number[129];
+    FLAC__uint64 lead_in;
+    FLAC__bool is_cd;
+    uint32_t num_tracks;
+    FLAC__StreamMetadata_CueSheet_Track *tracks;
+} FLAC__StreamMetadata_CueSheet;
+
+typedef int FLAC__StreamMetadata_Picture_Type;   /* format.h:734-758: 0 other ... 3 front cover ... 20 publisher logotype */
+
+typedef struct {
+    FLAC__StreamMetadata_Picture_Type type;
+    char *mime_type;
+    FLAC__byte *description;
+    FLAC__uint32 width;
+    FLAC__uint32 height;
+    FLAC__uint32 depth;
+    FLAC__uint32 colors;
+    FLAC__uint32 data_length;
+    FLAC__byte *data;
+} FLAC__StreamMetadata_Picture;
+
+typedef struct { FLAC__byte *data; } FLAC__StreamMetadata_Unknown;
+
 typedef struct {
     FLAC__MetadataType type;
     FLAC__bool is_last;
     uint32_t length;
     union {
         FLAC__StreamMetadata_StreamInfo stream_info;
-        /* the largest member of libFLAC's union is the cue sheet (160 bytes on LP64) */
-        unsigned char reserve_[160];
+        FLAC__StreamMetadata_Padding padding;
+        FLAC__StreamMetadata_Application application;
+        FLAC__StreamMetadata_SeekTable seek_table;
+        FLAC__StreamMetadata_VorbisComment vorbis_comment;
+        FLAC__StreamMetadata_CueSheet cue_sheet;
+        FLAC__StreamMetadata_Picture picture;
+        FLAC__StreamMetadata_Unknown unknown;
     } data;
 } FLAC__StreamMetadata;
 

@@ -422,7 +422,8 @@ struct DecImpl {
     void *client;
     FILE *file;
     bool own_file;
-    bool respond_streaminfo;
+    bool respond[128];                          // metadata filter by block type (stream_decoder.h:849-973)
+    std::vector<uint32_t> app_ids;              // APPLICATION ids whose filter is the opposite of respond[APPLICATION]
     flacgpu_ctx *ctx;
     // stream state
     std::vector<uint8_t> buf;       // bytes not yet consumed (from `base` on)
@@ -499,6 +500,162 @@ void report_errors(DecImpl *d)
     }
 }
 
+// Hand the metadata blocks of d[4 .. end) to the metadata callback, in stream order, filtered the way libFLAC's
+// read_metadata_ does (stream_decoder.h:849-973: by type; APPLICATION blocks also by id).  All multi-byte fields are
+// big-endian except the VORBIS_COMMENT lengths (format.h:600-880).
+void deliver_metadata(DecImpl *d, const uint8_t *buf, uint64_t end)
+{
+    auto be = [](const uint8_t *p, int n) { uint64_t v = 0; for (int i = 0; i < n; i++) v = (v << 8) | p[i]; return v; };
+    auto le32 = [](const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    uint64_t pos = 4;
+    while (pos + 4 <= end) {
+        const uint32_t last = buf[pos] >> 7, type = buf[pos] & 0x7F;
+        const uint32_t len = (uint32_t)be(buf + pos + 1, 3);
+        const uint8_t *b = buf + pos + 4;
+        pos += 4 + (uint64_t)len;
+        if (pos > end) break;
+        bool want = d->respond[type];
+        if (type == FLAC__METADATA_TYPE_APPLICATION && len >= 4) {
+            const uint32_t id = (uint32_t)be(b, 4);
+            for (uint32_t x : d->app_ids) if (x == id) { want = !want; break; }
+        }
+        if (!want) { if (last) break; continue; }
+        FLAC__StreamMetadata m;
+        memset(&m, 0, sizeof m);
+        m.type = (FLAC__MetadataType)type; m.is_last = (FLAC__bool)last; m.length = len;
+        // owned storage of the variable-size members; lives until the callback returns
+        std::vector<std::vector<uint8_t>> blobs;
+        auto keep = [&](const uint8_t *p, size_t n, bool nul) -> FLAC__byte * {
+            blobs.emplace_back(p, p + n);
+            if (nul) blobs.back().push_back(0);
+            if (blobs.back().empty()) blobs.back().push_back(0);
+            return blobs.back().data();
+        };
+        std::vector<FLAC__StreamMetadata_SeekPoint> points;
+        std::vector<FLAC__StreamMetadata_VorbisComment_Entry> comments;
+        std::vector<FLAC__StreamMetadata_CueSheet_Track> tracks;
+        std::vector<std::vector<FLAC__StreamMetadata_CueSheet_Index>> indices;
+        bool ok = true;
+        switch (type) {
+        case FLAC__METADATA_TYPE_STREAMINFO:
+            if (len < 34 || !d->have_si) ok = false;
+            else m.data.stream_info = d->si;
+            break;
+        case FLAC__METADATA_TYPE_PADDING:
+            break;
+        case FLAC__METADATA_TYPE_APPLICATION:
+            if (len < 4) { ok = false; break; }
+            memcpy(m.data.application.id, b, 4);
+            m.data.application.data = len > 4 ? keep(b + 4, len - 4, false) : nullptr;
+            break;
+        case FLAC__METADATA_TYPE_SEEKTABLE: {
+            const uint32_t np = len / 18;
+            points.resize(np);
+            for (uint32_t i = 0; i < np; i++) {
+                points[i].sample_number = be(b + 18 * i, 8);
+                points[i].stream_offset = be(b + 18 * i + 8, 8);
+                points[i].frame_samples = (uint32_t)be(b + 18 * i + 16, 2);
+            }
+            m.data.seek_table.num_points = np;
+            m.data.seek_table.points = np ? points.data() : nullptr;
+            break;
+        }
+        case FLAC__METADATA_TYPE_VORBIS_COMMENT: {
+            // libFLAC tolerates truncated blocks by dropping what does not fit (stream_decoder.c read_metadata_vorbiscomment_)
+            uint32_t o = 0;
+            FLAC__StreamMetadata_VorbisComment &vc = m.data.vorbis_comment;
+            if (len >= 8 && le32(b) <= len - 8) {
+                vc.vendor_string.length = le32(b);
+                vc.vendor_string.entry = keep(b + 4, vc.vendor_string.length, true);
+                o = 4 + vc.vendor_string.length;
+                uint32_t nc = le32(b + o);
+                o += 4;
+                if (nc > 100000) nc = 0;
+                for (uint32_t i = 0; i < nc; i++) {
+                    if (o + 4 > len) break;
+                    const uint32_t l = le32(b + o);
+                    if (l > len - o - 4) break;
+                    FLAC__StreamMetadata_VorbisComment_Entry e;
+                    e.length = l; e.entry = keep(b + o + 4, l, true);
+                    comments.push_back(e);
+                    o += 4 + l;
+                }
+                vc.num_comments = (uint32_t)comments.size();
+                vc.comments = comments.empty() ? nullptr : comments.data();
+            }
+            break;
+        }
+        case FLAC__METADATA_TYPE_CUESHEET: {
+            if (len < 396) { ok = false; break; }
+            FLAC__StreamMetadata_CueSheet &cs = m.data.cue_sheet;
+            memcpy(cs.media_catalog_number, b, 128);
+            cs.media_catalog_number[128] = 0;
+            cs.lead_in = be(b + 128, 8);
+            cs.is_cd = b[136] >> 7;
+            const uint32_t nt = b[395];
+            uint32_t o = 396;
+            tracks.resize(nt);
+            indices.resize(nt);
+            for (uint32_t t = 0; t < nt && ok; t++) {
+                if (o + 36 > len) { ok = false; break; }
+                FLAC__StreamMetadata_CueSheet_Track &tr = tracks[t];
+                memset(&tr, 0, sizeof tr);
+                tr.offset = be(b + o, 8);
+                tr.number = b[o + 8];
+                memcpy(tr.isrc, b + o + 9, 12);
+                tr.isrc[12] = 0;
+                tr.type = b[o + 21] >> 7;
+                tr.pre_emphasis = (b[o + 21] >> 6) & 1;
+                tr.num_indices = b[o + 35];
+                o += 36;
+                indices[t].resize(tr.num_indices);
+                for (uint32_t k = 0; k < tr.num_indices; k++) {
+                    if (o + 12 > len) { ok = false; break; }
+                    indices[t][k].offset = be(b + o, 8);
+                    indices[t][k].number = b[o + 8];
+                    o += 12;
+                }
+                tr.indices = tr.num_indices ? indices[t].data() : nullptr;
+            }
+            cs.num_tracks = nt;
+            cs.tracks = nt ? tracks.data() : nullptr;
+            break;
+        }
+        case FLAC__METADATA_TYPE_PICTURE: {
+            FLAC__StreamMetadata_Picture &pc = m.data.picture;
+            uint32_t o = 0;
+            auto need = [&](uint32_t nbytes) { if ((uint64_t)o + nbytes > len) { ok = false; return false; } return true; };
+            if (!need(8)) break;
+            pc.type = (FLAC__StreamMetadata_Picture_Type)be(b, 4);
+            uint32_t l = (uint32_t)be(b + 4, 4);
+            o = 8;
+            if (!need(l)) break;
+            pc.mime_type = (char *)keep(b + o, l, true);
+            o += l;
+            if (!need(4)) break;
+            l = (uint32_t)be(b + o, 4);
+            o += 4;
+            if (!need(l)) break;
+            pc.description = keep(b + o, l, true);
+            o += l;
+            if (!need(20)) break;
+            pc.width = (uint32_t)be(b + o, 4); pc.height = (uint32_t)be(b + o + 4, 4);
+            pc.depth = (uint32_t)be(b + o + 8, 4); pc.colors = (uint32_t)be(b + o + 12, 4);
+            pc.data_length = (uint32_t)be(b + o + 16, 4);
+            o += 20;
+            if (!need(pc.data_length)) break;
+            pc.data = pc.data_length ? keep(b + o, pc.data_length, false) : nullptr;
+            break;
+        }
+        default:
+            m.data.unknown.data = len ? keep(b, len, false) : nullptr;
+            break;
+        }
+        if (ok) d->meta_cb(&d->pub, &m, d->client);
+        if (last) break;
+    }
+}
+
 bool ensure_metadata(DecImpl *d)
 {
     while (!d->have_meta) {
@@ -522,13 +679,7 @@ bool ensure_metadata(DecImpl *d)
         }
         d->have_meta = true;
         d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
-        if (d->meta_cb && d->have_si && d->respond_streaminfo) {
-            FLAC__StreamMetadata m;
-            memset(&m, 0, sizeof m);
-            m.type = FLAC__METADATA_TYPE_STREAMINFO; m.is_last = 0; m.length = 34;
-            m.data.stream_info = d->si;
-            d->meta_cb(&d->pub, &m, d->client);
-        }
+        if (d->meta_cb) deliver_metadata(d, d->buf.data(), (uint64_t)a);
         d->buf.erase(d->buf.begin(), d->buf.begin() + a);
         d->consumed_total += (uint64_t)a;
     }
@@ -735,7 +886,8 @@ FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
     d->pub.protected_ = nullptr; d->pub.private_ = nullptr;
     d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
     d->md5_checking = 0; d->read_cb = nullptr; d->write_cb = nullptr; d->meta_cb = nullptr; d->error_cb = nullptr;
-    d->client = nullptr; d->file = nullptr; d->own_file = false; d->respond_streaminfo = true; d->ctx = nullptr;
+    d->client = nullptr; d->file = nullptr; d->own_file = false; d->ctx = nullptr;
+    memset(d->respond, 0, sizeof d->respond); d->respond[FLAC__METADATA_TYPE_STREAMINFO] = true; d->app_ids.clear();
     reset_stream(d);
     return &d->pub;
 }
@@ -760,31 +912,49 @@ FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *dec, FLAC_
 FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *dec, FLAC__MetadataType type)
 {
     DecImpl *d = impl(dec);
-    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
-    if (type == FLAC__METADATA_TYPE_STREAMINFO) d->respond_streaminfo = true;
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED || (uint32_t)type > FLAC__MAX_METADATA_TYPE) return 0;
+    d->respond[type] = true;
+    if (type == FLAC__METADATA_TYPE_APPLICATION) d->app_ids.clear();
     return 1;
 }
-FLAC__bool FLAC__stream_decoder_set_metadata_respond_application(FLAC__StreamDecoder *dec, const FLAC__byte[4]) { return impl(dec)->state == FLAC__STREAM_DECODER_UNINITIALIZED; }
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_application(FLAC__StreamDecoder *dec, const FLAC__byte id[4])
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED || !id) return 0;
+    if (d->respond[FLAC__METADATA_TYPE_APPLICATION]) return 1;          // already responding to every id
+    d->app_ids.push_back(((uint32_t)id[0] << 24) | ((uint32_t)id[1] << 16) | ((uint32_t)id[2] << 8) | id[3]);
+    return 1;
+}
 FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *dec)
 {
     DecImpl *d = impl(dec);
     if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
-    d->respond_streaminfo = true;
+    for (bool &r : d->respond) r = true;
+    d->app_ids.clear();
     return 1;
 }
 FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *dec, FLAC__MetadataType type)
 {
     DecImpl *d = impl(dec);
-    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
-    if (type == FLAC__METADATA_TYPE_STREAMINFO) d->respond_streaminfo = false;
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED || (uint32_t)type > FLAC__MAX_METADATA_TYPE) return 0;
+    d->respond[type] = false;
+    if (type == FLAC__METADATA_TYPE_APPLICATION) d->app_ids.clear();
     return 1;
 }
-FLAC__bool FLAC__stream_decoder_set_metadata_ignore_application(FLAC__StreamDecoder *dec, const FLAC__byte[4]) { return impl(dec)->state == FLAC__STREAM_DECODER_UNINITIALIZED; }
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_application(FLAC__StreamDecoder *dec, const FLAC__byte id[4])
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED || !id) return 0;
+    if (!d->respond[FLAC__METADATA_TYPE_APPLICATION]) return 1;         // already ignoring every id
+    d->app_ids.push_back(((uint32_t)id[0] << 24) | ((uint32_t)id[1] << 16) | ((uint32_t)id[2] << 8) | id[3]);
+    return 1;
+}
 FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *dec)
 {
     DecImpl *d = impl(dec);
     if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
-    d->respond_streaminfo = false;
+    for (bool &r : d->respond) r = false;
+    d->app_ids.clear();
     return 1;
 }
 
@@ -878,7 +1048,7 @@ FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *dec)
     }
     d->md5_checking = 0;
     reset_stream(d);
-    d->respond_streaminfo = true;
+    memset(d->respond, 0, sizeof d->respond); d->respond[FLAC__METADATA_TYPE_STREAMINFO] = true; d->app_ids.clear();
     d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
     return md5_ok;
 }

@@ -225,3 +225,50 @@ def md5_stream(name):
     elif edit == 'zero':
         data[26:42] = bytes(16)
     return bytes(data)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Metadata pass-through on decode.  A stream with one block of every kind in front of a single small frame, and the
+# filter set-ups to read it (and the fixtures) with.
+def metadata_stream():
+    import struct
+
+    def block(t, body, last=False):
+        return bytes([(0x80 if last else 0) | t]) + len(body).to_bytes(3, 'big') + body
+
+    with open(os.path.join(GOLDEN, 'data', 'mono.flac'), 'rb') as f:
+        mono = f.read()
+    si = mono[8:42]
+    frame = mono[8304:10663]                                  # first audio frame of the fixture
+    vc = struct.pack('<I', 6) + b'vendor' + struct.pack('<I', 3) + b''.join(struct.pack('<I', len(c)) + c for c in
+                                                                           (b'TITLE=probe', b'ARTIST=\xc3\xa9', b'EMPTY='))
+    seek = b''.join(struct.pack('>QQH', *p) for p in ((0, 0, 4096), (4096, 2359, 4096), (0xFFFFFFFFFFFFFFFF, 0, 0)))
+    cue_track = lambda off, num, isrc, flags, idx: (struct.pack('>QB', off, num) + isrc.ljust(12, b'\0') + bytes([flags]) + bytes(13) +
+                                                    bytes([len(idx)]) + b''.join(struct.pack('>QB', o, n) + bytes(3) for o, n in idx))
+    cue = (b'1234567890123'.ljust(128, b'\0') + struct.pack('>Q', 88200) + bytes([0x80]) + bytes(258) + bytes([2]) +
+           cue_track(0, 1, b'USRC17607839', 0x40, [(0, 0), (588, 1)]) + cue_track(44100 * 60, 170, b'', 0x80, []))
+    pic = (struct.pack('>I', 3) + struct.pack('>I', 9) + b'image/png' + struct.pack('>I', 5) + b'cover' +
+           struct.pack('>IIII', 4, 3, 24, 0) + struct.pack('>I', 10) + bytes(range(10)))
+    blocks = [block(0, si), block(2, b'riff' + b'payload-1'), block(1, bytes(37)), block(3, seek), block(4, vc),
+              block(2, b'aiff'), block(5, cue), block(6, pic), block(42, b'unknown block body'), block(1, b'', last=True)]
+    return b'fLaC' + b''.join(blocks) + frame
+
+
+METADATA_SETUPS = {
+    'default': [],
+    'all': [('respond_all',)],
+    'none': [('ignore_all',)],
+    'seektable_only': [('ignore_all',), ('respond', 3)],
+    'all_but_padding': [('respond_all',), ('ignore', 1)],
+    'one_app': [('ignore_all',), ('respond_app', b'aiff')],
+    'all_but_one_app': [('respond_all',), ('ignore_app', b'riff')],
+    'vc_and_pic': [('respond', 4), ('respond', 6), ('ignore', 0)],
+}
+METADATA_STREAMS = ['handmade', 'stereo', 'surround', '32bit']
+
+
+def metadata_input(name):
+    if name == 'handmade':
+        return metadata_stream()
+    with open(os.path.join(GOLDEN, 'data', name + '.flac'), 'rb') as f:
+        return f.read()

@@ -342,3 +342,22 @@ class TestMd5Checking:
         got = abi_decode.decode(cases.md5_stream(name), md5_checking=cases.MD5_CASES[name][2])
         assert got['finish'] == want['finish']
         assert len(got['frames']) == want['frames'] and got['errors'] == want['errors']
+
+
+class TestMetadataPassThrough:
+    """every metadata block type reaches the metadata callback as the FLAC__StreamMetadata structure
+    libFLAC builds, under the respond / ignore filters -- field by field against tests/golden/metadata_vectors.json
+    (recorded from the reference binary by oracle/gen_golden_metadata.py)."""
+
+    @pytest.mark.parametrize('setup', sorted(cases.METADATA_SETUPS))
+    @pytest.mark.parametrize('stream', cases.METADATA_STREAMS)
+    def test_blocks_equal_the_reference(self, stream, setup):
+        import json
+        from pyflac_amd import _lib
+        from tests import abi_decode
+        with open(os.path.join(cases.GOLDEN, 'metadata_vectors.json')) as f:
+            want = json.load(f)['%s/%s' % (stream, setup)]
+        got = abi_decode.read_metadata(_lib.lib(), cases.metadata_input(stream), cases.METADATA_SETUPS[setup])
+        assert got['ok'] == want['ok']
+        assert [b['type'] for b in got['blocks']] == [b['type'] for b in want['blocks']]
+        assert got['blocks'] == want['blocks']
