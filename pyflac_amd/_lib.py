@@ -118,6 +118,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           '(there is no CPU fallback)' % LIB_PATH)
+    # torch carries its own copy of the HIP runtime; whichever copy is loaded first serves the whole process, and a second
+    # one finds no device.  torch owns the device memory this package hands to the library, so its runtime goes first.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.FLAC__stream_encoder_new.restype = vp
