@@ -125,7 +125,8 @@ struct Indexer {
     uint64_t frame_start = 0;     // start of the frame being delimited (valid header already confirmed)
     bool in_frame = false;
     uint64_t scan = 0;            // next byte to examine
-    uint16_t crc = 0;             // running CRC-16 over [frame_start, scan)
+    uint16_t crc = 0;             // running CRC-16 over [frame_start, crc_pos)
+    uint64_t crc_pos = 0;         // the CRC is brought up to date only where a sync code shows up (crc_to)
     uint64_t max_len = 0;         // longest a frame with the current header can be (anything longer is damaged)
     uint64_t cur_number = 0;      // frame / sample number of the frame being delimited
     uint32_t cur_n = 0, cur_variable = 0;
@@ -134,6 +135,37 @@ struct Indexer {
     std::vector<uint32_t> errors; // FLAC__StreamDecoderErrorStatus to report, in stream order
     std::vector<uint64_t> error_pos;
 
+    // CRC-16 (x^16 + x^15 + x^2 + 1, MSB first), eight bytes per step: T[k][x] = CRC of byte x followed by k zero bytes
+    static const uint16_t (*tables())[256]
+    {
+        static uint16_t T[8][256];
+        static bool ok = false;
+        if (!ok) {
+            for (int i = 0; i < 256; i++) {
+                uint16_t c = (uint16_t)(i << 8);
+                for (int b = 0; b < 8; b++) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1));
+                T[0][i] = c;
+            }
+            for (int k = 1; k < 8; k++)
+                for (int i = 0; i < 256; i++) T[k][i] = (uint16_t)((T[k - 1][i] << 8) ^ T[0][T[k - 1][i] >> 8]);
+            ok = true;
+        }
+        return T;
+    }
+    void crc_to(const uint8_t *d, uint64_t upto)
+    {
+        const uint16_t (*T)[256] = tables();
+        uint16_t c = crc;
+        uint64_t p = crc_pos;
+        while (p + 8 <= upto) {
+            const uint8_t *b = d + p;
+            c = (uint16_t)(T[7][(uint8_t)((c >> 8) ^ b[0])] ^ T[6][(uint8_t)(c ^ b[1])] ^ T[5][b[2]] ^ T[4][b[3]] ^ T[3][b[4]] ^
+                           T[2][b[5]] ^ T[1][b[6]] ^ T[0][b[7]]);
+            p += 8;
+        }
+        for (; p < upto; p++) c = (uint16_t)((c << 8) ^ T[0][(c >> 8) ^ d[p]]);
+        crc = c; crc_pos = upto;
+    }
     void open_frame(const HostHeader &h)
     {
         // verbatim subframes (one extra bit for a side channel) + subframe headers with a long wasted-bits unary + footer
@@ -159,6 +191,7 @@ struct Indexer {
             // A frame longer than its header allows, or one that reaches the end of the data without a clean CRC-16,
             // is damaged: resynchronise (below).
             const bool at_end = scan >= len;
+            if (at_end && final && in_frame && !tail_checked) crc_to(d, len);
             const bool want_resync = in_frame && ((scan - frame_start > max_len) || (at_end && final && crc != 0 && !tail_checked));
             if (at_end && !want_resync) break;
             if (!in_frame) {
@@ -166,13 +199,11 @@ struct Indexer {
                 if (d[scan] == 0xFF && scan + 1 < len && (d[scan + 1] & 0xFE) == 0xF8) {
                     if (len - scan < 16 && !final) return;             // need the whole header
                     if (parse_header(d + scan, len - scan, si, &h)) {
-                        in_frame = true; frame_start = scan; crc = 0;
+                        in_frame = true; frame_start = scan; crc = 0; crc_pos = scan;
                         open_frame(h);
                         if (bounds.empty() || bounds.back() != scan) {
                             bounds.push_back(scan);
                         }
-                        // consume the header bytes
-                        for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan + i]]);
                         scan += h.hdr_bytes;
                         continue;
                     }
@@ -186,20 +217,32 @@ struct Indexer {
                 scan++;
                 continue;
             }
-            // inside a frame: a boundary candidate is a position where the running CRC is zero and a valid header follows
-            if (!at_end && crc == 0 && scan >= frame_start + 9 && d[scan] == 0xFF) {
-                if (scan + 1 >= len && !final) return;
-                if (scan + 1 < len && (d[scan + 1] & 0xFE) == 0xF8) {
+            // inside a frame: a boundary is a position where a valid header starts and the CRC-16 of everything since the
+            // frame start is zero.  Headers start with 0xFF: jump from one 0xFF to the next (memchr) and bring the CRC up to
+            // date only where the sync code is complete.
+            if (!at_end && !want_resync) {
+                const uint64_t lim = std::min<uint64_t>(len, frame_start + max_len + 1);
+                const uint8_t *q = scan < lim ? (const uint8_t *)memchr(d + scan, 0xFF, (size_t)(lim - scan)) : nullptr;
+                if (!q) { scan = lim; continue; }
+                scan = (uint64_t)(q - d);
+                if (scan + 1 >= len) {
+                    if (!final) return;
+                    scan++;
+                    continue;
+                }
+                if ((d[scan + 1] & 0xFE) == 0xF8 && scan >= frame_start + 9) {
                     if (len - scan < 16 && !final) return;
-                    if (parse_header(d + scan, len - scan, si, &h)) {
+                    crc_to(d, scan);
+                    if (crc == 0 && parse_header(d + scan, len - scan, si, &h)) {
                         bounds.push_back(scan);       // closes the current frame, opens the next
-                        frame_start = scan; crc = 0;
+                        frame_start = scan; crc = 0; crc_pos = scan;
                         open_frame(h);
-                        for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan + i]]);
                         scan += h.hdr_bytes;
                         continue;
                     }
                 }
+                scan++;
+                continue;
             }
             // Resynchronisation: no position with a clean CRC-16 inside the longest possible frame means the frame is
             // damaged.  It is cut at the next header that continues the numbering (the GPU pass then reports the CRC
@@ -233,8 +276,7 @@ struct Indexer {
                     const uint64_t cut = cut_sync ? cut_sync : cut_any;
                     if (cut) bounds.push_back(cut);
                     bounds.push_back(p2);
-                    frame_start = p2; crc = 0; open_frame(h);
-                    for (uint32_t i = 0; i < h.hdr_bytes; i++) crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[p2 + i]]);
+                    frame_start = p2; crc = 0; crc_pos = p2; open_frame(h);
                     scan = p2 + h.hdr_bytes;
                     continue;
                 }
@@ -242,8 +284,6 @@ struct Indexer {
                 scan = len;
                 continue;
             }
-            crc = (uint16_t)((crc << 8) ^ tab[(crc >> 8) ^ d[scan]]);
-            scan++;
         }
         if (final && in_frame) {
             // last frame ends at the end of the data (its CRC is checked on the GPU like every other frame)
@@ -845,7 +885,7 @@ bool fill_queue(DecImpl *d)
                 std::vector<uint64_t> nbnd;
                 for (size_t i = d->frames_delivered_bound; i < d->ix.bounds.size(); i++) nbnd.push_back(d->ix.bounds[i] - cut);
                 d->ix.bounds.swap(nbnd);
-                d->ix.scan -= cut; d->ix.frame_start -= cut;
+                d->ix.scan -= cut; d->ix.frame_start -= cut; d->ix.crc_pos -= cut;
                 for (auto &p : d->ix.error_pos) p = p >= cut ? p - cut : 0;
                 d->frames_delivered_bound = 0;
             }

@@ -82,6 +82,9 @@ class _Decoder:
     def _make_trampolines(self):
         def _read(_dec, byte_buffer, num_bytes, _client):
             try:
+                if getattr(self, '_eof_when_empty', False) and not self._buffer:
+                    num_bytes[0] = 0
+                    return 1   # END_OF_STREAM: a one-shot buffer has nothing more to come
                 # wait until there is something in the buffer, an error occurred, or finish() was called
                 self._event.wait()
                 if self._error:
@@ -89,23 +92,29 @@ class _Decoder:
                 if self._done:
                     num_bytes[0] = 0
                     return 1   # END_OF_STREAM
-                data = bytes()
                 maximum_bytes = int(num_bytes[0])
+                data = bytearray()
                 self._lock.acquire()
                 try:
-                    if len(self._buffer[0]) <= maximum_bytes:
-                        data = self._buffer.popleft()
-                        maximum_bytes -= len(data)
-                    if len(self._buffer) > 0 and len(self._buffer[0]) > maximum_bytes:
-                        data += self._buffer[0][0:maximum_bytes]
-                        self._buffer[0] = self._buffer[0][maximum_bytes:]
-                    if len(self._buffer) == 0 or (len(self._buffer) > 0 and len(self._buffer[0]) == 0):
+                    # whole queued items while they fit, then the head of the next one; items are memoryviews, so taking
+                    # a head is O(1) (slicing a bytes object here would copy the remainder on every call)
+                    while self._buffer and maximum_bytes > 0:
+                        head = self._buffer[0]
+                        take = min(len(head), maximum_bytes)
+                        data += head[:take]
+                        maximum_bytes -= take
+                        if take == len(head):
+                            self._buffer.popleft()
+                        else:
+                            self._buffer[0] = head[take:]
+                    if len(self._buffer) == 0:
                         self._event.clear()
                 finally:
                     self._lock.release()
                 actual_bytes = len(data)
                 num_bytes[0] = actual_bytes
-                C.memmove(byte_buffer, data, actual_bytes)
+                if actual_bytes:
+                    C.memmove(byte_buffer, (C.c_char * actual_bytes).from_buffer(data), actual_bytes)
                 return 0   # CONTINUE
             except Exception:   # noqa: BLE001  (def_extern(error=ABORT) in the reference)
                 return 2
@@ -115,14 +124,18 @@ class _Decoder:
                 h = frame.contents.header
                 if h.bits_per_sample not in (16, 32) and not getattr(self, '_allow_any_bps', False):
                     raise ValueError('Only int16/int32 data type is supported')
-                channels = []
-                for ch in range(0, h.channels):
-                    npbuffer = np.ctypeslib.as_array(buffer[ch], shape=(h.blocksize,))
-                    if h.bits_per_sample == 16:
-                        channels.append(npbuffer.astype(np.int16))
-                    else:
-                        channels.append(npbuffer.copy())
-                output = np.column_stack(channels)
+                n, nch = int(h.blocksize), int(h.channels)
+                base = C.addressof(buffer[0].contents)
+                if all(C.addressof(buffer[ch].contents) == base + 4 * n * ch for ch in range(1, nch)):
+                    # libflacgpu hands the channels over as one [channels][blocksize] plane: one view, one transposed copy
+                    planes = np.ctypeslib.as_array(C.cast(buffer[0], C.POINTER(C.c_int32 * (n * nch))).contents).reshape(nch, n)
+                    output = planes.T.astype(np.int16 if h.bits_per_sample == 16 else np.int32)
+                else:
+                    channels = []
+                    for ch in range(0, nch):
+                        npbuffer = np.ctypeslib.as_array(buffer[ch], shape=(n,))
+                        channels.append(npbuffer.astype(np.int16) if h.bits_per_sample == 16 else npbuffer.copy())
+                    output = np.column_stack(channels)
                 self.write_callback(output, int(h.sample_rate), int(h.channels), int(h.blocksize))
                 return 0   # CONTINUE
             except Exception:   # noqa: BLE001  (def_extern(error=ABORT) in the reference)
@@ -174,8 +187,11 @@ class StreamDecoder(_Decoder):
 
     def process(self, data: bytes):
         """Hand some FLAC bytes to the decoder (non-blocking)."""
+        view = memoryview(data).cast('B')
+        if len(view) == 0:
+            return
         self._lock.acquire()
-        self._buffer.append(data)
+        self._buffer.append(view)
         self._lock.release()
         self._event.set()
 
@@ -240,8 +256,10 @@ class OneShotDecoder(_Decoder):
     def __init__(self, write_callback: Callable[[np.ndarray, int, int, int], None], buffer: bytes):
         super().__init__()
         self._done = False
+        self._eof_when_empty = True
         self._buffer = deque()
-        self._buffer.append(buffer)
+        if len(buffer):
+            self._buffer.append(memoryview(buffer).cast('B'))
         self._event = threading.Event()
         self._event.set()
         self._lock = threading.Lock()

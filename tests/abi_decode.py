@@ -153,6 +153,7 @@ def metadata_to_dict(m):
 def read_metadata(L, data, setup):
     """Blocks the metadata callback of library `L` (ours or the reference binary) receives for stream `data`.
     `setup`: list of ('respond'|'ignore', type) / ('respond_all',) / ('ignore_all',) / ('respond_app'|'ignore_app', b'abcd')."""
+    L = C.CDLL(L._name)       # a private wrapper object: the signatures set below must not leak into the shared one
     L.FLAC__stream_decoder_new.restype = C.c_void_p
     dec = C.c_void_p(L.FLAC__stream_decoder_new())
     pos = [0]
