@@ -14,9 +14,7 @@ for md5 in (1, 0):
         enc = pyflac_amd.StreamEncoder(48000, lambda b, n, s, f: chunks.append(b), compression_level=5, blocksize=4096)
         t0 = time.perf_counter()
         if not md5:
-            enc._init()
-        if not md5:
-            pass
+            _lib.lib().FLAC__stream_encoder_set_do_md5(enc._encoder, 0)
         enc.process(pcm)
         enc.finish()
         t1 = time.perf_counter()
@@ -30,4 +28,3 @@ for md5 in (1, 0):
         n = pcm.size
         print('md5=%d rep %d: encode %.3f s (%.1f Msamples/s)  decode %.3f s (%.1f Msamples/s)  frames %d' %
               (md5, rep, t1 - t0, n / (t1 - t0) / 1e6, t3 - t2, n / (t3 - t2) / 1e6, len(chunks) - 3))
-    break
