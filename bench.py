@@ -66,7 +66,8 @@ def pmc_traffic(args, est):
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fh:
             t = json.load(fh)
-        if t.get('blocks') == int(est.nblocks) and t.get('level') == args.level and t.get('kernel') == 'fg_encode_fast_kernel':
+        if (args.workload == 'stream16' and t.get('blocks') == int(est.nblocks) and t.get('level') == args.level and
+                t.get('kernel') == 'fg_encode_fast_kernel'):
             return int(t['traffic_bytes_per_launch'])
     except (OSError, ValueError, KeyError):
         pass
@@ -81,6 +82,10 @@ def main():
     ap.add_argument('--seconds', type=float, default=600.0, help='length of the stream each GPU encodes')
     ap.add_argument('--level', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch'], default='stream16',
+                    help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz (use --level 8); '
+                         'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each)')
+    ap.add_argument('--streams', type=int, default=128, help='streams per GPU for --workload batch')
     args = ap.parse_args()
 
     import torch
@@ -98,8 +103,18 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     sr, ch, bps, bs = 48000, 2, 16, 4096
-    # each rank encodes its own stream (config 5 generator family); rank 0 at N=1 is config 2's stream
-    pcm16 = synth.config2_stereo16(args.seconds, 0, sr) if world == 1 else synth.config5_stream(rank, args.seconds, sr)
+    lengths = None
+    if args.workload == 'stream24':
+        sr, bps = 96000, 24
+        pcm16 = synth.config4_stereo24(args.seconds, 1 + rank, sr)          # int32 container, 24-bit values
+    elif args.workload == 'batch':
+        # configs[4]: the rank's share of the 1024-stream batch, concatenated in HBM, every stream its own frame numbering
+        per = [synth.config5_stream(rank * args.streams + i, args.seconds, sr) for i in range(args.streams)]
+        lengths = [len(x) for x in per]
+        pcm16 = np.concatenate(per)
+    else:
+        # each rank encodes its own stream (config 5 generator family); rank 0 at N=1 is config 2's stream
+        pcm16 = synth.config2_stereo16(args.seconds, 0, sr) if world == 1 else synth.config5_stream(rank, args.seconds, sr)
     pcm = torch.from_numpy(pcm16.astype(np.int32)).to(dev)     # int32 at the C ABI, like pyflac/encoder.py:112
     nsamp = pcm.shape[0]
     ctx = batch.Context(local)
@@ -117,7 +132,7 @@ def main():
 
     def step():
         nonlocal out, offs, dec
-        out, offs, est = ctx.encode(s, pcm, out=out, offsets=offs)
+        out, offs, est = ctx.encode(s, pcm, stream_lengths=lengths, out=out, offsets=offs)
         dec, status, dst = ctx.decode(out, offs, ch, bps, nsamp, out=dec)       # the frame index stays in HBM
         return est, dst, status
 
@@ -129,7 +144,7 @@ def main():
     if rank == 0:
         from oracle import oracle as O
         cfg, _ = O.config(args.level, ch, bps, sr, bs, True)
-        nchk = min(nsamp, 40 * bs)
+        nchk = min(nsamp if lengths is None else lengths[0], 40 * bs) // bs * bs
         ref, _sizes = O.encode_stream(cfg, pcm16[:nchk].astype(np.int32))
         h_offs = offs.cpu().numpy()
         nfr = nchk // bs
@@ -164,15 +179,18 @@ def main():
     achieved = alg_bytes / (enc_k * 1e-3) / 1e9
     if rank == 0:
         res = {
-            'metric': 'Msamples/s encode (level %d, 48kHz/16-bit stereo, blk 4096) + decode; bit-exact' % args.level,
+            'metric': 'Msamples/s encode (level %d, %dkHz/%d-bit stereo, blk 4096) + decode; bit-exact' % (args.level, sr // 1000, bps),
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]+[2]: single-stream encode then decode of its output, stereo 16-bit 48 kHz, '
+            'config': {'workload': '%s: %s encode then decode of its output, stereo %d-bit %d kHz, '
                                    'blocksize 4096, level %d, %.0f s (%d blocks) per GPU, int32 PCM resident in HBM, '
                                    'MD5 off (FLAC__stream_encoder_set_do_md5(0)); decoder uses the frame index the '
-                                   'encoder produced (device-resident)' % (args.level, args.seconds, est.nblocks),
-                       'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * 2), 4)},
+                                   'encoder produced (device-resident)' %
+                                   ({'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]'}[args.workload],
+                                    'single-stream' if lengths is None else '%d independent streams in one launch,' % len(lengths),
+                                    bps, sr // 1000, args.level, args.seconds, est.nblocks),
+                       'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4)},
             'encode_kernel_msamples_per_s': round(chsamples / (enc_k * 1e-3) / 1e6, 1),
             'decode_kernel_msamples_per_s': round(chsamples / (dec_k * 1e-3) / 1e6, 1),
             'encode_kernel_ms': round(enc_k, 3), 'decode_kernel_ms': round(dec_k, 3),
@@ -180,8 +198,8 @@ def main():
                          'unit': 'GB/s', 'frac': round(achieved / 8000.0, 5), 'traffic': pmc_traffic(args, est),
                          'algorithmic_bytes_per_launch': int(alg_bytes)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(synth.config2_stereo16(60.0, 0, sr), args.level, sr)
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
+            res['cpu_baseline'] = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), args.level, 48000)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
