@@ -848,15 +848,17 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
 
 }  // namespace
 
-// Frames per wave: narrow waves while the launch cannot fill the SIMDs (the kernels are chains of dependent work per lane),
-// full waves for large batches.
-static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes, uint32_t waves_per_simd)
+// Frames per wave.  A lane's work is one serial chain, so a wave takes as long as its slowest frame however many lanes are
+// busy; a launch that cannot fill the chip is spread thin.  Measured on the MI355X with 7032 frames (tools/gpu_gsweep.sh):
+// the parse kernel is fastest with about two waves per CU (14-20 frames per wave: 0.57 ms against 0.63 ms at four waves
+// per CU and 0.82 ms at eight), the restore kernel with four per CU.  Large batches fill the lanes (G up to the LDS limit).
+static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes, uint32_t waves_per_cu)
 {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    uint32_t simds = (uint32_t)cus * 4 * waves_per_simd;
-    if (getenv("FLACGPU_DEC_WPS")) simds = (uint32_t)cus * 4 * (uint32_t)atoi(getenv("FLACGPU_DEC_WPS"));
-    uint32_t g = (nframes + simds - 1) / simds;
+    uint32_t slots = (uint32_t)cus * waves_per_cu;
+    if (getenv("FLACGPU_DEC_WPS")) slots = (uint32_t)cus * 4 * (uint32_t)atoi(getenv("FLACGPU_DEC_WPS"));     // tuning aid: waves per SIMD
+    uint32_t g = (nframes + slots - 1) / slots;
     const uint32_t gmax = 64 / per_frame_lanes;
     if (g < 1) g = 1;
     if (g > gmax) g = gmax;
@@ -869,6 +871,7 @@ extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_le
 {
     if (nframes == 0) return 0;
     uint32_t G = fg_dec_group(nframes, 1, 2);
+    if (getenv("FLACGPU_DEC_G1")) G = (uint32_t)atoi(getenv("FLACGPU_DEC_G1"));      // tuning aid
     if (G > 32) G = 32;     // LDS per wave grows with G (ring + tile rows); 32 keeps several waves per CU
     const size_t lds = (size_t)G * (FG_RSTR + FG_TSTR) * 4;
     hipLaunchKernelGGL(fg_dec_rice_kernel, dim3((nframes + G - 1) / G), dim3(64), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G,
@@ -882,7 +885,8 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
 {
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
-    uint32_t G = fg_dec_group(nframes, C, 1);
+    uint32_t G = fg_dec_group(nframes, C, 4);
+    if (getenv("FLACGPU_DEC_G2")) G = (uint32_t)atoi(getenv("FLACGPU_DEC_G2"));      // tuning aid
     if (G * C > FG_RROWS) G = FG_RROWS / C;
     if (G < 1) return -1;
     const dim3 grid((nframes + G - 1) / G);
