@@ -193,14 +193,89 @@ __device__ __forceinline__ int32_t unzig(uint32_t u) { return (int32_t)(u >> 1) 
 // window form, 0xFF when every entry is a finished value, 0xFE when the subframe is CONSTANT (value in rowc[row]);
 // a 64-bit mask marks entries of a window-form tile that are finished values anyway.  The per-row facts stay in the
 // registers of the owning lane; the flush reads them with v_readlane (rows are visited in wave-uniform order).
-__global__ void __launch_bounds__(64)
+// Two waves per group of G frames.  Wave 0 parses (lane = frame, strictly serial per lane); wave 1 converts the tile wave 0
+// finished one step earlier into residuals and stores them (the parallel part), so that it is off the serial path.  Tiles
+// are double-buffered in LDS, the per-row facts of a tile travel through `meta`, one workgroup barrier per tile.
+#define FG_META 8                     // words per row and tile: (rn << 8 | tk), offset lo/hi, mask lo/hi, constant value
+
+__device__ __forceinline__ void fg_dec_flush_tile(const uint32_t *tile, const uint32_t *meta, uint32_t G, uint32_t i0, int lane, int32_t *scratch)
+{
+    const uint32_t icol = i0 + (uint32_t)lane;
+    uint32_t special = 0;
+    if ((uint32_t)lane < G) {
+        const uint32_t m = meta[lane * FG_META], rn_l = m >> 8, tk_l = m & 0xFF;
+        special = rn_l > i0 && (tk_l >= 0xFE || (meta[lane * FG_META + 3] | meta[lane * FG_META + 4]) != 0);
+    }
+    if (!__any(special)) {
+        // common case: every row is a full tile of code windows.  Four rows per pass: 16 lanes per row, four entries per
+        // lane (one 16-byte LDS read, one 16-byte store)
+        const uint32_t rsub = (uint32_t)lane >> 4, q4 = ((uint32_t)lane & 15) * 4;
+        for (uint32_t r0 = 0; r0 < G; r0 += 4) {
+            const uint32_t r = r0 + rsub;
+            const uint32_t src = r < G ? r : 0;
+            const uint32_t m = meta[src * FG_META];
+            const uint32_t rn_r = r < G ? (m >> 8) : 0, kk = m & 0xFF;
+            const u64 off_r = ((u64)meta[src * FG_META + 2] << 32) | meta[src * FG_META + 1];
+            if (i0 + q4 < rn_r) {
+                const uint4 pw = *(const uint4 *)&tile[r * FG_TSTR + q4];
+                const uint32_t p4[4] = {pw.x, pw.y, pw.z, pw.w};
+                int32_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t lz = (uint32_t)__clz(p4[e]);
+                    const uint32_t rest = (p4[e] << lz) << 1;
+                    const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                    res[e] = unzig(u);
+                }
+                int32_t *dst = scratch + off_r + i0 + q4;
+                if ((((uintptr_t)dst) & 15) == 0) *(int4 *)dst = make_int4(res[0], res[1], res[2], res[3]);
+                else { dst[0] = res[0]; dst[1] = res[1]; dst[2] = res[2]; dst[3] = res[3]; }
+            }
+        }
+        return;
+    }
+    for (uint32_t r = 0; r < G; r++) {
+        const uint32_t m = meta[r * FG_META], rn_s = m >> 8, kk = m & 0xFF;
+        if (i0 >= rn_s) continue;
+        const u64 off_s = ((u64)meta[r * FG_META + 2] << 32) | meta[r * FG_META + 1];
+        uint32_t val;
+        if (kk == 0xFE) val = meta[r * FG_META + 5];
+        else {
+            val = tile[r * FG_TSTR + lane];
+            if (kk != 0xFF) {
+                const uint32_t mlo = meta[r * FG_META + 3], mhi = meta[r * FG_META + 4];
+                const uint32_t done = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1;
+                const uint32_t lz = (uint32_t)__clz(val);
+                const uint32_t rest = (val << lz) << 1;
+                const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                val = done ? val : (uint32_t)unzig(u);
+            }
+        }
+        if (icol < rn_s) scratch[off_s + icol] = (int32_t)val;
+    }
+}
+
+__global__ void __launch_bounds__(128)
 fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
                    int32_t *scratch, FgDecSub *subs, FgDecResult *results, u64 *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
-    uint32_t *rings = dsm;                       // G rows of FG_RSTR words
-    uint32_t *tile = dsm + G * FG_RSTR;          // G rows of FG_TSTR words
-    const int lane = threadIdx.x;
+    uint32_t *rings = dsm;                               // G rows of FG_RSTR words
+    uint32_t *const tiles = dsm + G * FG_RSTR;           // two buffers of G rows of FG_TSTR words
+    uint32_t *const metas = tiles + 2 * G * FG_TSTR;     // two buffers of 64 rows of FG_META words
+    uint32_t *const ctrl = metas + 2 * 64 * FG_META;     // [0] tiles per launch group, [1] tiles per channel
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x >= 64) {
+        __syncthreads();
+        const uint32_t T = ctrl[0], tpc = ctrl[1];
+        for (uint32_t it = 0; it < T; it++) {
+            __syncthreads();
+            fg_dec_flush_tile(tiles + (it & 1) * G * FG_TSTR, metas + (it & 1) * 64 * FG_META, G, (it % tpc) * FG_TS, lane, scratch);
+        }
+        return;
+    }
+    uint32_t it = 0;                                     // tiles finished so far: buffer it & 1 is the one being filled
+#define tile (tiles + (it & 1) * G * FG_TSTR)
     const uint32_t f = blockIdx.x * G + lane;
     const bool mine = (uint32_t)lane < G && f < nframes;
     FgDecFrame fr;
@@ -212,6 +287,8 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
     if (alive && fr.bytes < fr.hdr_bytes + 2) { err = 1; alive = false; }
     const uint32_t n = fr.n, C = fr.channels;
     const uint32_t Cmax = wave_max32(alive ? C : 0), nmax = wave_max32(alive ? n : 0);
+    if (lane == 0) { ctrl[1] = (nmax + FG_TS - 1) / FG_TS; ctrl[0] = Cmax * ((nmax + FG_TS - 1) / FG_TS); }
+    __syncthreads();
     const uint32_t end_bits = alive ? (fr.bytes - 2) * 8 : 0;
     BitRd br;
     br.fg = nullptr; br.glim = 0; br.skip0 = 0; br.ring = rings; br.w0 = 0; br.w1 = 0; br.w2 = 0; br.w3 = 0; br.s = 0; br.wb = 12; br.H = 0;
@@ -404,59 +481,16 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
             }
             FG_TICK(3);
             if (isconst) tk = 0xFE;
-            wave_lds_fence();
-            // ---- cooperative flush: one row per pass, lane = column; the row's facts come from its lane's registers
-            const uint32_t meta = (rn << 8) | tk;                      // block sizes are below 2^16
-            const uint32_t icol = i0 + (uint32_t)lane;
-            if (!__any((uint32_t)lane < G && rn > i0 && (tk >= 0xFE || tmask != 0))) {
-                // common case: every row is a full tile of code windows.  Four rows per pass: 16 lanes per row, four
-                // entries per lane (one 16-byte LDS read, one 16-byte store); the row facts reach the lanes by permute.
-                const uint32_t rsub = (uint32_t)lane >> 4, q4 = ((uint32_t)lane & 15) * 4;
-                for (uint32_t r0 = 0; r0 < G; r0 += 4) {
-                    const uint32_t r = r0 + rsub;
-                    const int src = (int)(r < G ? r : 0);
-                    const uint32_t m = (uint32_t)__shfl((int)meta, src);
-                    const uint32_t rn_r = r < G ? (m >> 8) : 0, kk = m & 0xFF;
-                    const u64 off_r = ((u64)(uint32_t)__shfl((int)(uint32_t)(roff >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)roff, src);
-                    if (i0 + q4 < rn_r) {
-                        const uint4 pw = *(const uint4 *)&tile[r * FG_TSTR + q4];
-                        const uint32_t p4[4] = {pw.x, pw.y, pw.z, pw.w};
-                        int32_t res[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const uint32_t lz = (uint32_t)__clz(p4[e]);
-                            const uint32_t rest = (p4[e] << lz) << 1;
-                            const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
-                            res[e] = unzig(u);
-                        }
-                        int32_t *dst = scratch + off_r + i0 + q4;
-                        if ((((uintptr_t)dst) & 15) == 0) *(int4 *)dst = make_int4(res[0], res[1], res[2], res[3]);
-                        else { dst[0] = res[0]; dst[1] = res[1]; dst[2] = res[2]; dst[3] = res[3]; }
-                    }
-                }
+            // ---- hand the tile to the helper wave: the row's facts, then the barrier (it also orders the LDS writes)
+            {
+                uint32_t *m = metas + (it & 1) * 64 * FG_META + lane * FG_META;
+                m[0] = (rn << 8) | tk;                                  // block sizes are below 2^16; rn = 0 for idle lanes
+                m[1] = (uint32_t)roff; m[2] = (uint32_t)(roff >> 32);
+                m[3] = (uint32_t)tmask; m[4] = (uint32_t)(tmask >> 32);
+                m[5] = cval;
             }
-            else {
-                for (uint32_t r = 0; r < G; r++) {
-                    const uint32_t m = rl(meta, (int)r), rn_s = m >> 8, kk = m & 0xFF;
-                    if (i0 >= rn_s) continue;
-                    const u64 off_s = ((u64)rl((uint32_t)(roff >> 32), (int)r) << 32) | rl((uint32_t)roff, (int)r);
-                    uint32_t val;
-                    if (kk == 0xFE) val = rl(cval, (int)r);
-                    else {
-                        val = tile[r * FG_TSTR + lane];
-                        if (kk != 0xFF) {
-                            const uint32_t mlo = rl((uint32_t)tmask, (int)r), mhi = rl((uint32_t)(tmask >> 32), (int)r);
-                            const uint32_t done = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1;
-                            const uint32_t lz = (uint32_t)__clz(val);
-                            const uint32_t rest = (val << lz) << 1;
-                            const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
-                            val = done ? val : (uint32_t)unzig(u);
-                        }
-                    }
-                    if (icol < rn_s) scratch[off_s + icol] = (int32_t)val;
-                }
-            }
-            wave_lds_fence();
+            __syncthreads();
+            it++;
             if (act && br.pos() > end_bits) { err = 4; alive = false; rn = 0; }
             FG_TICK(4);
         }
@@ -472,6 +506,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
     }
     if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t)blockIdx.x * 8 + i] = tp[i];
 #undef FG_TICK
+#undef tile
 }
 
 // CRC-16 (poly 0x8005, init 0) of frame bytes [0, bytes-2), compared with the stored big-endian CRC.
@@ -873,8 +908,8 @@ extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_le
     uint32_t G = fg_dec_group(nframes, 1, 2);
     if (getenv("FLACGPU_DEC_G1")) G = (uint32_t)atoi(getenv("FLACGPU_DEC_G1"));      // tuning aid
     if (G > 32) G = 32;     // LDS per wave grows with G (ring + tile rows); 32 keeps several waves per CU
-    const size_t lds = (size_t)G * (FG_RSTR + FG_TSTR) * 4;
-    hipLaunchKernelGGL(fg_dec_rice_kernel, dim3((nframes + G - 1) / G), dim3(64), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G,
+    const size_t lds = ((size_t)G * (FG_RSTR + 2 * FG_TSTR) + 2 * 64 * FG_META + 4) * 4;
+    hipLaunchKernelGGL(fg_dec_rice_kernel, dim3((nframes + G - 1) / G), dim3(128), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G,
                        wide ? 0u : 1u, d_scratch, d_subs, d_results, d_prof);
     return (int)hipGetLastError();
 }
