@@ -305,12 +305,13 @@ bool encode_pending(EncImpl *e, bool flush_all)
     if (!e->d_pcm.ensure(pcm_bytes) || !e->d_out.ensure(bound) || !e->d_offs.ensure(((size_t)nblocks + 1) * 8)) {
         e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false;
     }
+    // MD5 of the consumed PCM on a helper thread beside everything else this call does (upload, kernels, download, the
+    // client's write callbacks); joined before the samples are dropped from `pending`, on every way out
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } md5j;
+    if (e->do_md5) md5j.t = std::thread([e, take, C] { e->md5.update_pcm(e->pending.data(), take * C, e->s.bits_per_sample); });
     if (hipMemcpy(e->d_pcm.p, e->pending.data(), pcm_bytes, hipMemcpyHostToDevice) != hipSuccess) {
         e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false;
     }
-    // MD5 of the consumed PCM on a helper thread while the GPU encodes
-    std::thread md5t;
-    if (e->do_md5) md5t = std::thread([&] { e->md5.update_pcm(e->pending.data(), take * C, e->s.bits_per_sample); });
     flacgpu_encode_stats st;
     const int rc = flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, e->d_out.p, e->d_out.cap, e->d_offs.p, &st);
     bool ok = rc == 0;
@@ -359,7 +360,6 @@ bool encode_pending(EncImpl *e, bool flush_all)
             }
         }
     }
-    if (md5t.joinable()) md5t.join();
     if (!ok) return false;
     uint64_t pos = 0;
     for (uint32_t b = 0; b < st.nblocks; b++) {
@@ -376,6 +376,7 @@ bool encode_pending(EncImpl *e, bool flush_all)
             e->progress_cb(&e->pub, e->bytes_written, e->samples_done, e->frame_number, est, e->client);
         }
     }
+    if (md5j.t.joinable()) md5j.t.join();
     e->pending.erase(e->pending.begin(), e->pending.begin() + (size_t)take * C);
     return true;
 }
