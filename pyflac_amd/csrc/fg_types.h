@@ -13,7 +13,7 @@
 // Error bits reported per block.
 #define FG_ERR_RANGE 1u        // input sample outside the bits-per-sample range
 #define FG_ERR_SLOT 2u         // frame did not fit its output slot
-#define FG_ERR_SIDE33 4u       // 33-bit side channel (32-bit stereo input) not representable
+#define FG_ERR_SIDE33 4u       // (unused since the generic kernel handles the 33-bit side channel; value kept reserved)
 #define FG_ERR_INTERNAL 8u
 #define FG_ERR_REDO 16u         // not an error: the specialised kernel hands this block to the generic kernel
 

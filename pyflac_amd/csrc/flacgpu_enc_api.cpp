@@ -318,7 +318,6 @@ bool encode_pending(EncImpl *e, bool flush_all)
     if (ok && st.error_flags) {
         ok = false;
         e->state = (st.error_flags & FG_ERR_RANGE) ? FLAC__STREAM_ENCODER_CLIENT_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
-        if (st.error_flags & FG_ERR_SIDE33) fg_set_error("32-bit stereo input needs a 33-bit side channel: not supported");
     }
     else if (!ok) e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
     if (ok) {
