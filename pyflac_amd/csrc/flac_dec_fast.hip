@@ -636,17 +636,20 @@ __device__ __forceinline__ void restore_range(int32_t (&h)[FG_DMAXO], const int3
 // (group boundaries of the 12-tap variant do not fall on pass boundaries; each phase restores the groups that are
 // complete, which is why pass p is written out one phase later.)
 template <bool WIDE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
                       int32_t *out, FgDecResult *results, uint32_t interleave, u64 *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];     // rows of FG_TRS words: chains (rounded up to 16) + 1 spare
-    const int lane = threadIdx.x;
+    // Two waves per workgroup with the same lane -> (frame, channel) mapping: wave 0 runs the serial recurrence on the LDS
+    // tile, wave 1 moves the data (scratch -> tile ahead of it, tile -> output behind it).  One barrier per 64-column step.
+    const int lane = threadIdx.x & 63;
+    const bool mover = threadIdx.x >= 64;
     const uint32_t chains = G * C;
     const uint32_t fi = (uint32_t)lane / C, ch = (uint32_t)lane % C;
     const uint32_t f = blockIdx.x * G + fi;
     const bool mine = (uint32_t)lane < chains && f < nframes;
-    uint32_t n = 0, status = 1, ca = 0;
+    uint32_t n = 0, status = 1, ca = 0, crcw = 0;
     u64 out_off = 0;
     if (mine) {
         const FgDecFrame fr = frames[f];
@@ -654,9 +657,11 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
             n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off;
             const uint32_t cw = results[f].crc;
             if (status == 0 && (cw & 0x80000000u)) status = 2;          // CRC-16 mismatch (fg_dec_crc_kernel)
-            if (ch == 0) { results[f].err = status; results[f].crc = cw & 0xFFFFu; }
+            crcw = cw;
         }
     }
+    __syncthreads();                                                    // both waves have read the parse / CRC results
+    if (!mover && mine && n != 0 && ch == 0) { results[f].err = status; results[f].crc = crcw & 0xFFFFu; }
     const bool ok = mine && n != 0 && status == 0;
     int32_t q[FG_DMAXO], h[FG_DMAXO];
 #pragma unroll
@@ -852,31 +857,49 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
     const uint32_t ng = big ? FG_TR / 12 : FG_TR / 8;
     const uint32_t ga = big ? 5 : 8, gb = big ? 10 : 16;       // groups that are complete after passes 0 and 1 have landed
 
-    issue(0, 0);
+    // Steps s = 3 * tile + pass.  Restore step (t, p) covers the sample groups of columns [64p, 64p + 64) (order > 8: 12-sample
+    // groups, so the first two steps end at columns 60 and 120; block 0 is complete after step (t, 1), blocks 1 and 2 after
+    // (t, 2)).  The mover stays off the block the recurrence is working on:
+    //   step (t, 0): write out (t-1, 1); land (t, 1); write out (t-1, 2); request (t, 2)
+    //   step (t, 1): land (t, 2); request (t+1, 0)
+    //   step (t, 2): write out (t, 0); land (t+1, 0); request (t+1, 1)
+    const uint32_t T = (nmax + FG_TR - 1) / FG_TR, S = 3 * T;
+    if (mover) {
+        if (T) { issue(0, 0); land(0); issue(0, 1); }
+        for (uint32_t s = 0; s <= S; s++) {
+            __syncthreads();
+            const uint32_t t = s / 3, p = s - 3 * t, i0 = t * FG_TR;
+            if (p == 0) {
+                if (t > 0) writeout(i0 - FG_TR, 1);
+                if (t < T) land(1);
+                if (t > 0) writeout(i0 - FG_TR, 2);
+                if (t < T) issue(i0, 2);
+            }
+            else if (p == 1) {
+                land(2);
+                if (t + 1 < T) issue(i0 + FG_TR, 0);
+            }
+            else {
+                writeout(i0, 0);
+                if (t + 1 < T) { land(0); issue(i0 + FG_TR, 1); }
+            }
+        }
+        return;
+    }
     for (uint32_t i0 = 0; i0 < nmax; i0 += FG_TR) {
         const bool first = i0 == 0;
+        __syncthreads();
         FG_TICK(0);
-        land(0); issue(i0, 1);
-        FG_TICK(1);
         if (big) restore_range<12, WIDE>(h, q, shift, order, first, 0, ga, rowp); else restore_range<8, WIDE>(h, q, shift, order, first, 0, ga, rowp);
+        __syncthreads();
         FG_TICK(2);
-        land(1); issue(i0, 2);
-        FG_TICK(1);
         if (big) restore_range<12, WIDE>(h, q, shift, order, first, ga, gb, rowp); else restore_range<8, WIDE>(h, q, shift, order, first, ga, gb, rowp);
-        wave_lds_fence();
+        __syncthreads();
         FG_TICK(2);
-        writeout(i0, 0);
-        FG_TICK(3);
-        land(2); issue(i0 + FG_TR, 0);
-        FG_TICK(1);
         if (big) restore_range<12, WIDE>(h, q, shift, order, first, gb, ng, rowp); else restore_range<8, WIDE>(h, q, shift, order, first, gb, ng, rowp);
-        wave_lds_fence();
         FG_TICK(2);
-        writeout(i0, 1);
-        writeout(i0, 2);
-        wave_lds_fence();
-        FG_TICK(3);
     }
+    __syncthreads();
     if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t)blockIdx.x * 8 + i] = tp[i];
 #undef FG_TICK
 }
@@ -926,8 +949,8 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
     if (G < 1) return -1;
     const dim3 grid((nframes + G - 1) / G);
     const size_t lds = (size_t)(((G * C + 15) & ~15u) + 1) * FG_TRS * 4;      // rounds of 16 rows + the spare row
-    if (wide) hipLaunchKernelGGL(fg_dec_restore_kernel<true>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
-    else hipLaunchKernelGGL(fg_dec_restore_kernel<false>, grid, dim3(64), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
+    if (wide) hipLaunchKernelGGL(fg_dec_restore_kernel<true>, grid, dim3(128), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
+    else hipLaunchKernelGGL(fg_dec_restore_kernel<false>, grid, dim3(128), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
     return (int)hipGetLastError();
 }
 
