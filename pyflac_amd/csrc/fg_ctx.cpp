@@ -451,17 +451,28 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         }
     }
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    // sizes -> offsets -> contiguous output
-    if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
-        fg_set_error("scan kernel launch failed"); return false;
-    }
+    // sizes -> offsets -> contiguous output, all queued behind the encode kernel; the host looks at the totals once, at the
+    // end.  (The copy kernel skips frames that would not fit `out_cap`; blocks the specialised kernel handed back show up as
+    // FG_ERR_REDO in the flags and are redone below, which repeats the scan and the copy: rare.)
     if (!c->ensure_pinned_res(64)) return false;
     unsigned long long *tail = (unsigned long long *)c->h_res;   // total bytes, OR of error flags
-    tail[0] = tail[1] = 0;
-    HIPCHK(hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    auto finish_pass = [&]() -> bool {
+        if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
+            fg_set_error("scan kernel launch failed"); return false;
+        }
+        if (d_out && fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
+                                    (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream, out_cap) != 0) {
+            fg_set_error("copy kernel launch failed"); return false;
+        }
+        if (d_offsets && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
+        tail[0] = tail[1] = 0;
+        if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+        if (hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
+        return hipStreamSynchronize(c->stream) == hipSuccess;
+    };
+    if (!finish_pass()) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
     if ((uint32_t)tail[1] & FG_ERR_REDO) {
-        // blocks the specialised kernel declined (wasted bits): encode them with the generic kernel and rescan
+        // blocks the specialised kernel declined (wasted bits): encode them with the generic kernel, then scan and copy again
         std::vector<FgBlockResult> r(nblocks);
         HIPCHK(hipMemcpyAsync(r.data(), c->results.p, (size_t)nblocks * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -474,26 +485,13 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
                                  (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {
                 fg_set_error("encode kernel launch failed"); return false;
             }
-            if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
-                fg_set_error("scan kernel launch failed"); return false;
-            }
-            HIPCHK(hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            if (!finish_pass()) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
         }
     }
     st->total_bytes = tail[0];
     st->error_flags = (uint32_t)tail[1] & ~FG_ERR_REDO;
     c->last_nblocks = nblocks;
-    if (d_out) {
-        if (tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
-        if (fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
-                           (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream) != 0) {
-            fg_set_error("copy kernel launch failed"); return false;
-        }
-    }
-    if (d_offsets) HIPCHK(hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
     HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
     return true;

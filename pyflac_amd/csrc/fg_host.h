@@ -23,10 +23,10 @@ int fg_launch_encode_fast(const void *d_pcm, const FgBlockDesc *d_descs, const f
                           const uint16_t *d_crctab, hipStream_t stream);
 int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
-                   const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream);
+                   const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap);
 int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
                           uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
-                          unsigned long long *d_totals, hipStream_t stream);
+                          unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream);
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);

@@ -435,8 +435,10 @@ fg_dec_headers_kernel(const uint8_t *stream, const u64 *offsets, uint32_t nframe
     results[f].crc = 0;
 }
 
-// Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.
-__global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals)
+// Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.  Frames that would
+// end past `cap` samples are rejected here (bytes = 0), so the decode kernels can be queued before the host has seen the
+// total: it finds totals[0] > cap afterwards and reports the short buffer.
+__global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap)
 {
     __shared__ u64 wtot[16];
     __shared__ uint32_t maxn;
@@ -452,7 +454,12 @@ __global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *to
     u64 total;
     u64 run = fgdev::block_scan_excl_u64(s, wtot, &total);
     if (tid == 0) { totals[0] = total; totals[1] = maxn; }
-    for (uint32_t b = b0; b < b1; b++) { frames[b].out_off = run; run += frames[b].n; }
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t nb = frames[b].n;
+        if (run + nb > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
+        else frames[b].out_off = run;
+        run += nb;
+    }
 }
 
 // First index at which two int32 arrays differ (0xFFFFFFFFFFFFFFFF if none): the encoder's verify pass compares what the
@@ -480,12 +487,12 @@ extern "C" int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_
 
 extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
                                      uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
-                                     unsigned long long *d_totals, hipStream_t stream)
+                                     unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream)
 {
     if (nframes == 0) return 0;
     hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, d_offsets, nframes,
                        si_channels, si_bps, d_frames, d_results);
-    hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals);
+    hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
     return (int)hipGetLastError();
 }
 

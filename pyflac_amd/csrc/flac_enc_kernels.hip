@@ -1248,10 +1248,11 @@ __global__ void fg_scan_sizes_kernel(const FgBlockResult *results, uint32_t nblo
 
 __global__ void __launch_bounds__(256)
 fg_compact_kernel(const uint8_t *slots, uint32_t slot_bytes, const FgBlockResult *results, const u64 *offsets,
-                  uint8_t *dst)
+                  uint8_t *dst, u64 dst_cap)
 {
     const uint32_t b = blockIdx.x;
     const uint32_t nb = results[b].bytes;
+    if (offsets[b] + nb > dst_cap) return;          // the host reports the short buffer once it has read the total
     const uint8_t *src = slots + (size_t)b * slot_bytes;
     uint8_t *d = dst + offsets[b];
     // head bytes up to a 4-byte boundary of dst, then word copies with a funnel shift on the source
@@ -1328,10 +1329,10 @@ int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned lo
 }
 
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
-                   const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream)
+                   const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap)
 {
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL(fg_compact_kernel, dim3(nblocks), dim3(256), 0, stream, d_slots, slot_bytes, d_results, d_offsets, d_dst);
+    hipLaunchKernelGGL(fg_compact_kernel, dim3(nblocks), dim3(256), 0, stream, d_slots, slot_bytes, d_results, d_offsets, d_dst, (u64)dst_cap);
     return (int)hipGetLastError();
 }
 

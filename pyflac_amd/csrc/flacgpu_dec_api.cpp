@@ -340,18 +340,24 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
     if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
-                              (FgDecResult *)c->dec_results.p, d_tot, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
+                              (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
     if (!c->ensure_pinned_res(64 + (size_t)nframes * sizeof(FgDecResult))) return false;
     unsigned long long *tot = (unsigned long long *)c->h_res;
     tot[0] = tot[1] = 0;
-    if (!HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
-        fg_set_error("header pass failed"); return false;
-    }
-    st->total_samples = tot[0];
-    st->max_blocksize = (uint32_t)tot[1];
     const uint32_t C = channels_hint ? channels_hint : 2;
-    if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
-    if (!c->dec_scratch.ensure((size_t)std::max<uint64_t>(tot[0], 1) * C * 4 + 256) || !c->dec_subs.ensure((size_t)npad * C * sizeof(FgDecSub)))
+    // The residual scratch is sized by the caller's capacity when that is a sane bound (the scan kernel rejects frames past
+    // it), so the decode kernels are queued without waiting for the header pass; a wildly generous capacity (no STREAMINFO:
+    // 65535 samples per frame) waits for the real total instead of allocating for it.
+    const uint64_t cap_bytes = cap_samples * C * 4 + 256;
+    const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20);
+    if (!queued) {
+        if (!HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+            fg_set_error("header pass failed"); return false;
+        }
+        if (tot[0] > cap_samples) { st->total_samples = tot[0]; fg_set_error("PCM output buffer too small"); return false; }
+    }
+    if (!c->dec_scratch.ensure(queued ? (size_t)cap_bytes : (size_t)std::max<uint64_t>(tot[0], 1) * C * 4 + 256) ||
+        !c->dec_subs.ensure((size_t)npad * C * sizeof(FgDecSub)))
         return false;
     if (!HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
     const int wide = (bps_hint == 0 || bps_hint > 16) ? 1 : 0;
@@ -379,12 +385,16 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     }
     if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
     FgDecResult *res = (FgDecResult *)((char *)c->h_res + 64);
+    if (queued && !HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream))) return false;
     if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
     if (h_frames) {
         h_frames->resize(nframes);
         if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
     }
     if (!HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    st->total_samples = tot[0];
+    st->max_blocksize = (uint32_t)tot[1];
+    if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
     {
         // frames outside the register-resident decoder's envelope (predictor order > 12, ...) go through the generic kernel
         std::vector<uint32_t> redo;
