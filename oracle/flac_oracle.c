@@ -471,7 +471,7 @@ static uint32_t find_best_partition_order(enc_ws *w, const int32_t *res, uint32_
  * the _limit_residual routine.  When data_len is a multiple of four this
  * is the exact sum; otherwise lanes 2 and 3 start one or two samples late against their history and the sums differ
  * from the plain C loop (which the same library uses on CPUs without AVX2).  Recovered from the disassembly of the
- * reference binary and pinned by tools/fuzz_oracle_vs_ref.py; sums are what pyFLAC users on x86-64 get. */
+ * reference binary and pinned by tests/tools/fuzz_oracle_vs_ref.py; sums are what pyFLAC users on x86-64 get. */
 static void avx2_lane_sums(const int64_t *d, uint32_t len, uint64_t t[5], int over[5])
 {
     const uint32_t q = len / 4;

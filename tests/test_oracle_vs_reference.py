@@ -53,7 +53,7 @@ def test_random_corpus(seed):
 
 @pytest.mark.parametrize('chunk', range(4))
 def test_fuzz_corpus_beyond_the_golden_seeds(chunk):
-    """tests/fuzzgen.py seeds past the ones with committed hashes (tools/fuzz_oracle_vs_ref.py runs thousands)."""
+    """tests/fuzzgen.py seeds past the ones with committed hashes (tests/tools/fuzz_oracle_vs_ref.py runs thousands)."""
     from tests import fuzzgen
     for seed in range(fuzzgen.GOLDEN_SEEDS + chunk * 50, fuzzgen.GOLDEN_SEEDS + chunk * 50 + 50):
         c = fuzzgen.case(seed)

@@ -1,8 +1,8 @@
 """Edge cases at the limits of the format: GPU encoder vs CPU oracle (and, where /root/reference exists, the oracle vs
-the reference binary).  usage: python tools/extremes.py [ref|gpu]"""
+the reference binary).  usage: python tests/tools/extremes.py [ref|gpu]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
 
 r = np.random.default_rng(5)

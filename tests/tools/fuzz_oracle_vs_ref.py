@@ -1,8 +1,8 @@
 """Differential fuzz: oracle/flac_oracle.c against the reference's libFLAC 1.4.3 binary on tests/fuzzgen.py cases.
-Build container only (needs /root/reference).  usage: python tools/fuzz_oracle_vs_ref.py [first] [count]"""
+Build container only (needs /root/reference).  usage: python tests/tools/fuzz_oracle_vs_ref.py [first] [count]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import libflac_ref as R
 from oracle import oracle as O
 from tests import fuzzgen

@@ -1,7 +1,7 @@
 """GPU bring-up diagnostic: batch-encode parity cases on the device and compare with the CPU oracle,
 stage by stage (uses the debug records the kernel writes).  Not part of the product."""
 import sys, os, time, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from pyflac_amd import batch, synth

@@ -1,8 +1,8 @@
 """Differential fuzz on the GPU box: libflacgpu's batch encoder against the CPU oracle (byte-identical frames) and the
-GPU decoder against the input, on tests/fuzzgen.py cases.  usage: python tools/gpu_fuzz.py [first] [count]"""
+GPU decoder against the input, on tests/fuzzgen.py cases.  usage: python tests/tools/gpu_fuzz.py [first] [count]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import oracle as O
 from pyflac_amd import batch
