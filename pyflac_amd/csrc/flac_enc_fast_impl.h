@@ -94,6 +94,40 @@ template <int MAXO> FGI int32_t fir24(const int32_t (&q)[MAXO], const int32_t (&
 #undef FG_H
     return sm;
 }
+// 17..25-bit samples (24-bit input, side channel included): the exact 64-bit sum without 64-bit multiplies.  A history
+// sample is kept as (x >> 12) in the high half and (x & 0xFFF) in the low half of one register (fpack); with coefficients
+// below 2^15 in magnitude and at most 12 taps both partial sums fit int32, and sum q*x = 4096 * sum q*hi + sum q*lo.
+// v_mad_i32_i16 multiplies the 16-bit halves op_sel picks and adds a 32-bit value (full rate; v_mad_i64_i32 is not).
+FGI int32_t fpack(int32_t x) { return (int32_t)(((uint32_t)(x >> 12) << 16) | ((uint32_t)x & 0xFFFu)); }
+template <int MAXO> FGI i64 fir48(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
+{
+    int32_t sl = 0, sh = 0;
+#define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
+#define FG_M6(OPS) "v_mad_i32_i16 %0, %1, %7, %0 " OPS "\n\tv_mad_i32_i16 %0, %2, %8, %0 " OPS "\n\tv_mad_i32_i16 %0, %3, %9, %0 " OPS "\n\t" \
+                   "v_mad_i32_i16 %0, %4, %10, %0 " OPS "\n\tv_mad_i32_i16 %0, %5, %11, %0 " OPS "\n\tv_mad_i32_i16 %0, %6, %12, %0 " OPS
+#define FG_M4(OPS) "v_mad_i32_i16 %0, %1, %5, %0 " OPS "\n\tv_mad_i32_i16 %0, %2, %6, %0 " OPS "\n\tv_mad_i32_i16 %0, %3, %7, %0 " OPS "\n\t" \
+                   "v_mad_i32_i16 %0, %4, %8, %0 " OPS
+    if (MAXO == 8) {
+        asm(FG_M4("op_sel:[0,0,0,0]") : "+v"(sl) : "v"(q[7 % MAXO]), "v"(q[6 % MAXO]), "v"(q[5 % MAXO]), "v"(q[4 % MAXO]), "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)));
+        asm(FG_M4("op_sel:[0,0,0,0]") : "+v"(sl) : "v"(q[3 % MAXO]), "v"(q[2 % MAXO]), "v"(q[1 % MAXO]), "v"(q[0]), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+        asm(FG_M4("op_sel:[0,1,0,0]") : "+v"(sh) : "v"(q[7 % MAXO]), "v"(q[6 % MAXO]), "v"(q[5 % MAXO]), "v"(q[4 % MAXO]), "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)));
+        asm(FG_M4("op_sel:[0,1,0,0]") : "+v"(sh) : "v"(q[3 % MAXO]), "v"(q[2 % MAXO]), "v"(q[1 % MAXO]), "v"(q[0]), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+    else {
+        asm(FG_M6("op_sel:[0,0,0,0]") : "+v"(sl) : "v"(q[11 % MAXO]), "v"(q[10 % MAXO]), "v"(q[9 % MAXO]), "v"(q[8 % MAXO]), "v"(q[7 % MAXO]), "v"(q[6 % MAXO]),
+            "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
+        asm(FG_M6("op_sel:[0,0,0,0]") : "+v"(sl) : "v"(q[5 % MAXO]), "v"(q[4 % MAXO]), "v"(q[3 % MAXO]), "v"(q[2 % MAXO]), "v"(q[1 % MAXO]), "v"(q[0]),
+            "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+        asm(FG_M6("op_sel:[0,1,0,0]") : "+v"(sh) : "v"(q[11 % MAXO]), "v"(q[10 % MAXO]), "v"(q[9 % MAXO]), "v"(q[8 % MAXO]), "v"(q[7 % MAXO]), "v"(q[6 % MAXO]),
+            "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
+        asm(FG_M6("op_sel:[0,1,0,0]") : "+v"(sh) : "v"(q[5 % MAXO]), "v"(q[4 % MAXO]), "v"(q[3 % MAXO]), "v"(q[2 % MAXO]), "v"(q[1 % MAXO]), "v"(q[0]),
+            "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+#undef FG_M6
+#undef FG_M4
+#undef FG_H
+    return (i64)(((u64)(i64)sh) << 12) + (i64)sl;
+}
 template <int MAXO> FGI i64 fir64(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
 {
     i64 sm = 0;
@@ -784,7 +818,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     const int32_t x = !MS ? (c == 0 ? l : r) : (c == 0 ? l : c == 1 ? r : c == 2 ? ((l + r) >> 1) : (l - r));
-                    h[c][(MAXO - 1 - j) % MAXO] = x;
+                    h[c][(MAXO - 1 - j) % MAXO] = ACC64 ? fpack(x) : x;
                 }
             }
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
@@ -795,11 +829,11 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                     int32_t res;
                     if (!ACC64) res = x - (fir24<MAXO>(q[c], h[c], u) >> shift[c]);
                     else {
-                        const i64 rr = (i64)x - (fir64<MAXO>(q[c], h[c], u) >> shift[c]);
+                        const i64 rr = (i64)x - (fir48<MAXO>(q[c], h[c], u) >> shift[c]);
                         if (rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) ovf[c] = 1;
                         res = (int32_t)rr;
                     }
-                    h[c][u] = x;
+                    h[c][u] = ACC64 ? fpack(x) : x;
                     // warm-up samples (the first `order` of the block, all in lane 0) are not residuals
                     if (!guard || lane > 0 || s >= order[c]) psum[c] += fabs32(res);
                 }
@@ -1130,7 +1164,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
                 if (lane > 0) x = fcv<MS, C_>(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? rowR[(int)seg - 1 - j - (int)rstr] : 0);
-                h[(MAXO - 1 - j) % MAXO] = x;
+                h[(MAXO - 1 - j) % MAXO] = ACC64 ? fpack(x) : x;
             }
             uint32_t pos = p0, len = 0;
             // Emission without LDS atomics (they run at about one lane per clock on this hardware).  A lane's bits are
@@ -1170,8 +1204,8 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 else {
                     int32_t res;
                     if (!ACC64) res = x - (fir24<MAXO>(q, h, u) >> shift);
-                    else res = (int32_t)((i64)x - (fir64<MAXO>(q, h, u) >> shift));
-                    h[u] = x;
+                    else res = (int32_t)((i64)x - (fir48<MAXO>(q, h, u) >> shift));
+                    h[u] = ACC64 ? fpack(x) : x;
                     const uint32_t uu = ((uint32_t)res << 1) ^ (uint32_t)(res >> 31);
                     lead = uu >> kr;
                     val = kone | (uu & kmask);
