@@ -1,5 +1,6 @@
 // fg_ctx.cpp -- device context, settings resolution, window tables, MD5/CRC and the batch encode entry
 // points of libflacgpu (Part 2 of include/flacgpu.h).
+#include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -103,6 +104,20 @@ bool flacgpu_ctx::sync_windows()
 }
 
 // ------------------------------------------------------------------ context
+hipError_t fg_stream_wait(hipStream_t stream)
+{
+    static const long spin_us = getenv("FLACGPU_SPIN_US") ? atol(getenv("FLACGPU_SPIN_US")) : 3000;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
+
 extern "C" int flacgpu_device_count(void)
 {
     int n = 0;
@@ -468,7 +483,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         tail[0] = tail[1] = 0;
         if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
         if (hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
-        return hipStreamSynchronize(c->stream) == hipSuccess;
+        return fg_stream_wait(c->stream) == hipSuccess;
     };
     if (!finish_pass()) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
     if ((uint32_t)tail[1] & FG_ERR_REDO) {

@@ -86,6 +86,10 @@ struct flacgpu_ctx {
 
 flacgpu_ctx *fg_default_ctx();   // lazily created context on the current/default device
 
+// End-of-call wait.  The batch calls last one to a few milliseconds; a blocking hipStreamSynchronize adds its wake-up
+// latency to each of them, so the stream is polled for a bounded time first (FLACGPU_SPIN_US, default 3000; 0 = never).
+hipError_t fg_stream_wait(hipStream_t stream);
+
 int fg_resolve_settings(flacgpu_settings *s);
 // settings helpers shared by the libFLAC-style encoder and the batch API
 void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, bool debug, FgEncParams *P);

@@ -391,7 +391,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         h_frames->resize(nframes);
         if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
     }
-    if (!HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    if (!HIPOK(fg_stream_wait(c->stream))) { fg_set_error("decode kernel failed"); return false; }
     st->total_samples = tot[0];
     st->max_blocksize = (uint32_t)tot[1];
     if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
