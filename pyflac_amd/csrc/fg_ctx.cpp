@@ -310,6 +310,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     uint64_t nb = 0;
     for (uint32_t i = 0; i < nstreams; i++) nb += (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
     descs.reserve(nb);
+    uint32_t win_n = 0, win_off = 0;                     // the window table is looked up when the block length changes
     for (uint32_t i = 0; i < nstreams; i++) {
         uint64_t pos = 0;
         uint32_t fn = streams[i].first_frame;
@@ -319,7 +320,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             d.pcm_off = streams[i].pcm_offset + pos;
             d.n = (uint32_t)std::min<uint64_t>(left, s->blocksize);
             d.frame_number = fn++;
-            d.win_off = s->max_lpc_order ? c->window_offset(d.n, s->apod_parts) : 0;
+            if (s->max_lpc_order && d.n != win_n) { win_n = d.n; win_off = c->window_offset(d.n, s->apod_parts); }
+            d.win_off = s->max_lpc_order ? win_off : 0;
             d.forced_ca = 0xFF;
             d.out_slot = (uint32_t)descs.size();
             d.reserved = 0;
