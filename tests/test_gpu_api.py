@@ -361,3 +361,49 @@ class TestMetadataPassThrough:
         assert got['ok'] == want['ok']
         assert [b['type'] for b in got['blocks']] == [b['type'] for b in want['blocks']]
         assert got['blocks'] == want['blocks']
+
+
+class TestConcurrentInstances:
+    """SURVEY section 8b, threading: different encoder / decoder instances are used concurrently from different threads (the
+    reference's StreamDecoder even runs on its own daemon thread).  The instances share one device context inside the
+    library; every stream must still come out byte-identical and decode back to its input."""
+
+    def test_encoders_and_decoders_on_threads(self):
+        import threading
+        import pyflac_amd
+        from oracle import oracle as O
+        from pyflac_amd import synth
+        nthreads = 6
+        inputs = [synth.config2_stereo16(1.5 + 0.25 * i, 40 + i) for i in range(nthreads)]
+        results = [None] * nthreads
+        errors = []
+
+        def work(i):
+            try:
+                chunks, blocks = [], []
+                enc = pyflac_amd.StreamEncoder(48000, lambda b, n, s, f: chunks.append(b), compression_level=5 if i % 2 else 8,
+                                               blocksize=4096, verify=bool(i % 3 == 0))
+                for j in range(0, len(inputs[i]), 30000):                 # several process() calls per stream
+                    enc.process(inputs[i][j:j + 30000])
+                assert enc.finish()
+                stream = b''.join(chunks)
+                dec = pyflac_amd.StreamDecoder(lambda a, sr, ch, n: blocks.append(a))
+                for j in range(0, len(stream), 50000):
+                    dec.process(stream[j:j + 50000])
+                dec.finish()
+                results[i] = (stream, np.concatenate(blocks))
+            except Exception as e:       # noqa: BLE001
+                errors.append((i, repr(e)))
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not errors, errors
+        for i in range(nthreads):
+            stream, pcm = results[i]
+            cfg, _ = O.config(5 if i % 2 else 8, 2, 16, 48000, 4096)
+            want, _sizes = O.encode_stream(cfg, inputs[i].astype(np.int32))
+            assert stream == want, i
+            assert np.array_equal(pcm, inputs[i]), i
