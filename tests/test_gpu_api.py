@@ -407,3 +407,16 @@ class TestConcurrentInstances:
             want, _sizes = O.encode_stream(cfg, inputs[i].astype(np.int32))
             assert stream == want, i
             assert np.array_equal(pcm, inputs[i]), i
+
+
+class TestRandomDamage:
+    """Seeded random damage (bit flips, deletions, insertions, zeroed runs, truncation) anywhere behind the metadata of the
+    four fixture streams: the decoder always finishes, never delivers anything but silence or the exact clean samples at
+    the frame's own sample number, and sample numbers never run backwards (tests/tools/gpu_damage_fuzz.py runs thousands)."""
+
+    @pytest.mark.timeout(300)
+    @pytest.mark.parametrize('chunk', range(4))
+    def test_never_garbage(self, chunk):
+        from tests.tools import gpu_damage_fuzz
+        for seed in range(chunk * 40, chunk * 40 + 40):
+            gpu_damage_fuzz.check(['stereo', 'mono', 'surround', '32bit'][seed % 4], seed)
