@@ -420,3 +420,60 @@ class TestRandomDamage:
         from tests.tools import gpu_damage_fuzz
         for seed in range(chunk * 40, chunk * 40 + 40):
             gpu_damage_fuzz.check(['stereo', 'mono', 'surround', '32bit'][seed % 4], seed)
+
+
+class TestRandomChunking:
+    """The stream encoder buffers across process() calls (blocksize + 1 look-ahead): however the input is cut up
+    -- empty calls, single samples, pieces longer than several blocks -- the callbacks carry the same bytes as for one call,
+    which are the oracle's."""
+
+    @pytest.mark.parametrize('seed', range(6))
+    def test_any_chunking_same_bytes(self, seed):
+        import pyflac_amd
+        from oracle import oracle as O
+        from tests import fuzzgen
+        r = np.random.default_rng(500 + seed)
+        ch = int(r.choice([1, 2, 2, 3]))
+        bps = int(r.choice([16, 16, 32]))
+        bs = int(r.choice([0, 576, 1000, 4096]))
+        level = int(r.choice([0, 3, 5, 8]))
+        n = int(r.integers(1, 30000))
+        pcm, _kind = fuzzgen._signal(r, n, ch, 16 if bps == 16 else 24)
+        pcm = pcm.astype(np.int16 if bps == 16 else np.int32)
+        if bps == 32:
+            pcm = pcm * 256                                  # int32 input means 32 bps in pyFLAC; exercise the top bits
+        cfg, rc = O.config(level, ch, bps, 44100, bs, True)
+        assert rc == 0
+        want, _ = O.encode_stream(cfg, pcm.astype(np.int32))
+        cuts = sorted(set(int(x) for x in r.integers(0, n + 1, int(r.integers(0, 40)))))
+        cuts = [0] + cuts + [n]
+        if r.random() < 0.5:
+            cuts = cuts[:1] + [cuts[1]] * 2 + cuts[1:]       # a repeated cut = an empty call
+        chunks = []
+        enc = pyflac_amd.StreamEncoder(44100, lambda b, nb, s, f: chunks.append(b), compression_level=level, blocksize=bs)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            enc.process(pcm[a:b])
+        assert enc.finish()
+        assert b''.join(chunks) == want, (seed, ch, bps, bs, level, n, len(cuts))
+
+    @pytest.mark.parametrize('seed', range(4))
+    def test_decoder_any_chunking(self, seed):
+        """The same for the decoder: the stream arrives in pieces of 1 byte to 100 KB (frames, headers and the metadata cut
+        anywhere); the blocks delivered are those of one big call."""
+        import pyflac_amd
+        name = ['stereo', 'mono', 'surround', '32bit'][seed]
+        with open(os.path.join(cases.GOLDEN, 'data', name + '.flac'), 'rb') as f:
+            data = f.read()
+        from tests import abi_decode
+        want = np.concatenate(abi_decode.decode(data)['blocks'])
+        r = np.random.default_rng(700 + seed)
+        blocks = []
+        dec = pyflac_amd.StreamDecoder(lambda a, sr, ch, n: blocks.append(a))
+        pos = 0
+        while pos < len(data):
+            k = int(r.choice([1, 2, 7, 100, 4096, 8192, 100000]))
+            dec.process(data[pos:pos + k])
+            pos += k
+        dec.finish()
+        got = np.concatenate(blocks)
+        assert np.array_equal(got.astype(np.int64), want.astype(np.int64))
