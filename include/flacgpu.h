@@ -559,6 +559,10 @@ int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t l
                               uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
                               uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
 
+/* FLAC__stream_encoder_process_interleaved for 16-bit interleaved input (an extension beside the libFLAC entry point,
+ * stream_encoder.h:1777-1824: same buffering, same return value): saves the caller the widening copy to FLAC__int32. */
+FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *encoder, const int16_t *buffer, uint32_t samples);
+
 /* Host-side frame indexer: parses metadata and frame headers of a complete FLAC stream in host memory and
  * returns frame byte offsets (validated by header CRC-8 and chained by frame CRC-16).  Returns the number
  * of frames, or a negative value on error. */

@@ -105,7 +105,7 @@ DATA_SYMBOLS = ['FLAC__StreamEncoderStateString', 'FLAC__StreamEncoderInitStatus
 EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu_ctx_create', 'flacgpu_ctx_destroy',
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
-                 'flacgpu_index_frames']
+                 'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16']
 
 _lib = None
 
@@ -184,6 +184,8 @@ def lib():
     L.flacgpu_decode_frames.restype = C.c_int
     L.flacgpu_decode_frames_dev.argtypes = L.flacgpu_decode_frames.argtypes
     L.flacgpu_decode_frames_dev.restype = C.c_int
+    L.flacgpu_stream_encoder_process_interleaved_i16.argtypes = [vp, vp, C.c_uint32]
+    L.flacgpu_stream_encoder_process_interleaved_i16.restype = C.c_int
     L.flacgpu_index_frames.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(StreamInfo), C.POINTER(C.c_uint64)]
     L.flacgpu_index_frames.restype = C.c_int64
     _lib = L

@@ -574,6 +574,19 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *enc, co
     return encode_pending(e, false) ? 1 : 0;
 }
 
+// Extension (include/flacgpu.h): the same with 16-bit interleaved input, widened straight into the pending buffer.  pyFLAC
+// widens int16 arrays to int32 in numpy before the call (pyflac/encoder.py:112); taking them as they are saves that pass.
+FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *enc, const int16_t *buffer, uint32_t samples)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_OK) return 0;
+    const size_t nv = (size_t)samples * e->s.channels, base = e->pending.size();
+    e->pending.resize(base + nv);
+    int32_t *dst = e->pending.data() + base;
+    for (size_t i = 0; i < nv; i++) dst[i] = buffer[i];
+    return encode_pending(e, false) ? 1 : 0;
+}
+
 FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *enc, const FLAC__int32 *const buffer[], uint32_t samples)
 {
     EncImpl *e = impl(enc);

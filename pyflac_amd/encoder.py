@@ -102,8 +102,13 @@ class _Encoder:
             self._bits_per_sample = self._explicit_bps or samples.dtype.itemsize * 8
             self._init()
 
-        samples = np.ascontiguousarray(samples).astype(np.int32)
-        result = _L.FLAC__stream_encoder_process_interleaved(self._encoder, samples.ctypes.data, len(samples))
+        if samples.dtype == np.int16 and self._bits_per_sample == 16:
+            # the library widens 16-bit input itself (one pass less than the reference's astype(int32), encoder.py:112)
+            samples = np.ascontiguousarray(samples)
+            result = _L.flacgpu_stream_encoder_process_interleaved_i16(self._encoder, samples.ctypes.data, len(samples))
+        else:
+            samples = np.ascontiguousarray(samples).astype(np.int32)
+            result = _L.FLAC__stream_encoder_process_interleaved(self._encoder, samples.ctypes.data, len(samples))
         if not result:
             raise EncoderProcessException(str(self.state))
 
