@@ -8,6 +8,7 @@
 // checking and channel reconstruction runs on the GPU; there is no CPU decode fallback.
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 
 #include <algorithm>
 
@@ -400,9 +401,9 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         std::vector<uint32_t> redo;
         for (uint32_t i = 0; i < nframes; i++) if (res[i].err == 3) redo.push_back(i);
         if (!redo.empty()) {
-            if (!c->descs.ensure(redo.size() * 4)) return false;
-            if (!HIPOK(hipMemcpyAsync(c->descs.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, c->stream))) return false;
-            if (fg_launch_decode_slow((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, (const uint32_t *)c->descs.p, (uint32_t)redo.size(),
+            if (!c->dec_redo.ensure(redo.size() * 4)) return false;   // own buffer: `descs` caches the encoder's block list
+            if (!HIPOK(hipMemcpyAsync(c->dec_redo.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, c->stream))) return false;
+            if (fg_launch_decode_slow((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, (const uint32_t *)c->dec_redo.p, (uint32_t)redo.size(),
                                       (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (const uint16_t *)c->crctab.p, (int32_t *)c->dec_scratch.p,
                                       interleave ? 1u : 0u, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
             if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream)) ||
@@ -532,12 +533,21 @@ bool pull(DecImpl *d, bool *short_read)
         *short_read = false;
         return true;
     }
-    const FLAC__StreamDecoderReadStatus rs = d->read_cb(&d->pub, d->buf.data() + old, &got, d->client);
+    // libFLAC calls the read callback again when it answers CONTINUE with no bytes (bitreader.c refills until it has data
+    // or the callback reports end of stream / abort); a client that never produces data spins there too.  The retry is
+    // bounded so that a broken callback ends in ABORTED instead of a hang.
+    FLAC__StreamDecoderReadStatus rs = FLAC__STREAM_DECODER_READ_STATUS_CONTINUE;
+    for (uint32_t tries = 0;; tries++) {
+        got = want;
+        rs = d->read_cb(&d->pub, d->buf.data() + old, &got, d->client);
+        if (rs != FLAC__STREAM_DECODER_READ_STATUS_CONTINUE || got != 0) break;
+        if (tries >= (1u << 20)) { d->buf.resize(old); d->state = FLAC__STREAM_DECODER_ABORTED; return false; }
+        if (tries >= 64) std::this_thread::yield();
+    }
     if (rs == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { d->buf.resize(old); d->state = FLAC__STREAM_DECODER_ABORTED; return false; }
     if (got > want) got = want;
     d->buf.resize(old + got);
-    if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || (got == 0 && rs != FLAC__STREAM_DECODER_READ_STATUS_CONTINUE)) d->eof = true;
-    if (got == 0 && rs == FLAC__STREAM_DECODER_READ_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return false; }  // contract violation
+    if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || got == 0) d->eof = true;
     *short_read = got < want;
     return true;
 }

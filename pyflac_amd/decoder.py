@@ -85,16 +85,23 @@ class _Decoder:
                 if getattr(self, '_eof_when_empty', False) and not self._buffer:
                     num_bytes[0] = 0
                     return 1   # END_OF_STREAM: a one-shot buffer has nothing more to come
-                # wait until there is something in the buffer, an error occurred, or finish() was called
-                self._event.wait()
-                if self._error:
-                    return 2   # ABORT
-                if self._done:
-                    num_bytes[0] = 0
-                    return 1   # END_OF_STREAM
                 maximum_bytes = int(num_bytes[0])
                 data = bytearray()
-                self._lock.acquire()
+                while True:
+                    # wait until there is something in the buffer, an error occurred, or finish() was called
+                    self._event.wait()
+                    if self._error:
+                        return 2   # ABORT
+                    self._lock.acquire()
+                    if self._buffer or self._done:
+                        break
+                    # woken with nothing to hand over (the flag outlived the data it announced): wait again
+                    self._event.clear()
+                    self._lock.release()
+                if self._done and not self._buffer:
+                    self._lock.release()
+                    num_bytes[0] = 0
+                    return 1   # END_OF_STREAM
                 try:
                     # whole queued items while they fit, then the head of the next one; items are memoryviews, so taking
                     # a head is O(1) (slicing a bytes object here would copy the remainder on every call)
@@ -107,7 +114,7 @@ class _Decoder:
                             self._buffer.popleft()
                         else:
                             self._buffer[0] = head[take:]
-                    if len(self._buffer) == 0:
+                    if len(self._buffer) == 0 and not self._done:
                         self._event.clear()
                 finally:
                     self._lock.release()
@@ -190,10 +197,11 @@ class StreamDecoder(_Decoder):
         view = memoryview(data).cast('B')
         if len(view) == 0:
             return
+        # the flag is raised under the lock: the reader clears it under the same lock only when the deque is empty
         self._lock.acquire()
         self._buffer.append(view)
-        self._lock.release()
         self._event.set()
+        self._lock.release()
 
     def finish(self):
         """Drain the buffer, stop the thread, reset the decoder.
@@ -203,8 +211,9 @@ class StreamDecoder(_Decoder):
         """
         while self._thread.is_alive() and self._error is None and len(self._buffer) > 0:
             time.sleep(0.01)
-        self._done = True
-        self._event.set()
+        with self._lock:   # under the lock, so that the reader cannot clear the flag after it was raised for good
+            self._done = True
+            self._event.set()
         self._thread.join()
         super().finish()
         if self._error:
