@@ -503,20 +503,28 @@ void flacgpu_ctx_destroy(flacgpu_ctx *ctx);
 const char *flacgpu_last_error(void);
 
 /* One stream of a batch: `nsamples` inter-channel samples starting at sample index `pcm_offset` of the
- * device PCM buffer; frames are numbered from first_frame. */
+ * device PCM buffer; frames are numbered from first_frame.  A stream may be handed over in several calls
+ * (first_frame = frames already encoded): with loose mid-side (levels 1 and 4) libFLAC decides the channel
+ * assignment on every `period`-th frame of the STREAM and the frames in between copy it
+ * (stream_encoder.h:826-838), so a continuation call passes the previous call's
+ * flacgpu_encode_stats.last_channel_assignment in prev_channel_assignment (0 at the start of a stream). */
 typedef struct {
     uint64_t pcm_offset;
     uint64_t nsamples;
     uint32_t first_frame;
-    uint32_t reserved;
+    uint32_t prev_channel_assignment;
 } flacgpu_stream_desc;
 
 typedef struct {
     uint32_t nblocks;             /* frames produced */
     uint32_t error_flags;         /* OR of per-block FG_ERR_* bits; 0 = ok */
     uint64_t total_bytes;         /* bytes written to d_out */
-    float encode_kernel_ms;       /* HIP-event time of the frame-encode kernel */
-    float total_gpu_ms;           /* HIP-event time of the whole enqueue (encode + compaction) */
+    float encode_kernel_ms;       /* HIP-event time of the frame-encode kernels (analysis + packing) */
+    float total_gpu_ms;           /* HIP-event time of the whole enqueue (encode + frame assembly) */
+    uint32_t last_channel_assignment;  /* loose mid-side: assignment (0 independent / 3 mid-side) of the last frame of the last stream */
+    uint32_t redo_blocks;         /* blocks the specialised kernels handed to the generic kernel */
+    float stage_ms[8];            /* with flacgpu_set_stage_timing(ctx, 1): autocorrelation, Levinson-Durbin, evaluation, packing,
+                                     sizes + scan, assembly + CRC-16 (HIP events between the kernels); else zeros */
 } flacgpu_encode_stats;
 
 /* Encode every block of every stream.  d_pcm: device address of interleaved PCM (int32, or int16 when
@@ -534,6 +542,7 @@ uint64_t flacgpu_encode_bound(const flacgpu_settings *settings, const flacgpu_st
 /* Debug: per-block analysis records of the last flacgpu_encode_streams call made with
  * flacgpu_set_debug(ctx, 1).  Layout: FgDebugRec (pyflac_amd/csrc/fg_types.h). */
 void flacgpu_set_debug(flacgpu_ctx *ctx, int on);
+void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int on);   /* fill flacgpu_encode_stats.stage_ms (adds event records between the kernels) */
 int flacgpu_copy_debug(flacgpu_ctx *ctx, void *host_dst, uint32_t first_block, uint32_t nblocks);
 int flacgpu_copy_block_results(flacgpu_ctx *ctx, void *host_dst, uint32_t nblocks);
 

@@ -53,12 +53,13 @@ class Settings(C.Structure):
 
 class StreamDesc(C.Structure):
     _fields_ = [('pcm_offset', C.c_uint64), ('nsamples', C.c_uint64), ('first_frame', C.c_uint32),
-                ('reserved', C.c_uint32)]
+                ('prev_channel_assignment', C.c_uint32)]
 
 
 class EncodeStats(C.Structure):
     _fields_ = [('nblocks', C.c_uint32), ('error_flags', C.c_uint32), ('total_bytes', C.c_uint64),
-                ('encode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float)]
+                ('encode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float),
+                ('last_channel_assignment', C.c_uint32), ('redo_blocks', C.c_uint32), ('stage_ms', C.c_float * 8)]
 
 
 class DecodeStats(C.Structure):

@@ -133,6 +133,7 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->evs[i]));
     if (!c->crctab.ensure(2048 * sizeof(uint16_t))) return false;
     if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -153,11 +154,12 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->descs, &c->slots, &c->results, &c->dbg, &c->crctab, &c->windows, &c->offsets, &c->scratch_pcm,
-                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo};
+                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo, &c->pipe};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 8; i++) if (c->evs[i]) (void)hipEventDestroy(c->evs[i]);
     for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -277,6 +279,7 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 }
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
+extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int on) { ctx->stage_timing = on != 0; }
 
 extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
 {
@@ -343,114 +346,159 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         P.sig_stride = 0;
         if (fg_enc_lds_bytes(&P) > 160 * 1024) { fg_set_error("settings need more LDS than the device has"); return false; }
     }
+    // ---- which kernels: the de-fused pipeline (flac_enc_pipe_impl.h) where it applies, round 1's single kernel with
+    // FLACGPU_PIPE=0, the generic kernel for everything else
+    const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
+    const bool use_pipe = cfg_fast && !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) && fg_pipe_supported(&P);
+    const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
+    const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
+    uint32_t chunk_cap_words = 0, fbw_words = 1280;
+    if (getenv("FLACGPU_FBW")) fbw_words = (uint32_t)atoi(getenv("FLACGPU_FBW"));
+    if (use_pipe) {
+        // a chunk holds at most a whole subframe (all of a subframe's bits may sit in one half) plus the frame header
+        const uint64_t per = ((uint64_t)s->blocksize * (s->bits_per_sample + 2)) / 8 + 512 + 64;
+        chunk_cap_words = (uint32_t)((per + 15) / 16 * 4);
+        const uint32_t need = s->channels * 2 * chunk_cap_words * 4;
+        if (need > P.slot_bytes) P.slot_bytes = (need + 255) & ~255u;
+    }
     if (!c->descs.ensure((size_t)nblocks * sizeof(FgBlockDesc))) return false;
     if (!c->slots.ensure((size_t)nblocks * P.slot_bytes)) return false;
     if (!c->results.ensure((size_t)nblocks * sizeof(FgBlockResult))) return false;
     if (!c->offsets.ensure(((size_t)nblocks + 2) * 8)) return false;
+    FgPipeLaunch PL;
+    memset(&PL, 0, sizeof PL);
+    if (use_pipe) {
+        if (!c->pipe.ensure(fg_pipe_scratch_bytes(&P, nblocks))) return false;
+        fg_pipe_carve(&P, nblocks, c->pipe.p, &PL.B);
+    }
     FgDebugRec *dbg = nullptr;
     if (c->debug) {
         if (!c->dbg.ensure((size_t)nblocks * sizeof(FgDebugRec))) return false;
         HIPCHK(hipMemsetAsync(c->dbg.p, 0, (size_t)nblocks * sizeof(FgDebugRec), c->stream));
         dbg = (FgDebugRec *)c->dbg.p;
     }
+    // can the pipeline / the single-wave kernel take this block?  (lane = segment: enough samples per lane for the
+    // predictor history, partitions no finer than a lane)
+    auto block_fast = [&](const FgBlockDesc &d) -> bool {
+        if (!cfg_fast) return false;
+        if (d.n < 64 * 16 || (d.n % 64) != 0) return false;
+        uint32_t pm = 0, b = d.n;
+        while (!(b & 1)) { pm++; b >>= 1; }
+        if (pm > s->max_partition_order) pm = s->max_partition_order;
+        return pm <= 6;
+    };
+    auto block_ws = [&](const FgBlockDesc &d) -> uint32_t { const uint32_t w = fg_pipe_block_ws(d.n); return (w == 2 && ws1_only) ? 1u : w; };
+    PL.pcm = d_pcm; PL.descs = (const FgBlockDesc *)c->descs.p; PL.windows = (const float *)c->windows.p; PL.P = P;
+    PL.slots = (uint8_t *)c->slots.p; PL.results = (FgBlockResult *)c->results.p; PL.dbg = dbg;
+    PL.chunk_cap_words = chunk_cap_words; PL.fbw_words = fbw_words; PL.acc64 = s->bits_per_sample > 16 ? 1 : 0;
+    PL.stream = (void *)c->stream;
     // the block list goes to the device once per distinct layout (repeated calls with the same streams skip the copy)
-    auto upload_descs = [&]() -> bool {
-        const size_t bytes = (size_t)nblocks * sizeof(FgBlockDesc);
-        if (c->dev_descs_ptr == c->descs.p && c->dev_descs.size() == descs.size() && memcmp(c->dev_descs.data(), descs.data(), bytes) == 0) return true;
-        if (hipMemcpyAsync(c->descs.p, descs.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { fg_set_error("H2D of the block list failed"); return false; }
+    auto upload_descs = [&](const std::vector<FgBlockDesc> &v, bool cache) -> bool {
+        const size_t bytes = v.size() * sizeof(FgBlockDesc);
+        if (cache && c->dev_descs_ptr == c->descs.p && c->dev_descs.size() == v.size() && memcmp(c->dev_descs.data(), v.data(), bytes) == 0) return true;
+        if (hipMemcpyAsync(c->descs.p, v.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { fg_set_error("H2D of the block list failed"); return false; }
         // the pageable copy is staged before the call returns, so the vector may be reused; remember what is there
-        c->dev_descs = descs;
-        c->dev_descs_ptr = c->descs.p;
+        if (cache) { c->dev_descs = v; c->dev_descs_ptr = c->descs.p; }
+        else { c->dev_descs.clear(); c->dev_descs_ptr = nullptr; }
         return true;
     };
-    // loose mid-side (levels 1, 4): the decision frames are independent of each other, the frames in between
-    // copy the decision.  First pass encodes the decision frames only.
+    // loose mid-side (levels 1, 4; stream_encoder.h:826-838): libFLAC decides between independent and mid-side coding on
+    // every `period`-th frame OF THE STREAM (frame number % period == 0) and the frames in between copy that decision, so
+    // the phase follows the absolute frame number and a continuation call starts with the assignment the previous call
+    // ended on.  The decision frames are independent of each other: a probe pass analyses them, the host spreads the result.
     if (P.do_mid_side && s->loose_mid_side) {
-        if (!upload_descs()) return false;
         uint32_t period = (uint32_t)((double)s->sample_rate * 0.4 / (double)s->blocksize + 0.5);
         if (period == 0) period = 1;
-        if (period > 1) {
-            std::vector<FgBlockDesc> dec;
-            std::vector<uint32_t> decidx;
-            size_t bi = 0;
-            for (uint32_t i = 0; i < nstreams; i++) {
-                const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
-                for (uint64_t k = 0; k < cnt; k += period) {
-                    FgBlockDesc pd = descs[bi + k];
-                    pd.out_slot = (uint32_t)dec.size();
-                    dec.push_back(pd); decidx.push_back((uint32_t)(bi + k));
-                }
-                bi += cnt;
+        std::vector<FgBlockDesc> dec, decp, decg;      // decision frames: all, pipeline-capable first, generic after
+        std::vector<uint32_t> decidx;
+        for (uint32_t b = 0; b < nblocks; b++)
+            if (descs[b].frame_number % period == 0) { decidx.push_back(b); (block_fast(descs[b]) && use_pipe ? decp : decg).push_back(descs[b]); }
+        dec = decp; dec.insert(dec.end(), decg.begin(), decg.end());
+        for (size_t k = 0; k < dec.size(); k++) dec[k].reserved = dec[k].out_slot;      // remember the block, probe into slot k
+        for (size_t k = 0; k < dec.size(); k++) dec[k].out_slot = (uint32_t)k;
+        std::vector<FgBlockResult> r(dec.size());
+        if (!dec.empty()) {
+            std::vector<FgBlockDesc> up = dec;
+            for (FgBlockDesc &d : up) d.reserved = 0;
+            if (!upload_descs(up, false)) return false;
+            if (!decp.empty()) {
+                PL.nblocks = (uint32_t)decp.size(); PL.stages = 1; PL.dbg = nullptr;
+                if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
+                PL.dbg = dbg;
             }
-            // loose mode compares only independent vs mid/side on decision frames
-            c->dev_descs.clear();
-            HIPCHK(hipMemcpyAsync(c->descs.p, dec.data(), dec.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
-            if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, (uint32_t)dec.size(),
+            if (!decg.empty() &&
+                fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + decp.size(), (const float *)c->windows.p, &P, (uint32_t)decg.size(),
                                  (uint8_t *)c->slots.p, (FgBlockResult *)c->results.p, nullptr, (const uint16_t *)c->crctab.p, c->stream) != 0) {
                 fg_set_error("encode kernel launch failed"); return false;
             }
-            std::vector<FgBlockResult> r(dec.size());
             HIPCHK(hipMemcpyAsync(r.data(), c->results.p, dec.size() * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            bi = 0;
-            size_t di = 0;
-            for (uint32_t i = 0; i < nstreams; i++) {
-                const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
-                for (uint64_t k = 0; k < cnt; k++) {
-                    if (k % period == 0) di = std::find(decidx.begin(), decidx.end(), (uint32_t)(bi + k)) - decidx.begin();
-                    const FgBlockResult &rr = r[di];
-                    const uint32_t ms = (rr.best_bits[2] + rr.best_bits[3]) < (rr.best_bits[0] + rr.best_bits[1]) ? 3u : 0u;
-                    descs[bi + k].forced_ca = ms;
-                }
-                bi += cnt;
-            }
-            if (!upload_descs()) return false;
         }
-        else {
-            // period 1: every frame decides, but only between independent and mid/side: handled by forcing
-            // after a probe is unnecessary -- emulate by a probe pass as well for simplicity
-            std::vector<FgBlockResult> r(nblocks);
-            if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nblocks, (uint8_t *)c->slots.p,
-                                 (FgBlockResult *)c->results.p, nullptr, (const uint16_t *)c->crctab.p, c->stream) != 0) {
-                fg_set_error("encode kernel launch failed"); return false;
+        std::vector<uint32_t> decision(nblocks, 0xFFFFFFFFu);
+        for (size_t k = 0; k < dec.size(); k++) {
+            const FgBlockResult &rr = r[k];
+            decision[dec[k].reserved] = (rr.best_bits[2] + rr.best_bits[3]) < (rr.best_bits[0] + rr.best_bits[1]) ? 3u : 0u;
+        }
+        size_t bi = 0;
+        for (uint32_t i = 0; i < nstreams; i++) {
+            const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+            uint32_t last = streams[i].prev_channel_assignment == 3 ? 3u : 0u;
+            for (uint64_t k = 0; k < cnt; k++) {
+                if (decision[bi + k] != 0xFFFFFFFFu) last = decision[bi + k];
+                descs[bi + k].forced_ca = last;
             }
-            HIPCHK(hipMemcpyAsync(r.data(), c->results.p, (size_t)nblocks * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            for (uint32_t b = 0; b < nblocks; b++)
-                descs[b].forced_ca = (r[b].best_bits[2] + r[b].best_bits[3]) < (r[b].best_bits[0] + r[b].best_bits[1]) ? 3u : 0u;
-            if (!upload_descs()) return false;
+            bi += cnt;
+            st->last_channel_assignment = last;
         }
     }
-    // blocks the specialised kernel covers go first, the rest to the generic kernel (same bytes either way)
+    // blocks the specialised kernels cover go first, the rest to the generic kernel (same bytes either way)
     uint32_t nfast = 0;
     {
-        const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
         std::vector<FgBlockDesc> ordered;
         ordered.reserve(nblocks);
-        std::vector<FgBlockDesc> slow;
+        std::vector<FgBlockDesc> slow, ws1;
         for (const FgBlockDesc &d : descs) {
-            // lane = segment of n/64 samples: at least the predictor history per lane, partitions no finer than a lane
-            bool fast = cfg_fast && d.n >= 64 * 16 && (d.n & 63) == 0;    // more samples per lane than any predictor order
-            if (fast) {
-                uint32_t pm = 0, b = d.n;
-                while (!(b & 1)) { pm++; b >>= 1; }
-                if (pm > s->max_partition_order) pm = s->max_partition_order;
-                if (pm > 6) fast = false;
-            }
-            if (fast) ordered.push_back(d); else slow.push_back(d);
+            if (!block_fast(d)) slow.push_back(d);
+            else if (use_pipe && block_ws(d) != 2) ws1.push_back(d);
+            else ordered.push_back(d);
         }
+        PL.nblocks_ws2 = use_pipe ? (uint32_t)ordered.size() : 0;
+        ordered.insert(ordered.end(), ws1.begin(), ws1.end());
         nfast = (uint32_t)ordered.size();
         ordered.insert(ordered.end(), slow.begin(), slow.end());
         descs.swap(ordered);
-        if (!upload_descs()) return false;
+        if (!upload_descs(descs, true)) return false;
     }
+    const bool timing = c->stage_timing && use_pipe;
+    int nev = 0;
+    auto mark = [&]() { if (timing && nev < 8) (void)hipEventRecord(c->evs[nev++], c->stream); };
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const bool side = nfast > 0 && nblocks > nfast;     // overlap the few generic blocks with the fast launch
     if (side) {
         HIPCHK(hipEventRecord(c->evx[0], c->stream));
         HIPCHK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
     }
-    if (nfast) {
+    bool piped = false;
+    if (nfast && use_pipe) {
+        PL.nblocks = nfast;
+        if (timing) {
+            // one launch per stage group so that the events land between the kernels
+            mark();
+            PL.stages = 1;
+            // (analysis = autocorrelation + Levinson-Durbin + evaluation; the split inside is in the rocprof trace)
+            if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
+            mark();
+            PL.stages = 2;
+            if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
+            mark();
+        }
+        else {
+            PL.stages = 3;
+            if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
+        }
+        piped = true;
+    }
+    else if (nfast) {
         const int rc = fg_launch_encode_fast(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nfast, (uint8_t *)c->slots.p,
                                              (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream);
         if (rc == -1) nfast = 0;
@@ -468,41 +516,57 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         }
     }
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    // sizes -> offsets -> contiguous output, all queued behind the encode kernel; the host looks at the totals once, at the
-    // end.  (The copy kernel skips frames that would not fit `out_cap`; blocks the specialised kernel handed back show up as
-    // FG_ERR_REDO in the flags and are redone below, which repeats the scan and the copy: rare.)
+    // sizes -> offsets -> contiguous output, all queued behind the encode kernels; the host looks at the totals once, at the
+    // end.  (Frames that would not fit `out_cap` are skipped; blocks the specialised kernels handed back show up as
+    // FG_ERR_REDO in the flags and are redone below, which repeats the scan and the assembly: rare.)
     if (!c->ensure_pinned_res(64)) return false;
     unsigned long long *tail = (unsigned long long *)c->h_res;   // total bytes, OR of error flags
-    auto finish_pass = [&]() -> bool {
+    auto finish_pass = [&](bool first) -> bool {
+        if (piped && first && fg_launch_pipe_sizes((const FgBlockDesc *)c->descs.p, nfast, PL.B.chunk_bits, nw, (FgBlockResult *)c->results.p, c->stream) != 0) {
+            fg_set_error("sizes kernel launch failed"); return false;
+        }
         if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
             fg_set_error("scan kernel launch failed"); return false;
         }
-        if (d_out && fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
-                                    (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream, out_cap) != 0) {
-            fg_set_error("copy kernel launch failed"); return false;
+        if (first) mark();
+        if (d_out) {
+            const int rc = piped ? fg_launch_pipe_assemble((const FgBlockDesc *)c->descs.p, nblocks, (const uint8_t *)c->slots.p, P.slot_bytes,
+                                                           chunk_cap_words, nw, PL.B.chunk_bits, (const FgBlockResult *)c->results.p,
+                                                           (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, out_cap,
+                                                           (const uint16_t *)c->crctab.p, c->stream)
+                                 : fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
+                                                  (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream, out_cap);
+            if (rc != 0) { fg_set_error("frame assembly kernel launch failed"); return false; }
         }
+        if (first) mark();
         if (d_offsets && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
         tail[0] = tail[1] = 0;
         if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
         if (hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
         return fg_stream_wait(c->stream) == hipSuccess;
     };
-    if (!finish_pass()) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
+    if (!finish_pass(true)) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
     if ((uint32_t)tail[1] & FG_ERR_REDO) {
-        // blocks the specialised kernel declined (wasted bits): encode them with the generic kernel, then scan and copy again
+        // blocks the specialised kernels declined (absurd code lengths; wasted bits in round 1's kernel): encode them with the
+        // generic kernel, then scan and assemble again
         std::vector<FgBlockResult> r(nblocks);
         HIPCHK(hipMemcpyAsync(r.data(), c->results.p, (size_t)nblocks * sizeof(FgBlockResult), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         std::vector<FgBlockDesc> redo;
         for (uint32_t i = 0; i < nfast; i++) if (r[descs[i].out_slot].err & FG_ERR_REDO) redo.push_back(descs[i]);
+        st->redo_blocks = (uint32_t)redo.size();
         if (!redo.empty()) {
-            c->dev_descs.clear();
-            HIPCHK(hipMemcpyAsync(c->descs.p, redo.data(), redo.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
-            if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, (uint32_t)redo.size(), (uint8_t *)c->slots.p,
+            // the redo list goes behind the block list the assembly kernel still needs
+            if (!c->descs.ensure(((size_t)nblocks + redo.size()) * sizeof(FgBlockDesc))) return false;
+            if (c->dev_descs_ptr != c->descs.p && !upload_descs(descs, true)) return false;      // (the buffer moved)
+            PL.descs = (const FgBlockDesc *)c->descs.p;
+            FgBlockDesc *d_redo = (FgBlockDesc *)c->descs.p + nblocks;
+            HIPCHK(hipMemcpyAsync(d_redo, redo.data(), redo.size() * sizeof(FgBlockDesc), hipMemcpyHostToDevice, c->stream));
+            if (fg_launch_encode(d_pcm, d_redo, (const float *)c->windows.p, &P, (uint32_t)redo.size(), (uint8_t *)c->slots.p,
                                  (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream) != 0) {
                 fg_set_error("encode kernel launch failed"); return false;
             }
-            if (!finish_pass()) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
+            if (!finish_pass(false)) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
         }
     }
     st->total_bytes = tail[0];
@@ -511,6 +575,10 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
     HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
+    if (timing) {
+        // analysis, packing, sizes + scan, assembly
+        for (int k = 0; k + 1 < nev; k++) (void)hipEventElapsedTime(&st->stage_ms[k], c->evs[k], c->evs[k + 1]);
+    }
     return true;
 }
 

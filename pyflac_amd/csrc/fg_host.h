@@ -21,6 +21,18 @@ size_t fg_fast_lds_bytes(const FgEncParams *P, int nch, int ms, int maxo);
 int fg_launch_encode_fast(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
                           uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
                           const uint16_t *d_crctab, hipStream_t stream);
+// de-fused pipeline (flac_enc_pipe.hip)
+int fg_pipe_supported(const FgEncParams *P);
+uint32_t fg_pipe_block_ws(uint32_t n);
+size_t fg_pipe_scratch_bytes(const FgEncParams *P, uint32_t nblocks);
+void fg_pipe_carve(const FgEncParams *P, uint32_t nblocks, void *base, FgPipeBufs *B);
+int fg_launch_encode_pipe(const FgPipeLaunch *L);
+int fg_launch_pipe_sizes(const FgBlockDesc *d_descs, uint32_t npipe, const uint32_t *d_chunk_bits, uint32_t nw, FgBlockResult *d_results,
+                         hipStream_t stream);
+int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
+                            uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
+                            const unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
+                            hipStream_t stream);
 int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
                    const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap);
@@ -62,9 +74,11 @@ struct flacgpu_ctx {
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
     hipEvent_t evx[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing
+    bool stage_timing = false;
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_prof, dec_redo;
+        dec_scratch, dec_subs, dec_prof, dec_redo, pipe;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`
     const void *dev_descs_ptr = nullptr;
     std::vector<float> h_windows;

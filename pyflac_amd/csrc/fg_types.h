@@ -68,6 +68,46 @@ struct FgDebugRec {
     uint64_t t[16];    // clock64() stamps at stage boundaries
 };
 
+
+// ---- de-fused encode pipeline (flac_enc_pipe_impl.h): records handed from kernel to kernel through HBM
+struct FgPipeDec {         // decision of one candidate of one block (K4 -> K5)
+    uint32_t bits;         // size of the best subframe found for this candidate
+    uint32_t type;         // 0 constant, 1 verbatim, 2 fixed, 3 lpc
+    uint32_t order, prec;
+    int32_t shift;
+    uint32_t porder, method, wasted;
+    int32_t q[12];
+    uint8_t k[64];         // Rice parameter per partition
+};
+
+struct FgPipeBufs {
+    double *autoc;         // [block][cand][nvec][MAXO + 1]                      K2 -> K3
+    uint32_t *wasted;      // [block][cand]                                      K2 -> K3, K4
+    uint32_t *nv;          // [block] autocorrelation vectors actually computed  K2 -> K3, K4
+    int32_t *qres;         // [block][cand][nvec][MAXO]                          K3 -> K4
+    uint32_t *lres;        // [block][cand][nvec]                                K3 -> K4
+    FgPipeDec *dec;        // [block][cand]                                      K4 -> K5
+    uint32_t *chunk_bits;  // [block][4]                                         K5 -> sizes, K6
+};
+
+struct FgPipeLaunch {
+    const void *pcm;
+    const FgBlockDesc *descs;
+    const float *windows;
+    FgEncParams P;
+    FgPipeBufs B;
+    uint32_t nblocks;
+    uint8_t *slots;
+    FgBlockResult *results;
+    FgDebugRec *dbg;
+    uint32_t chunk_cap_words;   // capacity of one wave's chunk inside the block's slot
+    uint32_t fbw_words;         // LDS frame-bit window of one packing wave
+    uint32_t nblocks_ws2;       // the first nblocks_ws2 blocks are packed by two waves per subframe, the rest by one
+    uint32_t acc64;             // > 16 bit samples
+    uint32_t stages;            // bit 0: analysis (K2-K4), bit 1: pack (K5)
+    void *stream;               // hipStream_t
+};
+
 // ---- decoder ----
 struct FgDecFrame {
     uint64_t byte_off;     // frame start in the stream buffer

@@ -1,0 +1,1422 @@
+// flac_enc_pipe_impl.h -- the de-fused FLAC frame encoder for gfx950: five kernels per launch instead of one.
+//
+// Round 1's single kernel (flac_enc_fast_impl.h) kept a block in one wavefront from PCM to frame.  It needed 240 VGPRs and
+// 22 KB of LDS per block, so 1.75 waves per SIMD were resident and no stage could hide its latency (dependent VALU chains,
+// the 4096-step fp64 autocorrelation chain, LDS round trips).  The stages want different mappings and different register
+// budgets, and HBM bandwidth is nowhere near a limit here (the encoder moves ~0.3 GB per launch), so the stages are
+// separate kernels that hand small records through HBM and re-read the PCM (it stays in the Infinity Cache):
+//
+//   K2 fg_pipe_autoc_kernel     wave = block.  Windowed signal straight from HBM, staged per 128-sample chunk as doubles,
+//                               libFLAC's order-preserving fp64 chains (lane = candidate x lag).  5.4 KB of LDS and < 64
+//                               VGPRs per wave: 7-8 waves per SIMD hide the dependent-FMA and LDS latency.  Also ORs the
+//                               samples: wasted bits per candidate.  The autocorrelation of the shifted signal is the
+//                               autocorrelation of the unshifted one times 2^-2w, exactly (power-of-two scaling commutes
+//                               with every rounding on the way), so the chain never waits for the wasted-bits result.
+//   K3 fg_pipe_levinson_kernel  lane = (block, candidate, window): Levinson-Durbin, order guess, quantiser.  The round-1
+//                               kernel ran this on 4 of 64 lanes.
+//   K4 fg_pipe_eval_kernel      workgroup = block, wave = candidate (L, R, M, S).  Samples staged once in LDS (lane =
+//                               segment rows); fixed-predictor error sums, constant detection, FIR residual of the LPC
+//                               candidates (history in VGPRs, coefficients in SGPRs), Rice partition search.  One
+//                               candidate per wave keeps it under 64 VGPRs: 8 blocks = 32 waves per CU.
+//   K5 fg_pipe_pack_kernel      workgroup = block, wave = (subframe, half).  Each wave Rice-codes its 64 segments into a
+//                               private word-aligned chunk (exact lengths, prefix sum, register-assembled words -- the
+//                               round-1 packer) with no cross-wave dependency.
+//   K6 fg_pipe_assemble_kernel  wave = frame.  Concatenates the chunks at bit granularity (funnel shifts), pads, computes
+//                               the CRC-16 and writes the frame at its final byte offset in the output stream (this
+//                               replaces the slot -> stream compaction copy of round 1).
+//
+// Bytes are identical to the round-1 kernels and to libFLAC 1.4.3 (tests/test_gpu_encode.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "fg_dev.h"
+#include "fg_types.h"
+
+#define FG_LN2 0.69314718055994530942
+#define LDS __attribute__((address_space(3)))
+#define FGI __device__ __forceinline__
+
+#define FGP_DH 32                        // autocorrelation: history doubles kept in front of each chunk
+#define FGP_CK 128                       // autocorrelation: chunk length
+// doubles per candidate row: 352 words, i.e. 32 banks (of 64) from row to row -- the two candidate rows that share a
+// ds_read_b64 lane group ({0-31} / {32-63}) read up to 13 consecutive doubles each and never meet on a bank
+#define FGP_CSTR (FGP_DH + FGP_CK + 16)
+
+using namespace fgdev;
+
+namespace {
+
+template <bool ACC64> struct PipeTypes {
+    typedef typename std::conditional<ACC64, u64, uint32_t>::type sum_t;
+    typedef typename std::conditional<ACC64, int32_t, int16_t>::type samp_t;   // <= 16 bit input is staged as int16
+    static constexpr uint32_t PADE = 2;   // elements of skew between rows: odd word stride, no bank conflicts
+};
+
+template <bool MS, int C> FGI int32_t pcv(int32_t L, int32_t R)
+{
+    if (!MS) return C == 0 ? L : R;
+    if (C == 0) return L;
+    if (C == 1) return R;
+    if (C == 2) return (L + R) >> 1;
+    return L - R;
+}
+
+FGI uint32_t pabs32(int32_t v) { return (uint32_t)(v < 0 ? -v : v); }
+
+// sum_j q[j] * h[(u - 1 - j) mod MAXO]: one v_mad_i32_i24 per tap, the coefficient from an SGPR (one candidate per wave, so
+// the MAXO coefficients are wave-uniform and fit the scalar file).  History slot of sample s is s mod MAXO.
+template <int MAXO> FGI int32_t pfir24(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
+{
+    int32_t sm = 0;
+#define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
+    if (MAXO == 8) {
+        asm("v_mad_i32_i24 %0, %1, %9, %0\n\tv_mad_i32_i24 %0, %2, %10, %0\n\tv_mad_i32_i24 %0, %3, %11, %0\n\t"
+            "v_mad_i32_i24 %0, %4, %12, %0\n\tv_mad_i32_i24 %0, %5, %13, %0\n\tv_mad_i32_i24 %0, %6, %14, %0\n\t"
+            "v_mad_i32_i24 %0, %7, %15, %0\n\tv_mad_i32_i24 %0, %8, %16, %0"
+            : "+v"(sm)
+            : "s"(q[7 % MAXO]), "s"(q[6 % MAXO]), "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]),
+              "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+    else {
+        asm("v_mad_i32_i24 %0, %1, %7, %0\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
+            "v_mad_i32_i24 %0, %4, %10, %0\n\tv_mad_i32_i24 %0, %5, %11, %0\n\tv_mad_i32_i24 %0, %6, %12, %0"
+            : "+v"(sm)
+            : "s"(q[11 % MAXO]), "s"(q[10 % MAXO]), "s"(q[9 % MAXO]), "s"(q[8 % MAXO]), "s"(q[7 % MAXO]), "s"(q[6 % MAXO]),
+              "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
+        asm("v_mad_i32_i24 %0, %1, %7, %0\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
+            "v_mad_i32_i24 %0, %4, %10, %0\n\tv_mad_i32_i24 %0, %5, %11, %0\n\tv_mad_i32_i24 %0, %6, %12, %0"
+            : "+v"(sm)
+            : "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]),
+              "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+#undef FG_H
+    return sm;
+}
+// 17..25-bit samples: the exact 64-bit sum from two 16 x 16-bit MAD chains over a history packed as (x >> 12, x & 0xFFF)
+// (flac_enc_fast_impl.h fir48 has the derivation); coefficients from SGPRs.
+FGI int32_t ppack(int32_t x) { return (int32_t)(((uint32_t)(x >> 12) << 16) | ((uint32_t)x & 0xFFFu)); }
+template <int MAXO> FGI i64 pfir48(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
+{
+    int32_t sl = 0, sh = 0;
+#define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
+#define FG_M6(OPS) "v_mad_i32_i16 %0, %1, %7, %0 " OPS "\n\tv_mad_i32_i16 %0, %2, %8, %0 " OPS "\n\tv_mad_i32_i16 %0, %3, %9, %0 " OPS "\n\t" \
+                   "v_mad_i32_i16 %0, %4, %10, %0 " OPS "\n\tv_mad_i32_i16 %0, %5, %11, %0 " OPS "\n\tv_mad_i32_i16 %0, %6, %12, %0 " OPS
+#define FG_M4(OPS) "v_mad_i32_i16 %0, %1, %5, %0 " OPS "\n\tv_mad_i32_i16 %0, %2, %6, %0 " OPS "\n\tv_mad_i32_i16 %0, %3, %7, %0 " OPS "\n\t" \
+                   "v_mad_i32_i16 %0, %4, %8, %0 " OPS
+    if (MAXO == 8) {
+        asm(FG_M4("op_sel:[0,0,0,0]") : "+v"(sl) : "s"(q[7 % MAXO]), "s"(q[6 % MAXO]), "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)));
+        asm(FG_M4("op_sel:[0,0,0,0]") : "+v"(sl) : "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+        asm(FG_M4("op_sel:[0,1,0,0]") : "+v"(sh) : "s"(q[7 % MAXO]), "s"(q[6 % MAXO]), "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)));
+        asm(FG_M4("op_sel:[0,1,0,0]") : "+v"(sh) : "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+    else {
+        asm(FG_M6("op_sel:[0,0,0,0]") : "+v"(sl) : "s"(q[11 % MAXO]), "s"(q[10 % MAXO]), "s"(q[9 % MAXO]), "s"(q[8 % MAXO]), "s"(q[7 % MAXO]), "s"(q[6 % MAXO]),
+            "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
+        asm(FG_M6("op_sel:[0,0,0,0]") : "+v"(sl) : "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]),
+            "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+        asm(FG_M6("op_sel:[0,1,0,0]") : "+v"(sh) : "s"(q[11 % MAXO]), "s"(q[10 % MAXO]), "s"(q[9 % MAXO]), "s"(q[8 % MAXO]), "s"(q[7 % MAXO]), "s"(q[6 % MAXO]),
+            "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
+        asm(FG_M6("op_sel:[0,1,0,0]") : "+v"(sh) : "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]),
+            "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
+    }
+#undef FG_M6
+#undef FG_M4
+#undef FG_H
+    return (i64)(((u64)(i64)sh) << 12) + (i64)sl;
+}
+
+FGI double p_ebps(double e, double scale)
+{
+    if (e > 0.0) {
+        const double bb = 0.5 * log(scale * e) / FG_LN2;
+        return bb >= 0.0 ? bb : 0.0;
+    }
+    else if (e < 0.0) return 1e32;
+    return 0.0;
+}
+
+// ================================================================================================ K2: autocorrelation + OR
+template <bool MS, int NCH, int MAXO>
+__global__ void __launch_bounds__(64)
+fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, FgPipeBufs B, FgDebugRec *dbg)
+{
+    constexpr int NC = MS ? 4 : NCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t bi = blockIdx.x;
+    const FgBlockDesc d = descs[bi];
+    const int lane = threadIdx.x;
+    const uint32_t n = d.n;
+    LDS double *dbuf = (LDS double *)smem;                      // NC rows of FGP_CSTR doubles
+    LDS double *autoc = dbuf + NC * FGP_CSTR;                   // [NC][nvec][MAXO + 1]
+    LDS uint32_t *wl = (LDS uint32_t *)(autoc + NC * P.nvec * (MAXO + 1));   // wasted bits per candidate
+    const float *window = windows + d.win_off;
+    FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
+    uint32_t orv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) orv[c] = 0;
+    // sample i of the block (both channels)
+    auto ldsamp = [&](uint32_t i, int32_t &L, int32_t &R) __attribute__((always_inline)) {
+        if (NCH == 2) {
+            if (P.pcm_i16) { const short2 v = ((const short2 *)pcm)[d.pcm_off + i]; L = v.x; R = v.y; }
+            else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; L = v.x; R = v.y; }
+        }
+        else {
+            if (P.pcm_i16) L = ((const int16_t *)pcm)[d.pcm_off + i];
+            else L = ((const int32_t *)pcm)[d.pcm_off + i];
+            R = 0;
+        }
+    };
+    uint32_t nv = 0;
+    const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+    if (mo == 0) {
+        // no LPC at this level: only the OR of the samples is needed
+        for (uint32_t i = lane; i < n; i += 64) {
+            int32_t L, R;
+            ldsamp(i, L, R);
+#pragma unroll
+            for (int c = 0; c < NC; c++) orv[c] |= (uint32_t)(c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R));
+        }
+    }
+    else {
+        const uint32_t cl = lane >> 4, l = lane & 15;
+        const bool on = cl < (uint32_t)NC && l <= mo;
+        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGP_CSTR + FGP_DH - (on ? l : 0);
+        uint32_t vb_ = 1, vc_ = 0;
+        bool more = true;
+        while (more) {
+            uint32_t vec_len = n, part = 0, sh = 0;
+            bool punch = false, skip = false;
+            if (nv > 0) {
+                if (n / vb_ <= 32) skip = true;
+                else if (!(vc_ & 1)) { vec_len = n / vb_; part = n / vb_ / 2; sh = (vc_ / 2 * n) / vb_; }
+                else punch = true;
+            }
+            if (!skip && !punch) {
+                double acc = 0.0;
+                for (uint32_t j = lane; j < NC * FGP_DH; j += 64) dbuf[(j / FGP_DH) * FGP_CSTR + (j % FGP_DH)] = 0.0;
+                wave_lds_fence();
+                // window value and samples of the next chunk travel while the chain of the current one runs
+                float wv[FGP_CK / 64];
+                int32_t xl[FGP_CK / 64], xr[FGP_CK / 64];
+                auto fetch = [&](uint32_t k0) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < FGP_CK / 64; u++) {
+                        const uint32_t i = k0 + u * 64 + lane;
+                        float w = 0.0f;
+                        int32_t L = 0, R = 0;
+                        if (i < vec_len) {
+                            uint32_t s_ = 0;
+                            bool any = true;
+                            if (part == 0) { w = window[i]; s_ = i; }
+                            else if (i < part) { w = window[i]; s_ = sh + i; }
+                            else if (i < 2 * part) { w = window[n - 2 * part + i]; s_ = sh + i; }
+                            else any = false;
+                            if (any) ldsamp(s_, L, R);
+                        }
+                        wv[u] = w; xl[u] = L; xr[u] = R;
+                    }
+                };
+                fetch(0);
+                for (uint32_t k0 = 0; k0 < vec_len; k0 += FGP_CK) {
+                    const uint32_t kn = (vec_len - k0) < FGP_CK ? (vec_len - k0) : FGP_CK;
+#pragma unroll
+                    for (int u = 0; u < FGP_CK / 64; u++) {
+                        const uint32_t j = u * 64 + lane;
+                        if (j < kn) {
+                            const int32_t L = xl[u], R = xr[u];
+                            const bool zero = part != 0 && (k0 + j) >= 2 * part;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) {
+                                const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
+                                if (nv == 0) orv[c] |= (uint32_t)x;
+                                const float dd = zero ? 0.0f : (float)x * wv[u];
+                                dbuf[c * FGP_CSTR + FGP_DH + j] = (double)dd;
+                            }
+                        }
+                    }
+                    if (k0 + FGP_CK < vec_len) fetch(k0 + FGP_CK);
+                    wave_lds_fence();
+                    if (on) {
+                        // Twelve steps per iteration in three groups of four: the operands of a group are requested two
+                        // groups ahead of its FMAs so that the LDS latency overlaps the dependent chain.  One asm block with
+                        // its own s_waitcnt: the compiler would merge the loads into ds_read2_b64, which moves half the bytes
+                        // per LDS cycle of ds_read_b64 (128 against 256 B/clk), and this loop is LDS-bound.
+                        // (Reads past the chunk stay inside the row and are not used.)
+#define FG_FMAC4(h) asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
+                        "v_fmac_f64_dpp %0, %2, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
+                        "v_fmac_f64_dpp %0, %3, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
+                        "v_fmac_f64_dpp %0, %4, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf"                 \
+                        : "+v"(acc) : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]))
+#define FG_F4(x) "v_fmac_f64_dpp %[acc], %[" #x "0], %[" #x "0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %[acc], %[" #x "1], %[" #x "1] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %[acc], %[" #x "2], %[" #x "2] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %[acc], %[" #x "3], %[" #x "3] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+#define FG_L4(x, o) "ds_read_b64 %[" #x "0], %[ad] offset:" #o "\n\tds_read_b64 %[" #x "1], %[ad] offset:" #o "+8\n\t" \
+                    "ds_read_b64 %[" #x "2], %[ad] offset:" #o "+16\n\tds_read_b64 %[" #x "3], %[ad] offset:" #o "+24\n\t"
+                        double ha[4], hb[4], hc[4];
+                        uint32_t ad = (uint32_t)(size_t)hist;
+                        uint32_t j = 0;
+                        asm volatile(FG_L4(a, 0) FG_L4(b, 32)
+                                     : [a0] "=&v"(ha[0]), [a1] "=&v"(ha[1]), [a2] "=&v"(ha[2]), [a3] "=&v"(ha[3]),
+                                       [b0] "=&v"(hb[0]), [b1] "=&v"(hb[1]), [b2] "=&v"(hb[2]), [b3] "=&v"(hb[3])
+                                     : [ad] "v"(ad));
+                        hc[0] = hc[1] = hc[2] = hc[3] = 0.0;
+                        for (; j + 12 <= kn; j += 12) {
+                            asm volatile(FG_L4(c, 64) "s_waitcnt lgkmcnt(8)\n\t" FG_F4(a)
+                                         FG_L4(a, 96) "s_waitcnt lgkmcnt(8)\n\t" FG_F4(b)
+                                         FG_L4(b, 128) "s_waitcnt lgkmcnt(8)\n\t" FG_F4(c)
+                                         "v_add_u32 %[ad], 0x60, %[ad]"
+                                         : [acc] "+v"(acc), [ad] "+v"(ad),
+                                           [a0] "+v"(ha[0]), [a1] "+v"(ha[1]), [a2] "+v"(ha[2]), [a3] "+v"(ha[3]),
+                                           [b0] "+v"(hb[0]), [b1] "+v"(hb[1]), [b2] "+v"(hb[2]), [b3] "+v"(hb[3]),
+                                           [c0] "+v"(hc[0]), [c1] "+v"(hc[1]), [c2] "+v"(hc[2]), [c3] "+v"(hc[3]));
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ha[0]), "+v"(ha[1]), "+v"(ha[2]), "+v"(ha[3]), "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]));
+                        if (j + 4 <= kn) { FG_FMAC4(ha); j += 4; if (j + 4 <= kn) { FG_FMAC4(hb); j += 4; } }
+                        for (; j < kn; j++) {
+                            const double h0 = hist[j];
+                            asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
+                        }
+#undef FG_FMAC4
+#undef FG_F4
+#undef FG_L4
+                    }
+                    wave_lds_fence();
+                    if (k0 + kn < vec_len) {
+                        double t[(NC * FGP_DH + 63) / 64];
+#pragma unroll
+                        for (int u = 0; u < (NC * FGP_DH + 63) / 64; u++) {
+                            const uint32_t j = u * 64 + lane;
+                            t[u] = (j < NC * FGP_DH) ? dbuf[(j / FGP_DH) * FGP_CSTR + FGP_CK + (j % FGP_DH)] : 0.0;
+                        }
+                        wave_lds_fence();
+#pragma unroll
+                        for (int u = 0; u < (NC * FGP_DH + 63) / 64; u++) {
+                            const uint32_t j = u * 64 + lane;
+                            if (j < NC * FGP_DH) dbuf[(j / FGP_DH) * FGP_CSTR + (j % FGP_DH)] = t[u];
+                        }
+                        wave_lds_fence();
+                    }
+                }
+                if (on) autoc[(cl * P.nvec + nv) * (MAXO + 1) + l] = acc;
+                wave_lds_fence();
+            }
+            else if (punch) {
+                // root - previous partial for lags < mo; lag mo keeps the partial (upstream quirk)
+                const uint32_t total = (uint32_t)NC * (mo + 1);
+                for (uint32_t j = lane; j < total; j += 64) {
+                    const uint32_t c = j / (mo + 1), ll = j % (mo + 1);
+                    LDS double *base = autoc + c * P.nvec * (MAXO + 1);
+                    const double prev = base[(nv - 1) * (MAXO + 1) + ll];
+                    base[nv * (MAXO + 1) + ll] = (ll < mo) ? base[ll] - prev : prev;
+                }
+                wave_lds_fence();
+            }
+            if (!skip) nv++;
+            if (P.apod_parts < 2) more = false;
+            else if (nv == 1 && vb_ == 1) { vb_ = 2; vc_ = 0; }
+            else {
+                if (vb_ == 2) { if (vc_ == 0) vc_ = 2; else { vc_ = 0; vb_++; } }
+                else if (vc_ < 2 * vb_ - 1) vc_++;
+                else { vc_ = 0; vb_++; }
+                if (vb_ > P.apod_parts) more = false;
+            }
+        }
+    }
+    // ---- wasted bits per candidate (libFLAC shifts them out before any analysis; the autocorrelation of the shifted signal
+    // is the one computed here times 2^-2w, exactly)
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t o = wave_or32(orv[c]);
+        uint32_t w = o ? (uint32_t)__builtin_ctz(o) : 0;
+        const uint32_t nominal = P.bps + ((MS && c == 3) ? 1u : 0u);
+        if (w > nominal) w = nominal;
+        if (lane == 0) { wl[c] = w; B.wasted[bi * NC + c] = w; }
+    }
+    if (lane == 0) B.nv[bi] = nv;
+    wave_lds_fence();
+    if (mo > 0) {
+        const uint32_t per = P.nvec * (MAXO + 1);
+        for (uint32_t j = lane; j < (uint32_t)NC * per; j += 64) {
+            const uint32_t c = j / per;
+            double a = autoc[j];
+            const uint32_t w = wl[c];
+            if (w) a = ldexp(a, -2 * (int)w);
+            B.autoc[(size_t)bi * NC * per + j] = a;
+            if (mydbg) {
+                const uint32_t r = j % per, v = r / (MAXO + 1), ll = r % (MAXO + 1);
+                if (v < nv && ll <= mo) mydbg->cand[c].autoc[v][ll] = a;
+            }
+        }
+        if (mydbg && lane < NC) mydbg->cand[lane].nvec = nv;
+    }
+}
+
+// ================================================================================================ K3: Levinson-Durbin, order guess, quantiser
+// lane = (block, candidate, vector).  lres = order | prec<<8 | (shift&255)<<16 | ok<<24 | ran<<25.  Same operations in the
+// same order as lpc.c (the file is compiled with -ffp-contract=off), so the same doubles.
+template <int MAXO>
+__global__ void __launch_bounds__(64)
+fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint32_t nblocks, uint32_t NC, uint32_t ms)
+{
+    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t per = NC * P.nvec;
+    if (idx >= nblocks * per) return;
+    const uint32_t bi = idx / per, r_ = idx % per, c = r_ / P.nvec, v = r_ % P.nvec;
+    const uint32_t n = descs[bi].n;
+    const uint32_t nv = B.nv[bi];
+    const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+    const double *Ap = B.autoc + (size_t)idx * (MAXO + 1);
+    bool on = v < nv && mo > 0;
+    double A[MAXO + 1];
+#pragma unroll
+    for (int j = 0; j <= MAXO; j++) A[j] = (on && (uint32_t)j <= mo) ? Ap[j] : 0.0;
+    if (on && A[0] == 0.0) on = false;
+    if (!on) {
+#pragma unroll
+        for (int j = 0; j <= MAXO; j++) A[j] = 0.0;
+    }
+    const uint32_t sb = P.bps + ((ms && c == 3) ? 1u : 0u) - B.wasted[bi * NC + c];
+    const double a0 = on ? A[0] : 1.0;
+    const uint32_t overhead = sb + P.qlp_precision;
+    const double scale = 0.5 / (double)n;
+    double er = a0, bestb = 4294967295.0;
+    double lp[MAXO], keep[MAXO], err2 = a0;
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) { lp[j] = 0.0; keep[j] = 0.0; }
+    uint32_t besti = 0;
+    bool stopped = false, have = false;
+#pragma unroll
+    for (int i = 0; i < MAXO; i++) {
+        if ((uint32_t)i < mo) {
+            double r = -A[i + 1];
+#pragma unroll
+            for (int j = 0; j < i; j++) r -= lp[j] * A[i - j];
+            r /= er;
+            lp[i] = r;
+#pragma unroll
+            for (int j = 0; j < (i >> 1); j++) {
+                const double tmp = lp[j], t2 = lp[i - 1 - j];
+                lp[j] = tmp + r * t2;
+                lp[i - 1 - j] = t2 + r * tmp;
+            }
+            if (i & 1) { const double t = lp[i >> 1]; lp[i >> 1] = t + t * r; }
+            er *= (1.0 - r * r);
+            bool better = false;
+            if (!stopped) {
+                const uint32_t o = i + 1;
+                const double bits = p_ebps(er, scale) * (double)(n - o) + (double)(o * overhead);
+                if (bits < bestb) { besti = i; bestb = bits; better = true; }
+                if (er == 0.0) stopped = true;
+            }
+            if (better || !have) {
+                if (better || i == 0) {
+#pragma unroll
+                    for (int j = 0; j <= i; j++) keep[j] = lp[j];
+                    err2 = er;
+                }
+                have = true;
+            }
+        }
+    }
+    const uint32_t ostar = besti + 1;
+    float lpf[MAXO];
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) lpf[j] = (float)(-keep[j]);
+    uint32_t result = 0;
+    int32_t qv_[MAXO];
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) qv_[j] = 0;
+    if (on) {
+        bool ok = !(p_ebps(err2, 0.5 / (double)(n - ostar)) >= (double)sb);
+        uint32_t prec = P.qlp_precision;
+        if (sb <= 17) { const uint32_t lim = 32 - sb - ilog2_32(ostar); if (lim < prec) prec = lim; }
+        int shift = 0;
+        if (ok) {
+            const int p1 = (int)prec - 1;
+            const int32_t qmax = (1 << p1) - 1, qmin = -(1 << p1);
+            double cmax = 0.0;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) if ((uint32_t)j < ostar) { const double dd = fabs((double)lpf[j]); if (dd > cmax) cmax = dd; }
+            if (cmax <= 0.0) ok = false;
+            else {
+                const int e = (int)((__double_as_longlong(cmax) >> 52) & 0x7FF) - 1022;
+                shift = p1 - (e - 1) - 1;
+                if (shift > 15) shift = 15;
+                else if (shift < -16) ok = false;
+            }
+            if (ok) {
+                double error = 0.0;
+                const bool neg = shift < 0;
+                const double mul = neg ? (double)(1 << (-shift)) : (double)(1 << shift);
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) {
+                    if ((uint32_t)j < ostar) {
+                        const double lpv = (double)lpf[j];
+                        error += neg ? lpv / mul : lpv * mul;
+                        const double rq = round(error);
+                        int32_t qv = (int32_t)(i64)rq;
+                        if (qv > qmax) qv = qmax; else if (qv < qmin) qv = qmin;
+                        error -= (double)qv;
+                        qv_[j] = qv;
+                    }
+                }
+                if (neg) shift = 0;
+            }
+        }
+        result = ostar | (prec << 8) | (((uint32_t)shift & 0xFF) << 16) | ((ok ? 1u : 0u) << 24) | (1u << 25);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) B.qres[(size_t)idx * MAXO + j] = qv_[j];
+    B.lres[idx] = result;
+}
+
+// ================================================================================================ staging: HBM -> LDS rows
+// Cooperative over NT threads.  Rows of `seg` samples (+PADE of skew); g -> element index g + (g / seg) * PADE.
+template <int NCH, bool ACC64, int NT>
+FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams &P, LDS typename PipeTypes<ACC64>::samp_t *sL,
+                        LDS typename PipeTypes<ACC64>::samp_t *sR, int tid, uint32_t seg)
+{
+    typedef typename PipeTypes<ACC64>::samp_t samp_t;
+    constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
+    const uint32_t n = d.n;
+    const uint32_t magic = 0xFFFFFFFFu / seg + 1;
+#define FGP_SADDR(g) ((g) + __umulhi((g), magic) * PADE)
+    const int32_t lim = (int32_t)(P.bps - 1);
+    uint32_t bad = 0;
+    uint32_t istart = 0;
+    if (NCH == 2 && !P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (seg & 1) == 0 && (((uintptr_t)pcm) & 15) == 0) {
+        // two inter-channel samples per load; the pair lands in one LDS row (even index, even row length)
+        const int4 *src = (const int4 *)((const int2 *)pcm + d.pcm_off);
+        for (uint32_t j0 = 0; j0 < n / 2; j0 += 4 * NT) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + u * NT + tid;
+                v[u] = make_int4(0, 0, 0, 0);
+                if (j < n / 2) v[u] = src[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + u * NT + tid;
+                if (j < n / 2) {
+                    const int32_t l0 = v[u].x, r0 = v[u].y, l1 = v[u].z, r1 = v[u].w;
+                    if (P.bps < 32) bad |= (uint32_t)(((l0 ^ (l0 >> 31)) >> lim) | ((r0 ^ (r0 >> 31)) >> lim) | ((l1 ^ (l1 >> 31)) >> lim) | ((r1 ^ (r1 >> 31)) >> lim));
+                    const uint32_t ad = FGP_SADDR(2 * j);
+                    if (sizeof(samp_t) == 2) {
+                        *(LDS uint32_t *)(sL + ad) = ((uint32_t)l0 & 0xFFFFu) | ((uint32_t)l1 << 16);
+                        *(LDS uint32_t *)(sR + ad) = ((uint32_t)r0 & 0xFFFFu) | ((uint32_t)r1 << 16);
+                    }
+                    else { sL[ad] = (samp_t)l0; sL[ad + 1] = (samp_t)l1; sR[ad] = (samp_t)r0; sR[ad + 1] = (samp_t)r1; }
+                }
+            }
+        }
+        istart = n;
+    }
+    for (uint32_t i0 = istart; i0 < n; i0 += 4 * NT) {
+        int32_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * NT + tid;
+            a[u] = 0; b[u] = 0;
+            if (i < n) {
+                if (NCH == 2) {
+                    if (P.pcm_i16) { const short2 v = ((const short2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
+                    else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
+                }
+                else {
+                    if (P.pcm_i16) a[u] = ((const int16_t *)pcm)[d.pcm_off + i];
+                    else a[u] = ((const int32_t *)pcm)[d.pcm_off + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * NT + tid;
+            if (i < n) {
+                if (P.bps < 32) bad |= (uint32_t)(((a[u] ^ (a[u] >> 31)) >> lim) | ((b[u] ^ (b[u] >> 31)) >> lim));
+                const uint32_t ad = FGP_SADDR(i);
+                sL[ad] = (samp_t)a[u];
+                if (NCH == 2) sR[ad] = (samp_t)b[u];
+            }
+        }
+    }
+#undef FGP_SADDR
+    return bad;
+}
+
+// ================================================================================================ K4: evaluation of one candidate by one wave
+// Rice parameter / partition order search over the 64 per-lane |residual| sums of one candidate (lane = partition of the
+// finest order, or a power-of-two fraction of it).  At partition order po, partition p lives in lane p * (64 >> po); going
+// one order down adds the neighbour 2^(5-po) lanes up.  Returns the best total in best_bits, its order in bpo, and leaves
+// the parameter of partition p in lane p * (64 >> bpo) of kb.
+template <bool ACC64>
+FGI void pipe_rice_search(typename PipeTypes<ACC64>::sum_t psum, bool dead_in, int lane, uint32_t n, uint32_t order, uint32_t sb,
+                          uint32_t pmin0, uint32_t pmax0, uint32_t limit, uint32_t &best_bits, uint32_t &bpo, uint32_t &kb)
+{
+    u64 sv = (u64)psum;
+    best_bits = 0; bpo = 0; kb = 0;
+    (void)dead_in;
+    auto up = [&](uint32_t v, uint32_t t) __attribute__((always_inline)) -> uint32_t {
+        switch (t) {
+        case 0: return dpp0<0x101>(v);
+        case 1: return dpp0<0x102>(v);
+        case 2: return dpp0<0x104>(v);
+        case 3: return dpp0<0x108>(v);
+        case 4: return (uint32_t)__shfl((int)v, (lane + 16) & 63);
+        default: return (uint32_t)__shfl((int)v, (lane + 32) & 63);
+        }
+    };
+    auto merge = [&](uint32_t t) __attribute__((always_inline)) {
+        u64 o = up((uint32_t)sv, t);
+        if (ACC64) o |= (u64)up((uint32_t)(sv >> 32), t) << 32;
+        sv += o;
+    };
+    for (uint32_t m = 6; m > pmax0; m--) merge(6 - m);
+    const uint32_t psz0 = n >> pmax0;
+    {
+        const bool wrap32 = (sb + 4) < (32 - ilog2_32(psz0));
+        if (wrap32) sv &= 0xFFFFFFFFull;
+    }
+    // 0x40000 / x for x < 2^16 through the reciprocal, corrected to the exact quotient
+    auto div18 = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+        uint32_t qd = (uint32_t)(262144.0f * __builtin_amdgcn_rcpf((float)x));
+        const int32_t r = (int32_t)(0x40000u - qd * x);
+        if (r < 0) qd--;
+        else if ((uint32_t)r >= x) qd++;
+        return qd;
+    };
+    const bool lane0 = lane == 0;
+    auto po_step = [&](auto PO) __attribute__((always_inline)) {
+        constexpr int po = decltype(PO)::value;
+        if (po > (int)pmax0 || po < (int)pmin0) return;
+        constexpr uint32_t stride = 64u >> po;
+        const bool valid = ((uint32_t)lane & (stride - 1)) == 0;
+        const uint32_t pbase = n >> po;
+        const uint32_t np = lane0 ? pbase - order : pbase;
+        const uint32_t dv = lane0 ? div18(pbase - order) : div18(pbase);
+        uint32_t kr, bits;
+        if (!ACC64) {
+            const uint32_t s32 = (uint32_t)sv;
+            const uint32_t s1 = (s32 > 1 ? s32 : 1) - 1;
+            const uint32_t qv = (uint32_t)(((u64)s1 * dv) >> 18);
+            kr = qv ? 32 - (uint32_t)__builtin_clz(qv) : 0;
+            if (kr >= limit) kr = limit - 1;
+            uint32_t pb = 4 + (1 + kr) * np + ((s32 << 1) >> kr) - (np >> 1);
+            if (!valid) pb = 0;
+            u64 total;
+            if (__any(pb >> 25)) total = wave_sum64((u64)pb) + 6;
+            else total = (u64)wave_sum(pb) + 6;
+            bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+        }
+        else {
+            const u64 s = sv;
+            kr = 0;
+            if (s >= 2) {
+                const u64 qv = ((s - 1) * dv) >> 18;
+                if (qv != 0) kr = ilog2_64(qv) + 1;
+            }
+            if (kr >= limit) kr = limit - 1;
+            u64 pb = (u64)4 + (u64)(1 + kr) * np + (kr ? (s >> (kr - 1)) : (s << 1)) - (np >> 1);
+            if (pb > 0xFFFFFFFFull) pb = 0xFFFFFFFFull;
+            if (!valid) pb = 0;
+            u64 total;
+            if (__any(pb >> 25)) total = wave_sum64(pb) + 6;
+            else total = (u64)wave_sum((uint32_t)pb) + 6;
+            bits = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+        }
+        if (best_bits == 0 || bits < best_bits) { best_bits = bits; bpo = (uint32_t)po; kb = kr; }
+        if (po > (int)pmin0) merge(6 - (uint32_t)po);
+    };
+    po_step(std::integral_constant<int, 6>()); po_step(std::integral_constant<int, 5>());
+    po_step(std::integral_constant<int, 4>()); po_step(std::integral_constant<int, 3>());
+    po_step(std::integral_constant<int, 2>()); po_step(std::integral_constant<int, 1>());
+    po_step(std::integral_constant<int, 0>());
+}
+
+// The candidate of a wave is a run-time value (one copy of the code for L, R, M and S instead of four -- the instruction
+// cache is shared by the CU's waves): candidate sample = (ca * l + cb * r) >> (cs + wasted bits), with (ca, cb, cs) =
+// L (1, 0, 0), R (0, 1, 0), M (1, 1, 1), S (1, -1, 0) in SGPRs: two 24-bit multiplies and one shift.
+FGI void pipe_cand_coef(bool ms, uint32_t c, int32_t &ca, int32_t &cb, uint32_t &cs)
+{
+    if (!ms) { ca = c == 0 ? 1 : 0; cb = c == 0 ? 0 : 1; cs = 0; }
+    else { ca = c == 1 ? 0 : 1; cb = c == 0 ? 0 : (c == 3 ? -1 : 1); cs = c == 2 ? 1 : 0; }
+}
+FGI int32_t pipe_cand(int32_t l, int32_t r, int32_t ca, int32_t cb, uint32_t sh)
+{
+    return (__mul24(l, ca) + __mul24(r, cb)) >> sh;
+}
+
+template <bool MS, int NCH, int MAXO, bool ACC64>
+FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
+                        FgDebugRec *mydbg, const LDS typename PipeTypes<ACC64>::samp_t *sL, const LDS typename PipeTypes<ACC64>::samp_t *sR,
+                        int lane, uint32_t range_err)
+{
+    constexpr int NC = MS ? 4 : NCH;
+    typedef typename PipeTypes<ACC64>::sum_t sum_t;
+    typedef typename PipeTypes<ACC64>::samp_t samp_t;
+    constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
+    const uint32_t n = d.n;
+    const uint32_t seg = n >> 6, rstr = seg + PADE;
+    const LDS samp_t *rowL = sL + (uint32_t)lane * rstr, *rowR = sR + (uint32_t)lane * rstr;
+    const uint32_t wst = rfl(B.wasted[bi * NC + C]);
+    const uint32_t nominal = P.bps + ((MS && C == 3) ? 1u : 0u);
+    const uint32_t sb = nominal - wst;
+    // candidate value of sample s of this lane's row (row offset `ro` = 0 or -rstr for the left neighbour)
+    int32_t cca, ccb;
+    uint32_t ccs;
+    pipe_cand_coef(MS, C, cca, ccb, ccs);
+    const uint32_t csh = ccs + wst;
+    auto samp = [&](int s) __attribute__((always_inline)) -> int32_t {
+        return pipe_cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, cca, ccb, csh);
+    };
+
+    uint32_t pmax0 = 0;
+    { uint32_t b = n; while (!(b & 1)) { pmax0++; b >>= 1; } if (pmax0 > 15) pmax0 = 15; }
+    if (P.max_po < pmax0) pmax0 = P.max_po;
+    const uint32_t pmin0 = P.min_po < pmax0 ? P.min_po : pmax0;
+
+    // ================================================================ fixed-predictor error sums (one pass)
+    // facc = sums over the lane's samples from sample 4 of the block on (what libFLAC's order guess uses), fwarm = the part
+    // of samples 0..3 that belongs to the order-k residual (s >= k): the per-lane sums double as the Rice partition sums of
+    // the fixed predictors.
+    u64 tot[5];
+    sum_t fsum = 0;            // per-lane sum of |residual| of the fixed predictor of the guessed order (set below)
+    uint32_t guess;
+    {
+        sum_t facc[5], fwarm[5];
+        int32_t p1 = 0, q1 = 0, q2 = 0, q3 = 0;
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) { facc[kk] = 0; fwarm[kk] = 0; }
+#pragma unroll
+        for (int s = -4; s < 4; s++) {
+            int32_t v = 0;
+            if (s >= 0) v = samp(s);
+            else if (lane > 0) v = samp((int)seg + s - (int)rstr);
+            const int32_t e1 = v - p1, e2 = e1 - q1, e3 = e2 - q2, e4 = e3 - q3;
+            p1 = v; q1 = e1; q2 = e2; q3 = e3;
+            if (s >= 0) {
+                const uint32_t ab[5] = {pabs32(v), pabs32(e1), pabs32(e2), pabs32(e3), pabs32(e4)};
+#pragma unroll
+                for (int kk = 0; kk < 5; kk++) {
+                    facc[kk] += (lane > 0) ? ab[kk] : 0u;
+                    if (s >= kk) fwarm[kk] += ab[kk];
+                }
+            }
+        }
+#pragma unroll 4
+        for (int s = 4; s < (int)seg; s++) {
+            const int32_t v = samp(s);
+            const int32_t e1 = v - p1, e2 = e1 - q1, e3 = e2 - q2, e4 = e3 - q3;
+            p1 = v; q1 = e1; q2 = e2; q3 = e3;
+            facc[0] += pabs32(v); facc[1] += pabs32(e1); facc[2] += pabs32(e2);
+            facc[3] += pabs32(e3); facc[4] += pabs32(e4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) tot[kk] = ACC64 ? wave_sum64((u64)facc[kk]) : (u64)wave_sum((uint32_t)facc[kk]);
+        // fixed order guess (fixed.c: the smallest total error wins, lower order on ties)
+        const u64 m34 = tot[3] < tot[4] ? tot[3] : tot[4];
+        const u64 m234 = tot[2] < m34 ? tot[2] : m34;
+        const u64 m1234 = tot[1] < m234 ? tot[1] : m234;
+        if (tot[0] <= m1234) guess = 0;
+        else if (tot[1] <= m234) guess = 1;
+        else if (tot[2] <= m34) guess = 2;
+        else if (tot[3] <= tot[4]) guess = 3;
+        else guess = 4;
+        // the lane's partition sum of that predictor: lane 0 adds the part of samples g..3
+        sum_t a = guess == 0 ? facc[0] : guess == 1 ? facc[1] : guess == 2 ? facc[2] : guess == 3 ? facc[3] : facc[4];
+        const sum_t w = guess == 0 ? fwarm[0] : guess == 1 ? fwarm[1] : guess == 2 ? fwarm[2] : guess == 3 ? fwarm[3] : fwarm[4];
+        if (lane == 0) a += w;
+        fsum = a;
+    }
+
+    // ---- baseline: verbatim / constant
+    uint32_t best;
+    uint32_t d_type = 1, d_order = 0, d_prec = 0, d_porder = 0, d_method = 0, d_k = 0;
+    int d_shift = 0;
+    int32_t bestq[MAXO];
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) bestq[j] = 0;
+    bool do_fixed = false, do_lpc = false;
+    {
+        const u64 vb = (u64)8 + (u64)n * sb;
+        best = vb < 0xFFFFFFFFull ? (uint32_t)vb : 0xFFFFFFFFu;
+        const uint32_t g = guess;
+        const u64 tg = g == 0 ? tot[0] : g == 1 ? tot[1] : g == 2 ? tot[2] : g == 3 ? tot[3] : tot[4];
+        const double len = (double)(n - 4);
+        const float rbg = (float)((tg > 0) ? log(FG_LN2 * (double)tg / len) / FG_LN2 : 0.0);
+        bool constant = false;
+        if (tot[1] == 0) {
+            const int32_t x0 = pipe_cand(sL[0], (NCH == 2) ? (int32_t)sR[0] : 0, cca, ccb, csh);
+            uint32_t ne = 0;
+#pragma unroll 1
+            for (uint32_t s = 0; s < seg; s++) ne |= (samp((int)s) != x0);
+            constant = !__any(ne != 0);
+        }
+        if (mydbg && lane == 0) {
+            for (int kk = 0; kk < 5; kk++) mydbg->cand[C].fixed_tot[kk] = tot[kk];
+            mydbg->cand[C].fixed_guess = g;
+        }
+        // limit_min_bitrate (libFLAC 1.4.3 as observed, oracle/flac_oracle.c): the last independent channel is evaluated with
+        // CONSTANT disabled when every earlier one chose CONSTANT; mid and side of the same frame then are, too -- unless only
+        // mid/side are evaluated at all (loose mid-side follower frames, forced_ca == 3).  "Every earlier independent channel
+        // chose CONSTANT" concerns the left channel only here (NCH <= 2): each wave looks at it itself.
+        if (P.limit_min_bitrate && C >= (uint32_t)(NCH - 1) && d.forced_ca != 3) {
+            bool forbid = true;
+            if (NCH == 2) {
+                // is the left channel constant?  (its wasted bits do not matter: all samples equal either way)
+                const int32_t l0 = sL[0];
+                uint32_t ne = 0;
+#pragma unroll 1
+                for (uint32_t s = 0; s < seg; s++) ne |= ((int32_t)rowL[s] != l0);
+                forbid = !__any(ne != 0);
+            }
+            if (forbid) constant = false;
+        }
+        if (constant) {
+            const uint32_t cb = 8 + sb;
+            if (cb < best) { best = cb; d_type = 0; }
+        }
+        else {
+            if (!(rbg >= (float)sb)) do_fixed = true;
+            if (P.max_lpc_order > 0) do_lpc = true;
+        }
+    }
+    const uint32_t nv = do_lpc ? rfl(B.nv[bi]) : 0;
+    const uint32_t limit = P.rice_limit;
+
+    // ================================================================ pass 0 = fixed predictor of the guessed order, then one
+    // pass per autocorrelation vector
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < 1 + nv; pass++) {
+        uint32_t order, prec = 0;
+        int shift = 0;
+        int32_t q[MAXO];
+        sum_t psum;
+        uint32_t ovf = 0;
+        const int kind = pass == 0 ? 0 : 1;
+        if (pass == 0) {
+            if (!do_fixed) continue;
+            order = guess;
+            psum = fsum;
+        }
+        else {
+            const uint32_t v = pass - 1;
+            const size_t ridx = ((size_t)bi * NC + C) * P.nvec + v;
+            const uint32_t r = rfl(B.lres[ridx]);
+            order = r & 0xFF; prec = (r >> 8) & 0xFF; shift = (int)(int8_t)((r >> 16) & 0xFF);
+            if (mydbg && lane == 0) mydbg->cand[C].lpc_guess[v] = ((r >> 25) & 1) ? (r & 0xFF) : 0;
+            if (!((r >> 24) & 1)) continue;
+            if (order == 0) order = 1;
+            const int32_t qall = (lane < MAXO) ? B.qres[ridx * MAXO + lane] : 0;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rl((uint32_t)qall, j);
+            // ---- FIR over the segment: history in registers, statically indexed (the loop is unrolled by its length)
+            int32_t h[MAXO];
+            psum = 0;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) {
+                int32_t x = 0;
+                if (lane > 0) x = samp((int)seg - 1 - j - (int)rstr);
+                h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
+            }
+            auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
+                const int32_t x = samp((int)s);
+                int32_t res;
+                if (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
+                else {
+                    const i64 rr = (i64)x - (pfir48<MAXO>(q, h, u) >> shift);
+                    if (rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) ovf = 1;
+                    res = (int32_t)rr;
+                }
+                h[u] = ACC64 ? ppack(x) : x;
+                // warm-up samples (the first `order` of the block, all in lane 0) are not residuals
+                if (!guard || lane > 0 || s >= order) psum += pabs32(res);
+            };
+            uint32_t s0 = 0;
+            if (seg >= (uint32_t)MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, (uint32_t)u, true);
+                s0 = MAXO;
+            }
+#pragma unroll 1
+            for (; s0 + MAXO <= seg; s0 += MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+        }
+        const bool dead = ACC64 && __any(ovf != 0);
+        uint32_t best_bits, bpo, kb;
+        pipe_rice_search<ACC64>(psum, dead, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb);
+        uint32_t est = 0;
+        if (!dead) {
+            est = kind == 0 ? (8 + order * sb) : (8 + 4 + 5 + order * (prec + sb));
+            if (best_bits < 0xFFFFFFFFu - est) est += best_bits; else est = 0xFFFFFFFFu;
+            if (est > 0 && est < best) {
+                best = est;
+                d_type = kind == 0 ? 2 : 3; d_order = order; d_prec = prec; d_shift = shift;
+                d_porder = bpo; d_k = kb;
+                d_method = __any((((uint32_t)lane & ((64u >> bpo) - 1)) == 0) && kb >= 15) ? 1 : 0;
+                if (kind == 1) {
+#pragma unroll
+                    for (int j = 0; j < MAXO; j++) bestq[j] = q[j];
+                }
+            }
+        }
+        if (mydbg && lane == 0) {
+            if (kind == 0) mydbg->cand[C].fixed_bits = est;
+            else mydbg->cand[C].lpc_bits[pass - 1] = est;
+        }
+    }
+
+    // ---- the decision record of this candidate
+    FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
+    if (lane == 0) {
+        dec->bits = best; dec->type = d_type; dec->order = d_order; dec->prec = d_prec; dec->shift = d_shift;
+        dec->porder = d_porder; dec->method = d_method; dec->wasted = wst;
+#pragma unroll
+        for (int j = 0; j < 12; j++) dec->q[j] = j < MAXO ? bestq[j < MAXO ? j : 0] : 0;
+        FgBlockResult *r = &results[d.out_slot];
+        r->best_bits[C] = best;
+        if (C == 0) {
+            r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
+#pragma unroll
+            for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
+            for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)bi * 4 + w] = 0;     // the packing waves fill in theirs
+        }
+    }
+    if (d_type >= 2 && ((uint32_t)lane & ((64u >> d_porder) - 1)) == 0) dec->k[(uint32_t)lane >> (6 - d_porder)] = (uint8_t)d_k;
+    if (mydbg) {
+        if (lane == 0) {
+            FgDebugCand *dc = &mydbg->cand[C];
+            dc->wasted = wst; dc->sbps = sb; dc->type = d_type; dc->order = d_type >= 2 ? d_order : 0;
+            dc->precision = d_type == 3 ? d_prec : 0; dc->shift = d_type == 3 ? d_shift : 0;
+            dc->bits = best; dc->porder = d_type >= 2 ? d_porder : 0; dc->rice_method = d_type >= 2 ? d_method : 0;
+            for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (d_type == 3 && j < d_order && j < (uint32_t)MAXO) ? bestq[j < (uint32_t)MAXO ? j : 0] : 0;
+        }
+        if (d_type >= 2 && ((uint32_t)lane & ((64u >> d_porder) - 1)) == 0) mydbg->cand[C].rice_params[(uint32_t)lane >> (6 - d_porder)] = d_k;
+    }
+}
+
+template <bool MS, int NCH, int MAXO, bool ACC64>
+__global__ void __launch_bounds__((MS ? 4 : NCH) * 64, 8)
+fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, FgBlockResult *results, FgDebugRec *dbg)
+{
+    constexpr int NC = MS ? 4 : NCH;
+    constexpr int NT = NC * 64;
+    typedef typename PipeTypes<ACC64>::samp_t samp_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t bi = blockIdx.x;
+    const FgBlockDesc d = descs[bi];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = rfl((uint32_t)tid >> 6);
+    const uint32_t sbytes = (((P.sig_stride + 128) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
+    LDS samp_t *sL = (LDS samp_t *)smem;
+    LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
+    LDS uint32_t *xch = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes);
+    if (tid == 0) xch[0] = 0;
+    __syncthreads();
+    const uint32_t bad = pipe_stage<NCH, ACC64, NT>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, d.n >> 6);
+    if (bad) xch[0] = 1;            // (benign race: every writer stores the same value)
+    __syncthreads();
+    const uint32_t range_err = xch[0] ? FG_ERR_RANGE : 0;
+    FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
+    pipe_eval_cand<MS, NCH, MAXO, ACC64>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, sL, sR, lane, range_err);
+}
+
+// ================================================================================================ K5: pack
+// Frame-bit window of one wave: a zeroed window of `fbw` words that starts at word `wbase` of the wave's chunk.  flush()
+// writes the complete words out as they are (most significant bit first inside the 32-bit value; K6 turns them into bytes).
+struct ChunkBits {
+    LDS uint32_t *w;
+    uint32_t *outw;
+    uint32_t wbase, cap_words, fbw, err;
+};
+
+FGI void cb_or(const ChunkBits &b, uint32_t pos, uint32_t val, uint32_t vbits)
+{
+    const uint32_t rel = pos - (b.wbase << 5);
+    const uint32_t word = rel >> 5, sh = rel & 31;
+    const u64 x = (u64)val << ((64 - sh - vbits) & 63);
+    __hip_atomic_fetch_or(&b.w[word], (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_or(&b.w[word + 1], (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// write out the complete words below bit position `upto` (and, with `all`, the partial word that follows)
+FGI void cb_flush(ChunkBits &b, int lane, uint32_t upto, bool all)
+{
+    const uint32_t wend = (upto >> 5) + ((all && (upto & 31)) ? 1u : 0u);
+    if (wend <= b.wbase) return;
+    const uint32_t nfull = wend - b.wbase;
+    if (wend > b.cap_words) b.err |= FG_ERR_SLOT;
+    wave_lds_fence();
+    for (uint32_t wi = b.wbase + (uint32_t)lane; wi < wend; wi += 64)
+        if (wi < b.cap_words) b.outw[wi] = b.w[wi - b.wbase];
+    const uint32_t carry = b.w[nfull];
+    wave_lds_fence();
+    for (uint32_t j = lane; j <= nfull + 1 && j < b.fbw + 2; j += 64) b.w[j] = 0;
+    wave_lds_fence();
+    if (lane == 0) b.w[0] = carry;
+    b.wbase = wend;
+    wave_lds_fence();
+}
+
+FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
+{
+    if (bitpos + bits - (b.wbase << 5) > 32u * b.fbw - 64u) cb_flush(b, lane, bitpos, false);
+}
+
+template <bool MS, int NCH, int MAXO, bool ACC64, int WS>
+__global__ void __launch_bounds__(NCH * WS * 64, 4)
+fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
+                    uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
+{
+    constexpr int NC = MS ? 4 : NCH;
+    constexpr int NW = NCH * WS;            // waves = chunks per frame
+    constexpr int NT = NW * 64;
+    constexpr uint32_t LPS = 64 * WS;       // lanes (segments) per subframe
+    typedef typename PipeTypes<ACC64>::samp_t samp_t;
+    constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t bi = blockIdx.x + bi0;
+    const FgBlockDesc d = descs[bi];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = rfl((uint32_t)tid >> 6);
+    const uint32_t si = wv / WS, hf = wv % WS;
+    const uint32_t n = d.n;
+    const uint32_t seg = n / LPS, rstr = seg + PADE;
+    const uint32_t sbytes = (((P.sig_stride + 2 * LPS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
+    LDS samp_t *sL = (LDS samp_t *)smem;
+    LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
+    LDS uint32_t *fbw = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes) + wv * (fbw_words + 2 + 64);
+    LDS uint32_t *misc = fbw + fbw_words + 2;                 // 64 words per wave: header bytes, then the packer's scratch words
+    (void)pipe_stage<NCH, ACC64, NT>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg);
+    for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0;
+    __syncthreads();
+
+    // ---- channel assignment from the four candidate totals (every wave computes it; wave-uniform)
+    uint32_t ca = 0, c = si;
+    if (MS) {
+        if (d.forced_ca != 0xFF) ca = d.forced_ca;
+        else {
+            const uint32_t b0 = rfl(B.dec[(size_t)bi * NC + 0].bits), b1 = rfl(B.dec[(size_t)bi * NC + (NC > 1 ? 1 : 0)].bits);
+            const uint32_t b2 = rfl(B.dec[(size_t)bi * NC + (NC > 2 ? 2 : 0)].bits), b3 = rfl(B.dec[(size_t)bi * NC + (NC > 3 ? 3 : 0)].bits);
+            const uint32_t b01 = b0 + b1, b03 = b0 + b3, b13 = b1 + b3, b23 = b2 + b3;
+            uint32_t mn = b01;
+            if (b03 < mn) { mn = b03; ca = 1; }
+            if (b13 < mn) { mn = b13; ca = 2; }
+            if (b23 < mn) { mn = b23; ca = 3; }
+        }
+        const uint32_t sub0 = ca == 2 ? 3 : (ca == 3 ? 2 : 0), sub1 = ca == 0 ? 1 : (ca == 2 ? 1 : 3);
+        c = si == 0 ? sub0 : sub1;
+    }
+    const FgPipeDec *dec = B.dec + (size_t)bi * NC + c;
+    const uint32_t type = rfl(dec->type), order = rfl(dec->order), prec = rfl(dec->prec), po = rfl(dec->porder), method = rfl(dec->method);
+    const uint32_t wst = rfl(dec->wasted);
+    int shift = (int)rfl((uint32_t)dec->shift);
+    const uint32_t sb = P.bps + ((MS && c == 3) ? 1u : 0u) - wst;
+    const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
+    const uint32_t Lg = hf * 64 + (uint32_t)lane;         // this lane's segment of the subframe
+    const LDS samp_t *rowL = sL + Lg * rstr, *rowR = sR + Lg * rstr;
+
+    ChunkBits fb;
+    fb.w = fbw; fb.fbw = fbw_words; fb.cap_words = chunk_cap_words; fb.wbase = 0; fb.err = 0;
+    fb.outw = (uint32_t *)(slots + (size_t)d.out_slot * P.slot_bytes) + (size_t)wv * chunk_cap_words;
+    uint32_t bitpos = 0;
+    bool redo = false;
+
+    if (wv == 0) {   // frame header: assembled by lane 0 in LDS, emitted one byte per lane
+        LDS uint8_t *hb = (LDS uint8_t *)misc;
+        uint32_t hl = 0;
+        if (lane == 0) {
+            uint32_t u, bs_hint = 0, sr_hint = 0;
+            hb[hl++] = 0xFF; hb[hl++] = 0xF8;
+            switch (n) {
+            case 192: u = 1; break; case 576: u = 2; break; case 1152: u = 3; break; case 2304: u = 4; break;
+            case 4608: u = 5; break; case 256: u = 8; break; case 512: u = 9; break; case 1024: u = 10; break;
+            case 2048: u = 11; break; case 4096: u = 12; break; case 8192: u = 13; break; case 16384: u = 14; break;
+            case 32768: u = 15; break;
+            default: bs_hint = u = (n <= 0x100) ? 6 : 7; break;
+            }
+            const uint32_t b2 = u << 4;
+            const uint32_t sr = P.sample_rate;
+            switch (sr) {
+            case 88200: u = 1; break; case 176400: u = 2; break; case 192000: u = 3; break; case 8000: u = 4; break;
+            case 16000: u = 5; break; case 22050: u = 6; break; case 24000: u = 7; break; case 32000: u = 8; break;
+            case 44100: u = 9; break; case 48000: u = 10; break; case 96000: u = 11; break;
+            default:
+                if (sr <= 255000 && sr % 1000 == 0) sr_hint = u = 12;
+                else if (sr <= 655350 && sr % 10 == 0) sr_hint = u = 14;
+                else if (sr <= 0xffff) sr_hint = u = 13;
+                else u = 0;
+                break;
+            }
+            hb[hl++] = (uint8_t)(b2 | u);
+            switch (ca) { case 0: u = P.channels - 1; break; case 1: u = 8; break; case 2: u = 9; break; default: u = 10; break; }
+            const uint32_t b3 = u << 4;
+            switch (P.bps) { case 8: u = 1; break; case 12: u = 2; break; case 16: u = 4; break; case 20: u = 5; break;
+                             case 24: u = 6; break; case 32: u = 7; break; default: u = 0; break; }
+            hb[hl++] = (uint8_t)(b3 | (u << 1));
+            const uint32_t v = d.frame_number;
+            if (v < 0x80) hb[hl++] = (uint8_t)v;
+            else if (v < 0x800) { hb[hl++] = 0xC0 | (v >> 6); hb[hl++] = 0x80 | (v & 0x3F); }
+            else if (v < 0x10000) { hb[hl++] = 0xE0 | (v >> 12); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            else if (v < 0x200000) { hb[hl++] = 0xF0 | (v >> 18); hb[hl++] = 0x80 | ((v >> 12) & 0x3F); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            else if (v < 0x4000000) { hb[hl++] = 0xF8 | (v >> 24); hb[hl++] = 0x80 | ((v >> 18) & 0x3F); hb[hl++] = 0x80 | ((v >> 12) & 0x3F); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            else { hb[hl++] = 0xFC | (v >> 30); hb[hl++] = 0x80 | ((v >> 24) & 0x3F); hb[hl++] = 0x80 | ((v >> 18) & 0x3F); hb[hl++] = 0x80 | ((v >> 12) & 0x3F); hb[hl++] = 0x80 | ((v >> 6) & 0x3F); hb[hl++] = 0x80 | (v & 0x3F); }
+            if (bs_hint == 6) hb[hl++] = (uint8_t)(n - 1);
+            else if (bs_hint == 7) { hb[hl++] = (uint8_t)((n - 1) >> 8); hb[hl++] = (uint8_t)(n - 1); }
+            if (sr_hint == 12) hb[hl++] = (uint8_t)(sr / 1000);
+            else if (sr_hint == 13) { hb[hl++] = (uint8_t)(sr >> 8); hb[hl++] = (uint8_t)sr; }
+            else if (sr_hint == 14) { hb[hl++] = (uint8_t)((sr / 10) >> 8); hb[hl++] = (uint8_t)(sr / 10); }
+            uint32_t c8 = 0;
+            for (uint32_t i = 0; i < hl; i++) {
+                c8 ^= hb[i];
+                for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
+            }
+            hb[hl++] = (uint8_t)c8;
+        }
+        hl = rfl(hl);
+        wave_lds_fence();
+        const uint32_t v = (uint32_t)lane < hl ? hb[lane] : 0, b = (uint32_t)lane < hl ? 8 : 0;
+        wave_lds_fence();
+        cb_or(fb, (uint32_t)lane * 8, v, b);
+        bitpos = hl * 8;
+        wave_lds_fence();
+        if (lane == 0) results[d.out_slot].ca = ca;
+    }
+    int32_t cca, ccb;
+    uint32_t ccs;
+    pipe_cand_coef(MS, c, cca, ccb, ccs);
+    const uint32_t csh = ccs + wst;
+    auto cand = [&](int32_t l, int32_t r) -> int32_t { return pipe_cand(l, r, cca, ccb, csh); };
+    if (hf == 0) {
+        // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes
+        // 1..order = warm-up samples, then precision/shift, coefficients, coding method + partition order
+        uint32_t hdr;
+        switch (type) {
+        case 0: hdr = 0x00; break;
+        case 1: hdr = 0x02; break;
+        case 2: hdr = 0x10 | (order << 1); break;
+        default: hdr = 0x40 | ((order - 1) << 1); break;
+        }
+        uint32_t pv = 0, pb = 0, val = 0, vb = 0;
+        const bool pred = type >= 2;
+        const uint32_t nw = type == 0 ? 1 : (pred ? order : 0);
+        if (lane == 0) {
+            pv = hdr | (wst ? 1u : 0u); pb = 8;
+            if (wst) { val = 1; vb = wst; }                  // wasted bits - 1 zeros, then a one
+        }
+        else if ((uint32_t)lane <= nw) {
+            const uint32_t g = (uint32_t)lane - 1;             // sample index (inside segment 0: order <= MAXO <= seg)
+            val = (uint32_t)cand(sL[g], (NCH == 2) ? (int32_t)sR[g] : 0) & mask; vb = sb;
+        }
+        else if (type == 3 && (uint32_t)lane == order + 1) { pv = prec - 1; pb = 4; val = (uint32_t)shift & 31; vb = 5; }
+        else if (type == 3 && (uint32_t)lane <= 2 * order + 1) { val = (uint32_t)dec->q[lane - order - 2] & ((1u << prec) - 1); vb = prec; }
+        else if (pred && (uint32_t)lane == (type == 3 ? 2 * order + 2 : order + 1)) { val = (method << 4) | po; vb = 6; }
+        const uint32_t mine = pb + vb;
+        const uint32_t incl = wave_scan_add(mine);
+        const uint32_t total = rl(incl, 63);
+        cb_reserve(fb, lane, bitpos, total);
+        const uint32_t o = bitpos + incl - mine;
+        cb_or(fb, o, pv, pb);
+        cb_or(fb, o + pb, val, vb);
+        bitpos += total;
+        wave_lds_fence();
+    }
+    if (type != 0) {
+        // ---- body: pass A = exact bit length of every lane's segment, prefix sum = its start, pass B = the codes
+        int32_t q[MAXO];
+        if (type == 3) {
+            const int32_t qall = (lane < MAXO) ? dec->q[lane < 12 ? lane : 0] : 0;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rl((uint32_t)qall, j);
+        }
+        else {
+            const uint32_t g = type == 2 ? order : 0;
+            const int32_t c0 = g == 0 ? 0 : (int32_t)g, c1 = g < 2 ? 0 : (g == 2 ? -1 : g == 3 ? -3 : -6);
+            const int32_t c2 = g < 3 ? 0 : (g == 3 ? 1 : 4), c3 = g < 4 ? 0 : -1;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) q[j] = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : 0;
+            shift = 0;
+        }
+        const uint32_t plen = method ? 5 : 4;
+        const uint32_t lpp = LPS >> po;                                  // lanes per partition
+        const uint32_t kr = type >= 2 ? (uint32_t)dec->k[Lg / lpp] : 0;   // this lane's Rice parameter
+        const bool pstart = type >= 2 && (Lg % lpp) == 0;
+        const uint32_t skip = (type >= 2 && Lg == 0) ? order : 0;        // warm-up samples are not coded
+        auto walk_t = [&](auto VERB, auto EMIT, auto ATOM, auto ALLF, uint32_t p0, bool inrange_) __attribute__((always_inline)) -> uint32_t {
+            constexpr bool verb = decltype(VERB)::value, emit = decltype(EMIT)::value, atom = decltype(ATOM)::value;
+            const bool inrange = decltype(ALLF)::value ? true : inrange_;
+            int32_t h[MAXO];
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) {
+                int32_t x = 0;
+                if (Lg > 0) x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
+            }
+            uint32_t pos = p0, len = 0;
+            // Emission without LDS atomics: a lane's bits are consecutive, so it keeps the word it is filling in a register
+            // (`cur`, window word `cw`) and stores it when it moves on; the word it ends in is shared with the next lane and
+            // is merged after the walk.  The stores are unconditional: a lane that has nothing to store writes to a scratch
+            // word of its own.  This needs every lane to span at least a word (no three lanes in one word): true for 32 or
+            // more samples per lane; shorter segments (atom) OR their bits into the window with LDS atomics instead.
+            LDS uint32_t *const dummy = misc + lane;
+            uint32_t cw = (p0 >> 5) - fb.wbase;
+            uint32_t cur = (emit && !atom && inrange) ? fb.w[cw] : 0;
+            auto put = [&](uint32_t at, uint32_t val, uint32_t vb) __attribute__((always_inline)) {
+                if (atom) { cb_or(fb, inrange ? at : (fb.wbase << 5), inrange ? val : 0, vb); return; }
+                const uint32_t rel = at - (fb.wbase << 5);
+                const uint32_t wi = rel >> 5, sh = rel & 31;
+                const u64 x = (u64)val << ((64 - sh - vb) & 63);
+                const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+                const bool moved = inrange && wi != cw;
+                *(moved ? fb.w + cw : dummy) = cur;
+                cur = moved ? hi : (cur | hi);
+                cw = wi;
+                const bool spill = inrange && lo != 0;
+                *(spill ? fb.w + cw : dummy) = cur;
+                cur = spill ? lo : cur;
+                cw += spill ? 1u : 0u;
+            };
+            if (pstart) {
+                if (emit) put(pos, kr, plen);
+                pos += plen; len += plen;
+            }
+            const uint32_t kmask = (1u << kr) - 1, kone = 1u << kr;
+            auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
+                const int32_t x = cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
+                uint32_t val, vb, lead;
+                if (verb) { val = (uint32_t)x & mask; vb = sb; lead = 0; }
+                else {
+                    int32_t res;
+                    if (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
+                    else res = (int32_t)((i64)x - (pfir48<MAXO>(q, h, u) >> shift));
+                    h[u] = ACC64 ? ppack(x) : x;
+                    const uint32_t uu = ((uint32_t)res << 1) ^ (uint32_t)(res >> 31);
+                    lead = uu >> kr;
+                    val = kone | (uu & kmask);
+                    vb = kr + 1;
+                }
+                if (guard) {
+                    const bool coded = s >= skip;
+                    if (emit) put(coded ? pos + lead : pos, coded ? val : 0, coded ? vb : 0);
+                    const uint32_t cl_ = coded ? lead + vb : 0;
+                    pos += cl_; len += cl_;
+                }
+                else {
+                    if (emit) put(pos + lead, val, vb);
+                    pos += lead + vb; len += lead + vb;
+                }
+            };
+            uint32_t s0 = 0;
+            if (seg >= (uint32_t)MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, (uint32_t)u, true);
+                s0 = MAXO;
+            }
+#pragma unroll 1
+            for (; s0 + MAXO <= seg; s0 += MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+            if (emit && !atom) {
+                wave_lds_fence();
+                if (inrange) fb.w[cw] |= cur;
+                wave_lds_fence();
+            }
+            return len;
+        };
+        auto walk = [&](bool emit, uint32_t p0, bool inrange, bool all) __attribute__((always_inline)) -> uint32_t {
+            typedef std::integral_constant<bool, true> T;
+            typedef std::integral_constant<bool, false> F;
+            if (!emit) return type == 1 ? walk_t(T(), F(), F(), F(), p0, inrange) : walk_t(F(), F(), F(), F(), p0, inrange);
+            if (seg < 32) return type == 1 ? walk_t(T(), T(), T(), F(), p0, inrange) : walk_t(F(), T(), T(), F(), p0, inrange);
+            if (all) return type == 1 ? walk_t(T(), T(), F(), T(), p0, true) : walk_t(F(), T(), F(), T(), p0, true);
+            return type == 1 ? walk_t(T(), T(), F(), F(), p0, inrange) : walk_t(F(), T(), F(), F(), p0, inrange);
+        };
+        const uint32_t mylen = walk(false, 0, false, false);
+        if (__any(mylen > (1u << 24))) redo = true;                  // absurd code lengths: the generic kernel copes
+        if (!redo) {
+            const uint32_t incl = wave_scan_add(mylen);
+            const uint32_t mystart = bitpos + incl - mylen, myend = bitpos + incl;
+            const uint32_t subend = bitpos + rl(incl, 63);
+            uint32_t a = 0;
+#pragma unroll 1
+            while (a < 64) {
+                cb_flush(fb, lane, rl(mystart, (int)a), false);
+                const uint32_t cap = (fb.wbase << 5) + 32u * fb.fbw - 64u;
+                const uint64_t fits = __ballot((uint32_t)lane >= a && myend <= cap);
+                const uint64_t shifted = fits >> a;
+                const uint32_t cnt = (~shifted) ? (uint32_t)__builtin_ctzll(~shifted) : 64u - a;
+                if (cnt == 0) { redo = true; break; }
+                const uint32_t b = a + cnt;
+                (void)walk(true, mystart, (uint32_t)lane >= a && (uint32_t)lane < b, a == 0 && b == 64);
+                wave_lds_fence();
+                a = b;
+            }
+            bitpos = subend;
+        }
+    }
+    if (!redo) cb_flush(fb, lane, bitpos, true);
+    if (lane == 0) {
+        B.chunk_bits[(size_t)bi * 4 + wv] = redo ? 0 : bitpos;
+        const uint32_t e = fb.err | (redo ? FG_ERR_REDO : 0u);
+        if (e) atomicOr(&results[d.out_slot].err, e);
+    }
+}
+
+// ================================================================================================ sizes of the pipeline's frames
+// bytes of frame = ceil(sum of chunk bits / 8) + 2 (CRC-16); written into the block results the scan kernel reads
+__global__ void fg_pipe_sizes_kernel(const FgBlockDesc *descs, uint32_t npipe, const uint32_t *chunk_bits, uint32_t nw, FgBlockResult *results)
+{
+    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= npipe) return;
+    uint32_t bits = 0;
+    for (uint32_t w = 0; w < nw; w++) bits += chunk_bits[(size_t)bi * 4 + w];
+    FgBlockResult *r = &results[descs[bi].out_slot];
+    r->bytes = (r->err & FG_ERR_REDO) ? 0 : ((bits + 7) >> 3) + 2;
+}
+
+// ================================================================================================ K6: chunks -> frame at its final place
+// One wave per block.  Pipeline blocks (results.reserved == 4): the frame's words are gathered from the chunks with funnel
+// shifts, the CRC-16 runs alongside (lane l owns the words l, l+64, ...: state * x^2048 + crc(word) through tables in LDS,
+// final fold with x^(32k) multipliers), and the bytes go to dst + offsets[slot].  Other blocks (generic kernel: complete
+// frames in their slots) are copied.
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64)
+fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_t *slots, uint32_t slot_bytes, uint32_t chunk_cap_words,
+                        uint32_t nw, const uint32_t *chunk_bits, const FgBlockResult *results, const u64 *offsets, uint8_t *dst,
+                        u64 dst_cap, const uint16_t *crctab)
+{
+    __shared__ uint16_t tab[1792];           // [0,256) byte table, [256,768) x^2048 tables, [768,832) x^(32k), [1024,1792) slicing tables
+    for (uint32_t j = threadIdx.x; j < 1792; j += WPB * 64) tab[j] = crctab[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t bi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (bi >= nblocks) return;
+    const FgBlockDesc d = descs[bi];
+    const FgBlockResult res = results[d.out_slot];
+    const uint32_t nb = res.bytes;
+    if (nb == 0 || offsets[d.out_slot] + nb > dst_cap) return;      // the host reports the short buffer once it has read the total
+    uint8_t *out = dst + offsets[d.out_slot];
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    if (res.reserved != 4) {
+        const uint32_t *sw = (const uint32_t *)(slots + (size_t)d.out_slot * slot_bytes);
+        const uint32_t nwd = nb >> 2;
+        for (uint32_t j = lane; j < nwd; j += 64) ((U32 *)out)[j].v = sw[j];
+        const uint32_t done = nwd * 4;
+        if ((uint32_t)lane < nb - done) out[done + lane] = ((const uint8_t *)sw)[done + lane];
+        return;
+    }
+    // chunk table (wave-uniform)
+    uint32_t S[4], Bc[4];
+    const uint32_t *cw[4];
+    uint32_t T = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t b = (uint32_t)w < nw ? chunk_bits[(size_t)bi * 4 + w] : 0;
+        S[w] = T; Bc[w] = b; T += b;
+        cw[w] = (const uint32_t *)(slots + (size_t)d.out_slot * slot_bytes) + (size_t)w * chunk_cap_words;
+    }
+    const uint32_t nbytes = (T + 7) >> 3;            // frame without its CRC-16
+    const uint32_t W = nbytes >> 2, tail = nbytes & 3;
+    auto gather = [&](uint32_t j) -> uint32_t {
+        uint32_t v = 0;
+        const int64_t b0 = (int64_t)j * 32;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int64_t rel = b0 - (int64_t)S[w];
+            if (Bc[w] != 0 && rel > -32 && rel < (int64_t)Bc[w]) {       // (an empty chunk's words were never written)
+                uint32_t x;
+                if (rel >= 0) {
+                    const uint32_t wi = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31;
+                    const uint32_t hi = cw[w][wi];
+                    const uint32_t lo = (((wi + 1) << 5) < Bc[w]) ? cw[w][wi + 1] : 0;
+                    x = (uint32_t)((((u64)hi << 32) | lo) >> (32 - sh));
+                }
+                else x = cw[w][0] >> (uint32_t)(-rel);
+                v |= x;
+            }
+        }
+        return v;
+    };
+    uint32_t crc = 0;
+    const uint32_t nrows = (W + 63) >> 6;
+    auto emit = [&](uint32_t j, uint32_t v) __attribute__((always_inline)) {
+        if (j < W) {
+            ((U32 *)out)[j].v = __builtin_bswap32(v);
+            uint32_t s = crc;
+            s = tab[256 + (s >> 8)] ^ tab[512 + (s & 0xFF)];
+            crc = s ^ tab[1536 + (v >> 24)] ^ tab[1280 + ((v >> 16) & 0xFF)] ^ tab[1024 + ((v >> 8) & 0xFF)] ^ tab[v & 0xFF];
+        }
+    };
+    // the chunk a run of rows [row, row + cnt) lies inside entirely (every word of it two loads and a funnel shift), or -1
+    auto interior = [&](uint32_t row, uint32_t cnt) -> int {
+        const uint32_t rb0 = row * 2048, rb1 = (row + cnt) * 2048 + 32;
+        int in = -1;
+#pragma unroll
+        for (int w = 0; w < 4; w++) if (rb0 >= S[w] && rb1 <= S[w] + Bc[w]) in = w;
+        return in;
+    };
+    uint32_t row = 0;
+    // four rows per step while they lie inside one chunk (all but a handful do): eight loads in flight per lane
+    while (row + 4 <= nrows) {
+        const int in = interior(row, 4);
+        if (in < 0) {
+            // a chunk boundary inside these rows: one row the general way, then try again
+            const uint32_t j = row * 64 + (uint32_t)lane;
+            emit(j, gather(j));
+            row++;
+            continue;
+        }
+        const uint32_t *p = in == 0 ? cw[0] : in == 1 ? cw[1] : in == 2 ? cw[2] : cw[3];
+        const uint32_t s_ = in == 0 ? S[0] : in == 1 ? S[1] : in == 2 ? S[2] : S[3];
+        const uint32_t j0 = row * 64 + (uint32_t)lane;
+        const uint32_t rel = j0 * 32 - s_;
+        const uint32_t wi = rel >> 5, sh = rel & 31;
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = p[wi + 64 * u]; b[u] = p[wi + 64 * u + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) emit(j0 + 64 * u, (uint32_t)((((u64)a[u] << 32) | b[u]) >> (32 - sh)));
+        row += 4;
+    }
+    for (; row < nrows; row++) {
+        const uint32_t j = row * 64 + (uint32_t)lane;
+        const int in = interior(row, 1);
+        uint32_t v;
+        if (in >= 0) {
+            const uint32_t *p = in == 0 ? cw[0] : in == 1 ? cw[1] : in == 2 ? cw[2] : cw[3];
+            const uint32_t s_ = in == 0 ? S[0] : in == 1 ? S[1] : in == 2 ? S[2] : S[3];
+            const uint32_t rel = j * 32 - s_;
+            const uint32_t wi = rel >> 5, sh = rel & 31;
+            v = (uint32_t)((((u64)p[wi] << 32) | p[wi + 1]) >> (32 - sh));
+        }
+        else v = gather(j);
+        emit(j, v);
+    }
+    // fold: lane l's last word is dist = (W - 1 - l) mod 64 words from the end
+    uint32_t s = 0;
+    if ((uint32_t)lane < W) s = gf16_mul(crc, tab[768 + ((W - 1 - (uint32_t)lane) & 63)]);
+    uint32_t c16 = wave_xor32(s);
+    if (lane == 0) {
+        const uint32_t wvl = tail ? gather(W) : 0;
+        for (uint32_t b = 0; b < tail; b++) {
+            const uint32_t byte = (wvl >> (24 - 8 * b)) & 0xFF;
+            out[W * 4 + b] = (uint8_t)byte;
+            c16 = ((c16 << 8) & 0xFFFF) ^ tab[((c16 >> 8) ^ byte) & 0xFF];
+        }
+        out[nbytes] = (uint8_t)(c16 >> 8);
+        out[nbytes + 1] = (uint8_t)c16;
+    }
+}
+
+}  // namespace

@@ -180,6 +180,7 @@ struct EncImpl {
     uint64_t bytes_written;
     std::vector<int32_t> pending;   // interleaved samples not yet encoded
     uint32_t frame_number;
+    uint32_t last_ca = 0;          // loose mid-side: channel assignment the previous process call ended on
     uint64_t samples_done;
     uint32_t min_frame, max_frame;
     FgMd5 md5;
@@ -273,7 +274,7 @@ FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
     e->blocksize = s.blocksize; e->qlp_precision = s.qlp_coeff_precision; e->do_mid_side = s.do_mid_side;
     e->loose_mid_side = s.loose_mid_side; e->min_po = s.min_partition_order; e->max_po = s.max_partition_order;
     e->pending.clear();
-    e->frame_number = 0; e->samples_done = 0; e->min_frame = 0; e->max_frame = 0; e->bytes_written = 0;
+    e->frame_number = 0; e->last_ca = 0; e->samples_done = 0; e->min_frame = 0; e->max_frame = 0; e->bytes_written = 0;
     e->md5.init();
     e->state = FLAC__STREAM_ENCODER_OK;
     // three metadata writes: "fLaC", STREAMINFO, VORBIS_COMMENT (stream_encoder.h:1484-1486)
@@ -299,7 +300,7 @@ bool encode_pending(EncImpl *e, bool flush_all)
     (void)hipSetDevice(c->device);
     const size_t pcm_bytes = (size_t)take * C * 4;
     flacgpu_stream_desc sd;
-    sd.pcm_offset = 0; sd.nsamples = take; sd.first_frame = e->frame_number; sd.reserved = 0;
+    sd.pcm_offset = 0; sd.nsamples = take; sd.first_frame = e->frame_number; sd.prev_channel_assignment = e->last_ca;
     uint32_t nblocks = 0;
     const uint64_t bound = flacgpu_encode_bound(&e->s, &sd, 1, &nblocks);
     if (!e->d_pcm.ensure(pcm_bytes) || !e->d_out.ensure(bound) || !e->d_offs.ensure(((size_t)nblocks + 1) * 8)) {
@@ -315,6 +316,7 @@ bool encode_pending(EncImpl *e, bool flush_all)
     flacgpu_encode_stats st;
     const int rc = flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, e->d_out.p, e->d_out.cap, e->d_offs.p, &st);
     bool ok = rc == 0;
+    if (ok) e->last_ca = st.last_channel_assignment;
     if (ok && st.error_flags) {
         ok = false;
         e->state = (st.error_flags & FG_ERR_RANGE) ? FLAC__STREAM_ENCODER_CLIENT_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
