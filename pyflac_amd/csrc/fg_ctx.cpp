@@ -131,6 +131,8 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->evs[i]));
@@ -161,6 +163,8 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 8; i++) if (c->evs[i]) (void)hipEventDestroy(c->evs[i]);
     for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+    for (int i = 0; i < 2; i++) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -391,7 +395,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     PL.pcm = d_pcm; PL.descs = (const FgBlockDesc *)c->descs.p; PL.windows = (const float *)c->windows.p; PL.P = P;
     PL.slots = (uint8_t *)c->slots.p; PL.results = (FgBlockResult *)c->results.p; PL.dbg = dbg;
     PL.chunk_cap_words = chunk_cap_words; PL.fbw_words = fbw_words; PL.acc64 = s->bits_per_sample > 16 ? 1 : 0;
-    PL.stream = (void *)c->stream;
+    PL.stream = (void *)c->stream; PL.stream2 = (void *)c->stream3; PL.ev_fork = (void *)c->evp[0]; PL.ev_join = (void *)c->evp[1];
     // the block list goes to the device once per distinct layout (repeated calls with the same streams skip the copy)
     auto upload_descs = [&](const std::vector<FgBlockDesc> &v, bool cache) -> bool {
         const size_t bytes = v.size() * sizeof(FgBlockDesc);

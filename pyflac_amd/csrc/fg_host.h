@@ -72,6 +72,8 @@ struct flacgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
+    hipStream_t stream3 = nullptr;   // short blocks of the pipeline's packing stage
+    hipEvent_t evp[2] = {nullptr, nullptr};
     hipEvent_t evx[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing

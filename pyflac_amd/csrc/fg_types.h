@@ -106,6 +106,8 @@ struct FgPipeLaunch {
     uint32_t acc64;             // > 16 bit samples
     uint32_t stages;            // bit 0: analysis (K2-K4), bit 1: pack (K5)
     void *stream;               // hipStream_t
+    void *stream2;              // side stream for the (few) blocks packed by one wave per subframe; events to fork and join
+    void *ev_fork, *ev_join;
 };
 
 // ---- decoder ----

@@ -65,6 +65,13 @@ template <bool MS, int C> FGI int32_t pcv(int32_t L, int32_t R)
 }
 
 FGI uint32_t pabs32(int32_t v) { return (uint32_t)(v < 0 ? -v : v); }
+// |a - b| + c on unsigned operands in one instruction
+FGI uint32_t psad(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 // sum_j q[j] * h[(u - 1 - j) mod MAXO]: one v_mad_i32_i24 per tap, the coefficient from an SGPR (one candidate per wave, so
 // the MAXO coefficients are wave-uniform and fit the scalar file).  History slot of sample s is s mod MAXO.
@@ -516,33 +523,72 @@ FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams
         }
         istart = n;
     }
-    for (uint32_t i0 = istart; i0 < n; i0 += 4 * NT) {
-        int32_t a[4], b[4];
+    if (NCH == 2 && P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (seg & 1) == 0 && (((uintptr_t)pcm) & 7) == 0) {
+        // int16 stereo: two inter-channel samples per 8-byte load, stored as one LDS word per channel
+        const int2 *src = (const int2 *)((const short2 *)pcm + d.pcm_off);
+        for (uint32_t j0 = 0; j0 < n / 2; j0 += 4 * NT) {
+            int2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + u * NT + tid;
-            a[u] = 0; b[u] = 0;
-            if (i < n) {
-                if (NCH == 2) {
-                    if (P.pcm_i16) { const short2 v = ((const short2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
-                    else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
-                }
-                else {
-                    if (P.pcm_i16) a[u] = ((const int16_t *)pcm)[d.pcm_off + i];
-                    else a[u] = ((const int32_t *)pcm)[d.pcm_off + i];
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + u * NT + tid;
+                v[u] = make_int2(0, 0);
+                if (j < n / 2) v[u] = src[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + u * NT + tid;
+                if (j < n / 2) {
+                    const uint32_t w0 = (uint32_t)v[u].x, w1 = (uint32_t)v[u].y;     // (l0, r0), (l1, r1)
+                    const uint32_t ad = FGP_SADDR(2 * j);
+                    if (P.bps < 16) {
+                        const int32_t l0 = (int16_t)w0, r0 = (int32_t)w0 >> 16, l1 = (int16_t)w1, r1 = (int32_t)w1 >> 16;
+                        bad |= (uint32_t)(((l0 ^ (l0 >> 31)) >> lim) | ((r0 ^ (r0 >> 31)) >> lim) | ((l1 ^ (l1 >> 31)) >> lim) | ((r1 ^ (r1 >> 31)) >> lim));
+                    }
+                    if (sizeof(samp_t) == 2) {
+                        *(LDS uint32_t *)(sL + ad) = (w0 & 0xFFFFu) | (w1 << 16);
+                        *(LDS uint32_t *)(sR + ad) = (w0 >> 16) | (w1 & 0xFFFF0000u);
+                    }
+                    else { sL[ad] = (samp_t)(int16_t)w0; sL[ad + 1] = (samp_t)(int16_t)w1; sR[ad] = (samp_t)((int32_t)w0 >> 16); sR[ad + 1] = (samp_t)((int32_t)w1 >> 16); }
                 }
             }
         }
+        istart = n;
+    }
+    // any other layout: one sample per lane and load, four loads in flight (the input format is tested outside the loops)
+    auto rest = [&](auto I16) __attribute__((always_inline)) {
+        constexpr bool i16 = decltype(I16)::value;
+        for (uint32_t i0 = istart; i0 < n; i0 += 4 * NT) {
+            int32_t a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + u * NT + tid;
-            if (i < n) {
-                if (P.bps < 32) bad |= (uint32_t)(((a[u] ^ (a[u] >> 31)) >> lim) | ((b[u] ^ (b[u] >> 31)) >> lim));
-                const uint32_t ad = FGP_SADDR(i);
-                sL[ad] = (samp_t)a[u];
-                if (NCH == 2) sR[ad] = (samp_t)b[u];
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * NT + tid;
+                a[u] = 0; b[u] = 0;
+                if (i < n) {
+                    if (NCH == 2) {
+                        if (i16) { const short2 v = ((const short2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
+                        else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
+                    }
+                    else {
+                        if (i16) a[u] = ((const int16_t *)pcm)[d.pcm_off + i];
+                        else a[u] = ((const int32_t *)pcm)[d.pcm_off + i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * NT + tid;
+                if (i < n) {
+                    if (P.bps < 32) bad |= (uint32_t)(((a[u] ^ (a[u] >> 31)) >> lim) | ((b[u] ^ (b[u] >> 31)) >> lim));
+                    const uint32_t ad = FGP_SADDR(i);
+                    sL[ad] = (samp_t)a[u];
+                    if (NCH == 2) sR[ad] = (samp_t)b[u];
+                }
             }
         }
+    };
+    if (istart < n) {
+        if (P.pcm_i16) rest(std::integral_constant<bool, true>());
+        else rest(std::integral_constant<bool, false>());
     }
 #undef FGP_SADDR
     return bad;
@@ -650,6 +696,104 @@ FGI int32_t pipe_cand(int32_t l, int32_t r, int32_t ca, int32_t cb, uint32_t sh)
     return (__mul24(l, ca) + __mul24(r, cb)) >> sh;
 }
 
+// The same search with every partition of every order evaluated at once.  The partition sums of all orders are differences
+// of the inclusive prefix sums P of the 64 lane sums (partition p of order o = leaves [p << (6-o), (p+1) << (6-o))), so one
+// scan and two cross-lane reads give every lane the sum of "its" partition: lanes 0..31 take the 32 partitions of order 5,
+// lanes 32..47 order 4, 48..55 order 3, 56..59 order 2, 60..61 order 1, lane 62 order 0; order 6 (one partition per lane)
+// is a round of its own.  One evaluation of (parameter, bits) per round instead of one per order, and a second scan gives the
+// totals of all orders.  Results: best_bits / bpo as pipe_rice_search; the parameter of partition `kpart` in `kpar` on the
+// lanes with kvalid.  Returns false (nothing computed) in the cases the sequential version handles: sums that wrapped in
+// libFLAC's 32-bit accumulation, or totals that need 64-bit sums.
+template <bool ACC64>
+FGI bool pipe_rice_search_tree(typename PipeTypes<ACC64>::sum_t psum, int lane, uint32_t n, uint32_t order, uint32_t sb, uint32_t pmin0,
+                               uint32_t pmax0, uint32_t limit, uint32_t &best_bits, uint32_t &bpo, uint32_t &kpar, uint32_t &kpart, bool &kvalid)
+{
+    // inclusive prefix sums of the lane sums
+    u64 P;
+    if (!ACC64) P = (u64)wave_scan_add((uint32_t)psum);          // (the block total of <= 16-bit input stays below 2^32)
+    else {
+        const u64 v = (u64)psum;
+        const u64 a = wave_scan_add((uint32_t)v & 0xFFFF), b = wave_scan_add(((uint32_t)v >> 16) & 0xFFFF), c = wave_scan_add((uint32_t)(v >> 32));
+        P = a + (b << 16) + (c << 32);
+    }
+    if (ACC64) {
+        // libFLAC sums a partition in 32 bits when bps + 4 + log2(partition size) < 32: harmless unless the residual is wilder
+        // than that bound, which the sequential version reproduces
+        const uint32_t tot_hi = rl((uint32_t)(P >> 32), 63);
+        const bool wrap32 = (sb + 4) < (32 - ilog2_32(n >> pmax0));
+        if (wrap32 && tot_hi != 0) return false;
+    }
+    auto div18 = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t {
+        uint32_t qd = (uint32_t)(262144.0f * __builtin_amdgcn_rcpf((float)x));
+        const int32_t r = (int32_t)(0x40000u - qd * x);
+        if (r < 0) qd--;
+        else if ((uint32_t)r >= x) qd++;
+        return qd;
+    };
+    // (parameter, bits) of one partition: sum s, np samples
+    auto node = [&](u64 s, uint32_t np, uint32_t &kr, uint32_t &pb) __attribute__((always_inline)) {
+        const uint32_t dv = div18(np);
+        if (!ACC64) {
+            const uint32_t s32 = (uint32_t)s;
+            const uint32_t s1 = (s32 > 1 ? s32 : 1) - 1;
+            const uint32_t qv = (uint32_t)(((u64)s1 * dv) >> 18);
+            kr = qv ? 32 - (uint32_t)__builtin_clz(qv) : 0;
+            if (kr >= limit) kr = limit - 1;
+            pb = 4 + (1 + kr) * np + ((s32 << 1) >> kr) - (np >> 1);
+        }
+        else {
+            kr = 0;
+            if (s >= 2) {
+                const u64 qv = ((s - 1) * dv) >> 18;
+                if (qv != 0) kr = ilog2_64(qv) + 1;
+            }
+            if (kr >= limit) kr = limit - 1;
+            u64 b = (u64)4 + (u64)(1 + kr) * np + (kr ? (s >> (kr - 1)) : (s << 1)) - (np >> 1);
+            if (b > 0xFFFFFFFFull) b = 0xFFFFFFFFull;
+            pb = (uint32_t)b;
+        }
+    };
+    // ---- orders 5..0: lane -> (order lev, partition p)
+    const uint32_t lo = (uint32_t)__builtin_clz(~((uint32_t)lane << 26));     // leading ones of the 6-bit lane number
+    const int lev = 5 - (int)lo;                                               // -1 for lane 63
+    const uint32_t base = 64u - (64u >> lo);
+    const uint32_t p = (uint32_t)lane - base;
+    const bool inB = lev >= 0 && (uint32_t)lev <= pmax0 && (uint32_t)lev >= pmin0;
+    const uint32_t width = 64u >> (lev < 0 ? 0 : lev);                         // leaves per partition
+    const uint32_t first = p * width, last = first + width - 1;                // leaf range
+    u64 hi_ = (u64)(uint32_t)__shfl((int)(uint32_t)P, (int)(last & 63));
+    u64 lo_ = (u64)(uint32_t)__shfl((int)(uint32_t)P, (int)((first - 1) & 63));
+    if (ACC64) {
+        hi_ |= (u64)(uint32_t)__shfl((int)(uint32_t)(P >> 32), (int)(last & 63)) << 32;
+        lo_ |= (u64)(uint32_t)__shfl((int)(uint32_t)(P >> 32), (int)((first - 1) & 63)) << 32;
+    }
+    const u64 sB = hi_ - (first == 0 ? 0 : lo_);
+    uint32_t kB, pbB;
+    {
+        const uint32_t pbase = n >> (lev < 0 ? 0 : lev);
+        node(sB, (p == 0) ? pbase - order : pbase, kB, pbB);
+        if (!inB) pbB = 0;
+    }
+    // ---- order 6: one partition per lane
+    uint32_t kA = 0, pbA = 0;
+    const bool doA = pmax0 == 6;
+    if (doA) node((u64)psum, (lane == 0) ? (n >> 6) - order : (n >> 6), kA, pbA);
+    if (__any((pbA | pbB) >> 25)) return false;                                // totals beyond 32 bits: the sequential version
+    const uint32_t SB = wave_scan_add(pbB);
+    const uint32_t t5 = rl(SB, 31), t4 = rl(SB, 47), t3 = rl(SB, 55), t2 = rl(SB, 59), t1 = rl(SB, 61), t0 = rl(SB, 62);
+    const uint32_t tot[7] = {t0 - t1, t1 - t2, t2 - t3, t3 - t4, t4 - t5, t5, doA ? wave_sum(pbA) : 0u};
+    best_bits = 0; bpo = 0;
+#pragma unroll
+    for (int po = 6; po >= 0; po--) {
+        if ((uint32_t)po > pmax0 || (uint32_t)po < pmin0) continue;
+        const uint32_t bits = tot[po] + 6;
+        if (best_bits == 0 || bits < best_bits) { best_bits = bits; bpo = (uint32_t)po; }
+    }
+    if (bpo == 6) { kpar = kA; kpart = (uint32_t)lane; kvalid = true; }
+    else { kpar = kB; kpart = p; kvalid = lev == (int)bpo; }
+    return true;
+}
+
 template <bool MS, int NCH, int MAXO, bool ACC64>
 FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
                         FgDebugRec *mydbg, const LDS typename PipeTypes<ACC64>::samp_t *sL, const LDS typename PipeTypes<ACC64>::samp_t *sR,
@@ -688,7 +832,11 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     uint32_t guess;
     {
         sum_t facc[5], fwarm[5];
-        int32_t p1 = 0, q1 = 0, q2 = 0, q3 = 0;
+        // Everything carries a bias FB (values and differences stay far below it), so |a - b| is one v_sad_u32 on the biased
+        // values -- with the running sum as its addend for <= 16-bit input -- and the differences themselves
+        // (e_k = e_{k-1} - previous e_{k-1}) keep the bias with one extra add: 12 instructions per sample instead of 19.
+        constexpr uint32_t FB = 1u << 30;
+        uint32_t P0 = FB, P1 = FB, P2 = FB, P3 = FB;      // previous value and previous 1st..3rd differences (of zeros)
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) { facc[kk] = 0; fwarm[kk] = 0; }
 #pragma unroll
@@ -696,24 +844,32 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             int32_t v = 0;
             if (s >= 0) v = samp(s);
             else if (lane > 0) v = samp((int)seg + s - (int)rstr);
-            const int32_t e1 = v - p1, e2 = e1 - q1, e3 = e2 - q2, e4 = e3 - q3;
-            p1 = v; q1 = e1; q2 = e2; q3 = e3;
+            const uint32_t vb = (uint32_t)v + FB;
+            const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
             if (s >= 0) {
-                const uint32_t ab[5] = {pabs32(v), pabs32(e1), pabs32(e2), pabs32(e3), pabs32(e4)};
+                const uint32_t ab[5] = {psad(vb, FB, 0), psad(vb, P0, 0), psad(e1b, P1, 0), psad(e2b, P2, 0), psad(e3b, P3, 0)};
 #pragma unroll
                 for (int kk = 0; kk < 5; kk++) {
                     facc[kk] += (lane > 0) ? ab[kk] : 0u;
                     if (s >= kk) fwarm[kk] += ab[kk];
                 }
             }
+            P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
         }
 #pragma unroll 4
         for (int s = 4; s < (int)seg; s++) {
-            const int32_t v = samp(s);
-            const int32_t e1 = v - p1, e2 = e1 - q1, e3 = e2 - q2, e4 = e3 - q3;
-            p1 = v; q1 = e1; q2 = e2; q3 = e3;
-            facc[0] += pabs32(v); facc[1] += pabs32(e1); facc[2] += pabs32(e2);
-            facc[3] += pabs32(e3); facc[4] += pabs32(e4);
+            const uint32_t vb = (uint32_t)samp(s) + FB;
+            const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
+            if (!ACC64) {
+                facc[0] = (sum_t)psad(vb, FB, (uint32_t)facc[0]); facc[1] = (sum_t)psad(vb, P0, (uint32_t)facc[1]);
+                facc[2] = (sum_t)psad(e1b, P1, (uint32_t)facc[2]); facc[3] = (sum_t)psad(e2b, P2, (uint32_t)facc[3]);
+                facc[4] = (sum_t)psad(e3b, P3, (uint32_t)facc[4]);
+            }
+            else {
+                facc[0] += psad(vb, FB, 0); facc[1] += psad(vb, P0, 0); facc[2] += psad(e1b, P1, 0);
+                facc[3] += psad(e2b, P2, 0); facc[4] += psad(e3b, P3, 0);
+            }
+            P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
         }
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) tot[kk] = ACC64 ? wave_sum64((u64)facc[kk]) : (u64)wave_sum((uint32_t)facc[kk]);
@@ -735,7 +891,8 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 
     // ---- baseline: verbatim / constant
     uint32_t best;
-    uint32_t d_type = 1, d_order = 0, d_prec = 0, d_porder = 0, d_method = 0, d_k = 0;
+    uint32_t d_type = 1, d_order = 0, d_prec = 0, d_porder = 0, d_method = 0, d_k = 0, d_kpart = 0;
+    bool d_kvalid = false;      // this lane holds the Rice parameter d_k of partition d_kpart
     int d_shift = 0;
     int32_t bestq[MAXO];
 #pragma unroll
@@ -852,7 +1009,13 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         }
         const bool dead = ACC64 && __any(ovf != 0);
         uint32_t best_bits, bpo, kb;
-        pipe_rice_search<ACC64>(psum, dead, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb);
+        uint32_t kpart;
+        bool kvalid;
+        if (!pipe_rice_search_tree<ACC64>(psum, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb, kpart, kvalid)) {
+            pipe_rice_search<ACC64>(psum, dead, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb);
+            kvalid = ((uint32_t)lane & ((64u >> bpo) - 1)) == 0;
+            kpart = (uint32_t)lane >> (6 - bpo);
+        }
         uint32_t est = 0;
         if (!dead) {
             est = kind == 0 ? (8 + order * sb) : (8 + 4 + 5 + order * (prec + sb));
@@ -860,8 +1023,8 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             if (est > 0 && est < best) {
                 best = est;
                 d_type = kind == 0 ? 2 : 3; d_order = order; d_prec = prec; d_shift = shift;
-                d_porder = bpo; d_k = kb;
-                d_method = __any((((uint32_t)lane & ((64u >> bpo) - 1)) == 0) && kb >= 15) ? 1 : 0;
+                d_porder = bpo; d_k = kb; d_kpart = kpart; d_kvalid = kvalid;
+                d_method = __any(kvalid && kb >= 15) ? 1 : 0;
                 if (kind == 1) {
 #pragma unroll
                     for (int j = 0; j < MAXO; j++) bestq[j] = q[j];
@@ -890,7 +1053,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)bi * 4 + w] = 0;     // the packing waves fill in theirs
         }
     }
-    if (d_type >= 2 && ((uint32_t)lane & ((64u >> d_porder) - 1)) == 0) dec->k[(uint32_t)lane >> (6 - d_porder)] = (uint8_t)d_k;
+    if (d_type >= 2 && d_kvalid) dec->k[d_kpart] = (uint8_t)d_k;
     if (mydbg) {
         if (lane == 0) {
             FgDebugCand *dc = &mydbg->cand[C];
@@ -899,7 +1062,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             dc->bits = best; dc->porder = d_type >= 2 ? d_porder : 0; dc->rice_method = d_type >= 2 ? d_method : 0;
             for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (d_type == 3 && j < d_order && j < (uint32_t)MAXO) ? bestq[j < (uint32_t)MAXO ? j : 0] : 0;
         }
-        if (d_type >= 2 && ((uint32_t)lane & ((64u >> d_porder) - 1)) == 0) mydbg->cand[C].rice_params[(uint32_t)lane >> (6 - d_porder)] = d_k;
+        if (d_type >= 2 && d_kvalid) mydbg->cand[C].rice_params[d_kpart] = d_k;
     }
 }
 
