@@ -356,7 +356,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     const bool use_pipe = cfg_fast && !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) && fg_pipe_supported(&P);
     const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
     const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
-    uint32_t chunk_cap_words = 0, fbw_words = 1280;
+    uint32_t chunk_cap_words = 0, fbw_words = s->bits_per_sample <= 16 ? 800 : 1280;   // 16-bit stereo: 5 workgroups per CU
     if (getenv("FLACGPU_FBW")) fbw_words = (uint32_t)atoi(getenv("FLACGPU_FBW"));
     if (use_pipe) {
         // a chunk holds at most a whole subframe (all of a subframe's bits may sit in one half) plus the frame header

@@ -39,11 +39,13 @@
 #define LDS __attribute__((address_space(3)))
 #define FGI __device__ __forceinline__
 
-#define FGP_DH 32                        // autocorrelation: history doubles kept in front of each chunk
+#define FGP_DH 16                        // autocorrelation: history doubles kept in front of each chunk (>= max lag + 1)
 #define FGP_CK 128                       // autocorrelation: chunk length
-// doubles per candidate row: 352 words, i.e. 32 banks (of 64) from row to row -- the two candidate rows that share a
-// ds_read_b64 lane group ({0-31} / {32-63}) read up to 13 consecutive doubles each and never meet on a bank
-#define FGP_CSTR (FGP_DH + FGP_CK + 16)
+// doubles per candidate row: 288 words, i.e. 32 banks (of 64) from row to row -- the two candidate rows that share a
+// ds_read_b64 lane group ({0-31} / {32-63}) read up to 14 consecutive doubles each and never meet on a bank.  No slack at
+// the end: the chain's read-ahead past a chunk lands in the next row (or the arrays behind the last one) and is not used.
+// 4.9 KB of LDS per wave keeps 28+ waves on a CU: the 7032 blocks of the headline stream are resident in one round.
+#define FGP_CSTR (FGP_DH + FGP_CK)
 
 using namespace fgdev;
 
@@ -146,17 +148,25 @@ FGI double p_ebps(double e, double scale)
 }
 
 // ================================================================================================ K2: autocorrelation + OR
+// (<= 80 SGPRs: above that the scalar file allows only 7 waves per SIMD, 7168 on the chip -- the 7032 blocks of the headline
+// stream would then only fit with a perfectly even spread over the CUs, and the stragglers would double the kernel's time)
+// Four independent waves (blocks) per workgroup: a CU holds at most 16 workgroups, so one-wave workgroups would leave half
+// of its 32 wave slots empty.  No barriers: the waves share nothing but the workgroup's LDS allocation.
+#define FGP_AWPB 4
 template <bool MS, int NCH, int MAXO>
-__global__ void __launch_bounds__(64)
-fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, FgPipeBufs B, FgDebugRec *dbg)
+__global__ void __launch_bounds__(64 * FGP_AWPB, 8) __attribute__((amdgpu_num_sgpr(72)))
+fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, FgPipeBufs B, FgDebugRec *dbg,
+                     uint32_t nblocks, uint32_t lds_per_wave)
 {
     constexpr int NC = MS ? 4 : NCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t bi = blockIdx.x;
+    const uint32_t wv = rfl(threadIdx.x >> 6);
+    const uint32_t bi = blockIdx.x * FGP_AWPB + wv;
+    if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t n = d.n;
-    LDS double *dbuf = (LDS double *)smem;                      // NC rows of FGP_CSTR doubles
+    LDS double *dbuf = (LDS double *)((LDS unsigned char *)smem + wv * lds_per_wave);   // NC rows of FGP_CSTR doubles
     LDS double *autoc = dbuf + NC * FGP_CSTR;                   // [NC][nvec][MAXO + 1]
     LDS uint32_t *wl = (LDS uint32_t *)(autoc + NC * P.nvec * (MAXO + 1));   // wasted bits per candidate
     const float *window = windows + d.win_off;
@@ -188,9 +198,12 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
         }
     }
     else {
-        const uint32_t cl = lane >> 4, l = lane & 15;
-        const bool on = cl < (uint32_t)NC && l <= mo;
-        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGP_CSTR + FGP_DH - (on ? l : 0);
+        // Lane p of a 16-lane row handles lag p - 1: lanes 1 .. mo+1 carry the chains of lags 0 .. mo, lane 0 is a helper
+        // one sample ahead of lag 0 (see the chain below).
+        const uint32_t cl = lane >> 4, pl = lane & 15;
+        const bool on = cl < (uint32_t)NC && pl <= mo + 1;
+        const uint32_t l = pl - 1;                       // lag (lane 0: "-1")
+        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGP_CSTR + FGP_DH + 1 - (on ? pl : 1);
         uint32_t vb_ = 1, vc_ = 0;
         bool more = true;
         while (more) {
@@ -232,7 +245,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
 #pragma unroll
                     for (int u = 0; u < FGP_CK / 64; u++) {
                         const uint32_t j = u * 64 + lane;
-                        if (j < kn) {
+                        if (j < kn && P.debug != 102) {
                             const int32_t L = xl[u], R = xr[u];
                             const bool zero = part != 0 && (k0 + j) >= 2 * part;
 #pragma unroll
@@ -246,53 +259,73 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                     }
                     if (k0 + FGP_CK < vec_len) fetch(k0 + FGP_CK);
                     wave_lds_fence();
-                    if (on) {
-                        // Twelve steps per iteration in three groups of four: the operands of a group are requested two
-                        // groups ahead of its FMAs so that the LDS latency overlaps the dependent chain.  One asm block with
-                        // its own s_waitcnt: the compiler would merge the loads into ds_read2_b64, which moves half the bytes
-                        // per LDS cycle of ds_read_b64 (128 against 256 B/clk), and this loop is LDS-bound.
+                    if (on && P.debug != 101) {
+                        // The chain.  Step j of lag l needs d[j] * d[j - l]; lane p = l + 1 reads x_p = d[j + 1 - p] from LDS on
+                        // EVEN steps only: on the odd step that follows, what it needs, d[j + 2 - p], is what lane p - 1 just
+                        // read, and comes over with a DPP row shift (two 32-bit moves) -- the helper lane 0 reads the sample
+                        // one ahead for that.  The d[j] operand of a step is lane 1's value, broadcast inside the FMA
+                        // (row_newbcast:1).  That halves the LDS reads, which bound this kernel (ds_read_b64, 2 LDS cycles a
+                        // wave-instruction; the compiler's ds_read2_b64 would take 4 per value).  Groups of eight steps (four
+                        // reads), requested two groups ahead of their FMAs; one asm block with its own s_waitcnt.
                         // (Reads past the chunk stay inside the row and are not used.)
-#define FG_FMAC4(h) asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
-                        "v_fmac_f64_dpp %0, %2, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
-                        "v_fmac_f64_dpp %0, %3, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"            \
-                        "v_fmac_f64_dpp %0, %4, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf"                 \
-                        : "+v"(acc) : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]))
-#define FG_F4(x) "v_fmac_f64_dpp %[acc], %[" #x "0], %[" #x "0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_fmac_f64_dpp %[acc], %[" #x "1], %[" #x "1] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_fmac_f64_dpp %[acc], %[" #x "2], %[" #x "2] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_fmac_f64_dpp %[acc], %[" #x "3], %[" #x "3] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-#define FG_L4(x, o) "ds_read_b64 %[" #x "0], %[ad] offset:" #o "\n\tds_read_b64 %[" #x "1], %[ad] offset:" #o "+8\n\t" \
-                    "ds_read_b64 %[" #x "2], %[ad] offset:" #o "+16\n\tds_read_b64 %[" #x "3], %[ad] offset:" #o "+24\n\t"
-                        double ha[4], hb[4], hc[4];
+#define FG_L4(x, o) "ds_read_b64 %[" #x "0], %[ad] offset:" #o "\n\tds_read_b64 %[" #x "1], %[ad] offset:" #o "+16\n\t" \
+                    "ds_read_b64 %[" #x "2], %[ad] offset:" #o "+32\n\tds_read_b64 %[" #x "3], %[ad] offset:" #o "+48\n\t"
+                        // (the y pairs are declared as four doubles whose halves the moves write one by one)
+                        double ha[4], hb[4], hc[4], ya = 0.0, yb = 0.0, yc = 0.0, yd = 0.0;
                         uint32_t ad = (uint32_t)(size_t)hist;
                         uint32_t j = 0;
-                        asm volatile(FG_L4(a, 0) FG_L4(b, 32)
+                        asm volatile(FG_L4(a, 0) FG_L4(b, 64)
                                      : [a0] "=&v"(ha[0]), [a1] "=&v"(ha[1]), [a2] "=&v"(ha[2]), [a3] "=&v"(ha[3]),
                                        [b0] "=&v"(hb[0]), [b1] "=&v"(hb[1]), [b2] "=&v"(hb[2]), [b3] "=&v"(hb[3])
                                      : [ad] "v"(ad));
                         hc[0] = hc[1] = hc[2] = hc[3] = 0.0;
-                        for (; j + 12 <= kn; j += 12) {
-                            asm volatile(FG_L4(c, 64) "s_waitcnt lgkmcnt(8)\n\t" FG_F4(a)
-                                         FG_L4(a, 96) "s_waitcnt lgkmcnt(8)\n\t" FG_F4(b)
-                                         FG_L4(b, 128) "s_waitcnt lgkmcnt(8)\n\t" FG_F4(c)
-                                         "v_add_u32 %[ad], 0x60, %[ad]"
-                                         : [acc] "+v"(acc), [ad] "+v"(ad),
-                                           [a0] "+v"(ha[0]), [a1] "+v"(ha[1]), [a2] "+v"(ha[2]), [a3] "+v"(ha[3]),
-                                           [b0] "+v"(hb[0]), [b1] "+v"(hb[1]), [b2] "+v"(hb[2]), [b3] "+v"(hb[3]),
-                                           [c0] "+v"(hc[0]), [c1] "+v"(hc[1]), [c2] "+v"(hc[2]), [c3] "+v"(hc[3]));
+#define FG_YOPS [ya] "+v"(ya), [yb] "+v"(yb), [yc] "+v"(yc), [yd] "+v"(yd)
+#define FG_G8C(h) do { \
+        uint32_t y0_, y1_, y2_, y3_, y4_, y5_, y6_, y7_; \
+        asm volatile("v_mov_b32_dpp %[y0], %[l0] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y1], %[h0] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_mov_b32_dpp %[y2], %[l1] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y3], %[h1] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_mov_b32_dpp %[y4], %[l2] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y5], %[h2] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_mov_b32_dpp %[y6], %[l3] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y7], %[h3] row_shr:1 row_mask:0xf bank_mask:0xf" \
+                     : [y0] "=&v"(y0_), [y1] "=&v"(y1_), [y2] "=&v"(y2_), [y3] "=&v"(y3_), [y4] "=&v"(y4_), [y5] "=&v"(y5_), [y6] "=&v"(y6_), [y7] "=&v"(y7_) \
+                     : [l0] "v"(__double2loint(h[0])), [h0] "v"(__double2hiint(h[0])), [l1] "v"(__double2loint(h[1])), [h1] "v"(__double2hiint(h[1])), \
+                       [l2] "v"(__double2loint(h[2])), [h2] "v"(__double2hiint(h[2])), [l3] "v"(__double2loint(h[3])), [h3] "v"(__double2hiint(h[3]))); \
+        const double ya_ = __hiloint2double((int)y1_, (int)y0_), yb_ = __hiloint2double((int)y3_, (int)y2_); \
+        const double yc_ = __hiloint2double((int)y5_, (int)y4_), yd_ = __hiloint2double((int)y7_, (int)y6_); \
+        asm volatile("v_fmac_f64_dpp %[acc], %[x0], %[x0] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[ya], %[ya] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[x1], %[x1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[yb], %[yb] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[x2], %[x2] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[yc], %[yc] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[x3], %[x3] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp %[acc], %[yd], %[yd] row_newbcast:1 row_mask:0xf bank_mask:0xf" \
+                     : [acc] "+v"(acc) : [x0] "v"(h[0]), [x1] "v"(h[1]), [x2] "v"(h[2]), [x3] "v"(h[3]), [ya] "v"(ya_), [yb] "v"(yb_), [yc] "v"(yc_), [yd] "v"(yd_)); \
+    } while (0)
+                        (void)ya; (void)yb; (void)yc; (void)yd;
+                        for (; j + 24 <= kn; j += 24) {
+                            asm volatile(FG_L4(c, 128) "s_waitcnt lgkmcnt(8)" : [c0] "=&v"(hc[0]), [c1] "=&v"(hc[1]), [c2] "=&v"(hc[2]), [c3] "=&v"(hc[3]),
+                                         "+v"(ha[0]), "+v"(ha[1]), "+v"(ha[2]), "+v"(ha[3]) : [ad] "v"(ad));
+                            FG_G8C(ha);
+                            asm volatile(FG_L4(a, 192) "s_waitcnt lgkmcnt(8)" : [a0] "=&v"(ha[0]), [a1] "=&v"(ha[1]), [a2] "=&v"(ha[2]), [a3] "=&v"(ha[3]),
+                                         "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]) : [ad] "v"(ad));
+                            FG_G8C(hb);
+                            asm volatile(FG_L4(b, 256) "s_waitcnt lgkmcnt(8)" : [b0] "=&v"(hb[0]), [b1] "=&v"(hb[1]), [b2] "=&v"(hb[2]), [b3] "=&v"(hb[3]),
+                                         "+v"(hc[0]), "+v"(hc[1]), "+v"(hc[2]), "+v"(hc[3]) : [ad] "v"(ad));
+                            FG_G8C(hc);
+                            ad += 192;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ha[0]), "+v"(ha[1]), "+v"(ha[2]), "+v"(ha[3]), "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]));
-                        if (j + 4 <= kn) { FG_FMAC4(ha); j += 4; if (j + 4 <= kn) { FG_FMAC4(hb); j += 4; } }
+                        if (j + 8 <= kn) { FG_G8C(ha); j += 8; if (j + 8 <= kn) { FG_G8C(hb); j += 8; } }
                         for (; j < kn; j++) {
                             const double h0 = hist[j];
-                            asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
+                            asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
                         }
-#undef FG_FMAC4
-#undef FG_F4
+#undef FG_G8C
+#undef FG_YOPS
 #undef FG_L4
                     }
                     wave_lds_fence();
-                    if (k0 + kn < vec_len) {
+                    if (k0 + kn < vec_len && P.debug != 103) {
                         double t[(NC * FGP_DH + 63) / 64];
 #pragma unroll
                         for (int u = 0; u < (NC * FGP_DH + 63) / 64; u++) {
@@ -308,7 +341,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                         wave_lds_fence();
                     }
                 }
-                if (on) autoc[(cl * P.nvec + nv) * (MAXO + 1) + l] = acc;
+                if (on && pl >= 1) autoc[(cl * P.nvec + nv) * (MAXO + 1) + l] = acc;
                 wave_lds_fence();
             }
             else if (punch) {
@@ -1135,7 +1168,7 @@ FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
 }
 
 template <bool MS, int NCH, int MAXO, bool ACC64, int WS>
-__global__ void __launch_bounds__(NCH * WS * 64, 4)
+__global__ void __launch_bounds__(NCH * WS * 64, 5)
 fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
                     uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
 {
