@@ -167,7 +167,9 @@ def main():
     def step():
         nonlocal out, offs, dec
         out, offs, est = ctx.encode(s, pcm, stream_lengths=lengths, out=out, offsets=offs)
-        dec, status, dst = ctx.decode(out, offs, ch, bps, nsamp, out=dec)       # the frame index stays in HBM
+        # decode from the bytes alone: the frame index is rebuilt on the GPU inside the timed region (the number of frames is
+        # what STREAMINFO tells a decoder: total samples / block size)
+        dec, status, dst = ctx.decode_stream(out[:est.total_bytes], ch, bps, nsamp, nframes=est.nblocks, out=dec)
         return est, dst, status
 
     for _ in range(args.warmup):

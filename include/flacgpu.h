@@ -553,6 +553,7 @@ typedef struct {
     uint32_t channels, bits_per_sample, sample_rate, max_blocksize;
     float decode_kernel_ms;
     float total_gpu_ms;
+    float index_ms;               /* flacgpu_decode_stream_dev: HIP-event time of the frame index pass (part of total_gpu_ms) */
 } flacgpu_decode_stats;
 
 /* Decode the audio frames of one FLAC stream held in device memory.  d_stream/len: the frame data (device);
@@ -567,6 +568,17 @@ int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, 
 int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *d_frame_offsets,
                               uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
                               uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
+
+/* Decode from the bytes alone: the frame index is made on the device (one pass over the stream: sync code, header
+ * fields, header CRC-8; every header found is filed under its frame number -- format.h:418-475), then the frames are decoded
+ * as above and their CRC-16 checked.  d_stream/len: the audio frames of ONE fixed-block-size stream (what follows the
+ * metadata blocks).  nframes_hint: the number of frames when known (STREAMINFO: ceil(total_samples / blocksize)), 0 to have
+ * them counted (one more pass and a host round trip).  first_frame_number: number of the first frame (0 for a whole
+ * stream).  d_frame_offsets_out (optional, device, nframes+1 uint64) receives the index.  Streams this does not cover
+ * (variable block size, two headers claiming one frame number) fail with a message; flacgpu_index_frames handles them. */
+int flacgpu_decode_stream_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, uint32_t nframes_hint, uint64_t first_frame_number,
+                              uint32_t channels, uint32_t bits_per_sample, void *d_pcm, uint64_t pcm_capacity_samples,
+                              void *h_frame_status, void *d_frame_offsets_out, flacgpu_decode_stats *stats);
 
 /* FLAC__stream_encoder_process_interleaved for 16-bit interleaved input (an extension beside the libFLAC entry point,
  * stream_encoder.h:1777-1824: same buffering, same return value): saves the caller the widening copy to FLAC__int32. */

@@ -65,7 +65,8 @@ class EncodeStats(C.Structure):
 class DecodeStats(C.Structure):
     _fields_ = [('nframes', C.c_uint32), ('error_frames', C.c_uint32), ('total_samples', C.c_uint64),
                 ('channels', C.c_uint32), ('bits_per_sample', C.c_uint32), ('sample_rate', C.c_uint32),
-                ('max_blocksize', C.c_uint32), ('decode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float)]
+                ('max_blocksize', C.c_uint32), ('decode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float),
+                ('index_ms', C.c_float)]
 
 
 ENC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
@@ -106,7 +107,8 @@ DATA_SYMBOLS = ['FLAC__StreamEncoderStateString', 'FLAC__StreamEncoderInitStatus
 EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu_ctx_create', 'flacgpu_ctx_destroy',
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
-                 'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16']
+                 'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev',
+                 'flacgpu_set_stage_timing']
 
 _lib = None
 
@@ -185,6 +187,11 @@ def lib():
     L.flacgpu_decode_frames.restype = C.c_int
     L.flacgpu_decode_frames_dev.argtypes = L.flacgpu_decode_frames.argtypes
     L.flacgpu_decode_frames_dev.restype = C.c_int
+    L.flacgpu_decode_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp,
+                                            C.POINTER(DecodeStats)]
+    L.flacgpu_decode_stream_dev.restype = C.c_int
+    L.flacgpu_set_stage_timing.argtypes = [vp, C.c_int]
+    L.flacgpu_set_stage_timing.restype = None
     L.flacgpu_stream_encoder_process_interleaved_i16.argtypes = [vp, vp, C.c_uint32]
     L.flacgpu_stream_encoder_process_interleaved_i16.restype = C.c_int
     L.flacgpu_index_frames.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(StreamInfo), C.POINTER(C.c_uint64)]

@@ -79,6 +79,7 @@ class Context:
             offsets = torch.empty(nb.value + 1, dtype=torch.int64, device=pcm.device)
         L.flacgpu_set_debug(self._h, 1 if debug else 0)
         st = _lib.EncodeStats()
+        torch.cuda.current_stream(pcm.device).synchronize()      # the library works on its own HIP streams: the input must be complete
         rc = L.flacgpu_encode_streams(self._h, C.byref(s), pcm.data_ptr(), 1 if is16 else 0, descs, len(stream_lengths),
                                       out.data_ptr(), out.numel(), offsets.data_ptr(), C.byref(st))
         if rc != 0:
@@ -115,12 +116,35 @@ class Context:
             out = torch.empty((max(int(max_samples), 1), channels), dtype=torch.int32, device=stream.device)
         status = np.zeros((max(nframes, 1), 2), np.uint32)
         st = _lib.DecodeStats()
+        torch.cuda.current_stream(stream.device).synchronize()
         fn = L.flacgpu_decode_frames_dev if on_dev else L.flacgpu_decode_frames
         rc = fn(self._h, stream.data_ptr(), stream.numel(), frame_offsets.data_ptr() if on_dev else offs.ctypes.data, nframes,
                 channels, bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, C.byref(st))
         if rc != 0:
             raise FlacGpuError(_lib.last_error())
         return out[:st.total_samples], status[:nframes], st
+
+
+    def decode_stream(self, stream, channels, bits_per_sample, max_samples, nframes=0, first_frame_number=0, out=None, offsets_out=None):
+        """Decode the audio frames of one fixed-block-size stream from its bytes alone (device uint8 tensor): the frame
+        index is made on the GPU.  ``nframes``: frames the stream holds when known (STREAMINFO), 0 = count them.
+
+        Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
+        """
+        L = _lib.lib()
+        assert stream.is_cuda and stream.dtype == torch.uint8 and stream.is_contiguous()
+        torch.cuda.current_stream(stream.device).synchronize()      # the library works on its own HIP streams
+        if out is None or out.numel() < max_samples * channels:
+            out = torch.empty((max(int(max_samples), 1), channels), dtype=torch.int32, device=stream.device)
+        cap = int(nframes) if nframes else max(stream.numel() // 16 + 16, 64)
+        status = np.zeros((max(cap, 1), 2), np.uint32)
+        st = _lib.DecodeStats()
+        rc = L.flacgpu_decode_stream_dev(self._h, stream.data_ptr(), stream.numel(), int(nframes), int(first_frame_number), channels,
+                                         bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data,
+                                         offsets_out.data_ptr() if offsets_out is not None else None, C.byref(st))
+        if rc != 0:
+            raise FlacGpuError(_lib.last_error())
+        return out[:st.total_samples], status[:st.nframes], st
 
 
 def index_frames(data):

@@ -39,6 +39,9 @@ int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockRes
 int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
                           uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
                           unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream);
+int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
+                        uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
+                        hipStream_t stream);
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
@@ -80,7 +83,7 @@ struct flacgpu_ctx {
     bool stage_timing = false;
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_prof, dec_redo, pipe;
+        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, pipe;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`
     const void *dev_descs_ptr = nullptr;
     std::vector<float> h_windows;

@@ -435,6 +435,120 @@ fg_dec_headers_kernel(const uint8_t *stream, const u64 *offsets, uint32_t nframe
     results[f].crc = 0;
 }
 
+// ---------------------------------------------------------------- frame index from the bytes alone
+// One pass over the stream, 16 bytes per lane.  A position is a frame start candidate when it carries the sync code
+// 0xFFF8 (fixed block size: the only kind libFLAC writes), a header whose fields are legal (format.h:418-462), whose
+// channel count and sample size are the stream's, and whose CRC-8 is right.  The header also carries the frame NUMBER, and
+// that decides where the offset goes: offsets[number - first_number].  No ordering pass, no compaction -- and the few false
+// candidates a compressed stream contains by chance (about 2^-31 of all positions pass the tests above) carry a random
+// 31-bit number, which falls outside the table; one that lands inside it collides with the true frame of that number and
+// is counted in info[1] (the host then falls back to its serial indexer).  Frames whose slot stays empty show up as
+// malformed in the header pass; the CRC-16 pass of the decoder checks every frame that was found.
+// info[0]: candidates seen (count mode only: nframes == 0, nothing is filed), info[1]: unresolved collisions, info[2]: candidates with the
+// variable-block-size sync code 0xFFF9 (their number is a sample number; not handled here), info[3]: highest slot filled + 1.
+__device__ __forceinline__ bool fg_idx_header(const uint8_t *p, u64 avail, uint32_t want_channels, uint32_t want_bps, u64 *number, uint32_t *variable)
+{
+    if (avail < 6 || p[0] != 0xFF || (p[1] & 0xFE) != 0xF8) return false;
+    const uint32_t bsc = p[2] >> 4, src = p[2] & 15, cac = p[3] >> 4, bpc = (p[3] >> 1) & 7;
+    if (bsc == 0 || src == 15 || cac > 10 || bpc == 3 || (p[3] & 1)) return false;
+    const uint32_t BP[8] = {0, 8, 12, 0, 16, 20, 24, 32};
+    const uint32_t ch = cac < 8 ? cac + 1 : 2;
+    if (want_channels && ch != want_channels) return false;
+    if (want_bps && bpc && BP[bpc] != want_bps) return false;
+    uint32_t pos = 4;
+    const uint32_t x = p[pos++];
+    uint32_t extra;
+    u64 v;
+    if (!(x & 0x80)) { extra = 0; v = x; }
+    else if ((x & 0xE0) == 0xC0) { extra = 1; v = x & 0x1F; }
+    else if ((x & 0xF0) == 0xE0) { extra = 2; v = x & 0x0F; }
+    else if ((x & 0xF8) == 0xF0) { extra = 3; v = x & 0x07; }
+    else if ((x & 0xFC) == 0xF8) { extra = 4; v = x & 0x03; }
+    else if ((x & 0xFE) == 0xFC) { extra = 5; v = x & 0x01; }
+    else if (x == 0xFE) { extra = 6; v = 0; }
+    else return false;
+    if (pos + extra + 1 > avail) return false;
+    for (uint32_t i = 0; i < extra; i++) { const uint32_t c = p[pos++]; if ((c & 0xC0) != 0x80) return false; v = (v << 6) | (c & 0x3F); }
+    if (bsc == 6) pos += 1; else if (bsc == 7) pos += 2;
+    if (src == 12) pos += 1; else if (src == 13 || src == 14) pos += 2;
+    if (pos + 1 > avail) return false;
+    uint32_t c8 = 0;
+    for (uint32_t i = 0; i < pos; i++) {
+        c8 ^= p[i];
+        for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
+    }
+    if (c8 != p[pos]) return false;
+    *number = v; *variable = p[1] & 1;
+    return true;
+}
+
+__global__ void __launch_bounds__(256)
+fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t bps, u64 first_number, uint32_t nframes, u64 *offsets,
+                    unsigned long long *info, u64 *alt)
+{
+    // groups of 16 bytes aligned in memory (one 16-byte load per lane and step); a wave walks the stream in steps of
+    // gridDim.x * 4 KiB (launching one short-lived wave per KiB would be bound by the dispatch rate, not by HBM)
+    const uintptr_t sa = (uintptr_t)stream;
+    const u64 mis = (u64)(sa & 15);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nframes != 0) offsets[nframes] = len;      // the end of the last frame
+    for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g * 16 < mis + len + 16 * 64; g += (u64)gridDim.x * 256) {
+    const u64 gstart = g * 16;                        // offset of the group relative to the aligned base (stream - mis)
+    const uint8_t *gp = stream - mis + gstart;
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    if (gstart >= mis && gstart + 16 <= mis + len) {
+        const uint4 v = *(const uint4 *)gp;
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    }
+    else {
+        for (uint32_t i = 0; i < 16; i++) {
+            const u64 o = gstart + i;
+            if (o >= mis && o < mis + len) w[i >> 2] |= (uint32_t)gp[i] << (8 * (i & 3));
+        }
+    }
+    // the byte behind the group: the next lane's first byte (the last lane of a wave loads it)
+    {
+        const uint32_t nxt = (uint32_t)__shfl_down((int)w[0], 1);
+        w[4] = nxt;
+        if ((threadIdx.x & 63) == 63) w[4] = (gstart + 16 < mis + len) ? gp[16] : 0;
+    }
+    // sync code = a 0xFF byte followed by 0xF8 / 0xF9: bytes equal to 0xFF whose successor has its top five bits set and
+    // bit 1 and 2 clear (SWAR over the four words and their one-byte-shifted neighbours; 1 group in 2000 gets past this)
+    uint32_t hit = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t a = w[k], b = (w[k] >> 8) | (w[k + 1] << 24);           // b = the successor of every byte of a
+        const uint32_t x = ~a, isff = (x - 0x01010101u) & ~x & 0x80808080u;    // 0x80 in every byte of a that is 0xFF (exact: no borrow passes a 0xFF byte... checked below)
+        const uint32_t y = (b & 0xFEFEFEFEu) ^ 0xF8F8F8F8u, isf8 = (y - 0x01010101u) & ~y & 0x80808080u;
+        hit |= isff & isf8;
+    }
+    if (!hit) continue;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t b0 = (w[i >> 2] >> (8 * (i & 3))) & 0xFF, b1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFF;
+        if (b0 != 0xFF || (b1 & 0xFE) != 0xF8) continue;
+        const u64 o = gstart + i;
+        if (o < mis || o + 1 >= mis + len) continue;
+        const u64 pos = o - mis;
+        u64 number;
+        uint32_t variable;
+        if (!fg_idx_header(stream + pos, len - pos, channels, bps, &number, &variable)) continue;
+        // (thousands of atomics on one address take longer than the whole pass over the bytes: the candidates are only
+        // counted when that is what the call is for)
+        if (nframes == 0) atomicAdd(&info[0], 1ull);
+        if (variable) { atomicAdd(&info[2], 1ull); continue; }
+        if (nframes == 0 || number < first_number) continue;
+        const u64 slot = number - first_number;
+        if (slot >= nframes) continue;
+        // first claim of a slot goes into the table, a second one beside it (fg_dec_index_resolve_kernel picks), a third fails
+        const unsigned long long old = atomicCAS((unsigned long long *)&offsets[slot], ~0ull, (unsigned long long)pos);
+        if (old != ~0ull && old != pos) {
+            const unsigned long long old2 = atomicCAS((unsigned long long *)&alt[slot], ~0ull, (unsigned long long)pos);
+            if (old2 != ~0ull && old2 != pos) atomicAdd(&info[1], 1ull);
+        }
+    }
+    }
+}
+
 // Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.  Frames that would
 // end past `cap` samples are rejected here (bytes = 0), so the decode kernels can be queued before the host has seen the
 // total: it finds totals[0] > cap afterwards and reports the short buffer.
@@ -493,6 +607,49 @@ extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned lon
     hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, d_offsets, nframes,
                        si_channels, si_bps, d_frames, d_results);
     hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
+    return (int)hipGetLastError();
+}
+
+// A compressed stream holds, by chance, a few byte sequences that pass for a frame header (roughly one per 300 MB for 16-bit
+// stereo), and their one- or two-byte frame number usually names an existing frame.  Frames lie in the stream in the order
+// of their numbers, so of two claims for slot k the true one is the one between the positions of frames k-1 and k+1.
+__global__ void __launch_bounds__(256)
+fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 len, unsigned long long *info)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    // info[3] = highest slot filled + 1 (one atomic per wave)
+    {
+        uint32_t top = (k < nframes && offsets[k] != ~(u64)0) ? k + 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)top, o); top = t > top ? t : top; }
+        if ((threadIdx.x & 63) == 0 && top) atomicMax(&info[3], (unsigned long long)top);
+    }
+    if (k >= nframes) return;
+    const u64 b = alt[k];
+    if (b == ~(u64)0) return;
+    const u64 a = offsets[k];
+    // neighbours with a single claim (a run of contested slots is not resolved here)
+    const bool pv = k == 0 || alt[k - 1] == ~(u64)0, nx = k + 1 >= nframes || alt[k + 1] == ~(u64)0;
+    const u64 lo = k == 0 ? 0 : offsets[k - 1], hi = k + 1 >= nframes ? len : offsets[k + 1];
+    if (!pv || !nx || (k > 0 && lo == ~(u64)0) || hi == ~(u64)0) { atomicAdd(&info[1], 1ull); return; }
+    const bool aok = (k == 0 || a > lo) && a < hi, bok = (k == 0 || b > lo) && b < hi;
+    if (aok == bok) { atomicAdd(&info[1], 1ull); return; }
+    if (bok) offsets[k] = b;
+}
+
+extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
+                                   uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
+                                   hipStream_t stream)
+{
+    if (len == 0) return 0;
+    const unsigned long long groups = (len + 15 + 15) / 16;
+    unsigned long long wgs = (groups + 255) / 256;
+    if (wgs > 2048) wgs = 2048;                     // 8 workgroups of 4 waves per CU: every wave slot of the chip, once
+    hipLaunchKernelGGL(fg_dec_index_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_stream, (u64)len, channels, bps,
+                       (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt);
+    if (nframes)
+        hipLaunchKernelGGL(fg_dec_index_resolve_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (const u64 *)d_alt,
+                           nframes, (u64)len, d_info);
     return (int)hipGetLastError();
 }
 

@@ -321,14 +321,46 @@ extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uin
 }
 
 // ------------------------------------------------------------------ batch decode of device-resident frames
+// h_offsets == nullptr: the frame index is made on the device from the bytes (fg_dec_index_kernel); nframes is then the
+// number of frames the stream is known to hold (STREAMINFO: total samples / block size), or 0 to have them counted first.
 static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
                                uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
                                FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
-                               bool offsets_on_device = false)
+                               bool offsets_on_device = false, uint64_t first_number = 0, uint64_t *d_offsets_out = nullptr)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     memset(st, 0, sizeof *st);
     if (!HIPOK(hipSetDevice(c->device))) { fg_set_error("hipSetDevice failed"); return false; }
+    const bool index_here = h_offsets == nullptr;
+    if (index_here && len != 0) {
+        if (!c->ensure_pinned_res(64)) return false;
+        unsigned long long *hinfo = (unsigned long long *)c->h_res;
+        if (!c->dec_info.ensure(64)) return false;
+        unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
+        if (nframes == 0) {
+            // count the candidates (an upper bound of the frames; false candidates are a handful), then see which slots fill
+            if (!HIPOK(hipMemsetAsync(d_info, 0, 32, c->stream)) ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, c->stream) != 0 ||
+                !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+                fg_set_error("frame index kernel failed"); return false;
+            }
+            if (hinfo[2]) { fg_set_error("variable block size stream: use flacgpu_index_frames"); return false; }
+            if (hinfo[0] > 0x7FFFFFFFull) { fg_set_error("too many frames"); return false; }
+            const uint32_t bound = (uint32_t)hinfo[0];
+            if (bound == 0) { st->nframes = 0; return true; }
+            if (!c->offsets.ensure(((size_t)bound + 4) * 8)) return false;
+            if (!c->dec_info.ensure(64 + (size_t)bound * 8)) return false;
+            d_info = (unsigned long long *)c->dec_info.p;
+            if (!HIPOK(hipMemsetAsync(c->offsets.p, 0xFF, ((size_t)bound + 1) * 8, c->stream)) || !HIPOK(hipMemsetAsync(d_info, 0, 32, c->stream)) ||
+                !HIPOK(hipMemsetAsync(d_info + 8, 0xFF, (size_t)bound * 8, c->stream)) ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, c->stream) != 0 ||
+                !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+                fg_set_error("frame index kernel failed"); return false;
+            }
+            nframes = (uint32_t)hinfo[3];
+            if (nframes == 0) { st->nframes = 0; return true; }
+        }
+    }
     st->nframes = nframes;
     if (nframes == 0) return true;
     if (channels_hint == 0) { fg_set_error("channel count required"); return false; }
@@ -338,8 +370,22 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         return false;
     unsigned long long *d_off = (unsigned long long *)c->offsets.p;
     unsigned long long *d_tot = d_off + nframes + 1;
-    if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
     if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
+    if (index_here) {
+        // one pass over the bytes: every frame header found puts its position into the slot of its frame number
+        if (!c->dec_info.ensure(64 + (size_t)nframes * 8)) return false;
+        unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
+        if (!HIPOK(hipMemsetAsync(d_off, 0xFF, ((size_t)nframes + 1) * 8, c->stream)) || !HIPOK(hipMemsetAsync(d_info, 0, 32, c->stream)) ||
+            !HIPOK(hipMemsetAsync(d_info + 8, 0xFF, (size_t)nframes * 8, c->stream)) ||
+            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, c->stream) != 0) {
+            fg_set_error("frame index kernel launch failed"); return false;
+        }
+        // (the end of the last frame: set by the kernel; a count-mode call may have found fewer frames than slots)
+        if (!HIPOK(hipMemcpyAsync(d_off + nframes, &len, 8, hipMemcpyHostToDevice, c->stream))) return false;
+        if (d_offsets_out && !HIPOK(hipMemcpyAsync(d_offsets_out, d_off, ((size_t)nframes + 1) * 8, hipMemcpyDeviceToDevice, c->stream))) return false;
+        (void)hipEventRecord(c->ev[3], c->stream);
+    }
+    else if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
     if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                               (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
     if (!c->ensure_pinned_res(64 + (size_t)nframes * sizeof(FgDecResult))) return false;
@@ -392,7 +438,14 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         h_frames->resize(nframes);
         if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
     }
+    unsigned long long *hinfo2 = (unsigned long long *)((char *)c->h_res + 32);
+    if (index_here && !HIPOK(hipMemcpyAsync(hinfo2, c->dec_info.p, 32, hipMemcpyDeviceToHost, c->stream))) return false;
     if (!HIPOK(fg_stream_wait(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    if (index_here) {
+        (void)hipEventElapsedTime(&st->index_ms, c->ev[0], c->ev[3]);
+        if (hinfo2[2]) { fg_set_error("variable block size stream: use flacgpu_index_frames"); return false; }
+        if (hinfo2[1]) { fg_set_error("ambiguous frame sync (several headers claim one frame number and their order does not decide): use flacgpu_index_frames"); return false; }
+    }
     st->total_samples = tot[0];
     st->max_blocksize = (uint32_t)tot[1];
     if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
@@ -446,6 +499,18 @@ extern "C" int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream,
     if (!ctx) { fg_set_error("null context"); return -1; }
     return decode_frames_impl(ctx, d_stream, len, d_frame_offsets, nframes, channels_hint, bps_hint, d_pcm, pcm_capacity_samples, 1,
                               (FgDecResult *)h_frame_status, nullptr, stats, true) ? 0 : -1;
+}
+
+extern "C" int flacgpu_decode_stream_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, uint32_t nframes_hint, uint64_t first_frame_number,
+                                         uint32_t channels, uint32_t bps, void *d_pcm, uint64_t pcm_capacity_samples, void *h_frame_status,
+                                         void *d_frame_offsets_out, flacgpu_decode_stats *stats)
+{
+    flacgpu_decode_stats local;
+    if (!stats) stats = &local;
+    if (!ctx) { fg_set_error("null context"); return -1; }
+    if (channels == 0) { fg_set_error("channel count required"); return -1; }
+    return decode_frames_impl(ctx, d_stream, len, nullptr, nframes_hint, channels, bps, d_pcm, pcm_capacity_samples, 1,
+                              (FgDecResult *)h_frame_status, nullptr, stats, true, first_frame_number, (uint64_t *)d_frame_offsets_out) ? 0 : -1;
 }
 
 extern "C" int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *h_frame_offsets,

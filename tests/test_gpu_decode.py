@@ -115,3 +115,65 @@ def test_handmade_streams(ctx, name, handmade_streams):
     assert np.array_equal(got.cpu().numpy().reshape(pcm.shape), pcm)
     res = abi_decode.decode(data)
     assert not res['errors'] and np.array_equal(np.concatenate(res['blocks']).reshape(pcm.shape), pcm)
+
+
+# ---------------------------------------------------------------------------------------------- frame index on the GPU
+def _decode_from_bytes(ctx, data, nframes_known):
+    """flacgpu_decode_stream_dev: the audio frames go to the device as bytes, nothing else."""
+    import torch
+    from pyflac_amd import batch
+    offs, si = batch.index_frames(data)            # host index: only to locate the audio and as the expected answer
+    audio = data[int(offs[0]):]
+    buf = torch.frombuffer(bytearray(audio) + bytearray(64), dtype=torch.uint8).cuda()[:len(audio)]
+    nfr = len(offs) - 1
+    got_offs = torch.zeros(nfr + 1, dtype=torch.int64, device='cuda')
+    pcm, status, st = ctx.decode_stream(buf, si.channels, si.bits_per_sample, nfr * max(si.max_blocksize, 16),
+                                        nframes=nfr if nframes_known else 0, offsets_out=got_offs if nframes_known else None)
+    return pcm.cpu().numpy(), status, st, got_offs.cpu().numpy(), offs - offs[0]
+
+
+@pytest.mark.parametrize('known', [True, False])
+@pytest.mark.parametrize('name', ['mono', 'stereo', 'surround', '32bit'])
+def test_gpu_frame_index_reference_fixtures(ctx, name, known):
+    """The index made on the GPU from the bytes equals the host indexer's, and the decode that follows is the oracle's PCM."""
+    from oracle import oracle as O
+    with open(os.path.join(cases.GOLDEN, 'data', name + '.flac'), 'rb') as f:
+        data = f.read()
+    want, _res = O.decode_stream(data)
+    got, status, st, goffs, hoffs = _decode_from_bytes(ctx, data, known)
+    assert st.nframes == len(hoffs) - 1
+    if known:
+        assert np.array_equal(goffs.astype(np.uint64), hoffs.astype(np.uint64))
+    assert int(status[:, 0].max()) == 0
+    assert np.array_equal(got, want)
+
+
+def test_gpu_frame_index_golden_streams(ctx):
+    """Every golden stream of the encoder corpus (all levels, 8..32 bit, odd block sizes, tails) indexes and decodes from
+    its bytes alone."""
+    from oracle import oracle as O
+    sm = np.load(os.path.join(cases.GOLDEN, 'small_streams.npz'))
+    n = 0
+    for key in sm.files:
+        data = sm[key].tobytes()
+        want, _res = O.decode_stream(data)
+        got, status, st, goffs, hoffs = _decode_from_bytes(ctx, data, True)
+        assert np.array_equal(goffs.astype(np.uint64), hoffs.astype(np.uint64)), key
+        assert int(status[:, 0].max()) == 0, key
+        assert np.array_equal(got, want), key
+        n += 1
+    assert n > 0
+
+
+def test_gpu_frame_index_reports_duplicate_frame_numbers(ctx):
+    """Two headers that claim the same frame number cannot be filed: the call fails loudly (the host indexer handles it)."""
+    import torch
+    from pyflac_amd import batch
+    with open(os.path.join(cases.GOLDEN, 'data', 'stereo.flac'), 'rb') as f:
+        data = f.read()
+    offs, si = batch.index_frames(data)
+    a, b = int(offs[1]), int(offs[2])
+    audio = data[int(offs[0]):b] + data[a:]          # frame 1 twice
+    buf = torch.frombuffer(bytearray(audio) + bytearray(64), dtype=torch.uint8).cuda()[:len(audio)]
+    with pytest.raises(batch.FlacGpuError, match='ambiguous'):
+        ctx.decode_stream(buf, si.channels, si.bits_per_sample, len(offs) * si.max_blocksize, nframes=len(offs) - 1)
