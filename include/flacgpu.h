@@ -523,8 +523,12 @@ typedef struct {
     float total_gpu_ms;           /* HIP-event time of the whole enqueue (encode + frame assembly) */
     uint32_t last_channel_assignment;  /* loose mid-side: assignment (0 independent / 3 mid-side) of the last frame of the last stream */
     uint32_t redo_blocks;         /* blocks the specialised kernels handed to the generic kernel */
-    float stage_ms[8];            /* with flacgpu_set_stage_timing(ctx, 1): autocorrelation, Levinson-Durbin, evaluation, packing,
-                                     sizes + scan, assembly + CRC-16 (HIP events between the kernels); else zeros */
+    float stage_ms[8];            /* with flacgpu_set_stage_timing(ctx, 1): analysis, packing, sizes + scan, assembly + CRC-16
+                                     (HIP events between the kernel groups); else zeros */
+    uint32_t log_guard_subframes; /* LPC order guesses that were within the guard threshold of a tie and were re-done with the
+                                     correctly rounded logarithm (see flacgpu_set_log_guard) */
+    uint32_t reserved0;
+    double lpc_order_min_margin;  /* smallest distance (bits) between the best and the second-best order estimate in this call */
 } flacgpu_encode_stats;
 
 /* Encode every block of every stream.  d_pcm: device address of interleaved PCM (int32, or int16 when
@@ -542,6 +546,13 @@ uint64_t flacgpu_encode_bound(const flacgpu_settings *settings, const flacgpu_st
 /* Debug: per-block analysis records of the last flacgpu_encode_streams call made with
  * flacgpu_set_debug(ctx, 1).  Layout: FgDebugRec (pyflac_amd/csrc/fg_types.h). */
 void flacgpu_set_debug(flacgpu_ctx *ctx, int on);
+/* libFLAC picks the LPC order by comparing estimates that contain log(); the device's log and glibc's may differ in the last
+ * bit, which can only matter when two orders are within ~1e-10 bits of each other.  Estimates closer than `threshold_bits`
+ * (default 1e-6) are re-done with a correctly rounded logarithm and counted in flacgpu_encode_stats.log_guard_subframes. */
+void flacgpu_set_log_guard(flacgpu_ctx *ctx, double threshold_bits);
+/* Window self-check: empty string, or a note that this host's cosf produced a tukey taper different from the committed one
+ * (the committed one is then used; the note is also left in flacgpu_last_error() when it happens). */
+const char *flacgpu_window_note(flacgpu_ctx *ctx);
 void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int on);   /* fill flacgpu_encode_stats.stage_ms (adds event records between the kernels) */
 int flacgpu_copy_debug(flacgpu_ctx *ctx, void *host_dst, uint32_t first_block, uint32_t nblocks);
 int flacgpu_copy_block_results(flacgpu_ctx *ctx, void *host_dst, uint32_t nblocks);

@@ -59,7 +59,8 @@ class StreamDesc(C.Structure):
 class EncodeStats(C.Structure):
     _fields_ = [('nblocks', C.c_uint32), ('error_flags', C.c_uint32), ('total_bytes', C.c_uint64),
                 ('encode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float),
-                ('last_channel_assignment', C.c_uint32), ('redo_blocks', C.c_uint32), ('stage_ms', C.c_float * 8)]
+                ('last_channel_assignment', C.c_uint32), ('redo_blocks', C.c_uint32), ('stage_ms', C.c_float * 8),
+                ('log_guard_subframes', C.c_uint32), ('reserved0', C.c_uint32), ('lpc_order_min_margin', C.c_double)]
 
 
 class DecodeStats(C.Structure):
@@ -108,7 +109,7 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev',
-                 'flacgpu_set_stage_timing']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note']
 
 _lib = None
 
@@ -191,6 +192,10 @@ def lib():
                                             C.POINTER(DecodeStats)]
     L.flacgpu_decode_stream_dev.restype = C.c_int
     L.flacgpu_set_stage_timing.argtypes = [vp, C.c_int]
+    L.flacgpu_set_log_guard.argtypes = [vp, C.c_double]
+    L.flacgpu_set_log_guard.restype = None
+    L.flacgpu_window_note.argtypes = [vp]
+    L.flacgpu_window_note.restype = C.c_char_p
     L.flacgpu_set_stage_timing.restype = None
     L.flacgpu_stream_encoder_process_interleaved_i16.argtypes = [vp, vp, C.c_uint32]
     L.flacgpu_stream_encoder_process_interleaved_i16.restype = C.c_int

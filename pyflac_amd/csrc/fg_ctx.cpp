@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "fg_host.h"
+#include "fg_window_tables.inc"
 
 static thread_local std::string g_err;
 void fg_set_error(const std::string &msg) { g_err = msg; }
@@ -87,6 +88,27 @@ uint32_t flacgpu_ctx::window_offset(uint32_t n, uint32_t parts)
     h_windows.resize(h_windows.size() + ((n + 3) & ~3u));
     const float p = parts >= 2 ? 0.5f / (float)(int32_t)parts : 0.5f;
     fg_tukey_window(h_windows.data() + e.off, (int32_t)n, p);
+    // Self-check (hard part 1): the tapers come from this host's cosf, as they do in libFLAC, so a C library
+    // whose cosf rounds differently would change encoder output silently.  The tapers of the preset shapes at the default
+    // block size are committed (fg_window_tables.inc, the build container's glibc): a host that disagrees gets the committed
+    // values and a note in flacgpu_last_error() / flacgpu_window_note().
+    if (n == 4096 && parts <= 3) {
+        const uint32_t *ref = parts >= 3 ? FG_TUKEY4096_P16 : parts == 2 ? FG_TUKEY4096_P25 : FG_TUKEY4096_P50;
+        const uint32_t np = parts >= 3 ? FG_TUKEY4096_P16_NP : parts == 2 ? FG_TUKEY4096_P25_NP : FG_TUKEY4096_P50_NP;
+        float *w = h_windows.data() + e.off;
+        bool differs = getenv("FLACGPU_WINDOW_SELFTEST") != nullptr;      // (test hook: pretend the host's cosf disagrees)
+        if (differs) for (uint32_t i = 0; i <= np; i++) { w[i] = 0.25f; w[n - np - 1 + i] = 0.25f; }
+        for (uint32_t i = 0; i <= np && !differs; i++) {
+            uint32_t a, b;
+            memcpy(&a, &w[i], 4); memcpy(&b, &w[n - np - 1 + i], 4);
+            if (a != ref[i] || b != ref[np + 1 + i]) differs = true;
+        }
+        if (differs) {
+            for (uint32_t i = 0; i <= np; i++) { memcpy(&w[i], &ref[i], 4); memcpy(&w[n - np - 1 + i], &ref[np + 1 + i], 4); }
+            window_note = "tukey window: this host's cosf differs from the committed table (glibc 2.35); the committed table is used";
+            fg_set_error(window_note);
+        }
+    }
     win_index.push_back(e);
     windows_dirty = true;
     return e.off;
@@ -283,7 +305,9 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 }
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
+extern "C" const char *flacgpu_window_note(flacgpu_ctx *ctx) { return ctx->window_note.c_str(); }
 extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int on) { ctx->stage_timing = on != 0; }
+extern "C" void flacgpu_set_log_guard(flacgpu_ctx *ctx, double thr) { ctx->log_guard_thr = thr; }
 
 extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
 {
@@ -339,6 +363,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     const uint32_t nblocks = (uint32_t)descs.size();
     memset(st, 0, sizeof *st);
     st->nblocks = nblocks;
+    st->lpc_order_min_margin = INFINITY;        // (no LPC order guess looked at yet)
     if (nblocks == 0) return true;
     if (s->max_lpc_order == 0 && c->h_windows.empty()) c->window_offset(16, 0);
     if (!c->sync_windows()) return false;
@@ -374,6 +399,10 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (use_pipe) {
         if (!c->pipe.ensure(fg_pipe_scratch_bytes(&P, nblocks))) return false;
         fg_pipe_carve(&P, nblocks, c->pipe.p, &PL.B);
+        // near-tie guard of the LPC order guess: count, smallest margin (as the bits of a positive double)
+        static const unsigned long long guard0[2] = {0ull, 0x7FF0000000000000ull};
+        HIPCHK(hipMemcpyAsync(PL.B.guard, guard0, 16, hipMemcpyHostToDevice, c->stream));
+        PL.guard_thr = c->log_guard_thr;
     }
     FgDebugRec *dbg = nullptr;
     if (c->debug) {
@@ -546,6 +575,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         if (d_offsets && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
         tail[0] = tail[1] = 0;
         if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+        if (use_pipe && hipMemcpyAsync(tail + 2, PL.B.guard, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
         if (hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
         return fg_stream_wait(c->stream) == hipSuccess;
     };
@@ -575,6 +605,11 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     st->total_bytes = tail[0];
     st->error_flags = (uint32_t)tail[1] & ~FG_ERR_REDO;
+    if (use_pipe) {
+        st->log_guard_subframes = (uint32_t)tail[2];
+        double mm; memcpy(&mm, &tail[3], 8);
+        st->lpc_order_min_margin = mm;
+    }
     c->last_nblocks = nblocks;
     if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
     HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));

@@ -81,6 +81,7 @@ struct flacgpu_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing
     bool stage_timing = false;
+    double log_guard_thr = 1e-6;
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
         dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, pipe;
@@ -89,6 +90,7 @@ struct flacgpu_ctx {
     std::vector<float> h_windows;
     std::vector<WindowEntry> win_index;
     bool windows_dirty = false;
+    std::string window_note;      // set when the window self-check replaced a table (see window_offset)
     bool debug = false;
     uint32_t last_nblocks = 0;
     // pinned staging for the stream (callback) API

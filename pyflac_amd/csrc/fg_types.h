@@ -88,6 +88,7 @@ struct FgPipeBufs {
     uint32_t *lres;        // [block][cand][nvec]                                K3 -> K4
     FgPipeDec *dec;        // [block][cand]                                      K4 -> K5
     uint32_t *chunk_bits;  // [block][4]                                         K5 -> sizes, K6
+    unsigned long long *guard;   // [0] order guesses re-done with the exact log, [1] smallest margin seen (double bits)
 };
 
 struct FgPipeLaunch {
@@ -105,6 +106,7 @@ struct FgPipeLaunch {
     uint32_t nblocks_ws2;       // the first nblocks_ws2 blocks are packed by two waves per subframe, the rest by one
     uint32_t acc64;             // > 16 bit samples
     uint32_t stages;            // bit 0: analysis (K2-K4), bit 1: pack (K5)
+    double guard_thr;           // order guesses closer than this many bits are re-done with the correctly rounded log
     void *stream;               // hipStream_t
     void *stream2;              // side stream for the (few) blocks packed by one wave per subframe; events to fork and join
     void *ev_fork, *ev_join;

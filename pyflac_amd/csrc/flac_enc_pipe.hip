@@ -42,6 +42,7 @@ size_t fg_pipe_scratch_bytes(const FgEncParams *P, uint32_t nblocks)
     add((size_t)nblocks * NC * P->nvec * 4);
     add((size_t)nblocks * NC * sizeof(FgPipeDec));
     add((size_t)nblocks * 4 * 4);
+    add(64);
     return b;
 }
 
@@ -57,6 +58,7 @@ void fg_pipe_carve(const FgEncParams *P, uint32_t nblocks, void *base, FgPipeBuf
     B->lres = (uint32_t *)take((size_t)nblocks * NC * P->nvec * 4);
     B->dec = (FgPipeDec *)take((size_t)nblocks * NC * sizeof(FgPipeDec));
     B->chunk_bits = (uint32_t *)take((size_t)nblocks * 4 * 4);
+    B->guard = (unsigned long long *)take(64);
 }
 
 // Returns 0 on success, -1 when no specialisation covers the configuration.

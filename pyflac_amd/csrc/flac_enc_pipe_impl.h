@@ -395,12 +395,75 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     }
 }
 
+// ---- correctly rounded log for the near-ties of the order guess (double-double arithmetic; rare path)
+// libFLAC picks the LPC order by comparing bits = 0.5 * log(scale * err) / ln 2 * (n - o) + o * overhead across orders with a
+// strict <.  glibc's log and the device's differ in the last bit now and then, which can only matter when two orders come
+// out within ~1e-10 bits of each other; such lanes repeat the comparison with a log that is exact to 2^-100 and rounded
+// once (what glibc returns in all but its documented 0.02-ulp band around rounding boundaries).
+struct pdd { double hi, lo; };
+FGI pdd pdd_sum(double a, double b) { const double s = a + b, bb = s - a; pdd r; r.hi = s; r.lo = (a - (s - bb)) + (b - bb); return r; }
+FGI pdd pdd_add(pdd x, pdd y)
+{
+    pdd s = pdd_sum(x.hi, y.hi);
+    s.lo += x.lo + y.lo;
+    return pdd_sum(s.hi, s.lo);
+}
+FGI pdd pdd_mul(pdd x, pdd y)
+{
+    const double p = x.hi * y.hi;
+    double e = fma(x.hi, y.hi, -p);
+    e += x.hi * y.lo + x.lo * y.hi;
+    return pdd_sum(p, e);
+}
+FGI pdd pdd_div(pdd x, pdd y)
+{
+    const double q1 = x.hi / y.hi;
+    // r = x - q1 * y
+    const double p = q1 * y.hi;
+    const double e = fma(q1, y.hi, -p);
+    const double r = ((x.hi - p) - e) + x.lo - q1 * y.lo;
+    const double q2 = r / y.hi;
+    return pdd_sum(q1, q2);
+}
+FGI double plog_cr(double x)       // x > 0, finite
+{
+    int k;
+    double m = frexp(x, &k);                         // m in [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; k--; }      // m in [1/sqrt 2, sqrt 2)
+    pdd one; one.hi = 1.0; one.lo = 0.0;
+    const pdd num = pdd_sum(m, -1.0), den = pdd_sum(m, 1.0);
+    const pdd sv = pdd_div(num, den);
+    const pdd s2 = pdd_mul(sv, sv);
+    // sum_{j=0}^{21} s2^j / (2j + 1), Horner from the top
+    pdd t; t.hi = 1.0 / 43.0; t.lo = fma(-t.hi, 43.0, 1.0) / 43.0;
+    for (int j = 20; j >= 0; j--) {
+        pdd c; const double dd = (double)(2 * j + 1);
+        c.hi = 1.0 / dd; c.lo = fma(-c.hi, dd, 1.0) / dd;
+        t = pdd_add(pdd_mul(t, s2), c);
+    }
+    pdd lm = pdd_mul(sv, t);
+    lm.hi *= 2.0; lm.lo *= 2.0;
+    pdd ln2; ln2.hi = 0.6931471805599453094; ln2.lo = 2.3190468138462996e-17;
+    pdd kk; kk.hi = (double)k; kk.lo = 0.0;
+    const pdd r = pdd_add(pdd_mul(kk, ln2), lm);
+    return r.hi + r.lo;
+}
+FGI double p_ebps_cr(double e, double scale)
+{
+    if (e > 0.0) {
+        const double bb = 0.5 * plog_cr(scale * e) / FG_LN2;
+        return bb >= 0.0 ? bb : 0.0;
+    }
+    else if (e < 0.0) return 1e32;
+    return 0.0;
+}
+
 // ================================================================================================ K3: Levinson-Durbin, order guess, quantiser
 // lane = (block, candidate, vector).  lres = order | prec<<8 | (shift&255)<<16 | ok<<24 | ran<<25.  Same operations in the
 // same order as lpc.c (the file is compiled with -ffp-contract=off), so the same doubles.
 template <int MAXO>
 __global__ void __launch_bounds__(64)
-fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint32_t nblocks, uint32_t NC, uint32_t ms)
+fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint32_t nblocks, uint32_t NC, uint32_t ms, double guard_thr)
 {
     const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
     const uint32_t per = NC * P.nvec;
@@ -425,8 +488,9 @@ fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, u
     const double scale = 0.5 / (double)n;
     double er = a0, bestb = 4294967295.0;
     double lp[MAXO], keep[MAXO], err2 = a0;
+    double erv[MAXO], bitsv[MAXO];              // error after each order and its bit estimate (for the near-tie guard)
 #pragma unroll
-    for (int j = 0; j < MAXO; j++) { lp[j] = 0.0; keep[j] = 0.0; }
+    for (int j = 0; j < MAXO; j++) { lp[j] = 0.0; keep[j] = 0.0; erv[j] = 0.0; bitsv[j] = -1.0; }
     uint32_t besti = 0;
     bool stopped = false, have = false;
 #pragma unroll
@@ -449,6 +513,7 @@ fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, u
             if (!stopped) {
                 const uint32_t o = i + 1;
                 const double bits = p_ebps(er, scale) * (double)(n - o) + (double)(o * overhead);
+                erv[i] = er; bitsv[i] = bits;
                 if (bits < bestb) { besti = i; bestb = bits; better = true; }
                 if (er == 0.0) stopped = true;
             }
@@ -459,6 +524,55 @@ fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, u
                     err2 = er;
                 }
                 have = true;
+            }
+        }
+    }
+    // ---- near-tie guard of the order guess (see plog_cr): margin = distance of the runner-up from the winner
+    if (on) {
+        double margin = 1e300;
+#pragma unroll
+        for (int i = 0; i < MAXO; i++)
+            if ((uint32_t)i != besti && bitsv[i] >= 0.0) { const double dm = bitsv[i] - bestb; margin = dm < margin ? dm : margin; }
+        if (margin < 1e300 && B.guard) atomicMin(&B.guard[1], (unsigned long long)__double_as_longlong(margin < 0.0 ? 0.0 : margin));
+        if (margin < guard_thr) {
+            if (B.guard) atomicAdd(&B.guard[0], 1ull);
+            double bb2 = 4294967295.0;
+            uint32_t b2 = 0;
+#pragma unroll
+            for (int i = 0; i < MAXO; i++) {
+                if (bitsv[i] >= 0.0) {
+                    const uint32_t o = i + 1;
+                    const double bits = p_ebps_cr(erv[i], scale) * (double)(n - o) + (double)(o * overhead);
+                    if (bits < bb2) { b2 = i; bb2 = bits; }
+                }
+            }
+            if (b2 != besti) {
+                // the exact comparison picks another order: its coefficient set comes from running the recursion again
+                besti = b2;
+                double er_ = a0;
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) lp[j] = 0.0;
+#pragma unroll
+                for (int i = 0; i < MAXO; i++) {
+                    if ((uint32_t)i <= besti && (uint32_t)i < mo) {
+                        double r = -A[i + 1];
+#pragma unroll
+                        for (int j = 0; j < i; j++) r -= lp[j] * A[i - j];
+                        r /= er_;
+                        lp[i] = r;
+#pragma unroll
+                        for (int j = 0; j < (i >> 1); j++) {
+                            const double tmp = lp[j], t2 = lp[i - 1 - j];
+                            lp[j] = tmp + r * t2;
+                            lp[i - 1 - j] = t2 + r * tmp;
+                        }
+                        if (i & 1) { const double t = lp[i >> 1]; lp[i >> 1] = t + t * r; }
+                        er_ *= (1.0 - r * r);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) keep[j] = (uint32_t)j <= besti ? lp[j] : 0.0;
+                err2 = er_;
             }
         }
     }

@@ -456,6 +456,34 @@ class TestRandomChunking:
         assert enc.finish()
         assert b''.join(chunks) == want, (seed, ch, bps, bs, level, n, len(cuts))
 
+    @pytest.mark.parametrize('level', [1, 4])
+    @pytest.mark.parametrize('seed', range(3))
+    def test_loose_mid_side_any_chunking(self, level, seed):
+        """Levels 1 and 4 decide the channel assignment on every `period`-th frame of the STREAM and copy it in between
+        (stream_encoder.h:826-838): the phase follows the absolute frame number and the decision is carried from one
+        process() call to the next, so the bytes do not depend on how the caller cuts the input."""
+        import pyflac_amd
+        from oracle import oracle as O
+        r = np.random.default_rng(900 + 10 * level + seed)
+        bs = int(r.choice([576, 1152, 4096]))
+        n = int(r.integers(20 * bs, 45 * bs))
+        t = np.arange(n)
+        # left/right correlation that changes along the stream, so that both assignments occur
+        l = 9000 * np.sin(t * 0.013) + r.integers(-200, 200, n)
+        w = 0.5 + 0.5 * np.sin(t * 2 * np.pi / (7.3 * bs))
+        rr = w * l + (1 - w) * (7000 * np.sin(t * 0.031 + 1.0)) + r.integers(-200, 200, n)
+        pcm = np.stack([l, rr], axis=1).astype(np.int16)
+        cfg, rc = O.config(level, 2, 16, 44100, bs, True)
+        assert rc == 0
+        want, _ = O.encode_stream(cfg, pcm.astype(np.int32))
+        cuts = [0] + sorted(set(int(x) for x in r.integers(0, n + 1, int(r.integers(3, 25))))) + [n]
+        chunks = []
+        enc = pyflac_amd.StreamEncoder(44100, lambda b, nb, s, f: chunks.append(b), compression_level=level, blocksize=bs)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            enc.process(pcm[a:b])
+        assert enc.finish()
+        assert b''.join(chunks) == want, (level, seed, bs, n, cuts)
+
     @pytest.mark.parametrize('seed', range(4))
     def test_decoder_any_chunking(self, seed):
         """The same for the decoder: the stream arrives in pieces of 1 byte to 100 KB (frames, headers and the metadata cut
@@ -477,3 +505,30 @@ class TestRandomChunking:
         dec.finish()
         got = np.concatenate(blocks)
         assert np.array_equal(got.astype(np.int64), want.astype(np.int64))
+
+
+def test_encode_after_decode_redo_on_one_context():
+    """a decode whose frames go through the generic decoder (predictor order > 12 here) used to write its
+    redo list over the cached encoder block list; an encode of the same layout afterwards read frame numbers as block
+    descriptors.  Encode -> decode (with redo) -> encode the same layout: the bytes of both encodes are equal."""
+    import torch
+    from pyflac_amd import batch
+    ctx = batch.Context(0)
+    r = np.random.default_rng(77)
+    n = 4096 * 5
+    t = np.arange(n)
+    a = np.stack([6000 * np.sin(t * 0.02) + r.integers(-50, 50, n), 5000 * np.sin(t * 0.017) + r.integers(-50, 50, n)], axis=1).astype(np.int32)
+    pcm = torch.from_numpy(a).cuda()
+    s5 = batch.settings(5, 2, 16, 48000, 4096, True)
+    out1, offs1, st1 = ctx.encode(s5, pcm)
+    b1 = out1[:st1.total_bytes].cpu().numpy().tobytes()
+    # a stream whose frames need the generic decoder: max LPC order 32 (outside the subset)
+    s32 = batch.settings(8, 2, 16, 48000, 4096, False)
+    s32.max_lpc_order = 32
+    o32, f32, st32 = ctx.encode(s32, pcm)
+    dec, status, dst = ctx.decode(o32[:st32.total_bytes].clone(), f32.clone(), 2, 16, n)
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec[:n], pcm)
+    out2, offs2, st2 = ctx.encode(s5, pcm)
+    assert out2[:st2.total_bytes].cpu().numpy().tobytes() == b1
+    dec2, status2, _ = ctx.decode(out2[:st2.total_bytes], offs2, 2, 16, n)
+    assert int(status2[:, 0].max()) == 0 and torch.equal(dec2[:n], pcm)

@@ -238,3 +238,107 @@ def test_full_size_round_trip_properties(ctx, seconds, level, kind):
     for b in np.linspace(0, st.nblocks - 2, 12).astype(int):
         want = O.encode_frame(cfg, arr[b * 4096:(b + 1) * 4096], int(b))
         assert body[int(offs_h[b]):int(offs_h[b + 1])] == want
+
+
+# ---------------------------------------------------------------------------------------------- round-2 additions
+def test_log_guard_forced_keeps_bytes_and_counts(golden):
+    """Near-tie guard of the LPC order guess (flacgpu_set_log_guard): with the threshold forced above every margin all order
+    guesses are repeated with the correctly rounded double-double logarithm -- the bytes must not change (the two logs agree
+    wherever the margin is comfortable) and the counter must move.  With the default threshold the counter stays at zero
+    exactly when the smallest margin seen is above it."""
+    import torch
+    from pyflac_amd import batch, _lib
+    c2 = batch.Context(0)
+    L = _lib.lib()
+    for name in ('cfg2_20s_l5', 'cfg4_10s_l8', 'noise16_st', 'sines24_l8_bs4608'):
+        spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
+        pcm, bps = cases.make_pcm(spec)
+        L.flacgpu_set_log_guard(c2._h, 1e30)
+        stream, _offs, _s = _gpu_stream(c2, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
+        assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256'], name
+        a = np.asarray(cases.as_int_array(pcm, bps))
+        s = batch.settings(level, a.shape[1], bps, sr, bs, subset)
+        t = torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).cuda()
+        _o, _f, st = c2.encode(s, t)
+        assert st.log_guard_subframes > 0, name
+        assert 0.0 <= st.lpc_order_min_margin < 1e30
+        L.flacgpu_set_log_guard(c2._h, 1e-6)
+        _o, _f, st = c2.encode(s, t)
+        assert (st.log_guard_subframes == 0) == (st.lpc_order_min_margin >= 1e-6), (name, st.log_guard_subframes, st.lpc_order_min_margin)
+
+
+def test_log_guard_margin_over_fuzz_corpus(ctx, fuzz_golden):
+    """Hunt for near-ties: the smallest margin between the two best LPC order estimates over the seeded fuzz corpus (the
+    cases the pipeline encodes).  Whenever it falls below the guard threshold the guard must have fired -- the bytes of
+    these cases are compared with the reference's in test_fuzz_corpus_matches_reference_hashes."""
+    import torch
+    from pyflac_amd import batch
+    from tests import fuzzgen
+    smallest, seen = float('inf'), 0
+    for seed in range(240):
+        g = fuzz_golden[str(seed)]
+        c = fuzzgen.case(seed)
+        if g['init_status'] or c['level'] < 3 or c['ch'] > 2 or c['bps'] > 24:
+            continue
+        s = batch.settings(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+        t = torch.from_numpy(np.ascontiguousarray(c['pcm'].astype(np.int32))).cuda()
+        _o, _f, st = ctx.encode(s, t)
+        if st.lpc_order_min_margin < 1e29:
+            seen += 1
+            smallest = min(smallest, st.lpc_order_min_margin)
+            assert (st.log_guard_subframes > 0) == (st.lpc_order_min_margin < 1e-6), seed
+    assert seen > 20
+    print('smallest LPC order margin over %d fuzz cases: %.3e bits' % (seen, smallest))
+
+
+def test_window_selfcheck(golden, monkeypatch):
+    """The tukey tapers of the preset shapes at block size 4096 are committed; a host whose cosf disagrees gets the committed
+    values and a note.  FLACGPU_WINDOW_SELFTEST corrupts the generated table first: the bytes must still be the golden ones."""
+    from pyflac_amd import batch, _lib
+    L = _lib.lib()
+    c1 = batch.Context(0)
+    for name in ('cfg2_20s_l5', 'cfg4_10s_l8'):
+        spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
+        pcm, bps = cases.make_pcm(spec)
+        stream, _o, _s = _gpu_stream(c1, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
+        assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256']
+    assert L.flacgpu_window_note(c1._h) == b'', 'this host\'s cosf disagrees with the committed window table'
+    monkeypatch.setenv('FLACGPU_WINDOW_SELFTEST', '1')
+    c2 = batch.Context(0)
+    for name in ('cfg2_20s_l5', 'cfg4_10s_l8'):
+        spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
+        pcm, bps = cases.make_pcm(spec)
+        stream, _o, _s = _gpu_stream(c2, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
+        assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256']
+    assert b'committed table is used' in L.flacgpu_window_note(c2._h)
+
+
+def test_round1_single_kernel_still_matches_golden(ctx, golden, monkeypatch):
+    """FLACGPU_PIPE=0 selects round 1's one-kernel-per-block encoder; same bytes."""
+    monkeypatch.setenv('FLACGPU_PIPE', '0')
+    for name in ('cfg2_20s_l5', 'wasted4_st', 'sines24_l8_bs4608', 'noise16_st'):
+        spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
+        pcm, bps = cases.make_pcm(spec)
+        stream, _o, _s = _gpu_stream(ctx, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
+        assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256'], name
+
+
+def test_wasted_bits_stay_in_the_pipeline(ctx):
+    """Blocks whose samples share trailing zero bits (16-bit audio in a 24-bit container) are encoded by the pipeline itself
+    (no hand-over to the generic kernel) and equal the oracle's bytes."""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    n = 4096 * 6
+    t_ = np.arange(n)
+    base = (8000 * np.sin(t_ * 0.01) + rng.integers(-300, 300, n)).astype(np.int64)
+    a = np.stack([base << 8, (base // 2 + 5) << 8], axis=1).astype(np.int32)     # 24-bit samples, 8 wasted bits
+    for level in (5, 8):
+        s = batch.settings(level, 2, 24, 96000, 4096, True)
+        cfg, _ = O.config(level, 2, 24, 96000, 4096, True)
+        out, offs, st = ctx.encode(s, torch.from_numpy(a).cuda())
+        assert st.redo_blocks == 0
+        want, _res = O.encode_stream(cfg, a)
+        body = out[:st.total_bytes].cpu().numpy().tobytes()
+        assert want.endswith(body) and len(body) > 0
