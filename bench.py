@@ -88,43 +88,77 @@ def cpu_baseline(pcm16, level, sr, budget_s=12.0):
                           'how': 'one oracle process per host core, about 3 s of encodes each, aggregate over the slowest worker'},
             'sample': '%.0f s of the same synthetic stream x%d encode / x%d decode passes, MD5 off, 1 thread; '
                       'oracle/flac_oracle.c is a scalar restatement of libFLAC 1.4.3 (the reference binary does not '
-                      'travel to the GPU box; it measured ~1.5x the oracle in the build container)' %
+                      'travel to the GPU box; reference_binary_ratio has what it measured against the oracle)' %
                       (a32.shape[0] / sr, reps, dreps),
             'wall_s': round(time.perf_counter() - t0, 1)}
 
 
-def pmc_traffic(args, est):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json, written by
-    tools/rocprof_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command); None when the file does
-    not describe this workload."""
+def committed_profile(name):
+    """A committed profile summary (profiles/<name>), or None."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fh:
-            t = json.load(fh)
-        if (args.workload == 'stream16' and t.get('blocks') == int(est.nblocks) and t.get('level') == args.level and
-                t.get('kernel') == 'fg_encode_fast_kernel'):
-            return int(t['traffic_bytes_per_launch'])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        with open(os.path.join(ROOT, 'profiles', name)) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+def api_e2e(seconds, sr):
+    """Drop-in API end to end on host buffers (PCIe, callbacks and MD5 included): numpy int16 -> StreamEncoder.process ->
+    write callbacks -> bytes -> StreamDecoder -> numpy blocks.  Never part of `value`."""
+    import pyflac_amd
+    from pyflac_amd import synth, _lib
+    pcm = synth.config2_stereo16(seconds, 0, sr)
+    out = {}
+    for md5 in (1, 0):
+        best_e = best_d = None
+        for _rep in range(2):
+            chunks = []
+            enc = pyflac_amd.StreamEncoder(sr, lambda b, n, s, f: chunks.append(b), compression_level=5, blocksize=4096)
+            if not md5:
+                _lib.lib().FLAC__stream_encoder_set_do_md5(enc._encoder, 0)
+            t0 = time.perf_counter()
+            enc.process(pcm)
+            enc.finish()
+            t1 = time.perf_counter()
+            stream = b''.join(chunks)
+            blocks = []
+            dec = pyflac_amd.StreamDecoder(lambda a, r, c, n: blocks.append(a))
+            t2 = time.perf_counter()
+            dec.process(stream)
+            dec.finish()
+            t3 = time.perf_counter()
+            best_e = t1 - t0 if best_e is None else min(best_e, t1 - t0)
+            best_d = t3 - t2 if best_d is None else min(best_d, t3 - t2)
+        assert sum(len(b) for b in blocks) == len(pcm)
+        out['md5_on' if md5 else 'md5_off'] = {'encode_msamples_per_s': round(pcm.size / best_e / 1e6, 1),
+                                               'decode_msamples_per_s': round(pcm.size / best_d / 1e6, 1)}
+    out['sample'] = '%.0f s stereo 16-bit numpy array through pyflac_amd.StreamEncoder / StreamDecoder, best of 2' % seconds
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--seconds', type=float, default=600.0, help='length of the stream each GPU encodes')
-    ap.add_argument('--level', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=300, help='timed steps (default: about half a second of work)')
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--seconds', type=float, default=None, help='length of each stream (default 600; 60 for --workload batch)')
+    ap.add_argument('--level', type=int, default=None, help='compression level (default 5; 8 for --workload stream24)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch'], default='stream16',
-                    help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz (use --level 8); '
-                         'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
+    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted'], default='stream16',
+                    help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz level 8; '
+                         'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each); '
+                         'wasted: the stream16 signal in a 24-bit container (8 wasted bits in every block)')
     ap.add_argument('--streams', type=int, default=128, help='streams per GPU for --workload batch')
     args = ap.parse_args()
+    if args.seconds is None:
+        args.seconds = 60.0 if args.workload == 'batch' else 600.0
+    if args.level is None:
+        args.level = 8 if args.workload == 'stream24' else 5
 
     import torch
     import torch.distributed as dist
-    from pyflac_amd import batch, synth
+    from pyflac_amd import batch, shard, synth
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -141,9 +175,15 @@ def main():
     if args.workload == 'stream24':
         sr, bps = 96000, 24
         pcm16 = synth.config4_stereo24(args.seconds, 1 + rank, sr)          # int32 container, 24-bit values
+    elif args.workload == 'wasted':
+        bps = 24
+        pcm16 = synth.config2_stereo16(args.seconds, rank, sr).astype(np.int32) << 8
     elif args.workload == 'batch':
-        # configs[4]: the rank's share of the 1024-stream batch, concatenated in HBM, every stream its own frame numbering
-        per = [synth.config5_stream(rank * args.streams + i, args.seconds, sr) for i in range(args.streams)]
+        # configs[4]: this rank's share of the world * streams batch -- stream s runs on rank s mod world
+        # (pyflac_amd.shard.streams_for_rank, the mapping batch.MultiContext uses inside one process) -- concatenated in HBM,
+        # every stream with its own frame numbering, all of them in ONE launch
+        mine = shard.streams_for_rank(world * args.streams, rank, world)
+        per = [synth.config5_stream(sidx, args.seconds, sr) for sidx in mine]
         lengths = [len(x) for x in per]
         pcm16 = np.concatenate(per)
     else:
@@ -155,21 +195,25 @@ def main():
     s = batch.settings(args.level, ch, bps, sr, bs, True)
 
     # the only shared datum: the 86-byte stream header, broadcast from rank 0 (RCCL over xGMI)
-    hdr = torch.zeros(86, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        from pyflac_amd.encoder import stream_header_bytes
-        hdr.copy_(torch.frombuffer(bytearray(stream_header_bytes(s)), dtype=torch.uint8))
+    from pyflac_amd.encoder import stream_header_bytes
+    hdr = stream_header_bytes(s) if rank == 0 else b''
     if world > 1:
-        dist.broadcast(hdr, 0)
+        hdr = shard.broadcast_header(hdr, dev)
+    assert len(hdr) == 86
 
     out = offs = dec = None
+    single = lengths is None
 
     def step():
         nonlocal out, offs, dec
         out, offs, est = ctx.encode(s, pcm, stream_lengths=lengths, out=out, offsets=offs)
-        # decode from the bytes alone: the frame index is rebuilt on the GPU inside the timed region (the number of frames is
-        # what STREAMINFO tells a decoder: total samples / block size)
-        dec, status, dst = ctx.decode_stream(out[:est.total_bytes], ch, bps, nsamp, nframes=est.nblocks, out=dec)
+        if single:
+            # decode from the bytes alone: the frame index is rebuilt on the GPU inside the timed region (the number of
+            # frames is what STREAMINFO tells a decoder: total samples / block size)
+            dec, status, dst = ctx.decode_stream(out[:est.total_bytes], ch, bps, nsamp, nframes=est.nblocks, out=dec)
+        else:
+            # many streams back to back: every stream restarts its frame numbers, so the index is the encoder's (in HBM)
+            dec, status, dst = ctx.decode(out, offs, ch, bps, nsamp, out=dec)
         return est, dst, status
 
     for _ in range(args.warmup):
@@ -177,8 +221,6 @@ def main():
     # bit-exactness gate (outside the timed region): the round trip equals the input
     assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
     assert torch.equal(dec[:nsamp], pcm), 'round trip is not bit-exact'
-    # (the comparison of the encoded frames with the CPU oracle's is part of the cpu_baseline leg below: the oracle is only
-    # touched there)
     h_chk = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
         nchk = min(nsamp, 40 * bs) // bs * bs
@@ -188,13 +230,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    enc_ms = dec_ms = 0.0
+    enc_ms = dec_ms = enc_tot = dec_tot = idx_ms = 0.0
     total_bytes = 0
+    per_step = []
+    tl = t0
     for _ in range(args.steps):
         est, dst, status = step()
         enc_ms += est.encode_kernel_ms
+        enc_tot += est.total_gpu_ms
         dec_ms += dst.decode_kernel_ms
+        dec_tot += dst.total_gpu_ms
+        idx_ms += dst.index_ms
         total_bytes = est.total_bytes
+        tn = time.perf_counter()          # (every library call is synchronous: no extra synchronisation inside the timed region)
+        per_step.append(tn - tl)
+        tl = tn
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,33 +256,86 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     chsamples = nsamp * ch                                   # per rank per step
     value = chsamples * world / (ms_per_step * 1e-3) / 1e6
-    enc_k = enc_ms / args.steps
-    dec_k = dec_ms / args.steps
-    alg_bytes = chsamples * 4 + total_bytes                   # read int32 PCM once + write the frames once
-    achieved = alg_bytes / (enc_k * 1e-3) / 1e9
+    K = args.steps
+    enc_k, dec_k, enc_t, dec_t = enc_ms / K, dec_ms / K, enc_tot / K, dec_tot / K
+    alg_bytes = chsamples * 4 + total_bytes                   # read int32 PCM once + write the frames once (and back for decode)
+
+    # stage times of the encoder (HIP events between its kernel groups): a few extra steps outside the timed region
+    from pyflac_amd import _lib
+    L = _lib.lib()
+    L.flacgpu_set_stage_timing(ctx._h, 1)
+    stage = np.zeros(4)
+    for _ in range(5):
+        e2, _d2, _s2 = step()
+        stage += np.array(list(e2.stage_ms)[:4])
+    stage /= 5
+    L.flacgpu_set_stage_timing(ctx._h, 0)
+
     if rank == 0:
+        ps = np.sort(np.array(per_step)) * 1e3
+        pmc = committed_profile('r02_pmc.json') or {}
+        same = pmc.get('workload') == args.workload and pmc.get('level') == args.level and pmc.get('blocks') == int(est.nblocks)
+        enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
+        dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
         res = {
             'metric': 'Msamples/s encode (level %d, %dkHz/%d-bit stereo, blk 4096) + decode; bit-exact' % (args.level, sr // 1000, bps),
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int32', 'data': 'synthetic',
-            'config': {'workload': '%s: %s encode then decode of its output, stereo %d-bit %d kHz, '
-                                   'blocksize 4096, level %d, %.0f s (%d blocks) per GPU, int32 PCM resident in HBM, '
-                                   'MD5 off (FLAC__stream_encoder_set_do_md5(0)); decoder uses the frame index the '
-                                   'encoder produced (device-resident)' %
-                                   ({'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]'}[args.workload],
-                                    'single-stream' if lengths is None else '%d independent streams in one launch,' % len(lengths),
-                                    bps, sr // 1000, args.level, args.seconds, est.nblocks),
-                       'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4)},
+            'config': {'workload': '%s: %s encode, then decode of its output from the bytes%s, stereo %d-bit %d kHz, blocksize 4096, '
+                                   'level %d, %.0f s%s (%d blocks) per GPU, int32 PCM resident in HBM, MD5 off '
+                                   '(FLAC__stream_encoder_set_do_md5(0))' %
+                                   ({'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]',
+                                     'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)'}[args.workload],
+                                    'single-stream' if single else '%d independent streams in one launch,' % len(lengths),
+                                    ' alone (frame index rebuilt on the GPU inside the timed region)' if single else
+                                    ' (frame index: the encoder\'s offsets, device-resident)',
+                                    bps, sr // 1000, args.level, args.seconds, '' if single else ' each', est.nblocks),
+                       'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4),
+                       'timed_s': round(dt, 3)},
+            'ms_per_step_min': round(float(ps[0]), 3), 'ms_per_step_median': round(float(ps[len(ps) // 2]), 3),
             'encode_kernel_msamples_per_s': round(chsamples / (enc_k * 1e-3) / 1e6, 1),
             'decode_kernel_msamples_per_s': round(chsamples / (dec_k * 1e-3) / 1e6, 1),
             'encode_kernel_ms': round(enc_k, 3), 'decode_kernel_ms': round(dec_k, 3),
-            'roofline': {'bound': 'hbm', 'kernel': 'fg_encode_fast_kernel', 'achieved': round(achieved, 2), 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': round(achieved / 8000.0, 5), 'traffic': pmc_traffic(args, est),
-                         'algorithmic_bytes_per_launch': int(alg_bytes)},
+            'encode_gpu_ms': round(enc_t, 3), 'decode_gpu_ms': round(dec_t, 3), 'decode_index_ms': round(idx_ms / K, 3),
+            'encode_stage_ms': {'analysis (autocorrelation, Levinson-Durbin, evaluation)': round(float(stage[0]), 3),
+                                'packing': round(float(stage[1]), 3), 'sizes + scan': round(float(stage[2]), 3),
+                                'assembly + CRC-16': round(float(stage[3]), 3)},
+            # the encoder is six kernels back to back (fg_pipe_autoc / levinson / eval / pack, sizes + scan, fg_pipe_assemble):
+            # one encode = PCM read once, frames written once; time = HIP events around all of them on the library's stream.
+            # The per-kernel durations are in profiles/r02_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command).
+            'roofline': {'bound': 'hbm', 'kernel': 'encode pipeline (fg_pipe_autoc_kernel .. fg_pipe_assemble_kernel; dominant: '
+                                                   'fg_pipe_autoc_kernel)',
+                         'achieved': round(enc_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(enc_ach / 8000.0, 5),
+                         'traffic': pmc.get('encode_traffic_bytes_per_launch') if same else None,
+                         'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(enc_t, 4)},
+            'roofline_decode': {'bound': 'hbm', 'kernel': 'decode (fg_dec_index / headers / scan / rice + crc / restore; dominant: '
+                                                          'fg_dec_rice_kernel)',
+                                'achieved': round(dec_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(dec_ach / 8000.0, 5),
+                                'traffic': pmc.get('decode_traffic_bytes_per_launch') if same else None,
+                                'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(dec_t, 4)},
         }
+        if same and pmc.get('encode_valu_insts_per_launch'):
+            # the ceiling these integer kernels actually run against: VALU issue (one wave-instruction per 2 cycles and SIMD,
+            # fp64 4 cycles), 1024 SIMDs at 2.4 GHz; instruction counts from the committed PMC pass of this same command
+            slots = 1024 * 2.4e9 / 2
+            res['issue_ceiling'] = {'unit': 'VALU wave-instructions/s', 'peak': slots,
+                                    'encode_valu_insts_per_launch': pmc['encode_valu_insts_per_launch'],
+                                    'encode_frac': round(pmc['encode_valu_insts_per_launch'] / (enc_t * 1e-3) / slots, 4),
+                                    'decode_valu_insts_per_launch': pmc.get('decode_valu_insts_per_launch'),
+                                    'decode_frac': (round(pmc['decode_valu_insts_per_launch'] / (dec_t * 1e-3) / slots, 4)
+                                                    if pmc.get('decode_valu_insts_per_launch') else None),
+                                    'source': 'profiles/r02_pmc.json'}
+        if world == 1 and not args.no_e2e and args.workload == 'stream16':
+            res['api_e2e'] = api_e2e(min(args.seconds, 600.0), sr)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
             res['cpu_baseline'] = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), args.level, 48000)
+            ratio = committed_profile('r02_cpu_ref_ratio.json')
+            if ratio:
+                res['cpu_baseline']['reference_binary_ratio'] = {
+                    'encode': ratio['reference_over_oracle_encode'], 'decode': ratio['reference_over_oracle_decode'],
+                    'reference_encode_msamples_per_s_build_container': ratio['reference_encode_msamples_per_s'],
+                    'measured_by': ratio['command'] + ' (build container; the binary does not travel): profiles/r02_cpu_ref_ratio.json'}
             # checker use of the same oracle: the first 40 frames the GPU wrote are the oracle's, byte for byte
             from oracle import oracle as O
             cfg, _ = O.config(args.level, ch, bps, sr, bs, True)

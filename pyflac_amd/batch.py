@@ -147,6 +147,50 @@ class Context:
         return out[:st.total_samples], status[:st.nframes], st
 
 
+class MultiContext:
+    """Single-process front end over several GPUs (BASELINE config 5: a batch of independent streams): stream s is encoded
+    on device s mod ndevices (pyflac_amd.shard.streams_for_rank), each device encodes its share in ONE launch, and the
+    frames come back in stream order.  No data-path collective: streams are independent.  With one process per GPU
+    (torch.distributed, bench.py --gpus N) the same mapping is used across ranks."""
+
+    def __init__(self, devices=None):
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
+        if not devices:
+            raise FlacGpuError('no GPU visible: pyflac_amd has no CPU fallback')
+        self.devices = list(devices)
+        self.contexts = [Context(d) for d in self.devices]
+
+    def close(self):
+        for c in self.contexts:
+            c.close()
+
+    def encode_streams(self, s, streams):
+        """``streams``: list of host arrays ([samples, channels] int16 / int32), one per stream.  Returns a list (stream
+        order) of ``(frames: bytes, frame_sizes: list[int])``."""
+        from . import shard
+
+        def make(ctx, dev):
+            def run(mine):
+                if not mine:
+                    return []
+                with torch.cuda.device(dev):
+                    host = np.concatenate([np.ascontiguousarray(x) for x in mine])
+                    pcm = torch.from_numpy(host).to('cuda:%d' % dev)
+                    out, offs, st = ctx.encode(s, pcm, stream_lengths=[len(x) for x in mine])
+                    h_out = out[:st.total_bytes].cpu().numpy().tobytes()
+                    h_offs = offs.cpu().numpy()
+                res, b = [], 0
+                for x in mine:
+                    nb = -(-len(x) // s.blocksize)
+                    lo, hi = int(h_offs[b]), int(h_offs[b + nb])
+                    res.append((h_out[lo:hi], [int(v) for v in np.diff(h_offs[b:b + nb + 1])]))
+                    b += nb
+                return res
+            return run
+        return shard.encode_sharded(list(streams), [make(c, d) for c, d in zip(self.contexts, self.devices)])
+
+
 def index_frames(data):
     """Host frame index of a complete FLAC stream (bytes).  Returns (offsets uint64[nframes+1], StreamInfo)."""
     L = _lib.lib()

@@ -42,3 +42,45 @@ def gather_frame_sizes(sizes, device):
     mn = min(int(o[0]) for o in out if int(o[2]) > 0) if any(int(o[2]) for o in out) else 0
     mx = max(int(o[1]) for o in out)
     return mn, mx, sum(int(o[2]) for o in out)
+
+
+def assemble_in_stream_order(nstreams, world, per_rank_results):
+    """Inverse of `streams_for_rank`: per_rank_results[r][i] is the result of the i-th stream of rank r (stream
+    r + i * world); returns the list of results in stream order ("outputs gathered by the host in
+    stream order")."""
+    out = [None] * nstreams
+    for r in range(world):
+        mine = streams_for_rank(nstreams, r, world)
+        assert len(per_rank_results[r]) == len(mine), (r, len(per_rank_results[r]), len(mine))
+        for i, sidx in enumerate(mine):
+            out[sidx] = per_rank_results[r][i]
+    assert all(o is not None for o in out)
+    return out
+
+
+def encode_sharded(streams, encoders):
+    """Encode `streams` (a list of per-stream inputs) on `len(encoders)` devices of this process: stream s goes to device
+    s mod world; encoders[r](list_of_streams) -> list of per-stream outputs, called concurrently (one thread per device; the
+    library calls release the GIL).  Returns the outputs in stream order.  pyflac_amd.batch.MultiContext passes one GPU
+    context per device; the CPU test passes stubs."""
+    import threading
+    world = len(encoders)
+    results = [None] * world
+    errors = [None] * world
+
+    def run(r):
+        try:
+            mine = streams_for_rank(len(streams), r, world)
+            results[r] = encoders[r]([streams[i] for i in mine])
+        except BaseException as e:     # noqa: BLE001 (re-raised in the caller's thread)
+            errors[r] = e
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return assemble_in_stream_order(len(streams), world, results)

@@ -26,7 +26,14 @@ def _worker(rank, world, port, q):
     mine = shard.streams_for_rank(1024, rank, world)
     rng = shard.block_range_for_rank(7032, rank, world)
     mn, mx, cnt = shard.gather_frame_sizes([100 + rank, 200 + rank], torch.device('cpu'))
-    q.put((rank, got, mine[:3], len(mine), rng, (mn, mx, cnt)))
+    # the config-5 mapping driven end to end with a stub encoder: every rank "encodes" its round-robin share, the shares are
+    # gathered (gloo) and put back into stream order exactly as bench.py / MultiContext do
+    nstreams = 11
+    stub = [('rank%d:stream%d' % (rank, sidx)) for sidx in shard.streams_for_rank(nstreams, rank, world)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, stub)
+    ordered = shard.assemble_in_stream_order(nstreams, world, gathered)
+    q.put((rank, got, mine[:3], len(mine), rng, (mn, mx, cnt), ordered))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,6 +54,8 @@ def test_world2_sharding_and_header_broadcast():
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3, 5] and res[0][3] == res[1][3] == 512
     assert res[0][4] == (0, 3516) and res[1][4] == (3516, 7032)
     assert res[0][5] == res[1][5] == (100, 201, 4)
+    want = ['rank%d:stream%d' % (sidx % 2, sidx) for sidx in range(11)]
+    assert res[0][6] == want and res[1][6] == want
 
 
 def test_partitions_cover_everything():
@@ -57,3 +66,31 @@ def test_partitions_cover_everything():
         edges = [shard.block_range_for_rank(7031, r, world) for r in range(world)]
         assert edges[0][0] == 0 and edges[-1][1] == 7031
         assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def test_encode_sharded_returns_stream_order():
+    """pyflac_amd.shard.encode_sharded (the engine of batch.MultiContext) with stub per-device encoders: stream s runs on
+    device s mod world, the devices run concurrently, results come back in stream order; an error on one device surfaces."""
+    import threading
+    import pytest
+    from pyflac_amd import shard
+    seen = {}
+    together = threading.Barrier(4)
+
+    def make(r, meet=False):
+        def run(mine):
+            if meet:
+                together.wait(timeout=30)          # only passes when the four devices run at the same time
+            seen[r] = list(mine)
+            return [('dev%d' % r, x) for x in mine]
+        return run
+    streams = ['s%d' % i for i in range(13)]
+    out = shard.encode_sharded(streams, [make(r, True) for r in range(4)])
+    assert out == [('dev%d' % (i % 4), 's%d' % i) for i in range(13)]
+    assert seen[1] == ['s1', 's5', 's9']
+    assert shard.encode_sharded(['a'], [make(0), make(1)]) == [('dev0', 'a')]
+
+    def bad(_mine):
+        raise RuntimeError('device lost')
+    with pytest.raises(RuntimeError, match='device lost'):
+        shard.encode_sharded(streams, [make(0), bad])

@@ -532,3 +532,26 @@ def test_encode_after_decode_redo_on_one_context():
     assert out2[:st2.total_bytes].cpu().numpy().tobytes() == b1
     dec2, status2, _ = ctx.decode(out2[:st2.total_bytes], offs2, 2, 16, n)
     assert int(status2[:, 0].max()) == 0 and torch.equal(dec2[:n], pcm)
+
+
+def test_multi_context_returns_streams_in_order():
+    """batch.MultiContext spreads streams over the devices it is given (two contexts on the one visible GPU here) with the
+    round-robin mapping of pyflac_amd.shard and returns every stream's frames in stream order: equal to encoding each
+    stream on its own."""
+    import torch
+    from pyflac_amd import batch
+    r = np.random.default_rng(3)
+    streams = []
+    for i in range(5):
+        n = int(r.integers(3000, 20000))
+        t = np.arange(n)
+        streams.append(np.stack([4000 * np.sin(t * (0.01 + 0.002 * i)), 3000 * np.sin(t * 0.02 + i)], axis=1).astype(np.int16))
+    s = batch.settings(5, 2, 16, 48000, 4096, True)
+    mc = batch.MultiContext([0, 0])
+    got = mc.encode_streams(s, streams)
+    one = batch.Context(0)
+    for x, (frames, sizes) in zip(streams, got):
+        out, offs, st = one.encode(s, torch.from_numpy(x).cuda())
+        assert frames == out[:st.total_bytes].cpu().numpy().tobytes()
+        assert sizes == [int(v) for v in np.diff(offs.cpu().numpy())]
+    mc.close()

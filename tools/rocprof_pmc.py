@@ -1,0 +1,44 @@
+"""Turn the PMC passes of tools/rocprof_run.sh into profiles/r02_pmc.json: HBM traffic and VALU instruction counts per
+encode launch (all fg_pipe_* kernels + sizes/scan) and per decode launch (all fg_dec_* kernels).
+
+Units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of coalesced streaming reads, so it is doubled (round 1 checked this against a kernel with a known
+230 MB input); WRITE_SIZE is taken as is.  Counter values are per dispatch; a "launch" is one dispatch of every kernel of
+the group (the short-block packing kernel included).
+usage: python tools/rocprof_pmc.py gpurun_out/prof_<tag> <workload> <blocks> <level>
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root, workload, blocks, level = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+
+
+def per_kernel(sub, name):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(root, sub, '*counter_collection.csv')):
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') == name:
+                k = row.get('Kernel_Name', '').split('(anonymous namespace)::')[-1].split('(')[0]
+                acc[k].append(float(row['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch, write, valu = per_kernel('pmc3', 'FETCH_SIZE'), per_kernel('pmc4', 'WRITE_SIZE'), per_kernel('pmc1', 'SQ_INSTS_VALU')
+enc = lambda k: k.startswith('fg_pipe_') or k.startswith('fg_scan_sizes') or k.startswith('fg_encode')
+dec = lambda k: k.startswith('fg_dec')
+rows = {}
+for k in sorted(set(fetch) | set(write) | set(valu)):
+    if enc(k) or dec(k):
+        rows[k] = {'FETCH_SIZE_KiB_raw': round(fetch.get(k, 0.0), 1), 'WRITE_SIZE_KiB_raw': round(write.get(k, 0.0), 1),
+                   'traffic_bytes': int(fetch.get(k, 0.0) * 2048 + write.get(k, 0.0) * 1024), 'valu_insts': int(valu.get(k, 0))}
+out = {'workload': workload, 'blocks': blocks, 'level': level, 'fetch_correction': 2.0,
+       'encode_traffic_bytes_per_launch': sum(r['traffic_bytes'] for k, r in rows.items() if enc(k)),
+       'decode_traffic_bytes_per_launch': sum(r['traffic_bytes'] for k, r in rows.items() if dec(k)),
+       'encode_valu_insts_per_launch': sum(r['valu_insts'] for k, r in rows.items() if enc(k)),
+       'decode_valu_insts_per_launch': sum(r['valu_insts'] for k, r in rows.items() if dec(k)),
+       'kernels': rows,
+       'source': os.path.basename(root.rstrip('/')) + ' (rocprofv3 --pmc, separate passes: SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE)'}
+os.makedirs('profiles', exist_ok=True)
+name = 'profiles/r02_pmc.json' if workload == 'stream16' else 'profiles/r02_pmc_%s.json' % workload
+json.dump(out, open(name, 'w'), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}))
