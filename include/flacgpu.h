@@ -591,6 +591,13 @@ int flacgpu_decode_stream_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t l
                               uint32_t channels, uint32_t bits_per_sample, void *d_pcm, uint64_t pcm_capacity_samples,
                               void *h_frame_status, void *d_frame_offsets_out, flacgpu_decode_stats *stats);
 
+/* How much of FLAC__Frame.subframes[] the decoder's write callback sees (format.h:285-396).  0: nothing, 1 (default): type,
+ * wasted bits, order, precision, shift, coefficients, warm-up samples, partition order, Rice parameters (the pointers stay
+ * valid until the next frame is delivered), 2: also the `residual` / verbatim `data` arrays (costs one more copy of the size
+ * of the PCM from the device).  Frames the generic decode kernel handles (predictor order > 12, 33-bit side channels) carry
+ * no subframe details. */
+void flacgpu_stream_decoder_set_subframe_detail(FLAC__StreamDecoder *decoder, int level);
+
 /* FLAC__stream_encoder_process_interleaved for 16-bit interleaved input (an extension beside the libFLAC entry point,
  * stream_encoder.h:1777-1824: same buffering, same return value): saves the caller the widening copy to FLAC__int32. */
 FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *encoder, const int16_t *buffer, uint32_t samples);

@@ -109,7 +109,7 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev',
-                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_stream_decoder_set_subframe_detail']
 
 _lib = None
 

@@ -178,7 +178,7 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->descs, &c->slots, &c->results, &c->dbg, &c->crctab, &c->windows, &c->offsets, &c->scratch_pcm,
-                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->pipe};
+                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_rparams, &c->dec_warm, &c->pipe};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -386,7 +386,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (use_pipe) {
         // a chunk holds at most a whole subframe (all of a subframe's bits may sit in one half) plus the frame header
         const uint64_t per = ((uint64_t)s->blocksize * (s->bits_per_sample + 2)) / 8 + 512 + 64;
-        chunk_cap_words = (uint32_t)((per + 15) / 16 * 4);
+        chunk_cap_words = (uint32_t)((per + 255) / 256 * 64);      // whole 256-byte rows: chunks start on a row boundary
         const uint32_t need = s->channels * 2 * chunk_cap_words * 4;
         if (need > P.slot_bytes) P.slot_bytes = (need + 255) & ~255u;
     }

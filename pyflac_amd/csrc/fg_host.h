@@ -14,6 +14,7 @@
 extern "C" {
 size_t fg_enc_lds_bytes(const FgEncParams *P);
 int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream);
+int fg_launch_widen16(const int16_t *d_src, int32_t *d_dst, unsigned long long n, hipStream_t stream);
 int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
                      uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
                      const uint16_t *d_crctab, hipStream_t stream);
@@ -47,7 +48,9 @@ int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, c
                           hipStream_t stream);
 int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                           int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
-                          hipStream_t stream);
+                          uint16_t *d_rparams, hipStream_t stream);
+int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const FgDecSub *d_subs,
+                            const int32_t *d_scratch, int32_t *d_warm, hipStream_t stream);
 int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream);
 int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
                          const uint16_t *d_crctab, hipStream_t stream);
@@ -84,7 +87,7 @@ struct flacgpu_ctx {
     double log_guard_thr = 1e-6;
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, pipe;
+        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, pipe;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`
     const void *dev_descs_ptr = nullptr;
     std::vector<float> h_windows;

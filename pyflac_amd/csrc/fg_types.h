@@ -127,8 +127,9 @@ struct FgDecSub {
     uint32_t order;        // samples stored verbatim at the start of the subframe (0 for CONSTANT / VERBATIM)
     int32_t shift;
     uint32_t wasted;
-    uint32_t flags;
-    int32_t q[12];         // FIR coefficients (quantised LPC, or the binomial coefficients of a fixed predictor)
+    uint32_t flags;        // bits 0-1 type (0 constant, 1 verbatim, 2 fixed, 3 lpc), 2-6 coefficient precision, 7-10 partition
+                           // order, 11 five-bit Rice parameters, 12 record valid (frames of the generic decoder leave it 0)
+    int32_t q[12];         // (constant subframe: q[0] = the value)         // FIR coefficients (quantised LPC, or the binomial coefficients of a fixed predictor)
 };
 
 struct FgDecResult {

@@ -31,6 +31,7 @@ using namespace fgdev;
 #define FG_DMAXO 12
 #define FG_TS 64            // residual tile of the parse kernel (samples per lane)
 #define FG_TSTR 68          // its LDS row stride (words): 16-byte aligned rows, neighbouring lanes 4 banks apart
+#define FG_DEC_RPARAMS 256  // Rice parameters kept per subframe for FLAC__Frame.subframes[] (partition order <= 8)
 
 namespace {
 
@@ -257,7 +258,7 @@ __device__ __forceinline__ void fg_dec_flush_tile(const uint32_t *tile, const ui
 
 __global__ void __launch_bounds__(128)
 fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
-                   int32_t *scratch, FgDecSub *subs, FgDecResult *results, u64 *prof)
+                   int32_t *scratch, FgDecSub *subs, FgDecResult *results, u64 *prof, uint16_t *rparams)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
     uint32_t *rings = dsm;                               // G rows of FG_RSTR words
@@ -335,6 +336,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
             if (!err && order > n) err = 1;
             if (!err && order > FG_DMAXO) err = 3;
             int shift = 0;
+            uint32_t sprec = 0;
             if (!err) {
                 if (mode == 0) { isconst = true; cval = (uint32_t)br.sbits(sb); order = 0; }
                 else if (mode == 1) { kind = 2; order = 0; }
@@ -343,6 +345,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                     mask0 = ((u64)1 << order) - 1;      // order <= 12 here
                     if (t >= 32) {
                         const uint32_t prec = br.bits(4) + 1;
+                        sprec = prec;
                         if (prec == 16) err = 1;
                         shift = br.sbits(5);
                         if (shift < 0) err = 1;
@@ -370,7 +373,13 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                 }
             }
             if (err) { alive = false; kind = 0; isconst = false; }
-            else { sd->order = order; sd->shift = shift; sd->wasted = wasted; sd->flags = 0; }
+            else {
+                // what FLAC__Frame.subframes[] reports (fg_types.h FgDecSub): type, coefficient precision, partition order, method
+                const uint32_t stype = mode == 0 ? 0u : mode == 1 ? 1u : (t >= 32 ? 3u : 2u);
+                sd->order = order; sd->shift = shift; sd->wasted = wasted;
+                sd->flags = stype | (sprec << 2) | (po << 7) | ((plen == 5 ? 1u : 0u) << 11) | (1u << 12);
+                if (mode == 0) sd->q[0] = (int32_t)cval;
+            }
         }
         uint32_t rn = (on && !err) ? n : 0;                       // samples this lane's row contributes
         const u64 roff = fr.out_off * C + (u64)ch * n;
@@ -388,6 +397,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                     k = br.bits(plen);
                     is_esc = (k == escv);
                     if (is_esc) raw = br.bits(5);
+                    if (rparams && part < FG_DEC_RPARAMS) rparams[((size_t)f * C + ch) * FG_DEC_RPARAMS + part] = (uint16_t)(is_esc ? (0x8000u | (raw << 8)) : k);
                     part++;
                     pend = po == 0 ? n : part * psz;
                 }
@@ -454,6 +464,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                                 k = br.bits(plen);
                                 is_esc = (k == escv);
                                 if (is_esc) raw = br.bits(5);
+                                if (rparams && part < FG_DEC_RPARAMS) rparams[((size_t)f * C + ch) * FG_DEC_RPARAMS + part] = (uint16_t)(is_esc ? (0x8000u | (raw << 8)) : k);
                                 part++;
                                 pend = po == 0 ? n : part * psz;
                             }
@@ -904,7 +915,32 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
 #undef FG_TICK
 }
 
+// The first samples of every subframe (the predictor's warm-up, or the start of a verbatim subframe) as they were coded:
+// FLAC__Subframe_Fixed / _LPC.warmup of the frame handed to the write callback.  thread = (subframe, j).
+__global__ void __launch_bounds__(256)
+fg_dec_warmup_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch, int32_t *warm)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t sf = t >> 5, j = t & 31;
+    if (sf >= nframes * C) return;
+    const uint32_t f = sf / C, ch = sf % C;
+    const FgDecFrame fr = frames[f];
+    int32_t v = 0;
+    if (fr.bytes != 0 && fr.channels == C && (subs[sf].flags & (1u << 12)) && j < subs[sf].order && j < fr.n)
+        v = scratch[fr.out_off * C + (u64)ch * fr.n + j];
+    warm[(size_t)sf * 32 + j] = v;
+}
+
 }  // namespace
+
+extern "C" int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const FgDecSub *d_subs,
+                                       const int32_t *d_scratch, int32_t *d_warm, hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    const uint32_t total = nframes * channels * 32;
+    hipLaunchKernelGGL(fg_dec_warmup_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, d_frames, nframes, channels, d_subs, d_scratch, d_warm);
+    return (int)hipGetLastError();
+}
 
 // Frames per wave.  A lane's work is one serial chain, so a wave takes as long as its slowest frame however many lanes are
 // busy; a launch that cannot fill the chip is spread thin.  Measured on the MI355X with 7032 frames (tools/gpu_gsweep.sh):
@@ -925,7 +961,7 @@ static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes, uint32_
 
 extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                                      int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
-                                     hipStream_t stream)
+                                     uint16_t *d_rparams, hipStream_t stream)
 {
     if (nframes == 0) return 0;
     uint32_t G = fg_dec_group(nframes, 1, 2);
@@ -933,7 +969,7 @@ extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_le
     if (G > 32) G = 32;     // LDS per wave grows with G (ring + tile rows); 32 keeps several waves per CU
     const size_t lds = ((size_t)G * (FG_RSTR + 2 * FG_TSTR) + 2 * 64 * FG_META + 4) * 4;
     hipLaunchKernelGGL(fg_dec_rice_kernel, dim3((nframes + G - 1) / G), dim3(128), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G,
-                       wide ? 0u : 1u, d_scratch, d_subs, d_results, d_prof);
+                       wide ? 0u : 1u, d_scratch, d_subs, d_results, d_prof, d_rparams);
     return (int)hipGetLastError();
 }
 

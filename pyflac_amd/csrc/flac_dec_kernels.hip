@@ -534,8 +534,10 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
         if (!fg_idx_header(stream + pos, len - pos, channels, bps, &number, &variable)) continue;
         // (thousands of atomics on one address take longer than the whole pass over the bytes: the candidates are only
         // counted when that is what the call is for)
-        if (nframes == 0) atomicAdd(&info[0], 1ull);
+        // sync code 0xFFF9 (variable block size: the number is a sample number) is not filed; a fixed-block-size stream
+        // holds such byte sequences by chance, so they only count as evidence when nothing else is found
         if (variable) { atomicAdd(&info[2], 1ull); continue; }
+        if (nframes == 0) atomicAdd(&info[0], 1ull);
         if (nframes == 0 || number < first_number) continue;
         const u64 slot = number - first_number;
         if (slot >= nframes) continue;

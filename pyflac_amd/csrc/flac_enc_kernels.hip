@@ -1321,6 +1321,20 @@ int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float 
     return (int)hipGetLastError();
 }
 
+// int16 -> int32 (the stream encoder uploads 16-bit input as it is)
+__global__ void fg_widen16_kernel(const int16_t *src, int32_t *dst, unsigned long long n)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int fg_launch_widen16(const int16_t *d_src, int32_t *d_dst, unsigned long long n, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    unsigned long long wg = (n + 255) / 256;
+    if (wg > 4096) wg = 4096;
+    hipLaunchKernelGGL(fg_widen16_kernel, dim3((unsigned)wg), dim3(256), 0, stream, d_src, d_dst, n);
+    return (int)hipGetLastError();
+}
+
 int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream)
 {
     if (nblocks == 0) return 0;

@@ -1186,11 +1186,17 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 
     // ---- the decision record of this candidate
     FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
-    if (lane == 0) {
-        dec->bits = best; dec->type = d_type; dec->order = d_order; dec->prec = d_prec; dec->shift = d_shift;
-        dec->porder = d_porder; dec->method = d_method; dec->wasted = wst;
+    {
+        // the 20 header words of the record in one coalesced store (lane j = word j; everything here is wave-uniform)
+        uint32_t wv_ = 0;
+        const uint32_t hw[8] = {best, d_type, d_order, d_prec, (uint32_t)d_shift, d_porder, d_method, wst};
 #pragma unroll
-        for (int j = 0; j < 12; j++) dec->q[j] = j < MAXO ? bestq[j < MAXO ? j : 0] : 0;
+        for (int j = 0; j < 8; j++) wv_ = lane == j ? hw[j] : wv_;
+#pragma unroll
+        for (int j = 0; j < 12; j++) wv_ = lane == 8 + j ? (j < MAXO ? (uint32_t)bestq[j < MAXO ? j : 0] : 0u) : wv_;
+        if (lane < 20) ((uint32_t *)dec)[lane] = wv_;
+    }
+    if (lane == 0) {
         FgBlockResult *r = &results[d.out_slot];
         r->best_bits[C] = best;
         if (C == 0) {
@@ -1265,8 +1271,11 @@ FGI void cb_flush(ChunkBits &b, int lane, uint32_t upto, bool all)
     const uint32_t nfull = wend - b.wbase;
     if (wend > b.cap_words) b.err |= FG_ERR_SLOT;
     wave_lds_fence();
-    for (uint32_t wi = b.wbase + (uint32_t)lane; wi < wend; wi += 64)
-        if (wi < b.cap_words) b.outw[wi] = b.w[wi - b.wbase];
+    // rows of 64 words aligned in the chunk (256-byte aligned in memory): whole cache lines except at the two ends
+    for (uint32_t row = b.wbase & ~63u; row < wend; row += 64) {
+        const uint32_t wi = row + (uint32_t)lane;
+        if (wi >= b.wbase && wi < wend && wi < b.cap_words) b.outw[wi] = b.w[wi - b.wbase];
+    }
     const uint32_t carry = b.w[nfull];
     wave_lds_fence();
     for (uint32_t j = lane; j <= nfull + 1 && j < b.fbw + 2; j += 64) b.w[j] = 0;

@@ -321,12 +321,25 @@ extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uin
 }
 
 // ------------------------------------------------------------------ batch decode of device-resident frames
+// What the stream decoder needs to fill FLAC__Frame.subframes[] (format.h:285-396): the parse kernel's per-subframe records,
+// the Rice parameters, the warm-up samples; with level 2 also the whole residual plane (frame-planar, warm-up samples in
+// place) for the `residual` / verbatim `data` pointers.
+struct DecDetail {
+    int level = 1;
+    std::vector<FgDecSub> subs;
+    std::vector<uint16_t> rparams;      // FG_DEC_RPARAMS per subframe
+    std::vector<int32_t> warm;          // 32 per subframe
+    std::vector<int32_t> planes;        // level 2: [frame][channel][n] as the kernels keep it
+};
+#define FG_DEC_RPARAMS 256
+
 // h_offsets == nullptr: the frame index is made on the device from the bytes (fg_dec_index_kernel); nframes is then the
 // number of frames the stream is known to hold (STREAMINFO: total samples / block size), or 0 to have them counted first.
 static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
                                uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
                                FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
-                               bool offsets_on_device = false, uint64_t first_number = 0, uint64_t *d_offsets_out = nullptr)
+                               bool offsets_on_device = false, uint64_t first_number = 0, uint64_t *d_offsets_out = nullptr,
+                               DecDetail *detail = nullptr)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     memset(st, 0, sizeof *st);
@@ -344,7 +357,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
-            if (hinfo[2]) { fg_set_error("variable block size stream: use flacgpu_index_frames"); return false; }
+            if (hinfo[0] == 0 && hinfo[2]) { fg_set_error("variable block size stream: use flacgpu_index_frames"); return false; }
             if (hinfo[0] > 0x7FFFFFFFull) { fg_set_error("too many frames"); return false; }
             const uint32_t bound = (uint32_t)hinfo[0];
             if (bound == 0) { st->nframes = 0; return true; }
@@ -420,8 +433,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
                              (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
     if (forked && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
+    uint16_t *d_rparams = nullptr;
+    if (detail && detail->level >= 1) {
+        if (!c->dec_rparams.ensure((size_t)npad * C * FG_DEC_RPARAMS * 2) || !c->dec_warm.ensure((size_t)npad * C * 32 * 4)) return false;
+        d_rparams = (uint16_t *)c->dec_rparams.p;
+        // (the subframe records of frames the fast decoder does not take stay zero: flags bit 12 = valid)
+        if (!HIPOK(hipMemsetAsync(c->dec_subs.p, 0, (size_t)npad * C * sizeof(FgDecSub), c->stream))) return false;
+    }
     if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                              (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, c->stream) != 0) {
+                              (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, d_rparams, c->stream) != 0) {
         fg_set_error("decode kernel launch failed"); return false;
     }
     if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
@@ -431,6 +451,14 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         fg_set_error("decode kernel launch failed"); return false;
     }
     if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
+    if (detail && detail->level >= 1) {
+        if (fg_launch_decode_warmup((const FgDecFrame *)c->dec_frames.p, nframes, C, (const FgDecSub *)c->dec_subs.p, (const int32_t *)c->dec_scratch.p,
+                                    (int32_t *)c->dec_warm.p, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+        detail->subs.resize((size_t)nframes * C); detail->rparams.resize((size_t)nframes * C * FG_DEC_RPARAMS); detail->warm.resize((size_t)nframes * C * 32);
+        if (!HIPOK(hipMemcpyAsync(detail->subs.data(), c->dec_subs.p, detail->subs.size() * sizeof(FgDecSub), hipMemcpyDeviceToHost, c->stream)) ||
+            !HIPOK(hipMemcpyAsync(detail->rparams.data(), c->dec_rparams.p, detail->rparams.size() * 2, hipMemcpyDeviceToHost, c->stream)) ||
+            !HIPOK(hipMemcpyAsync(detail->warm.data(), c->dec_warm.p, detail->warm.size() * 4, hipMemcpyDeviceToHost, c->stream))) return false;
+    }
     FgDecResult *res = (FgDecResult *)((char *)c->h_res + 64);
     if (queued && !HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream))) return false;
     if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
@@ -443,12 +471,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (!HIPOK(fg_stream_wait(c->stream))) { fg_set_error("decode kernel failed"); return false; }
     if (index_here) {
         (void)hipEventElapsedTime(&st->index_ms, c->ev[0], c->ev[3]);
-        if (hinfo2[2]) { fg_set_error("variable block size stream: use flacgpu_index_frames"); return false; }
         if (hinfo2[1]) { fg_set_error("ambiguous frame sync (several headers claim one frame number and their order does not decide): use flacgpu_index_frames"); return false; }
     }
     st->total_samples = tot[0];
     st->max_blocksize = (uint32_t)tot[1];
     if (tot[0] > cap_samples) { fg_set_error("PCM output buffer too small"); return false; }
+    if (detail && detail->level >= 2 && tot[0]) {
+        detail->planes.resize((size_t)tot[0] * C);
+        if (!HIPOK(hipMemcpy(detail->planes.data(), c->dec_scratch.p, detail->planes.size() * 4, hipMemcpyDeviceToHost))) return false;
+    }
     {
         // frames outside the register-resident decoder's envelope (predictor order > 12, ...) go through the generic kernel
         std::vector<uint32_t> redo;
@@ -485,6 +516,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     uint32_t bad = 0;
     for (uint32_t i = 0; i < nframes; i++) if (res[i].err) bad++;
     st->error_frames = bad;
+    if (index_here && bad == nframes && ((unsigned long long *)((char *)c->h_res + 32))[2]) {
+        // nothing was found under the fixed-block-size sync code, but headers with the variable-block-size one were
+        fg_set_error("variable block size stream: use flacgpu_index_frames"); return false;
+    }
     st->channels = C; st->bits_per_sample = bps_hint;
     if (h_status) memcpy(h_status, res, (size_t)nframes * sizeof(FgDecResult));
     return true;
@@ -527,6 +562,9 @@ extern "C" int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uin
 // ------------------------------------------------------------------ libFLAC-style stream decoder
 namespace {
 
+struct DecImpl;
+void fill_subframes(DecImpl *d, FLAC__Frame &f, const FgDecFrame &fr, uint32_t fi);
+
 struct DecImpl {
     FLAC__StreamDecoder pub;
     FLAC__StreamDecoderState state;
@@ -566,6 +604,11 @@ struct DecImpl {
     bool last_set;
     std::vector<int32_t> silence;
     DevBuf d_stream, d_pcm;
+    // FLAC__Frame.subframes[] of the frame being delivered
+    int subframe_detail = 1;      // flacgpu_stream_decoder_set_subframe_detail
+    DecDetail detail;
+    FLAC__EntropyCodingMethod_PartitionedRiceContents rice_contents[8];
+    std::vector<uint32_t> rice_prm[8], rice_raw[8];
 };
 
 inline DecImpl *impl(FLAC__StreamDecoder *d) { return reinterpret_cast<DecImpl *>(d); }
@@ -834,8 +877,9 @@ bool decode_available(DecImpl *d)
     flacgpu_decode_stats st;
     std::vector<FgDecResult> status(nframes);
     std::vector<FgDecFrame> frames;
+    d->detail.level = d->subframe_detail;
     if (!decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
-                            cap, 0, status.data(), &frames, &st)) {
+                            cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr)) {
         d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
     }
     d->pcm.resize((size_t)st.total_samples * (C ? C : 2));
@@ -949,10 +993,70 @@ bool deliver_one(DecImpl *d)
     }
     const int32_t *chan[8];
     for (uint32_t c = 0; c < 8; c++) chan[c] = c < fr.channels ? d->pcm.data() + (size_t)fr.out_off * fr.channels + (size_t)c * fr.n : nullptr;
+    if (d->subframe_detail > 0) fill_subframes(d, f, fr, d->next_frame - 1);
     d->last_blocksize = fr.n; d->last_ca = fr.ca;
     d->last_hdr = f.header; d->last_set = true;
     d->samples_decoded = number + fr.n;
     return write_frame(d, f, chan);
+}
+
+// FLAC__Frame.subframes[] of a delivered frame (format.h:285-396, pyflac/builder/decoder.py:146-231): what the parse kernel
+// recorded per subframe.  Pointers stay valid until the next frame is delivered.
+void fill_subframes(DecImpl *d, FLAC__Frame &f, const FgDecFrame &fr, uint32_t fi)
+{
+    const uint32_t C = fr.channels;
+    if ((size_t)(fi + 1) * C > d->detail.subs.size()) return;
+    for (uint32_t ch = 0; ch < C && ch < 8; ch++) {
+        const FgDecSub &sd = d->detail.subs[(size_t)fi * C + ch];
+        FLAC__Subframe &sf = f.subframes[ch];
+        if (!(sd.flags & (1u << 12))) continue;                 // a frame of the generic decoder: no record
+        const uint32_t type = sd.flags & 3, prec = (sd.flags >> 2) & 31, po = (sd.flags >> 7) & 15, method = (sd.flags >> 11) & 1;
+        const int32_t *plane = d->detail.planes.empty() ? nullptr : d->detail.planes.data() + (size_t)fr.out_off * C + (size_t)ch * fr.n;
+        const int32_t *warm = d->detail.warm.data() + ((size_t)fi * C + ch) * 32;
+        sf.wasted_bits = sd.wasted;
+        auto rice = [&](FLAC__EntropyCodingMethod &ecm) {
+            ecm.type = method ? FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 : FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE;
+            ecm.data.partitioned_rice.order = po;
+            const uint32_t np = 1u << po;
+            d->rice_prm[ch].assign(np, 0); d->rice_raw[ch].assign(np, 0);
+            const uint16_t *rp = d->detail.rparams.data() + ((size_t)fi * C + ch) * FG_DEC_RPARAMS;
+            for (uint32_t p = 0; p < np && p < FG_DEC_RPARAMS; p++) {
+                if (rp[p] & 0x8000) { d->rice_prm[ch][p] = method ? 31 : 15; d->rice_raw[ch][p] = (rp[p] >> 8) & 31; }
+                else d->rice_prm[ch][p] = rp[p] & 31;
+            }
+            d->rice_contents[ch].parameters = d->rice_prm[ch].data();
+            d->rice_contents[ch].raw_bits = d->rice_raw[ch].data();
+            d->rice_contents[ch].capacity_by_order = po;
+            ecm.data.partitioned_rice.contents = &d->rice_contents[ch];
+        };
+        switch (type) {
+        case 0:
+            sf.type = FLAC__SUBFRAME_TYPE_CONSTANT;
+            sf.data.constant.value = sd.q[0];
+            break;
+        case 1:
+            sf.type = FLAC__SUBFRAME_TYPE_VERBATIM;
+            sf.data.verbatim.data.int32 = plane;               // null unless the sample arrays were asked for (detail level 2)
+            sf.data.verbatim.data_type = FLAC__VERBATIM_SUBFRAME_DATA_TYPE_INT32;
+            break;
+        case 2:
+            sf.type = FLAC__SUBFRAME_TYPE_FIXED;
+            sf.data.fixed.order = sd.order;
+            for (uint32_t j = 0; j < sd.order && j < 4; j++) sf.data.fixed.warmup[j] = warm[j];
+            sf.data.fixed.residual = plane ? plane + sd.order : nullptr;
+            rice(sf.data.fixed.entropy_coding_method);
+            break;
+        default:
+            sf.type = FLAC__SUBFRAME_TYPE_LPC;
+            sf.data.lpc.order = sd.order;
+            sf.data.lpc.qlp_coeff_precision = prec;
+            sf.data.lpc.quantization_level = sd.shift;
+            for (uint32_t j = 0; j < sd.order && j < 12; j++) { sf.data.lpc.qlp_coeff[j] = sd.q[j]; sf.data.lpc.warmup[j] = warm[j]; }
+            sf.data.lpc.residual = plane ? plane + sd.order : nullptr;
+            rice(sf.data.lpc.entropy_coding_method);
+            break;
+        }
+    }
 }
 
 // Make progress: after this call either at least one frame is queued, or the stream has ended / aborted.
@@ -1026,6 +1130,11 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *dec)
     d->d_stream.release(); d->d_pcm.release();
     delete d;
 }
+
+// Extension: how much of FLAC__Frame.subframes[] the write callback sees.  0: nothing (type fields stay zero), 1 (default):
+// type, wasted bits, order, precision, shift, coefficients, warm-up, partition order and Rice parameters, 2: also the
+// `residual` / verbatim `data` sample arrays (one more device-to-host copy of the size of the PCM).
+void flacgpu_stream_decoder_set_subframe_detail(FLAC__StreamDecoder *dec, int level) { impl(dec)->subframe_detail = level < 0 ? 0 : level > 2 ? 2 : level; }
 
 FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *dec, FLAC__bool value)
 {

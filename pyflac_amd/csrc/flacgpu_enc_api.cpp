@@ -184,9 +184,11 @@ struct EncImpl {
     uint64_t samples_done;
     uint32_t min_frame, max_frame;
     FgMd5 md5;
-    std::vector<uint8_t> hbuf;      // host copy of encoded frames
+    void *h_pin = nullptr;          // pinned host copy of the encoded frames (+ offsets) of one call
+    size_t h_pin_cap = 0;
     std::vector<uint64_t> hoffs;
     DevBuf d_pcm, d_out, d_offs;    // per-encoder device staging
+    DevBuf d_in16;                  // 16-bit input as uploaded, before the device widens it into d_pcm
     DevBuf d_verify;                // verify: decoded PCM + the first-mismatch word
     // verify: where the round trip differed (FLAC__stream_encoder_get_verify_decoder_error_stats)
     uint64_t v_abs_sample; uint32_t v_frame, v_channel, v_sample; int32_t v_expected, v_got;
@@ -287,15 +289,27 @@ FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
     return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
 }
 
-// Encode `nblocks_full` complete blocks (and, if last, the remaining partial block) from e->pending.
-bool encode_pending(EncImpl *e, bool flush_all)
+// Encode the complete blocks (with `flush_all`, also the remaining partial block) of what is buffered in e->pending followed
+// by the caller's new samples (`in32` or `in16`, interleaved, `in_samples` inter-channel samples; both null = nothing new).
+// The new samples go to the device straight from the caller's buffer -- 16-bit input as 16-bit, widened by a kernel -- and
+// only what is left over (less than a block + 1 sample) is copied into e->pending.
+bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, const int16_t *in16 = nullptr, uint64_t in_samples = 0)
 {
     const uint32_t C = e->s.channels, bs = e->s.blocksize;
-    const uint64_t have = e->pending.size() / C;
+    const uint64_t pend = e->pending.size() / C;
+    const uint64_t have = pend + in_samples;
+    auto keep_input = [&](uint64_t from) {          // append the caller's samples [from, in_samples) to e->pending
+        const size_t base = e->pending.size(), nv = (size_t)(in_samples - from) * C;
+        e->pending.resize(base + nv);
+        int32_t *dst = e->pending.data() + base;
+        if (in32) memcpy(dst, in32 + (size_t)from * C, nv * 4);
+        else if (in16) { const int16_t *src = in16 + (size_t)from * C; for (size_t k = 0; k < nv; k++) dst[k] = src[k]; }
+    };
     uint64_t take;
     if (flush_all) take = have;
     else take = have >= 1 ? ((have - 1) / bs) * bs : 0;   // libFLAC emits a frame once blocksize+1 samples are buffered
-    if (take == 0) return true;
+    if (take == 0) { keep_input(0); return true; }
+    const uint64_t from_pend = std::min<uint64_t>(take, pend), from_in = take - from_pend;
     flacgpu_ctx *c = e->ctx;
     (void)hipSetDevice(c->device);
     const size_t pcm_bytes = (size_t)take * C * 4;
@@ -303,15 +317,38 @@ bool encode_pending(EncImpl *e, bool flush_all)
     sd.pcm_offset = 0; sd.nsamples = take; sd.first_frame = e->frame_number; sd.prev_channel_assignment = e->last_ca;
     uint32_t nblocks = 0;
     const uint64_t bound = flacgpu_encode_bound(&e->s, &sd, 1, &nblocks);
-    if (!e->d_pcm.ensure(pcm_bytes) || !e->d_out.ensure(bound) || !e->d_offs.ensure(((size_t)nblocks + 1) * 8)) {
+    if (!e->d_pcm.ensure(pcm_bytes) || !e->d_out.ensure(bound) || !e->d_offs.ensure(((size_t)nblocks + 1) * 8) ||
+        (in16 && from_in && !e->d_in16.ensure((size_t)from_in * C * 2))) {
         e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false;
     }
     // MD5 of the consumed PCM on a helper thread beside everything else this call does (upload, kernels, download, the
-    // client's write callbacks); joined before the samples are dropped from `pending`, on every way out
+    // client's write callbacks); joined before the samples are dropped from `pending`, on every way out.  16-bit input at 16
+    // bits per sample is hashed as it lies in memory (the MD5 is over little-endian samples, format.h:560).
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } md5j;
-    if (e->do_md5) md5j.t = std::thread([e, take, C] { e->md5.update_pcm(e->pending.data(), take * C, e->s.bits_per_sample); });
-    if (hipMemcpy(e->d_pcm.p, e->pending.data(), pcm_bytes, hipMemcpyHostToDevice) != hipSuccess) {
-        e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false;
+    if (e->do_md5) md5j.t = std::thread([=] {
+        if (from_pend) e->md5.update_pcm(e->pending.data(), from_pend * C, e->s.bits_per_sample);
+        if (from_in) {
+            if (in32) e->md5.update_pcm(in32, from_in * C, e->s.bits_per_sample);
+            else if (e->s.bits_per_sample > 8 && e->s.bits_per_sample <= 16) e->md5.update((const uint8_t *)in16, (size_t)from_in * C * 2);
+            else {
+                std::vector<int32_t> w(4096);
+                for (uint64_t o = 0; o < from_in * C; o += 4096) {
+                    const size_t k = (size_t)std::min<uint64_t>(4096, from_in * C - o);
+                    for (size_t q = 0; q < k; q++) w[q] = in16[o + q];
+                    e->md5.update_pcm(w.data(), k, e->s.bits_per_sample);
+                }
+            }
+        }
+    });
+    {
+        bool up = true;
+        int32_t *d_pcm = (int32_t *)e->d_pcm.p;
+        if (from_pend) up = hipMemcpyAsync(d_pcm, e->pending.data(), (size_t)from_pend * C * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        if (up && from_in && in32) up = hipMemcpyAsync(d_pcm + (size_t)from_pend * C, in32, (size_t)from_in * C * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        if (up && from_in && in16)
+            up = hipMemcpyAsync(e->d_in16.p, in16, (size_t)from_in * C * 2, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                 fg_launch_widen16((const int16_t *)e->d_in16.p, d_pcm + (size_t)from_pend * C, (uint64_t)from_in * C, c->stream) == 0;
+        if (!up || hipStreamSynchronize(c->stream) != hipSuccess) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false; }
     }
     flacgpu_encode_stats st;
     const int rc = flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, e->d_out.p, e->d_out.cap, e->d_offs.p, &st);
@@ -322,12 +359,26 @@ bool encode_pending(EncImpl *e, bool flush_all)
         e->state = (st.error_flags & FG_ERR_RANGE) ? FLAC__STREAM_ENCODER_CLIENT_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
     }
     else if (!ok) e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
+    const uint8_t *hout = nullptr;
     if (ok) {
-        e->hbuf.resize(st.total_bytes);
-        e->hoffs.resize((size_t)st.nblocks + 1);
-        if (hipMemcpy(e->hbuf.data(), e->d_out.p, st.total_bytes, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(e->hoffs.data(), e->d_offs.p, ((size_t)st.nblocks + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
-            ok = false; e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR;
+        // frames and their offsets land in pinned memory (per encoder; grown on demand) and are handed out from there
+        const size_t need = (((size_t)st.total_bytes + 63) & ~(size_t)63) + ((size_t)st.nblocks + 1) * 8;
+        if (need > e->h_pin_cap) {
+            if (e->h_pin) (void)hipHostFree(e->h_pin);
+            e->h_pin = nullptr; e->h_pin_cap = 0;
+            const size_t want = std::max(need, (size_t)1 << 20) * 3 / 2;
+            if (hipHostMalloc(&e->h_pin, want, hipHostMallocDefault) == hipSuccess) e->h_pin_cap = want;
+        }
+        if (!e->h_pin) { ok = false; e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; }
+        else {
+            uint8_t *hp = (uint8_t *)e->h_pin;
+            uint64_t *ho = (uint64_t *)(hp + (((size_t)st.total_bytes + 63) & ~(size_t)63));
+            if (hipMemcpyAsync(hp, e->d_out.p, st.total_bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(ho, e->d_offs.p, ((size_t)st.nblocks + 1) * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) {
+                ok = false; e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR;
+            }
+            else { hout = hp; e->hoffs.assign(ho, ho + st.nblocks + 1); }
         }
     }
     // verify (stream_encoder.h: FLAC__stream_encoder_set_verify): decode the fresh frames on the GPU and compare with the
@@ -345,7 +396,11 @@ bool encode_pending(EncImpl *e, bool flush_all)
             unsigned long long *d_first = (unsigned long long *)((char *)e->d_verify.p + (((size_t)nvals * 4 + 15) & ~(size_t)15));
             unsigned long long first = 0;
             // FLACGPU_VERIFY_SELFTEST: disturb the reference copy so that the mismatch path can be exercised by a test
-            if (getenv("FLACGPU_VERIFY_SELFTEST")) { const int32_t poison = e->pending[0] ^ 0x55; (void)hipMemcpy(e->d_pcm.p, &poison, 4, hipMemcpyHostToDevice); }
+            if (getenv("FLACGPU_VERIFY_SELFTEST")) {
+                const int32_t first0 = from_pend ? e->pending[0] : (in32 ? in32[0] : (int32_t)in16[0]);
+                const int32_t poison = first0 ^ 0x55;
+                (void)hipMemcpy(e->d_pcm.p, &poison, 4, hipMemcpyHostToDevice);
+            }
             if (fg_launch_compare((const int32_t *)e->d_verify.p, (const int32_t *)e->d_pcm.p, nvals, d_first, c->stream) != 0 ||
                 hipMemcpyAsync(&first, d_first, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess) { ok = false; e->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR; }
@@ -366,7 +421,7 @@ bool encode_pending(EncImpl *e, bool flush_all)
     for (uint32_t b = 0; b < st.nblocks; b++) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(bs, take - pos);
         const uint32_t fb = (uint32_t)(e->hoffs[b + 1] - e->hoffs[b]);
-        if (!emit(e, e->hbuf.data() + e->hoffs[b], fb, n, e->frame_number)) return false;
+        if (!emit(e, hout + e->hoffs[b], fb, n, e->frame_number)) return false;
         if (e->min_frame == 0 || fb < e->min_frame) e->min_frame = fb;
         if (fb > e->max_frame) e->max_frame = fb;
         e->frame_number++;
@@ -378,7 +433,8 @@ bool encode_pending(EncImpl *e, bool flush_all)
         }
     }
     if (md5j.t.joinable()) md5j.t.join();
-    e->pending.erase(e->pending.begin(), e->pending.begin() + (size_t)take * C);
+    e->pending.erase(e->pending.begin(), e->pending.begin() + (size_t)from_pend * C);
+    keep_input(from_in);
     return true;
 }
 
@@ -405,7 +461,8 @@ void FLAC__stream_encoder_delete(FLAC__StreamEncoder *enc)
         if (e->file && e->own_file) fclose(e->file);
     }
     if (e->ctx) (void)hipSetDevice(e->ctx->device);
-    e->d_pcm.release(); e->d_out.release(); e->d_offs.release(); e->d_verify.release();
+    e->d_pcm.release(); e->d_out.release(); e->d_offs.release(); e->d_verify.release(); e->d_in16.release();
+    if (e->h_pin) (void)hipHostFree(e->h_pin);
     delete e;
 }
 
@@ -571,22 +628,17 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *enc, co
 {
     EncImpl *e = impl(enc);
     if (e->state != FLAC__STREAM_ENCODER_OK) return 0;
-    const size_t nv = (size_t)samples * e->s.channels;
-    e->pending.insert(e->pending.end(), buffer, buffer + nv);
-    return encode_pending(e, false) ? 1 : 0;
+    return encode_pending(e, false, buffer, nullptr, samples) ? 1 : 0;
 }
 
-// Extension (include/flacgpu.h): the same with 16-bit interleaved input, widened straight into the pending buffer.  pyFLAC
-// widens int16 arrays to int32 in numpy before the call (pyflac/encoder.py:112); taking them as they are saves that pass.
+// Extension (include/flacgpu.h): the same with 16-bit interleaved input.  pyFLAC widens int16 arrays to int32 in numpy before
+// the call (pyflac/encoder.py:112); taking them as they are saves that pass and halves the bytes that cross PCIe (the device
+// widens them).
 FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *enc, const int16_t *buffer, uint32_t samples)
 {
     EncImpl *e = impl(enc);
     if (e->state != FLAC__STREAM_ENCODER_OK) return 0;
-    const size_t nv = (size_t)samples * e->s.channels, base = e->pending.size();
-    e->pending.resize(base + nv);
-    int32_t *dst = e->pending.data() + base;
-    for (size_t i = 0; i < nv; i++) dst[i] = buffer[i];
-    return encode_pending(e, false) ? 1 : 0;
+    return encode_pending(e, false, nullptr, buffer, samples) ? 1 : 0;
 }
 
 FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *enc, const FLAC__int32 *const buffer[], uint32_t samples)
