@@ -256,25 +256,19 @@ __device__ __forceinline__ void fg_dec_flush_tile(const uint32_t *tile, const ui
     }
 }
 
-__global__ void __launch_bounds__(128)
-fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
-                   int32_t *scratch, FgDecSub *subs, FgDecResult *results, u64 *prof, uint16_t *rparams)
+// LDS areas of a parse workgroup.  subp / frm exist only in the fused kernel: subp[ch & 3][row][16] = order, shift, wasted,
+// valid, q[12] of the subframe being parsed; frm[row][8] = n, channels, channel assignment, out_off lo / hi, accepted.
+struct FgParseLds { uint32_t *rings, *tiles, *metas, *ctrl, *subp, *frm; };
+#define FG_SUBP 16
+#define FG_FRM 8
+
+// The parser wave (lane = frame): shared by fg_dec_rice_kernel and fg_dec_fused_kernel.
+template <bool FUSED>
+__device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G,
+                                              uint32_t narrow, FgDecSub *subs, FgDecResult *results, u64 *prof, uint16_t *rparams,
+                                              const FgParseLds L, const int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
-    uint32_t *rings = dsm;                               // G rows of FG_RSTR words
-    uint32_t *const tiles = dsm + G * FG_RSTR;           // two buffers of G rows of FG_TSTR words
-    uint32_t *const metas = tiles + 2 * G * FG_TSTR;     // two buffers of 64 rows of FG_META words
-    uint32_t *const ctrl = metas + 2 * 64 * FG_META;     // [0] tiles per launch group, [1] tiles per channel
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x >= 64) {
-        __syncthreads();
-        const uint32_t T = ctrl[0], tpc = ctrl[1];
-        for (uint32_t it = 0; it < T; it++) {
-            __syncthreads();
-            fg_dec_flush_tile(tiles + (it & 1) * G * FG_TSTR, metas + (it & 1) * 64 * FG_META, G, (it % tpc) * FG_TS, lane, scratch);
-        }
-        return;
-    }
+    uint32_t *const rings = L.rings, *const tiles = L.tiles, *const metas = L.metas, *const ctrl = L.ctrl;
     uint32_t it = 0;                                     // tiles finished so far: buffer it & 1 is the one being filled
 #define tile (tiles + (it & 1) * G * FG_TSTR)
     const uint32_t f = blockIdx.x * G + lane;
@@ -289,6 +283,10 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
     const uint32_t n = fr.n, C = fr.channels;
     const uint32_t Cmax = wave_max32(alive ? C : 0), nmax = wave_max32(alive ? n : 0);
     if (lane == 0) { ctrl[1] = (nmax + FG_TS - 1) / FG_TS; ctrl[0] = Cmax * ((nmax + FG_TS - 1) / FG_TS); }
+    if (FUSED && (uint32_t)lane < G) {
+        uint32_t *fm = L.frm + lane * FG_FRM;
+        fm[0] = alive ? n : 0; fm[1] = C; fm[2] = fr.ca; fm[3] = (uint32_t)fr.out_off; fm[4] = (uint32_t)(fr.out_off >> 32); fm[5] = alive ? 1u : 0u;
+    }
     __syncthreads();
     const uint32_t end_bits = alive ? (fr.bytes - 2) * 8 : 0;
     BitRd br;
@@ -317,6 +315,10 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
         uint32_t cval = 0;
         bool is_esc = false, aligned = false, isconst = false;
         const bool on = alive && ch < C;
+        if (FUSED && !on && (uint32_t)lane < G) {
+            uint32_t *sp = L.subp + ((ch & 3) * G + lane) * FG_SUBP;
+            for (uint32_t j = 0; j < FG_SUBP; j++) sp[j] = 0;
+        }
         if (on) {
             FgDecSub *sd = &subs[(size_t)f * C + ch];
             sb = fr.bps;
@@ -379,6 +381,13 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
                 sd->order = order; sd->shift = shift; sd->wasted = wasted;
                 sd->flags = stype | (sprec << 2) | (po << 7) | ((plen == 5 ? 1u : 0u) << 11) | (1u << 12);
                 if (mode == 0) sd->q[0] = (int32_t)cval;
+            }
+            if (FUSED) {
+                // what the recurrence and the output waves need, two / three tiles from now (four buffers: a channel may be a
+                // single tile long)
+                uint32_t *sp = L.subp + ((ch & 3) * G + lane) * FG_SUBP;
+                sp[0] = err ? 0u : order; sp[1] = err ? 0u : (uint32_t)shift; sp[2] = err ? 0u : wasted; sp[3] = err ? 0u : 1u;
+                for (uint32_t j = 0; j < 12; j++) sp[4 + j] = (!err && j < order && mode == 2) ? (uint32_t)sd->q[j] : 0u;
             }
         }
         uint32_t rn = (on && !err) ? n : 0;                       // samples this lane's row contributes
@@ -515,9 +524,34 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
         }
         results[f].err = err;
     }
+    if (FUSED) { __syncthreads(); __syncthreads(); }          // the recurrence and the output waves finish the last two tiles
     if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t)blockIdx.x * 8 + i] = tp[i];
 #undef FG_TICK
 #undef tile
+}
+
+__global__ void __launch_bounds__(128)
+fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
+                   int32_t *scratch, FgDecSub *subs, FgDecResult *results, u64 *prof, uint16_t *rparams)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
+    FgParseLds L;
+    L.rings = dsm;                               // G rows of FG_RSTR words
+    L.tiles = dsm + G * FG_RSTR;                 // two buffers of G rows of FG_TSTR words
+    L.metas = L.tiles + 2 * G * FG_TSTR;         // two buffers of 64 rows of FG_META words
+    L.ctrl = L.metas + 2 * 64 * FG_META;         // [0] tiles per launch group, [1] tiles per channel
+    L.subp = nullptr; L.frm = nullptr;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x >= 64) {
+        __syncthreads();
+        const uint32_t T = L.ctrl[0], tpc = L.ctrl[1];
+        for (uint32_t it = 0; it < T; it++) {
+            __syncthreads();
+            fg_dec_flush_tile(L.tiles + (it & 1) * G * FG_TSTR, L.metas + (it & 1) * 64 * FG_META, G, (it % tpc) * FG_TS, lane, scratch);
+        }
+        return;
+    }
+    fg_parse_wave<false>(stream, stream_len, frames, nframes, G, narrow, subs, results, prof, rparams, L, lane);
 }
 
 // CRC-16 (poly 0x8005, init 0) of frame bytes [0, bytes-2), compared with the stored big-endian CRC.
@@ -915,6 +949,344 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
 #undef FG_TICK
 }
 
+// ------------------------------------------------------------------------------------------------ fused decode
+// One workgroup of four waves per group of G frames; the tiles of 64 samples per frame travel through LDS:
+//   wave 0  parser       lane = frame    bit-serial: delimits the Rice codes of tile t            (fg_parse_wave)
+//   wave 1  converter    16 lanes / row  windows of tile t-1 -> residuals, into a ring of three residual tiles in LDS
+//   wave 2  recurrence   lane = frame    s[i] = r[i] + (sum q*s >> shift) over tile t-2, history in registers
+//   wave 3  output       lane = column   tile t-3: channel 0 of a stereo frame is parked in HBM (one int32 plane per frame),
+//                                        channel 1 fetches it back, undoes the decorrelation and stores both, interleaved
+// One barrier per tile.  The recurrence (78 cycles a sample) is faster than the parse (104 cycles a code), so the kernel takes
+// what the parse takes; the residual plane of the two-kernel version (4 bytes per sample out and in again) is gone, what
+// remains is the channel-0 plane.  Frames the kernels cannot take (status 3) and frames that fail are settled afterwards
+// (generic kernel / fg_dec_fix_kernel writes silence).
+#define FG_RT 3             // residual tiles in flight
+
+template <int MAXO, bool WIDE, bool GATE>
+__device__ __forceinline__ void frestore_group(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, uint32_t ibase, uint32_t *rowp)
+{
+    int32_t r[MAXO];
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4) {
+        const uint4 t = *(const uint4 *)(rowp + u);
+        r[u] = (int32_t)t.x; r[u + 1] = (int32_t)t.y; r[u + 2] = (int32_t)t.z; r[u + 3] = (int32_t)t.w;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u++) {
+        int32_t pred;
+        if (!WIDE) {
+            int32_t sum = 0;
+#pragma unroll
+            for (int j = (MAXO == 8 ? 7 : 11); j >= 0; j--) sum += __mul24(q[j], h[(u - 1 - j + 2 * MAXO) % MAXO]);
+            pred = sum >> shift;
+        }
+        else {
+            i64 sum = 0;
+#pragma unroll
+            for (int j = (MAXO == 8 ? 7 : 11); j >= 0; j--) sum += (i64)q[j] * (i64)h[(u - 1 - j + 2 * MAXO) % MAXO];
+            pred = (int32_t)(sum >> shift);
+        }
+        int32_t v = r[u] + pred;
+        if (GATE) v = (ibase + (uint32_t)u >= order) ? v : r[u];
+        h[u] = v;
+        r[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4) *(uint4 *)(rowp + u) = make_uint4((uint32_t)r[u], (uint32_t)r[u + 1], (uint32_t)r[u + 2], (uint32_t)r[u + 3]);
+}
+
+// converter: tile of windows -> tile of residuals in LDS (the LDS twin of fg_dec_flush_tile); rn[row] = samples of the row
+__device__ __forceinline__ void fg_dec_convert_tile(const uint32_t *tile, const uint32_t *meta, uint32_t G, uint32_t i0, int lane, uint32_t *dst,
+                                                    uint32_t *rn_out, int32_t *warm, const uint32_t *frm, uint32_t fbase, uint32_t ch)
+{
+    if ((uint32_t)lane < G) rn_out[lane] = meta[lane * FG_META] >> 8;
+    uint32_t special = 0;
+    if ((uint32_t)lane < G) {
+        const uint32_t m = meta[lane * FG_META], rn_l = m >> 8, tk_l = m & 0xFF;
+        special = rn_l > i0 && (tk_l >= 0xFE || (meta[lane * FG_META + 3] | meta[lane * FG_META + 4]) != 0);
+    }
+    if (!__any(special)) {
+        const uint32_t rsub = (uint32_t)lane >> 4, q4 = ((uint32_t)lane & 15) * 4;
+        for (uint32_t r0 = 0; r0 < G; r0 += 4) {
+            const uint32_t r = r0 + rsub;
+            const uint32_t src = r < G ? r : 0;
+            const uint32_t m = meta[src * FG_META];
+            const uint32_t rn_r = r < G ? (m >> 8) : 0, kk = m & 0xFF;
+            if (i0 + q4 < rn_r) {
+                const uint4 pw = *(const uint4 *)&tile[r * FG_TSTR + q4];
+                const uint32_t p4[4] = {pw.x, pw.y, pw.z, pw.w};
+                uint32_t res[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t lz = (uint32_t)__clz(p4[e]);
+                    const uint32_t rest = (p4[e] << lz) << 1;
+                    const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                    res[e] = (uint32_t)unzig(u);
+                }
+                *(uint4 *)&dst[r * FG_TSTR + q4] = make_uint4(res[0], res[1], res[2], res[3]);
+            }
+        }
+        return;
+    }
+    for (uint32_t r = 0; r < G; r++) {
+        const uint32_t m = meta[r * FG_META], rn_s = m >> 8, kk = m & 0xFF;
+        if (i0 >= rn_s) continue;
+        uint32_t val;
+        if (kk == 0xFE) val = meta[r * FG_META + 5];
+        else {
+            val = tile[r * FG_TSTR + lane];
+            if (kk != 0xFF) {
+                const uint32_t mlo = meta[r * FG_META + 3], mhi = meta[r * FG_META + 4];
+                const uint32_t done = ((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1;
+                const uint32_t lz = (uint32_t)__clz(val);
+                const uint32_t rest = (val << lz) << 1;
+                const uint32_t u = (lz << kk) | (kk ? (rest >> (32 - kk)) : 0);
+                val = done ? val : (uint32_t)unzig(u);
+            }
+        }
+        dst[r * FG_TSTR + lane] = val;
+        // FLAC__Frame.subframes[].warmup: the first samples of the subframe as coded (they sit in the first tile)
+        if (warm && i0 == 0 && lane < 32) {
+            const uint32_t C = frm[r * FG_FRM + 1];
+            if (ch < C) warm[((size_t)(fbase + r) * C + ch) * 32 + lane] = (int32_t)val;
+        }
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256)
+fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
+                    int32_t *scratch, FgDecSub *subs, FgDecResult *results, uint16_t *rparams, int32_t *warm, int32_t *out,
+                    uint32_t interleave)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
+    FgParseLds L;
+    L.rings = dsm;
+    L.tiles = dsm + G * FG_RSTR;
+    L.metas = L.tiles + 2 * G * FG_TSTR;
+    L.ctrl = L.metas + 2 * 64 * FG_META;
+    uint32_t *const rt = L.ctrl + 8;                          // FG_RT residual tiles of (G + 1) rows (the last one is a spare)
+    uint32_t *const rnm = rt + FG_RT * (G + 1) * FG_TSTR;     // samples per row, per residual tile: FG_RT x 64
+    L.subp = rnm + FG_RT * 64;                                // 4 x G x FG_SUBP
+    L.frm = L.subp + 4 * G * FG_SUBP;                         // G x FG_FRM
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        fg_parse_wave<true>(stream, stream_len, frames, nframes, G, narrow, subs, results, nullptr, rparams, L, lane);
+        return;
+    }
+    __syncthreads();
+    const uint32_t T = L.ctrl[0], tpc = L.ctrl[1];
+    const uint32_t fbase = blockIdx.x * G;
+    if (wave == 1) {
+        // ---- converter: after barrier j, tile j - 1
+        for (uint32_t j = 1; j <= T + 2; j++) {
+            __syncthreads();
+            if (j <= T) {
+                const uint32_t it = j - 1;
+                fg_dec_convert_tile(L.tiles + (it & 1) * G * FG_TSTR, L.metas + (it & 1) * 64 * FG_META, G, (it % tpc) * FG_TS, lane,
+                                    rt + (it % FG_RT) * (G + 1) * FG_TSTR, rnm + (it % FG_RT) * 64, warm, L.frm, fbase, it / tpc);
+            }
+        }
+        return;
+    }
+    if (wave == 2) {
+        // ---- recurrence: after barrier j, tile j - 2.  lane = frame row; idle lanes work on the spare row.
+        int32_t q[16], h[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { q[k] = 0; h[k] = 0; }
+        uint32_t order = 0;
+        int shift = 0;
+        bool big = false;
+        for (uint32_t j = 1; j <= T + 2; j++) {
+            __syncthreads();
+            if (j < 2 || j > T + 1 || (interleave & 0x200)) continue;
+            const uint32_t it = j - 2, ch = it / tpc, i0 = (it % tpc) * FG_TS;
+            if (i0 == 0) {
+                // a new channel: this row's predictor
+                order = 0; shift = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) { q[k] = 0; h[k] = 0; }
+                if ((uint32_t)lane < G) {
+                    const uint32_t *sp = L.subp + ((ch & 3) * G + lane) * FG_SUBP;
+                    order = sp[0]; shift = (int)sp[1];
+#pragma unroll
+                    for (int k = 0; k < 12; k++) q[k] = (int32_t)sp[4 + k];
+                }
+                big = __any(order > 8);
+            }
+            uint32_t *rowp = rt + ((it % FG_RT) * (G + 1) + ((uint32_t)lane < G ? (uint32_t)lane : G)) * FG_TSTR;
+            const bool first = i0 == 0;
+            if (big) {
+                // 12-tap history kept in 16 slots (64 = 4 x 16: the slot of a sample is a compile-time constant)
+                frestore_group<16, WIDE, true>(h, q, shift, first ? order : 0, 0, rowp);
+                frestore_group<16, WIDE, false>(h, q, shift, order, 0, rowp + 16);
+                frestore_group<16, WIDE, false>(h, q, shift, order, 0, rowp + 32);
+                frestore_group<16, WIDE, false>(h, q, shift, order, 0, rowp + 48);
+            }
+            else {
+                frestore_group<8, WIDE, true>(h, q, shift, first ? order : 0, 0, rowp);
+                frestore_group<8, WIDE, true>(h, q, shift, first ? order : 0, 8, rowp + 8);
+#pragma unroll 1
+                for (uint32_t g = 2; g < 8; g++) frestore_group<8, WIDE, false>(h, q, shift, order, 0, rowp + g * 8);
+            }
+        }
+        return;
+    }
+    // ---- output: after barrier j, tile j - 3.
+    // Fast form (stereo, whole 64-sample tile inside every live row, 16-byte aligned planes): lane = (row, quarter): 16 samples
+    // per lane and round of 16 rows, 16-byte LDS reads, loads and stores; the row's facts sit in the lane's registers (fetched
+    // at the start of a channel).  Anything else (mono, more channels, tails, odd offsets): lane = column, row after row.
+    const uint32_t nrnd = (G + 15) >> 4;
+    uint32_t f_c[2] = {0, 0}, f_ca[2] = {0, 0}, f_n[2] = {0, 0}, f_w[2] = {0, 0};
+    u64 f_oo[2] = {0, 0};
+    const bool out_al = (((uintptr_t)out) & 15) == 0 && (((uintptr_t)scratch) & 15) == 0;
+    for (uint32_t j = 1; j <= T + 2; j++) {
+        __syncthreads();
+        if (j < 3 || (interleave & 0x100)) continue;
+        const uint32_t it = j - 3, ch = it / tpc, i0 = (it % tpc) * FG_TS;
+        const uint32_t *tile = rt + (it % FG_RT) * (G + 1) * FG_TSTR;
+        const uint32_t *rn_ = rnm + (it % FG_RT) * 64;
+        if (i0 == 0) {
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
+                const bool have = row < G;
+                const uint32_t *fm = L.frm + (have ? row : 0) * FG_FRM;
+                f_n[R] = have ? fm[0] : 0; f_c[R] = have ? fm[1] : 0; f_ca[R] = fm[2];
+                f_oo[R] = ((u64)fm[4] << 32) | fm[3];
+                f_w[R] = have ? L.subp[((ch & 3) * G + row) * FG_SUBP + 2] : 0;
+            }
+        }
+        // is this tile one for the fast form?
+        bool ok_fast = out_al && (ch < 2);
+        {
+            bool bad = false;
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
+                if ((uint32_t)R < nrnd && row < G) {
+                    const uint32_t rn = rn_[row];
+                    if (rn > i0) bad |= (f_c[R] != 2) || (i0 + FG_TS > rn) || ((f_oo[R] & 1) != 0) || ((f_n[R] & 3) != 0);
+                }
+            }
+            ok_fast = ok_fast && !__any(bad);
+        }
+        if (ok_fast) {
+            const uint32_t cq = ((uint32_t)lane & 3) * 16;
+            uint4 pa[2][4];
+            bool live[2] = {false, false};
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
+                live[R] = (uint32_t)R < nrnd && row < G && rn_[row < G ? row : 0] > i0;
+                if (live[R] && ch == 1) {
+                    const uint4 *src = (const uint4 *)(scratch + f_oo[R] * 2 + i0 + cq);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) pa[R][t] = src[t];
+                }
+            }
+#pragma unroll
+            for (int R = 0; R < 2; R++) {
+                if (!live[R]) continue;
+                const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
+                const uint4 *lt = (const uint4 *)&tile[row * FG_TSTR + cq];
+                const uint32_t wsh = f_w[R];
+                if (ch == 0) {
+                    uint4 *dstp = (uint4 *)(scratch + f_oo[R] * 2 + i0 + cq);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { const uint4 v = lt[t]; dstp[t] = make_uint4(v.x << wsh, v.y << wsh, v.z << wsh, v.w << wsh); }
+                }
+                else {
+                    const uint32_t cc = f_ca[R];
+                    int32_t *o = out + f_oo[R] * 2;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const uint4 vb = lt[t], va = pa[R][t];
+                        const uint32_t xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+                        int32_t lo[4], ro[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int32_t av = (int32_t)xa[e], bv = (int32_t)(xb[e] << wsh);
+                            const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)xb[e] << wsh) : (i64)bv;
+                            const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
+                            const int32_t ma = (int32_t)((mid + side) >> 1), mb = (int32_t)((mid - side) >> 1);
+                            lo[e] = cc == 2 ? av + bv : cc == 3 ? ma : av;
+                            ro[e] = cc == 1 ? av - bv : cc == 3 ? mb : bv;
+                        }
+                        const uint32_t i = i0 + cq + 4 * t;
+                        if (interleave & 1) {
+                            int4 *dd = (int4 *)(o + (size_t)i * 2);
+                            dd[0] = make_int4(lo[0], ro[0], lo[1], ro[1]);
+                            dd[1] = make_int4(lo[2], ro[2], lo[3], ro[3]);
+                        }
+                        else {
+                            *(int4 *)(o + i) = make_int4(lo[0], lo[1], lo[2], lo[3]);
+                            *(int4 *)(o + f_n[R] + i) = make_int4(ro[0], ro[1], ro[2], ro[3]);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- general form
+        const uint32_t i = i0 + (uint32_t)lane;
+        for (uint32_t r = 0; r < G; r++) {
+            const uint32_t *fm = L.frm + r * FG_FRM;
+            const uint32_t rn = rn_[r], C = fm[1];
+            if (i0 >= rn || ch >= C) continue;
+            const uint32_t nfr = fm[0], ca = fm[2];
+            const u64 oo = ((u64)fm[4] << 32) | fm[3];
+            const uint32_t wasted = L.subp[((ch & 3) * G + r) * FG_SUBP + 2];
+            const uint32_t x = tile[r * FG_TSTR + lane];
+            if (i >= rn) continue;
+            if (C == 2) {
+                if (ch == 0) scratch[oo * 2 + i] = (int32_t)(x << wasted);           // parked until the second channel arrives
+                else {
+                    const int32_t av = scratch[oo * 2 + i], bv = (int32_t)(x << wasted);
+                    // (32-bit streams: a side channel with wasted bits is a 33-bit value once shifted back)
+                    const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)x << wasted) : (i64)bv;
+                    const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
+                    const int32_t ma = (int32_t)((mid + side) >> 1), mb = (int32_t)((mid - side) >> 1);
+                    const int32_t lo = ca == 2 ? av + bv : ca == 3 ? ma : av;
+                    const int32_t ro = ca == 1 ? av - bv : ca == 3 ? mb : bv;
+                    int32_t *o = out + oo * 2;
+                    if (interleave & 1) ((int2 *)o)[i] = make_int2(lo, ro);
+                    else { o[i] = lo; o[nfr + i] = ro; }
+                }
+            }
+            else {
+                int32_t *o = out + oo * C;
+                const int32_t v = (int32_t)(x << wasted);
+                if (interleave & 1) o[(size_t)i * C + ch] = v;
+                else o[(size_t)ch * nfr + i] = v;
+            }
+        }
+    }
+}
+
+// Settle the frames after the fused kernel and the CRC-16 kernel: merge the CRC verdict into the status, and write silence
+// for frames that failed (libFLAC delivers silence on a CRC mismatch; status 3 = the generic kernel decodes it next).
+__global__ void __launch_bounds__(256)
+fg_dec_fix_kernel(const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, int32_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= nframes) return;
+    const FgDecFrame fr = frames[f];
+    uint32_t status = 1, crcw = 0;
+    if (fr.bytes != 0) {
+        status = results[f].err;
+        crcw = results[f].crc;
+        if (status == 0 && (crcw & 0x80000000u)) status = 2;
+    }
+    if (fr.n != 0 && lane == 0) { results[f].err = status; results[f].crc = crcw & 0xFFFFu; }
+    if (status != 0 && status != 3 && fr.n != 0 && fr.channels != 0) {
+        int32_t *o = out + fr.out_off * fr.channels;
+        for (uint32_t k = lane; k < fr.n * fr.channels; k += 64) o[k] = 0;
+    }
+}
+
 // The first samples of every subframe (the predictor's warm-up, or the start of a verbatim subframe) as they were coded:
 // FLAC__Subframe_Fixed / _LPC.warmup of the frame handed to the write callback.  thread = (subframe, j).
 __global__ void __launch_bounds__(256)
@@ -987,6 +1359,41 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
     const size_t lds = (size_t)(((G * C + 15) & ~15u) + 1) * FG_TRS * 4;      // rounds of 16 rows + the spare row
     if (wide) hipLaunchKernelGGL(fg_dec_restore_kernel<true>, grid, dim3(128), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
     else hipLaunchKernelGGL(fg_dec_restore_kernel<false>, grid, dim3(128), lds, stream, d_frames, nframes, G, C, d_subs, d_scratch, d_pcm, d_results, interleave, d_prof);
+    return (int)hipGetLastError();
+}
+
+// The fused decoder (parse + convert + recurrence + output in one kernel); fg_launch_decode_fix after it and the CRC kernel.
+extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
+                                      int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
+                                      int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    // one workgroup (four waves, one per SIMD) per CU while the frames allow: 28 frames per group for the 7032 frames of a
+    // 600 s stream (0.51 ms; 0.56 ms with two groups of 14 per CU, which share the SIMDs)
+    uint32_t G = fg_dec_group(nframes, 1, 1);
+    if (getenv("FLACGPU_DEC_G1")) G = (uint32_t)atoi(getenv("FLACGPU_DEC_G1"));      // tuning aid
+    if (G > 32) G = 32;
+    const size_t lds = ((size_t)G * (FG_RSTR + 2 * FG_TSTR) + 2 * 64 * FG_META + 8 + (size_t)FG_RT * (G + 1) * FG_TSTR + FG_RT * 64 +
+                        4 * (size_t)G * FG_SUBP + (size_t)G * FG_FRM) * 4;
+    static size_t configured[2] = {0, 0};
+    const void *fn = wide ? (const void *)fg_dec_fused_kernel<true> : (const void *)fg_dec_fused_kernel<false>;
+    if (lds > configured[wide ? 1 : 0]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        configured[wide ? 1 : 0] = lds;
+    }
+    if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 = no output wave, 2 = no recurrence
+    const dim3 grid((nframes + G - 1) / G);
+    if (wide) hipLaunchKernelGGL(fg_dec_fused_kernel<true>, grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, 0u,
+                                 d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave);
+    else hipLaunchKernelGGL(fg_dec_fused_kernel<false>, grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, 1u,
+                            d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results, int32_t *d_pcm, hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    hipLaunchKernelGGL(fg_dec_fix_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_frames, nframes, d_results, d_pcm);
     return (int)hipGetLastError();
 }
 

@@ -440,19 +440,36 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         // (the subframe records of frames the fast decoder does not take stay zero: flags bit 12 = valid)
         if (!HIPOK(hipMemsetAsync(c->dec_subs.p, 0, (size_t)npad * C * sizeof(FgDecSub), c->stream))) return false;
     }
-    if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                              (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, d_rparams, c->stream) != 0) {
-        fg_set_error("decode kernel launch failed"); return false;
+    // One fused kernel (parse -> residuals -> recurrence -> output through LDS), or, when the residual planes themselves are
+    // wanted (subframe detail level 2) or with FLACGPU_DEC_FUSED=0, the two-kernel version with the plane in HBM.
+    static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
+    const bool fused = !fused_off && !d_prof && !(detail && detail->level >= 2);
+    if (fused) {
+        if (fg_launch_decode_fused((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+                                   (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams,
+                                   d_rparams ? (int32_t *)c->dec_warm.p : nullptr, (int32_t *)d_pcm, interleave ? 1u : 0u, c->stream) != 0) {
+            fg_set_error("decode kernel launch failed"); return false;
+        }
+        if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+        if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
+            fg_set_error("decode kernel launch failed"); return false;
+        }
     }
-    if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-    if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
-                                (const FgDecSub *)c->dec_subs.p, (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p,
-                                (const uint16_t *)c->crctab.p, interleave ? 1u : 0u, wide, d_prof ? d_prof + (size_t)npad * 8 : nullptr, c->stream) != 0) {
-        fg_set_error("decode kernel launch failed"); return false;
+    else {
+        if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+                                  (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, d_rparams, c->stream) != 0) {
+            fg_set_error("decode kernel launch failed"); return false;
+        }
+        if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+        if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
+                                    (const FgDecSub *)c->dec_subs.p, (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p,
+                                    (const uint16_t *)c->crctab.p, interleave ? 1u : 0u, wide, d_prof ? d_prof + (size_t)npad * 8 : nullptr, c->stream) != 0) {
+            fg_set_error("decode kernel launch failed"); return false;
+        }
     }
     if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
     if (detail && detail->level >= 1) {
-        if (fg_launch_decode_warmup((const FgDecFrame *)c->dec_frames.p, nframes, C, (const FgDecSub *)c->dec_subs.p, (const int32_t *)c->dec_scratch.p,
+        if (!fused && fg_launch_decode_warmup((const FgDecFrame *)c->dec_frames.p, nframes, C, (const FgDecSub *)c->dec_subs.p, (const int32_t *)c->dec_scratch.p,
                                     (int32_t *)c->dec_warm.p, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
         detail->subs.resize((size_t)nframes * C); detail->rparams.resize((size_t)nframes * C * FG_DEC_RPARAMS); detail->warm.resize((size_t)nframes * C * 32);
         if (!HIPOK(hipMemcpyAsync(detail->subs.data(), c->dec_subs.p, detail->subs.size() * sizeof(FgDecSub), hipMemcpyDeviceToHost, c->stream)) ||
