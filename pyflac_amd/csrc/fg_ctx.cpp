@@ -393,7 +393,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (!c->descs.ensure((size_t)nblocks * sizeof(FgBlockDesc))) return false;
     if (!c->slots.ensure((size_t)nblocks * P.slot_bytes)) return false;
     if (!c->results.ensure((size_t)nblocks * sizeof(FgBlockResult))) return false;
-    if (!c->offsets.ensure(((size_t)nblocks + 2) * 8)) return false;
+    if (!c->offsets.ensure(((size_t)nblocks + 4) * 8)) return false;
     FgPipeLaunch PL;
     memset(&PL, 0, sizeof PL);
     if (use_pipe) {
@@ -562,20 +562,21 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             fg_set_error("scan kernel launch failed"); return false;
         }
         if (first) mark();
+        const bool asm_here = d_out && piped;       // the assembly kernel also hands out the frame index and the guard counters
         if (d_out) {
             const int rc = piped ? fg_launch_pipe_assemble((const FgBlockDesc *)c->descs.p, nblocks, (const uint8_t *)c->slots.p, P.slot_bytes,
                                                            chunk_cap_words, nw, PL.B.chunk_bits, (const FgBlockResult *)c->results.p,
-                                                           (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, out_cap,
-                                                           (const uint16_t *)c->crctab.p, c->stream)
+                                                           (unsigned long long *)c->offsets.p, (uint8_t *)d_out, out_cap,
+                                                           (const uint16_t *)c->crctab.p, (unsigned long long *)d_offsets, PL.B.guard, c->stream)
                                  : fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
                                                   (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream, out_cap);
             if (rc != 0) { fg_set_error("frame assembly kernel launch failed"); return false; }
         }
         if (first) mark();
-        if (d_offsets && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
+        if (d_offsets && !asm_here && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
         tail[0] = tail[1] = 0;
-        if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
-        if (use_pipe && hipMemcpyAsync(tail + 2, PL.B.guard, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+        if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, asm_here ? 32 : 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+        if (use_pipe && !asm_here && hipMemcpyAsync(tail + 2, PL.B.guard, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
         if (hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
         return fg_stream_wait(c->stream) == hipSuccess;
     };

@@ -32,8 +32,9 @@ int fg_launch_pipe_sizes(const FgBlockDesc *d_descs, uint32_t npipe, const uint3
                          hipStream_t stream);
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
-                            const unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
-                            hipStream_t stream);
+                            unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
+                            unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream);
+int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes, hipStream_t stream);
 int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
                    const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap);

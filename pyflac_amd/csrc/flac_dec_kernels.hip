@@ -639,6 +639,20 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
     if (bok) offsets[k] = b;
 }
 
+// offsets[0 .. nframes] and alt[0 .. nframes) empty (all ones), the four counters zero: one launch instead of three fills
+__global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long long *info, uint32_t nframes)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= nframes) offsets[k] = ~(u64)0;
+    if (k < nframes) alt[k] = ~(u64)0;
+    if (k < 4) info[k] = 0;
+}
+extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_dec_index_init_kernel, dim3((nframes + 256) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (u64 *)d_alt, d_info, nframes);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                                    uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
                                    hipStream_t stream)

@@ -85,13 +85,14 @@ int fg_launch_pipe_sizes(const FgBlockDesc *d_descs, uint32_t npipe, const uint3
 
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
-                            const unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
-                            hipStream_t stream)
+                            unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
+                            unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream)
 {
     if (nblocks == 0) return 0;
     constexpr int WPB = 4;
     hipLaunchKernelGGL((fg_pipe_assemble_kernel<WPB>), dim3((nblocks + WPB - 1) / WPB), dim3(WPB * 64), 0, stream, d_descs, nblocks, d_slots,
-                       slot_bytes, chunk_cap_words, nw, d_chunk_bits, d_results, (const u64 *)d_offsets, d_dst, (u64)dst_cap, d_crctab);
+                       slot_bytes, chunk_cap_words, nw, d_chunk_bits, d_results, (u64 *)d_offsets, d_dst, (u64)dst_cap, d_crctab,
+                       (u64 *)d_user_offsets, d_guard);
     return (int)hipGetLastError();
 }
 

@@ -1296,9 +1296,8 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                     uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
 {
     constexpr int NC = MS ? 4 : NCH;
-    constexpr int NW = NCH * WS;            // waves = chunks per frame
+    constexpr int NW = NCH * WS;            // waves launched per block
     constexpr int NT = NW * 64;
-    constexpr uint32_t LPS = 64 * WS;       // lanes (segments) per subframe
     typedef typename PipeTypes<ACC64>::samp_t samp_t;
     constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1306,10 +1305,14 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const FgBlockDesc d = descs[bi];
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = rfl((uint32_t)tid >> 6);
-    const uint32_t si = wv / WS, hf = wv % WS;
     const uint32_t n = d.n;
+    // waves per subframe of THIS block: WS when a lane then still walks >= 32 samples, else one (short blocks -- normally the
+    // tail blocks of the streams -- ride in the same launch; their spare waves leave after the staging)
+    const uint32_t ws = (WS == 2 && n % 128 == 0 && n / 128 >= 32) ? 2u : 1u;
+    const uint32_t LPS = 64 * ws;           // lanes (segments) per subframe
+    const uint32_t si = wv / ws, hf = wv % ws;
     const uint32_t seg = n / LPS, rstr = seg + PADE;
-    const uint32_t sbytes = (((P.sig_stride + 2 * LPS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
+    const uint32_t sbytes = (((P.sig_stride + 2 * 64 * WS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
     LDS samp_t *sL = (LDS samp_t *)smem;
     LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
     LDS uint32_t *fbw = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes) + wv * (fbw_words + 2 + 64);
@@ -1317,6 +1320,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     (void)pipe_stage<NCH, ACC64, NT>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg);
     for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0;
     __syncthreads();
+    if (wv >= (uint32_t)NCH * ws) return;           // (no barrier after this point)
 
     // ---- channel assignment from the four candidate totals (every wave computes it; wave-uniform)
     uint32_t ca = 0, c = si;
@@ -1345,7 +1349,8 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 
     ChunkBits fb;
     fb.w = fbw; fb.fbw = fbw_words; fb.cap_words = chunk_cap_words; fb.wbase = 0; fb.err = 0;
-    fb.outw = (uint32_t *)(slots + (size_t)d.out_slot * P.slot_bytes) + (size_t)wv * chunk_cap_words;
+    const uint32_t chunk = si * 2 + hf;            // chunk slots in bit order: (subframe 0, half 0), (0, 1), (1, 0), (1, 1)
+    fb.outw = (uint32_t *)(slots + (size_t)d.out_slot * P.slot_bytes) + (size_t)chunk * chunk_cap_words;
     uint32_t bitpos = 0;
     bool redo = false;
 
@@ -1586,7 +1591,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     }
     if (!redo) cb_flush(fb, lane, bitpos, true);
     if (lane == 0) {
-        B.chunk_bits[(size_t)bi * 4 + wv] = redo ? 0 : bitpos;
+        B.chunk_bits[(size_t)bi * 4 + chunk] = redo ? 0 : bitpos;
         const uint32_t e = fb.err | (redo ? FG_ERR_REDO : 0u);
         if (e) atomicOr(&results[d.out_slot].err, e);
     }
@@ -1612,8 +1617,8 @@ __global__ void fg_pipe_sizes_kernel(const FgBlockDesc *descs, uint32_t npipe, c
 template <int WPB>
 __global__ void __launch_bounds__(WPB * 64)
 fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_t *slots, uint32_t slot_bytes, uint32_t chunk_cap_words,
-                        uint32_t nw, const uint32_t *chunk_bits, const FgBlockResult *results, const u64 *offsets, uint8_t *dst,
-                        u64 dst_cap, const uint16_t *crctab)
+                        uint32_t nw, const uint32_t *chunk_bits, const FgBlockResult *results, u64 *offsets, uint8_t *dst,
+                        u64 dst_cap, const uint16_t *crctab, u64 *user_offsets, const unsigned long long *guard)
 {
     __shared__ uint16_t tab[1792];           // [0,256) byte table, [256,768) x^2048 tables, [768,832) x^(32k), [1024,1792) slicing tables
     for (uint32_t j = threadIdx.x; j < 1792; j += WPB * 64) tab[j] = crctab[j];
@@ -1624,6 +1629,12 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
     const FgBlockDesc d = descs[bi];
     const FgBlockResult res = results[d.out_slot];
     const uint32_t nb = res.bytes;
+    // the frame index for the caller (saves a device-to-device copy), and the guard counters beside the totals the host reads
+    if (lane == 0 && user_offsets) {
+        user_offsets[d.out_slot] = offsets[d.out_slot];
+        if (bi == 0) user_offsets[nblocks] = offsets[nblocks];
+    }
+    if (lane == 0 && bi == 0 && guard) { offsets[nblocks + 2] = guard[0]; offsets[nblocks + 3] = guard[1]; }
     if (nb == 0 || offsets[d.out_slot] + nb > dst_cap) return;      // the host reports the short buffer once it has read the total
     uint8_t *out = dst + offsets[d.out_slot];
     struct __attribute__((packed)) U32 { uint32_t v; };

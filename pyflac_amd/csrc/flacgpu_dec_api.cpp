@@ -388,13 +388,11 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
         if (!c->dec_info.ensure(64 + (size_t)nframes * 8)) return false;
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
-        if (!HIPOK(hipMemsetAsync(d_off, 0xFF, ((size_t)nframes + 1) * 8, c->stream)) || !HIPOK(hipMemsetAsync(d_info, 0, 32, c->stream)) ||
-            !HIPOK(hipMemsetAsync(d_info + 8, 0xFF, (size_t)nframes * 8, c->stream)) ||
+        if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, c->stream) != 0 ||
             fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, c->stream) != 0) {
             fg_set_error("frame index kernel launch failed"); return false;
         }
-        // (the end of the last frame: set by the kernel; a count-mode call may have found fewer frames than slots)
-        if (!HIPOK(hipMemcpyAsync(d_off + nframes, &len, 8, hipMemcpyHostToDevice, c->stream))) return false;
+        // (the end of the last frame, offsets[nframes] = len, is set by the index kernel)
         if (d_offsets_out && !HIPOK(hipMemcpyAsync(d_offsets_out, d_off, ((size_t)nframes + 1) * 8, hipMemcpyDeviceToDevice, c->stream))) return false;
         (void)hipEventRecord(c->ev[3], c->stream);
     }
