@@ -217,6 +217,10 @@ typedef void (*FLAC__StreamEncoderProgressCallback)(const FLAC__StreamEncoder *e
 FLAC__StreamEncoder *FLAC__stream_encoder_new(void);
 void FLAC__stream_encoder_delete(FLAC__StreamEncoder *encoder);
 
+/* Not part of pyFLAC's cdef (pyflac/builder/encoder.py:266-322) but of libFLAC's encoder interface (stream_encoder.h:1214): the
+ * metadata blocks written behind STREAMINFO.  PADDING, APPLICATION, SEEKTABLE (verbatim), VORBIS_COMMENT (moved to the front,
+ * vendor string replaced by libFLAC's), CUESHEET, PICTURE and unknown types. */
+FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *encoder, FLAC__StreamMetadata **metadata, uint32_t num_blocks);
 FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_set_channels(FLAC__StreamEncoder *encoder, uint32_t value);
 FLAC__bool FLAC__stream_encoder_set_bits_per_sample(FLAC__StreamEncoder *encoder, uint32_t value);

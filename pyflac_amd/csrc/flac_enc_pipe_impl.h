@@ -1697,27 +1697,41 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
         return in;
     };
     uint32_t row = 0;
-    // four rows per step while they lie inside one chunk (all but a handful do): eight loads in flight per lane
+    // Four rows per step while they lie inside one chunk (all but a handful do): eight loads per lane, and the loads of the
+    // NEXT group are requested before the current one is turned into frame words, so that a frame's ~12 groups do not each
+    // wait out a trip to memory.
+    uint32_t a[4], b[4], sh = 0;
+    auto issue = [&](uint32_t r0, int in_, uint32_t (&xa)[4], uint32_t (&xb)[4], uint32_t &xsh) __attribute__((always_inline)) {
+        const uint32_t *p = in_ == 0 ? cw[0] : in_ == 1 ? cw[1] : in_ == 2 ? cw[2] : cw[3];
+        const uint32_t s_ = in_ == 0 ? S[0] : in_ == 1 ? S[1] : in_ == 2 ? S[2] : S[3];
+        const uint32_t rel = (r0 * 64 + (uint32_t)lane) * 32 - s_;
+        const uint32_t wi = rel >> 5;
+        xsh = rel & 31;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { xa[u] = p[wi + 64 * u]; xb[u] = p[wi + 64 * u + 1]; }
+    };
+    int in = (row + 4 <= nrows) ? interior(row, 4) : -1;
+    if (in >= 0) issue(row, in, a, b, sh);
     while (row + 4 <= nrows) {
-        const int in = interior(row, 4);
         if (in < 0) {
             // a chunk boundary inside these rows: one row the general way, then try again
             const uint32_t j = row * 64 + (uint32_t)lane;
             emit(j, gather(j));
             row++;
+            in = (row + 4 <= nrows) ? interior(row, 4) : -1;
+            if (in >= 0) issue(row, in, a, b, sh);
             continue;
         }
-        const uint32_t *p = in == 0 ? cw[0] : in == 1 ? cw[1] : in == 2 ? cw[2] : cw[3];
-        const uint32_t s_ = in == 0 ? S[0] : in == 1 ? S[1] : in == 2 ? S[2] : S[3];
+        const uint32_t nrow = row + 4;
+        const int nin = (nrow + 4 <= nrows) ? interior(nrow, 4) : -1;
+        uint32_t na[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0}, nsh = 0;
+        if (nin >= 0) issue(nrow, nin, na, nb, nsh);
         const uint32_t j0 = row * 64 + (uint32_t)lane;
-        const uint32_t rel = j0 * 32 - s_;
-        const uint32_t wi = rel >> 5, sh = rel & 31;
-        uint32_t a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = p[wi + 64 * u]; b[u] = p[wi + 64 * u + 1]; }
 #pragma unroll
         for (int u = 0; u < 4; u++) emit(j0 + 64 * u, (uint32_t)((((u64)a[u] << 32) | b[u]) >> (32 - sh)));
-        row += 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = na[u]; b[u] = nb[u]; }
+        sh = nsh; row = nrow; in = nin;
     }
     for (; row < nrows; row++) {
         const uint32_t j = row * 64 + (uint32_t)lane;

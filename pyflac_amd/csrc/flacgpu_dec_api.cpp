@@ -132,6 +132,11 @@ struct Indexer {
     uint64_t cur_number = 0;      // frame / sample number of the frame being delimited
     uint32_t cur_n = 0, cur_variable = 0;
     bool tail_checked = false;    // the resync search already ran over the final, damaged frame
+    // Fast mode (clean streams): a frame boundary is accepted where a valid header CONTINUES THE NUMBERING, without the
+    // running CRC-16 (the GPU pass checks the CRC-16 of every frame anyway).  Anything irregular -- a frame longer than its
+    // header allows, a frame the GPU pass rejects -- makes the decoder restore its snapshot and repeat the round in careful
+    // mode (CRC-16 at every candidate, the resynchronisation rules below), so damaged streams behave exactly as before.
+    bool fast = true, fast_failed = false;
     std::vector<uint64_t> bounds; // accepted frame boundaries: frames are [bounds[i], bounds[i+1])
     std::vector<uint32_t> errors; // FLAC__StreamDecoderErrorStatus to report, in stream order
     std::vector<uint64_t> error_pos;
@@ -192,8 +197,9 @@ struct Indexer {
             // A frame longer than its header allows, or one that reaches the end of the data without a clean CRC-16,
             // is damaged: resynchronise (below).
             const bool at_end = scan >= len;
-            if (at_end && final && in_frame && !tail_checked) crc_to(d, len);
-            const bool want_resync = in_frame && ((scan - frame_start > max_len) || (at_end && final && crc != 0 && !tail_checked));
+            if (at_end && final && in_frame && !tail_checked && !fast) crc_to(d, len);
+            const bool want_resync = in_frame && ((scan - frame_start > max_len) || (at_end && final && !fast && crc != 0 && !tail_checked));
+            if (want_resync && fast) { fast_failed = true; return; }
             if (at_end && !want_resync) break;
             if (!in_frame) {
                 // search for a frame start
@@ -233,8 +239,16 @@ struct Indexer {
                 }
                 if ((d[scan + 1] & 0xFE) == 0xF8 && scan >= frame_start + 9) {
                     if (len - scan < 16 && !final) return;
-                    crc_to(d, scan);
-                    if (crc == 0 && parse_header(d + scan, len - scan, si, &h)) {
+                    bool boundary;
+                    if (fast) {
+                        const uint64_t step = cur_variable ? cur_n : 1;
+                        boundary = parse_header(d + scan, len - scan, si, &h) && h.variable == cur_variable && h.number == cur_number + step;
+                    }
+                    else {
+                        crc_to(d, scan);
+                        boundary = crc == 0 && parse_header(d + scan, len - scan, si, &h);
+                    }
+                    if (boundary) {
                         bounds.push_back(scan);       // closes the current frame, opens the next
                         frame_start = scan; crc = 0; crc_pos = scan;
                         open_frame(h);
@@ -311,6 +325,7 @@ extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uin
     if (streaminfo) *streaminfo = si;
     if (audio_offset) *audio_offset = (uint64_t)a;
     Indexer ix;
+    ix.fast = false;          // (no GPU pass behind this entry point: every boundary is confirmed by the frame's CRC-16)
     ix.feed(stream + a, len - a, true, have ? &si : nullptr);
     const uint64_t nfr = ix.bounds.size() > 0 ? ix.bounds.size() - 1 : 0;
     if (frame_offsets) {
@@ -1095,12 +1110,25 @@ bool fill_queue(DecImpl *d)
             }
         }
         d->frames.clear(); d->status.clear(); d->next_frame = 0;
-        d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr);
-        report_errors(d);
-        if (d->ix.bounds.size() >= 2 && d->frames_delivered_bound + 1 < d->ix.bounds.size()) {
-            if (!decode_available(d)) return false;
-            if (!d->frames.empty()) return true;
+        // Index the new bytes -- in fast mode first (see Indexer::fast), with a snapshot to return to: if the index or the GPU
+        // pass finds anything irregular, the round is repeated in careful mode (and the decoder stays there).
+        Indexer snap;
+        const bool try_fast = d->ix.fast;
+        if (try_fast) snap = d->ix;
+        const uint64_t fdb = d->frames_delivered_bound;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr);
+            bool redo = d->ix.fast && d->ix.fast_failed;
+            if (!redo && d->ix.bounds.size() >= 2 && d->frames_delivered_bound + 1 < d->ix.bounds.size()) {
+                if (!decode_available(d)) return false;
+                if (d->ix.fast) for (const FgDecResult &r : d->status) if (r.err != 0 && r.err != 3) { redo = true; break; }
+            }
+            if (!redo) break;
+            d->ix = snap; d->ix.fast = false; d->ix.fast_failed = false;
+            d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = fdb;
         }
+        report_errors(d);
+        if (!d->frames.empty()) return true;
         if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
         // need more data; keep pulling while the callback keeps filling the request (drains what is available)
         bool short_read = false;

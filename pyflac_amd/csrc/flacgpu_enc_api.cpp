@@ -181,6 +181,7 @@ struct EncImpl {
     std::vector<int32_t> pending;   // interleaved samples not yet encoded
     uint32_t frame_number;
     uint32_t last_ca = 0;          // loose mid-side: channel assignment the previous process call ended on
+    std::vector<FLAC__StreamMetadata *> metadata;   // FLAC__stream_encoder_set_metadata: the caller's blocks (pointers only)
     uint64_t samples_done;
     uint32_t min_frame, max_frame;
     FgMd5 md5;
@@ -197,6 +198,7 @@ struct EncImpl {
 void set_defaults(EncImpl *e)
 {
     e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1; e->limit_min_bitrate = 0;
+    e->metadata.clear();
     e->v_abs_sample = 0; e->v_frame = 0; e->v_channel = 0; e->v_sample = 0; e->v_expected = 0; e->v_got = 0;
     e->channels = 2; e->bps = 16; e->sample_rate = 44100; e->blocksize = 0;
     e->total_estimate = 0;
@@ -248,6 +250,118 @@ size_t build_header(const EncImpl *e, uint8_t *out, uint32_t minf, uint32_t maxf
     return (size_t)(p - out);
 }
 
+// ---- metadata blocks supplied through FLAC__stream_encoder_set_metadata (stream_encoder.h:1132-1214, format.h:560-880)
+// Serialise one block (4-byte header + body) the way libFLAC's stream_encoder_framing.c does.  Returns false for a block
+// that cannot be written (unknown layout, inconsistent length).
+static void put_be(std::vector<uint8_t> &o, uint64_t v, int bytes) { for (int i = bytes - 1; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i))); }
+static void put_le32(std::vector<uint8_t> &o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+
+static bool serialise_metadata(const FLAC__StreamMetadata *m, bool is_last, std::vector<uint8_t> &o)
+{
+    std::vector<uint8_t> b;
+    switch (m->type) {
+    case FLAC__METADATA_TYPE_PADDING:
+        b.assign(m->length, 0);
+        break;
+    case FLAC__METADATA_TYPE_APPLICATION:
+        if (m->length < 4) return false;
+        b.insert(b.end(), m->data.application.id, m->data.application.id + 4);
+        if (m->length > 4) {
+            if (!m->data.application.data) return false;
+            b.insert(b.end(), m->data.application.data, m->data.application.data + (m->length - 4));
+        }
+        break;
+    case FLAC__METADATA_TYPE_SEEKTABLE:
+        for (uint32_t i = 0; i < m->data.seek_table.num_points; i++) {
+            const FLAC__StreamMetadata_SeekPoint &p = m->data.seek_table.points[i];
+            put_be(b, p.sample_number, 8); put_be(b, p.stream_offset, 8); put_be(b, p.frame_samples, 2);
+        }
+        break;
+    case FLAC__METADATA_TYPE_VORBIS_COMMENT: {
+        // the vendor string is always libFLAC's own (stream_encoder.h:1180-1186)
+        const uint32_t vl = (uint32_t)strlen(FLAC__VENDOR_STRING);
+        put_le32(b, vl);
+        b.insert(b.end(), (const uint8_t *)FLAC__VENDOR_STRING, (const uint8_t *)FLAC__VENDOR_STRING + vl);
+        put_le32(b, m->data.vorbis_comment.num_comments);
+        for (uint32_t i = 0; i < m->data.vorbis_comment.num_comments; i++) {
+            const FLAC__StreamMetadata_VorbisComment_Entry &c = m->data.vorbis_comment.comments[i];
+            put_le32(b, c.length);
+            if (c.length) { if (!c.entry) return false; b.insert(b.end(), c.entry, c.entry + c.length); }
+        }
+        break;
+    }
+    case FLAC__METADATA_TYPE_CUESHEET: {
+        const FLAC__StreamMetadata_CueSheet &cs = m->data.cue_sheet;
+        b.insert(b.end(), (const uint8_t *)cs.media_catalog_number, (const uint8_t *)cs.media_catalog_number + 128);
+        put_be(b, cs.lead_in, 8);
+        b.push_back(cs.is_cd ? 0x80 : 0x00);                       // 1 bit + 7 of the 2071 reserved bits
+        b.insert(b.end(), 258, 0);
+        b.push_back((uint8_t)cs.num_tracks);
+        for (uint32_t t = 0; t < cs.num_tracks; t++) {
+            const FLAC__StreamMetadata_CueSheet_Track &tr = cs.tracks[t];
+            put_be(b, tr.offset, 8);
+            b.push_back(tr.number);
+            b.insert(b.end(), (const uint8_t *)tr.isrc, (const uint8_t *)tr.isrc + 12);
+            b.push_back((uint8_t)((tr.type ? 0x80 : 0) | (tr.pre_emphasis ? 0x40 : 0)));      // 2 bits + 6 of the 110 reserved bits
+            b.insert(b.end(), 13, 0);
+            b.push_back(tr.num_indices);
+            for (uint32_t k = 0; k < tr.num_indices; k++) {
+                put_be(b, tr.indices[k].offset, 8);
+                b.push_back(tr.indices[k].number);
+                b.insert(b.end(), 3, 0);
+            }
+        }
+        break;
+    }
+    case FLAC__METADATA_TYPE_PICTURE: {
+        const FLAC__StreamMetadata_Picture &pc = m->data.picture;
+        const size_t ml = pc.mime_type ? strlen(pc.mime_type) : 0, dl = pc.description ? strlen((const char *)pc.description) : 0;
+        put_be(b, (uint32_t)pc.type, 4);
+        put_be(b, ml, 4); b.insert(b.end(), (const uint8_t *)pc.mime_type, (const uint8_t *)pc.mime_type + ml);
+        put_be(b, dl, 4); b.insert(b.end(), (const uint8_t *)pc.description, (const uint8_t *)pc.description + dl);
+        put_be(b, pc.width, 4); put_be(b, pc.height, 4); put_be(b, pc.depth, 4); put_be(b, pc.colors, 4);
+        put_be(b, pc.data_length, 4);
+        if (pc.data_length) { if (!pc.data) return false; b.insert(b.end(), pc.data, pc.data + pc.data_length); }
+        break;
+    }
+    case FLAC__METADATA_TYPE_STREAMINFO:
+        return false;
+    default:
+        if (m->length) { if (!m->data.unknown.data) return false; b.insert(b.end(), m->data.unknown.data, m->data.unknown.data + m->length); }
+        break;
+    }
+    if (b.size() >= (1u << 24)) return false;
+    o.push_back((uint8_t)((is_last ? 0x80 : 0) | ((uint32_t)m->type & 0x7F)));
+    put_be(o, b.size(), 3);
+    o.insert(o.end(), b.begin(), b.end());
+    return true;
+}
+
+// What init checks about the supplied blocks (stream_encoder.c init_stream_internal_): no STREAMINFO, at most one SEEKTABLE
+// and one VORBIS_COMMENT, a legal seek table (ascending sample numbers, placeholders last)
+static bool metadata_acceptable(const std::vector<FLAC__StreamMetadata *> &v)
+{
+    bool seek = false, vc = false;
+    for (const FLAC__StreamMetadata *m : v) {
+        if (!m) return false;
+        if (m->type == FLAC__METADATA_TYPE_STREAMINFO) return false;
+        if (m->type == FLAC__METADATA_TYPE_SEEKTABLE) {
+            if (seek) return false;
+            seek = true;
+            uint64_t prev = 0;
+            bool got = false;
+            for (uint32_t i = 0; i < m->data.seek_table.num_points; i++) {
+                const uint64_t sn = m->data.seek_table.points[i].sample_number;
+                if (got && sn != 0xFFFFFFFFFFFFFFFFull && sn <= prev) return false;
+                if (got && prev == 0xFFFFFFFFFFFFFFFFull && sn != prev) return false;
+                prev = sn; got = true;
+            }
+        }
+        if (m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT) { if (vc) return false; vc = true; }
+    }
+    return true;
+}
+
 FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
 {
     if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
@@ -264,6 +378,7 @@ FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
         fg_set_error("setting not supported by the GPU encoder");
         return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
     }
+    if (!metadata_acceptable(e->metadata)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
     e->ctx = fg_default_ctx();
     if (!e->ctx) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
     FgEncParams P;
@@ -279,10 +394,24 @@ FLAC__StreamEncoderInitStatus init_common(EncImpl *e)
     e->frame_number = 0; e->last_ca = 0; e->samples_done = 0; e->min_frame = 0; e->max_frame = 0; e->bytes_written = 0;
     e->md5.init();
     e->state = FLAC__STREAM_ENCODER_OK;
-    // three metadata writes: "fLaC", STREAMINFO, VORBIS_COMMENT (stream_encoder.h:1484-1486)
+    // metadata writes: "fLaC", STREAMINFO, then either the default VORBIS_COMMENT followed by the caller's blocks, or -- when
+    // the caller supplied a VORBIS_COMMENT -- the caller's blocks alone, in the order given (native FLAC keeps the order;
+    // only Ogg FLAC moves the VORBIS_COMMENT to the front, stream_encoder.h:1484-1486 / the golden vectors).
     uint8_t hdr[128];
     const size_t hl = build_header(e, hdr, 0, 0, 0, nullptr);
-    if (!emit(e, hdr, 4, 0, 0) || !emit(e, hdr + 4, 38, 0, 0) || !emit(e, hdr + 42, hl - 42, 0, 0)) {
+    bool user_vc = false;
+    for (const FLAC__StreamMetadata *m : e->metadata) user_vc |= m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT;
+    bool ok = emit(e, hdr, 4, 0, 0) && emit(e, hdr + 4, 38, 0, 0);
+    if (ok && !user_vc) {
+        if (!e->metadata.empty()) hdr[42] &= 0x7F;          // the default VORBIS_COMMENT is no longer the last block
+        ok = emit(e, hdr + 42, hl - 42, 0, 0);
+    }
+    std::vector<uint8_t> blk;
+    for (size_t i = 0; ok && i < e->metadata.size(); i++) {
+        blk.clear();
+        ok = serialise_metadata(e->metadata[i], i + 1 == e->metadata.size(), blk) && emit(e, blk.data(), blk.size(), 0, 0);
+    }
+    if (!ok) {
         e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
         return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
     }
@@ -474,6 +603,18 @@ void FLAC__stream_encoder_delete(FLAC__StreamEncoder *enc)
         e->field = value;                                                                     \
         return 1;                                                                             \
     }
+// The blocks to write behind STREAMINFO (stream_encoder.h:1132-1214).  Only the pointers are kept: the blocks must stay alive
+// until finish.  A SEEKTABLE is written as given (what libFLAC does for a client without a seek callback); the seek points
+// of a template are not filled in.
+FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *enc, FLAC__StreamMetadata **metadata, uint32_t num_blocks)
+{
+    EncImpl *e = impl(enc);
+    if (e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+    if (!metadata) num_blocks = 0;
+    e->metadata.assign(metadata, metadata + num_blocks);
+    return 1;
+}
+
 SETTER(verify, verify, FLAC__bool)
 SETTER(channels, channels, uint32_t)
 SETTER(bits_per_sample, bps, uint32_t)

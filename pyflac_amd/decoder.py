@@ -251,7 +251,9 @@ class FileDecoder(_Decoder):
         if self.__output:
             self.__output.close()
             data, info = wav.read(str(self.__output_file))
-            return data, info.samplerate
+            # the reference returns soundfile.read(..., always_2d=True): float64 in [-1, 1), the integer samples divided by
+            # 2^(bits - 1) (libsndfile's normalisation)
+            return data.astype(np.float64) / float(1 << (info.bits - 1)), info.samplerate
 
     def _write_callback(self, data: np.ndarray, sample_rate: int, num_channels: int, num_samples: int):
         if self.__output is None:

@@ -121,70 +121,30 @@ class _Encoder:
     def state(self) -> EncoderState:
         return EncoderState(_L.FLAC__stream_encoder_get_state(self._encoder))
 
-    # -- Getters & Setters (pyflac/encoder.py:145-231)
-    @property
-    def _verify(self) -> bool:
-        return bool(_L.FLAC__stream_encoder_get_verify(self._encoder))
+    # -- Settings.  The reference's private accessors (_verify, _channels, ...) are generated from one table: attribute ->
+    # (libFLAC setting name, Python type, readable).  `_x = v` calls FLAC__stream_encoder_set_<name>, reading `_x` calls
+    # FLAC__stream_encoder_get_<name>; the compression level is write-only in libFLAC.
+    _SETTINGS = {
+        '_verify': ('verify', bool, True), '_channels': ('channels', int, True),
+        '_bits_per_sample': ('bits_per_sample', int, True), '_sample_rate': ('sample_rate', int, True),
+        '_blocksize': ('blocksize', int, True), '_compression_level': ('compression_level', int, False),
+        '_streamable_subset': ('streamable_subset', bool, True), '_limit_min_bitrate': ('limit_min_bitrate', bool, True),
+    }
 
-    @_verify.setter
-    def _verify(self, value: bool):
-        _L.FLAC__stream_encoder_set_verify(self._encoder, bool(value))
+    def __setattr__(self, name, value):
+        spec = _Encoder._SETTINGS.get(name)
+        if spec is None:
+            object.__setattr__(self, name, value)
+        else:
+            getattr(_L, 'FLAC__stream_encoder_set_' + spec[0])(self._encoder, spec[1](value))
 
-    @property
-    def _channels(self) -> int:
-        return _L.FLAC__stream_encoder_get_channels(self._encoder)
-
-    @_channels.setter
-    def _channels(self, value: int):
-        _L.FLAC__stream_encoder_set_channels(self._encoder, value)
-
-    @property
-    def _bits_per_sample(self) -> int:
-        return _L.FLAC__stream_encoder_get_bits_per_sample(self._encoder)
-
-    @_bits_per_sample.setter
-    def _bits_per_sample(self, value: int):
-        _L.FLAC__stream_encoder_set_bits_per_sample(self._encoder, value)
-
-    @property
-    def _sample_rate(self) -> int:
-        return _L.FLAC__stream_encoder_get_sample_rate(self._encoder)
-
-    @_sample_rate.setter
-    def _sample_rate(self, value: int):
-        _L.FLAC__stream_encoder_set_sample_rate(self._encoder, value)
-
-    @property
-    def _blocksize(self) -> int:
-        return _L.FLAC__stream_encoder_get_blocksize(self._encoder)
-
-    @_blocksize.setter
-    def _blocksize(self, value: int):
-        _L.FLAC__stream_encoder_set_blocksize(self._encoder, value)
-
-    @property
-    def _compression_level(self) -> int:
-        raise NotImplementedError
-
-    @_compression_level.setter
-    def _compression_level(self, value: int):
-        _L.FLAC__stream_encoder_set_compression_level(self._encoder, value)
-
-    @property
-    def _streamable_subset(self) -> bool:
-        return bool(_L.FLAC__stream_encoder_get_streamable_subset(self._encoder))
-
-    @_streamable_subset.setter
-    def _streamable_subset(self, value: bool):
-        _L.FLAC__stream_encoder_set_streamable_subset(self._encoder, bool(value))
-
-    @property
-    def _limit_min_bitrate(self) -> bool:
-        return bool(_L.FLAC__stream_encoder_get_limit_min_bitrate(self._encoder))
-
-    @_limit_min_bitrate.setter
-    def _limit_min_bitrate(self, value: bool):
-        _L.FLAC__stream_encoder_set_limit_min_bitrate(self._encoder, bool(value))
+    def __getattr__(self, name):          # only reached for names that are not ordinary attributes
+        spec = _Encoder._SETTINGS.get(name)
+        if spec is None:
+            raise AttributeError(name)
+        if not spec[2]:
+            raise NotImplementedError
+        return spec[1](getattr(_L, 'FLAC__stream_encoder_get_' + spec[0])(self._encoder))
 
 
 class StreamEncoder(_Encoder):

@@ -212,7 +212,9 @@ class TestFileEncoderDecoder:
         assert hashlib.sha256(data).hexdigest() == golden['fixture_%s_l5' % name]['file_sha256']
         dec = pyflac_amd.FileDecoder(out)
         audio, rate = dec.process()
-        assert rate == sr and np.array_equal(audio.astype(np.int64), np.asarray(pcm).reshape(audio.shape))
+        # like soundfile.read(always_2d=True) in the reference: float64 in [-1, 1), the samples over 2^(bits - 1)
+        assert rate == sr and audio.dtype == np.float64 and audio.ndim == 2
+        assert np.array_equal(np.round(audio * float(1 << (bps - 1))).astype(np.int64), np.asarray(pcm).reshape(audio.shape))
 
     def test_command_line(self, wavs, golden):
         """python -m pyflac_amd (the reference's `pyflac` tool, pyflac/__main__.py:35-56): WAV -> FLAC -> WAV by file magic,
@@ -701,3 +703,71 @@ class TestSubframes:
                         assert rec == [int(v) for v in x[:len(rec)]], (level, b, ci)
                     elif sub['type'] == 'CONSTANT':
                         assert sub['value'] == int(x[0])
+
+
+class TestEncoderSetMetadata:
+    """8f-4, encode side: FLAC__stream_encoder_set_metadata (stream_encoder.h:1214).  What the write callback receives during
+    init_stream -- "fLaC", STREAMINFO, the VORBIS_COMMENT (the caller's, moved to the front and with libFLAC's vendor string,
+    or the default one), then the caller's other blocks with the is_last flag on the final one -- equals what the reference
+    binary wrote for the same block lists (tests/golden/setmeta_vectors.json, oracle/gen_golden_setmeta.py), as does the
+    init status for lists libFLAC refuses."""
+
+    @staticmethod
+    def _new(L, blocks, out):
+        import ctypes as C
+        from pyflac_amd import _lib
+        from tests import metadata_build as MB
+        L.FLAC__stream_encoder_set_metadata.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.FLAC__stream_encoder_set_metadata.restype = C.c_int
+        enc = C.c_void_p(L.FLAC__stream_encoder_new())
+
+        def _w(e, buf, n, samples, frame, cd):
+            out.append(bytes(C.cast(buf, C.POINTER(C.c_ubyte * n)).contents) if n else b'')
+            return 0
+        wcb = _lib.ENC_WRITE_CB(_w)
+        L.FLAC__stream_encoder_set_channels(enc, 2)
+        L.FLAC__stream_encoder_set_bits_per_sample(enc, 16)
+        L.FLAC__stream_encoder_set_sample_rate(enc, 44100)
+        L.FLAC__stream_encoder_set_compression_level(enc, 5)
+        arr = MB.block_array(blocks)
+        ok = L.FLAC__stream_encoder_set_metadata(enc, arr, len(blocks))
+        rc = L.FLAC__stream_encoder_init_stream(enc, wcb, C.cast(None, _lib.ENC_SEEK_CB), C.cast(None, _lib.ENC_TELL_CB),
+                                                C.cast(None, _lib.ENC_META_CB), None)
+        return enc, wcb, ok, rc
+
+    def test_against_reference(self):
+        import json
+        from pyflac_amd import _lib
+        from tests import metadata_build as MB
+        with open(os.path.join(cases.GOLDEN, 'setmeta_vectors.json')) as f:
+            golden = json.load(f)
+        L = _lib.lib()
+        for name, blocks in MB.cases().items():
+            out = []
+            enc, _wcb, ok, rc = self._new(L, blocks, out)
+            L.FLAC__stream_encoder_finish(enc)
+            L.FLAC__stream_encoder_delete(enc)
+            assert ok == golden[name]['set_ok'], name
+            assert rc == golden[name]['init_status'], name
+            assert [b.hex() for b in out] == golden[name]['writes'], name
+
+    def test_stream_with_metadata_decodes(self):
+        """A stream with user metadata in front still decodes (our decoder and the oracle)."""
+        from pyflac_amd import _lib
+        from tests import abi_decode
+        from tests import metadata_build as MB
+        from oracle import oracle as O
+        L = _lib.lib()
+        out = []
+        enc, _wcb, ok, rc = self._new(L, MB.cases()['vorbis_not_first'], out)
+        assert ok and rc == 0
+        t = np.arange(9000)
+        pcm = np.ascontiguousarray(np.stack([3000 * np.sin(t * 0.02), 2000 * np.sin(t * 0.031)], axis=1).astype(np.int32))
+        assert L.FLAC__stream_encoder_process_interleaved(enc, pcm.ctypes.data, len(pcm))
+        assert L.FLAC__stream_encoder_finish(enc)
+        L.FLAC__stream_encoder_delete(enc)
+        stream = b''.join(out)
+        want, _res = O.decode_stream(stream)
+        assert np.array_equal(want.reshape(-1, 2), pcm)
+        got = abi_decode.decode(stream)
+        assert np.array_equal(np.concatenate(got['blocks']), pcm)

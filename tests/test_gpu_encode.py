@@ -122,17 +122,6 @@ def test_generic_kernel_equals_fast_kernel(ctx, monkeypatch):
     assert a == b
 
 
-@pytest.mark.parametrize('name', ['cfg2_1s_l5', 'cfg2_1s_l8', 'cfg4_1s_l8', 'hard16_l5', 'lr_equal', 'const16_st', 'sines20_st',
-                                  'fixture_stereo_bs1024', 'cfg2_1s_l0'])
-def test_wave_per_candidate_kernel_matches_golden(ctx, golden, name, monkeypatch):
-    """FLACGPU_WAVE=1 selects the workgroup-per-block variant (one wavefront per L/R/M/S candidate); same bytes."""
-    monkeypatch.setenv('FLACGPU_WAVE', '1')
-    spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
-    pcm, bps = cases.make_pcm(spec)
-    stream, _offs, _s = _gpu_stream(ctx, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
-    assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256']
-
-
 def test_many_streams_one_launch(ctx):
     """Config 5 shape: independent streams in one launch equal the same streams encoded one by one."""
     import torch
