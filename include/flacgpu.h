@@ -523,11 +523,11 @@ typedef struct {
     uint32_t nblocks;             /* frames produced */
     uint32_t error_flags;         /* OR of per-block FG_ERR_* bits; 0 = ok */
     uint64_t total_bytes;         /* bytes written to d_out */
-    float encode_kernel_ms;       /* HIP-event time of the frame-encode kernels (analysis + packing) */
-    float total_gpu_ms;           /* HIP-event time of the whole enqueue (encode + frame assembly) */
+    float encode_kernel_ms;       /* HIP-event time of the frame-encode kernels (analysis + packing); timing level >= 1 */
+    float total_gpu_ms;           /* GPU time of the whole enqueue (encode + frame assembly): wall-clock stamps, or HIP events at level >= 1 */
     uint32_t last_channel_assignment;  /* loose mid-side: assignment (0 independent / 3 mid-side) of the last frame of the last stream */
     uint32_t redo_blocks;         /* blocks the specialised kernels handed to the generic kernel */
-    float stage_ms[8];            /* with flacgpu_set_stage_timing(ctx, 1): analysis, packing, sizes + scan, assembly + CRC-16
+    float stage_ms[8];            /* with flacgpu_set_stage_timing(ctx, 2): analysis, packing, sizes + scan, assembly + CRC-16
                                      (HIP events between the kernel groups); else zeros */
     uint32_t log_guard_subframes; /* LPC order guesses that were within the guard threshold of a tie and were re-done with the
                                      correctly rounded logarithm (see flacgpu_set_log_guard) */
@@ -557,7 +557,12 @@ void flacgpu_set_log_guard(flacgpu_ctx *ctx, double threshold_bits);
 /* Window self-check: empty string, or a note that this host's cosf produced a tukey taper different from the committed one
  * (the committed one is then used; the note is also left in flacgpu_last_error() when it happens). */
 const char *flacgpu_window_note(flacgpu_ctx *ctx);
-void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int on);   /* fill flacgpu_encode_stats.stage_ms (adds event records between the kernels) */
+/* What the batch calls time, and how they end.  level 0 (default): no HIP events (each record idles the GPU for a few
+ * microseconds between two kernels); the call ends with a kernel that writes totals and wall-clock stamps into pinned memory,
+ * which the host polls; total_gpu_ms comes from the stamps, the *_kernel_ms / index_ms / stage_ms fields stay 0.
+ * level 1: HIP events around the call and around its kernel groups (all *_ms fields but stage_ms).  level 2: also between the
+ * encoder's stages (stage_ms). */
+void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level);
 int flacgpu_copy_debug(flacgpu_ctx *ctx, void *host_dst, uint32_t first_block, uint32_t nblocks);
 int flacgpu_copy_block_results(flacgpu_ctx *ctx, void *host_dst, uint32_t nblocks);
 

@@ -140,6 +140,21 @@ hipError_t fg_stream_wait(hipStream_t stream)
     return hipStreamSynchronize(stream);
 }
 
+bool flacgpu_ctx::wait_signal(unsigned long long seq)
+{
+    static const long spin_us = getenv("FLACGPU_SPIN_US") ? atol(getenv("FLACGPU_SPIN_US")) : 3000;
+    volatile unsigned long long *flag = h_sig;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; it++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+            if ((it & 63) == 63 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess) return false;
+    return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+}
+
 extern "C" int flacgpu_device_count(void)
 {
     int n = 0;
@@ -158,6 +173,13 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->evs[i]));
+    if (hipHostMalloc((void **)&c->h_sig, 128, hipHostMallocDefault) != hipSuccess) { fg_set_error("hipHostMalloc failed"); return false; }
+    memset(c->h_sig, 0, 128);
+    if (!c->stamp.ensure(64)) return false;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_khz = (double)khz;
+    }
     if (!c->crctab.ensure(2048 * sizeof(uint16_t))) return false;
     if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -182,6 +204,8 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_sig) (void)hipHostFree(c->h_sig);
+    c->stamp.release();
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 8; i++) if (c->evs[i]) (void)hipEventDestroy(c->evs[i]);
     for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
@@ -306,7 +330,7 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
 extern "C" const char *flacgpu_window_note(flacgpu_ctx *ctx) { return ctx->window_note.c_str(); }
-extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int on) { ctx->stage_timing = on != 0; }
+extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level) { ctx->stage_timing = level < 0 ? 0 : level > 2 ? 2 : level; }
 extern "C" void flacgpu_set_log_guard(flacgpu_ctx *ctx, double thr) { ctx->log_guard_thr = thr; }
 
 extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
@@ -336,13 +360,24 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         s->qlp_coeff_precision > 15 || s->max_lpc_order > 32) {
         fg_set_error("invalid encoder settings"); return false;
     }
-    // block list
-    std::vector<FgBlockDesc> descs;
+    // block list.  A repeated call with the same settings and stream list (and no per-call frame decisions: loose
+    // mid-side rewrites the list) reuses the ordered list of the previous call, already on the device.
+    std::vector<unsigned char> key;
+    {
+        const size_t sb = sizeof *s, tb = (size_t)nstreams * sizeof *streams;
+        key.resize(sb + tb + 1);
+        memcpy(key.data(), s, sb);
+        if (tb) memcpy(key.data() + sb, streams, tb);
+        key[sb + tb] = (unsigned char)(pcm_is_i16 ? 1 : 0);
+    }
+    const bool reuse = !(s->do_mid_side && s->loose_mid_side) && !c->debug && c->dev_descs_ptr == c->descs.p && c->dev_descs_ptr != nullptr &&
+                       !c->dev_descs.empty() && key == c->desc_key;
+    std::vector<FgBlockDesc> built;
     uint64_t nb = 0;
     for (uint32_t i = 0; i < nstreams; i++) nb += (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
-    descs.reserve(nb);
+    if (!reuse) built.reserve(nb);
     uint32_t win_n = 0, win_off = 0;                     // the window table is looked up when the block length changes
-    for (uint32_t i = 0; i < nstreams; i++) {
+    for (uint32_t i = 0; i < nstreams && !reuse; i++) {
         uint64_t pos = 0;
         uint32_t fn = streams[i].first_frame;
         while (pos < streams[i].nsamples) {
@@ -354,12 +389,13 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             if (s->max_lpc_order && d.n != win_n) { win_n = d.n; win_off = c->window_offset(d.n, s->apod_parts); }
             d.win_off = s->max_lpc_order ? win_off : 0;
             d.forced_ca = 0xFF;
-            d.out_slot = (uint32_t)descs.size();
+            d.out_slot = (uint32_t)built.size();
             d.reserved = 0;
-            descs.push_back(d);
+            built.push_back(d);
             pos += d.n;
         }
     }
+    std::vector<FgBlockDesc> &descs = reuse ? c->dev_descs : built;
     const uint32_t nblocks = (uint32_t)descs.size();
     memset(st, 0, sizeof *st);
     st->nblocks = nblocks;
@@ -399,9 +435,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (use_pipe) {
         if (!c->pipe.ensure(fg_pipe_scratch_bytes(&P, nblocks))) return false;
         fg_pipe_carve(&P, nblocks, c->pipe.p, &PL.B);
-        // near-tie guard of the LPC order guess: count, smallest margin (as the bits of a positive double)
-        static const unsigned long long guard0[2] = {0ull, 0x7FF0000000000000ull};
-        HIPCHK(hipMemcpyAsync(PL.B.guard, guard0, 16, hipMemcpyHostToDevice, c->stream));
+        // near-tie guard of the LPC order guess: count, smallest margin (as the bits of a positive double); the
+        // autocorrelation kernel resets both
         PL.guard_thr = c->log_guard_thr;
     }
     FgDebugRec *dbg = nullptr;
@@ -440,6 +475,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // the phase follows the absolute frame number and a continuation call starts with the assignment the previous call
     // ended on.  The decision frames are independent of each other: a probe pass analyses them, the host spreads the result.
     if (P.do_mid_side && s->loose_mid_side) {
+        c->desc_key.clear();
         uint32_t period = (uint32_t)((double)s->sample_rate * 0.4 / (double)s->blocksize + 0.5);
         if (period == 0) period = 1;
         std::vector<FgBlockDesc> dec, decp, decg;      // decision frames: all, pipeline-capable first, generic after
@@ -486,7 +522,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     // blocks the specialised kernels cover go first, the rest to the generic kernel (same bytes either way)
     uint32_t nfast = 0;
-    {
+    if (reuse) { nfast = c->desc_nfast; PL.nblocks_ws2 = c->desc_nws2; }
+    else {
         std::vector<FgBlockDesc> ordered;
         ordered.reserve(nblocks);
         std::vector<FgBlockDesc> slow, ws1;
@@ -500,12 +537,20 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         nfast = (uint32_t)ordered.size();
         ordered.insert(ordered.end(), slow.begin(), slow.end());
         descs.swap(ordered);
+        c->desc_key.clear();
         if (!upload_descs(descs, true)) return false;
+        if (!(P.do_mid_side && s->loose_mid_side)) { c->desc_key = key; c->desc_nfast = nfast; c->desc_nws2 = PL.nblocks_ws2; }
     }
-    const bool timing = c->stage_timing && use_pipe;
+    // How the call ends and what is timed.  Level 0 (default): no events -- every event record costs a few microseconds of
+    // idle GPU between two kernels -- a stamp kernel in front, a signal kernel at the end (fg_signal_kernel: totals and
+    // stamps into pinned memory, the host polls the sequence number).  Level 1: HIP events around the call and the
+    // encode kernels.  Level 2: also between the pipeline's stages.
+    const bool lean = c->stage_timing == 0;
+    const bool timing = c->stage_timing >= 2 && use_pipe;
     int nev = 0;
     auto mark = [&]() { if (timing && nev < 8) (void)hipEventRecord(c->evs[nev++], c->stream); };
-    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (lean) { if (fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; } }
+    else HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const bool side = nfast > 0 && nblocks > nfast;     // overlap the few generic blocks with the fast launch
     if (side) {
         HIPCHK(hipEventRecord(c->evx[0], c->stream));
@@ -548,17 +593,15 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             HIPCHK(hipStreamWaitEvent(c->stream, c->evx[1], 0));
         }
     }
-    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    if (!lean) HIPCHK(hipEventRecord(c->ev[1], c->stream));
     // sizes -> offsets -> contiguous output, all queued behind the encode kernels; the host looks at the totals once, at the
     // end.  (Frames that would not fit `out_cap` are skipped; blocks the specialised kernels handed back show up as
     // FG_ERR_REDO in the flags and are redone below, which repeats the scan and the assembly: rare.)
     if (!c->ensure_pinned_res(64)) return false;
     unsigned long long *tail = (unsigned long long *)c->h_res;   // total bytes, OR of error flags
     auto finish_pass = [&](bool first) -> bool {
-        if (piped && first && fg_launch_pipe_sizes((const FgBlockDesc *)c->descs.p, nfast, PL.B.chunk_bits, nw, (FgBlockResult *)c->results.p, c->stream) != 0) {
-            fg_set_error("sizes kernel launch failed"); return false;
-        }
-        if (fg_launch_scan((const FgBlockResult *)c->results.p, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
+        // (frame sizes of the pipeline's blocks: from the chunk bit counts, inside the scan)
+        if (fg_launch_scan((FgBlockResult *)c->results.p, piped ? PL.B.chunk_bits : nullptr, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
             fg_set_error("scan kernel launch failed"); return false;
         }
         if (first) mark();
@@ -574,6 +617,18 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         }
         if (first) mark();
         if (d_offsets && !asm_here && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
+        if (lean) {
+            // totals and error flags (offsets[nblocks .. +1]), guard counters (offsets[nblocks + 2 .. +3] when the assembly kernel
+            // parked them there, the guard words themselves otherwise)
+            const unsigned long long seq = ++c->sig_seq;
+            const unsigned long long *tl = (const unsigned long long *)c->offsets.p + nblocks;
+            const bool sep = use_pipe && !asm_here;
+            if (fg_launch_signal(tl, asm_here ? 4 : 2, sep ? PL.B.guard : nullptr, sep ? 2 : 0, (const unsigned long long *)c->stamp.p,
+                                 c->h_sig, seq, c->stream) != 0) return false;
+            if (!c->wait_signal(seq)) return false;
+            for (int k = 0; k < 4; k++) tail[k] = c->h_sig[2 + k];
+            return true;
+        }
         tail[0] = tail[1] = 0;
         if (hipMemcpyAsync(tail, (char *)c->offsets.p + (size_t)nblocks * 8, asm_here ? 32 : 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
         if (use_pipe && !asm_here && hipMemcpyAsync(tail + 2, PL.B.guard, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
@@ -606,15 +661,18 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     st->total_bytes = tail[0];
     st->error_flags = (uint32_t)tail[1] & ~FG_ERR_REDO;
-    if (use_pipe) {
+    if (piped) {        // (the autocorrelation kernel resets the counters: they mean something only when the pipeline ran)
         st->log_guard_subframes = (uint32_t)tail[2];
         double mm; memcpy(&mm, &tail[3], 8);
         st->lpc_order_min_margin = mm;
     }
     c->last_nblocks = nblocks;
     if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
-    HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
-    HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
+    if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);    // (encode_kernel_ms: levels 1, 2)
+    else {
+        HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
+        HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
+    }
     if (timing) {
         // analysis, packing, sizes + scan, assembly
         for (int k = 0; k + 1 < nev; k++) (void)hipEventElapsedTime(&st->stage_ms[k], c->evs[k], c->evs[k + 1]);

@@ -28,14 +28,19 @@ uint32_t fg_pipe_block_ws(uint32_t n);
 size_t fg_pipe_scratch_bytes(const FgEncParams *P, uint32_t nblocks);
 void fg_pipe_carve(const FgEncParams *P, uint32_t nblocks, void *base, FgPipeBufs *B);
 int fg_launch_encode_pipe(const FgPipeLaunch *L);
-int fg_launch_pipe_sizes(const FgBlockDesc *d_descs, uint32_t npipe, const uint32_t *d_chunk_bits, uint32_t nw, FgBlockResult *d_results,
-                         hipStream_t stream);
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
                             unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream);
 int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes, hipStream_t stream);
-int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
+// end-of-call hand-over through pinned memory (flac_enc_kernels.hip)
+int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream);
+int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
+                     const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream);
+int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
+                     const unsigned long long *src1, uint32_t n1, const unsigned long long *d_stamp, unsigned long long *h_sig,
+                     unsigned long long seq, hipStream_t stream);
+int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
                    const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap);
 int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
@@ -88,11 +93,19 @@ struct flacgpu_ctx {
     hipEvent_t evx[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing
-    bool stage_timing = false;
+    int stage_timing = 0;            // 0: no events (end of call through the pinned signal area, GPU time from wall-clock stamps),
+                                     // 1: HIP events around the call and its kernel groups, 2: also between the encoder's stages
+    unsigned long long *h_sig = nullptr;   // pinned: [0] sequence number, [2..10) payload, [10] start stamp, [11] end stamp
+    unsigned long long sig_seq = 0;
+    double wall_khz = 100000.0;      // rate of the device's constant wall clock
+    DevBuf stamp;
+    bool wait_signal(unsigned long long seq);   // poll h_sig[0] (bounded), then hipStreamSynchronize; false on a device error
     double log_guard_thr = 1e-6;
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
         dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, pipe;
+    std::vector<unsigned char> desc_key;   // settings + stream list the block list in `dev_descs` was built for
+    uint32_t desc_nfast = 0, desc_nws2 = 0;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`
     const void *dev_descs_ptr = nullptr;
     std::vector<float> h_windows;

@@ -554,28 +554,47 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
 // Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.  Frames that would
 // end past `cap` samples are rejected here (bytes = 0), so the decode kernels can be queued before the host has seen the
 // total: it finds totals[0] > cap afterwards and reports the short buffer.
-__global__ void fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap)
+// (one workgroup of 1024 threads, tiles of 4096 frames: block sizes fetched into LDS, four neighbours per thread, one
+// workgroup scan per tile)
+#define FG_DSCAN_TILE 4096
+__global__ void __launch_bounds__(1024)
+fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap)
 {
     __shared__ u64 wtot[16];
     __shared__ uint32_t maxn;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t per = (nframes + nt - 1) / nt;
-    const uint32_t b0 = tid * per < nframes ? tid * per : nframes, b1 = (b0 + per) < nframes ? (b0 + per) : nframes;
+    __shared__ uint32_t sz[FG_DSCAN_TILE];
+    const uint32_t tid = threadIdx.x;
     if (tid == 0) maxn = 0;
-    __syncthreads();
-    u64 s = 0;
     uint32_t m = 0;
-    for (uint32_t b = b0; b < b1; b++) { s += frames[b].n; m = frames[b].n > m ? frames[b].n : m; }
-    atomicMax(&maxn, m);
-    u64 total;
-    u64 run = fgdev::block_scan_excl_u64(s, wtot, &total);
-    if (tid == 0) { totals[0] = total; totals[1] = maxn; }
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t nb = frames[b].n;
-        if (run + nb > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
-        else frames[b].out_off = run;
-        run += nb;
+    u64 carry = 0;
+    for (uint32_t t0 = 0; t0 < nframes; t0 += FG_DSCAN_TILE) {
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < FG_DSCAN_TILE / 1024; j++) {
+            const uint32_t b = t0 + j * 1024 + tid;
+            const uint32_t nb = b < nframes ? frames[b].n : 0;
+            m = nb > m ? nb : m;
+            sz[j * 1024 + tid] = nb;
+        }
+        __syncthreads();
+        const uint4 v = *(const uint4 *)&sz[tid * 4];
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        u64 total;
+        u64 run = carry + fgdev::block_scan_excl_u64((u64)v.x + v.y + v.z + v.w, wtot, &total);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t b = t0 + tid * 4 + j;
+            if (b < nframes) {
+                if (run + vv[j] > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
+                else frames[b].out_off = run;
+            }
+            run += vv[j];
+        }
+        carry += total;
     }
+    atomicMax(&maxn, m);
+    __syncthreads();
+    if (tid == 0) { totals[0] = carry; totals[1] = maxn; }
 }
 
 // First index at which two int32 arrays differ (0xFFFFFFFFFFFFFFFF if none): the encoder's verify pass compares what the

@@ -1227,23 +1227,56 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
 
 // ------------------------------------------------------------------ compaction: slots -> contiguous stream
 // offsets[b] = sum of bytes of blocks < b (exclusive), offsets[nblocks] = total, offsets[nblocks+1] = OR of errors.
-__global__ void fg_scan_sizes_kernel(const FgBlockResult *results, uint32_t nblocks, u64 *offsets)
+// One workgroup of 1024 threads walks the blocks in tiles of 4096: the sizes are fetched coalesced into LDS (a pipeline
+// block -- results.reserved == 4 -- gets its size here, from the bit counts of its four chunks: ceil(sum / 8) + 2 for the
+// CRC-16), every thread then sums four neighbours, one workgroup scan per tile, carry into the next tile.
+#define FG_SCAN_TILE 4096
+__global__ void __launch_bounds__(1024)
+fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets)
 {
     __shared__ u64 wtot[16];
     __shared__ uint32_t errs;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t per = (nblocks + nt - 1) / nt;
-    const uint32_t b0 = tid * per < nblocks ? tid * per : nblocks, b1 = (b0 + per) < nblocks ? (b0 + per) : nblocks;
-    u64 s = 0;
-    uint32_t e = 0;
+    __shared__ uint32_t sz[FG_SCAN_TILE];
+    const uint32_t tid = threadIdx.x;
     if (tid == 0) errs = 0;
-    __syncthreads();
-    for (uint32_t b = b0; b < b1; b++) { s += results[b].bytes; e |= results[b].err; }
+    uint32_t e = 0;
+    u64 carry = 0;
+    for (uint32_t t0 = 0; t0 < nblocks; t0 += FG_SCAN_TILE) {
+        __syncthreads();                    // (previous tile's readers are done with sz[]; errs initialised)
+#pragma unroll
+        for (uint32_t j = 0; j < FG_SCAN_TILE / 1024; j++) {
+            const uint32_t b = t0 + j * 1024 + tid;
+            uint32_t bytes = 0;
+            if (b < nblocks) {
+                const uint4 r = *(const uint4 *)&results[b];               // bytes, ca, err, best_bits[0]
+                const uint32_t kind = results[b].reserved;
+                bytes = r.x;
+                e |= r.z;
+                if (chunk_bits && kind == 4) {
+                    const uint4 cb = *(const uint4 *)&chunk_bits[(size_t)b * 4];
+                    bytes = (r.z & FG_ERR_REDO) ? 0u : ((cb.x + cb.y + cb.z + cb.w + 7) >> 3) + 2;
+                    results[b].bytes = bytes;
+                }
+            }
+            sz[j * 1024 + tid] = bytes;
+        }
+        __syncthreads();
+        const uint4 v = *(const uint4 *)&sz[tid * 4];
+        u64 total;
+        u64 run = carry + fgdev::block_scan_excl_u64((u64)v.x + v.y + v.z + v.w, wtot, &total);
+        const uint32_t b = t0 + tid * 4;
+        if (b < nblocks) offsets[b] = run;
+        run += v.x;
+        if (b + 1 < nblocks) offsets[b + 1] = run;
+        run += v.y;
+        if (b + 2 < nblocks) offsets[b + 2] = run;
+        run += v.z;
+        if (b + 3 < nblocks) offsets[b + 3] = run;
+        carry += total;
+    }
     if (e) atomicOr(&errs, e);
-    u64 total;
-    u64 run = fgdev::block_scan_excl_u64(s, wtot, &total);
-    if (tid == 0) { offsets[nblocks] = total; offsets[nblocks + 1] = errs; }
-    for (uint32_t b = b0; b < b1; b++) { offsets[b] = run; run += results[b].bytes; }
+    __syncthreads();
+    if (tid == 0) { offsets[nblocks] = carry; offsets[nblocks + 1] = errs; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -1274,6 +1307,43 @@ fg_compact_kernel(const uint8_t *slots, uint32_t slot_bytes, const FgBlockResult
     if (threadIdx.x < nb - done) d[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
+
+// ------------------------------------------------------------------ end-of-call hand-over to the host
+// The batch calls end with one tiny kernel instead of device-to-host copies, an event and a stream synchronisation: it writes
+// the few words the host wants (totals, error flags, counters) and two time stamps (constant-rate wall clock) into a pinned
+// landing area and then raises a sequence number there, which the host polls.  The stream orders it behind every kernel
+// of the call.  host[0] = sequence, host[2 .. 10) = payload, host[10] = start stamp, host[11] = end stamp.
+__global__ void fg_stamp_kernel(u64 *stamp)
+{
+    if (threadIdx.x == 0) stamp[0] = wall_clock64();
+}
+
+__device__ __forceinline__ void fg_signal_tail(const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1, const u64 *stamp, u64 *host, u64 seq)
+{
+    for (uint32_t i = 0; i < n0; i++) host[2 + i] = src0[i];
+    for (uint32_t i = 0; i < n1; i++) host[2 + n0 + i] = src1[i];
+    host[10] = stamp ? stamp[0] : 0;
+    host[11] = wall_clock64();
+    __threadfence_system();
+    __hip_atomic_store(&host[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void fg_signal_kernel(const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1, const u64 *stamp, u64 *host, u64 seq)
+{
+    if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
+}
+
+// the decoder's variant: the per-frame status words (8 bytes a frame) travel too
+__global__ void __launch_bounds__(1024)
+fg_export_kernel(const u64 *rows, uint32_t nrows, u64 *host_rows, const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1,
+                 const u64 *stamp, u64 *host, u64 seq)
+{
+    for (uint32_t i = threadIdx.x; i < nrows; i += 1024) host_rows[i] = rows[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host-callable launchers (C ABI, used by flacgpu_api.cpp)
@@ -1296,6 +1366,29 @@ size_t fg_enc_lds_bytes(const FgEncParams *P)
     add(128 * 4);
     add(sizeof(Dec) * 8);
     return off;
+}
+
+int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_stamp_kernel, dim3(1), dim3(64), 0, stream, (u64 *)d_stamp);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
+                     const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_signal_kernel, dim3(1), dim3(64), 0, stream, (const u64 *)src0, n0, (const u64 *)src1, n1, (const u64 *)d_stamp,
+                       (u64 *)h_sig, (u64)seq);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
+                     const unsigned long long *src1, uint32_t n1, const unsigned long long *d_stamp, unsigned long long *h_sig,
+                     unsigned long long seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_export_kernel, dim3(1), dim3(1024), 0, stream, (const u64 *)d_rows, nrows, (u64 *)h_rows, (const u64 *)src0, n0,
+                       (const u64 *)src1, n1, (const u64 *)d_stamp, (u64 *)h_sig, (u64)seq);
+    return (int)hipGetLastError();
 }
 
 int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream)
@@ -1335,10 +1428,10 @@ int fg_launch_widen16(const int16_t *d_src, int32_t *d_dst, unsigned long long n
     return (int)hipGetLastError();
 }
 
-int fg_launch_scan(const FgBlockResult *d_results, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream)
+int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream)
 {
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, nblocks, d_offsets);
+    hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, d_offsets);
     return (int)hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 // flac_enc_pipe.hip -- dispatcher over the de-fused encoder pipeline (flac_enc_pipe_impl.h, pipe_*.hip) and the launchers of
-// its shape-independent kernels (frame sizes, chunk assembly + CRC-16).
+// its shape-independent kernel (chunk assembly + CRC-16; the frame sizes come out of the scan, flac_enc_kernels.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -73,14 +73,6 @@ int fg_launch_encode_pipe(const FgPipeLaunch *L)
     if (nch == 2 && ms) { if (maxo == 8) FG_CALLP(ms_o8); else FG_CALLP(ms_o12); }
     else if (nch == 2) { if (maxo == 8) FG_CALLP(st_o8); else FG_CALLP(st_o12); }
     else { if (maxo == 8) FG_CALLP(mono_o8); else FG_CALLP(mono_o12); }
-}
-
-int fg_launch_pipe_sizes(const FgBlockDesc *d_descs, uint32_t npipe, const uint32_t *d_chunk_bits, uint32_t nw, FgBlockResult *d_results,
-                         hipStream_t stream)
-{
-    if (npipe == 0) return 0;
-    hipLaunchKernelGGL(fg_pipe_sizes_kernel, dim3((npipe + 255) / 256), dim3(256), 0, stream, d_descs, npipe, d_chunk_bits, nw, d_results);
-    return (int)hipGetLastError();
 }
 
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,

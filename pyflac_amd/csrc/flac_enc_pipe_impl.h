@@ -162,6 +162,8 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wv = rfl(threadIdx.x >> 6);
     const uint32_t bi = blockIdx.x * FGP_AWPB + wv;
+    // near-tie guard of the LPC order guess (Levinson-Durbin kernel, next launch): count 0, smallest margin +infinity
+    if (blockIdx.x == 0 && threadIdx.x == 0 && B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; }
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
     const int lane = threadIdx.x & 63;
@@ -1203,7 +1205,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
 #pragma unroll
             for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
-            for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)bi * 4 + w] = 0;     // the packing waves fill in theirs
+            for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)d.out_slot * 4 + w] = 0;     // the packing waves fill in theirs
         }
     }
     if (d_type >= 2 && d_kvalid) dec->k[d_kpart] = (uint8_t)d_k;
@@ -1591,22 +1593,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     }
     if (!redo) cb_flush(fb, lane, bitpos, true);
     if (lane == 0) {
-        B.chunk_bits[(size_t)bi * 4 + chunk] = redo ? 0 : bitpos;
+        B.chunk_bits[(size_t)d.out_slot * 4 + chunk] = redo ? 0 : bitpos;
         const uint32_t e = fb.err | (redo ? FG_ERR_REDO : 0u);
         if (e) atomicOr(&results[d.out_slot].err, e);
     }
-}
-
-// ================================================================================================ sizes of the pipeline's frames
-// bytes of frame = ceil(sum of chunk bits / 8) + 2 (CRC-16); written into the block results the scan kernel reads
-__global__ void fg_pipe_sizes_kernel(const FgBlockDesc *descs, uint32_t npipe, const uint32_t *chunk_bits, uint32_t nw, FgBlockResult *results)
-{
-    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bi >= npipe) return;
-    uint32_t bits = 0;
-    for (uint32_t w = 0; w < nw; w++) bits += chunk_bits[(size_t)bi * 4 + w];
-    FgBlockResult *r = &results[descs[bi].out_slot];
-    r->bytes = (r->err & FG_ERR_REDO) ? 0 : ((bits + 7) >> 3) + 2;
 }
 
 // ================================================================================================ K6: chunks -> frame at its final place
@@ -1652,7 +1642,7 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
     uint32_t T = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const uint32_t b = (uint32_t)w < nw ? chunk_bits[(size_t)bi * 4 + w] : 0;
+        const uint32_t b = (uint32_t)w < nw ? chunk_bits[(size_t)d.out_slot * 4 + w] : 0;
         S[w] = T; Bc[w] = b; T += b;
         cw[w] = (const uint32_t *)(slots + (size_t)d.out_slot * slot_bytes) + (size_t)w * chunk_cap_words;
     }

@@ -398,7 +398,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         return false;
     unsigned long long *d_off = (unsigned long long *)c->offsets.p;
     unsigned long long *d_tot = d_off + nframes + 1;
-    if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
+    // end of call and timing as in the encoder (fg_ctx.cpp): level 0 = stamp kernel in front, export kernel at the end (status
+    // words, totals and stamps into pinned memory, the host polls a sequence number), no events; levels 1, 2 = HIP events
+    static const bool want_prof = getenv("FLACGPU_DEC_PROF") != nullptr;
+    const bool lean = c->stage_timing == 0 && !h_frames && !detail && !want_prof;
+    if (lean) { if (fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; } }
+    else if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
         if (!c->dec_info.ensure(64 + (size_t)nframes * 8)) return false;
@@ -409,7 +414,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         }
         // (the end of the last frame, offsets[nframes] = len, is set by the index kernel)
         if (d_offsets_out && !HIPOK(hipMemcpyAsync(d_offsets_out, d_off, ((size_t)nframes + 1) * 8, hipMemcpyDeviceToDevice, c->stream))) return false;
-        (void)hipEventRecord(c->ev[3], c->stream);
+        if (!lean) (void)hipEventRecord(c->ev[3], c->stream);
     }
     else if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
     if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
@@ -432,10 +437,9 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (!c->dec_scratch.ensure(queued ? (size_t)cap_bytes : (size_t)std::max<uint64_t>(tot[0], 1) * C * 4 + 256) ||
         !c->dec_subs.ensure((size_t)npad * C * sizeof(FgDecSub)))
         return false;
-    if (!HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
+    if (!lean && !HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
     const int wide = (bps_hint == 0 || bps_hint > 16) ? 1 : 0;
     // FLACGPU_DEC_PROF=1: per-wave clock64() totals of the kernel stages, averaged and printed to stderr (tuning aid)
-    static const bool want_prof = getenv("FLACGPU_DEC_PROF") != nullptr;
     unsigned long long *d_prof = nullptr;
     if (want_prof && c->dec_prof.ensure((size_t)npad * 2 * 8 * 8)) {
         d_prof = (unsigned long long *)c->dec_prof.p;
@@ -480,7 +484,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             fg_set_error("decode kernel launch failed"); return false;
         }
     }
-    if (!HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
+    if (!lean && !HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
     if (detail && detail->level >= 1) {
         if (!fused && fg_launch_decode_warmup((const FgDecFrame *)c->dec_frames.p, nframes, C, (const FgDecSub *)c->dec_subs.p, (const int32_t *)c->dec_scratch.p,
                                     (int32_t *)c->dec_warm.p, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
@@ -490,17 +494,27 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             !HIPOK(hipMemcpyAsync(detail->warm.data(), c->dec_warm.p, detail->warm.size() * 4, hipMemcpyDeviceToHost, c->stream))) return false;
     }
     FgDecResult *res = (FgDecResult *)((char *)c->h_res + 64);
-    if (queued && !HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream))) return false;
-    if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
-    if (h_frames) {
-        h_frames->resize(nframes);
-        if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
-    }
     unsigned long long *hinfo2 = (unsigned long long *)((char *)c->h_res + 32);
-    if (index_here && !HIPOK(hipMemcpyAsync(hinfo2, c->dec_info.p, 32, hipMemcpyDeviceToHost, c->stream))) return false;
-    if (!HIPOK(fg_stream_wait(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    if (lean) {
+        const unsigned long long seq = ++c->sig_seq;
+        if (fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
+                             index_here ? 4 : 0, (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream) != 0 ||
+            !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
+        tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
+        for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
+    }
+    else {
+        if (queued && !HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream))) return false;
+        if (!HIPOK(hipMemcpyAsync(res, c->dec_results.p, (size_t)nframes * sizeof(FgDecResult), hipMemcpyDeviceToHost, c->stream))) return false;
+        if (h_frames) {
+            h_frames->resize(nframes);
+            if (!HIPOK(hipMemcpyAsync(h_frames->data(), c->dec_frames.p, (size_t)nframes * sizeof(FgDecFrame), hipMemcpyDeviceToHost, c->stream))) return false;
+        }
+        if (index_here && !HIPOK(hipMemcpyAsync(hinfo2, c->dec_info.p, 32, hipMemcpyDeviceToHost, c->stream))) return false;
+        if (!HIPOK(fg_stream_wait(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+    }
     if (index_here) {
-        (void)hipEventElapsedTime(&st->index_ms, c->ev[0], c->ev[3]);
+        if (!lean) (void)hipEventElapsedTime(&st->index_ms, c->ev[0], c->ev[3]);
         if (hinfo2[1]) { fg_set_error("ambiguous frame sync (several headers claim one frame number and their order does not decide): use flacgpu_index_frames"); return false; }
     }
     st->total_samples = tot[0];
@@ -541,8 +555,11 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             }
         }
     }
-    (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);
+    if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);     // (decode_kernel_ms, index_ms: levels 1, 2)
+    else {
+        (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);
+    }
     uint32_t bad = 0;
     for (uint32_t i = 0; i < nframes; i++) if (res[i].err) bad++;
     st->error_frames = bad;

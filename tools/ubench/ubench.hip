@@ -222,6 +222,62 @@ BENCH_BEGIN(k_rice_step_v3)
     a = w0 + w1 + w2 + w3 + sm;
 BENCH_END
 
+// does a wave with few active lanes issue faster?  (EXEC = 16 / 32 lanes around a dependent chain)
+BENCH_BEGIN(k_dep_add_exec16)
+    asm volatile("s_mov_b64 exec, 0xffff\n .rept " STR(REP) "\n v_add_u32 %0, %0, %1\n .endr\n s_mov_b64 exec, -1" : "+v"(a) : "v"(b));
+BENCH_END
+
+BENCH_BEGIN(k_dep_add_exec32)
+    asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 exec_hi, 0\n .rept " STR(REP) "\n v_add_u32 %0, %0, %1\n .endr\n s_mov_b64 exec, s[20:21]" : "+v"(a) : "v"(b) : "s20", "s21");
+BENCH_END
+
+BENCH_BEGIN(k_rice_step_v3_exec16)
+    uint32_t w0 = a, w1 = b, w2 = c, w3 = d, sm = 5, smk = 3, lz, p, wb = threadIdx.x * 4, u0, u1;
+    asm volatile("s_mov_b64 exec, 0xffff\n .rept " STR(REP) "\n"
+        "v_alignbit_b32 %[p], %[w0], %[w1], %[sm]\n"
+        "v_ffbh_u32 %[lz], %[p]\n"
+        "v_and_b32 %[lz], 15, %[lz]\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "v_perm_b32 %[t1], 0, %[w3], %[sel]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "v_cndmask_b32 %[w1], %[w1], %[w2], vcc\n"
+        "v_cndmask_b32 %[w2], %[w2], %[t1], vcc\n"
+        "v_addc_co_u32 %[wb], vcc, %[wb], %[wb], vcc\n"
+        "v_and_b32 %[t0], 0x3fc, %[wb]\n"
+        "ds_read_b32 %[w3], %[t0]\n"
+        "v_sub_u32 %[sm], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[sm]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        ".endr\n s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, -1"
+        : [w0]"+v"(w0), [w1]"+v"(w1), [w2]"+v"(w2), [w3]"+v"(w3), [sm]"+v"(sm), [smk]"+v"(smk), [lz]"=&v"(lz), [p]"=&v"(p), [wb]"+v"(wb), [t0]"=&v"(u0), [t1]"=&v"(u1)
+        : [sel]"s"(0x00010203u), [kp1]"v"(11u) : "vcc", "memory");
+    a = w0 + w1 + w2 + w3 + sm;
+BENCH_END
+
+// the delimiting step without the LDS read (how much of v3 is the read's latency?)
+BENCH_BEGIN(k_rice_step_nolds)
+    uint32_t w0 = a, w1 = b, w2 = c, w3 = d, sm = 5, smk = 3, lz, p, wb = threadIdx.x * 4, u0, u1;
+    asm volatile(".rept " STR(REP) "\n"
+        "v_alignbit_b32 %[p], %[w0], %[w1], %[sm]\n"
+        "v_ffbh_u32 %[lz], %[p]\n"
+        "v_and_b32 %[lz], 15, %[lz]\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "v_perm_b32 %[t1], 0, %[w3], %[sel]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "v_cndmask_b32 %[w1], %[w1], %[w2], vcc\n"
+        "v_cndmask_b32 %[w2], %[w2], %[t1], vcc\n"
+        "v_addc_co_u32 %[wb], vcc, %[wb], %[wb], vcc\n"
+        "v_and_b32 %[t0], 0x3fc, %[wb]\n"
+        "v_xor_b32 %[w3], %[t0], %[w3]\n"
+        "v_sub_u32 %[sm], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[sm]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        ".endr\n"
+        : [w0]"+v"(w0), [w1]"+v"(w1), [w2]"+v"(w2), [w3]"+v"(w3), [sm]"+v"(sm), [smk]"+v"(smk), [lz]"=&v"(lz), [p]"=&v"(p), [wb]"+v"(wb), [t0]"=&v"(u0), [t1]"=&v"(u1)
+        : [sel]"s"(0x00010203u), [kp1]"v"(11u) : "vcc", "memory");
+    a = w0 + w1 + w2 + w3 + sm;
+BENCH_END
+
 BENCH_BEGIN(k_fmac64_dpp)
     asm volatile(".rept " STR(REP) "\n v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n .endr" : "+v"(fa) : "v"(fb));
 BENCH_END
@@ -292,6 +348,8 @@ int main()
         {"dependent v_fmac_f64_dpp row_newbcast", k_fmac64_dpp, 1}, {"2 x v_mov_b32_dpp + v_fma_f64 (x3)", k_fma64_bcast_movs, 3},
         {"rice step v1 (saveexec + skip branch)", k_rice_step_v1, 1}, {"rice step v2 (saveexec, no branch)", k_rice_step_v2, 1},
         {"rice step v3 (selects, unconditional LDS read)", k_rice_step_v3, 1},
+        {"dependent v_add_u32, EXEC = 16 lanes", k_dep_add_exec16, 1}, {"dependent v_add_u32, EXEC = 32 lanes", k_dep_add_exec32, 1},
+        {"rice step v3, EXEC = 16 lanes", k_rice_step_v3_exec16, 1}, {"rice step v3 without the LDS read", k_rice_step_nolds, 1},
         {"dependent DPP v_add row_shr", k_dpp_dep, 1}, {"loop: v_add + s_sub + s_cmp + s_cbranch (x4)", k_loop_branch, 4},
     };
     for (int nwg : {1, 1280}) {
