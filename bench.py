@@ -145,6 +145,7 @@ def main():
     ap.add_argument('--level', type=int, default=None, help='compression level (default 5; 8 for --workload stream24)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
+    ap.add_argument('--no-passes', action='store_true', help='skip the event passes after the timed loop (profiling runs: the trace then holds the timed loop only)')
     ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted'], default='stream16',
                     help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz level 8; '
                          'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each); '
@@ -264,7 +265,7 @@ def main():
     L.flacgpu_set_stage_timing(ctx._h, 1)
     enc_ms = dec_ms = enc_tot = dec_tot = idx_ms = 0.0
     KE = max(1, min(K, 100))
-    for _ in range(KE):
+    for _ in range(0 if args.no_passes else KE):
         est, dst, status = step()
         enc_ms += est.encode_kernel_ms
         enc_tot += est.total_gpu_ms
@@ -274,7 +275,7 @@ def main():
     enc_k, dec_k, enc_t, dec_t, idx_ms = enc_ms / KE, dec_ms / KE, enc_tot / KE, dec_tot / KE, idx_ms / KE
     L.flacgpu_set_stage_timing(ctx._h, 2)
     stage = np.zeros(4)
-    for _ in range(5):
+    for _ in range(0 if args.no_passes else 5):
         e2, _d2, _s2 = step()
         stage += np.array(list(e2.stage_ms)[:4])
     stage /= 5

@@ -176,6 +176,7 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     if (hipHostMalloc((void **)&c->h_sig, 128, hipHostMallocDefault) != hipSuccess) { fg_set_error("hipHostMalloc failed"); return false; }
     memset(c->h_sig, 0, 128);
     if (!c->stamp.ensure(64)) return false;
+    HIPCHK(hipMemset(c->stamp.p, 0, 64));
     {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_khz = (double)khz;
@@ -549,7 +550,12 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     const bool timing = c->stage_timing >= 2 && use_pipe;
     int nev = 0;
     auto mark = [&]() { if (timing && nev < 8) (void)hipEventRecord(c->evs[nev++], c->stream); };
-    if (lean) { if (fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; } }
+    PL.B.stamp = nullptr;
+    if (lean) {
+        // (the pipeline's first kernel takes the stamp itself)
+        if (nfast && use_pipe) PL.B.stamp = (unsigned long long *)c->stamp.p;
+        else if (fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; }
+    }
     else HIPCHK(hipEventRecord(c->ev[0], c->stream));
     const bool side = nfast > 0 && nblocks > nfast;     // overlap the few generic blocks with the fast launch
     if (side) {

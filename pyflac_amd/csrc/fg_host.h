@@ -32,13 +32,14 @@ int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const 
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
                             unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream);
-int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes, hipStream_t stream);
+int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes,
+                             unsigned long long *d_stamp, hipStream_t stream);
 // end-of-call hand-over through pinned memory (flac_enc_kernels.hip)
 int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream);
 int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
                      const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream);
 int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
-                     const unsigned long long *src1, uint32_t n1, const unsigned long long *d_stamp, unsigned long long *h_sig,
+                     const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
                      unsigned long long seq, hipStream_t stream);
 int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
@@ -57,7 +58,7 @@ int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const Fg
                           uint16_t *d_rparams, hipStream_t stream);
 int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                            int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                           int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, hipStream_t stream);
+                           int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream);
 int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results, int32_t *d_pcm, hipStream_t stream);
 int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const FgDecSub *d_subs,
                             const int32_t *d_scratch, int32_t *d_warm, hipStream_t stream);

@@ -87,8 +87,9 @@ struct FgPipeBufs {
     int32_t *qres;         // [block][cand][nvec][MAXO]                          K3 -> K4
     uint32_t *lres;        // [block][cand][nvec]                                K3 -> K4
     FgPipeDec *dec;        // [block][cand]                                      K4 -> K5
-    uint32_t *chunk_bits;  // [block][4]                                         K5 -> sizes, K6
+    uint32_t *chunk_bits;  // [slot][4]                                          K5 -> size scan, K6
     unsigned long long *guard;   // [0] order guesses re-done with the exact log, [1] smallest margin seen (double bits)
+    unsigned long long *stamp;   // when set: K2 leaves the start-of-call wall-clock stamp here (fg_signal_kernel reads it)
 };
 
 struct FgPipeLaunch {

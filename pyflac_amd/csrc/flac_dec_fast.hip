@@ -33,6 +33,8 @@ using namespace fgdev;
 #define FG_TSTR 68          // its LDS row stride (words): 16-byte aligned rows, neighbouring lanes 4 banks apart
 #define FG_DEC_RPARAMS 256  // Rice parameters kept per subframe for FLAC__Frame.subframes[] (partition order <= 8)
 
+#define FG_LDSP __attribute__((address_space(3)))
+
 namespace {
 
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
@@ -44,14 +46,19 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v)
     return v;
 }
 
-// MSB-first bit reader.  The window is w0, w1 with w2 (byte-swapped) and w3 (raw, just requested from LDS) queued behind; `s` in
+// MSB-first bit reader.  The window is w0, w1 with w2 and w3 (just requested from LDS) queued behind; `s` in
 // [0, 31] is 32 minus the bit offset into w0 (offset 1..32), so peek() is one v_alignbit and always returns 32 valid
 // bits, and consuming up to 32 bits advances by at most one word.  The stream reaches the lane through a private ring
 // of 16-byte groups in LDS:
 //   * HBM -> registers: every lane loads the next few aligned groups of its own frame at the start of a residual tile
 //     (issue()), with wave-uniform control flow, and parks them in the ring one tile later (land()) -- the memory
-//     latency is covered by a whole tile of parsing and never sits inside the per-code loop;
-//   * ring -> window: one ds_read per 32 bits consumed, one word ahead of its use.
+//     latency is covered by a whole tile of parsing and never sits inside the per-code loop.  (A row-by-row refill --
+//     64 lanes load 64 consecutive groups of ONE frame, coalesced -- was tried and is slower: the scalar bookkeeping
+//     per visited row costs more than the eight divergent loads it saves.)
+//   * ring -> window: one ds_read per 32 bits consumed, one word ahead of its use.  The ring holds the words already
+//     byte-swapped (big-endian stream -> register order, done once per group when it is parked), and its first FG_RMIR
+//     groups are repeated behind its end, so that the per-code loop of a tile (at most 256 bytes further) reads on
+//     without wrapping its address.
 // Groups are aligned to 16 bytes in memory, so a load never straddles a page and the group that holds the last stream
 // byte is the last one touched (indices are clamped to it).  consume() checks that the ring holds the next word and
 // fetches synchronously if not (headers, escapes, very long codes); consume_fast() relies on the tile-start
@@ -59,7 +66,8 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v)
 typedef uint32_t fg_u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) fg_u32x4 *FgGroupPtr;
 #define FG_RG 64                      // ring capacity in groups (1 KiB per lane)
-#define FG_RSTR (FG_RG * 4)           // ring row stride in words
+#define FG_RMIR 20                    // groups repeated behind the end (a tile's 256 bytes + the look-ahead words)
+#define FG_RSTR ((FG_RG + FG_RMIR) * 4)   // ring row stride in words
 #define FG_RAHEAD 20                  // groups guaranteed ahead of the read position at a tile start
 #define FG_RCAP 52                    // never hold more than this many groups ahead
 #define FG_PF 8                       // groups fetched per lane and tile
@@ -79,10 +87,17 @@ struct BitRd {
     fg_u32x4 pf[FG_PF];
 
     __device__ __forceinline__ fg_u32x4 ldgroup(uint32_t g) const { return fg[g < glim ? g : glim]; }
+    // group g of the frame into its ring slot (and the slot's repeat behind the end), words in register order
+    __device__ __forceinline__ void park(uint32_t g, fg_u32x4 v)
+    {
+        v.x = be32(v.x); v.y = be32(v.y); v.z = be32(v.z); v.w = be32(v.w);
+        const uint32_t slot = g & (FG_RG - 1);
+        *(fg_u32x4 *)&ring[slot * 4] = v;
+        if (slot < FG_RMIR) *(fg_u32x4 *)&ring[(slot + FG_RG) * 4] = v;
+    }
     __device__ __forceinline__ void selfload()
     {
-        const fg_u32x4 v = ldgroup(H);
-        *(fg_u32x4 *)&ring[(H & (FG_RG - 1)) * 4] = v;
+        park(H, ldgroup(H));
         H++;
     }
     __device__ __forceinline__ uint32_t ringword() const { return *(const uint32_t *)((const char *)ring + (wb & (FG_RG * 16 - 1))); }
@@ -102,9 +117,9 @@ struct BitRd {
         const uint32_t w = b >> 5, sk = b & 31;
         wb = w * 4; H = w >> 2; pfH = H; pfn = 0; pfvalid = false;
         w0 = 0;
-        if (sk) w0 = be32(fetch());
-        w1 = be32(fetch());
-        w2 = be32(fetch());
+        if (sk) w0 = fetch();
+        w1 = fetch();
+        w2 = fetch();
         w3 = fetch();
         s = (32 - sk) & 31;
     }
@@ -114,7 +129,7 @@ struct BitRd {
     __device__ __forceinline__ void consume(uint32_t n)   // n <= 32
     {
         s -= n;
-        if ((int32_t)s < 0) { s += 32; w0 = w1; w1 = w2; w2 = be32(w3); w3 = fetch(); }
+        if ((int32_t)s < 0) { s += 32; w0 = w1; w1 = w2; w2 = w3; w3 = fetch(); }
     }
     // straight-line variant for the per-code loop (no availability check, see FG_RAHEAD)
     __device__ __forceinline__ void consume_fast(uint32_t n)
@@ -124,7 +139,7 @@ struct BitRd {
         s &= 31;
         w0 = adv ? w1 : w0;
         w1 = adv ? w2 : w1;
-        if (adv) { w2 = be32(w3); w3 = ringword(); wb += 4; }
+        if (adv) { w2 = w3; w3 = ringword(); wb += 4; }
     }
     __device__ __forceinline__ uint32_t bits(uint32_t n)   // n <= 32
     {
@@ -156,14 +171,16 @@ struct BitRd {
     {
         if (fg && pfvalid) {       // lanes without a frame own no ring; nothing was requested before the first tile
 #pragma unroll
-            for (int t = 0; t < FG_PF; t++) *(fg_u32x4 *)&ring[((pfH + t) & (FG_RG - 1)) * 4] = pf[t];
+            for (int t = 0; t < FG_PF; t++) park(pfH + t, pf[t]);
         }
         const uint32_t h2 = pfH + pfn;
         H = h2 > H ? h2 : H;
         pfn = 0;
     }
     // tile start, step 2: guarantee the look-ahead of the lanes that will parse, then request the next FG_PF groups
-    // (straight-line code: one address, FG_PF loads; a lane that is far enough ahead simply does not count them)
+    // (straight-line code: one address, FG_PF loads; a lane that is far enough ahead simply does not count them.  A
+    // request count that follows the consumption -- fewer loads and parks on most tiles -- was tried: the conditional
+    // loads cost more in waits than they save.)
     __device__ __forceinline__ void issue(bool on)
     {
         const uint32_t cg = wb >> 4;
@@ -427,40 +444,56 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
                         br.save(keep);
                         // Per code: lz = leading zeros of the window, length = lz + k + 1.  The dependent chain is kept
                         // short: the word advance is decided by comparing lz with (s - k - 1), prepared one code earlier.
+                        // The window here is w0, w1 with one word looked ahead: `addr` is the LDS address of that word's
+                        // ring slot, it moves on by a word with every advance and the slot is simply read again after every
+                        // code (the same word when nothing moved) -- selects instead of an EXEC-mask region, which costs
+                        // more.  The 64 codes are one block of assembly so that the order is ours: the ring read is issued
+                        // as soon as the advance is known and its result is used by the last instruction of the NEXT code
+                        // (two registers take the reads in turn), a code and a half of work over the LDS latency; the four
+                        // windows of a group sit in v[248:251] and leave with one ds_write_b128.
                         const uint32_t kp1 = k + 1;
-                        uint32_t lzmax = 0;
-                        uint32_t w0 = br.w0, w1 = br.w1, w2 = br.w2, w3 = br.w3, wb = br.wb - 4;      // wb: ring offset of w3's word
-                        uint32_t sm = br.s;
-                        int32_t smk = (int32_t)(sm - kp1);
-                        const char *rbase = (const char *)br.ring;
-#pragma unroll
-                        for (uint32_t jj = 0; jj < FG_TS; jj += 4) {
-                            uint32_t pw[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const uint32_t p = __builtin_amdgcn_alignbit(w0, w1, sm);
-                                uint32_t lz;
-                                asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(p));       // 0xFFFFFFFF for an all-zero window
-                                pw[u] = p;
-                                const bool adv = smk < (int32_t)lz;
-                                lzmax = lz > lzmax ? lz : lzmax;
-                                sm = (uint32_t)(smk - (int32_t)lz) & 31;
-                                smk = (int32_t)(sm - kp1);
-                                // word advance as selects, the queue tail re-read every code (same word when nothing
-                                // moved): no EXEC-mask region in the loop, which costs more than these few selects
-                                const uint32_t nx = be32(w3);
-                                w0 = adv ? w1 : w0;
-                                w1 = adv ? w2 : w1;
-                                w2 = adv ? nx : w2;
-                                wb += adv ? 4u : 0u;
-                                w3 = *(const uint32_t *)(rbase + (wb & (FG_RG * 16 - 1)));
-                            }
-                            *(uint4 *)(row + jj) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-                        }
+                        uint32_t w0 = br.w0, w1 = br.w1, na = br.w2, nb, tsh = br.s, pmin = 0xFFFFFFFFu, t_sm, t_lz, t_a4;
+                        int32_t smk = (int32_t)(br.s - kp1);
+                        const uint32_t a0 = (uint32_t)(uintptr_t)(const FG_LDSP char *)((const char *)br.ring + ((br.wb - 8) & (FG_RG * 16 - 1)));
+                        uint32_t addr = a0;
+                        const uint32_t rowa = (uint32_t)(uintptr_t)(FG_LDSP uint32_t *)row;
+#define FG_RC(P, A, B, N, EXTRA)                                                  \
+    "v_alignbit_b32 " P ", %[w0], %[w1], %[t]\n"                                  \
+    "v_ffbh_u32 %[lz], " P "\n"                                                   \
+    "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"                                           \
+    "v_cndmask_b32_e64 %[a4], 0, 4, vcc\n"                                        \
+    "v_add_u32 %[addr], %[addr], %[a4]\n"                                         \
+    "ds_read_b32 " B ", %[addr]\n" EXTRA                                          \
+    "v_sub_u32 %[t], %[smk], %[lz]\n"                                             \
+    "v_and_b32 %[sm], 31, %[t]\n"                                                 \
+    "v_sub_u32 %[smk], %[sm], %[kp1]\n"                                           \
+    "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"                                    \
+    "s_waitcnt lgkmcnt(" #N ")\n"                                                 \
+    "v_cndmask_b32 %[w1], %[w1], " A ", vcc\n"
+#define FG_WST(OFF) "ds_write_b128 %[row], v[248:251] offset:" #OFF "\n"
+#define FG_RG4(OFF)                                                                                          \
+    FG_RC("v248", "%[na]", "%[nb]", 2, "")                                                                   \
+    FG_RC("v249", "%[nb]", "%[na]", 1, "v_min3_u32 %[pmin], %[pmin], v248, v249\n")                          \
+    FG_RC("v250", "%[na]", "%[nb]", 1, "")                                                                   \
+    FG_RC("v251", "%[nb]", "%[na]", 2, FG_WST(OFF) "v_min3_u32 %[pmin], %[pmin], v250, v251\n")
+                        asm volatile(FG_RG4(0) FG_RG4(16) FG_RG4(32) FG_RG4(48) FG_RG4(64) FG_RG4(80) FG_RG4(96) FG_RG4(112)
+                                     FG_RG4(128) FG_RG4(144) FG_RG4(160) FG_RG4(176) FG_RG4(192) FG_RG4(208) FG_RG4(224) FG_RG4(240)
+                                     "s_waitcnt lgkmcnt(0)\n"
+                                     : [w0] "+v"(w0), [w1] "+v"(w1), [na] "+v"(na), [nb] "=&v"(nb), [t] "+v"(tsh), [smk] "+v"(smk), [pmin] "+v"(pmin),
+                                       [addr] "+v"(addr), [sm] "=&v"(t_sm), [lz] "=&v"(t_lz), [a4] "=&v"(t_a4)
+                                     : [row] "v"(rowa), [kp1] "v"(kp1)
+                                     : "vcc", "v248", "v249", "v250", "v251", "memory");
+#undef FG_RG4
+#undef FG_RC
+                        const uint32_t sm = tsh & 31;
+                        const bool toolong = pmin < (1u << (kp1 - 1));          // some code: leading zeros + k + 1 > 32 (or an all-zero window)
+                        const uint32_t w2 = na, w3 = *(const uint32_t *)((const char *)br.ring + ((br.wb - 4 + (addr - a0)) & (FG_RG * 16 - 1))),
+                                       wb = br.wb - 4 + (addr - a0);
+#undef FG_WST
                         // a code longer than the window (or an all-zero window) voids the attempt
-                        if (__any(lzmax > 32 - kp1)) br.restore(keep);
+                        if (__any(toolong)) br.restore(keep);
                         else { br.w0 = w0; br.w1 = w1; br.w2 = w2; br.w3 = w3; br.wb = wb + 4; br.s = sm; }
-                        if (!__any(lzmax > 32 - kp1)) { tk = k; ii = FG_TS; tp[5]++; } else tp[6]++;
+                        if (!__any(toolong)) { tk = k; ii = FG_TS; tp[5]++; } else tp[6]++;
                     }
                     if (ii < FG_TS) tp[7]++;
                     for (; ii < FG_TS; ii++) {
@@ -1057,7 +1090,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__(256)
 fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
                     int32_t *scratch, FgDecSub *subs, FgDecResult *results, uint16_t *rparams, int32_t *warm, int32_t *out,
-                    uint32_t interleave)
+                    uint32_t interleave, u64 *prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dsm[];
     FgParseLds L;
@@ -1072,22 +1105,27 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     if (wave == 0) {
-        fg_parse_wave<true>(stream, stream_len, frames, nframes, G, narrow, subs, results, nullptr, rparams, L, lane);
+        fg_parse_wave<true>(stream, stream_len, frames, nframes, G, narrow, subs, results, prof, rparams, L, lane);
         return;
     }
-    __syncthreads();
+    // FLACGPU_DEC_PROF=2: clock64() ticks every helper wave spends waiting at the tile barrier, and its total (tuning aid)
+    u64 pw_wait = 0, pw_t0 = prof ? clock64() : 0;
+#define FG_BAR() do { if (prof) { const u64 a_ = clock64(); __syncthreads(); pw_wait += clock64() - a_; } else __syncthreads(); } while (0)
+#define FG_PROF_END() do { if (prof && lane == 0) { u64 *pp_ = prof + ((size_t)((nframes + 63) & ~63u) + blockIdx.x) * 8 + wave * 2; pp_[0] = pw_wait; pp_[1] = clock64() - pw_t0; } } while (0)
+    FG_BAR();
     const uint32_t T = L.ctrl[0], tpc = L.ctrl[1];
     const uint32_t fbase = blockIdx.x * G;
     if (wave == 1) {
         // ---- converter: after barrier j, tile j - 1
         for (uint32_t j = 1; j <= T + 2; j++) {
-            __syncthreads();
+            FG_BAR();
             if (j <= T) {
                 const uint32_t it = j - 1;
                 fg_dec_convert_tile(L.tiles + (it & 1) * G * FG_TSTR, L.metas + (it & 1) * 64 * FG_META, G, (it % tpc) * FG_TS, lane,
                                     rt + (it % FG_RT) * (G + 1) * FG_TSTR, rnm + (it % FG_RT) * 64, warm, L.frm, fbase, it / tpc);
             }
         }
+        FG_PROF_END();
         return;
     }
     if (wave == 2) {
@@ -1099,7 +1137,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         int shift = 0;
         bool big = false;
         for (uint32_t j = 1; j <= T + 2; j++) {
-            __syncthreads();
+            FG_BAR();
             if (j < 2 || j > T + 1 || (interleave & 0x200)) continue;
             const uint32_t it = j - 2, ch = it / tpc, i0 = (it % tpc) * FG_TS;
             if (i0 == 0) {
@@ -1131,6 +1169,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 for (uint32_t g = 2; g < 8; g++) frestore_group<8, WIDE, false>(h, q, shift, order, 0, rowp + g * 8);
             }
         }
+        FG_PROF_END();
         return;
     }
     // ---- output: after barrier j, tile j - 3.
@@ -1140,11 +1179,22 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     const uint32_t nrnd = (G + 15) >> 4;
     uint32_t f_c[2] = {0, 0}, f_ca[2] = {0, 0}, f_n[2] = {0, 0}, f_w[2] = {0, 0};
     u64 f_oo[2] = {0, 0};
+    uint4 pa[2][4];                               // channel 0 of the tile that is next for the fast form (prefetched), per round
+    uint32_t pa_it[2] = {~0u, ~0u};               // ... and which tile that is
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) pa[R][t] = make_uint4(0, 0, 0, 0);
     const bool out_al = (((uintptr_t)out) & 15) == 0 && (((uintptr_t)scratch) & 15) == 0;
+    u64 pw_busy[2] = {0, 0}, pw_b0 = 0;
+    uint32_t pw_ch = 0;
     for (uint32_t j = 1; j <= T + 2; j++) {
-        __syncthreads();
+        if (prof && j > 3) pw_busy[pw_ch & 1] += clock64() - pw_b0;
+        FG_BAR();
+        if (prof) pw_b0 = clock64();
         if (j < 3 || (interleave & 0x100)) continue;
         const uint32_t it = j - 3, ch = it / tpc, i0 = (it % tpc) * FG_TS;
+        pw_ch = ch;
         const uint32_t *tile = rt + (it % FG_RT) * (G + 1) * FG_TSTR;
         const uint32_t *rn_ = rnm + (it % FG_RT) * 64;
         if (i0 == 0) {
@@ -1174,13 +1224,13 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         }
         if (ok_fast) {
             const uint32_t cq = ((uint32_t)lane & 3) * 16;
-            uint4 pa[2][4];
             bool live[2] = {false, false};
 #pragma unroll
             for (int R = 0; R < 2; R++) {
                 const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                 live[R] = (uint32_t)R < nrnd && row < G && rn_[row < G ? row : 0] > i0;
-                if (live[R] && ch == 1) {
+                // channel 0 of this stretch comes back from HBM: normally requested a tile ago (see the end of this block)
+                if (live[R] && ch == 1 && pa_it[R] != it) {
                     const uint4 *src = (const uint4 *)(scratch + f_oo[R] * 2 + i0 + cq);
 #pragma unroll
                     for (int t = 0; t < 4; t++) pa[R][t] = src[t];
@@ -1208,9 +1258,17 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             const int32_t av = (int32_t)xa[e], bv = (int32_t)(xb[e] << wsh);
-                            const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)xb[e] << wsh) : (i64)bv;
-                            const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
-                            const int32_t ma = (int32_t)((mid + side) >> 1), mb = (int32_t)((mid - side) >> 1);
+                            int32_t ma, mb;
+                            if (WIDE) {
+                                const i64 side = (i64)((u64)(i64)(int32_t)xb[e] << wsh);
+                                const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
+                                ma = (int32_t)((mid + side) >> 1); mb = (int32_t)((mid - side) >> 1);
+                            }
+                            else {
+                                // (up to 16-bit samples: mid and side need 18 bits)
+                                const int32_t mid = (int32_t)(((uint32_t)av << 1) | ((uint32_t)bv & 1));
+                                ma = (mid + bv) >> 1; mb = (mid - bv) >> 1;
+                            }
                             lo[e] = cc == 2 ? av + bv : cc == 3 ? ma : av;
                             ro[e] = cc == 1 ? av - bv : cc == 3 ? mb : bv;
                         }
@@ -1224,6 +1282,21 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                             *(int4 *)(o + i) = make_int4(lo[0], lo[1], lo[2], lo[3]);
                             *(int4 *)(o + f_n[R] + i) = make_int4(ro[0], ro[1], ro[2], ro[3]);
                         }
+                    }
+                }
+            }
+            // request channel 0 of the next tile (the first tile of channel 1 after the last of channel 0, or the next one
+            // of channel 1): the load then has a whole tile to arrive
+            {
+                const uint32_t itn = it + 1, chn = itn / tpc, i0n = (itn % tpc) * FG_TS;
+#pragma unroll
+                for (int R = 0; R < 2; R++) {
+                    const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
+                    if (itn < T && chn == 1 && (uint32_t)R < nrnd && row < G && f_c[R] == 2 && i0n + FG_TS <= f_n[R]) {
+                        const uint4 *src = (const uint4 *)(scratch + f_oo[R] * 2 + i0n + cq);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) pa[R][t] = src[t];
+                        pa_it[R] = itn;
                     }
                 }
             }
@@ -1263,6 +1336,10 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
             }
         }
     }
+    FG_PROF_END();
+    if (prof && lane == 0) { u64 *pp_ = prof + ((size_t)((nframes + 63) & ~63u) + blockIdx.x) * 8; pp_[0] = pw_busy[0]; pp_[1] = pw_busy[1]; }
+#undef FG_BAR
+#undef FG_PROF_END
 }
 
 // Settle the frames after the fused kernel and the CRC-16 kernel: merge the CRC verdict into the status, and write silence
@@ -1365,7 +1442,7 @@ extern "C" int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame
 // The fused decoder (parse + convert + recurrence + output in one kernel); fg_launch_decode_fix after it and the CRC kernel.
 extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                                       int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                                      int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, hipStream_t stream)
+                                      int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream)
 {
     if (nframes == 0) return 0;
     // one workgroup (four waves, one per SIMD) per CU while the frames allow: 28 frames per group for the 7032 frames of a
@@ -1384,9 +1461,9 @@ extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_l
     if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 = no output wave, 2 = no recurrence
     const dim3 grid((nframes + G - 1) / G);
     if (wide) hipLaunchKernelGGL(fg_dec_fused_kernel<true>, grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, 0u,
-                                 d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave);
+                                 d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave, (u64 *)d_prof);
     else hipLaunchKernelGGL(fg_dec_fused_kernel<false>, grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, 1u,
-                            d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave);
+                            d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave, (u64 *)d_prof);
     return (int)hipGetLastError();
 }
 

@@ -554,41 +554,52 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
 // Exclusive scan of the block sizes -> out_off; totals[0] = total samples, totals[1] = max block size.  Frames that would
 // end past `cap` samples are rejected here (bytes = 0), so the decode kernels can be queued before the host has seen the
 // total: it finds totals[0] > cap afterwards and reports the short buffer.
-// (one workgroup of 1024 threads, tiles of 4096 frames: block sizes fetched into LDS, four neighbours per thread, one
+// (one workgroup of 1024 threads, tiles of 8192 frames: block sizes fetched into LDS, eight neighbours per thread, one
 // workgroup scan per tile)
-#define FG_DSCAN_TILE 4096
+#define FG_DSCAN_TILE 8192
+#define FG_DSCAN_PER (FG_DSCAN_TILE / 1024)
 __global__ void __launch_bounds__(1024)
 fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap)
 {
     __shared__ u64 wtot[16];
     __shared__ uint32_t maxn;
-    __shared__ uint32_t sz[FG_DSCAN_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t sz[FG_DSCAN_TILE];
     const uint32_t tid = threadIdx.x;
     if (tid == 0) maxn = 0;
     uint32_t m = 0;
     u64 carry = 0;
     for (uint32_t t0 = 0; t0 < nframes; t0 += FG_DSCAN_TILE) {
         __syncthreads();
+        uint32_t nb[FG_DSCAN_PER];
 #pragma unroll
-        for (uint32_t j = 0; j < FG_DSCAN_TILE / 1024; j++) {
+        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
             const uint32_t b = t0 + j * 1024 + tid;
-            const uint32_t nb = b < nframes ? frames[b].n : 0;
-            m = nb > m ? nb : m;
-            sz[j * 1024 + tid] = nb;
+            nb[j] = b < nframes ? frames[b].n : 0;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
+            m = nb[j] > m ? nb[j] : m;
+            sz[j * 1024 + tid] = nb[j];
         }
         __syncthreads();
-        const uint4 v = *(const uint4 *)&sz[tid * 4];
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-        u64 total;
-        u64 run = carry + fgdev::block_scan_excl_u64((u64)v.x + v.y + v.z + v.w, wtot, &total);
+        uint32_t v[FG_DSCAN_PER];
+        u64 mine = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t b = t0 + tid * 4 + j;
+        for (uint32_t j = 0; j < FG_DSCAN_PER; j += 4) {
+            const uint4 t = *(const uint4 *)&sz[tid * FG_DSCAN_PER + j];
+            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+            mine += (u64)t.x + t.y + t.z + t.w;
+        }
+        u64 total;
+        u64 run = carry + fgdev::block_scan_excl_u64(mine, wtot, &total);
+#pragma unroll
+        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
+            const uint32_t b = t0 + tid * FG_DSCAN_PER + j;
             if (b < nframes) {
-                if (run + vv[j] > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
+                if (run + v[j] > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
                 else frames[b].out_off = run;
             }
-            run += vv[j];
+            run += v[j];
         }
         carry += total;
     }
@@ -659,16 +670,20 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
 }
 
 // offsets[0 .. nframes] and alt[0 .. nframes) empty (all ones), the four counters zero: one launch instead of three fills
-__global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long long *info, uint32_t nframes)
+// (stamp, when given: the start-of-call wall-clock stamp, see fg_signal_kernel)
+__global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long long *info, uint32_t nframes, u64 *stamp)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && stamp) stamp[0] = wall_clock64();
     if (k <= nframes) offsets[k] = ~(u64)0;
     if (k < nframes) alt[k] = ~(u64)0;
     if (k < 4) info[k] = 0;
 }
-extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes, hipStream_t stream)
+extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes,
+                                        unsigned long long *d_stamp, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fg_dec_index_init_kernel, dim3((nframes + 256) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (u64 *)d_alt, d_info, nframes);
+    hipLaunchKernelGGL(fg_dec_index_init_kernel, dim3((nframes + 256) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (u64 *)d_alt, d_info, nframes,
+                       (u64 *)d_stamp);
     return (int)hipGetLastError();
 }
 

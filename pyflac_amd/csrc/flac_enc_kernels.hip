@@ -1227,51 +1227,64 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
 
 // ------------------------------------------------------------------ compaction: slots -> contiguous stream
 // offsets[b] = sum of bytes of blocks < b (exclusive), offsets[nblocks] = total, offsets[nblocks+1] = OR of errors.
-// One workgroup of 1024 threads walks the blocks in tiles of 4096: the sizes are fetched coalesced into LDS (a pipeline
+// One workgroup of 1024 threads walks the blocks in tiles of 8192: the sizes are fetched coalesced into LDS (a pipeline
 // block -- results.reserved == 4 -- gets its size here, from the bit counts of its four chunks: ceil(sum / 8) + 2 for the
-// CRC-16), every thread then sums four neighbours, one workgroup scan per tile, carry into the next tile.
-#define FG_SCAN_TILE 4096
+// CRC-16), every thread then sums eight neighbours, one workgroup scan per tile, carry into the next tile.  All loads of a
+// tile are issued before anything is stored (the stores into `results` would otherwise fence the later loads).
+#define FG_SCAN_TILE 8192
+#define FG_SCAN_PER (FG_SCAN_TILE / 1024)
 __global__ void __launch_bounds__(1024)
 fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets)
 {
     __shared__ u64 wtot[16];
     __shared__ uint32_t errs;
-    __shared__ uint32_t sz[FG_SCAN_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t sz[FG_SCAN_TILE];
     const uint32_t tid = threadIdx.x;
     if (tid == 0) errs = 0;
     uint32_t e = 0;
     u64 carry = 0;
     for (uint32_t t0 = 0; t0 < nblocks; t0 += FG_SCAN_TILE) {
         __syncthreads();                    // (previous tile's readers are done with sz[]; errs initialised)
+        uint4 r[FG_SCAN_PER], cb[FG_SCAN_PER];
+        uint32_t kind[FG_SCAN_PER];
 #pragma unroll
-        for (uint32_t j = 0; j < FG_SCAN_TILE / 1024; j++) {
+        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
             const uint32_t b = t0 + j * 1024 + tid;
-            uint32_t bytes = 0;
+            r[j] = make_uint4(0, 0, 0, 0); cb[j] = r[j]; kind[j] = 0;
             if (b < nblocks) {
-                const uint4 r = *(const uint4 *)&results[b];               // bytes, ca, err, best_bits[0]
-                const uint32_t kind = results[b].reserved;
-                bytes = r.x;
-                e |= r.z;
-                if (chunk_bits && kind == 4) {
-                    const uint4 cb = *(const uint4 *)&chunk_bits[(size_t)b * 4];
-                    bytes = (r.z & FG_ERR_REDO) ? 0u : ((cb.x + cb.y + cb.z + cb.w + 7) >> 3) + 2;
-                    results[b].bytes = bytes;
-                }
+                r[j] = *(const uint4 *)&results[b];                        // bytes, ca, err, best_bits[0]
+                kind[j] = results[b].reserved;
+                if (chunk_bits) cb[j] = *(const uint4 *)&chunk_bits[(size_t)b * 4];
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
+            const uint32_t b = t0 + j * 1024 + tid;
+            uint32_t bytes = r[j].x;
+            e |= r[j].z;
+            if (chunk_bits && kind[j] == 4) {
+                bytes = (r[j].z & FG_ERR_REDO) ? 0u : ((cb[j].x + cb[j].y + cb[j].z + cb[j].w + 7) >> 3) + 2;
+                if (b < nblocks) results[b].bytes = bytes;
             }
             sz[j * 1024 + tid] = bytes;
         }
         __syncthreads();
-        const uint4 v = *(const uint4 *)&sz[tid * 4];
+        uint32_t v[FG_SCAN_PER];
+        u64 mine = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < FG_SCAN_PER; j += 4) {
+            const uint4 t = *(const uint4 *)&sz[tid * FG_SCAN_PER + j];
+            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+            mine += (u64)t.x + t.y + t.z + t.w;
+        }
         u64 total;
-        u64 run = carry + fgdev::block_scan_excl_u64((u64)v.x + v.y + v.z + v.w, wtot, &total);
-        const uint32_t b = t0 + tid * 4;
-        if (b < nblocks) offsets[b] = run;
-        run += v.x;
-        if (b + 1 < nblocks) offsets[b + 1] = run;
-        run += v.y;
-        if (b + 2 < nblocks) offsets[b + 2] = run;
-        run += v.z;
-        if (b + 3 < nblocks) offsets[b + 3] = run;
+        u64 run = carry + fgdev::block_scan_excl_u64(mine, wtot, &total);
+#pragma unroll
+        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
+            const uint32_t b = t0 + tid * FG_SCAN_PER + j;
+            if (b < nblocks) offsets[b] = run;
+            run += v[j];
+        }
         carry += total;
     }
     if (e) atomicOr(&errs, e);
@@ -1333,15 +1346,23 @@ __global__ void fg_signal_kernel(const u64 *src0, uint32_t n0, const u64 *src1, 
     if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
 }
 
-// the decoder's variant: the per-frame status words (8 bytes a frame) travel too
+// the decoder's variant: the per-frame status words travel too (16-byte units, a few workgroups; the last one to finish --
+// counter in stamp[1] -- raises the flag)
 __global__ void __launch_bounds__(1024)
-fg_export_kernel(const u64 *rows, uint32_t nrows, u64 *host_rows, const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1,
-                 const u64 *stamp, u64 *host, u64 seq)
+fg_export_kernel(const uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1,
+                 u64 *stamp, u64 *host, u64 seq)
 {
-    for (uint32_t i = threadIdx.x; i < nrows; i += 1024) host_rows[i] = rows[i];
+    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < nquads; i += gridDim.x * 1024) host_rows[i] = rows[i];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
+    if (threadIdx.x == 0) {
+        const u64 done = atomicAdd((unsigned long long *)&stamp[1], 1ull);
+        if (done == gridDim.x - 1) {
+            stamp[1] = 0;
+            __threadfence();
+            fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
+        }
+    }
 }
 
 }  // namespace
@@ -1383,11 +1404,15 @@ int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned
 }
 
 int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
-                     const unsigned long long *src1, uint32_t n1, const unsigned long long *d_stamp, unsigned long long *h_sig,
+                     const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
                      unsigned long long seq, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fg_export_kernel, dim3(1), dim3(1024), 0, stream, (const u64 *)d_rows, nrows, (u64 *)h_rows, (const u64 *)src0, n0,
-                       (const u64 *)src1, n1, (const u64 *)d_stamp, (u64 *)h_sig, (u64)seq);
+    // rows of 8 bytes, moved as 16-byte units (both buffers are padded past nrows)
+    const uint32_t nquads = (nrows + 1) / 2;
+    uint32_t wgs = (nquads + 1023) / 1024;
+    wgs = wgs < 1 ? 1 : wgs > 8 ? 8 : wgs;
+    hipLaunchKernelGGL(fg_export_kernel, dim3(wgs), dim3(1024), 0, stream, (const uint4 *)d_rows, nquads, (uint4 *)h_rows, (const u64 *)src0, n0,
+                       (const u64 *)src1, n1, (u64 *)d_stamp, (u64 *)h_sig, (u64)seq);
     return (int)hipGetLastError();
 }
 

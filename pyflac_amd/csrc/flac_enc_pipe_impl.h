@@ -163,7 +163,10 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     const uint32_t wv = rfl(threadIdx.x >> 6);
     const uint32_t bi = blockIdx.x * FGP_AWPB + wv;
     // near-tie guard of the LPC order guess (Levinson-Durbin kernel, next launch): count 0, smallest margin +infinity
-    if (blockIdx.x == 0 && threadIdx.x == 0 && B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (B.stamp) B.stamp[0] = wall_clock64();
+        if (B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; }
+    }
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
     const int lane = threadIdx.x & 63;

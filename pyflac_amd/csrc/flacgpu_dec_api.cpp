@@ -402,13 +402,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // words, totals and stamps into pinned memory, the host polls a sequence number), no events; levels 1, 2 = HIP events
     static const bool want_prof = getenv("FLACGPU_DEC_PROF") != nullptr;
     const bool lean = c->stage_timing == 0 && !h_frames && !detail && !want_prof;
-    if (lean) { if (fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; } }
+    if (lean) {     // (with the index made here, its first kernel takes the stamp)
+        if (!index_here && fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; }
+    }
     else if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
         if (!c->dec_info.ensure(64 + (size_t)nframes * 8)) return false;
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
-        if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, c->stream) != 0 ||
+        if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, lean ? (unsigned long long *)c->stamp.p : nullptr, c->stream) != 0 ||
             fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, c->stream) != 0) {
             fg_set_error("frame index kernel launch failed"); return false;
         }
@@ -419,7 +421,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     else if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
     if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                               (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
-    if (!c->ensure_pinned_res(64 + (size_t)nframes * sizeof(FgDecResult))) return false;
+    if (!c->ensure_pinned_res(64 + ((size_t)nframes + 2) * sizeof(FgDecResult))) return false;
     unsigned long long *tot = (unsigned long long *)c->h_res;
     tot[0] = tot[1] = 0;
     const uint32_t C = channels_hint ? channels_hint : 2;
@@ -460,11 +462,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // One fused kernel (parse -> residuals -> recurrence -> output through LDS), or, when the residual planes themselves are
     // wanted (subframe detail level 2) or with FLACGPU_DEC_FUSED=0, the two-kernel version with the plane in HBM.
     static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
-    const bool fused = !fused_off && !d_prof && !(detail && detail->level >= 2);
+    static const bool prof_fused = getenv("FLACGPU_DEC_PROF") && atoi(getenv("FLACGPU_DEC_PROF")) == 2;
+    const bool fused = !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
     if (fused) {
         if (fg_launch_decode_fused((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
                                    (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams,
-                                   d_rparams ? (int32_t *)c->dec_warm.p : nullptr, (int32_t *)d_pcm, interleave ? 1u : 0u, c->stream) != 0) {
+                                   d_rparams ? (int32_t *)c->dec_warm.p : nullptr, (int32_t *)d_pcm, interleave ? 1u : 0u, d_prof, c->stream) != 0) {
             fg_set_error("decode kernel launch failed"); return false;
         }
         if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
@@ -498,7 +501,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (lean) {
         const unsigned long long seq = ++c->sig_seq;
         if (fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
-                             index_here ? 4 : 0, (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream) != 0 ||
+                             index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream) != 0 ||
             !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
         tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
         for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
