@@ -375,15 +375,19 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
 // ---------------------------------------------------------------- frame header parse (format.h:418-462)
 // lane = frame.  offsets[f] .. offsets[f+1] delimit the frame.  Fills FgDecFrame except out_off.
 __global__ void __launch_bounds__(256)
-fg_dec_headers_kernel(const uint8_t *stream, const u64 *offsets, uint32_t nframes, uint32_t si_channels, uint32_t si_bps,
+fg_dec_headers_kernel(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t nframes, uint32_t si_channels, uint32_t si_bps,
                       FgDecFrame *frames, FgDecResult *results)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nframes) return;
-    const uint8_t *p = stream + offsets[f];
-    const uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
+    // the index may come from the device (the index kernel leaves ~0 in the slot of a frame it did not find; a caller's table
+    // is not looked at by the host): nothing is read through an offset that does not lie inside the stream
+    const u64 o0 = offsets[f], o1 = offsets[f + 1];
+    const bool inside = o0 < stream_len && o1 <= stream_len && o1 > o0 && o1 - o0 < 0x7FFFFFFFull;
+    const uint8_t *p = stream + (inside ? o0 : 0);
+    const uint32_t len = inside ? (uint32_t)(o1 - o0) : 0;
     FgDecFrame fr;
-    fr.byte_off = offsets[f]; fr.out_off = 0; fr.bytes = len; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0;
+    fr.byte_off = inside ? o0 : 0; fr.out_off = 0; fr.bytes = len; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0;
     uint32_t bad = 0;
     if (len < 7 || p[0] != 0xFF || (p[1] & 0xFE) != 0xF8) bad = 1;
     uint32_t pos = 2, n = 0;
@@ -446,17 +450,20 @@ fg_dec_headers_kernel(const uint8_t *stream, const u64 *offsets, uint32_t nframe
 // malformed in the header pass; the CRC-16 pass of the decoder checks every frame that was found.
 // info[0]: candidates seen (count mode only: nframes == 0, nothing is filed), info[1]: unresolved collisions, info[2]: candidates with the
 // variable-block-size sync code 0xFFF9 (their number is a sample number; not handled here), info[3]: highest slot filled + 1.
-__device__ __forceinline__ bool fg_idx_header(const uint8_t *p, u64 avail, uint32_t want_channels, uint32_t want_bps, u64 *number, uint32_t *variable)
+// (the header bytes come through `p(i)`, i < 16: the index kernel has them in registers)
+template <typename Bytes>
+__device__ __forceinline__ bool fg_idx_header(const Bytes &p, u64 avail, uint32_t want_channels, uint32_t want_bps, u64 *number, uint32_t *variable,
+                                              const uint8_t *crc8tab)
 {
-    if (avail < 6 || p[0] != 0xFF || (p[1] & 0xFE) != 0xF8) return false;
-    const uint32_t bsc = p[2] >> 4, src = p[2] & 15, cac = p[3] >> 4, bpc = (p[3] >> 1) & 7;
-    if (bsc == 0 || src == 15 || cac > 10 || bpc == 3 || (p[3] & 1)) return false;
+    if (avail < 6 || p(0) != 0xFF || (p(1) & 0xFE) != 0xF8) return false;
+    const uint32_t bsc = p(2) >> 4, src = p(2) & 15, cac = p(3) >> 4, bpc = (p(3) >> 1) & 7;
+    if (bsc == 0 || src == 15 || cac > 10 || bpc == 3 || (p(3) & 1)) return false;
     const uint32_t BP[8] = {0, 8, 12, 0, 16, 20, 24, 32};
     const uint32_t ch = cac < 8 ? cac + 1 : 2;
     if (want_channels && ch != want_channels) return false;
     if (want_bps && bpc && BP[bpc] != want_bps) return false;
     uint32_t pos = 4;
-    const uint32_t x = p[pos++];
+    const uint32_t x = p(pos++);
     uint32_t extra;
     u64 v;
     if (!(x & 0x80)) { extra = 0; v = x; }
@@ -468,17 +475,14 @@ __device__ __forceinline__ bool fg_idx_header(const uint8_t *p, u64 avail, uint3
     else if (x == 0xFE) { extra = 6; v = 0; }
     else return false;
     if (pos + extra + 1 > avail) return false;
-    for (uint32_t i = 0; i < extra; i++) { const uint32_t c = p[pos++]; if ((c & 0xC0) != 0x80) return false; v = (v << 6) | (c & 0x3F); }
+    for (uint32_t i = 0; i < extra; i++) { const uint32_t c = p(pos++); if ((c & 0xC0) != 0x80) return false; v = (v << 6) | (c & 0x3F); }
     if (bsc == 6) pos += 1; else if (bsc == 7) pos += 2;
     if (src == 12) pos += 1; else if (src == 13 || src == 14) pos += 2;
     if (pos + 1 > avail) return false;
     uint32_t c8 = 0;
-    for (uint32_t i = 0; i < pos; i++) {
-        c8 ^= p[i];
-        for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
-    }
-    if (c8 != p[pos]) return false;
-    *number = v; *variable = p[1] & 1;
+    for (uint32_t i = 0; i < pos; i++) c8 = crc8tab[c8 ^ p(i)];          // CRC-8, polynomial 0x07 (format.h:446-449)
+    if (c8 != p(pos)) return false;
+    *number = v; *variable = p(1) & 1;
     return true;
 }
 
@@ -491,63 +495,151 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
     const uintptr_t sa = (uintptr_t)stream;
     const u64 mis = (u64)(sa & 15);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nframes != 0) offsets[nframes] = len;      // the end of the last frame
-    for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g * 16 < mis + len + 16 * 64; g += (u64)gridDim.x * 256) {
-    const u64 gstart = g * 16;                        // offset of the group relative to the aligned base (stream - mis)
-    const uint8_t *gp = stream - mis + gstart;
-    uint32_t w[5] = {0, 0, 0, 0, 0};
-    if (gstart >= mis && gstart + 16 <= mis + len) {
-        const uint4 v = *(const uint4 *)gp;
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    }
-    else {
-        for (uint32_t i = 0; i < 16; i++) {
-            const u64 o = gstart + i;
-            if (o >= mis && o < mis + len) w[i >> 2] |= (uint32_t)gp[i] << (8 * (i & 3));
-        }
-    }
-    // the byte behind the group: the next lane's first byte (the last lane of a wave loads it)
+    // CRC-8 table of the header check: what a candidate costs decides the length of this pass (one in 150 waves' steps
+    // holds one, and the whole wave waits for it)
+    __shared__ uint8_t crc8tab[256];
     {
-        const uint32_t nxt = (uint32_t)__shfl_down((int)w[0], 1);
-        w[4] = nxt;
-        if ((threadIdx.x & 63) == 63) w[4] = (gstart + 16 < mis + len) ? gp[16] : 0;
+        uint32_t c8 = threadIdx.x;
+        for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
+        crc8tab[threadIdx.x] = (uint8_t)c8;
     }
+    __syncthreads();
+    // FG_IXU groups per lane are requested before the first is looked at: one 16-byte load in flight per lane does not
+    // keep HBM busy (the pass is latency-bound that way), four do
+    constexpr int FG_IXU = 4;
+    const u64 stride = (u64)gridDim.x * 256;
+    // Phase 1 of a step, per group (inlined four times, small): the SWAR test; when any lane of the wave has a candidate the
+    // wave also fetches the 16 bytes behind every group from the neighbouring lane (a header is at most 16 bytes long).
     // sync code = a 0xFF byte followed by 0xF8 / 0xF9: bytes equal to 0xFF whose successor has its top five bits set and
-    // bit 1 and 2 clear (SWAR over the four words and their one-byte-shifted neighbours; 1 group in 2000 gets past this)
-    uint32_t hit = 0;
+    // bit 1 and 2 clear (SWAR over the four words and their one-byte-shifted neighbours; 1 group in 2000 gets past this).
+    // Returns the candidate positions of this lane, one bit per byte of the group; W[0..7] = the group and its successor.
+    auto scan = [&](const uint32_t (&w)[5], const uint32_t (&n63)[4], uint32_t (&W)[8]) -> uint32_t {
+        uint32_t hit = 0, hitw[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t a = w[k], b = (w[k] >> 8) | (w[k + 1] << 24);           // b = the successor of every byte of a
-        const uint32_t x = ~a, isff = (x - 0x01010101u) & ~x & 0x80808080u;    // 0x80 in every byte of a that is 0xFF (exact: no borrow passes a 0xFF byte... checked below)
-        const uint32_t y = (b & 0xFEFEFEFEu) ^ 0xF8F8F8F8u, isf8 = (y - 0x01010101u) & ~y & 0x80808080u;
-        hit |= isff & isf8;
-    }
-    if (!hit) continue;
-#pragma unroll
-    for (uint32_t i = 0; i < 16; i++) {
-        const uint32_t b0 = (w[i >> 2] >> (8 * (i & 3))) & 0xFF, b1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFF;
-        if (b0 != 0xFF || (b1 & 0xFE) != 0xF8) continue;
-        const u64 o = gstart + i;
-        if (o < mis || o + 1 >= mis + len) continue;
-        const u64 pos = o - mis;
-        u64 number;
-        uint32_t variable;
-        if (!fg_idx_header(stream + pos, len - pos, channels, bps, &number, &variable)) continue;
-        // (thousands of atomics on one address take longer than the whole pass over the bytes: the candidates are only
-        // counted when that is what the call is for)
-        // sync code 0xFFF9 (variable block size: the number is a sample number) is not filed; a fixed-block-size stream
-        // holds such byte sequences by chance, so they only count as evidence when nothing else is found
-        if (variable) { atomicAdd(&info[2], 1ull); continue; }
-        if (nframes == 0) atomicAdd(&info[0], 1ull);
-        if (nframes == 0 || number < first_number) continue;
-        const u64 slot = number - first_number;
-        if (slot >= nframes) continue;
-        // first claim of a slot goes into the table, a second one beside it (fg_dec_index_resolve_kernel picks), a third fails
-        const unsigned long long old = atomicCAS((unsigned long long *)&offsets[slot], ~0ull, (unsigned long long)pos);
-        if (old != ~0ull && old != pos) {
-            const unsigned long long old2 = atomicCAS((unsigned long long *)&alt[slot], ~0ull, (unsigned long long)pos);
-            if (old2 != ~0ull && old2 != pos) atomicAdd(&info[1], 1ull);
+        for (int k = 0; k < 4; k++) {
+            const uint32_t a = w[k], b = (w[k] >> 8) | (w[k + 1] << 24);           // b = the successor of every byte of a
+            const uint32_t x = ~a, isff = (x - 0x01010101u) & ~x & 0x80808080u;    // 0x80 in every byte of a that is 0xFF (a borrow can flag a byte wrongly: the bytes decide later)
+            const uint32_t y = (b & 0xFEFEFEFEu) ^ 0xF8F8F8F8u, isf8 = (y - 0x01010101u) & ~y & 0x80808080u;
+            hitw[k] = isff & isf8;
+            hit |= hitw[k];
         }
-    }
+#pragma unroll
+        for (int k = 0; k < 8; k++) W[k] = 0;
+        if (!__any(hit != 0)) return 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { W[k] = w[k]; W[4 + k] = (uint32_t)__shfl_down((int)w[k], 1); }
+        if ((threadIdx.x & 63) == 63) { W[4] = n63[0]; W[5] = n63[1]; W[6] = n63[2]; W[7] = n63[3]; }
+        uint32_t cand = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cand |= ((((hitw[k] >> 7) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu) << (4 * k);
+        return cand;
+    };
+    // Phase 2, once per step: the candidates of the four groups.  One copy of the header check, reached through rolled
+    // loops (the group's words are picked with selects): with a copy per group and per byte position this kernel's code
+    // outgrew the instruction cache, and the rarely taken candidate path then ran at the speed of instruction fetches
+    // from memory -- 40 us of a 55 us pass.  Nothing here goes back to the stream: a chain of dependent byte loads per
+    // candidate, the whole wave waiting, was the other half of that.
+    auto candidates = [&](u64 g0, const uint32_t (&cnd)[FG_IXU], const uint32_t (&Wall)[FG_IXU][8]) {
+#pragma unroll 1
+        for (uint32_t u = 0; u < (uint32_t)FG_IXU; u++) {
+            uint32_t cand = u == 0 ? cnd[0] : u == 1 ? cnd[1] : u == 2 ? cnd[2] : cnd[3];
+            if (!__any(cand != 0)) continue;
+            uint32_t W[9];
+#pragma unroll
+            for (int k = 0; k < 8; k++) W[k] = u == 0 ? Wall[0][k] : u == 1 ? Wall[1][k] : u == 2 ? Wall[2][k] : Wall[3][k];
+            W[8] = 0;
+            const u64 gstart = (g0 + (u64)u * stride) * 16;
+#pragma unroll 1
+            while (cand) {
+                const uint32_t i = (uint32_t)__ffs((int)cand) - 1;
+                cand &= cand - 1;
+                const uint32_t b0 = (W[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                const u64 o = gstart + i;
+                if (b0 != 0xFF || o < mis || o + 1 >= mis + len) continue;
+                const u64 pos = o - mis;
+                u64 number;
+                uint32_t variable;
+                // the 16 bytes from position i on: words q .. q + 4 of the window, funnelled by r bytes
+                const uint32_t q = i >> 2, r = i & 3;
+                uint32_t V[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) V[j] = q == 0 ? W[j] : q == 1 ? W[j + 1] : q == 2 ? W[j + 2] : W[j + 3];
+                uint32_t Hh[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) Hh[j] = __builtin_amdgcn_alignbyte(V[j + 1], V[j], r);
+                const auto hb = [&](uint32_t qq) -> uint32_t {
+                    const uint32_t wv = qq < 8 ? (qq < 4 ? Hh[0] : Hh[1]) : (qq < 12 ? Hh[2] : Hh[3]);
+                    return (wv >> (8 * (qq & 3))) & 0xFF;
+                };
+                if (!fg_idx_header(hb, len - pos, channels, bps, &number, &variable, crc8tab)) continue;
+                // (thousands of atomics on one address take longer than the whole pass over the bytes: the candidates are only
+                // counted when that is what the call is for)
+                // sync code 0xFFF9 (variable block size: the number is a sample number) is not filed; a fixed-block-size stream
+                // holds such byte sequences by chance, so they only count as evidence when nothing else is found
+                if (variable) { atomicAdd(&info[2], 1ull); continue; }
+                if (nframes == 0) atomicAdd(&info[0], 1ull);
+                if (nframes == 0 || number < first_number) continue;
+                const u64 slot = number - first_number;
+                if (slot >= nframes) continue;
+                // Claims of a slot: the smallest position goes into the table, the largest (+ 1) beside it, and they are
+                // counted (fg_dec_index_resolve_kernel picks between two, three fail).  None of the three atomics returns
+                // anything: a returning one holds the whole wave for a round trip to memory, and there is one per frame.
+                atomicMin((unsigned long long *)&offsets[slot], (unsigned long long)pos);
+                atomicMax((unsigned long long *)&alt[slot], (unsigned long long)pos + 1);
+                atomicAdd((uint32_t *)(alt + nframes) + slot, 1u);
+            }
+        }
+    };
+    // (a group that is not wholly inside the stream -- the first and the last one -- is read byte by byte afterwards; its
+    // 16-byte load goes to a group that is, so that all loads of a step are issued back to back with no branch between them)
+    const u64 gsafe = mis ? 16 : 0;
+    const bool anysafe = gsafe + 16 <= mis + len;
+    auto bytes_of = [&](u64 gstart, uint32_t (&d)[4]) {
+        d[0] = d[1] = d[2] = d[3] = 0;
+        if (gstart < mis + len && gstart + 16 > mis) {
+            const uint8_t *gp = stream - mis + gstart;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 4; k++) {              // (rolled: stream edges only, keep it out of the way)
+                uint32_t v = 0;
+#pragma unroll 1
+                for (uint32_t i = 0; i < 4; i++) {
+                    const u64 o = gstart + 4 * k + i;
+                    if (o >= mis && o < mis + len) v |= (uint32_t)gp[4 * k + i] << (8 * i);
+                }
+                d[0] = k == 0 ? v : d[0]; d[1] = k == 1 ? v : d[1]; d[2] = k == 2 ? v : d[2]; d[3] = k == 3 ? v : d[3];
+            }
+        }
+    };
+    const bool last_lane = (threadIdx.x & 63) == 63;
+    for (u64 g0 = (u64)blockIdx.x * 256 + threadIdx.x; g0 * 16 < mis + len + 16 * 64; g0 += stride * FG_IXU) {
+        uint32_t w[FG_IXU][5], nx63[FG_IXU][4], Wall[FG_IXU][8], cnd[FG_IXU];
+        uint4 va[FG_IXU], vb[FG_IXU];
+        bool in_a[FG_IXU], in_b[FG_IXU];
+#pragma unroll
+        for (int u = 0; u < FG_IXU; u++) {
+            const u64 gstart = (g0 + (u64)u * stride) * 16;       // offset of the group relative to the aligned base (stream - mis)
+            in_a[u] = gstart >= mis && gstart + 16 <= mis + len;
+            // what lies behind the group (the successor of its last byte; the rest of a header that starts in it) is in the
+            // next lane's registers -- except for the last lane of the wave, which loads its own next group along with
+            // this one (a load in the candidate path would hold the wave for its whole latency; the other lanes repeat
+            // their own address here)
+            in_b[u] = last_lane && gstart + 16 >= mis && gstart + 32 <= mis + len;
+            const uint8_t *base = stream - mis;
+            va[u] = anysafe ? *(const uint4 *)(base + (in_a[u] ? gstart : gsafe)) : make_uint4(0, 0, 0, 0);
+            vb[u] = anysafe ? *(const uint4 *)(base + (in_b[u] ? gstart + 16 : in_a[u] ? gstart : gsafe)) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < FG_IXU; u++) {
+            const u64 gstart = (g0 + (u64)u * stride) * 16;
+            w[u][0] = va[u].x; w[u][1] = va[u].y; w[u][2] = va[u].z; w[u][3] = va[u].w;
+            if (!in_a[u]) { uint32_t d[4]; bytes_of(gstart, d); w[u][0] = d[0]; w[u][1] = d[1]; w[u][2] = d[2]; w[u][3] = d[3]; }
+            nx63[u][0] = vb[u].x; nx63[u][1] = vb[u].y; nx63[u][2] = vb[u].z; nx63[u][3] = vb[u].w;
+            if (last_lane && !in_b[u]) bytes_of(gstart + 16, nx63[u]);
+            const uint32_t nxt = (uint32_t)__shfl_down((int)w[u][0], 1);
+            w[u][4] = last_lane ? nx63[u][0] : nxt;
+            cnd[u] = scan(w[u], nx63[u], Wall[u]);
+        }
+        if (__any((cnd[0] | cnd[1] | cnd[2] | cnd[3]) != 0)) candidates(g0, cnd, Wall);
     }
 }
 
@@ -631,12 +723,12 @@ extern "C" int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_
     return (int)hipGetLastError();
 }
 
-extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, const unsigned long long *d_offsets, uint32_t nframes,
+extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len, const unsigned long long *d_offsets, uint32_t nframes,
                                      uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
                                      unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream)
 {
     if (nframes == 0) return 0;
-    hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, d_offsets, nframes,
+    hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, (u64)stream_len, d_offsets, nframes,
                        si_channels, si_bps, d_frames, d_results);
     hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
     return (int)hipGetLastError();
@@ -649,6 +741,7 @@ __global__ void __launch_bounds__(256)
 fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 len, unsigned long long *info)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t *cnt = (const uint32_t *)(alt + nframes);       // claims per slot
     // info[3] = highest slot filled + 1 (one atomic per wave)
     {
         uint32_t top = (k < nframes && offsets[k] != ~(u64)0) ? k + 1 : 0;
@@ -657,26 +750,29 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
         if ((threadIdx.x & 63) == 0 && top) atomicMax(&info[3], (unsigned long long)top);
     }
     if (k >= nframes) return;
-    const u64 b = alt[k];
-    if (b == ~(u64)0) return;
-    const u64 a = offsets[k];
+    const uint32_t c = cnt[k];
+    if (c < 2) return;
+    const u64 a = offsets[k], b = alt[k] - 1;              // the smallest and the largest position claiming the slot
+    if (a == b) return;                                     // (one position found twice cannot happen; harmless)
+    if (c > 2) { atomicAdd(&info[1], 1ull); return; }
     // neighbours with a single claim (a run of contested slots is not resolved here)
-    const bool pv = k == 0 || alt[k - 1] == ~(u64)0, nx = k + 1 >= nframes || alt[k + 1] == ~(u64)0;
+    const bool pv = k == 0 || cnt[k - 1] == 1, nx = k + 1 >= nframes || cnt[k + 1] == 1;
     const u64 lo = k == 0 ? 0 : offsets[k - 1], hi = k + 1 >= nframes ? len : offsets[k + 1];
-    if (!pv || !nx || (k > 0 && lo == ~(u64)0) || hi == ~(u64)0) { atomicAdd(&info[1], 1ull); return; }
+    if (!pv || !nx) { atomicAdd(&info[1], 1ull); return; }
     const bool aok = (k == 0 || a > lo) && a < hi, bok = (k == 0 || b > lo) && b < hi;
     if (aok == bok) { atomicAdd(&info[1], 1ull); return; }
     if (bok) offsets[k] = b;
 }
 
-// offsets[0 .. nframes] and alt[0 .. nframes) empty (all ones), the four counters zero: one launch instead of three fills
+// offsets[0 .. nframes] empty (all ones: identity of the minimum), alt[0 .. nframes) zero (identity of the maximum), the claim
+// counts behind alt zero, the four counters zero: one launch instead of four fills
 // (stamp, when given: the start-of-call wall-clock stamp, see fg_signal_kernel)
 __global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long long *info, uint32_t nframes, u64 *stamp)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0 && stamp) stamp[0] = wall_clock64();
     if (k <= nframes) offsets[k] = ~(u64)0;
-    if (k < nframes) alt[k] = ~(u64)0;
+    if (k < nframes) { alt[k] = 0; ((uint32_t *)(alt + nframes))[k] = 0; }
     if (k < 4) info[k] = 0;
 }
 extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes,
@@ -692,9 +788,13 @@ extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long l
                                    hipStream_t stream)
 {
     if (len == 0) return 0;
+    // (every lane takes four groups a step; at most 8 workgroups of 4 waves per CU -- every wave slot of the chip, once --
+    // and as many steps for every workgroup: the grid is sized so that the steps come out even)
     const unsigned long long groups = (len + 15 + 15) / 16;
-    unsigned long long wgs = (groups + 255) / 256;
-    if (wgs > 2048) wgs = 2048;                     // 8 workgroups of 4 waves per CU: every wave slot of the chip, once
+    const unsigned long long need = (groups + 1023) / 1024;
+    const unsigned long long steps = (need + 2047) / 2048;
+    unsigned long long wgs = (need + steps - 1) / steps;
+    if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(fg_dec_index_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_stream, (u64)len, channels, bps,
                        (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt);
     if (nframes)

@@ -377,10 +377,9 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             const uint32_t bound = (uint32_t)hinfo[0];
             if (bound == 0) { st->nframes = 0; return true; }
             if (!c->offsets.ensure(((size_t)bound + 4) * 8)) return false;
-            if (!c->dec_info.ensure(64 + (size_t)bound * 8)) return false;
+            if (!c->dec_info.ensure(64 + (size_t)bound * 12 + 16)) return false;       // counters, second claims, claim counts
             d_info = (unsigned long long *)c->dec_info.p;
-            if (!HIPOK(hipMemsetAsync(c->offsets.p, 0xFF, ((size_t)bound + 1) * 8, c->stream)) || !HIPOK(hipMemsetAsync(d_info, 0, 32, c->stream)) ||
-                !HIPOK(hipMemsetAsync(d_info + 8, 0xFF, (size_t)bound * 8, c->stream)) ||
+            if (fg_launch_dec_index_init((unsigned long long *)c->offsets.p, d_info + 8, d_info, bound, nullptr, c->stream) != 0 ||
                 fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, c->stream) != 0 ||
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
@@ -408,7 +407,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     else if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
-        if (!c->dec_info.ensure(64 + (size_t)nframes * 8)) return false;
+        if (!c->dec_info.ensure(64 + (size_t)nframes * 12 + 16)) return false;      // counters, second claims, claim counts
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
         if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, lean ? (unsigned long long *)c->stamp.p : nullptr, c->stream) != 0 ||
             fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, c->stream) != 0) {
@@ -419,7 +418,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (!lean) (void)hipEventRecord(c->ev[3], c->stream);
     }
     else if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
-    if (fg_launch_dec_headers((const uint8_t *)d_stream, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
+    if (fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                               (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
     if (!c->ensure_pinned_res(64 + ((size_t)nframes + 2) * sizeof(FgDecResult))) return false;
     unsigned long long *tot = (unsigned long long *)c->h_res;

@@ -177,3 +177,22 @@ def test_gpu_frame_index_reports_duplicate_frame_numbers(ctx):
     buf = torch.frombuffer(bytearray(audio) + bytearray(64), dtype=torch.uint8).cuda()[:len(audio)]
     with pytest.raises(batch.FlacGpuError, match='ambiguous'):
         ctx.decode_stream(buf, si.channels, si.bits_per_sample, len(offs) * si.max_blocksize, nframes=len(offs) - 1)
+
+
+def test_index_finds_nothing_in_garbage(ctx):
+    """decode_stream over bytes that are not FLAC, with a frame count to look for (what STREAMINFO would have said): every
+    slot of the device index stays empty, the header pass must reject the frames without reading through the empty slots
+    (a device fault here takes the process down), and the call reports all frames as bad instead of decoding anything."""
+    import torch
+    from pyflac_amd import batch
+    rng = np.random.default_rng(1)
+    for n, nf in ((1 << 20, 100), (5000, 3), (1 << 24, 5000)):
+        data = torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8)).cuda()
+        dec, status, st = ctx.decode_stream(data, 2, 16, 1 << 20, nframes=nf)
+        assert st.nframes == nf and st.error_frames == nf and st.total_samples == 0
+        assert (status[:, 0] != 0).all()
+    # a table of device-resident offsets that point outside the stream (flacgpu_decode_frames_dev does not look at them on the host)
+    data = torch.from_numpy(rng.integers(0, 256, 4096, dtype=np.uint8)).cuda()
+    offs = torch.tensor([0, 1 << 40, 5, 4096], dtype=torch.int64).cuda()
+    dec, status, st = ctx.decode(data, offs, 2, 16, 1 << 16)
+    assert st.error_frames == 3 and st.total_samples == 0
