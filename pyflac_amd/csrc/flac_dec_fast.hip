@@ -558,6 +558,12 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
         results[f].err = err;
     }
     if (FUSED) { __syncthreads(); __syncthreads(); }          // the recurrence and the output waves finish the last two tiles
+    if (FUSED && prof) {
+        // [6]: distinct SIMDs under the four waves, [7]: 1 when another wave sits on the parser's SIMD
+        const uint32_t a = ctrl[4], b = ctrl[5], c = ctrl[6], d = ctrl[7];
+        tp[6] = ((1u << a) | (1u << b) | (1u << c) | (1u << d)) == 15u ? 4 : __popc((1u << a) | (1u << b) | (1u << c) | (1u << d));
+        tp[7] = (a == b || a == c || a == d) ? 1 : 0;
+    }
     if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t)blockIdx.x * 8 + i] = tp[i];
 #undef FG_TICK
 #undef tile
@@ -1104,6 +1110,11 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     L.frm = L.subp + 4 * G * FG_SUBP;                         // G x FG_FRM
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
+    if (prof && lane == 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        L.ctrl[4 + wave] = (hwid >> 4) & 3;          // SIMD of this wave (FLACGPU_DEC_PROF=2 reports how many the four share)
+    }
     if (wave == 0) {
         fg_parse_wave<true>(stream, stream_len, frames, nframes, G, narrow, subs, results, prof, rparams, L, lane);
         return;
