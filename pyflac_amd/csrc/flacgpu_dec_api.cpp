@@ -611,6 +611,42 @@ extern "C" int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uin
 // ------------------------------------------------------------------ libFLAC-style stream decoder
 namespace {
 
+// Landing buffer of the decoded PCM on the host: pinned (the copy from the device runs at PCIe speed instead of through the
+// runtime's staging buffers), grow-only and never initialised (value-initialising 200 MB -- what a std::vector does on
+// resize -- took a quarter of a one-shot decode), and handed from a finished decoder to the next one through a one-slot
+// pool, so that a sequence of decoders pins and faults the pages in once.
+struct HostPcm {
+    int32_t *p = nullptr;
+    size_t cap = 0;         // in samples
+    bool pinned = false;
+    void drop() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; pinned = false; }
+    static std::mutex &pool_mu() { static std::mutex m; return m; }
+    static HostPcm &pool() { static HostPcm spare; return spare; }
+    bool ensure(size_t n)
+    {
+        if (n <= cap) return true;
+        {
+            std::lock_guard<std::mutex> lk(pool_mu());
+            HostPcm &sp = pool();
+            if (sp.cap >= n) { drop(); p = sp.p; cap = sp.cap; pinned = sp.pinned; sp.p = nullptr; sp.cap = 0; sp.pinned = false; return true; }
+        }
+        drop();
+        void *np = nullptr;
+        if (hipHostMalloc(&np, n * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) { p = (int32_t *)np; pinned = true; }
+        else { (void)hipGetLastError(); p = (int32_t *)malloc(n * sizeof(int32_t)); pinned = false; }
+        cap = p ? n : 0;
+        return p != nullptr;
+    }
+    void give_back()
+    {
+        std::lock_guard<std::mutex> lk(pool_mu());
+        HostPcm &sp = pool();
+        if (cap > sp.cap) { sp.drop(); sp.p = p; sp.cap = cap; sp.pinned = pinned; p = nullptr; cap = 0; pinned = false; }
+        else drop();
+    }
+    int32_t *data() const { return p; }
+};
+
 struct DecImpl;
 void fill_subframes(DecImpl *d, FLAC__Frame &f, const FgDecFrame &fr, uint32_t fi);
 
@@ -639,7 +675,7 @@ struct DecImpl {
     uint64_t frames_delivered_bound;  // index into ix.bounds of the next frame to decode
     uint64_t samples_decoded;
     // decoded frames waiting for delivery
-    std::vector<int32_t> pcm;         // frame-planar
+    HostPcm pcm;                      // frame-planar
     std::vector<FgDecFrame> frames;
     std::vector<FgDecResult> status;
     size_t next_frame;
@@ -669,7 +705,7 @@ void reset_stream(DecImpl *d)
     memset(&d->si, 0, sizeof d->si);
     d->ix = Indexer();
     d->errors_reported = 0; d->frames_delivered_bound = 0; d->samples_decoded = 0;
-    d->pcm.clear(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->last_blocksize = 0; d->last_ca = 0;
+    d->frames.clear(); d->status.clear(); d->next_frame = 0; d->last_blocksize = 0; d->last_ca = 0;
     d->do_md5 = d->md5_checking != 0; d->md5.init();
     d->first_pos = 0; d->fixed_blocksize = 0; d->last_set = false; memset(&d->last_hdr, 0, sizeof d->last_hdr);
 }
@@ -912,12 +948,24 @@ bool decode_available(DecImpl *d)
     const uint64_t first = d->ix.bounds[d->frames_delivered_bound], last = d->ix.bounds[nb - 1];
     flacgpu_ctx *c = d->ctx;
     (void)hipSetDevice(c->device);
+    // FLACGPU_API_PROF=1: wall time of the phases of this call on stderr (tuning aid)
+    static const bool api_prof = getenv("FLACGPU_API_PROF") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t) {
+        if (!api_prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[flacgpu api prof] decode_available %-10s %8.3f ms (%u frames)\n", what,
+                std::chrono::duration_cast<std::chrono::microseconds>(now - t).count() / 1000.0, nframes);
+        t = now;
+    };
+    auto tl = tp0;
     std::vector<uint64_t> offs(nframes + 1);
     for (uint32_t i = 0; i <= nframes; i++) offs[i] = d->ix.bounds[d->frames_delivered_bound + i] - first;
     if (!d->d_stream.ensure((size_t)(last - first) + 64)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     if (!HIPOK(hipMemcpy(d->d_stream.p, d->buf.data() + first, (size_t)(last - first), hipMemcpyHostToDevice))) {
         d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
     }
+    lap("upload", tl);
     const uint32_t C = d->have_si ? d->si.channels : 0;
     // upper bound of the sample count: 65535 per frame is wasteful; use the STREAMINFO max block size when known
     uint64_t cap = (uint64_t)nframes * ((d->have_si && d->si.max_blocksize) ? d->si.max_blocksize : 65535);
@@ -931,10 +979,14 @@ bool decode_available(DecImpl *d)
                             cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr)) {
         d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
     }
-    d->pcm.resize((size_t)st.total_samples * (C ? C : 2));
-    if (st.total_samples && !HIPOK(hipMemcpy(d->pcm.data(), d->d_pcm.p, d->pcm.size() * 4, hipMemcpyDeviceToHost))) {
+    lap("decode", tl);
+    const size_t npcm = (size_t)st.total_samples * (C ? C : 2);
+    if (!d->pcm.ensure(npcm)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+    lap("buffer", tl);
+    if (st.total_samples && !HIPOK(hipMemcpy(d->pcm.data(), d->d_pcm.p, npcm * 4, hipMemcpyDeviceToHost))) {
         d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
     }
+    lap("download", tl);
     d->frames.swap(frames);
     d->status.swap(status);
     d->next_frame = 0;
@@ -1136,7 +1188,12 @@ bool fill_queue(DecImpl *d)
         if (try_fast) snap = d->ix;
         const uint64_t fdb = d->frames_delivered_bound;
         for (int attempt = 0; attempt < 2; attempt++) {
+            const auto tf0 = std::chrono::steady_clock::now();
             d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr);
+            if (getenv("FLACGPU_API_PROF"))
+                fprintf(stderr, "[flacgpu api prof] index feed %8.3f ms (%zu bytes, %s)\n",
+                        std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tf0).count() / 1000.0, d->buf.size(),
+                        d->ix.fast ? "fast" : "careful");
             bool redo = d->ix.fast && d->ix.fast_failed;
             if (!redo && d->ix.bounds.size() >= 2 && d->frames_delivered_bound + 1 < d->ix.bounds.size()) {
                 if (!decode_available(d)) return false;
@@ -1190,6 +1247,7 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *dec)
     if (d->file && d->own_file) fclose(d->file);
     if (d->ctx) (void)hipSetDevice(d->ctx->device);
     d->d_stream.release(); d->d_pcm.release();
+    d->pcm.give_back();
     delete d;
 }
 
