@@ -1184,12 +1184,18 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             }
         }
         if (mydbg && lane == 0) {
-            if (kind == 0) mydbg->cand[C].fixed_bits = est;
-            else mydbg->cand[C].lpc_bits[pass - 1] = est;
+            // (the records carry libFLAC's numbers: with the wasted-bits field, see the decision record below)
+            const uint32_t estw = (est == 0 || est > 0xFFFFFFFFu - wst) ? est : est + wst;
+            if (kind == 0) mydbg->cand[C].fixed_bits = estw;
+            else mydbg->cand[C].lpc_bits[pass - 1] = estw;
         }
     }
 
     // ---- the decision record of this candidate
+    // Every estimate above left out the unary wasted-bits field of the subframe header (`wasted` bits, libFLAC adds
+    // subframe->wasted_bits to each of its estimates): inside a candidate it is the same for every subframe type, between the
+    // candidates of a block it is not (a DC signal: left odd, right a multiple of four) and decides the channel assignment.
+    best = best > 0xFFFFFFFFu - wst ? 0xFFFFFFFFu : best + wst;
     FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
     {
         // the 20 header words of the record in one coalesced store (lane j = word j; everything here is wave-uniform)

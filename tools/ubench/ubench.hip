@@ -278,6 +278,45 @@ BENCH_BEGIN(k_rice_step_nolds)
     a = w0 + w1 + w2 + w3 + sm;
 BENCH_END
 
+// the decoder's delimiting step as shipped (flac_dec_fast.hip, FG_RC): two-word window, look-ahead read consumed by the last
+// instruction of the next code
+BENCH_BEGIN(k_rice_step_v5)
+    uint32_t w0 = a, w1 = b, na = c, nb = d, t = 5, sm, lz, a4, pmin = 0xffffffffu, addr = threadIdx.x * 64;
+    int32_t smk = 3;
+    asm volatile(".rept " STR(REP) "\n"
+        "v_alignbit_b32 v248, %[w0], %[w1], %[t]\n"
+        "v_ffbh_u32 %[lz], v248\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "v_cndmask_b32_e64 %[a4], 0, 4, vcc\n"
+        "v_add_u32 %[addr], %[addr], %[a4]\n"
+        "v_and_b32 %[addr], 0xffc, %[addr]\n"
+        "ds_read_b32 %[nb], %[addr]\n"
+        "v_sub_u32 %[t], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[t]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_cndmask_b32 %[w1], %[w1], %[na], vcc\n"
+        "v_alignbit_b32 v249, %[w0], %[w1], %[t]\n"
+        "v_ffbh_u32 %[lz], v249\n"
+        "v_cmp_lt_i32 vcc, %[smk], %[lz]\n"
+        "v_cndmask_b32_e64 %[a4], 0, 4, vcc\n"
+        "v_add_u32 %[addr], %[addr], %[a4]\n"
+        "v_and_b32 %[addr], 0xffc, %[addr]\n"
+        "ds_read_b32 %[na], %[addr]\n"
+        "v_min3_u32 %[pmin], %[pmin], v248, v249\n"
+        "v_sub_u32 %[t], %[smk], %[lz]\n"
+        "v_and_b32 %[sm], 31, %[t]\n"
+        "v_sub_u32 %[smk], %[sm], %[kp1]\n"
+        "v_cndmask_b32 %[w0], %[w0], %[w1], vcc\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_cndmask_b32 %[w1], %[w1], %[nb], vcc\n"
+        ".endr\n s_waitcnt lgkmcnt(0)"
+        : [w0]"+v"(w0), [w1]"+v"(w1), [na]"+v"(na), [nb]"+v"(nb), [t]"+v"(t), [smk]"+v"(smk), [pmin]"+v"(pmin), [addr]"+v"(addr), [sm]"=&v"(sm), [lz]"=&v"(lz), [a4]"=&v"(a4)
+        : [kp1]"v"(11u) : "vcc", "v248", "v249", "memory");
+    a = w0 + w1 + na + nb + pmin + t;
+BENCH_END
+
 BENCH_BEGIN(k_fmac64_dpp)
     asm volatile(".rept " STR(REP) "\n v_fmac_f64_dpp %0, %1, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n .endr" : "+v"(fa) : "v"(fb));
 BENCH_END
@@ -350,6 +389,7 @@ int main()
         {"rice step v3 (selects, unconditional LDS read)", k_rice_step_v3, 1},
         {"dependent v_add_u32, EXEC = 16 lanes", k_dep_add_exec16, 1}, {"dependent v_add_u32, EXEC = 32 lanes", k_dep_add_exec32, 1},
         {"rice step v3, EXEC = 16 lanes", k_rice_step_v3_exec16, 1}, {"rice step v3 without the LDS read", k_rice_step_nolds, 1},
+        {"rice step v5 (shipped: 2 codes, + 2 wrap ands)", k_rice_step_v5, 2},
         {"dependent DPP v_add row_shr", k_dpp_dep, 1}, {"loop: v_add + s_sub + s_cmp + s_cbranch (x4)", k_loop_branch, 4},
     };
     for (int nwg : {1, 1280}) {
