@@ -110,12 +110,18 @@ struct BitRd {
         wb += 4;
         return x;
     }
-    __device__ __forceinline__ void init(FgGroupPtr frame_group, uint32_t group_limit, uint32_t frame_bit0, uint32_t start_bit, uint32_t *lds_ring)
+    // where the reading starts (init_pos), then -- the ring may have been filled meanwhile -- the window (init_words)
+    __device__ __forceinline__ void init_pos(FgGroupPtr frame_group, uint32_t group_limit, uint32_t frame_bit0, uint32_t start_bit, uint32_t *lds_ring)
     {
         fg = frame_group; glim = group_limit; skip0 = frame_bit0; ring = lds_ring;
         const uint32_t b = frame_bit0 + start_bit;
-        const uint32_t w = b >> 5, sk = b & 31;
+        const uint32_t w = b >> 5;
         wb = w * 4; H = w >> 2; pfH = H; pfn = 0; pfvalid = false;
+        s = b & 31;             // (bit offset into the first word until init_words)
+    }
+    __device__ __forceinline__ void init_words()
+    {
+        const uint32_t sk = s;
         w0 = 0;
         if (sk) w0 = fetch();
         w1 = fetch();
@@ -181,10 +187,15 @@ struct BitRd {
     // (straight-line code: one address, FG_PF loads; a lane that is far enough ahead simply does not count them.  A
     // request count that follows the consumption -- fewer loads and parks on most tiles -- was tried: the conditional
     // loads cost more in waits than they save.)
-    __device__ __forceinline__ void issue(bool on)
+    __device__ __forceinline__ void ensure_ahead(bool on)
     {
         const uint32_t cg = wb >> 4;
         if (__any(on && H < cg + FG_RAHEAD)) { if (on) while (H < cg + FG_RAHEAD) selfload(); }
+    }
+    __device__ __forceinline__ void issue(bool on, bool ensure = true)
+    {
+        const uint32_t cg = wb >> 4;
+        if (ensure) ensure_ahead(on);
         // start of the batch, pulled back at the very end of the stream so that every load stays inside it
         const uint32_t last = glim >= FG_PF - 1 ? glim - (FG_PF - 1) : 0;
         pfH = H < last ? H : last;
@@ -275,11 +286,27 @@ __device__ __forceinline__ void fg_dec_flush_tile(const uint32_t *tile, const ui
 
 // LDS areas of a parse workgroup.  subp / frm exist only in the fused kernel: subp[ch & 3][row][16] = order, shift, wasted,
 // valid, q[12] of the subframe being parsed; frm[row][8] = n, channels, channel assignment, out_off lo / hi, accepted.
-struct FgParseLds { uint32_t *rings, *tiles, *metas, *ctrl, *subp, *frm; };
+struct FgParseLds { uint32_t *rings, *tiles, *metas, *ctrl, *subp, *frm, *feed; };
 #define FG_SUBP 16
 #define FG_FRM 8
 
+// The reader of frame `fr` positioned behind its header (window not loaded yet): the same arithmetic for the parser and for
+// the wave that feeds its ring.
+__device__ __forceinline__ void fg_frame_reader(BitRd &br, const uint8_t *stream, u64 stream_len, const FgDecFrame &fr, uint32_t *ring)
+{
+    const uintptr_t sa = (uintptr_t)stream;
+    const FgGroupPtr gbase = (FgGroupPtr)(sa & ~(uintptr_t)15);
+    const u64 mis = (u64)(sa & 15);
+    const u64 total_groups = (mis + stream_len + 15) >> 4;
+    const u64 fb = mis + fr.byte_off;
+    const u64 g0 = fb >> 4;
+    const u64 room = total_groups > g0 ? total_groups - g0 - 1 : 0;
+    br.init_pos(gbase + g0, room > 0x0FFFFFF0ull ? 0x0FFFFFF0u : (uint32_t)room, (uint32_t)(fb & 15) * 8, fr.hdr_bytes * 8, ring);
+}
+
 // The parser wave (lane = frame): shared by fg_dec_rice_kernel and fg_dec_fused_kernel.
+// In the fused kernel the ring is fed by the converter wave (FgRingFeed below): the parser only publishes its read position
+// (and how far it fetched for itself) at the end of a tile and picks up how far the ring is filled at the start of the next.
 template <bool FUSED>
 __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G,
                                               uint32_t narrow, FgDecSub *subs, FgDecResult *results, u64 *prof, uint16_t *rparams,
@@ -309,17 +336,12 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
     BitRd br;
     br.fg = nullptr; br.glim = 0; br.skip0 = 0; br.ring = rings; br.w0 = 0; br.w1 = 0; br.w2 = 0; br.w3 = 0; br.s = 0; br.wb = 12; br.H = 0;
     br.pfH = 0; br.pfn = 0; br.pfvalid = false;
-    if (alive) {
-        const uintptr_t sa = (uintptr_t)stream;
-        const FgGroupPtr gbase = (FgGroupPtr)(sa & ~(uintptr_t)15);
-        const u64 mis = (u64)(sa & 15);
-        const u64 total_groups = (mis + stream_len + 15) >> 4;
-        const u64 fb = mis + fr.byte_off;
-        const u64 g0 = fb >> 4;
-        const u64 room = total_groups > g0 ? total_groups - g0 - 1 : 0;
-        br.init(gbase + g0, room > 0x0FFFFFF0ull ? 0x0FFFFFF0u : (uint32_t)room, (uint32_t)(fb & 15) * 8, fr.hdr_bytes * 8,
-                rings + lane * FG_RSTR);
+    if (alive) fg_frame_reader(br, stream, stream_len, fr, rings + lane * FG_RSTR);
+    if (FUSED) {
+        __syncthreads();                                    // the feeding wave has filled the first groups of every ring
+        if (alive) { const uint32_t hp = L.feed[64 + lane]; br.H = hp > br.H ? hp : br.H; }
     }
+    if (alive) br.init_words();
 
     u64 tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = prof ? clock64() : 0;
 #define FG_TICK(i) do { if (prof) { const u64 now_ = clock64(); tp[i] += now_ - tlast; tlast = now_; } } while (0)
@@ -430,8 +452,16 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
                 fastlane = !is_esc;
             }
             if (__any(act)) {
-                br.land();
-                br.issue(act);
+                if (FUSED) {
+                    // how far the feeding wave has got (published a tile ago); a lane that is short all the same -- very
+                    // long codes, the first tiles of a frame -- fetches for itself
+                    if (alive) { const uint32_t hp = L.feed[64 + lane]; br.H = hp > br.H ? hp : br.H; }
+                    br.ensure_ahead(act);
+                }
+                else {
+                    br.land();
+                    br.issue(act);
+                }
                 FG_TICK(2);
                 if (act) {
                     uint32_t *row = &tile[lane * FG_TSTR];
@@ -542,6 +572,7 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
                 m[3] = (uint32_t)tmask; m[4] = (uint32_t)(tmask >> 32);
                 m[5] = cval;
             }
+            if (FUSED) { L.feed[lane] = br.wb; L.feed[128 + lane] = br.H; }       // read position and what this lane fetched itself, for the feeding wave
             __syncthreads();
             it++;
             if (act && br.pos() > end_bits) { err = 4; alive = false; rn = 0; }
@@ -579,7 +610,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
     L.tiles = dsm + G * FG_RSTR;                 // two buffers of G rows of FG_TSTR words
     L.metas = L.tiles + 2 * G * FG_TSTR;         // two buffers of 64 rows of FG_META words
     L.ctrl = L.metas + 2 * 64 * FG_META;         // [0] tiles per launch group, [1] tiles per channel
-    L.subp = nullptr; L.frm = nullptr;
+    L.subp = nullptr; L.frm = nullptr; L.feed = nullptr;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x >= 64) {
         __syncthreads();
@@ -1108,6 +1139,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     uint32_t *const rnm = rt + FG_RT * (G + 1) * FG_TSTR;     // samples per row, per residual tile: FG_RT x 64
     L.subp = rnm + FG_RT * 64;                                // 4 x G x FG_SUBP
     L.frm = L.subp + 4 * G * FG_SUBP;                         // G x FG_FRM
+    L.feed = L.frm + G * FG_FRM;                              // [0, 64): the parser's read positions, [64, 128): fill levels (feeder), [128, 192): fill levels (parser)
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     if (prof && lane == 0) {
@@ -1127,9 +1159,41 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     const uint32_t T = L.ctrl[0], tpc = L.ctrl[1];
     const uint32_t fbase = blockIdx.x * G;
     if (wave == 1) {
-        // ---- converter: after barrier j, tile j - 1
+        // ---- converter, and feeder of the parser's rings (lane = frame): the parser spends a third of its time per tile
+        // requesting, byte-swapping and parking the eight groups its lanes consume -- this wave has that time to spare.  Per
+        // tile: park what was requested a tile ago, publish the fill level (L.feed[64 + lane]; the parser reads it after
+        // the next barrier), request the next groups behind the parser's read position as it was at the end of the last
+        // tile (L.feed[lane]).  Three tiles pass between a read position and the data it asked for being usable, so the
+        // rings start 40 groups full (five round trips before the parser's first word) and the parser keeps its own
+        // fetch for lanes that run short.  Parked slots lie beyond everything the parser may read (same bound as before,
+        // taken from an older -- smaller -- read position), and a group both waves happen to fetch has the same bytes.
+        BitRd fd;
+        fd.fg = nullptr; fd.glim = 0; fd.skip0 = 0; fd.ring = L.rings; fd.w0 = fd.w1 = fd.w2 = fd.w3 = 0; fd.s = 0; fd.wb = 12; fd.H = 0;
+        fd.pfH = 0; fd.pfn = 0; fd.pfvalid = false;
+        bool feeding = false;
+        {
+            const uint32_t f = fbase + (uint32_t)lane;
+            if ((uint32_t)lane < G && f < nframes) {
+                const FgDecFrame fr = frames[f];
+                if (fr.bytes != 0 && fr.bytes >= fr.hdr_bytes + 2) { feeding = true; fg_frame_reader(fd, stream, stream_len, fr, L.rings + lane * FG_RSTR); }
+            }
+            for (int r = 0; r < 5; r++) { fd.issue(feeding, false); fd.land(); }
+            L.feed[lane] = fd.wb;
+            L.feed[64 + lane] = fd.H;
+            L.feed[128 + lane] = fd.H;
+        }
+        FG_BAR();
         for (uint32_t j = 1; j <= T + 2; j++) {
             FG_BAR();
+            if (j <= T) {
+                fd.wb = L.feed[lane];
+                fd.land();
+                // (a lane that outran the feed fetched for itself: go on behind what it has, not behind our own count --
+                // groups the parser has passed must not be parked over newer ones)
+                { const uint32_t hs = L.feed[128 + lane]; fd.H = hs > fd.H ? hs : fd.H; }
+                L.feed[64 + lane] = fd.H;
+                fd.issue(feeding, false);
+            }
             if (j <= T) {
                 const uint32_t it = j - 1;
                 fg_dec_convert_tile(L.tiles + (it & 1) * G * FG_TSTR, L.metas + (it & 1) * 64 * FG_META, G, (it % tpc) * FG_TS, lane,
@@ -1139,6 +1203,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         FG_PROF_END();
         return;
     }
+    FG_BAR();                                     // (the rings' first fill, see the converter)
     if (wave == 2) {
         // ---- recurrence: after barrier j, tile j - 2.  lane = frame row; idle lanes work on the spare row.
         int32_t q[16], h[16];
@@ -1247,6 +1312,15 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                     for (int t = 0; t < 4; t++) pa[R][t] = src[t];
                 }
             }
+            // Every prefetched value is touched before the first store of the tile goes out: memory operations retire in
+            // order, so a wait for one of these loads placed behind stores waits for the stores too (the compiler put a
+            // full vmcnt(0) between the two rounds: two store round trips per tile).
+            if (ch == 1) {
+#pragma unroll
+                for (int R = 0; R < 2; R++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) asm volatile("" : "+v"(pa[R][t].x), "+v"(pa[R][t].y), "+v"(pa[R][t].z), "+v"(pa[R][t].w));
+            }
 #pragma unroll
             for (int R = 0; R < 2; R++) {
                 if (!live[R]) continue;
@@ -1297,17 +1371,20 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 }
             }
             // request channel 0 of the next tile (the first tile of channel 1 after the last of channel 0, or the next one
-            // of channel 1): the load then has a whole tile to arrive
+            // of channel 1): the load then has a whole tile to arrive.  Every lane loads in both rounds -- from the start of
+            // the plane when its row has nothing to fetch --, so that no load has to be merged with an old value (the
+            // compiler would wait for it on the spot, one memory latency per round).
             {
                 const uint32_t itn = it + 1, chn = itn / tpc, i0n = (itn % tpc) * FG_TS;
+                if (itn < T && chn == 1) {
 #pragma unroll
-                for (int R = 0; R < 2; R++) {
-                    const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
-                    if (itn < T && chn == 1 && (uint32_t)R < nrnd && row < G && f_c[R] == 2 && i0n + FG_TS <= f_n[R]) {
-                        const uint4 *src = (const uint4 *)(scratch + f_oo[R] * 2 + i0n + cq);
+                    for (int R = 0; R < 2; R++) {
+                        const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
+                        const bool want = (uint32_t)R < nrnd && row < G && f_c[R] == 2 && i0n + FG_TS <= f_n[R];
+                        const uint4 *src = (const uint4 *)(want ? scratch + f_oo[R] * 2 + i0n + cq : scratch);
 #pragma unroll
                         for (int t = 0; t < 4; t++) pa[R][t] = src[t];
-                        pa_it[R] = itn;
+                        pa_it[R] = want ? itn : ~0u;
                     }
                 }
             }
@@ -1462,7 +1539,7 @@ extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_l
     if (getenv("FLACGPU_DEC_G1")) G = (uint32_t)atoi(getenv("FLACGPU_DEC_G1"));      // tuning aid
     if (G > 32) G = 32;
     const size_t lds = ((size_t)G * (FG_RSTR + 2 * FG_TSTR) + 2 * 64 * FG_META + 8 + (size_t)FG_RT * (G + 1) * FG_TSTR + FG_RT * 64 +
-                        4 * (size_t)G * FG_SUBP + (size_t)G * FG_FRM) * 4;
+                        4 * (size_t)G * FG_SUBP + (size_t)G * FG_FRM + 192) * 4;
     static size_t configured[2] = {0, 0};
     const void *fn = wide ? (const void *)fg_dec_fused_kernel<true> : (const void *)fg_dec_fused_kernel<false>;
     if (lds > configured[wide ? 1 : 0]) {
