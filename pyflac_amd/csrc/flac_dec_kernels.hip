@@ -498,6 +498,10 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
     // CRC-8 table of the header check: what a candidate costs decides the length of this pass (one in 150 waves' steps
     // holds one, and the whole wave waits for it)
     __shared__ uint8_t crc8tab[256];
+    constexpr uint32_t FG_IXQ = 512;                // candidates a workgroup can park (it sees about six)
+    __shared__ uint32_t qn;
+    __shared__ uint32_t qw[FG_IXQ * 6];
+    if (threadIdx.x == 0) qn = 0;
     {
         uint32_t c8 = threadIdx.x;
         for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
@@ -539,6 +543,36 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
     // outgrew the instruction cache, and the rarely taken candidate path then ran at the speed of instruction fetches
     // from memory -- 40 us of a 55 us pass.  Nothing here goes back to the stream: a chain of dependent byte loads per
     // candidate, the whole wave waiting, was the other half of that.
+    // A candidate whose header checks out files its claim: the smallest position goes into the table, the largest (+ 1)
+    // beside it, and the claims are counted (fg_dec_index_resolve_kernel picks between two, three fail).  None of the three
+    // atomics returns anything: a returning one holds the whole wave for a round trip to memory, and there is one per frame.
+    auto check = [&](u64 pos, const uint32_t (&Hh)[4]) {
+        const auto hb = [&](uint32_t qq) -> uint32_t {
+            const uint32_t wv = qq < 8 ? (qq < 4 ? Hh[0] : Hh[1]) : (qq < 12 ? Hh[2] : Hh[3]);
+            return (wv >> (8 * (qq & 3))) & 0xFF;
+        };
+        u64 number;
+        uint32_t variable;
+        if (!fg_idx_header(hb, len - pos, channels, bps, &number, &variable, crc8tab)) return;
+        // (thousands of atomics on one address take longer than the whole pass over the bytes: the candidates are only
+        // counted when that is what the call is for)
+        // sync code 0xFFF9 (variable block size: the number is a sample number) is not filed; a fixed-block-size stream
+        // holds such byte sequences by chance, so they only count as evidence when nothing else is found
+        if (variable) { atomicAdd(&info[2], 1ull); return; }
+        if (nframes == 0) atomicAdd(&info[0], 1ull);
+        if (nframes == 0 || number < first_number) return;
+        const u64 slot = number - first_number;
+        if (slot >= nframes) return;
+        atomicMin((unsigned long long *)&offsets[slot], (unsigned long long)pos);
+        atomicMax((unsigned long long *)&alt[slot], (unsigned long long)pos + 1);
+        atomicAdd((uint32_t *)(alt + nframes) + slot, 1u);
+    };
+    // Phase 2, once per step: the candidates of the four groups are only COLLECTED -- position and the 16 bytes from it on go
+    // into a queue in LDS -- and the header checks run after the pass, one candidate per lane (phase 3): in the wave that
+    // finds it a candidate keeps 63 lanes waiting, and one wave step in 150 has one.  One rolled copy of this code (the
+    // group's words are picked with selects): with a copy per group and per byte position the kernel outgrew the
+    // instruction cache and the rarely taken path ran at the speed of instruction fetches from memory.  Nothing here goes
+    // back to the stream: a chain of dependent byte loads per candidate was the other half of a 55 us pass.
     auto candidates = [&](u64 g0, const uint32_t (&cnd)[FG_IXU], const uint32_t (&Wall)[FG_IXU][8]) {
 #pragma unroll 1
         for (uint32_t u = 0; u < (uint32_t)FG_IXU; u++) {
@@ -557,8 +591,6 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
                 const u64 o = gstart + i;
                 if (b0 != 0xFF || o < mis || o + 1 >= mis + len) continue;
                 const u64 pos = o - mis;
-                u64 number;
-                uint32_t variable;
                 // the 16 bytes from position i on: words q .. q + 4 of the window, funnelled by r bytes
                 const uint32_t q = i >> 2, r = i & 3;
                 uint32_t V[5];
@@ -567,26 +599,16 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
                 uint32_t Hh[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) Hh[j] = __builtin_amdgcn_alignbyte(V[j + 1], V[j], r);
-                const auto hb = [&](uint32_t qq) -> uint32_t {
-                    const uint32_t wv = qq < 8 ? (qq < 4 ? Hh[0] : Hh[1]) : (qq < 12 ? Hh[2] : Hh[3]);
-                    return (wv >> (8 * (qq & 3))) & 0xFF;
-                };
-                if (!fg_idx_header(hb, len - pos, channels, bps, &number, &variable, crc8tab)) continue;
-                // (thousands of atomics on one address take longer than the whole pass over the bytes: the candidates are only
-                // counted when that is what the call is for)
-                // sync code 0xFFF9 (variable block size: the number is a sample number) is not filed; a fixed-block-size stream
-                // holds such byte sequences by chance, so they only count as evidence when nothing else is found
-                if (variable) { atomicAdd(&info[2], 1ull); continue; }
-                if (nframes == 0) atomicAdd(&info[0], 1ull);
-                if (nframes == 0 || number < first_number) continue;
-                const u64 slot = number - first_number;
-                if (slot >= nframes) continue;
-                // Claims of a slot: the smallest position goes into the table, the largest (+ 1) beside it, and they are
-                // counted (fg_dec_index_resolve_kernel picks between two, three fail).  None of the three atomics returns
-                // anything: a returning one holds the whole wave for a round trip to memory, and there is one per frame.
-                atomicMin((unsigned long long *)&offsets[slot], (unsigned long long)pos);
-                atomicMax((unsigned long long *)&alt[slot], (unsigned long long)pos + 1);
-                atomicAdd((uint32_t *)(alt + nframes) + slot, 1u);
+                if (((Hh[0] >> 8) & 0xFE) != 0xF8) continue;
+                const uint32_t e = atomicAdd(&qn, 1u);
+                if (e < FG_IXQ) {
+                    uint32_t *qe = &qw[e * 6];
+                    qe[0] = (uint32_t)pos; qe[1] = (uint32_t)(pos >> 32); qe[2] = Hh[0]; qe[3] = Hh[1]; qe[4] = Hh[2]; qe[5] = Hh[3];
+                }
+                // (queue full -- 512 candidates in the 48 KB of a workgroup, a stretch that is all sync codes: counted as
+                // unresolved, the call fails loudly and the host indexer takes over; a second copy of the header check
+                // here would double this kernel's cold code)
+                else atomicAdd(&info[1], 1ull);
             }
         }
     };
@@ -640,6 +662,14 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
             cnd[u] = scan(w[u], nx63[u], Wall[u]);
         }
         if (__any((cnd[0] | cnd[1] | cnd[2] | cnd[3]) != 0)) candidates(g0, cnd, Wall);
+    }
+    // Phase 3: the parked candidates, one per lane
+    __syncthreads();
+    const uint32_t nq = qn < FG_IXQ ? qn : FG_IXQ;
+    for (uint32_t e = threadIdx.x; e < nq; e += 256) {
+        const uint32_t *qe = &qw[e * 6];
+        const uint32_t Hh[4] = {qe[2], qe[3], qe[4], qe[5]};
+        check(((u64)qe[1] << 32) | qe[0], Hh);
     }
 }
 
