@@ -607,14 +607,15 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     unsigned long long *tail = (unsigned long long *)c->h_res;   // total bytes, OR of error flags
     auto finish_pass = [&](bool first) -> bool {
         // (frame sizes of the pipeline's blocks: from the chunk bit counts, inside the scan)
-        if (fg_launch_scan((FgBlockResult *)c->results.p, piped ? PL.B.chunk_bits : nullptr, nblocks, (unsigned long long *)c->offsets.p, c->stream) != 0) {
+        if (fg_launch_scan((FgBlockResult *)c->results.p, piped ? PL.B.chunk_bits : nullptr, nblocks, (unsigned long long *)c->offsets.p,
+                           (piped && first && nfast == nblocks && d_out) ? 1 : 0, piped ? PL.B.guard + 2 : nullptr, c->stream) != 0) {
             fg_set_error("scan kernel launch failed"); return false;
         }
         if (first) mark();
         const bool asm_here = d_out && piped;       // the assembly kernel also hands out the frame index and the guard counters
         if (d_out) {
             const int rc = piped ? fg_launch_pipe_assemble((const FgBlockDesc *)c->descs.p, nblocks, (const uint8_t *)c->slots.p, P.slot_bytes,
-                                                           chunk_cap_words, nw, PL.B.chunk_bits, (const FgBlockResult *)c->results.p,
+                                                           chunk_cap_words, nw, PL.B.chunk_bits, (FgBlockResult *)c->results.p,
                                                            (unsigned long long *)c->offsets.p, (uint8_t *)d_out, out_cap,
                                                            (const uint16_t *)c->crctab.p, (unsigned long long *)d_offsets, PL.B.guard, c->stream)
                                  : fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,

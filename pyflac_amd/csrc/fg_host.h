@@ -29,7 +29,7 @@ size_t fg_pipe_scratch_bytes(const FgEncParams *P, uint32_t nblocks);
 void fg_pipe_carve(const FgEncParams *P, uint32_t nblocks, void *base, FgPipeBufs *B);
 int fg_launch_encode_pipe(const FgPipeLaunch *L);
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
-                            uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
+                            uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
                             unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream);
 int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes,
@@ -41,7 +41,8 @@ int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned
 int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
                      const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
                      unsigned long long seq, hipStream_t stream);
-int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream);
+int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, int all_pipe,
+                   const unsigned long long *d_errs, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
                    const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap);
 int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len, const unsigned long long *d_offsets, uint32_t nframes,

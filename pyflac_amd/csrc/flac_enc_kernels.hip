@@ -1233,8 +1233,14 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
 // tile are issued before anything is stored (the stores into `results` would otherwise fence the later loads).
 #define FG_SCAN_TILE 8192
 #define FG_SCAN_PER (FG_SCAN_TILE / 1024)
+// `all_pipe` (every block went through the pipeline, first pass): the sizes come from the chunk bit counts alone -- 16 bytes
+// a block, coalesced -- and the OR of the error flags from the pipeline's own word (errs_in); nothing is read from the
+// 32-byte result records, whose 21 k strided lines through one CU's L1 were most of this kernel's time.  (A block that
+// waits for the generic kernel gets a wrong size here: the host sees FG_ERR_REDO in the flags and repeats the scan in the
+// general form after the redo.)
 __global__ void __launch_bounds__(1024)
-fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets)
+fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets, uint32_t all_pipe,
+                     const unsigned long long *errs_in)
 {
     __shared__ u64 wtot[16];
     __shared__ uint32_t errs;
@@ -1252,8 +1258,11 @@ fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_
             const uint32_t b = t0 + j * 1024 + tid;
             r[j] = make_uint4(0, 0, 0, 0); cb[j] = r[j]; kind[j] = 0;
             if (b < nblocks) {
-                r[j] = *(const uint4 *)&results[b];                        // bytes, ca, err, best_bits[0]
-                kind[j] = results[b].reserved;
+                if (all_pipe) kind[j] = 4;
+                else {
+                    r[j] = *(const uint4 *)&results[b];                    // bytes, ca, err, best_bits[0]
+                    kind[j] = results[b].reserved;
+                }
                 if (chunk_bits) cb[j] = *(const uint4 *)&chunk_bits[(size_t)b * 4];
             }
         }
@@ -1263,8 +1272,8 @@ fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_
             uint32_t bytes = r[j].x;
             e |= r[j].z;
             if (chunk_bits && kind[j] == 4) {
-                bytes = (r[j].z & FG_ERR_REDO) ? 0u : ((cb[j].x + cb[j].y + cb[j].z + cb[j].w + 7) >> 3) + 2;
-                if (b < nblocks) results[b].bytes = bytes;
+                bytes = (b >= nblocks || (r[j].z & FG_ERR_REDO)) ? 0u : ((cb[j].x + cb[j].y + cb[j].z + cb[j].w + 7) >> 3) + 2;
+                if (!all_pipe && b < nblocks) results[b].bytes = bytes;       // (all_pipe: the assembly kernel writes it back)
             }
             sz[j * 1024 + tid] = bytes;
         }
@@ -1289,7 +1298,7 @@ fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_
     }
     if (e) atomicOr(&errs, e);
     __syncthreads();
-    if (tid == 0) { offsets[nblocks] = carry; offsets[nblocks + 1] = errs; }
+    if (tid == 0) { offsets[nblocks] = carry; offsets[nblocks + 1] = (all_pipe && errs_in) ? (u64)errs_in[0] : (u64)errs; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -1453,10 +1462,12 @@ int fg_launch_widen16(const int16_t *d_src, int32_t *d_dst, unsigned long long n
     return (int)hipGetLastError();
 }
 
-int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, hipStream_t stream)
+int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, int all_pipe,
+                   const unsigned long long *d_errs, hipStream_t stream)
 {
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, d_offsets);
+    hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, d_offsets,
+                       (uint32_t)((all_pipe && d_chunk_bits && d_errs) ? 1 : 0), d_errs);
     return (int)hipGetLastError();
 }
 

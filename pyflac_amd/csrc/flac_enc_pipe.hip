@@ -76,7 +76,7 @@ int fg_launch_encode_pipe(const FgPipeLaunch *L)
 }
 
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
-                            uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, const FgBlockResult *d_results,
+                            uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
                             unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream)
 {

@@ -165,7 +165,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     // near-tie guard of the LPC order guess (Levinson-Durbin kernel, next launch): count 0, smallest margin +infinity
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (B.stamp) B.stamp[0] = wall_clock64();
-        if (B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; }
+        if (B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }     // ([2]: OR of the error flags of the pipeline's blocks)
     }
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
@@ -1212,6 +1212,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         r->best_bits[C] = best;
         if (C == 0) {
             r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
+            if (range_err && B.guard) atomicOr(&B.guard[2], (unsigned long long)range_err);
 #pragma unroll
             for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
             for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)d.out_slot * 4 + w] = 0;     // the packing waves fill in theirs
@@ -1604,7 +1605,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     if (lane == 0) {
         B.chunk_bits[(size_t)d.out_slot * 4 + chunk] = redo ? 0 : bitpos;
         const uint32_t e = fb.err | (redo ? FG_ERR_REDO : 0u);
-        if (e) atomicOr(&results[d.out_slot].err, e);
+        if (e) { atomicOr(&results[d.out_slot].err, e); if (B.guard) atomicOr(&B.guard[2], (unsigned long long)e); }
     }
 }
 
@@ -1616,7 +1617,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 template <int WPB>
 __global__ void __launch_bounds__(WPB * 64)
 fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_t *slots, uint32_t slot_bytes, uint32_t chunk_cap_words,
-                        uint32_t nw, const uint32_t *chunk_bits, const FgBlockResult *results, u64 *offsets, uint8_t *dst,
+                        uint32_t nw, const uint32_t *chunk_bits, FgBlockResult *results, u64 *offsets, uint8_t *dst,
                         u64 dst_cap, const uint16_t *crctab, u64 *user_offsets, const unsigned long long *guard)
 {
     __shared__ uint16_t tab[1792];           // [0,256) byte table, [256,768) x^2048 tables, [768,832) x^(32k), [1024,1792) slicing tables
@@ -1627,7 +1628,19 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
     const FgBlockResult res = results[d.out_slot];
-    const uint32_t nb = res.bytes;
+    // chunk table of a pipeline block (wave-uniform); its size is ceil(sum of the chunk bits / 8) + 2 for the CRC-16, and 0
+    // while it waits for the generic kernel (FG_ERR_REDO)
+    uint32_t S[4], Bc[4];
+    const uint32_t *cw[4];
+    uint32_t T = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t b = ((uint32_t)w < nw && res.reserved == 4) ? chunk_bits[(size_t)d.out_slot * 4 + w] : 0;
+        S[w] = T; Bc[w] = b; T += b;
+        cw[w] = (const uint32_t *)(slots + (size_t)d.out_slot * slot_bytes) + (size_t)w * chunk_cap_words;
+    }
+    const uint32_t nb = res.reserved == 4 ? ((res.err & FG_ERR_REDO) ? 0u : ((T + 7) >> 3) + 2) : res.bytes;
+    if (lane == 0 && res.reserved == 4) results[d.out_slot].bytes = nb;        // (the scan no longer writes the pipeline's sizes back)
     // the frame index for the caller (saves a device-to-device copy), and the guard counters beside the totals the host reads
     if (lane == 0 && user_offsets) {
         user_offsets[d.out_slot] = offsets[d.out_slot];
@@ -1644,16 +1657,6 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
         const uint32_t done = nwd * 4;
         if ((uint32_t)lane < nb - done) out[done + lane] = ((const uint8_t *)sw)[done + lane];
         return;
-    }
-    // chunk table (wave-uniform)
-    uint32_t S[4], Bc[4];
-    const uint32_t *cw[4];
-    uint32_t T = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t b = (uint32_t)w < nw ? chunk_bits[(size_t)d.out_slot * 4 + w] : 0;
-        S[w] = T; Bc[w] = b; T += b;
-        cw[w] = (const uint32_t *)(slots + (size_t)d.out_slot * slot_bytes) + (size_t)w * chunk_cap_words;
     }
     const uint32_t nbytes = (T + 7) >> 3;            // frame without its CRC-16
     const uint32_t W = nbytes >> 2, tail = nbytes & 3;
