@@ -339,7 +339,7 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
     if (alive) fg_frame_reader(br, stream, stream_len, fr, rings + lane * FG_RSTR);
     if (FUSED) {
         __syncthreads();                                    // the feeding wave has filled the first groups of every ring
-        if (alive) { const uint32_t hp = L.feed[64 + lane]; br.H = hp > br.H ? hp : br.H; }
+        if (alive) { const uint32_t hp = L.feed[128 + lane]; br.H = hp > br.H ? hp : br.H; }
     }
     if (alive) br.init_words();
 
@@ -455,7 +455,7 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
                 if (FUSED) {
                     // how far the feeding wave has got (published a tile ago); a lane that is short all the same -- very
                     // long codes, the first tiles of a frame -- fetches for itself
-                    if (alive) { const uint32_t hp = L.feed[64 + lane]; br.H = hp > br.H ? hp : br.H; }
+                    if (alive) { const uint32_t hp = L.feed[128 + lane]; br.H = hp > br.H ? hp : br.H; }
                     br.ensure_ahead(act);
                 }
                 else {
@@ -567,12 +567,12 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
             // ---- hand the tile to the helper wave: the row's facts, then the barrier (it also orders the LDS writes)
             {
                 uint32_t *m = metas + (it & 1) * 64 * FG_META + lane * FG_META;
-                m[0] = (rn << 8) | tk;                                  // block sizes are below 2^16; rn = 0 for idle lanes
-                m[1] = (uint32_t)roff; m[2] = (uint32_t)(roff >> 32);
-                m[3] = (uint32_t)tmask; m[4] = (uint32_t)(tmask >> 32);
-                m[5] = cval;
+                // (rn << 8) | tk: block sizes are below 2^16, rn = 0 for idle lanes; output offset; mask; constant value -- one
+                // 16-byte and one 8-byte store (the rows are 32 bytes apart)
+                *(uint4 *)m = make_uint4((rn << 8) | tk, (uint32_t)roff, (uint32_t)(roff >> 32), (uint32_t)tmask);
+                *(uint2 *)(m + 4) = make_uint2((uint32_t)(tmask >> 32), cval);
             }
-            if (FUSED) { L.feed[lane] = br.wb; L.feed[128 + lane] = br.H; }       // read position and what this lane fetched itself, for the feeding wave
+            if (FUSED) *(uint2 *)(L.feed + 2 * lane) = make_uint2(br.wb, br.H);   // read position and what this lane fetched itself, for the feeding wave
             __syncthreads();
             it++;
             if (act && br.pos() > end_bits) { err = 4; alive = false; rn = 0; }
@@ -1139,7 +1139,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     uint32_t *const rnm = rt + FG_RT * (G + 1) * FG_TSTR;     // samples per row, per residual tile: FG_RT x 64
     L.subp = rnm + FG_RT * 64;                                // 4 x G x FG_SUBP
     L.frm = L.subp + 4 * G * FG_SUBP;                         // G x FG_FRM
-    L.feed = L.frm + G * FG_FRM;                              // [0, 64): the parser's read positions, [64, 128): fill levels (feeder), [128, 192): fill levels (parser)
+    L.feed = L.frm + G * FG_FRM;                              // [0, 128): the parser's (read position, own fill level) pairs, [128, 192): fill levels from the feeder
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     if (prof && lane == 0) {
@@ -1161,9 +1161,9 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     if (wave == 1) {
         // ---- converter, and feeder of the parser's rings (lane = frame): the parser spends a third of its time per tile
         // requesting, byte-swapping and parking the eight groups its lanes consume -- this wave has that time to spare.  Per
-        // tile: park what was requested a tile ago, publish the fill level (L.feed[64 + lane]; the parser reads it after
+        // tile: park what was requested a tile ago, publish the fill level (L.feed[128 + lane]; the parser reads it after
         // the next barrier), request the next groups behind the parser's read position as it was at the end of the last
-        // tile (L.feed[lane]).  Three tiles pass between a read position and the data it asked for being usable, so the
+        // tile (L.feed[2 lane]).  Three tiles pass between a read position and the data it asked for being usable, so the
         // rings start 40 groups full (five round trips before the parser's first word) and the parser keeps its own
         // fetch for lanes that run short.  Parked slots lie beyond everything the parser may read (same bound as before,
         // taken from an older -- smaller -- read position), and a group both waves happen to fetch has the same bytes.
@@ -1178,20 +1178,20 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 if (fr.bytes != 0 && fr.bytes >= fr.hdr_bytes + 2) { feeding = true; fg_frame_reader(fd, stream, stream_len, fr, L.rings + lane * FG_RSTR); }
             }
             for (int r = 0; r < 5; r++) { fd.issue(feeding, false); fd.land(); }
-            L.feed[lane] = fd.wb;
-            L.feed[64 + lane] = fd.H;
+            *(uint2 *)(L.feed + 2 * lane) = make_uint2(fd.wb, fd.H);
             L.feed[128 + lane] = fd.H;
         }
         FG_BAR();
         for (uint32_t j = 1; j <= T + 2; j++) {
             FG_BAR();
             if (j <= T) {
-                fd.wb = L.feed[lane];
+                const uint2 pp = *(const uint2 *)(L.feed + 2 * lane);          // the parser's read position and own fill level
+                fd.wb = pp.x;
                 fd.land();
                 // (a lane that outran the feed fetched for itself: go on behind what it has, not behind our own count --
                 // groups the parser has passed must not be parked over newer ones)
-                { const uint32_t hs = L.feed[128 + lane]; fd.H = hs > fd.H ? hs : fd.H; }
-                L.feed[64 + lane] = fd.H;
+                fd.H = pp.y > fd.H ? pp.y : fd.H;
+                L.feed[128 + lane] = fd.H;
                 fd.issue(feeding, false);
             }
             if (j <= T) {
