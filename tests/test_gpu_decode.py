@@ -196,3 +196,21 @@ def test_index_finds_nothing_in_garbage(ctx):
     offs = torch.tensor([0, 1 << 40, 5, 4096], dtype=torch.int64).cuda()
     dec, status, st = ctx.decode(data, offs, 2, 16, 1 << 16)
     assert st.error_frames == 3 and st.total_samples == 0
+
+
+def test_index_candidate_queue_overflow_fails_loudly(ctx):
+    """A stretch of the stream that is nothing but sync codes overflows the index kernel's candidate queue (512 per
+    workgroup): the call must say so (the host indexer then takes over in the stream decoder) -- no fault, no silent
+    result."""
+    import torch
+    from pyflac_amd import batch
+    data = torch.from_numpy(np.frombuffer(b'\xff\xf8' * (1 << 17), np.uint8).copy()).cuda()
+    with pytest.raises(batch.FlacGpuError):
+        ctx.decode_stream(data, 2, 16, 1 << 20, nframes=64)
+    # and the context is still good for a real stream afterwards
+    from pyflac_amd import synth
+    pcm = torch.from_numpy(synth.config2_stereo16(1.0, 5).astype(np.int32)).cuda()
+    s = batch.settings(5, 2, 16, 48000, 4096, True)
+    out, offs, st = ctx.encode(s, pcm)
+    dec, status, dst = ctx.decode_stream(out[:st.total_bytes], 2, 16, pcm.shape[0], nframes=st.nblocks)
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec[:pcm.shape[0]], pcm)
