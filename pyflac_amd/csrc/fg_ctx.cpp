@@ -514,8 +514,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             const uint64_t cnt = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
             uint32_t last = streams[i].prev_channel_assignment == 3 ? 3u : 0u;
             for (uint64_t k = 0; k < cnt; k++) {
-                if (decision[bi + k] != 0xFFFFFFFFu) last = decision[bi + k];
-                descs[bi + k].forced_ca = last;
+                const bool decides = decision[bi + k] != 0xFFFFFFFFu;
+                if (decides) last = decision[bi + k];
+                descs[bi + k].forced_ca = (decides && last == 3) ? (3u | 0x80u) : last;
             }
             bi += cnt;
             st->last_channel_assignment = last;

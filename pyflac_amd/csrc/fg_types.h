@@ -37,7 +37,10 @@ struct FgBlockDesc {
     uint32_t n;            // samples per channel in this block
     uint32_t frame_number;
     uint32_t win_off;      // offset (floats) of this block length's window table
-    uint32_t forced_ca;    // 0xFF = choose; else 0 or 3 (loose mid-side follower frames)
+    uint32_t forced_ca;    // 0xFF = choose; else 0 or 3 (loose mid-side: the frames between two decisions copy the last one and
+                           // evaluate only what they use; 3 | 0x80 = the decision frame itself when it chose mid/side: libFLAC
+                           // evaluated all four candidates there, so limit_min_bitrate applies to mid and side as in any
+                           // full frame -- a follower's mid/side are never limited)
     uint32_t out_slot;     // index of the output slot / result / debug record of this block
     uint32_t reserved;
 };

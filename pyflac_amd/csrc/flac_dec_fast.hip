@@ -82,6 +82,9 @@ struct BitRd {
     uint32_t w0, w1, w2, w3, s;
     uint32_t wb;            // byte offset (relative to fg) of the next word to read from the ring; w3 = word wb/4 - 1
     uint32_t H;             // groups below H are in the ring (or already consumed)
+    uint32_t hlim;          // this reader must not fetch groups at or beyond hlim itself (fused kernel: another wave may still
+                            // be parking the groups 64 below them into the same slots, see FgRingFeed); ~0 = no limit
+    bool over;              // ... it wanted to: the frame goes to the generic decoder
     uint32_t pfH, pfn;      // groups [pfH, pfH + FG_PF) are in flight, the first pfn of them count
     bool pfvalid;
     fg_u32x4 pf[FG_PF];
@@ -97,6 +100,7 @@ struct BitRd {
     }
     __device__ __forceinline__ void selfload()
     {
+        if (H >= hlim) { over = true; H++; return; }       // (what is read from here on is unspecified; the caller gives the frame up)
         park(H, ldgroup(H));
         H++;
     }
@@ -176,8 +180,12 @@ struct BitRd {
     __device__ __forceinline__ void land()
     {
         if (fg && pfvalid) {       // lanes without a frame own no ring; nothing was requested before the first tile
+            // only groups that are not there yet, and only into slots whose old group (64 below) lies behind the read
+            // position: after a leap -- a code of several hundred bytes, fetched word by word -- the registers hold
+            // groups the reader has long passed, and their slots belong to newer ones
+            const uint32_t cg = wb >> 4;
 #pragma unroll
-            for (int t = 0; t < FG_PF; t++) park(pfH + t, pf[t]);
+            for (int t = 0; t < FG_PF; t++) { const uint32_t g = pfH + t; if (g >= H && g < cg + 63) park(g, pf[t]); }
         }
         const uint32_t h2 = pfH + pfn;
         H = h2 > H ? h2 : H;
@@ -335,8 +343,16 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
     const uint32_t end_bits = alive ? (fr.bytes - 2) * 8 : 0;
     BitRd br;
     br.fg = nullptr; br.glim = 0; br.skip0 = 0; br.ring = rings; br.w0 = 0; br.w1 = 0; br.w2 = 0; br.w3 = 0; br.s = 0; br.wb = 12; br.H = 0;
+    br.hlim = ~0u; br.over = false;
     br.pfH = 0; br.pfn = 0; br.pfvalid = false;
     if (alive) fg_frame_reader(br, stream, stream_len, fr, rings + lane * FG_RSTR);
+    // Read positions (in groups) at the end of the last tile and of the one before.  What the feeding wave parks during a
+    // tile was requested one tile earlier behind the position of two tiles ago (cg_e2), in [cg_e2, cg_e2 + 60): a group this
+    // wave fetched for itself at or beyond cg_e2 + 64 would share a slot with one of those and could be overwritten by
+    // it.  Tiles of ordinary codes advance 16 groups at most; a frame with codes of hundreds of bytes (residuals near
+    // 2^31 under a small Rice parameter) leaps further, hits the limit and goes to the generic decoder (status 3).
+    uint32_t cg_e1 = br.wb >> 4, cg_e2 = cg_e1;
+    if (FUSED) br.hlim = cg_e2 + 64;
     if (FUSED) {
         __syncthreads();                                    // the feeding wave has filled the first groups of every ring
         if (alive) { const uint32_t hp = L.feed[128 + lane]; br.H = hp > br.H ? hp : br.H; }
@@ -456,6 +472,7 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
                     // how far the feeding wave has got (published a tile ago); a lane that is short all the same -- very
                     // long codes, the first tiles of a frame -- fetches for itself
                     if (alive) { const uint32_t hp = L.feed[128 + lane]; br.H = hp > br.H ? hp : br.H; }
+                    br.hlim = cg_e2 + 64;
                     br.ensure_ahead(act);
                 }
                 else {
@@ -572,14 +589,19 @@ __device__ __forceinline__ void fg_parse_wave(const uint8_t *stream, u64 stream_
                 *(uint4 *)m = make_uint4((rn << 8) | tk, (uint32_t)roff, (uint32_t)(roff >> 32), (uint32_t)tmask);
                 *(uint2 *)(m + 4) = make_uint2((uint32_t)(tmask >> 32), cval);
             }
-            if (FUSED) *(uint2 *)(L.feed + 2 * lane) = make_uint2(br.wb, br.H);   // read position and what this lane fetched itself, for the feeding wave
+            if (FUSED) {
+                *(uint2 *)(L.feed + 2 * lane) = make_uint2(br.wb, br.H);          // read position and what this lane fetched itself, for the feeding wave
+                cg_e2 = cg_e1; cg_e1 = br.wb >> 4;
+            }
             __syncthreads();
             it++;
-            if (act && br.pos() > end_bits) { err = 4; alive = false; rn = 0; }
+            if (alive && br.over) { err = 3; alive = false; rn = 0; }      // (see hlim: the generic decoder takes the frame)
+            else if (act && br.pos() > end_bits) { err = 4; alive = false; rn = 0; }
             FG_TICK(4);
         }
     }
     if (accepted) {
+        if (br.over) err = 3;              // (only ever set while the lane was still parsing: what followed is not to be trusted)
         if (!err) {
             const uint32_t endb = (br.pos() + 7) & ~7u;
             const uint32_t padb = endb - br.pos();
@@ -1169,6 +1191,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         // taken from an older -- smaller -- read position), and a group both waves happen to fetch has the same bytes.
         BitRd fd;
         fd.fg = nullptr; fd.glim = 0; fd.skip0 = 0; fd.ring = L.rings; fd.w0 = fd.w1 = fd.w2 = fd.w3 = 0; fd.s = 0; fd.wb = 12; fd.H = 0;
+        fd.hlim = ~0u; fd.over = false;
         fd.pfH = 0; fd.pfn = 0; fd.pfvalid = false;
         bool feeding = false;
         {

@@ -984,7 +984,7 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     // ================================================================ channel assignment
     uint32_t ca = 0, sub0 = 0, sub1 = 1;
     if (MS) {
-        if (d.forced_ca != 0xFF) ca = d.forced_ca;
+        if (d.forced_ca != 0xFF) ca = d.forced_ca & 0x7F;       // (bit 7: a loose mid-side DECISION frame, see FgBlockDesc)
         else {
             const uint32_t b01 = best[0] + best[NC > 1 ? 1 : 0], b03 = best[0] + best[NC > 3 ? 3 : 0];
             const uint32_t b13 = best[NC > 1 ? 1 : 0] + best[NC > 3 ? 3 : 0], b23 = best[NC > 2 ? 2 : 0] + best[NC > 3 ? 3 : 0];

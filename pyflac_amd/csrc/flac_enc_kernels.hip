@@ -1163,7 +1163,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
         e.stage(pcm, d.pcm_off, 0, 2);
         e.analyse(0, mydbg);
         uint32_t b0 = e.decs[0].bits, b1 = e.decs[1].bits, b2 = e.decs[2].bits, b3 = e.decs[3].bits;
-        if (d.forced_ca != 0xFF) ca = d.forced_ca;
+        if (d.forced_ca != 0xFF) ca = d.forced_ca & 0x7F;       // (bit 7: a loose mid-side DECISION frame, see FgBlockDesc)
         else {
             uint32_t bits[4] = {b0 + b1, b0 + b3, b1 + b3, b2 + b3};
             uint32_t mn = bits[0];

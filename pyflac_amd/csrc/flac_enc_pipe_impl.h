@@ -1337,7 +1337,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     // ---- channel assignment from the four candidate totals (every wave computes it; wave-uniform)
     uint32_t ca = 0, c = si;
     if (MS) {
-        if (d.forced_ca != 0xFF) ca = d.forced_ca;
+        if (d.forced_ca != 0xFF) ca = d.forced_ca & 0x7F;       // (bit 7: a loose mid-side DECISION frame, see FgBlockDesc)
         else {
             const uint32_t b0 = rfl(B.dec[(size_t)bi * NC + 0].bits), b1 = rfl(B.dec[(size_t)bi * NC + (NC > 1 ? 1 : 0)].bits);
             const uint32_t b2 = rfl(B.dec[(size_t)bi * NC + (NC > 2 ? 2 : 0)].bits), b3 = rfl(B.dec[(size_t)bi * NC + (NC > 3 ? 3 : 0)].bits);

@@ -53,7 +53,7 @@ def _signal(r, n, ch, bps):
         if r.random() < 0.3:
             x[:, -1] = np.round(x[:, -1] / (1 << min(bps - 2, w + 2))) * (1 << min(bps - 2, w + 2))
     elif kind == 'decay':
-        x = amp * np.exp(-t / r.uniform(n / 50 + 1, n)) * np.sin(t * r.uniform(0.01, 0.4, ch)) + r.normal(0, 0.6, (n, ch))
+        x = amp * np.exp(-t / r.uniform(n / 50 + 1, max(n, n / 50 + 1))) * np.sin(t * r.uniform(0.01, 0.4, ch)) + r.normal(0, 0.6, (n, ch))
     else:  # steps
         lv = r.integers(-amp - 1, amp + 1, (n // int(r.integers(50, 3000)) + 2, ch))
         x = lv[np.minimum(np.arange(n) * len(lv) // max(n, 1), len(lv) - 1)].astype(np.float64)

@@ -214,3 +214,24 @@ def test_index_candidate_queue_overflow_fails_loudly(ctx):
     out, offs, st = ctx.encode(s, pcm)
     dec, status, dst = ctx.decode_stream(out[:st.total_bytes], 2, 16, pcm.shape[0], nframes=st.nblocks)
     assert int(status[:, 0].max()) == 0 and torch.equal(dec[:pcm.shape[0]], pcm)
+
+
+def test_codes_of_hundreds_of_bytes_leave_the_fast_decoder(ctx):
+    """Fuzz seed 79157 (found in round 2): three 32-bit channels of step signals under a small Rice parameter -- single codes
+    run over hundreds of bytes, the parser fetches its way through them word by word and leaps past everything the feeding
+    wave of the fused kernel expects.  Groups still in flight then shared ring slots with newer ones and overwrote them
+    (status 4 on a good frame).  The leap is now detected and the frame handed to the generic decoder; the result is the
+    input."""
+    import torch
+    from oracle import oracle as O
+    from tests import fuzzgen
+    c = fuzzgen.case(79157)
+    cfg, _rc = O.config(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+    a32 = np.ascontiguousarray(c['pcm'].astype(np.int32))
+    want, _ = O.encode_stream(cfg, a32)
+    _pcm, _res, offs = O.decode_stream(want, want_offsets=True)
+    o = np.asarray(list(offs) + [len(want)], np.uint64) - 86
+    body = torch.from_numpy(np.frombuffer(want[86:], np.uint8).copy()).cuda()
+    dec, status, st = ctx.decode(body, o, c['ch'], c['bps'], len(a32))
+    assert status[:, 0].tolist() == [0] * (len(o) - 1)
+    assert torch.equal(dec.reshape(-1, c['ch'])[:len(a32)].cpu(), torch.from_numpy(a32))

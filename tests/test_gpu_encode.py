@@ -413,3 +413,27 @@ def test_wasted_bits_differ_between_candidates(ctx):
             for v in range(oc.n_vectors):
                 assert oc.lpc_bits[v] == gc.lpc_bits[v], (b, c, v)
     assert len(seen) > 1
+
+
+@pytest.mark.parametrize('seed', [79464, 93095])
+def test_loose_mid_side_decision_frame_with_limit_min_bitrate(ctx, seed):
+    """Fuzz seeds 79464 / 93095 (found in round 2): levels 1 and 4 decide between independent and mid/side coding on every
+    n-th frame and copy the decision in between.  libFLAC evaluates all four candidates on a DECISION frame, so
+    limit_min_bitrate (no frame of CONSTANT subframes only) applies to its mid and side channels as in any full frame; the
+    frames that merely copy the decision evaluate mid/side alone and are never limited.  The decision frame used to be
+    encoded like a copying one: a silent first block came out with a CONSTANT mid channel."""
+    import torch
+    from pyflac_amd import batch
+    from pyflac_amd.encoder import stream_header_bytes
+    from oracle import oracle as O
+    from tests import fuzzgen
+    c = fuzzgen.case(seed)
+    assert c['limit_min_bitrate'] and c['level'] in (1, 4)
+    cfg, _rc = O.config(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+    s = batch.settings(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+    cfg.limit_min_bitrate = 1
+    s.limit_min_bitrate = 1
+    a32 = np.ascontiguousarray(c['pcm'].astype(np.int32))
+    want, _ = O.encode_stream(cfg, a32)
+    out, offs, st = ctx.encode(s, torch.from_numpy(a32).cuda())
+    assert stream_header_bytes(s) + out[:st.total_bytes].cpu().numpy().tobytes() == want

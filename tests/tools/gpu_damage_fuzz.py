@@ -13,6 +13,8 @@ def damaged(data, audio_off, r):
     for _ in range(int(r.integers(1, 6))):
         kind = r.choice(['flip', 'flip', 'flip', 'del', 'ins', 'trunc', 'zero'])
         pos = int(r.integers(audio_off, max(audio_off + 1, len(d))))
+        if pos >= len(d):
+            continue                            # (an earlier truncation left nothing behind the metadata)
         if kind == 'flip':
             d[pos] ^= int(r.integers(1, 256))
         elif kind == 'del':
