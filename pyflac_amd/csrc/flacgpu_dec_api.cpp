@@ -198,7 +198,9 @@ struct Indexer {
             // is damaged: resynchronise (below).
             const bool at_end = scan >= len;
             if (at_end && final && in_frame && !tail_checked && !fast) crc_to(d, len);
-            const bool want_resync = in_frame && ((scan - frame_start > max_len) || (at_end && final && !fast && crc != 0 && !tail_checked));
+            // (tail_checked: the search below already ran to the end of the final data for this frame and found nothing --
+            // without it a last frame longer than max_len asked for the same search forever)
+            const bool want_resync = in_frame && !tail_checked && ((scan - frame_start > max_len) || (at_end && final && !fast && crc != 0));
             if (want_resync && fast) { fast_failed = true; return; }
             if (at_end && !want_resync) break;
             if (!in_frame) {
@@ -288,7 +290,11 @@ struct Indexer {
                             if (!cut_sync && d[e + 1] == 0xFF && e + 2 < len && (d[e + 2] & 0xFC) == 0xF8) cut_sync = e + 1;
                         }
                     }
-                    const uint64_t cut = cut_sync ? cut_sync : cut_any;
+                    // (c2 == 0 here: the whole stretch up to the next header is ONE intact frame that is merely longer than
+                    // any libFLAC encoder would make it -- escape-coded partitions with more raw bits than the sample size,
+                    // Rice codes longer than verbatim samples; a zero of the running CRC inside it is then a coincidence,
+                    // one per 64 KiB)
+                    const uint64_t cut = c2 == 0 ? 0 : (cut_sync ? cut_sync : cut_any);
                     if (cut) bounds.push_back(cut);
                     bounds.push_back(p2);
                     frame_start = p2; crc = 0; crc_pos = p2; open_frame(h);

@@ -130,3 +130,25 @@ def test_frame_index_resynchronises_after_damage(L, name):
     kept = [moved(int(p)) for p in offs[:-1] if not header_hit(int(p))]
     assert len(kept) >= len(offs) - 3 or any(e[0] == 'trunc' for e in edits) or name == 'many_flips'
     assert all(p in got for p in kept), sorted(set(kept) - got)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('seed', [1, 5, 17, 40])
+def test_host_frame_index_on_frames_longer_than_any_encoder_makes_them(seed):
+    """Valid streams whose frames exceed the verbatim size (escape-coded partitions with more raw bits than the sample
+    size: tests/tools/dec_stream_fuzz.py builds them bit by bit) -- the host index bounds a frame by that size to
+    resynchronise after damage, so these go through its resync path.  Seed 1 (round 2): the LAST frame of such a stream
+    made the search repeat forever (a hang in FLAC__stream_decoder_process_*); seed 5: a chance zero of the running
+    CRC-16 inside a 200 KB frame was taken for a frame end.  The offsets must be the oracle's."""
+    import importlib.util
+    from oracle import oracle as O
+    from pyflac_amd import batch
+    spec = importlib.util.spec_from_file_location('dsf', os.path.join(os.path.dirname(__file__), 'tools', 'dec_stream_fuzz.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    c = m.case(seed)
+    assert c is not None
+    data = c[0]
+    _p, _r, ooffs = O.decode_stream(data, want_offsets=True)
+    hoffs, _si = batch.index_frames(data)
+    assert [int(x) for x in hoffs] == [int(x) for x in ooffs] + [len(data)]
