@@ -981,10 +981,17 @@ bool decode_available(DecImpl *d)
     std::vector<FgDecResult> status(nframes);
     std::vector<FgDecFrame> frames;
     d->detail.level = d->subframe_detail;
-    if (!decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
-                            cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr)) {
-        d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
+    bool ok = decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
+                                 cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr);
+    if (!ok && st.total_samples > cap && st.total_samples <= (uint64_t)nframes * 65535) {
+        // A frame header that names a larger block than STREAMINFO's maximum (damage that the CRC-8 let through, or a stream
+        // that lies about itself): libFLAC decodes such a frame all the same.  Once more with room for what the headers say.
+        cap = st.total_samples;
+        if (!d->d_pcm.ensure((size_t)cap * Cb * 4)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+        ok = decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
+                                cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr);
     }
+    if (!ok) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     lap("decode", tl);
     const size_t npcm = (size_t)st.total_samples * (C ? C : 2);
     if (!d->pcm.ensure(npcm)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
