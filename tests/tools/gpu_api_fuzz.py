@@ -24,16 +24,22 @@ for seed in range(first, first + count):
     if bps == 32:
         pcm = pcm * 256
     tag = 'seed %d ch%d bps%d bs%d l%d n%d' % (seed, ch, bps, bs, level, n)
+    verify = bool(r.random() < 0.3)
+    lmb = bool(r.random() < 0.3)
+    tag += ' verify' if verify else ''
+    tag += ' lmb' if lmb else ''
     cfg, rc = O.config(level, ch, bps, 44100, bs, True)
     if rc:
         continue
+    cfg.limit_min_bitrate = 1 if lmb else 0
     want, _ = O.encode_stream(cfg, pcm.astype(np.int32))
     cuts = sorted(set(int(x) for x in r.integers(0, n + 1, int(r.integers(0, 25)))))
     cuts = [0] + cuts + [n]
     if r.random() < 0.4:
         cuts = cuts[:1] + [cuts[1]] * 2 + cuts[1:]
     chunks = []
-    enc = pyflac_amd.StreamEncoder(44100, lambda b, nb, s, f: chunks.append(b), compression_level=level, blocksize=bs)
+    enc = pyflac_amd.StreamEncoder(44100, lambda b, nb, s, f: chunks.append(b), compression_level=level, blocksize=bs, verify=verify,
+                                   limit_min_bitrate=lmb)
     for a, b in zip(cuts[:-1], cuts[1:]):
         enc.process(pcm[a:b])
     if not enc.finish() or b''.join(chunks) != want:
