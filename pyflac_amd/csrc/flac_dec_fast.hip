@@ -184,8 +184,14 @@ struct BitRd {
             // position: after a leap -- a code of several hundred bytes, fetched word by word -- the registers hold
             // groups the reader has long passed, and their slots belong to newer ones
             const uint32_t cg = wb >> 4;
+            if (pfH >= H && pfH + FG_PF <= cg + 63) {       // (the usual case, straight-line)
 #pragma unroll
-            for (int t = 0; t < FG_PF; t++) { const uint32_t g = pfH + t; if (g >= H && g < cg + 63) park(g, pf[t]); }
+                for (int t = 0; t < FG_PF; t++) park(pfH + t, pf[t]);
+            }
+            else {
+#pragma unroll
+                for (int t = 0; t < FG_PF; t++) { const uint32_t g = pfH + t; if (g >= H && g < cg + 63) park(g, pf[t]); }
+            }
         }
         const uint32_t h2 = pfH + pfn;
         H = h2 > H ? h2 : H;
