@@ -152,3 +152,17 @@ def test_host_frame_index_on_frames_longer_than_any_encoder_makes_them(seed):
     _p, _r, ooffs = O.decode_stream(data, want_offsets=True)
     hoffs, _si = batch.index_frames(data)
     assert [int(x) for x in hoffs] == [int(x) for x in ooffs] + [len(data)]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('args', [['tests/tools/index_damage_fuzz.py', '0', '500'], ['tests/tools/dec_stream_fuzz.py', 'index', '0', '80']],
+                         ids=['damaged_small_block_streams', 'constructed_streams'])
+def test_host_frame_index_fuzz_slice(args):
+    """The host frame index needs no GPU: a slice of its two fuzzers (random damage on small-block streams under a watchdog;
+    constructed streams against the oracle's offsets) runs with the CPU suite."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable] + args, cwd=root, capture_output=True, text=True, timeout=550)
+    out = p.stdout.strip().splitlines()
+    assert p.returncode == 0 and out and re.search(r'\b0 bad', out[-1]), (out[-6:], p.stderr[-400:])
