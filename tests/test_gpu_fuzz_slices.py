@@ -15,9 +15,9 @@ def _run(args, timeout=600):
     p = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     tail = (p.stdout + p.stderr).strip().splitlines()[-12:]
     assert p.returncode == 0, tail
-    last = [ln for ln in p.stdout.splitlines() if re.search(r'\\b\\d+ bad', ln)]
+    last = [ln for ln in p.stdout.splitlines() if re.search(r'\b\d+ bad', ln)]
     assert last, tail
-    assert re.search(r'\\b0 bad', last[-1]), tail
+    assert re.search(r'\b0 bad', last[-1]), tail
 
 
 @pytest.mark.parametrize('args', [
