@@ -3,7 +3,7 @@
 (oracle/flac_oracle.c) on the bench's own input, in the BUILD container (the binary does not travel to the GPU box).
 bench.py reports the oracle's rate as cpu_baseline (kind "port") and quotes this ratio as a number.
 
-  python tools/cpu_ref_ratio.py [seconds] > profiles/r02_cpu_ref_ratio.json
+  python tests/tools/cpu_ref_ratio.py [seconds] > profiles/r02_cpu_ref_ratio.json
 """
 import json
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import libflac_ref as R     # noqa: E402
 from oracle import oracle as O           # noqa: E402
@@ -46,7 +46,7 @@ print(json.dumps({
     'what': 'reference binary (libFLAC 1.4.3 as bundled with pyFLAC 3.0.0) vs oracle/flac_oracle.c, 1 thread, MD5 off, best of 5',
     'host': 'build container (%d CPUs)' % (os.cpu_count() or 0),
     'sample': '%.0f s stereo 16-bit 48 kHz, level 5, blocksize 4096 (pyflac_amd.synth.config2_stereo16)' % secs,
-    'command': 'python tools/cpu_ref_ratio.py %.0f' % secs,
+    'command': 'python tests/tools/cpu_ref_ratio.py %.0f' % secs,
     'oracle_encode_msamples_per_s': round(n / t_or / 1e6, 2), 'reference_encode_msamples_per_s': round(n / t_ref / 1e6, 2),
     'oracle_decode_msamples_per_s': round(n / t_od / 1e6, 2), 'reference_decode_msamples_per_s': round(n / t_rd / 1e6, 2),
     'reference_over_oracle_encode': round(t_or / t_ref, 3), 'reference_over_oracle_decode': round(t_od / t_rd, 3),

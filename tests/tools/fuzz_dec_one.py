@@ -1,8 +1,8 @@
 """One fuzz case, decode side: the oracle's stream through the GPU decoder (fused and two-kernel form), per-frame status.
-usage: python tools/fuzz_dec_one.py <seed>"""
+usage: python tests/tools/fuzz_dec_one.py <seed>"""
 import os, sys, subprocess
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) > 2:
     os.environ['FLACGPU_DEC_FUSED'] = sys.argv[2]
 import torch

@@ -1,8 +1,8 @@
 """One fuzz case in detail: oracle frames vs GPU frames (first differing frame: header bytes, candidate records of the GPU).
-usage: python tools/fuzz_one.py <seed>"""
+usage: python tests/tools/fuzz_one.py <seed>"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import oracle as O
 from pyflac_amd import batch
