@@ -1059,6 +1059,7 @@ fg_dec_restore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t G, ui
 // remains is the channel-0 plane.  Frames the kernels cannot take (status 3) and frames that fail are settled afterwards
 // (generic kernel / fg_dec_fix_kernel writes silence).
 #define FG_RT 3             // residual tiles in flight
+#define FG_FUSED_GMAX 48    // frames per workgroup of the fused kernel at most (150 KB of LDS)
 
 template <int MAXO, bool WIDE, bool GATE>
 __device__ __forceinline__ void frestore_group(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, uint32_t ibase, uint32_t *rowp)
@@ -1151,7 +1152,8 @@ __device__ __forceinline__ void fg_dec_convert_tile(const uint32_t *tile, const 
     }
 }
 
-template <bool WIDE>
+// NR: rounds of 16 rows the output wave makes per tile (2 up to 32 frames per workgroup, 3 up to 48)
+template <bool WIDE, int NR>
 __global__ void __launch_bounds__(256)
 fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, uint32_t G, uint32_t narrow,
                     int32_t *scratch, FgDecSub *subs, FgDecResult *results, uint16_t *rparams, int32_t *warm, int32_t *out,
@@ -1282,14 +1284,16 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     // per lane and round of 16 rows, 16-byte LDS reads, loads and stores; the row's facts sit in the lane's registers (fetched
     // at the start of a channel).  Anything else (mono, more channels, tails, odd offsets): lane = column, row after row.
     const uint32_t nrnd = (G + 15) >> 4;
-    uint32_t f_c[2] = {0, 0}, f_ca[2] = {0, 0}, f_n[2] = {0, 0}, f_w[2] = {0, 0};
-    u64 f_oo[2] = {0, 0};
-    uint4 pa[2][4];                               // channel 0 of the tile that is next for the fast form (prefetched), per round
-    uint32_t pa_it[2] = {~0u, ~0u};               // ... and which tile that is
+    uint32_t f_c[NR] = {}, f_ca[NR] = {}, f_n[NR] = {}, f_w[NR] = {};
+    u64 f_oo[NR] = {};
+    uint4 pa[NR][4];                               // channel 0 of the tile that is next for the fast form (prefetched), per round
+    uint32_t pa_it[NR];               // ... and which tile that is
 #pragma unroll
-    for (int R = 0; R < 2; R++)
+    for (int R = 0; R < NR; R++) {
+        pa_it[R] = ~0u;
 #pragma unroll
         for (int t = 0; t < 4; t++) pa[R][t] = make_uint4(0, 0, 0, 0);
+    }
     const bool out_al = (((uintptr_t)out) & 15) == 0 && (((uintptr_t)scratch) & 15) == 0;
     u64 pw_busy[2] = {0, 0}, pw_b0 = 0;
     uint32_t pw_ch = 0;
@@ -1304,7 +1308,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         const uint32_t *rn_ = rnm + (it % FG_RT) * 64;
         if (i0 == 0) {
 #pragma unroll
-            for (int R = 0; R < 2; R++) {
+            for (int R = 0; R < NR; R++) {
                 const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                 const bool have = row < G;
                 const uint32_t *fm = L.frm + (have ? row : 0) * FG_FRM;
@@ -1318,7 +1322,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         {
             bool bad = false;
 #pragma unroll
-            for (int R = 0; R < 2; R++) {
+            for (int R = 0; R < NR; R++) {
                 const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                 if ((uint32_t)R < nrnd && row < G) {
                     const uint32_t rn = rn_[row];
@@ -1329,9 +1333,9 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
         }
         if (ok_fast) {
             const uint32_t cq = ((uint32_t)lane & 3) * 16;
-            bool live[2] = {false, false};
+            bool live[NR] = {};
 #pragma unroll
-            for (int R = 0; R < 2; R++) {
+            for (int R = 0; R < NR; R++) {
                 const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                 live[R] = (uint32_t)R < nrnd && row < G && rn_[row < G ? row : 0] > i0;
                 // channel 0 of this stretch comes back from HBM: normally requested a tile ago (see the end of this block)
@@ -1346,12 +1350,12 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
             // full vmcnt(0) between the two rounds: two store round trips per tile).
             if (ch == 1) {
 #pragma unroll
-                for (int R = 0; R < 2; R++)
+                for (int R = 0; R < NR; R++)
 #pragma unroll
                     for (int t = 0; t < 4; t++) asm volatile("" : "+v"(pa[R][t].x), "+v"(pa[R][t].y), "+v"(pa[R][t].z), "+v"(pa[R][t].w));
             }
 #pragma unroll
-            for (int R = 0; R < 2; R++) {
+            for (int R = 0; R < NR; R++) {
                 if (!live[R]) continue;
                 const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                 const uint4 *lt = (const uint4 *)&tile[row * FG_TSTR + cq];
@@ -1407,7 +1411,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 const uint32_t itn = it + 1, chn = itn / tpc, i0n = (itn % tpc) * FG_TS;
                 if (itn < T && chn == 1) {
 #pragma unroll
-                    for (int R = 0; R < 2; R++) {
+                    for (int R = 0; R < NR; R++) {
                         const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                         const bool want = (uint32_t)R < nrnd && row < G && f_c[R] == 2 && i0n + FG_TS <= f_n[R];
                         const uint4 *src = (const uint4 *)(want ? scratch + f_oo[R] * 2 + i0n + cq : scratch);
@@ -1565,22 +1569,39 @@ extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_l
     // one workgroup (four waves, one per SIMD) per CU while the frames allow: 28 frames per group for the 7032 frames of a
     // 600 s stream (0.51 ms; 0.56 ms with two groups of 14 per CU, which share the SIMDs)
     uint32_t G = fg_dec_group(nframes, 1, 1);
+    // Large batches: the workgroup's LDS (ring, tiles and residual tiles per frame) holds 48 frames, and a CU holds one
+    // workgroup, so the frames are spread evenly over the fewest passes of 48 per CU (90 112 frames: 8 passes of 44).
+    if (G > 32) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint32_t per_pass = (uint32_t)cus * FG_FUSED_GMAX;
+        const uint32_t passes = (nframes + per_pass - 1) / per_pass;
+        G = (nframes + (uint32_t)cus * passes - 1) / ((uint32_t)cus * passes);
+        if (G < 32) G = 32;
+    }
     if (getenv("FLACGPU_DEC_G1")) G = (uint32_t)atoi(getenv("FLACGPU_DEC_G1"));      // tuning aid
-    if (G > 32) G = 32;
+    if (G > FG_FUSED_GMAX) G = FG_FUSED_GMAX;
     const size_t lds = ((size_t)G * (FG_RSTR + 2 * FG_TSTR) + 2 * 64 * FG_META + 8 + (size_t)FG_RT * (G + 1) * FG_TSTR + FG_RT * 64 +
                         4 * (size_t)G * FG_SUBP + (size_t)G * FG_FRM + 192) * 4;
-    static size_t configured[2] = {0, 0};
-    const void *fn = wide ? (const void *)fg_dec_fused_kernel<true> : (const void *)fg_dec_fused_kernel<false>;
-    if (lds > configured[wide ? 1 : 0]) {
+    static size_t configured[4] = {0, 0, 0, 0};
+    const int which = (wide ? 1 : 0) + (G > 32 ? 2 : 0);
+    const void *fn = which == 0 ? (const void *)fg_dec_fused_kernel<false, 2> : which == 1 ? (const void *)fg_dec_fused_kernel<true, 2>
+                   : which == 2 ? (const void *)fg_dec_fused_kernel<false, 3> : (const void *)fg_dec_fused_kernel<true, 3>;
+    if (lds > configured[which]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        configured[wide ? 1 : 0] = lds;
+        configured[which] = lds;
     }
     if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 = no output wave, 2 = no recurrence
     const dim3 grid((nframes + G - 1) / G);
-    if (wide) hipLaunchKernelGGL(fg_dec_fused_kernel<true>, grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, 0u,
-                                 d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave, (u64 *)d_prof);
-    else hipLaunchKernelGGL(fg_dec_fused_kernel<false>, grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, 1u,
-                            d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave, (u64 *)d_prof);
+#define FG_FUSED_LAUNCH(W, N) hipLaunchKernelGGL((fg_dec_fused_kernel<W, N>), grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, \
+                                                 W ? 0u : 1u, d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave, (u64 *)d_prof)
+    switch (which) {
+    case 0: FG_FUSED_LAUNCH(false, 2); break;
+    case 1: FG_FUSED_LAUNCH(true, 2); break;
+    case 2: FG_FUSED_LAUNCH(false, 3); break;
+    default: FG_FUSED_LAUNCH(true, 3); break;
+    }
+#undef FG_FUSED_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -83,6 +83,31 @@ def test_frames_per_wave_shapes(ctx, monkeypatch, wps, seconds, ch):
     assert torch.equal(dec.reshape(-1, ch), t)
 
 
+@pytest.mark.parametrize('ch,bps,bs,g1', [(2, 16, 256, None), (2, 16, 1152, '48'), (2, 24, 576, '41'), (1, 16, 256, '47'), (2, 16, 4096, '33')])
+def test_more_than_32_frames_per_workgroup(ctx, monkeypatch, ch, bps, bs, g1):
+    """Launches of more than 32 frames per CU put up to 48 frames into a workgroup of the fused decoder (three rounds of 16
+    rows in its output wave instead of two): decode stays the identity -- stereo decorrelation, 24-bit, mono (the general
+    output form), a ragged last frame, and group sizes that leave the last round and the last workgroup part empty."""
+    import torch
+    from pyflac_amd import batch, synth
+    if g1:
+        monkeypatch.setenv('FLACGPU_DEC_G1', g1)
+    nfr = 256 * 36 + 5 if g1 is None else 700
+    n = nfr * bs - bs // 3
+    pcm = synth.config2_stereo16(n / 48000.0 + 0.01, 11)[:n, :ch].astype(np.int32)
+    if bps == 24:
+        pcm = pcm * 181 + (np.arange(n, dtype=np.int32)[:, None] % 7)
+    t = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    s = batch.settings(5, ch, bps, 48000, bs)
+    out, offs, st = ctx.encode(s, t)
+    assert st.nblocks == nfr
+    dec, status, _dst = ctx.decode(out[:st.total_bytes], offs, ch, bps, n)
+    assert int(status[:, 0].max()) == 0
+    assert torch.equal(dec.reshape(-1, ch), t)
+    dec2, status2, _ = ctx.decode_stream(out[:st.total_bytes], ch, bps, n, nframes=nfr)
+    assert int(status2[:, 0].max()) == 0 and torch.equal(dec2.reshape(-1, ch), t)
+
+
 def test_device_resident_frame_index(ctx):
     """flacgpu_decode_frames_dev: the frame index the encoder wrote is consumed from HBM; same result as the host index."""
     import torch
