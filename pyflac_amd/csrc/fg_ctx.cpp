@@ -430,7 +430,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (!c->descs.ensure((size_t)nblocks * sizeof(FgBlockDesc))) return false;
     if (!c->slots.ensure((size_t)nblocks * P.slot_bytes)) return false;
     if (!c->results.ensure((size_t)nblocks * sizeof(FgBlockResult))) return false;
-    if (!c->offsets.ensure(((size_t)nblocks + 4) * 8)) return false;
+    if (!c->offsets.ensure(fg_scan_words(nblocks) * 8)) return false;
     FgPipeLaunch PL;
     memset(&PL, 0, sizeof PL);
     if (use_pipe) {

@@ -41,10 +41,12 @@ int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned
 int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
                      const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
                      unsigned long long seq, hipStream_t stream);
+size_t fg_scan_words(uint32_t nblocks);
 int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, int all_pipe,
                    const unsigned long long *d_errs, hipStream_t stream);
 int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockResult *d_results, uint32_t nblocks,
                    const unsigned long long *d_offsets, uint8_t *d_dst, hipStream_t stream, uint64_t dst_cap);
+size_t fg_dec_scan_words(uint32_t nframes);
 int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len, const unsigned long long *d_offsets, uint32_t nframes,
                           uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
                           unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream);

@@ -680,6 +680,47 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
 // workgroup scan per tile)
 #define FG_DSCAN_TILE 8192
 #define FG_DSCAN_PER (FG_DSCAN_TILE / 1024)
+// one tile: block sizes into LDS, eight neighbours per thread, one workgroup scan; returns the tile's total
+__device__ __forceinline__ u64 fg_dec_scan_tile(FgDecFrame *frames, uint32_t nframes, uint32_t t0, u64 carry, u64 cap, uint32_t *sz, u64 *wtot,
+                                                uint32_t &m, bool write)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t nb[FG_DSCAN_PER];
+#pragma unroll
+    for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
+        const uint32_t b = t0 + j * 1024 + tid;
+        nb[j] = b < nframes ? frames[b].n : 0;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
+        m = nb[j] > m ? nb[j] : m;
+        sz[j * 1024 + tid] = nb[j];
+    }
+    __syncthreads();
+    uint32_t v[FG_DSCAN_PER];
+    u64 mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < FG_DSCAN_PER; j += 4) {
+        const uint4 t = *(const uint4 *)&sz[tid * FG_DSCAN_PER + j];
+        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+        mine += (u64)t.x + t.y + t.z + t.w;
+    }
+    u64 total;
+    u64 run = carry + fgdev::block_scan_excl_u64(mine, wtot, &total);
+    if (write) {
+#pragma unroll
+        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
+            const uint32_t b = t0 + tid * FG_DSCAN_PER + j;
+            if (b < nframes) {
+                if (run + v[j] > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
+                else frames[b].out_off = run;
+            }
+            run += v[j];
+        }
+    }
+    return total;
+}
+
 __global__ void __launch_bounds__(1024)
 fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap)
 {
@@ -692,42 +733,57 @@ fg_dec_scan_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap)
     u64 carry = 0;
     for (uint32_t t0 = 0; t0 < nframes; t0 += FG_DSCAN_TILE) {
         __syncthreads();
-        uint32_t nb[FG_DSCAN_PER];
-#pragma unroll
-        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
-            const uint32_t b = t0 + j * 1024 + tid;
-            nb[j] = b < nframes ? frames[b].n : 0;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
-            m = nb[j] > m ? nb[j] : m;
-            sz[j * 1024 + tid] = nb[j];
-        }
-        __syncthreads();
-        uint32_t v[FG_DSCAN_PER];
-        u64 mine = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < FG_DSCAN_PER; j += 4) {
-            const uint4 t = *(const uint4 *)&sz[tid * FG_DSCAN_PER + j];
-            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
-            mine += (u64)t.x + t.y + t.z + t.w;
-        }
-        u64 total;
-        u64 run = carry + fgdev::block_scan_excl_u64(mine, wtot, &total);
-#pragma unroll
-        for (uint32_t j = 0; j < FG_DSCAN_PER; j++) {
-            const uint32_t b = t0 + tid * FG_DSCAN_PER + j;
-            if (b < nframes) {
-                if (run + v[j] > cap) { frames[b].bytes = 0; frames[b].out_off = 0; }
-                else frames[b].out_off = run;
-            }
-            run += v[j];
-        }
-        carry += total;
+        carry += fg_dec_scan_tile(frames, nframes, t0, carry, cap, sz, wtot, m, true);
     }
     atomicMax(&maxn, m);
     __syncthreads();
     if (tid == 0) { totals[0] = carry; totals[1] = maxn; }
+}
+
+// More than one tile (batches of many streams): one workgroup per tile.  First every tile's total and largest block
+// (tsum[t], tsum[ntiles + t]), then every workgroup adds up the totals in front of its tile and scans it; workgroup 0 also
+// writes the grand total and the maximum.
+__global__ void __launch_bounds__(1024)
+fg_dec_scan_sums_kernel(FgDecFrame *frames, uint32_t nframes, u64 *tsum, uint32_t ntiles)
+{
+    __shared__ u64 wtot[16];
+    __shared__ uint32_t maxn;
+    __shared__ __attribute__((aligned(16))) uint32_t sz[FG_DSCAN_TILE];
+    if (threadIdx.x == 0) maxn = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    const u64 total = fg_dec_scan_tile(frames, nframes, blockIdx.x * FG_DSCAN_TILE, 0, 0, sz, wtot, m, false);
+    atomicMax(&maxn, m);
+    __syncthreads();
+    if (threadIdx.x == 0) { tsum[blockIdx.x] = total; tsum[ntiles + blockIdx.x] = maxn; }
+}
+
+__global__ void __launch_bounds__(1024)
+fg_dec_scan_tiles_kernel(FgDecFrame *frames, uint32_t nframes, u64 *totals, u64 cap, const u64 *tsum, uint32_t ntiles)
+{
+    __shared__ u64 wtot[16];
+    __shared__ uint32_t maxn;
+    __shared__ __attribute__((aligned(16))) uint32_t sz[FG_DSCAN_TILE];
+    const uint32_t tid = threadIdx.x, t = blockIdx.x;
+    if (tid == 0) maxn = 0;
+    u64 before = 0, all = 0;
+    uint32_t mx = 0;
+    for (uint32_t u = tid; u < ntiles; u += 1024) {
+        const u64 x = tsum[u];
+        all += x;
+        if (u < t) before += x;
+        const uint32_t y = (uint32_t)tsum[ntiles + u];
+        mx = y > mx ? y : mx;
+    }
+    u64 base, grand;
+    (void)fgdev::block_scan_excl_u64(before, wtot, &base);
+    __syncthreads();
+    (void)fgdev::block_scan_excl_u64(all, wtot, &grand);
+    if (t == 0) atomicMax(&maxn, mx);
+    __syncthreads();
+    if (t == 0 && tid == 0) { totals[0] = grand; totals[1] = maxn; }
+    uint32_t m = 0;
+    (void)fg_dec_scan_tile(frames, nframes, t * FG_DSCAN_TILE, base, cap, sz, wtot, m, true);
 }
 
 // First index at which two int32 arrays differ (0xFFFFFFFFFFFFFFFF if none): the encoder's verify pass compares what the
@@ -753,6 +809,9 @@ extern "C" int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_
     return (int)hipGetLastError();
 }
 
+// 64-bit words the totals array of fg_launch_dec_headers needs for `nframes` frames (totals + the scan's tile totals)
+extern "C" size_t fg_dec_scan_words(uint32_t nframes) { return 4 + 2 * (size_t)((nframes + FG_DSCAN_TILE - 1) / FG_DSCAN_TILE) + 2; }
+
 extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len, const unsigned long long *d_offsets, uint32_t nframes,
                                      uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
                                      unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream)
@@ -760,7 +819,15 @@ extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long
     if (nframes == 0) return 0;
     hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, (u64)stream_len, d_offsets, nframes,
                        si_channels, si_bps, d_frames, d_results);
-    hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
+    const uint32_t ntiles = (nframes + FG_DSCAN_TILE - 1) / FG_DSCAN_TILE;
+    if (ntiles == 1) hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
+    else {
+        // (the tile totals lie behind the three totals: the caller sizes the array with fg_dec_scan_words())
+        u64 *tsum = (u64 *)d_totals + 4;
+        hipLaunchKernelGGL(fg_dec_scan_sums_kernel, dim3(ntiles), dim3(1024), 0, stream, d_frames, nframes, tsum, ntiles);
+        hipLaunchKernelGGL(fg_dec_scan_tiles_kernel, dim3(ntiles), dim3(1024), 0, stream, d_frames, nframes, (u64 *)d_totals, (u64)cap_samples,
+                           (const u64 *)tsum, ntiles);
+    }
     return (int)hipGetLastError();
 }
 

@@ -1238,6 +1238,59 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
 // 32-byte result records, whose 21 k strided lines through one CU's L1 were most of this kernel's time.  (A block that
 // waits for the generic kernel gets a wrong size here: the host sees FG_ERR_REDO in the flags and repeats the scan in the
 // general form after the redo.)
+// one tile; returns its total.  `write`: offsets and (general form) the sizes of the pipeline's blocks are stored
+__device__ __forceinline__ u64 fg_scan_tile(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets, uint32_t all_pipe,
+                                            uint32_t t0, u64 carry, uint32_t *sz, u64 *wtot, uint32_t &e, bool write)
+{
+    const uint32_t tid = threadIdx.x;
+    uint4 r[FG_SCAN_PER], cb[FG_SCAN_PER];
+    uint32_t kind[FG_SCAN_PER];
+#pragma unroll
+    for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
+        const uint32_t b = t0 + j * 1024 + tid;
+        r[j] = make_uint4(0, 0, 0, 0); cb[j] = r[j]; kind[j] = 0;
+        if (b < nblocks) {
+            if (all_pipe) kind[j] = 4;
+            else {
+                r[j] = *(const uint4 *)&results[b];                    // bytes, ca, err, best_bits[0]
+                kind[j] = results[b].reserved;
+            }
+            if (chunk_bits) cb[j] = *(const uint4 *)&chunk_bits[(size_t)b * 4];
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
+        const uint32_t b = t0 + j * 1024 + tid;
+        uint32_t bytes = r[j].x;
+        e |= r[j].z;
+        if (chunk_bits && kind[j] == 4) {
+            bytes = (b >= nblocks || (r[j].z & FG_ERR_REDO)) ? 0u : ((cb[j].x + cb[j].y + cb[j].z + cb[j].w + 7) >> 3) + 2;
+            if (write && !all_pipe && b < nblocks) results[b].bytes = bytes;       // (all_pipe: the assembly kernel writes it back)
+        }
+        sz[j * 1024 + tid] = bytes;
+    }
+    __syncthreads();
+    uint32_t v[FG_SCAN_PER];
+    u64 mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < FG_SCAN_PER; j += 4) {
+        const uint4 t = *(const uint4 *)&sz[tid * FG_SCAN_PER + j];
+        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+        mine += (u64)t.x + t.y + t.z + t.w;
+    }
+    u64 total;
+    u64 run = carry + fgdev::block_scan_excl_u64(mine, wtot, &total);
+    if (write) {
+#pragma unroll
+        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
+            const uint32_t b = t0 + tid * FG_SCAN_PER + j;
+            if (b < nblocks) offsets[b] = run;
+            run += v[j];
+        }
+    }
+    return total;
+}
+
 __global__ void __launch_bounds__(1024)
 fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets, uint32_t all_pipe,
                      const unsigned long long *errs_in)
@@ -1251,54 +1304,57 @@ fg_scan_sizes_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_
     u64 carry = 0;
     for (uint32_t t0 = 0; t0 < nblocks; t0 += FG_SCAN_TILE) {
         __syncthreads();                    // (previous tile's readers are done with sz[]; errs initialised)
-        uint4 r[FG_SCAN_PER], cb[FG_SCAN_PER];
-        uint32_t kind[FG_SCAN_PER];
-#pragma unroll
-        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
-            const uint32_t b = t0 + j * 1024 + tid;
-            r[j] = make_uint4(0, 0, 0, 0); cb[j] = r[j]; kind[j] = 0;
-            if (b < nblocks) {
-                if (all_pipe) kind[j] = 4;
-                else {
-                    r[j] = *(const uint4 *)&results[b];                    // bytes, ca, err, best_bits[0]
-                    kind[j] = results[b].reserved;
-                }
-                if (chunk_bits) cb[j] = *(const uint4 *)&chunk_bits[(size_t)b * 4];
-            }
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
-            const uint32_t b = t0 + j * 1024 + tid;
-            uint32_t bytes = r[j].x;
-            e |= r[j].z;
-            if (chunk_bits && kind[j] == 4) {
-                bytes = (b >= nblocks || (r[j].z & FG_ERR_REDO)) ? 0u : ((cb[j].x + cb[j].y + cb[j].z + cb[j].w + 7) >> 3) + 2;
-                if (!all_pipe && b < nblocks) results[b].bytes = bytes;       // (all_pipe: the assembly kernel writes it back)
-            }
-            sz[j * 1024 + tid] = bytes;
-        }
-        __syncthreads();
-        uint32_t v[FG_SCAN_PER];
-        u64 mine = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < FG_SCAN_PER; j += 4) {
-            const uint4 t = *(const uint4 *)&sz[tid * FG_SCAN_PER + j];
-            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
-            mine += (u64)t.x + t.y + t.z + t.w;
-        }
-        u64 total;
-        u64 run = carry + fgdev::block_scan_excl_u64(mine, wtot, &total);
-#pragma unroll
-        for (uint32_t j = 0; j < FG_SCAN_PER; j++) {
-            const uint32_t b = t0 + tid * FG_SCAN_PER + j;
-            if (b < nblocks) offsets[b] = run;
-            run += v[j];
-        }
-        carry += total;
+        carry += fg_scan_tile(results, chunk_bits, nblocks, offsets, all_pipe, t0, carry, sz, wtot, e, true);
     }
     if (e) atomicOr(&errs, e);
     __syncthreads();
     if (tid == 0) { offsets[nblocks] = carry; offsets[nblocks + 1] = (all_pipe && errs_in) ? (u64)errs_in[0] : (u64)errs; }
+}
+
+// More than one tile (batches of many streams: 90 112 blocks took one workgroup 0.22 ms): one workgroup per tile.  First
+// every tile's total and error flags (tsum[t], tsum[ntiles + t]; nothing else is stored), then every workgroup adds up the
+// totals in front of its tile and scans it; workgroup 0 also writes the grand total and the flags.
+__global__ void __launch_bounds__(1024)
+fg_scan_sums_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, uint32_t all_pipe, u64 *tsum, uint32_t ntiles)
+{
+    __shared__ u64 wtot[16];
+    __shared__ uint32_t errs;
+    __shared__ __attribute__((aligned(16))) uint32_t sz[FG_SCAN_TILE];
+    if (threadIdx.x == 0) errs = 0;
+    __syncthreads();
+    uint32_t e = 0;
+    const u64 total = fg_scan_tile(results, chunk_bits, nblocks, nullptr, all_pipe, blockIdx.x * FG_SCAN_TILE, 0, sz, wtot, e, false);
+    if (e) atomicOr(&errs, e);
+    __syncthreads();
+    if (threadIdx.x == 0) { tsum[blockIdx.x] = total; tsum[ntiles + blockIdx.x] = errs; }
+}
+
+__global__ void __launch_bounds__(1024)
+fg_scan_tiles_kernel(FgBlockResult *results, const uint32_t *chunk_bits, uint32_t nblocks, u64 *offsets, uint32_t all_pipe,
+                     const unsigned long long *errs_in, const u64 *tsum, uint32_t ntiles)
+{
+    __shared__ u64 wtot[16];
+    __shared__ uint32_t errs;
+    __shared__ __attribute__((aligned(16))) uint32_t sz[FG_SCAN_TILE];
+    const uint32_t tid = threadIdx.x, t = blockIdx.x;
+    if (tid == 0) errs = 0;
+    u64 before = 0, all = 0;
+    uint32_t eo = 0;
+    for (uint32_t u = tid; u < ntiles; u += 1024) {
+        const u64 x = tsum[u];
+        all += x;
+        if (u < t) before += x;
+        eo |= (uint32_t)tsum[ntiles + u];
+    }
+    u64 base, grand;
+    (void)fgdev::block_scan_excl_u64(before, wtot, &base);
+    __syncthreads();
+    (void)fgdev::block_scan_excl_u64(all, wtot, &grand);
+    if (t == 0 && eo) atomicOr(&errs, eo);
+    __syncthreads();
+    if (t == 0 && tid == 0) { offsets[nblocks] = grand; offsets[nblocks + 1] = (all_pipe && errs_in) ? (u64)errs_in[0] : (u64)errs; }
+    uint32_t e = 0;
+    (void)fg_scan_tile(results, chunk_bits, nblocks, offsets, all_pipe, t * FG_SCAN_TILE, base, sz, wtot, e, true);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1462,12 +1518,23 @@ int fg_launch_widen16(const int16_t *d_src, int32_t *d_dst, unsigned long long n
     return (int)hipGetLastError();
 }
 
+// 64-bit words the offsets array of fg_launch_scan needs for `nblocks` blocks
+size_t fg_scan_words(uint32_t nblocks) { return (size_t)nblocks + 4 + 2 * (size_t)((nblocks + FG_SCAN_TILE - 1) / FG_SCAN_TILE) + 2; }
+
 int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, int all_pipe,
                    const unsigned long long *d_errs, hipStream_t stream)
 {
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, d_offsets,
-                       (uint32_t)((all_pipe && d_chunk_bits && d_errs) ? 1 : 0), d_errs);
+    const uint32_t ap = (uint32_t)((all_pipe && d_chunk_bits && d_errs) ? 1 : 0);
+    const uint32_t ntiles = (nblocks + FG_SCAN_TILE - 1) / FG_SCAN_TILE;
+    if (ntiles == 1) hipLaunchKernelGGL(fg_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, d_offsets, ap, d_errs);
+    else {
+        // (the tile totals lie behind offsets[nblocks .. nblocks + 3]: the caller sizes the array with fg_scan_words())
+        u64 *tsum = (u64 *)d_offsets + nblocks + 4;
+        hipLaunchKernelGGL(fg_scan_sums_kernel, dim3(ntiles), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, ap, tsum, ntiles);
+        hipLaunchKernelGGL(fg_scan_tiles_kernel, dim3(ntiles), dim3(1024), 0, stream, d_results, d_chunk_bits, nblocks, (u64 *)d_offsets, ap, d_errs,
+                           (const u64 *)tsum, ntiles);
+    }
     return (int)hipGetLastError();
 }
 

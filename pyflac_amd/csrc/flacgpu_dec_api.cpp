@@ -399,7 +399,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (channels_hint == 0) { fg_set_error("channel count required"); return false; }
     const uint32_t npad = (nframes + 63) & ~63u;
     if (!c->dec_frames.ensure((size_t)npad * sizeof(FgDecFrame)) || !c->dec_results.ensure((size_t)npad * sizeof(FgDecResult)) ||
-        !c->offsets.ensure(((size_t)nframes + 4) * 8))
+        !c->offsets.ensure(((size_t)nframes + 1 + fg_dec_scan_words(nframes)) * 8))
         return false;
     unsigned long long *d_off = (unsigned long long *)c->offsets.p;
     unsigned long long *d_tot = d_off + nframes + 1;

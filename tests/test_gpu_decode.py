@@ -108,6 +108,36 @@ def test_more_than_32_frames_per_workgroup(ctx, monkeypatch, ch, bps, bs, g1):
     assert int(status2[:, 0].max()) == 0 and torch.equal(dec2.reshape(-1, ch), t)
 
 
+def test_scans_over_more_than_one_tile(ctx):
+    """Launches of more than 8192 frames scan their sizes with one workgroup per tile of 8192 (encoder: byte offsets of the
+    frames; decoder: sample offsets): a batch of three ragged streams, 9502 blocks, gives the bytes of the three streams
+    encoded one by one (single-tile scans), decodes to the input, and a PCM buffer that is too short is still reported."""
+    import torch
+    from pyflac_amd import batch, synth
+    from pyflac_amd.batch import FlacGpuError
+    bs = 256
+    lengths = [bs * 4000 + 100, bs * 3000 + 7, bs * 2500]
+    total = sum(lengths)
+    pcm = synth.config2_stereo16(total / 48000.0 + 0.01, 17)[:total].astype(np.int32)
+    t = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    s = batch.settings(5, 2, 16, 48000, bs)
+    out, offs, st = ctx.encode(s, t, stream_lengths=lengths)
+    assert st.nblocks == 4001 + 3001 + 2500
+    whole = out[:st.total_bytes].cpu().numpy().tobytes()
+    h_offs = offs.cpu().numpy()
+    assert int(h_offs[-1]) == st.total_bytes and (np.diff(h_offs.astype(np.int64)) > 0).all()
+    parts, pos = [], 0
+    for n in lengths:
+        o1, _f1, s1 = ctx.encode(s, t[pos:pos + n].contiguous())
+        parts.append(o1[:s1.total_bytes].cpu().numpy().tobytes())
+        pos += n
+    assert whole == b''.join(parts)
+    dec, status, _ = ctx.decode(out[:st.total_bytes], offs, 2, 16, total)
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec.reshape(-1, 2), t)
+    with pytest.raises(FlacGpuError):
+        ctx.decode(out[:st.total_bytes], offs, 2, 16, total - 1000)
+
+
 def test_device_resident_frame_index(ctx):
     """flacgpu_decode_frames_dev: the frame index the encoder wrote is consumed from HBM; same result as the host index."""
     import torch
