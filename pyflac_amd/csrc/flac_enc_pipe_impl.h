@@ -39,6 +39,7 @@
 #define LDS __attribute__((address_space(3)))
 #define FGI __device__ __forceinline__
 
+#define FGP_F64 1                        // evaluation: residuals of 17..25-bit samples through fp64 FMAs (pfir_f64; 0 = pfir48)
 #define FGP_DH 16                        // autocorrelation: history doubles kept in front of each chunk (>= max lag + 1)
 #define FGP_CK 128                       // autocorrelation: chunk length
 // doubles per candidate row: 288 words, i.e. 32 banks (of 64) from row to row -- the two candidate rows that share a
@@ -135,6 +136,21 @@ template <int MAXO> FGI i64 pfir48(const int32_t (&q)[MAXO], const int32_t (&h)[
 #undef FG_M4
 #undef FG_H
     return (i64)(((u64)(i64)sh) << 12) + (i64)sl;
+}
+
+// The same sum in fp64: samples below 2^25 and coefficients below 2^15 give products below 2^40 and sums of twelve below
+// 2^44 -- every fused multiply-add is exact, one instruction per tap (v_fma_f64 runs at the rate of the 32-bit integer
+// operations on this chip; the two 16-bit chains above take two).  Two chains of half the taps each, for the latency.
+template <int MAXO> FGI double pfir_f64(const double (&q)[MAXO], const double (&h)[MAXO], int u)
+{
+    double a = 0.0, b = 0.0;
+#define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
+#pragma unroll
+    for (int j = MAXO - 1; j >= MAXO / 2; j--) a = __builtin_fma(q[j], FG_H(j), a);
+#pragma unroll
+    for (int j = MAXO / 2 - 1; j >= 0; j--) b = __builtin_fma(q[j], FG_H(j), b);
+#undef FG_H
+    return a + b;
 }
 
 FGI double p_ebps(double e, double scale)
@@ -1008,8 +1024,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             }
             P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
         }
-#pragma unroll 4
-        for (int s = 4; s < (int)seg; s++) {
+        auto fstep = [&](int s) __attribute__((always_inline)) {
             const uint32_t vb = (uint32_t)samp(s) + FB;
             const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
             if (!ACC64) {
@@ -1022,7 +1037,15 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                 facc[3] += psad(e2b, P2, 0); facc[4] += psad(e3b, P3, 0);
             }
             P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
+        };
+        int s4 = 4;
+#pragma unroll 1
+        for (; s4 + 4 <= (int)seg; s4 += 4) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) fstep(s4 + t);
         }
+#pragma unroll 1
+        for (; s4 < (int)seg; s4++) fstep(s4);
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) tot[kk] = ACC64 ? wave_sum64((u64)facc[kk]) : (u64)wave_sum((uint32_t)facc[kk]);
         // fixed order guess (fixed.c: the smallest total error wins, lower order on ties)
@@ -1125,17 +1148,33 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rl((uint32_t)qall, j);
             // ---- FIR over the segment: history in registers, statically indexed (the loop is unrolled by its length)
             int32_t h[MAXO];
+            double hd[MAXO], qd[MAXO];          // (17..25-bit samples: history and coefficients as doubles, pfir_f64)
+            const double scl = __hiloint2double((int)((1023u - (uint32_t)shift) << 20), 0);      // 2^-shift
+            if constexpr (FGP_F64 && ACC64) {
+                const double qdl = (double)qall;
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) qd[j] = __hiloint2double((int)rl((uint32_t)__double2hiint(qdl), j), (int)rl((uint32_t)__double2loint(qdl), j));
+            }
             psum = 0;
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
                 if (lane > 0) x = samp((int)seg - 1 - j - (int)rstr);
                 h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
+                if constexpr (FGP_F64 && ACC64) hd[(MAXO - 1 - j) % MAXO] = (double)x;
             }
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
                 const int32_t x = samp((int)s);
                 int32_t res;
-                if (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
+                if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
+                else if constexpr (FGP_F64) {
+                    // x - (sum >> shift): the scaling by 2^-shift is exact, floor() is the arithmetic shift
+                    const double xd = (double)x;
+                    const double rr = xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl);
+                    if (rr <= -2147483648.0 || rr > 2147483647.0) ovf = 1;
+                    res = (int32_t)rr;
+                    hd[u] = xd;
+                }
                 else {
                     const i64 rr = (i64)x - (pfir48<MAXO>(q, h, u) >> shift);
                     if (rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) ovf = 1;
@@ -1231,8 +1270,10 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     }
 }
 
+// (samples above 16 bits are staged as int32: 33 KB of LDS per stereo block let four workgroups share a CU, so those forms
+// may use 128 registers -- the 64 that eight workgroups per CU allow cost them 25 spilled vector registers)
 template <bool MS, int NCH, int MAXO, bool ACC64>
-__global__ void __launch_bounds__((MS ? 4 : NCH) * 64, 8)
+__global__ void __launch_bounds__((MS ? 4 : NCH) * 64, ACC64 ? 4 : 8)
 fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, FgBlockResult *results, FgDebugRec *dbg)
 {
     constexpr int NC = MS ? 4 : NCH;
@@ -1531,7 +1572,9 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 if (verb) { val = (uint32_t)x & mask; vb = sb; lead = 0; }
                 else {
                     int32_t res;
-                    if (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
+                    // (17..25-bit samples: the two 16-bit chains here -- pfir_f64 needs twice the registers for the history,
+                    // which this kernel spills: packing 0.46 ms against 0.32 ms on 24-bit stereo at level 8)
+                    if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
                     else res = (int32_t)((i64)x - (pfir48<MAXO>(q, h, u) >> shift));
                     h[u] = ACC64 ? ppack(x) : x;
                     const uint32_t uu = ((uint32_t)res << 1) ^ (uint32_t)(res >> 31);
