@@ -1344,7 +1344,7 @@ FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
 }
 
 template <bool MS, int NCH, int MAXO, bool ACC64, int WS>
-__global__ void __launch_bounds__(NCH * WS * 64, 5)
+__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 4 : 5)
 fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
                     uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
 {
