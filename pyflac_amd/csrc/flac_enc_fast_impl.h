@@ -742,7 +742,6 @@ fg_encode_fast_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     // pass per autocorrelation vector.  Each pass: every lane runs the FIR of every candidate over its segment (history in
     // registers, coefficients in SGPRs); its |residual| total is a partition sum.  Then the Rice parameter / partition
     // order search (lane = partition) and the strict-< update of the best (libFLAC's candidate order).
-    const uint32_t parts0 = 1u << pmax0;
     u64 te_fir = 0, te_search = 0, te_setup = 0, te_l = mydbg ? clock64() : 0;
 #define FG_TE(acc) do { if (mydbg) { const u64 n_ = clock64(); acc += n_ - te_l; te_l = n_; } } while (0)
 #pragma unroll 1
