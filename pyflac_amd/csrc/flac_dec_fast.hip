@@ -1288,6 +1288,12 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
     u64 f_oo[NR] = {};
     uint4 pa[NR][4];                               // channel 0 of the tile that is next for the fast form (prefetched), per round
     uint32_t pa_it[NR];               // ... and which tile that is
+    // The parked channel is kept as 16-bit values while they fit (tile by tile, from the start of the frame: bytes
+    // [128 k, 128 k + 128) of the frame's plane for tile k); from the first tile that holds a larger value -- the side
+    // channel of a right-side frame, a predictor gone wild in a damaged or hand-made stream -- or that takes the general
+    // form, the frame goes on in 32 bits at the usual place (bytes [256 k, ..): behind everything parked before).
+    // f_wf = first 32-bit tile of the row's frame.
+    uint32_t f_wf[NR];
 #pragma unroll
     for (int R = 0; R < NR; R++) {
         pa_it[R] = ~0u;
@@ -1315,8 +1321,10 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 f_n[R] = have ? fm[0] : 0; f_c[R] = have ? fm[1] : 0; f_ca[R] = fm[2];
                 f_oo[R] = ((u64)fm[4] << 32) | fm[3];
                 f_w[R] = have ? L.subp[((ch & 3) * G + row) * FG_SUBP + 2] : 0;
+                if (ch == 0) f_wf[R] = WIDE ? 0u : ~0u;
             }
         }
+        const uint32_t tk = it % tpc;
         // is this tile one for the fast form?
         bool ok_fast = out_al && (ch < 2);
         {
@@ -1340,9 +1348,10 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 live[R] = (uint32_t)R < nrnd && row < G && rn_[row < G ? row : 0] > i0;
                 // channel 0 of this stretch comes back from HBM: normally requested a tile ago (see the end of this block)
                 if (live[R] && ch == 1 && pa_it[R] != it) {
-                    const uint4 *src = (const uint4 *)(scratch + f_oo[R] * 2 + i0 + cq);
-#pragma unroll
-                    for (int t = 0; t < 4; t++) pa[R][t] = src[t];
+                    const bool p16 = tk < f_wf[R];
+                    const uint4 *src = (const uint4 *)((const char *)(scratch + f_oo[R] * 2) + (size_t)(i0 + cq) * (p16 ? 2 : 4));
+                    pa[R][0] = src[0]; pa[R][1] = src[1];
+                    if (!p16) { pa[R][2] = src[2]; pa[R][3] = src[3]; }
                 }
             }
             // Every prefetched value is touched before the first store of the tile goes out: memory operations retire in
@@ -1361,17 +1370,47 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                 const uint4 *lt = (const uint4 *)&tile[row * FG_TSTR + cq];
                 const uint32_t wsh = f_w[R];
                 if (ch == 0) {
-                    uint4 *dstp = (uint4 *)(scratch + f_oo[R] * 2 + i0 + cq);
+                    uint4 v[4];
+                    uint32_t big = 0;
 #pragma unroll
-                    for (int t = 0; t < 4; t++) { const uint4 v = lt[t]; dstp[t] = make_uint4(v.x << wsh, v.y << wsh, v.z << wsh, v.w << wsh); }
+                    for (int t = 0; t < 4; t++) {
+                        const uint4 x = lt[t];
+                        v[t] = make_uint4(x.x << wsh, x.y << wsh, x.z << wsh, x.w << wsh);
+                        big |= (v[t].x + 32768u) | (v[t].y + 32768u) | (v[t].z + 32768u) | (v[t].w + 32768u);
+                    }
+                    if (tk < f_wf[R]) {
+                        // does the row's tile (this lane's quarter and its three neighbours') fit 16 bits?
+                        big >>= 16;
+                        big |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)big, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+                        big |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)big, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+                        if (big) f_wf[R] = tk;
+                    }
+                    char *plane = (char *)(scratch + f_oo[R] * 2);
+                    if (tk < f_wf[R]) {
+                        uint4 *dstp = (uint4 *)(plane + (size_t)(i0 + cq) * 2);
+                        dstp[0] = make_uint4(__builtin_amdgcn_perm(v[0].y, v[0].x, 0x05040100u), __builtin_amdgcn_perm(v[0].w, v[0].z, 0x05040100u),
+                                             __builtin_amdgcn_perm(v[1].y, v[1].x, 0x05040100u), __builtin_amdgcn_perm(v[1].w, v[1].z, 0x05040100u));
+                        dstp[1] = make_uint4(__builtin_amdgcn_perm(v[2].y, v[2].x, 0x05040100u), __builtin_amdgcn_perm(v[2].w, v[2].z, 0x05040100u),
+                                             __builtin_amdgcn_perm(v[3].y, v[3].x, 0x05040100u), __builtin_amdgcn_perm(v[3].w, v[3].z, 0x05040100u));
+                    }
+                    else {
+                        uint4 *dstp = (uint4 *)(plane + (size_t)(i0 + cq) * 4);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) dstp[t] = v[t];
+                    }
                 }
                 else {
                     const uint32_t cc = f_ca[R];
                     int32_t *o = out + f_oo[R] * 2;
+                    const bool p16 = tk < f_wf[R];
+                    const uint32_t pw[8] = {pa[R][0].x, pa[R][0].y, pa[R][0].z, pa[R][0].w, pa[R][1].x, pa[R][1].y, pa[R][1].z, pa[R][1].w};
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const uint4 vb = lt[t], va = pa[R][t];
-                        const uint32_t xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+                        // (16-bit parking: value k of the lane's sixteen is half k & 1 of word k >> 1)
+                        const uint32_t xa[4] = {p16 ? (uint32_t)((int32_t)(pw[2 * t] << 16) >> 16) : va.x, p16 ? (uint32_t)((int32_t)pw[2 * t] >> 16) : va.y,
+                                                p16 ? (uint32_t)((int32_t)(pw[2 * t + 1] << 16) >> 16) : va.z, p16 ? (uint32_t)((int32_t)pw[2 * t + 1] >> 16) : va.w};
+                        const uint32_t xb[4] = {vb.x, vb.y, vb.z, vb.w};
                         int32_t lo[4], ro[4];
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
@@ -1414,16 +1453,21 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
                     for (int R = 0; R < NR; R++) {
                         const uint32_t row = R * 16 + ((uint32_t)lane >> 2);
                         const bool want = (uint32_t)R < nrnd && row < G && f_c[R] == 2 && i0n + FG_TS <= f_n[R];
-                        const uint4 *src = (const uint4 *)(want ? scratch + f_oo[R] * 2 + i0n + cq : scratch);
-#pragma unroll
-                        for (int t = 0; t < 4; t++) pa[R][t] = src[t];
+                        const bool p16 = (itn % tpc) < f_wf[R];
+                        const uint4 *src = (const uint4 *)(want ? (const char *)(scratch + f_oo[R] * 2) + (size_t)(i0n + cq) * (p16 ? 2 : 4) : (const char *)scratch);
+                        const uint4 *src2 = (want && !p16) ? src : (const uint4 *)scratch;       // (16-bit parking: the second half is not needed)
+                        pa[R][0] = src[0]; pa[R][1] = src[1]; pa[R][2] = src2[2]; pa[R][3] = src2[3];
                         pa_it[R] = want ? itn : ~0u;
                     }
                 }
             }
             continue;
         }
-        // ---- general form
+        // ---- general form (32-bit parking, and for the rest of the frame)
+        if (ch == 0) {
+#pragma unroll
+            for (int R = 0; R < NR; R++) f_wf[R] = f_wf[R] < tk ? f_wf[R] : tk;
+        }
         const uint32_t i = i0 + (uint32_t)lane;
         for (uint32_t r = 0; r < G; r++) {
             const uint32_t *fm = L.frm + r * FG_FRM;
@@ -1437,7 +1481,11 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
             if (C == 2) {
                 if (ch == 0) scratch[oo * 2 + i] = (int32_t)(x << wasted);           // parked until the second channel arrives
                 else {
-                    const int32_t av = scratch[oo * 2 + i], bv = (int32_t)(x << wasted);
+                    // (the tile's format is the row's, kept by the lanes of the fast form: 16 bits below f_wf)
+                    uint32_t wf = 0;
+#pragma unroll
+                    for (int R = 0; R < NR; R++) if ((r >> 4) == (uint32_t)R) wf = (uint32_t)__builtin_amdgcn_readlane((int)f_wf[R], (int)((r & 15) * 4));
+                    const int32_t av = tk < wf ? (int32_t)((const int16_t *)(scratch + oo * 2))[i] : scratch[oo * 2 + i], bv = (int32_t)(x << wasted);
                     // (32-bit streams: a side channel with wasted bits is a 33-bit value once shifted back)
                     const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)x << wasted) : (i64)bv;
                     const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);

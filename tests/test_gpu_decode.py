@@ -138,6 +138,42 @@ def test_scans_over_more_than_one_tile(ctx):
         ctx.decode(out[:st.total_bytes], offs, 2, 16, total - 1000)
 
 
+def test_parked_channel_switches_to_32_bits_inside_a_frame(ctx):
+    """The fused decoder parks the first coded channel of a stereo frame in HBM as 16-bit values tile by tile (64 samples)
+    for as long as they fit, and goes on in 32 bits from the first tile that holds a larger value.  Hand-made frames (16-bit
+    stereo, block size 4096, fixed / verbatim subframes): a right-side frame whose side channel L - R is small for the first
+    1000 samples and needs 17 bits from there on, a mid-side frame at full scale, a right-side frame that needs 17 bits from
+    its first sample, a left-side frame; and the same with a short last frame (general output form)."""
+    import torch
+    from oracle import gen_golden_handmade as H
+    r = np.random.default_rng(77)
+    n = 4096
+    t = np.arange(n)
+    loud = (30000 * np.sign(np.sin(t * 0.05))).astype(np.int64) + r.integers(-200, 200, n)
+    quiet = r.integers(-900, 900, n)
+    frames, pcms = [], []
+    def add(x, ca, m=n):
+        specs = [{'type': 'fixed', 'order': 2, 'po': 3, 'method': 0, 'part_mode': H.mode_mix(0.0), 'wasted': 0},
+                 {'type': 'verbatim', 'wasted': 0}]
+        frames.append(H.frame(r, x[:m], 16, 48000, len(frames), False, ca, specs))
+        pcms.append(x[:m])
+    a = np.stack([np.where(t < 1000, quiet, loud), np.where(t < 1000, quiet // 2, -loud)], axis=1)
+    add(a, 2)
+    add(np.stack([loud, -loud + 3], axis=1), 3)
+    add(np.stack([loud, -loud], axis=1), 2)
+    add(np.stack([loud, -loud], axis=1), 1)
+    add(a, 2, 4096 - 1000)
+    total = sum(len(p) for p in pcms)
+    data = H.streaminfo(n, n, 48000, 2, 16, total) + b''.join(frames)
+    want = np.concatenate(pcms).astype(np.int32)
+    got, status, si = _decode(ctx, data)
+    assert int(status[:, 0].max()) == 0
+    assert np.array_equal(got.reshape(-1, 2), want)
+    buf = torch.frombuffer(bytearray(data[42:]) + bytearray(64), dtype=torch.uint8).cuda()
+    dec2, status2, _ = ctx.decode_stream(buf[:len(data) - 42], 2, 16, total, nframes=len(frames))
+    assert int(status2[:, 0].max()) == 0 and np.array_equal(dec2.cpu().numpy().reshape(-1, 2), want)
+
+
 def test_device_resident_frame_index(ctx):
     """flacgpu_decode_frames_dev: the frame index the encoder wrote is consumed from HBM; same result as the host index."""
     import torch
