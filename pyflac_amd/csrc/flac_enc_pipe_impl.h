@@ -39,6 +39,7 @@
 #define LDS __attribute__((address_space(3)))
 #define FGI __device__ __forceinline__
 
+#define FGP_F64P 1                       // packing: the same (with the 168 registers that three workgroups per CU leave: 24-bit level 8 0.28 -> 0.25 ms)
 #define FGP_F64 1                        // evaluation: residuals of 17..25-bit samples through fp64 FMAs (pfir_f64; 0 = pfir48)
 #define FGP_DH 16                        // autocorrelation: history doubles kept in front of each chunk (>= max lag + 1)
 #define FGP_CK 128                       // autocorrelation: chunk length
@@ -1344,7 +1345,7 @@ FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
 }
 
 template <bool MS, int NCH, int MAXO, bool ACC64, int WS>
-__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 4 : 5)
+__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : 5)
 fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
                     uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
 {
@@ -1522,6 +1523,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             for (int j = 0; j < MAXO; j++) q[j] = j == 0 ? c0 : j == 1 ? c1 : j == 2 ? c2 : j == 3 ? c3 : 0;
             shift = 0;
         }
+        double qd[MAXO];
+        const double scl = __hiloint2double((int)((1023u - (uint32_t)shift) << 20), 0);      // 2^-shift
+        if constexpr (FGP_F64P && ACC64) {
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) qd[j] = (double)q[j];
+        }
         const uint32_t plen = method ? 5 : 4;
         const uint32_t lpp = LPS >> po;                                  // lanes per partition
         const uint32_t kr = type >= 2 ? (uint32_t)dec->k[Lg / lpp] : 0;   // this lane's Rice parameter
@@ -1531,11 +1538,13 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             constexpr bool verb = decltype(VERB)::value, emit = decltype(EMIT)::value, atom = decltype(ATOM)::value;
             const bool inrange = decltype(ALLF)::value ? true : inrange_;
             int32_t h[MAXO];
+            double hd[MAXO];                    // (17..25-bit samples: pfir_f64, as in the evaluation)
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
                 if (Lg > 0) x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
                 h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
+                if constexpr (FGP_F64P && ACC64) hd[(MAXO - 1 - j) % MAXO] = (double)x;
             }
             uint32_t pos = p0, len = 0;
             // Emission without LDS atomics: a lane's bits are consecutive, so it keeps the word it is filling in a register
@@ -1572,9 +1581,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 if (verb) { val = (uint32_t)x & mask; vb = sb; lead = 0; }
                 else {
                     int32_t res;
-                    // (17..25-bit samples: the two 16-bit chains here -- pfir_f64 needs twice the registers for the history,
-                    // which this kernel spills: packing 0.46 ms against 0.32 ms on 24-bit stereo at level 8)
                     if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
+                    else if constexpr (FGP_F64P) {
+                        const double xd = (double)x;
+                        res = (int32_t)(xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl));
+                        hd[u] = xd;
+                    }
                     else res = (int32_t)((i64)x - (pfir48<MAXO>(q, h, u) >> shift));
                     h[u] = ACC64 ? ppack(x) : x;
                     const uint32_t uu = ((uint32_t)res << 1) ^ (uint32_t)(res >> 31);
