@@ -1,0 +1,864 @@
+// flac_dec_wave.hip -- wave-parallel FLAC subframe parser for gfx950: one frame per wavefront, 64 lanes on ONE Rice partition.
+//
+// The lane-serial parser (flac_dec_fast.hip: lane = frame) needs as many frames as the chip has lanes; a single stream has a
+// few thousand, so its parse ran on one wave per CU with under half the lanes alive and took what 8192 serial codes take.
+// Here the serial dependency of a Rice-coded partition -- a code starts where the previous one ends -- is broken the way
+// self-synchronising variable-length codes allow:
+//
+//   * the bits of the partition are cut into chunks of B = 16 .. 128 bits, one per lane (a batch = 64 B bits; B follows the
+//     Rice parameter and what is left of the partition); a code belongs to the chunk its first bit lies in.  Every lane
+//     keeps its chunk and the 95 bits behind it as a private row of words in LDS (odd row stride: no bank conflicts);
+//   * every lane walks its chunk from a GUESSED entry (offset 0): per code one two-word LDS read, v_alignbit, v_ffbh and
+//     v_add3 (count leading zeros = quotient, + k + 1 = length).  It keeps the number of codes and the exit offset, i.e.
+//     where the first code of the next chunk starts;
+//   * sync rounds: a lane whose entry differs from its left neighbour's exit walks again from there.  Lane 0 is right
+//     from the start, so after round r lanes 0..r are final; because a wrong walk falls into step with the right one as
+//     soon as both hit the same stop bit (about one code in five), a handful of rounds settle all 64 lanes.  The loop
+//     ends when no entry changed -- or when every lane in front of the first changed one already covers what is left of
+//     the partition;
+//   * one DPP prefix sum over the counts gives every lane the sample index of its first code; a last walk extracts
+//     quotient and remainder, undoes the zig-zag and puts the residuals into an LDS buffer by sample index, which the
+//     wave then writes to the plane with coalesced stores;
+//   * the lane that owns the partition's last code knows where the next partition starts.
+//
+// A code whose unary part exceeds the 32-bit window (a residual above 32 * 2^k) stops the batch in front of it, is read bit
+// by bit, and the batches resume behind it.  Escape-coded partitions, VERBATIM and CONSTANT subframes and the warm-up /
+// coefficient fields are fixed-width fields at computable positions: lane = field.
+//
+// Output: the residual plane (frame-planar int32, warm-up samples in place), the FgDecSub records and the parse status,
+// exactly as fg_dec_rice_kernel leaves them for fg_dec_restore_kernel.  Frames outside the restore kernel's envelope
+// (predictor order > 12, 33-bit subframes, ...) get status 3 and go to the generic decoder as before.
+//
+// Reference path replaced: read_subframe_*, read_residual_partitioned_rice_ inside libFLAC (SURVEY.md section 8a row D2,
+// Appendix B; format: /root/reference/pyflac/include/FLAC/format.h:191-396).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "fg_dev.h"
+#include "fg_types.h"
+
+using namespace fgdev;
+
+#define FG_DMAXO 12
+#define FG_DEC_RPARAMS 256
+
+namespace {
+
+// Where the bits of one frame live: big-endian 32-bit words from the aligned word that holds the frame's first byte.
+struct WRd {
+    const uint32_t *fw;
+    uint32_t lw;          // last loadable word, relative to fw (the word that holds the last stream byte)
+    uint32_t bit0;        // bit offset of the frame start inside fw[0]: 0, 8, 16 or 24
+};
+
+__device__ __forceinline__ uint32_t wr_word(const WRd &r, uint32_t w) { return __builtin_bswap32(r.fw[w < r.lw ? w : r.lw]); }
+
+// 32 bits from frame-relative bit position `pos` (per lane, or uniform)
+__device__ __forceinline__ uint32_t wr_peek(const WRd &r, uint32_t pos)
+{
+    const uint32_t gp = r.bit0 + pos, w = gp >> 5, o = gp & 31;
+    const uint32_t hi = wr_word(r, w), lo = wr_word(r, w + 1);
+    return o ? __builtin_amdgcn_alignbit(hi, lo, 32 - o) : hi;
+}
+__device__ __forceinline__ uint32_t wr_bits(const WRd &r, uint32_t pos, uint32_t n)        // n <= 32
+{
+    return n ? wr_peek(r, pos) >> (32 - n) : 0;
+}
+__device__ __forceinline__ int32_t wr_sbits(const WRd &r, uint32_t pos, uint32_t n)
+{
+    return n ? (int32_t)wr_peek(r, pos) >> (32 - n) : 0;
+}
+
+__device__ __forceinline__ int32_t unzig(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
+
+__device__ __forceinline__ uint32_t wave_min32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t < v ? t : v; }
+    return v;
+}
+
+// A lane's row in LDS: the stream from the word that holds its chunk's first bit, every word with its bits reversed (stream
+// bit b of a word = bit b counted from the LSB).  The 32 bits that start q bits into the row are then
+// alignbit(row[(q >> 5) + 1], row[q >> 5], q) -- v_alignbit shifts right by the low five bits of q, no special case at word
+// boundaries --, a code's leading zeros are the window's TRAILING zeros (v_ffbl), and the remainder comes out bit-reversed.
+__device__ __forceinline__ uint32_t row_word(uint32_t raw) { return __builtin_bitreverse32(__builtin_bswap32(raw)); }
+__device__ __forceinline__ uint32_t row_win(const uint32_t *row, uint32_t q)
+{
+    const uint32_t *w = row + (q >> 5);
+    return __builtin_amdgcn_alignbit(w[1], w[0], q);
+}
+
+// Walk the chunk [q, hi) from q: number of codes that start inside it, and how far behind its end the next code starts.
+// A window without a stop bit counts as a code of 32 zeros: wrong, but it moves on, and the output walk reports it.
+// Eight VALU instructions and one LDS read a code; lanes leave the loop through EXEC as they pass `hi`.
+__device__ __forceinline__ void row_walk(const uint32_t *row, uint32_t q, uint32_t hi, uint32_t kp1, uint32_t &cnt, uint32_t &exitq)
+{
+    uint32_t n = 0, t;
+    unsigned long long sv;
+    const uint32_t ra = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)row;
+    asm volatile("s_mov_b64 %[sv], exec\n"
+                 "v_cmp_lt_u32 vcc, %[q], %[hi]\n"
+                 "s_and_b64 exec, exec, vcc\n"
+                 "s_cbranch_execz 2f\n"
+                 "1:\n"
+                 "v_lshrrev_b32 %[t], 5, %[q]\n"
+                 "v_lshl_add_u32 %[t], %[t], 2, %[ra]\n"
+                 "ds_read2_b32 v[62:63], %[t] offset1:1\n"
+                 "v_add_u32 %[n], 1, %[n]\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 "v_alignbit_b32 %[t], v63, v62, %[q]\n"
+                 "v_ffbl_b32 %[t], %[t]\n"
+                 "v_min_u32 %[t], 32, %[t]\n"
+                 "v_add3_u32 %[q], %[q], %[kp1], %[t]\n"
+                 "v_cmp_lt_u32 vcc, %[q], %[hi]\n"
+                 "s_and_b64 exec, exec, vcc\n"
+                 "s_cbranch_execnz 1b\n"
+                 "2:\n"
+                 "s_mov_b64 exec, %[sv]\n"
+                 : [q] "+v"(q), [n] "+v"(n), [t] "=&v"(t), [sv] "=&s"(sv)
+                 : [hi] "v"(hi), [kp1] "v"(kp1), [ra] "v"(ra)
+                 : "vcc", "v62", "v63", "memory");
+    cnt = n;
+    exitq = q - hi;
+}
+
+// lane i <- lane i - 1 (lane 0 <- 0): DPP wave_shr:1
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
+
+#define WP_ROWS_W (64 * 7)      // 64 rows of at most 7 words (B = 128: 4 + 3)
+#define WP_OUT_W 960            // residuals of one batch (64 lanes x at most 15 codes: B <= 15 (k + 1))
+#define WP_WAVE_W (WP_ROWS_W + WP_OUT_W)
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256, 7)
+fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch,
+                     FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters)
+{
+    __shared__ uint32_t lds[4 * WP_WAVE_W];
+    const int lane = threadIdx.x & 63;
+    uint32_t *const rows = lds + (threadIdx.x >> 6) * WP_WAVE_W;
+    int32_t *const outb = (int32_t *)(rows + WP_ROWS_W);
+    const uint32_t f = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (f >= nframes) return;
+    const FgDecFrame fr = frames[f];
+    if (fr.bytes == 0) return;                          // rejected by the header pass
+    uint32_t err = 0;
+    if (fr.bytes < fr.hdr_bytes + 2) err = 1;
+    const uint32_t n = fr.n, C = fr.channels;
+    const uint32_t end_bits = err ? 0 : (fr.bytes - 2) * 8;
+
+    WRd rd;
+    {
+        const uintptr_t sa = (uintptr_t)stream;
+        const u64 mis = (u64)(sa & 3);
+        const u64 fb = mis + fr.byte_off;
+        const u64 lastw = (mis + stream_len - 1) >> 2, w0 = fb >> 2;
+        rd.fw = (const uint32_t *)(sa & ~(uintptr_t)3) + w0;
+        const u64 room = lastw > w0 ? lastw - w0 : 0;
+        rd.lw = room > 0x07FFFFF0ull ? 0x07FFFFF0u : (uint32_t)room;
+        rd.bit0 = (uint32_t)(fb & 3) * 8;
+    }
+    uint32_t pos = fr.hdr_bytes * 8;                    // frame-relative bit position (uniform)
+    uint32_t n_batches = 0, n_rounds = 0, n_hard = 0;   // (counters: tuning aid)
+
+    for (uint32_t ch = 0; ch < C && !err; ch++) {
+        FgDecSub *sd = &subs[(size_t)f * C + ch];
+        int32_t *pl = scratch + fr.out_off * C + (u64)ch * n;
+        uint32_t sb = fr.bps;
+        if ((fr.ca == 1 && ch == 1) || (fr.ca == 2 && ch == 0) || (fr.ca == 3 && ch == 1)) sb++;
+        const uint32_t hdr = wr_bits(rd, pos, 8);
+        pos += 8;
+        uint32_t wasted = 0;
+        if (hdr & 0x80) err = 1;
+        if (!err && (hdr & 1)) {
+            // unary-coded wasted bits - 1
+            uint32_t z = 0;
+            for (;;) {
+                const uint32_t p = wr_peek(rd, pos);
+                if (p) { const uint32_t l = (uint32_t)__builtin_clz(p); z += l; pos += l + 1; break; }
+                z += 32; pos += 32;
+                if (pos > end_bits) break;
+            }
+            wasted = z + 1;
+            if (wasted >= sb) err = 1; else sb -= wasted;
+        }
+        if (!err && sb > (WIDE ? 32u : 24u)) err = 3;
+        const uint32_t t = (hdr >> 1) & 0x3F;
+        uint32_t mode = 0, order = 0;
+        if (t == 0) mode = 0;
+        else if (t == 1) mode = 1;
+        else if (t >= 8 && t <= 12) { mode = 2; order = t & 7; }
+        else if (t >= 32) { mode = 2; order = (t & 31) + 1; }
+        else if (!err) err = 1;
+        if (!err && order > n) err = 1;
+        if (!err && order > FG_DMAXO) err = 3;
+        if (err) break;
+
+        int shift = 0;
+        uint32_t sprec = 0, po = 0, plen = 4;
+        int32_t cval = 0;
+        if (mode == 0) {
+            cval = wr_sbits(rd, pos, sb);
+            pos += sb;
+            for (uint32_t i = lane; i < n; i += 64) pl[i] = cval;
+        }
+        else if (mode == 1) {
+            for (uint32_t i = lane; i < n; i += 64) pl[i] = wr_sbits(rd, pos + i * sb, sb);
+            pos += n * sb;
+        }
+        else {
+            // warm-up samples: lane = sample
+            if ((uint32_t)lane < order) pl[lane] = wr_sbits(rd, pos + (uint32_t)lane * sb, sb);
+            pos += order * sb;
+            if (t >= 32) {
+                const uint32_t ps = wr_bits(rd, pos, 9);
+                pos += 9;
+                const uint32_t prec = (ps >> 5) + 1;
+                sprec = prec;
+                if (prec == 16) err = 1;
+                shift = (int32_t)(ps << 27) >> 27;
+                if (!err && shift < 0) err = 1;
+                // the 32-bit restore is exact only under libFLAC's own width rule (lpc.c: bps + precision + ilog2(order) <= 32)
+                if (!err && !WIDE && sb + prec + ilog2_32(order) > 32) err = 3;
+                if (err) break;
+                if ((uint32_t)lane < order) sd->q[lane] = wr_sbits(rd, pos + (uint32_t)lane * prec, prec);
+                pos += order * prec;
+            }
+            else if (lane == 0) {
+                // fixed predictor of order k as FIR with binomial coefficients
+                const int32_t c0 = (int32_t)order, c1 = order < 2 ? 0 : (order == 2 ? -1 : order == 3 ? -3 : -6);
+                const int32_t c2 = order < 3 ? 0 : (order == 3 ? 1 : 4), c3 = order < 4 ? 0 : -1;
+                sd->q[0] = c0; sd->q[1] = c1; sd->q[2] = c2; sd->q[3] = c3;
+            }
+            const uint32_t mp = wr_bits(rd, pos, 6);
+            pos += 6;
+            const uint32_t method = mp >> 4;
+            if (method > 1) { err = 1; break; }
+            po = mp & 15;
+            plen = method ? 5 : 4;
+            const uint32_t escv = method ? 31 : 15;
+            const uint32_t psz = n >> po;
+            if ((po > 0 && ((n & ((1u << po) - 1)) != 0 || psz < order)) || (po == 0 && n < order)) { err = 1; break; }
+
+            uint32_t si = order;                         // next sample of the subframe
+            for (uint32_t part = 0; part < (1u << po) && !err; part++) {
+                const uint32_t pend = po == 0 ? n : (part + 1) * psz;
+                uint32_t R = pend - si;                  // codes left in this partition
+                const uint32_t k = wr_bits(rd, pos, plen);
+                pos += plen;
+                if (k == escv) {
+                    const uint32_t raw = wr_bits(rd, pos, 5);
+                    pos += 5;
+                    if (rparams && part < FG_DEC_RPARAMS && lane == 0) rparams[((size_t)f * C + ch) * FG_DEC_RPARAMS + part] = (uint16_t)(0x8000u | (raw << 8));
+                    for (uint32_t i = lane; i < R; i += 64) pl[si + i] = wr_sbits(rd, pos + i * raw, raw);
+                    pos += R * raw;
+                    si = pend;
+                    if (pos > end_bits) err = 4;
+                    continue;
+                }
+                if (rparams && part < FG_DEC_RPARAMS && lane == 0) rparams[((size_t)f * C + ch) * FG_DEC_RPARAMS + part] = (uint16_t)k;
+                const uint32_t kp1 = k + 1;
+                while (R > 0) {
+                    n_batches++;
+                    // ---- chunk size: at most 15 codes per lane (the output buffer), and no wider than the rest of the partition needs
+                    uint32_t B = 15 * kp1;
+                    B = B >= 128 ? 128u : (B >= 64 ? 64u : (B >= 32 ? 32u : 16u));         // (k = 0: 16 one-bit codes at most -- see the guard at the store)
+                    { const uint32_t est = (R < WP_OUT_W ? R : WP_OUT_W) * (k + 2) + 32; while (B > 16 && 32 * B >= est) B >>= 1; }
+                    const uint32_t nw = ((B + 62) >> 5) + 2, rs = nw | 1;      // 4, 4, 5, 7 words; odd row stride
+                    const uint32_t Rb = R < WP_OUT_W ? R : WP_OUT_W;           // codes this batch may deliver (the output buffer)
+                    // ---- this lane's row: the words from the one that holds its chunk's first bit
+                    const uint32_t a0 = rd.bit0 + pos + B * (uint32_t)lane, wr0 = a0 >> 5, q0 = a0 & 31, hi = q0 + B;
+                    uint32_t *const row = rows + rs * (uint32_t)lane;
+                    {
+                        const uint32_t wlast = ((rd.bit0 + pos + B * 63u) >> 5) + 6;
+                        if (wlast <= rd.lw) {
+#pragma unroll
+                            for (uint32_t t = 0; t < 7; t++) if (t < nw) row[t] = row_word(rd.fw[wr0 + t]);
+                        }
+                        else {
+#pragma unroll
+                            for (uint32_t t = 0; t < 7; t++) { const uint32_t w = wr0 + t; if (t < nw) row[t] = row_word(rd.fw[w < rd.lw ? w : rd.lw]); }
+                        }
+                    }
+                    // ---- guess, then sync rounds
+                    uint32_t e = 0, cnt, xq;
+                    row_walk(row, q0, hi, kp1, cnt, xq);
+                    uint32_t pfx = 0;
+                    for (uint32_t round = 0; round < 64; round++) {
+                        const uint32_t px = wave_shr1(xq);
+                        const bool changed = px != e;
+                        const u64 chm = __ballot(changed);
+                        if (chm == 0) break;
+                        // lanes in front of the first changed one are final: if they cover the rest of the partition, stop
+                        const uint32_t first = (uint32_t)__builtin_ctzll(chm);
+                        pfx = wave_scan_add(cnt) - cnt;
+                        if (rl(pfx, (int)first) >= Rb) break;
+                        n_rounds++;
+                        if (changed) { e = px; row_walk(row, q0 + e, hi, kp1, cnt, xq); }
+                    }
+                    const uint32_t incl = wave_scan_add(cnt);
+                    pfx = incl - cnt;
+                    const uint32_t total = rl(incl, 63);
+                    // ---- output walk: residuals into the LDS buffer by sample index
+                    uint32_t hardidx = 0xFFFFFFFFu, hardq = 0, endq = 0;
+                    bool has_end = false;
+                    {
+                        uint32_t q = q0 + e, idx = pfx;
+                        while (q < hi) {
+                            const uint32_t win = row_win(row, q);
+                            const uint32_t lz = win ? (uint32_t)__builtin_ctz(win) : 32u;
+                            uint32_t remw = (win >> (lz & 31)) >> 1;                  // the bits behind the stop bit
+                            if (lz + kp1 > 32) remw = row_win(row, q + (lz < 32 ? lz : 31u) + 1);      // ... when they do not lie in the window
+                            const uint32_t rem = (__builtin_bitreverse32(remw) >> 1) >> (31 - k);
+                            const int32_t val = unzig((lz << k) | rem);
+                            if (lz >= 32 && hardidx == 0xFFFFFFFFu) { hardidx = idx; hardq = q - q0; }
+                            if (idx < Rb) outb[idx] = val;
+                            q += lz + kp1;
+                            if (idx == Rb - 1) { endq = q - q0; has_end = true; }
+                            idx++;
+                        }
+                    }
+                    const uint32_t lim = total < Rb ? total : Rb;
+                    uint32_t hmin = 0xFFFFFFFFu;
+                    if (__any(hardidx < lim)) hmin = wave_min32(hardidx);
+                    // ---- the buffer goes to the plane: lane = sample (coalesced)
+                    {
+                        const uint32_t nout = hmin < lim ? hmin : lim;
+                        wave_lds_fence();
+                        for (uint32_t j = (uint32_t)lane; j < nout; j += 64) pl[si + j] = outb[j];
+                    }
+                    if (hmin < lim) {
+                        // a code with 32 or more leading zeros: everything in front of it stands; read it bit by bit, resume
+                        n_hard++;
+                        const u64 own = __ballot(hardidx == hmin);
+                        const int L = (int)__builtin_ctzll(own);
+                        uint32_t hp = pos + B * (uint32_t)L + rl(hardq, L);
+                        uint32_t z = 0;
+                        bool found = false;
+                        while (hp <= end_bits) {
+                            const uint32_t p = wr_peek(rd, hp);
+                            if (p) { const uint32_t l = (uint32_t)__builtin_clz(p); z += l; hp += l + 1; found = true; break; }
+                            z += 32; hp += 32;
+                        }
+                        if (!found) { err = 4; break; }
+                        const uint32_t rem = wr_bits(rd, hp, k);
+                        hp += k;
+                        if (lane == 0) pl[si + hmin] = unzig((z << k) | rem);
+                        si += hmin + 1; R -= hmin + 1; pos = hp;
+                    }
+                    else if (total >= Rb) {
+                        // the batch reaches the end of the partition (or fills the buffer): go on behind code Rb - 1
+                        const u64 own = __ballot(has_end);
+                        const int L = (int)__builtin_ctzll(own);
+                        pos = pos + B * (uint32_t)L + rl(endq, L);
+                        si += Rb; R -= Rb;
+                    }
+                    else {
+                        pos += B * 64u + rl(xq, 63);
+                        si += total; R -= total;
+                    }
+                    if (pos > end_bits) { err = 4; break; }
+                }
+            }
+            if (err) break;
+        }
+        // what FLAC__Frame.subframes[] reports (fg_types.h FgDecSub): type, coefficient precision, partition order, method
+        if (lane == 0) {
+            const uint32_t stype = mode == 0 ? 0u : mode == 1 ? 1u : (t >= 32 ? 3u : 2u);
+            sd->order = order; sd->shift = shift; sd->wasted = wasted;
+            sd->flags = stype | (sprec << 2) | (po << 7) | ((plen == 5 ? 1u : 0u) << 11) | (1u << 12);
+            if (mode == 0) sd->q[0] = cval;
+        }
+        if (pos > end_bits) err = 4;
+    }
+    if (!err) {
+        const uint32_t endb = (pos + 7) & ~7u;
+        const uint32_t padb = endb - pos;
+        if (endb != end_bits) err = 4;
+        else if (padb && (wr_peek(rd, pos) >> (32 - padb)) != 0) err = 5;      // libFLAC read_zero_padding_: lost sync
+    }
+    if (lane == 0) {
+        results[f].err = err;
+        if (counters) {
+            atomicAdd(&counters[0], (unsigned long long)n_batches);
+            atomicAdd(&counters[1], (unsigned long long)n_rounds);
+            atomicAdd(&counters[2], (unsigned long long)n_hard);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ restore
+// fg_dec_wrestore_kernel: the prediction recurrence and the output stage behind the wave-parallel parser.
+//
+//   workgroup = 64 chains (chain = one subframe: frame f, channel ch; chains of a frame are neighbours), four waves:
+//   wave 0     recurrence  lane = chain: s[i] = r[i] + ((sum_j q[j] s[i-1-j]) >> shift) over a 64-sample tile in LDS, the history
+//                          in registers (slot of a sample = i mod 4 / 8 / 16: static register indices); one v_mad_i32_i24 per
+//                          tap, the older taps in two interleaved chains.  This is the one serial chain of the decoder that
+//                          nothing parallelises (the floor in the shift makes the recurrence non-linear): 4096 steps of about
+//                          (order + 3) instructions for a block of 4096.
+//   wave 1     loader      tiles t + 1 and t + 2 of all 64 residual rows from the plane straight into LDS
+//                          (global_load_lds_dwordx4: no registers, no landing pass; sixteen instructions a tile).  Two tiles are
+//                          in flight because a step of the recurrence (1.4 us) is shorter than a round trip to the loaded
+//                          memory system (2.5 us): with one tile in flight the kernel ran at the pace of that latency.
+//   waves 2-3  writers     tile t - 1 out: wasted-bits shift, stereo decorrelation undone, channels interleaved, 16-byte
+//                          stores; silence for frames that failed.  They never wait for memory (a wave that loads AND stores
+//                          waits for its stores' round trip whenever it needs a load: memory operations retire in order).
+//   Four tile buffers (two landing, one computing, one being written out), one workgroup barrier per tile.
+//
+//   Tile layout: row r = 64 words, no padding (the DMA writes 64 lanes x 16 bytes contiguously); the four-word group g of
+//   row r sits at slot g ^ (r & 15), so that the sixteen lanes of one LDS access cycle -- sixteen different rows, same g -- hit
+//   sixteen different slots.  The loader permutes the global addresses accordingly (still whole 256-byte rows per 16 lanes).
+//   What lies behind the end of a row, or in rows without a frame, is garbage by design: the recurrence runs over it, the
+//   writers never look at it.
+//
+// Replaces fg_dec_restore_kernel (flac_dec_fast.hip: 32 chains per two-wave workgroup, tiles of 192) behind the wave parser;
+// same inputs (residual plane, FgDecSub, parse status + CRC verdict) and the same output contract.
+// Reference path replaced: FLAC__fixed_restore_signal, FLAC__lpc_restore_signal, undo_channel_coding.
+#define WR_TS 64
+#define WR_NB 4
+#define WR_FA 12            // words of facts per chain
+#define WR_TILE_W (64 * WR_TS)
+
+// byte offset of group g (four samples) inside a lane's row; xr = (row & 15) << 4
+__device__ __forceinline__ uint32_t wr_goff(uint32_t g, uint32_t xr) { return (g << 4) ^ xr; }
+
+// Eight steps of the 8-tap recurrence as one block of assembly: per sample v_mul_i32_i24 + 7 v_mad_i32_i24 (one chain -- a lone
+// wave issues an instruction every ~4.5 cycles whether or not it depends on the last one), the shift, the add that makes the
+// sample and puts it into its history slot.  Ten instructions a sample.  Written out because the compiler does not: left
+// alone it builds the sum from v_mul_i32_i24 and v_add3_u32 (three instructions for two taps), and a mad given to it one
+// asm statement at a time is followed by a pad s_nop each.
+__device__ __forceinline__ void wr_group8_asm(int32_t (&h)[16], const int32_t (&q)[16], int shift, const int32_t (&r)[8])
+{
+    int32_t t;
+    asm volatile("v_mul_i32_i24 %[t], %[q7], %[h0]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h7], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h0], %[r0], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h1]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h0], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h1], %[r1], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h2]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h1], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h2], %[r2], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h3]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h2], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h3], %[r3], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h4]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h3], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h4], %[r4], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h5]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h4], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h5], %[r5], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h6]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h5], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h6], %[r6], %[t]\n"
+                 "v_mul_i32_i24 %[t], %[q7], %[h7]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h6], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 "v_add_u32 %[h7], %[r7], %[t]\n"
+                 : [t] "=&v"(t), [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]),
+                   [h6] "+v"(h[6]), [h7] "+v"(h[7])
+                 : [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [q4] "v"(q[4]), [q5] "v"(q[5]), [q6] "v"(q[6]), [q7] "v"(q[7]),
+                   [sh] "v"(shift), [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [r4] "v"(r[4]), [r5] "v"(r[5]),
+                   [r6] "v"(r[6]), [r7] "v"(r[7]));
+}
+
+// MAXO samples from sample index i0 of the tile (a multiple of MAXO)
+template <int MAXO, bool WIDE, bool GATE>
+__device__ __forceinline__ void wr_group(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, uint32_t i0, char *rowb, uint32_t xr)
+{
+    constexpr int TAPS = MAXO == 16 ? 12 : MAXO;
+    int32_t r[MAXO];
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4) {
+        const uint4 t = *(const uint4 *)(rowb + wr_goff((i0 + u) >> 2, xr));
+        r[u] = (int32_t)t.x; r[u + 1] = (int32_t)t.y; r[u + 2] = (int32_t)t.z; r[u + 3] = (int32_t)t.w;
+    }
+    if constexpr (MAXO == 8 && !WIDE && !GATE) {
+        const int32_t r8[8] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
+        wr_group8_asm(h, q, shift, r8);
+        *(uint4 *)(rowb + wr_goff(i0 >> 2, xr)) = make_uint4((uint32_t)h[0], (uint32_t)h[1], (uint32_t)h[2], (uint32_t)h[3]);
+        *(uint4 *)(rowb + wr_goff((i0 + 4) >> 2, xr)) = make_uint4((uint32_t)h[4], (uint32_t)h[5], (uint32_t)h[6], (uint32_t)h[7]);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u++) {
+        int32_t pred;
+        if (!WIDE) {
+            // (the 8-tap form of whole tiles is wr_group8_asm; this one serves the first 16 samples and orders above 8)
+            int32_t sum = 0;
+#pragma unroll
+            for (int j = TAPS - 1; j >= 0; j--) sum += __mul24(q[j], h[(u - 1 - j + 2 * MAXO) % MAXO]);
+            pred = sum >> shift;
+        }
+        else {
+            i64 sum = 0;
+#pragma unroll
+            for (int j = TAPS - 1; j >= 0; j--) sum += (i64)q[j] * (i64)h[(u - 1 - j + 2 * MAXO) % MAXO];
+            pred = (int32_t)(sum >> shift);
+        }
+        int32_t v = r[u] + pred;
+        if (GATE) v = (i0 + (uint32_t)u >= order) ? v : r[u];
+        h[u] = v;
+        r[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4)
+        *(uint4 *)(rowb + wr_goff((i0 + u) >> 2, xr)) = make_uint4((uint32_t)r[u], (uint32_t)r[u + 1], (uint32_t)r[u + 2], (uint32_t)r[u + 3]);
+}
+
+template <int MAXO, bool WIDE>
+__device__ __forceinline__ void wr_tile(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, bool first, char *rowb, uint32_t xr)
+{
+    if (first) {
+        // (the warm-up samples, at most 12, lie in the first 16)
+#pragma unroll
+        for (int g = 0; g < 16 / MAXO; g++) wr_group<MAXO, WIDE, true>(h, q, shift, order, g * MAXO, rowb, xr);
+#pragma unroll
+        for (int g = 16 / MAXO; g < WR_TS / MAXO; g++) wr_group<MAXO, WIDE, false>(h, q, shift, order, g * MAXO, rowb, xr);
+    }
+    else if constexpr (MAXO == 8 && !WIDE) {
+        // the residuals of group g + 1 are requested before group g is computed: an LDS round trip is 100+ cycles, a fifth of a group
+        uint4 ra = *(const uint4 *)(rowb + wr_goff(0, xr)), rb = *(const uint4 *)(rowb + wr_goff(1, xr));
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            uint4 na = ra, nb = rb;
+            if (g < 7) { na = *(const uint4 *)(rowb + wr_goff(2 * g + 2, xr)); nb = *(const uint4 *)(rowb + wr_goff(2 * g + 3, xr)); }
+            const int32_t r8[8] = {(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y, (int32_t)rb.z, (int32_t)rb.w};
+            wr_group8_asm(h, q, shift, r8);
+            *(uint4 *)(rowb + wr_goff(2 * g, xr)) = make_uint4((uint32_t)h[0], (uint32_t)h[1], (uint32_t)h[2], (uint32_t)h[3]);
+            *(uint4 *)(rowb + wr_goff(2 * g + 1, xr)) = make_uint4((uint32_t)h[4], (uint32_t)h[5], (uint32_t)h[6], (uint32_t)h[7]);
+            ra = na; rb = nb;
+        }
+    }
+    else {
+#pragma unroll
+        for (int g = 0; g < WR_TS / MAXO; g++) wr_group<MAXO, WIDE, false>(h, q, shift, order, g * MAXO, rowb, xr);
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256)
+fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
+                       int32_t *out, FgDecResult *results, uint32_t interleave)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
+    uint32_t *const tiles = wsm;                                   // WR_NB x 64 rows x 64 words
+    uint32_t *const fa = wsm + WR_NB * WR_TILE_W;                  // 64 x WR_FA: n_in, n_out, plane lo/hi, out_off lo/hi, ca, wasted, n
+    uint32_t *const ctl = fa + 64 * WR_FA;                         // [0] nmax, [1] all planes 16-byte aligned, [2] stereo fast output
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    // whole frames per workgroup: G = 64 / C frames, lanes G C .. 63 idle (a frame's status is merged by the workgroup that owns it)
+    const uint32_t G = 64 / C;
+    const uint32_t f = blockIdx.x * G + (uint32_t)lane / C, ch = (uint32_t)lane % C;
+    const bool mine = (uint32_t)lane < G * C && f < nframes;
+
+    int32_t q[16], h[16];
+    uint32_t order = 0;
+    int shift = 0;
+    if (wave == 0) {
+        // ---- facts of this chain (and the CRC verdict merged into the frame status, as fg_dec_restore_kernel does)
+        uint32_t n = 0, status = 1, ca = 0, wasted = 0;
+        u64 out_off = 0;
+        if (mine) {
+            const FgDecFrame fr = frames[f];
+            if (fr.bytes != 0 && fr.channels == C) {
+                n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off;
+                const uint32_t cw = results[f].crc;
+                if (status == 0 && (cw & 0x80000000u)) status = 2;          // CRC-16 mismatch (fg_dec_crc_kernel)
+            }
+        }
+        const bool ok = mine && n != 0 && status == 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { q[j] = 0; h[j] = 0; }
+        if (ok) {
+            const FgDecSub *sd = &subs[(size_t)f * C + ch];
+            order = sd->order; shift = sd->shift; wasted = sd->wasted;
+#pragma unroll
+            for (int j = 0; j < FG_DMAXO; j++) if ((uint32_t)j < order) q[j] = sd->q[j];
+        }
+        const uint32_t n_in = ok ? n : 0;
+        const uint32_t n_out = (mine && status != 3) ? n : 0;               // status 3: the generic kernel writes the frame
+        const u64 plane = ok ? out_off * C + (u64)ch * n : 0;
+        uint32_t *fm = fa + lane * WR_FA;
+        fm[0] = n_in; fm[1] = n_out; fm[2] = (uint32_t)plane; fm[3] = (uint32_t)(plane >> 32);
+        fm[4] = (uint32_t)out_off; fm[5] = (uint32_t)(out_off >> 32); fm[6] = ca; fm[7] = wasted; fm[8] = n;
+        uint32_t nmax = n_out;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
+        const bool al = !__any(n_in != 0 && (plane & 3) != 0);
+        // stereo fast output: every frame of the group starts on an even lane (C == 2), 16-byte aligned output rows
+        const bool so = C == 2 && !__any(n_out != 0 && ((out_off & 1) != 0 || (n & 3) != 0)) && (((uintptr_t)out) & 15) == 0;
+        if (lane == 0) { ctl[0] = nmax; ctl[1] = (al && (((uintptr_t)scratch) & 15) == 0) ? 1u : 0u; ctl[2] = so ? 1u : 0u; }
+    }
+    __syncthreads();
+    // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])
+    if (wave == 0 && mine && ch == 0) {
+        const FgDecFrame fr = frames[f];
+        if (fr.bytes != 0 && fr.channels == C && fr.n != 0) {
+            uint32_t status = results[f].err;
+            const uint32_t cw = results[f].crc;
+            if (status == 0 && (cw & 0x80000000u)) status = 2;
+            results[f].err = status; results[f].crc = cw & 0xFFFFu;
+        }
+    }
+    const uint32_t nmax = ctl[0];
+    const bool planes_al = ctl[1] != 0, stereo_fast = ctl[2] != 0;
+    const uint32_t T = (nmax + WR_TS - 1) / WR_TS;
+    const uint32_t S = T + 1;                  // steps (barriers) of every wave
+
+    if (wave == 0) {
+        const bool big = __any(order > 8), small = !__any(order > 4);
+        const uint32_t xr = ((uint32_t)lane & 15) << 4;
+        for (uint32_t s = 1; s <= S; s++) {
+            __syncthreads();
+            if (s > T || (interleave & 0x200)) continue;
+            const uint32_t t = s - 1;
+            char *rowb = (char *)(tiles + (t % WR_NB) * WR_TILE_W + (uint32_t)lane * WR_TS);
+            if (big) wr_tile<16, WIDE>(h, q, shift, order, t == 0, rowb, xr);
+            else if (small) wr_tile<4, WIDE>(h, q, shift, order, t == 0, rowb, xr);
+            else wr_tile<8, WIDE>(h, q, shift, order, t == 0, rowb, xr);
+        }
+        return;
+    }
+
+    if (wave == 1) {
+        // ---- loader.  Instruction k of a tile fills rows 4k .. 4k + 3: lane L writes slot L & 15 of row 4k + (L >> 4), i.e. it
+        // fetches group (L & 15) ^ (row & 15).  Lanes behind the end of their row (and all lanes past the last tile) fetch from
+        // the start of the plane area instead: every path issues the same sixteen loads, so the counts in the waits are exact.
+        // Planes that are not 16-byte aligned (odd block sizes) go word by word: 64 loads a tile, lane = column.
+        u64 rbase[16];
+        uint32_t rlen[16], rcol[16];
+        if (planes_al) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t row = 4u * (uint32_t)k + ((uint32_t)lane >> 4);
+                const uint32_t *fm = fa + row * WR_FA;
+                rbase[k] = ((u64)fm[3] << 32) | fm[2];
+                rlen[k] = fm[0];
+                rcol[k] = ((((uint32_t)lane & 15) ^ (row & 15)) << 2);
+            }
+        }
+        auto issue = [&](uint32_t t) __attribute__((always_inline)) {
+            uint32_t *tb = tiles + (t % WR_NB) * WR_TILE_W;
+            if (planes_al) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t c0 = t * WR_TS + rcol[k];
+                    const int32_t *src = (t < T && c0 < rlen[k]) ? scratch + rbase[k] + c0 : scratch;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(tb + 4 * k * WR_TS), 16, 0, 0);
+                }
+            }
+            else {
+                for (uint32_t row = 0; row < 64; row++) {
+                    const uint32_t *fm = fa + row * WR_FA;
+                    const uint32_t c = (((((uint32_t)lane >> 2) ^ (row & 15)) << 2) | ((uint32_t)lane & 3));
+                    const uint32_t c0 = t * WR_TS + c;
+                    const int32_t *src = (t < T && c0 < fm[0]) ? scratch + (((u64)fm[3] << 32) | fm[2]) + c0 : scratch;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(tb + row * WR_TS), 4, 0, 0);
+                }
+            }
+        };
+        issue(0); issue(1);
+        if (planes_al) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t s = 1; s <= S; s++) {
+            // barrier s publishes tile s - 1 (and whatever older)
+            asm volatile("s_barrier" ::: "memory");
+            issue(s + 1);
+            if (planes_al) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // ---- writers: 128 lanes
+    const uint32_t ml = threadIdx.x - 128;
+    uint32_t w_rn[4], w_cc[4], w_wa[4], w_wb[4];
+    bool w_ok[4];
+    u64 w_oo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t *fm = fa + ((((uint32_t)k * 128 + ml) >> 4) * 2) * WR_FA;
+        w_rn[k] = fm[1]; w_ok[k] = fm[0] != 0; w_cc[k] = fm[6]; w_wa[k] = fm[7]; w_wb[k] = fm[WR_FA + 7];
+        w_oo[k] = ((u64)fm[5] << 32) | fm[4];
+    }
+    auto writeout = [&](uint32_t t) __attribute__((always_inline)) {
+        const uint32_t *tb = tiles + (t % WR_NB) * WR_TILE_W;
+        const uint32_t i0 = t * WR_TS;
+        if (stereo_fast) {
+            // task = (frame pair of rows, group): 32 x 16, four per lane -- always the same four frames, whose facts sit in registers
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t id = (uint32_t)k * 128 + ml;
+                const uint32_t r0 = (id >> 4) * 2, g = id & 15, i = i0 + g * 4;
+                const uint32_t rn = w_rn[k];
+                if (i >= rn) continue;
+                const uint32_t cc = w_cc[k], wa = w_wa[k], wb = w_wb[k];
+                int32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+                if (w_ok[k]) {
+                    const uint4 ta = *(const uint4 *)&tb[r0 * WR_TS + ((g ^ (r0 & 15)) << 2)];
+                    const uint4 tb4 = *(const uint4 *)&tb[(r0 + 1) * WR_TS + ((g ^ ((r0 + 1) & 15)) << 2)];
+                    const uint32_t xa[4] = {ta.x, ta.y, ta.z, ta.w}, xb[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int32_t av = (int32_t)(xa[e] << wa), bv = (int32_t)(xb[e] << wb);
+                        int32_t ma, mb;
+                        if (WIDE) {
+                            // (32-bit streams: a side channel with wasted bits is a 33-bit value once shifted back)
+                            const i64 side = (i64)((u64)(i64)(int32_t)xb[e] << wb);
+                            const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
+                            ma = (int32_t)((mid + side) >> 1); mb = (int32_t)((mid - side) >> 1);
+                        }
+                        else {
+                            const int32_t mid = (int32_t)(((uint32_t)av << 1) | ((uint32_t)bv & 1));
+                            ma = (mid + bv) >> 1; mb = (mid - bv) >> 1;
+                        }
+                        a[e] = cc == 2 ? av + bv : cc == 3 ? ma : av;
+                        b[e] = cc == 1 ? av - bv : cc == 3 ? mb : bv;
+                    }
+                }
+                int32_t *o = out + w_oo[k] * 2;
+                if (interleave & 1) {
+                    int4 *d = (int4 *)(o + (size_t)i * 2);
+                    d[0] = make_int4(a[0], b[0], a[1], b[1]);
+                    d[1] = make_int4(a[2], b[2], a[3], b[3]);
+                }
+                else {
+                    *(int4 *)(o + i) = make_int4(a[0], a[1], a[2], a[3]);
+                    *(int4 *)(o + rn + i) = make_int4(b[0], b[1], b[2], b[3]);
+                }
+            }
+            return;
+        }
+        // general form: task = (row, column)
+        for (uint32_t id = ml; id < 64 * WR_TS; id += 128) {
+            const uint32_t row = id >> 6, col = id & 63, i = i0 + col;
+            const uint32_t *fm = fa + row * WR_FA;
+            const uint32_t rn = fm[1];
+            if (i >= rn) continue;
+            const uint32_t cch = row % C;
+            const u64 oo = ((u64)fm[5] << 32) | fm[4];
+            int32_t v = 0;
+            if (C == 2) {
+                const uint32_t r0 = row & ~1u;
+                const uint32_t *f0 = fa + r0 * WR_FA;
+                if (f0[0] != 0) {
+                    const uint32_t xa = tb[r0 * WR_TS + ((((col >> 2) ^ (r0 & 15)) << 2) | (col & 3))];
+                    const uint32_t xb = tb[(r0 + 1) * WR_TS + ((((col >> 2) ^ ((r0 + 1) & 15)) << 2) | (col & 3))];
+                    const uint32_t cc = f0[6], wa = f0[7], wb = f0[WR_FA + 7];
+                    const int32_t av = (int32_t)(xa << wa), bv = (int32_t)(xb << wb);
+                    const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)xb << wb) : (i64)bv;
+                    const i64 mid = (i64)(((u64)(i64)av) << 1) | (side & 1);
+                    const int32_t ma = (int32_t)((mid + side) >> 1), mb = (int32_t)((mid - side) >> 1);
+                    const int32_t lo = cc == 2 ? av + bv : cc == 3 ? ma : av;
+                    const int32_t ro = cc == 1 ? av - bv : cc == 3 ? mb : bv;
+                    v = cch == 0 ? lo : ro;
+                }
+            }
+            else if (fm[0] != 0) v = (int32_t)(tb[row * WR_TS + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3))] << fm[7]);
+            int32_t *o = out + oo * C;
+            if (interleave & 1) o[(size_t)i * C + cch] = v;
+            else o[(size_t)cch * rn + i] = v;
+        }
+    };
+    // (tile T - 1 is computed in step T and leaves in step S = T + 1)
+    for (uint32_t s = 1; s <= S; s++) {
+        __syncthreads();
+        if (s >= 2 && !(interleave & 0x100)) writeout(s - 2);
+    }
+}
+
+}  // namespace
+
+// Same contract as fg_launch_decode_fast (flac_dec_fast.hip): residual plane, subframe records, parse status.
+extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
+                                       int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
+                                       unsigned long long *d_counters, hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    const dim3 grid((nframes + 3) / 4);
+    if (wide) hipLaunchKernelGGL(fg_dec_wparse_kernel<true>, grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
+    else hipLaunchKernelGGL(fg_dec_wparse_kernel<false>, grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
+    return (int)hipGetLastError();
+}
+
+// Same contract as fg_launch_decode_finish (flac_dec_fast.hip), without the profile words.
+extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
+                                         const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
+                                         hipStream_t stream)
+{
+    if (nframes == 0) return 0;
+    const uint32_t C = channels ? channels : 1;
+    if (C > 64) return -1;
+    if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 no output, 2 no recurrence
+    const uint32_t G = 64 / C;
+    const dim3 grid((nframes + G - 1) / G);
+    const size_t lds = ((size_t)WR_NB * WR_TILE_W + 64 * WR_FA + 8) * 4;
+    static bool configured[2] = {false, false};
+    const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true> : (const void *)fg_dec_wrestore_kernel<false>;
+    if (!configured[wide ? 1 : 0]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        configured[wide ? 1 : 0] = true;
+    }
+    if (wide) hipLaunchKernelGGL(fg_dec_wrestore_kernel<true>, grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
+    else hipLaunchKernelGGL(fg_dec_wrestore_kernel<false>, grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
+    return (int)hipGetLastError();
+}

@@ -468,7 +468,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // wanted (subframe detail level 2) or with FLACGPU_DEC_FUSED=0, the two-kernel version with the plane in HBM.
     static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
     static const bool prof_fused = getenv("FLACGPU_DEC_PROF") && atoi(getenv("FLACGPU_DEC_PROF")) == 2;
-    const bool fused = !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
+    static const int wave_parse = getenv("FLACGPU_DEC_WAVE") ? atoi(getenv("FLACGPU_DEC_WAVE")) : 1;     // 0: the lane-serial fused kernel of round 2
+    const bool fused = !wave_parse && !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
     if (fused) {
         if (fg_launch_decode_fused((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
                                    (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams,
@@ -481,12 +482,33 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         }
     }
     else {
-        if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+        if (wave_parse) {
+            // wave-parallel parse (flac_dec_wave.hip): one frame per wavefront; FLACGPU_DEC_WAVE=2 also counts batches / sync rounds
+            unsigned long long *d_cnt = nullptr;
+            if (wave_parse >= 2 && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
+            if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+                                        (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream) != 0) {
+                fg_set_error("decode kernel launch failed"); return false;
+            }
+            if (d_cnt) {
+                unsigned long long hc[3] = {0, 0, 0};
+                if (HIPOK(hipMemcpyAsync(hc, d_cnt, 24, hipMemcpyDeviceToHost, c->stream)) && HIPOK(hipStreamSynchronize(c->stream)))
+                    fprintf(stderr, "[flacgpu dec wave] %u frames: %llu batches, %llu sync rounds, %llu long codes\n", nframes, hc[0], hc[1], hc[2]);
+            }
+        }
+        else if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
                                   (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, d_rparams, c->stream) != 0) {
             fg_set_error("decode kernel launch failed"); return false;
         }
         if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-        if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
+        static const bool old_restore = getenv("FLACGPU_DEC_WRESTORE") && atoi(getenv("FLACGPU_DEC_WRESTORE")) == 0;
+        if (wave_parse && !old_restore) {
+            if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, interleave ? 1u : 0u, wide, c->stream) != 0) {
+                fg_set_error("decode kernel launch failed"); return false;
+            }
+        }
+        else if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
                                     (const FgDecSub *)c->dec_subs.p, (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p,
                                     (const uint16_t *)c->crctab.p, interleave ? 1u : 0u, wide, d_prof ? d_prof + (size_t)npad * 8 : nullptr, c->stream) != 0) {
             fg_set_error("decode kernel launch failed"); return false;
