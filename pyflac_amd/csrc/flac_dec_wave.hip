@@ -91,35 +91,39 @@ __device__ __forceinline__ uint32_t row_win(const uint32_t *row, uint32_t q)
 }
 
 // Walk the chunk [q, hi) from q: number of codes that start inside it, and how far behind its end the next code starts.
-// A window without a stop bit counts as a code of 32 zeros: wrong, but it moves on, and the output walk reports it.
-// Eight VALU instructions and one LDS read a code; lanes leave the loop through EXEC as they pass `hi`.
+// Seven VALU instructions and one LDS read a code; lanes leave the loop through EXEC as they pass `hi`.  A window without a
+// stop bit makes v_ffbl return -1: the walk then moves on by k bits -- wrong, but it moves on (k >= 1), and the output walk
+// reports the code.  With k = 0 that would stand still, so that case keeps a v_min_u32 (SAFE).
+#define WP_WALK_ASM(GUARD)                                                  \
+    asm volatile("s_mov_b64 %[sv], exec\n"                                  \
+                 "v_cmp_lt_u32 vcc, %[q], %[hi]\n"                          \
+                 "s_and_b64 exec, exec, vcc\n"                              \
+                 "s_cbranch_execz 2f\n"                                     \
+                 "1:\n"                                                     \
+                 "v_lshrrev_b32 %[t], 5, %[q]\n"                            \
+                 "v_lshl_add_u32 %[t], %[t], 2, %[ra]\n"                    \
+                 "ds_read2_b32 v[62:63], %[t] offset1:1\n"                  \
+                 "v_add_u32 %[n], 1, %[n]\n"                                \
+                 "s_waitcnt lgkmcnt(0)\n"                                   \
+                 "v_alignbit_b32 %[t], v63, v62, %[q]\n"                    \
+                 "v_ffbl_b32 %[t], %[t]\n" GUARD                            \
+                 "v_add3_u32 %[q], %[q], %[kp1], %[t]\n"                    \
+                 "v_cmp_lt_u32 vcc, %[q], %[hi]\n"                          \
+                 "s_and_b64 exec, exec, vcc\n"                              \
+                 "s_cbranch_execnz 1b\n"                                    \
+                 "2:\n"                                                     \
+                 "s_mov_b64 exec, %[sv]\n"                                  \
+                 : [q] "+v"(q), [n] "+v"(n), [t] "=&v"(t), [sv] "=&s"(sv)   \
+                 : [hi] "v"(hi), [kp1] "v"(kp1), [ra] "v"(ra)               \
+                 : "vcc", "v62", "v63", "memory")
+template <bool SAFE>
 __device__ __forceinline__ void row_walk(const uint32_t *row, uint32_t q, uint32_t hi, uint32_t kp1, uint32_t &cnt, uint32_t &exitq)
 {
     uint32_t n = 0, t;
     unsigned long long sv;
     const uint32_t ra = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)row;
-    asm volatile("s_mov_b64 %[sv], exec\n"
-                 "v_cmp_lt_u32 vcc, %[q], %[hi]\n"
-                 "s_and_b64 exec, exec, vcc\n"
-                 "s_cbranch_execz 2f\n"
-                 "1:\n"
-                 "v_lshrrev_b32 %[t], 5, %[q]\n"
-                 "v_lshl_add_u32 %[t], %[t], 2, %[ra]\n"
-                 "ds_read2_b32 v[62:63], %[t] offset1:1\n"
-                 "v_add_u32 %[n], 1, %[n]\n"
-                 "s_waitcnt lgkmcnt(0)\n"
-                 "v_alignbit_b32 %[t], v63, v62, %[q]\n"
-                 "v_ffbl_b32 %[t], %[t]\n"
-                 "v_min_u32 %[t], 32, %[t]\n"
-                 "v_add3_u32 %[q], %[q], %[kp1], %[t]\n"
-                 "v_cmp_lt_u32 vcc, %[q], %[hi]\n"
-                 "s_and_b64 exec, exec, vcc\n"
-                 "s_cbranch_execnz 1b\n"
-                 "2:\n"
-                 "s_mov_b64 exec, %[sv]\n"
-                 : [q] "+v"(q), [n] "+v"(n), [t] "=&v"(t), [sv] "=&s"(sv)
-                 : [hi] "v"(hi), [kp1] "v"(kp1), [ra] "v"(ra)
-                 : "vcc", "v62", "v63", "memory");
+    if (SAFE) WP_WALK_ASM("v_min_u32 %[t], 32, %[t]\n");
+    else WP_WALK_ASM("");
     cnt = n;
     exitq = q - hi;
 }
@@ -127,12 +131,16 @@ __device__ __forceinline__ void row_walk(const uint32_t *row, uint32_t q, uint32
 // lane i <- lane i - 1 (lane 0 <- 0): DPP wave_shr:1
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }
 
-#define WP_ROWS_W (64 * 7)      // 64 rows of at most 7 words (B = 128: 4 + 3)
-#define WP_OUT_W 960            // residuals of one batch (64 lanes x at most 15 codes: B <= 15 (k + 1))
+#define WP_ROWS_W (64 * 9)      // 64 rows of at most 9 words (B = 192: 6 + 3)
+#define WP_OUT_W 704            // words: the residuals of one batch, 704 of 32 bits (11 a lane) or 1408 of 16 bits (22 a lane)
+// (5120 bytes of LDS a wave: eight workgroups of four waves fill a CU's 160 KB, so that all frames of a ten-minute stream --
+// 7032 -- are resident at once; with fewer slots than frames the kernel takes two wave lifetimes instead of one)
 #define WP_WAVE_W (WP_ROWS_W + WP_OUT_W)
+typedef uint32_t wp_u32x4 __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte accesses at 4-byte alignment
+typedef int32_t wp_i32x4 __attribute__((ext_vector_type(4), aligned(4)));
 
 template <bool WIDE>
-__global__ void __launch_bounds__(256, 7)
+__global__ void __launch_bounds__(256, 8)
 fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch,
                      FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters)
 {
@@ -260,52 +268,71 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                 }
                 if (rparams && part < FG_DEC_RPARAMS && lane == 0) rparams[((size_t)f * C + ch) * FG_DEC_RPARAMS + part] = (uint16_t)k;
                 const uint32_t kp1 = k + 1;
+                // Residuals that fit 16 bits go through the output buffer as such (twice the codes per batch, so chunks of up to 256
+                // bits and fewer sync rounds): with k <= 12 a value outgrows 16 bits only through a quotient of 2^(16 - k) or more,
+                // and those codes take the bit-by-bit path that codes of 32 and more leading zeros take anyway.
+                const bool o16 = k <= 12;
+                const uint32_t hardlz = k == 12 ? 16u : 32u;
+                const uint32_t outcap = o16 ? 2u * WP_OUT_W : WP_OUT_W;
                 while (R > 0) {
                     n_batches++;
-                    // ---- chunk size: at most 15 codes per lane (the output buffer), and no wider than the rest of the partition needs
-                    uint32_t B = 15 * kp1;
-                    B = B >= 128 ? 128u : (B >= 64 ? 64u : (B >= 32 ? 32u : 16u));         // (k = 0: 16 one-bit codes at most -- see the guard at the store)
-                    { const uint32_t est = (R < WP_OUT_W ? R : WP_OUT_W) * (k + 2) + 32; while (B > 16 && 32 * B >= est) B >>= 1; }
-                    const uint32_t nw = ((B + 62) >> 5) + 2, rs = nw | 1;      // 4, 4, 5, 7 words; odd row stride
-                    const uint32_t Rb = R < WP_OUT_W ? R : WP_OUT_W;           // codes this batch may deliver (the output buffer)
+                    // ---- chunk size: at most outcap / 64 codes per lane, and no wider than the rest of the partition needs
+                    const uint32_t Rb = R < outcap ? R : outcap;               // codes this batch may deliver
+                    uint32_t B = (outcap >> 6) * kp1;                           // (a multiple of 32, or 16)
+                    B = B >= 192 ? 192u : (B >= 32 ? (B & ~31u) : 16u);
+                    { const uint32_t est = Rb * (k + 2) + 32; while (B > 16 && 32 * B >= est) B = B > 32 ? ((B >> 1) + 31) & ~31u : 16u; }
+                    const uint32_t nw = ((B + 62) >> 5) + 2, rs = nw | 1;      // 4 .. 9 words; odd row stride
+                    const bool maybe_end = Rb * kp1 < 64 * B;                  // (else the batch cannot hold what is left)
                     // ---- this lane's row: the words from the one that holds its chunk's first bit
                     const uint32_t a0 = rd.bit0 + pos + B * (uint32_t)lane, wr0 = a0 >> 5, q0 = a0 & 31, hi = q0 + B;
                     uint32_t *const row = rows + rs * (uint32_t)lane;
                     {
-                        const uint32_t wlast = ((rd.bit0 + pos + B * 63u) >> 5) + 6;
+                        const uint32_t wlast = ((rd.bit0 + pos + B * 63u) >> 5) + 8;
                         if (wlast <= rd.lw) {
-#pragma unroll
-                            for (uint32_t t = 0; t < 7; t++) if (t < nw) row[t] = row_word(rd.fw[wr0 + t]);
+                            const wp_u32x4 v0 = *(const wp_u32x4 *)(rd.fw + wr0);
+                            row[0] = row_word(v0.x); row[1] = row_word(v0.y); row[2] = row_word(v0.z); row[3] = row_word(v0.w);
+                            if (nw > 4) {
+                                const wp_u32x4 v1 = *(const wp_u32x4 *)(rd.fw + wr0 + 4);
+                                row[4] = row_word(v1.x);
+                                if (nw > 5) row[5] = row_word(v1.y);
+                                if (nw > 6) row[6] = row_word(v1.z);
+                                if (nw > 7) row[7] = row_word(v1.w);
+                                if (nw > 8) row[8] = row_word(rd.fw[wr0 + 8]);
+                            }
                         }
                         else {
 #pragma unroll
-                            for (uint32_t t = 0; t < 7; t++) { const uint32_t w = wr0 + t; if (t < nw) row[t] = row_word(rd.fw[w < rd.lw ? w : rd.lw]); }
+                            for (uint32_t t = 0; t < 9; t++) { const uint32_t w = wr0 + t; if (t < nw) row[t] = row_word(rd.fw[w < rd.lw ? w : rd.lw]); }
                         }
                     }
                     // ---- guess, then sync rounds
                     uint32_t e = 0, cnt, xq;
-                    row_walk(row, q0, hi, kp1, cnt, xq);
-                    uint32_t pfx = 0;
+                    if (k == 0) row_walk<true>(row, q0, hi, kp1, cnt, xq); else row_walk<false>(row, q0, hi, kp1, cnt, xq);
                     for (uint32_t round = 0; round < 64; round++) {
                         const uint32_t px = wave_shr1(xq);
                         const bool changed = px != e;
                         const u64 chm = __ballot(changed);
                         if (chm == 0) break;
-                        // lanes in front of the first changed one are final: if they cover the rest of the partition, stop
-                        const uint32_t first = (uint32_t)__builtin_ctzll(chm);
-                        pfx = wave_scan_add(cnt) - cnt;
-                        if (rl(pfx, (int)first) >= Rb) break;
+                        if (maybe_end) {
+                            // lanes in front of the first changed one are final: if they cover the rest of the partition, stop
+                            const uint32_t first = (uint32_t)__builtin_ctzll(chm);
+                            const uint32_t pf = wave_scan_add(cnt) - cnt;
+                            if (rl(pf, (int)first) >= Rb) break;
+                        }
                         n_rounds++;
-                        if (changed) { e = px; row_walk(row, q0 + e, hi, kp1, cnt, xq); }
+                        if (changed) {
+                            e = px;
+                            if (k == 0) row_walk<true>(row, q0 + e, hi, kp1, cnt, xq); else row_walk<false>(row, q0 + e, hi, kp1, cnt, xq);
+                        }
                     }
                     const uint32_t incl = wave_scan_add(cnt);
-                    pfx = incl - cnt;
+                    const uint32_t pfx = incl - cnt;
                     const uint32_t total = rl(incl, 63);
                     // ---- output walk: residuals into the LDS buffer by sample index
-                    uint32_t hardidx = 0xFFFFFFFFu, hardq = 0, endq = 0;
-                    bool has_end = false;
+                    uint32_t hardidx = 0xFFFFFFFFu, hardq = 0;
                     {
                         uint32_t q = q0 + e, idx = pfx;
+                        int16_t *const out16 = (int16_t *)outb;
                         while (q < hi) {
                             const uint32_t win = row_win(row, q);
                             const uint32_t lz = win ? (uint32_t)__builtin_ctz(win) : 32u;
@@ -313,24 +340,41 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                             if (lz + kp1 > 32) remw = row_win(row, q + (lz < 32 ? lz : 31u) + 1);      // ... when they do not lie in the window
                             const uint32_t rem = (__builtin_bitreverse32(remw) >> 1) >> (31 - k);
                             const int32_t val = unzig((lz << k) | rem);
-                            if (lz >= 32 && hardidx == 0xFFFFFFFFu) { hardidx = idx; hardq = q - q0; }
-                            if (idx < Rb) outb[idx] = val;
+                            if (lz >= hardlz && hardidx == 0xFFFFFFFFu) { hardidx = idx; hardq = q - q0; }
+                            if (idx < Rb) { if (o16) out16[idx] = (int16_t)val; else outb[idx] = val; }
                             q += lz + kp1;
-                            if (idx == Rb - 1) { endq = q - q0; has_end = true; }
                             idx++;
                         }
                     }
                     const uint32_t lim = total < Rb ? total : Rb;
                     uint32_t hmin = 0xFFFFFFFFu;
                     if (__any(hardidx < lim)) hmin = wave_min32(hardidx);
-                    // ---- the buffer goes to the plane: lane = sample (coalesced)
+                    // ---- the buffer goes to the plane: four samples a lane and store
                     {
                         const uint32_t nout = hmin < lim ? hmin : lim;
+                        int32_t *const dst = pl + si;
                         wave_lds_fence();
-                        for (uint32_t j = (uint32_t)lane; j < nout; j += 64) pl[si + j] = outb[j];
+                        if (o16) {
+                            const uint2 *const o2 = (const uint2 *)outb;
+                            for (uint32_t j = 4u * (uint32_t)lane; j < nout; j += 256) {
+                                const uint2 w = o2[j >> 2];
+                                const int32_t v0 = (int32_t)(w.x << 16) >> 16, v1 = (int32_t)w.x >> 16, v2 = (int32_t)(w.y << 16) >> 16, v3 = (int32_t)w.y >> 16;
+                                if (j + 4 <= nout) { wp_i32x4 v; v.x = v0; v.y = v1; v.z = v2; v.w = v3; *(wp_i32x4 *)(dst + j) = v; }
+                                else { dst[j] = v0; if (j + 1 < nout) dst[j + 1] = v1; if (j + 2 < nout) dst[j + 2] = v2; }
+                            }
+                        }
+                        else {
+                            const int4 *const o4 = (const int4 *)outb;
+                            for (uint32_t j = 4u * (uint32_t)lane; j < nout; j += 256) {
+                                const int4 w = o4[j >> 2];
+                                if (j + 4 <= nout) { wp_i32x4 v; v.x = w.x; v.y = w.y; v.z = w.z; v.w = w.w; *(wp_i32x4 *)(dst + j) = v; }
+                                else { dst[j] = w.x; if (j + 1 < nout) dst[j + 1] = w.y; if (j + 2 < nout) dst[j + 2] = w.z; }
+                            }
+                        }
                     }
                     if (hmin < lim) {
-                        // a code with 32 or more leading zeros: everything in front of it stands; read it bit by bit, resume
+                        // a code with too many leading zeros for the window (or the 16-bit buffer): everything in front of it stands;
+                        // read it bit by bit, resume behind it
                         n_hard++;
                         const u64 own = __ballot(hardidx == hmin);
                         const int L = (int)__builtin_ctzll(own);
@@ -349,9 +393,19 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                         si += hmin + 1; R -= hmin + 1; pos = hp;
                     }
                     else if (total >= Rb) {
-                        // the batch reaches the end of the partition (or fills the buffer): go on behind code Rb - 1
-                        const u64 own = __ballot(has_end);
-                        const int L = (int)__builtin_ctzll(own);
+                        // the batch reaches the end of the partition (or fills the buffer): the lane that owns code Rb - 1 walks up to
+                        // it once more and says where the next code starts
+                        const bool own = pfx < Rb && Rb <= pfx + cnt;
+                        uint32_t endq = 0;
+                        if (own) {
+                            uint32_t q = q0 + e;
+                            for (uint32_t j = pfx; j < Rb; j++) {
+                                const uint32_t win = row_win(row, q);
+                                q += (win ? (uint32_t)__builtin_ctz(win) : 32u) + kp1;
+                            }
+                            endq = q - q0;
+                        }
+                        const int L = (int)__builtin_ctzll(__ballot(own));
                         pos = pos + B * (uint32_t)L + rl(endq, L);
                         si += Rb; R -= Rb;
                     }
