@@ -204,6 +204,7 @@ def main():
 
     out = offs = dec = None
     single = lengths is None
+    ranges = [None]
 
     def step():
         nonlocal out, offs, dec
@@ -213,8 +214,17 @@ def main():
             # frames is what STREAMINFO tells a decoder: total samples / block size)
             dec, status, dst = ctx.decode_stream(out[:est.total_bytes], ch, bps, nsamp, nframes=est.nblocks, out=dec)
         else:
-            # many streams back to back: every stream restarts its frame numbers, so the index is the encoder's (in HBM)
-            dec, status, dst = ctx.decode(out, offs, ch, bps, nsamp, out=dec)
+            # many streams back to back, every stream numbering its frames from 0: decoded from the bytes alone as well -- one
+            # pass over all bytes files every stream's frames under its own numbers (flacgpu_decode_streams_dev).  What is passed
+            # beside the bytes is what the STREAMINFO blocks hold: the frame count of every stream, and where its bytes end
+            if ranges[0] is None:
+                h = offs.cpu().numpy().astype(np.int64)      # (once, outside the timed region: the streams' byte lengths)
+                ranges[0], fi = [], 0
+                for n in lengths:
+                    nfr = -(-n // bs)
+                    ranges[0].append((int(h[fi + nfr] - h[fi]), nfr))
+                    fi += nfr
+            dec, status, dst = ctx.decode_streams(out[:est.total_bytes], ranges[0], ch, bps, nsamp, out=dec)
         return est, dst, status
 
     for _ in range(args.warmup):
@@ -302,7 +312,7 @@ def main():
                                      'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)'}[args.workload],
                                     'single-stream' if single else '%d independent streams in one launch,' % len(lengths),
                                     ' alone (frame index rebuilt on the GPU inside the timed region)' if single else
-                                    ' (frame index: the encoder\'s offsets, device-resident)',
+                                    ' alone (every stream\'s frame index rebuilt on the GPU inside the timed region, one pass over all bytes)',
                                     bps, sr // 1000, args.level, args.seconds, '' if single else ' each', est.nblocks),
                        'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4),
                        'timed_s': round(dt, 3)},
@@ -325,8 +335,8 @@ def main():
                          'achieved': round(enc_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(enc_ach / 8000.0, 5),
                          'traffic': pmc.get('encode_traffic_bytes_per_launch') if same else None,
                          'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(enc_t, 4)},
-            'roofline_decode': {'bound': 'hbm', 'kernel': 'decode (fg_dec_index / headers / scan / fg_dec_fused_kernel + crc / fix; dominant: '
-                                                          'fg_dec_fused_kernel)',
+            'roofline_decode': {'bound': 'hbm', 'kernel': 'decode (fg_dec_index / headers / scan / fg_dec_wparse_kernel + crc / fg_dec_wrestore_kernel; '
+                                                          'dominant: fg_dec_wparse_kernel)',
                                 'achieved': round(dec_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(dec_ach / 8000.0, 5),
                                 'traffic': pmc.get('decode_traffic_bytes_per_launch') if same else None,
                                 'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(dec_t, 4)},

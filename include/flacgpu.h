@@ -594,11 +594,27 @@ int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t l
  * as above and their CRC-16 checked.  d_stream/len: the audio frames of ONE fixed-block-size stream (what follows the
  * metadata blocks).  nframes_hint: the number of frames when known (STREAMINFO: ceil(total_samples / blocksize)), 0 to have
  * them counted (one more pass and a host round trip).  first_frame_number: number of the first frame (0 for a whole
- * stream).  d_frame_offsets_out (optional, device, nframes+1 uint64) receives the index.  Streams this does not cover
+ * stream).  h_frame_status (optional) receives at most status_capacity rows of {status, crc} -- stats->nframes tells how
+ * many frames were found.  d_frame_offsets_out (optional, device, nframes+1 uint64) receives the index.  Streams this does not cover
  * (variable block size, two headers claiming one frame number) fail with a message; flacgpu_index_frames handles them. */
 int flacgpu_decode_stream_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, uint32_t nframes_hint, uint64_t first_frame_number,
                               uint32_t channels, uint32_t bits_per_sample, void *d_pcm, uint64_t pcm_capacity_samples,
-                              void *h_frame_status, void *d_frame_offsets_out, flacgpu_decode_stats *stats);
+                              void *h_frame_status, uint64_t status_capacity, void *d_frame_offsets_out, flacgpu_decode_stats *stats);
+
+/* The same for several streams laid back to back in one device buffer (BASELINE config 5: a batch of independent streams,
+ * SURVEY.md section 8e): one pass over all bytes finds every stream's frames, every stream numbers its frames from its own
+ * first_frame_number, and the PCM of the streams comes out back to back in stream order.  The ranges must cover the buffer
+ * without gaps, in order; nframes of every stream is required (STREAMINFO).  h_frame_status (optional) receives at most
+ * status_capacity rows of {status, crc}; stats->nframes tells how many there are. */
+typedef struct {
+    uint64_t byte_offset, byte_length;     /* the audio frames of the stream inside the buffer */
+    uint64_t first_frame_number;
+    uint32_t nframes;
+    uint32_t reserved;
+} flacgpu_stream_range;
+int flacgpu_decode_streams_dev(flacgpu_ctx *ctx, const void *d_bytes, uint64_t len, const flacgpu_stream_range *ranges, uint32_t nranges,
+                               uint32_t channels, uint32_t bits_per_sample, void *d_pcm, uint64_t pcm_capacity_samples,
+                               void *h_frame_status, uint64_t status_capacity, void *d_frame_offsets_out, flacgpu_decode_stats *stats);
 
 /* How much of FLAC__Frame.subframes[] the decoder's write callback sees (format.h:285-396).  0: nothing, 1 (default): type,
  * wasted bits, order, precision, shift, coefficients, warm-up samples, partition order, Rice parameters (the pointers stay

@@ -63,6 +63,11 @@ class EncodeStats(C.Structure):
                 ('log_guard_subframes', C.c_uint32), ('reserved0', C.c_uint32), ('lpc_order_min_margin', C.c_double)]
 
 
+class StreamRange(C.Structure):
+    _fields_ = [('byte_offset', C.c_uint64), ('byte_length', C.c_uint64), ('first_frame_number', C.c_uint64),
+                ('nframes', C.c_uint32), ('reserved', C.c_uint32)]
+
+
 class DecodeStats(C.Structure):
     _fields_ = [('nframes', C.c_uint32), ('error_frames', C.c_uint32), ('total_samples', C.c_uint64),
                 ('channels', C.c_uint32), ('bits_per_sample', C.c_uint32), ('sample_rate', C.c_uint32),
@@ -108,7 +113,7 @@ DATA_SYMBOLS = ['FLAC__StreamEncoderStateString', 'FLAC__StreamEncoderInitStatus
 EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu_ctx_create', 'flacgpu_ctx_destroy',
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
-                 'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev',
+                 'flacgpu_index_frames', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
                  'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_stream_decoder_set_subframe_detail']
 
 _lib = None
@@ -188,9 +193,12 @@ def lib():
     L.flacgpu_decode_frames.restype = C.c_int
     L.flacgpu_decode_frames_dev.argtypes = L.flacgpu_decode_frames.argtypes
     L.flacgpu_decode_frames_dev.restype = C.c_int
-    L.flacgpu_decode_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp,
-                                            C.POINTER(DecodeStats)]
+    L.flacgpu_decode_stream_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp,
+                                            C.c_uint64, vp, C.POINTER(DecodeStats)]
     L.flacgpu_decode_stream_dev.restype = C.c_int
+    L.flacgpu_decode_streams_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(StreamRange), C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64,
+                                             vp, C.c_uint64, vp, C.POINTER(DecodeStats)]
+    L.flacgpu_decode_streams_dev.restype = C.c_int
     L.flacgpu_set_stage_timing.argtypes = [vp, C.c_int]
     L.flacgpu_set_log_guard.argtypes = [vp, C.c_double]
     L.flacgpu_set_log_guard.restype = None

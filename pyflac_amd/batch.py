@@ -143,12 +143,49 @@ class Context:
         torch.cuda.current_stream(stream.device).synchronize()      # the library works on its own HIP streams
         if out is None or out.numel() < max_samples * channels:
             out = torch.empty((max(int(max_samples), 1), channels), dtype=torch.int32, device=stream.device)
+        # the status rows: one per frame when the count is known; otherwise whatever fits -- the library never writes more
+        # rows than it is told there is room for, and says how many frames it found (a second call fetches the rest)
         cap = int(nframes) if nframes else max(stream.numel() // 16 + 16, 64)
         status = np.zeros((max(cap, 1), 2), np.uint32)
         st = _lib.DecodeStats()
         rc = L.flacgpu_decode_stream_dev(self._h, stream.data_ptr(), stream.numel(), int(nframes), int(first_frame_number), channels,
-                                         bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data,
+                                         bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, status.shape[0],
                                          offsets_out.data_ptr() if offsets_out is not None else None, C.byref(st))
+        if rc != 0:
+            raise FlacGpuError(_lib.last_error())
+        if st.nframes > status.shape[0]:
+            # (tiny frames: more of them than the guess) -- decode again with the count now known
+            return self.decode_stream(stream, channels, bits_per_sample, max_samples, nframes=st.nframes,
+                                      first_frame_number=first_frame_number, out=out, offsets_out=offsets_out)
+        return out[:st.total_samples], status[:st.nframes], st
+
+    def decode_streams(self, data, ranges, channels, bits_per_sample, max_samples, out=None, offsets_out=None):
+        """Decode several fixed-block-size streams laid back to back in the device uint8 tensor ``data`` from their bytes alone,
+        in one launch.  ``ranges``: one ``(byte_length, nframes)`` or ``(byte_length, nframes, first_frame_number)`` per stream,
+        in order.  The PCM of the streams comes out back to back.
+
+        Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
+        """
+        L = _lib.lib()
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        torch.cuda.current_stream(data.device).synchronize()
+        if out is None or out.numel() < max_samples * channels:
+            out = torch.empty((max(int(max_samples), 1), channels), dtype=torch.int32, device=data.device)
+        rg = (_lib.StreamRange * len(ranges))()
+        pos = total = 0
+        for i, r in enumerate(ranges):
+            rg[i].byte_offset = pos
+            rg[i].byte_length = int(r[0])
+            rg[i].nframes = int(r[1])
+            rg[i].first_frame_number = int(r[2]) if len(r) > 2 else 0
+            pos += int(r[0])
+            total += int(r[1])
+        assert pos == data.numel()
+        status = np.zeros((max(total, 1), 2), np.uint32)
+        st = _lib.DecodeStats()
+        rc = L.flacgpu_decode_streams_dev(self._h, data.data_ptr(), data.numel(), rg, len(ranges), channels, bits_per_sample,
+                                          out.data_ptr(), max_samples, status.ctypes.data, status.shape[0],
+                                          offsets_out.data_ptr() if offsets_out is not None else None, C.byref(st))
         if rc != 0:
             raise FlacGpuError(_lib.last_error())
         return out[:st.total_samples], status[:st.nframes], st
@@ -197,12 +234,38 @@ class MultiContext:
             return run
         return shard.encode_sharded(list(streams), [make(c, d) for c, d in zip(self.contexts, self.devices)])
 
+    def decode_streams(self, streams, channels, bits_per_sample, blocksize):
+        """``streams``: list (stream order) of ``(frames: bytes, nframes, nsamples)`` -- the audio frames of a fixed-block-size
+        stream, how many there are and how many samples they hold (STREAMINFO).  Stream s is decoded on device s mod ndevices, each
+        device decodes its share from the bytes alone in ONE launch.  Returns the PCM (host int32 arrays) in stream order."""
+        from . import shard
+
+        def make(ctx, dev):
+            def run(mine):
+                if not mine:
+                    return []
+                with torch.cuda.device(dev):
+                    blob = np.frombuffer(b''.join(m[0] for m in mine), np.uint8).copy()
+                    data = torch.from_numpy(blob).to('cuda:%d' % dev)
+                    total = sum(int(m[2]) for m in mine)
+                    pcm, status, st = ctx.decode_streams(data, [(len(m[0]), int(m[1])) for m in mine], channels, bits_per_sample, total)
+                    if st.error_frames:
+                        raise FlacGpuError('%d frames failed' % st.error_frames)
+                    host = pcm.cpu().numpy()
+                res, at = [], 0
+                for m in mine:
+                    res.append(host[at:at + int(m[2])])
+                    at += int(m[2])
+                return res
+            return run
+        return shard.run_sharded(list(streams), [make(c, d) for c, d in zip(self.contexts, self.devices)])
+
 
 def index_frames(data):
     """Host frame index of a complete FLAC stream (bytes).  Returns (offsets uint64[nframes+1], StreamInfo)."""
     L = _lib.lib()
     buf = np.frombuffer(data, np.uint8)
-    cap = max(len(data) // 16 + 16, 64)
+    cap = max(len(data) // 9 + 16, 64)          # (no frame is shorter than 9 bytes)
     offs = np.zeros(cap, np.uint64)
     si = _lib.StreamInfo()
     audio = C.c_uint64(0)

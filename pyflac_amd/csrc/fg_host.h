@@ -52,7 +52,7 @@ int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len
                           unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream);
 int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                         uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                        hipStream_t stream);
+                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream);
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
@@ -113,7 +113,7 @@ struct flacgpu_ctx {
     double log_guard_thr = 1e-6;
     std::mutex mu;
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, pipe;
+        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe;
     std::vector<unsigned char> desc_key;   // settings + stream list the block list in `dev_descs` was built for
     uint32_t desc_nfast = 0, desc_nws2 = 0;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`

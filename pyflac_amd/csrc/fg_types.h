@@ -126,6 +126,15 @@ struct FgDecFrame {
     uint32_t channels, ca, bps;
 };
 
+// One stream of a multi-stream decode call (flacgpu_decode_streams_dev): where its bytes start, how its frames are numbered and
+// where its frames go in the frame table.
+struct FgDecRange {
+    uint64_t byte_start;
+    uint64_t first_number;
+    uint32_t slot_base;
+    uint32_t nframes;
+};
+
 // Per-subframe predictor description handed from the parse kernel to the restore kernel.
 struct FgDecSub {
     uint32_t order;        // samples stored verbatim at the start of the subframe (0 for CONSTANT / VERBATIM)

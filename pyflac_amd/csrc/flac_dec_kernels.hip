@@ -488,7 +488,7 @@ __device__ __forceinline__ bool fg_idx_header(const Bytes &p, u64 avail, uint32_
 
 __global__ void __launch_bounds__(256)
 fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t bps, u64 first_number, uint32_t nframes, u64 *offsets,
-                    unsigned long long *info, u64 *alt)
+                    unsigned long long *info, u64 *alt, const FgDecRange *ranges, uint32_t nranges)
 {
     // groups of 16 bytes aligned in memory (one 16-byte load per lane and step); a wave walks the stream in steps of
     // gridDim.x * 4 KiB (launching one short-lived wave per KiB would be bound by the dispatch rate, not by HBM)
@@ -559,9 +559,27 @@ fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t 
         // sync code 0xFFF9 (variable block size: the number is a sample number) is not filed; a fixed-block-size stream
         // holds such byte sequences by chance, so they only count as evidence when nothing else is found
         if (variable) { atomicAdd(&info[2], 1ull); return; }
-        if (nframes == 0) atomicAdd(&info[0], 1ull);
-        if (nframes == 0 || number < first_number) return;
-        const u64 slot = number - first_number;
+        if (nframes == 0) {
+            // counting pass: the candidates, and the largest frame number that a stream of this length can hold (no frame is
+            // shorter than 9 bytes) -- the table is sized by the larger of the two
+            atomicAdd(&info[0], 1ull);
+            if (number >= first_number && number - first_number < len / 9 + 1) atomicMax(&info[4], (unsigned long long)(number - first_number + 1));
+            return;
+        }
+        u64 slot;
+        if (nranges) {
+            // several streams laid back to back: the stream this position lies in numbers its frames from its own first number
+            // and files them from its own slot on (binary search over the streams' first bytes; this path runs once per frame)
+            uint32_t lo = 0, hi = nranges - 1;
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (ranges[mid].byte_start <= pos) lo = mid; else hi = mid - 1; }
+            const FgDecRange rg = ranges[lo];
+            if (number < rg.first_number || number - rg.first_number >= rg.nframes) return;
+            slot = rg.slot_base + (number - rg.first_number);
+        }
+        else {
+            if (number < first_number) return;
+            slot = number - first_number;
+        }
         if (slot >= nframes) return;
         atomicMin((unsigned long long *)&offsets[slot], (unsigned long long)pos);
         atomicMax((unsigned long long *)&alt[slot], (unsigned long long)pos + 1);
@@ -882,7 +900,7 @@ extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned 
 
 extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                                    uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                                   hipStream_t stream)
+                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream)
 {
     if (len == 0) return 0;
     // (every lane takes four groups a step; at most 8 workgroups of 4 waves per CU -- every wave slot of the chip, once --
@@ -893,7 +911,7 @@ extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long l
     unsigned long long wgs = (need + steps - 1) / steps;
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(fg_dec_index_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_stream, (u64)len, channels, bps,
-                       (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt);
+                       (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt, d_ranges, nranges);
     if (nframes)
         hipLaunchKernelGGL(fg_dec_index_resolve_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (const u64 *)d_alt,
                            nframes, (u64)len, d_info);

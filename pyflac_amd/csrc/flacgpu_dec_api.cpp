@@ -360,7 +360,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
                                FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
                                bool offsets_on_device = false, uint64_t first_number = 0, uint64_t *d_offsets_out = nullptr,
-                               DecDetail *detail = nullptr)
+                               DecDetail *detail = nullptr, uint64_t status_capacity = ~0ull, const FgDecRange *h_ranges = nullptr,
+                               uint32_t nranges = 0)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     memset(st, 0, sizeof *st);
@@ -373,20 +374,23 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
         if (nframes == 0) {
             // count the candidates (an upper bound of the frames; false candidates are a handful), then see which slots fill
-            if (!HIPOK(hipMemsetAsync(d_info, 0, 32, c->stream)) ||
-                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, c->stream) != 0 ||
-                !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+            if (!HIPOK(hipMemsetAsync(d_info, 0, 64, c->stream)) ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, nullptr, 0, c->stream) != 0 ||
+                !HIPOK(hipMemcpyAsync(hinfo, d_info, 64, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
             if (hinfo[0] == 0 && hinfo[2]) { fg_set_error("variable block size stream: use flacgpu_index_frames"); return false; }
-            if (hinfo[0] > 0x7FFFFFFFull) { fg_set_error("too many frames"); return false; }
-            const uint32_t bound = (uint32_t)hinfo[0];
+            // the table holds every frame number seen: a stream with a damaged header has one candidate less than frames, and its
+            // last frame must not fall off the table (hinfo[4] = the largest plausible number + 1)
+            const unsigned long long want = hinfo[0] > hinfo[4] ? hinfo[0] : hinfo[4];
+            if (want > 0x7FFFFFFFull) { fg_set_error("too many frames"); return false; }
+            const uint32_t bound = (uint32_t)want;
             if (bound == 0) { st->nframes = 0; return true; }
             if (!c->offsets.ensure(((size_t)bound + 4) * 8)) return false;
             if (!c->dec_info.ensure(64 + (size_t)bound * 12 + 16)) return false;       // counters, second claims, claim counts
             d_info = (unsigned long long *)c->dec_info.p;
             if (fg_launch_dec_index_init((unsigned long long *)c->offsets.p, d_info + 8, d_info, bound, nullptr, c->stream) != 0 ||
-                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, c->stream) != 0 ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, nullptr, 0, c->stream) != 0 ||
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
@@ -415,8 +419,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
         if (!c->dec_info.ensure(64 + (size_t)nframes * 12 + 16)) return false;      // counters, second claims, claim counts
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
+        const FgDecRange *d_ranges = nullptr;
+        if (nranges) {
+            // several streams in one buffer: every stream files its frames from its own slot on
+            if (!c->dec_ranges.ensure((size_t)nranges * sizeof(FgDecRange)) ||
+                !HIPOK(hipMemcpyAsync(c->dec_ranges.p, h_ranges, (size_t)nranges * sizeof(FgDecRange), hipMemcpyHostToDevice, c->stream))) return false;
+            d_ranges = (const FgDecRange *)c->dec_ranges.p;
+        }
         if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, lean ? (unsigned long long *)c->stamp.p : nullptr, c->stream) != 0 ||
-            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, c->stream) != 0) {
+            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, d_ranges, nranges, c->stream) != 0) {
             fg_set_error("frame index kernel launch failed"); return false;
         }
         // (the end of the last frame, offsets[nframes] = len, is set by the index kernel)
@@ -598,7 +609,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         fg_set_error("variable block size stream: use flacgpu_index_frames"); return false;
     }
     st->channels = C; st->bits_per_sample = bps_hint;
-    if (h_status) memcpy(h_status, res, (size_t)nframes * sizeof(FgDecResult));
+    if (h_status) memcpy(h_status, res, (size_t)std::min<uint64_t>(nframes, status_capacity) * sizeof(FgDecResult));
     return true;
 }
 
@@ -615,14 +626,41 @@ extern "C" int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream,
 
 extern "C" int flacgpu_decode_stream_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, uint32_t nframes_hint, uint64_t first_frame_number,
                                          uint32_t channels, uint32_t bps, void *d_pcm, uint64_t pcm_capacity_samples, void *h_frame_status,
-                                         void *d_frame_offsets_out, flacgpu_decode_stats *stats)
+                                         uint64_t status_capacity, void *d_frame_offsets_out, flacgpu_decode_stats *stats)
 {
     flacgpu_decode_stats local;
     if (!stats) stats = &local;
     if (!ctx) { fg_set_error("null context"); return -1; }
     if (channels == 0) { fg_set_error("channel count required"); return -1; }
     return decode_frames_impl(ctx, d_stream, len, nullptr, nframes_hint, channels, bps, d_pcm, pcm_capacity_samples, 1,
-                              (FgDecResult *)h_frame_status, nullptr, stats, true, first_frame_number, (uint64_t *)d_frame_offsets_out) ? 0 : -1;
+                              (FgDecResult *)h_frame_status, nullptr, stats, true, first_frame_number, (uint64_t *)d_frame_offsets_out,
+                              nullptr, status_capacity) ? 0 : -1;
+}
+
+// Several fixed-block-size streams laid back to back in one device buffer, decoded from their bytes alone in one launch (the
+// decode side of BASELINE config 5: the frame index of every stream is made on the GPU).
+extern "C" int flacgpu_decode_streams_dev(flacgpu_ctx *ctx, const void *d_bytes, uint64_t len, const flacgpu_stream_range *ranges, uint32_t nranges,
+                                          uint32_t channels, uint32_t bps, void *d_pcm, uint64_t pcm_capacity_samples, void *h_frame_status,
+                                          uint64_t status_capacity, void *d_frame_offsets_out, flacgpu_decode_stats *stats)
+{
+    flacgpu_decode_stats local;
+    if (!stats) stats = &local;
+    if (!ctx) { fg_set_error("null context"); return -1; }
+    if (channels == 0) { fg_set_error("channel count required"); return -1; }
+    if (!ranges || nranges == 0) { fg_set_error("no streams"); return -1; }
+    std::vector<FgDecRange> rg(nranges);
+    uint64_t at = 0, frames = 0;
+    for (uint32_t i = 0; i < nranges; i++) {
+        if (ranges[i].byte_offset != at) { fg_set_error("the streams must lie back to back from the start of the buffer"); return -1; }
+        if (ranges[i].nframes == 0) { fg_set_error("frame count of every stream required (STREAMINFO: total samples / block size)"); return -1; }
+        rg[i].byte_start = at; rg[i].first_number = ranges[i].first_frame_number; rg[i].slot_base = (uint32_t)frames; rg[i].nframes = ranges[i].nframes;
+        at += ranges[i].byte_length; frames += ranges[i].nframes;
+        if (frames > 0x7FFFFFFFull) { fg_set_error("too many frames"); return -1; }
+    }
+    if (at != len) { fg_set_error("the streams must cover the whole buffer"); return -1; }
+    return decode_frames_impl(ctx, d_bytes, len, nullptr, (uint32_t)frames, channels, bps, d_pcm, pcm_capacity_samples, 1,
+                              (FgDecResult *)h_frame_status, nullptr, stats, true, 0, (uint64_t *)d_frame_offsets_out, nullptr,
+                              status_capacity, rg.data(), nranges) ? 0 : -1;
 }
 
 extern "C" int flacgpu_decode_frames(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *h_frame_offsets,

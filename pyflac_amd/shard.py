@@ -58,6 +58,12 @@ def assemble_in_stream_order(nstreams, world, per_rank_results):
     return out
 
 
+def run_sharded(streams, workers):
+    """`encode_sharded` under the name the decode side uses: the same round-robin mapping and stream-order reassembly, whatever
+    the per-device workers do with their share."""
+    return encode_sharded(streams, workers)
+
+
 def encode_sharded(streams, encoders):
     """Encode `streams` (a list of per-stream inputs) on `len(encoders)` devices of this process: stream s goes to device
     s mod world; encoders[r](list_of_streams) -> list of per-stream outputs, called concurrently (one thread per device; the

@@ -33,7 +33,14 @@ def _worker(rank, world, port, q):
     gathered = [None] * world
     dist.all_gather_object(gathered, stub)
     ordered = shard.assemble_in_stream_order(nstreams, world, gathered)
-    q.put((rank, got, mine[:3], len(mine), rng, (mn, mx, cnt), ordered))
+    # the decode side of the same mapping: every rank "decodes" the frames of ITS streams (stub: the stream's name reversed), the
+    # PCM is gathered and lands in stream order -- what MultiContext.decode_streams / bench.py --workload batch do per device
+    frames = ['frames-of-stream%d' % sidx for sidx in range(nstreams)]
+    dec = [frames[sidx][::-1] for sidx in shard.streams_for_rank(nstreams, rank, world)]
+    gathered2 = [None] * world
+    dist.all_gather_object(gathered2, dec)
+    ordered2 = shard.assemble_in_stream_order(nstreams, world, gathered2)
+    q.put((rank, got, mine[:3], len(mine), rng, (mn, mx, cnt), ordered, ordered2))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +63,8 @@ def test_world2_sharding_and_header_broadcast():
     assert res[0][5] == res[1][5] == (100, 201, 4)
     want = ['rank%d:stream%d' % (sidx % 2, sidx) for sidx in range(11)]
     assert res[0][6] == want and res[1][6] == want
+    want2 = [('frames-of-stream%d' % sidx)[::-1] for sidx in range(11)]
+    assert res[0][7] == want2 and res[1][7] == want2
 
 
 def test_partitions_cover_everything():

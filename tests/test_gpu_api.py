@@ -556,6 +556,11 @@ def test_multi_context_returns_streams_in_order():
         out, offs, st = one.encode(s, torch.from_numpy(x).cuda())
         assert frames == out[:st.total_bytes].cpu().numpy().tobytes()
         assert sizes == [int(v) for v in np.diff(offs.cpu().numpy())]
+    # ... and back: every device decodes its share from the bytes alone in one launch, the PCM returns in stream order
+    pcm = mc.decode_streams([(frames, len(sizes), len(x)) for x, (frames, sizes) in zip(streams, got)], 2, 16, 4096)
+    assert len(pcm) == len(streams)
+    for x, y in zip(streams, pcm):
+        assert np.array_equal(y, x.astype(np.int32))
     mc.close()
 
 

@@ -326,3 +326,58 @@ def test_codes_of_hundreds_of_bytes_leave_the_fast_decoder(ctx):
     dec, status, st = ctx.decode(body, o, c['ch'], c['bps'], len(a32))
     assert status[:, 0].tolist() == [0] * (len(o) - 1)
     assert torch.equal(dec.reshape(-1, c['ch'])[:len(a32)].cpu(), torch.from_numpy(a32))
+
+
+def test_many_streams_decode_from_bytes_alone(ctx):
+    """flacgpu_decode_streams_dev (config 5, decode side): several streams laid back to back, every stream numbering its frames
+    from 0, are indexed and decoded from their bytes alone in one launch; the index equals the encoder's offsets."""
+    import torch
+    from pyflac_amd import batch, synth
+    streams = [synth.config5_stream(s, 0.3 + 0.11 * s) for s in range(7)]          # ragged lengths: every stream ends in a tail block
+    s = batch.settings(5, 2, 16, 48000, 4096, True)
+    t = torch.from_numpy(np.concatenate(streams).astype(np.int32)).cuda()
+    out, offs, st = ctx.encode(s, t, stream_lengths=[len(x) for x in streams])
+    h_offs = offs.cpu().numpy().astype(np.int64)
+    ranges, fi = [], 0
+    for x in streams:
+        nfr = -(-len(x) // 4096)
+        ranges.append((int(h_offs[fi + nfr] - h_offs[fi]), nfr))
+        fi += nfr
+    goffs = torch.zeros(fi + 1, dtype=torch.int64, device='cuda')
+    dec, status, dst = ctx.decode_streams(out[:st.total_bytes], ranges, 2, 16, t.shape[0], offsets_out=goffs)
+    assert dst.nframes == fi and int(status[:, 0].max()) == 0
+    assert np.array_equal(goffs.cpu().numpy(), h_offs[:fi + 1])
+    assert torch.equal(dec, t)
+    # a frame count that is wrong for one stream: its surplus frames are not found (status != 0), nothing is decoded out of place
+    bad = list(ranges)
+    bad[2] = (bad[2][0], bad[2][1] + 1)
+    dec2, status2, dst2 = ctx.decode_streams(out[:st.total_bytes], bad, 2, 16, t.shape[0] + 4096)
+    assert dst2.nframes == fi + 1 and dst2.error_frames >= 1
+
+
+def test_count_mode_with_frames_shorter_than_any_guess(ctx):
+    """Block size 16, mono, silence: frames of 11 or 12 bytes.  With the frame count unknown the status rows are sized by a
+    guess; the library writes no more rows than it is told there is room for and reports the count."""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    cfg, _ = O.config(5, 1, 16, 44100, 16, False)
+    pcm = np.zeros((16 * 400, 1), np.int16)      # (400 frames: a workgroup of the index kernel parks 512 candidates at most)
+    data, sizes = O.encode_stream(cfg, pcm)
+    assert max(sizes) <= 13                   # (below the 16 bytes the old guess assumed)
+    offs, si = batch.index_frames(data)
+    audio = data[int(offs[0]):]
+    buf = torch.frombuffer(bytearray(audio) + bytearray(64), dtype=torch.uint8).cuda()[:len(audio)]
+    dec, status, st = ctx.decode_stream(buf, 1, 16, len(pcm), nframes=0)
+    assert st.nframes == 400 and status.shape[0] == 400 and int(status[:, 0].max()) == 0
+    assert np.array_equal(dec.cpu().numpy(), pcm.astype(np.int32))
+    # the raw call with room for three rows: three rows are written, the count is reported
+    from pyflac_amd import _lib
+    import ctypes as C
+    rows = np.full((8, 2), 0xAAAAAAAA, np.uint32)
+    st2 = _lib.DecodeStats()
+    out = torch.empty((len(pcm), 1), dtype=torch.int32, device='cuda')
+    rc = _lib.lib().flacgpu_decode_stream_dev(ctx._h, buf.data_ptr(), buf.numel(), 0, 0, 1, 16, out.data_ptr(), len(pcm), rows.ctypes.data, 3,
+                                              None, C.byref(st2))
+    assert rc == 0 and st2.nframes == 400
+    assert (rows[:3, 0] == 0).all() and (rows[3:] == 0xAAAAAAAA).all()
