@@ -218,8 +218,11 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void);
 void FLAC__stream_encoder_delete(FLAC__StreamEncoder *encoder);
 
 /* Not part of pyFLAC's cdef (pyflac/builder/encoder.py:266-322) but of libFLAC's encoder interface (stream_encoder.h:1214): the
- * metadata blocks written behind STREAMINFO.  PADDING, APPLICATION, SEEKTABLE (verbatim), VORBIS_COMMENT (moved to the front,
- * vendor string replaced by libFLAC's), CUESHEET, PICTURE and unknown types. */
+ * metadata blocks written behind STREAMINFO, in the order given (native FLAC keeps the caller's order; only Ogg FLAC moves the
+ * VORBIS_COMMENT to the front).  PADDING, APPLICATION, SEEKTABLE (verbatim), VORBIS_COMMENT (takes the place of the default one,
+ * vendor string replaced by libFLAC's), CUESHEET, PICTURE and unknown types.  Lists libFLAC refuses at init -- a STREAMINFO
+ * block, two SEEKTABLEs or VORBIS_COMMENTs, an unsorted SEEKTABLE, a CUESHEET or PICTURE that fails
+ * FLAC__format_cuesheet_is_legal / FLAC__format_picture_is_legal -- give FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA. */
 FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *encoder, FLAC__StreamMetadata **metadata, uint32_t num_blocks);
 FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_set_channels(FLAC__StreamEncoder *encoder, uint32_t value);
@@ -619,7 +622,8 @@ int flacgpu_decode_streams_dev(flacgpu_ctx *ctx, const void *d_bytes, uint64_t l
 /* How much of FLAC__Frame.subframes[] the decoder's write callback sees (format.h:285-396).  0: nothing, 1 (default): type,
  * wasted bits, order, precision, shift, coefficients, warm-up samples, partition order, Rice parameters (the pointers stay
  * valid until the next frame is delivered), 2: also the `residual` / verbatim `data` arrays (costs one more copy of the size
- * of the PCM from the device).  Frames the generic decode kernel handles (predictor order > 12, 33-bit side channels) carry
+ * of the PCM from the device).  Frames the generic decode kernel handles (predictor order > 12, 33-bit side channels) and
+ * subframes with a residual partition order above 8 (non-subset streams; the Rice parameters of 256 partitions are kept) carry
  * no subframe details. */
 void flacgpu_stream_decoder_set_subframe_detail(FLAC__StreamDecoder *decoder, int level);
 

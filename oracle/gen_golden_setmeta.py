@@ -44,3 +44,9 @@ if __name__ == '__main__':
         json.dump(res, f, indent=1)
     for k, v in res.items():
         print('%-24s set %d init %2d  %d writes, %d bytes' % (k, v['set_ok'], v['init_status'], len(v['writes']), sum(len(w) // 2 for w in v['writes'])))
+    # CUESHEET / PICTURE legality: the init status only
+    leg = {name: run(R.lib(), blocks)['init_status'] for name, blocks in MB.legality_cases().items()}
+    with open(os.path.join(ROOT, 'tests', 'golden', 'legality_vectors.json'), 'w') as f:
+        json.dump(leg, f, indent=1)
+    for k, v in leg.items():
+        print('%-36s init %2d' % (k, v))

@@ -697,3 +697,22 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
     if (!c) { fg_set_error("null context"); return -1; }
     return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, kernel): one process may drive several devices
+// (batch.MultiContext: one thread per device), so what has been configured is kept per device, behind a mutex.
+#include <map>
+extern "C" int fg_func_set_lds(const void *fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &cur = done[std::make_pair(dev, fn)];
+    if (bytes > cur) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        cur = bytes;
+    }
+    return 0;
+}

@@ -35,6 +35,8 @@ using namespace fgdev;
 
 #define FG_LDSP __attribute__((address_space(3)))
 
+extern "C" int fg_func_set_lds(const void *fn, size_t bytes);   // fg_ctx.cpp: per device, thread-safe
+
 namespace {
 
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
@@ -1631,14 +1633,10 @@ extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_l
     if (G > FG_FUSED_GMAX) G = FG_FUSED_GMAX;
     const size_t lds = ((size_t)G * (FG_RSTR + 2 * FG_TSTR) + 2 * 64 * FG_META + 8 + (size_t)FG_RT * (G + 1) * FG_TSTR + FG_RT * 64 +
                         4 * (size_t)G * FG_SUBP + (size_t)G * FG_FRM + 192) * 4;
-    static size_t configured[4] = {0, 0, 0, 0};
     const int which = (wide ? 1 : 0) + (G > 32 ? 2 : 0);
     const void *fn = which == 0 ? (const void *)fg_dec_fused_kernel<false, 2> : which == 1 ? (const void *)fg_dec_fused_kernel<true, 2>
                    : which == 2 ? (const void *)fg_dec_fused_kernel<false, 3> : (const void *)fg_dec_fused_kernel<true, 3>;
-    if (lds > configured[which]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        configured[which] = lds;
-    }
+    if (fg_func_set_lds(fn, lds) != 0) return -1;
     if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 = no output wave, 2 = no recurrence
     const dim3 grid((nframes + G - 1) / G);
 #define FG_FUSED_LAUNCH(W, N) hipLaunchKernelGGL((fg_dec_fused_kernel<W, N>), grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, \

@@ -43,6 +43,8 @@ using namespace fgdev;
 #define FG_DMAXO 12
 #define FG_DEC_RPARAMS 256
 
+extern "C" int fg_func_set_lds(const void *fn, size_t bytes);   // fg_ctx.cpp: per device, thread-safe
+
 namespace {
 
 // Where the bits of one frame live: big-endian 32-bit words from the aligned word that holds the frame's first byte.
@@ -906,12 +908,8 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     const uint32_t G = 64 / C;
     const dim3 grid((nframes + G - 1) / G);
     const size_t lds = ((size_t)WR_NB * WR_TILE_W + 64 * WR_FA + 8) * 4;
-    static bool configured[2] = {false, false};
     const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true> : (const void *)fg_dec_wrestore_kernel<false>;
-    if (!configured[wide ? 1 : 0]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-        configured[wide ? 1 : 0] = true;
-    }
+    if (fg_func_set_lds(fn, lds) != 0) return -1;
     if (wide) hipLaunchKernelGGL(fg_dec_wrestore_kernel<true>, grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
     else hipLaunchKernelGGL(fg_dec_wrestore_kernel<false>, grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
     return (int)hipGetLastError();

@@ -1433,6 +1433,7 @@ fg_export_kernel(const uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64
 }  // namespace
 
 // ------------------------------------------------------------------ host-callable launchers (C ABI, used by flacgpu_api.cpp)
+extern "C" int fg_func_set_lds(const void *fn, size_t bytes);   // fg_ctx.cpp: per device, thread-safe
 extern "C" {
 
 size_t fg_enc_lds_bytes(const FgEncParams *P)
@@ -1493,12 +1494,7 @@ int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float 
 {
     if (nblocks == 0) return 0;
     const size_t lds = fg_enc_lds_bytes(P);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)fg_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = lds;
-    }
+    { const int e = fg_func_set_lds((const void *)fg_encode_kernel, lds); if (e != 0) return e; }
     hipLaunchKernelGGL(fg_encode_kernel, dim3(nblocks), dim3(64), lds, stream, d_pcm, d_descs, d_windows, *P, d_slots,
                        d_results, d_dbg, d_crctab);
     return (int)hipGetLastError();

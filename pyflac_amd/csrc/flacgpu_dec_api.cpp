@@ -1185,6 +1185,9 @@ void fill_subframes(DecImpl *d, FLAC__Frame &f, const FgDecFrame &fr, uint32_t f
         FLAC__Subframe &sf = f.subframes[ch];
         if (!(sd.flags & (1u << 12))) continue;                 // a frame of the generic decoder: no record
         const uint32_t type = sd.flags & 3, prec = (sd.flags >> 2) & 31, po = (sd.flags >> 7) & 15, method = (sd.flags >> 11) & 1;
+        // (Rice parameters are kept for the first 256 partitions: a non-subset stream with a partition order above 8 gets no
+        // subframe details rather than details that end in zeros -- include/flacgpu.h says so)
+        if (type >= 2 && po > 8) continue;
         const int32_t *plane = d->detail.planes.empty() ? nullptr : d->detail.planes.data() + (size_t)fr.out_off * C + (size_t)ch * fr.n;
         const int32_t *warm = d->detail.warm.data() + ((size_t)fi * C + ch) * 32;
         sf.wasted_bits = sd.wasted;

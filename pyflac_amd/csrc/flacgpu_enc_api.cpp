@@ -339,6 +339,64 @@ static bool serialise_metadata(const FLAC__StreamMetadata *m, bool is_last, std:
 
 // What init checks about the supplied blocks (stream_encoder.c init_stream_internal_): no STREAMINFO, at most one SEEKTABLE
 // and one VORBIS_COMMENT, a legal seek table (ascending sample numbers, placeholders last)
+// FLAC__format_cuesheet_is_legal / FLAC__format_picture_is_legal as libFLAC's encoder applies them at init (a CUESHEET is
+// checked against the CD-DA subset when it says is_cd); pinned by tests/golden/legality_vectors.json, recorded from the
+// reference binary.
+static uint32_t utf8_len(const uint8_t *u)
+{
+    if ((u[0] & 0x80) == 0) return 1;
+    if ((u[0] & 0xE0) == 0xC0 && (u[1] & 0xC0) == 0x80) return (u[0] & 0xFE) == 0xC0 ? 0 : 2;               // (overlong)
+    if ((u[0] & 0xF0) == 0xE0 && (u[1] & 0xC0) == 0x80 && (u[2] & 0xC0) == 0x80) {
+        if (u[0] == 0xE0 && (u[1] & 0xE0) == 0x80) return 0;                                                   // overlong
+        if (u[0] == 0xED && (u[1] & 0xE0) == 0xA0) return 0;                                                   // U+D800 .. U+DFFF
+        if (u[0] == 0xEF && u[1] == 0xBF && (u[2] & 0xFE) == 0xBE) return 0;                                   // U+FFFE, U+FFFF
+        return 3;
+    }
+    if ((u[0] & 0xF8) == 0xF0 && (u[1] & 0xC0) == 0x80 && (u[2] & 0xC0) == 0x80 && (u[3] & 0xC0) == 0x80)
+        return (u[0] == 0xF0 && (u[1] & 0xF0) == 0x80) ? 0 : 4;
+    if ((u[0] & 0xFC) == 0xF8 && (u[1] & 0xC0) == 0x80 && (u[2] & 0xC0) == 0x80 && (u[3] & 0xC0) == 0x80 && (u[4] & 0xC0) == 0x80)
+        return (u[0] == 0xF8 && (u[1] & 0xF8) == 0x80) ? 0 : 5;
+    if ((u[0] & 0xFE) == 0xFC && (u[1] & 0xC0) == 0x80 && (u[2] & 0xC0) == 0x80 && (u[3] & 0xC0) == 0x80 && (u[4] & 0xC0) == 0x80 &&
+        (u[5] & 0xC0) == 0x80)
+        return (u[0] == 0xFC && (u[1] & 0xFC) == 0x80) ? 0 : 6;
+    return 0;
+}
+
+static bool picture_is_legal(const FLAC__StreamMetadata_Picture &p)
+{
+    if (!p.mime_type || !p.description) return false;
+    for (const char *c = p.mime_type; *c; c++) if ((uint8_t)*c < 0x20 || (uint8_t)*c > 0x7E) return false;
+    for (const uint8_t *b = p.description; *b;) {
+        const uint32_t n = utf8_len(b);
+        if (n == 0) return false;
+        b += n;
+    }
+    return true;
+}
+
+static bool cuesheet_is_legal(const FLAC__StreamMetadata_CueSheet &cs)
+{
+    const bool cd = cs.is_cd != 0;
+    if (cd && (cs.lead_in < 2 * 44100 || cs.lead_in % 588 != 0)) return false;
+    if (cs.num_tracks == 0) return false;                                   // (the lead-out is a track)
+    if (cd && cs.tracks[cs.num_tracks - 1].number != 170) return false;
+    for (uint32_t i = 0; i < cs.num_tracks; i++) {
+        const FLAC__StreamMetadata_CueSheet_Track &t = cs.tracks[i];
+        if (t.number == 0) return false;
+        if (cd && !((t.number >= 1 && t.number <= 99) || t.number == 170)) return false;
+        if (cd && t.offset % 588 != 0) return false;
+        if (i < cs.num_tracks - 1) {
+            if (t.num_indices == 0) return false;
+            if (t.indices[0].number > 1) return false;
+        }
+        for (uint32_t j = 0; j < t.num_indices; j++) {
+            if (cd && t.indices[j].offset % 588 != 0) return false;
+            if (j > 0 && t.indices[j].number != t.indices[j - 1].number + 1) return false;
+        }
+    }
+    return true;
+}
+
 static bool metadata_acceptable(const std::vector<FLAC__StreamMetadata *> &v)
 {
     bool seek = false, vc = false;
@@ -358,6 +416,8 @@ static bool metadata_acceptable(const std::vector<FLAC__StreamMetadata *> &v)
             }
         }
         if (m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT) { if (vc) return false; vc = true; }
+        if (m->type == FLAC__METADATA_TYPE_CUESHEET && !cuesheet_is_legal(m->data.cue_sheet)) return false;
+        if (m->type == FLAC__METADATA_TYPE_PICTURE && !picture_is_legal(m->data.picture)) return false;
     }
     return true;
 }

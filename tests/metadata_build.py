@@ -125,3 +125,32 @@ def cases():
         'two_vorbis_refused': [vorbis_comment(b'', []), vorbis_comment(b'', [b'A=b'])],
         'bad_seektable_refused': [seektable([(1000, 0, 0), (500, 0, 0)])],
     }
+
+
+# name -> list of blocks: CUESHEET / PICTURE blocks libFLAC's encoder refuses (format.c FLAC__format_cuesheet_is_legal /
+# FLAC__format_picture_is_legal) next to legal neighbours of each; only the init status is compared (tests/golden/legality_vectors.json)
+def legality_cases():
+    T = lambda off, num, idx: (off, num, b'', 0, 0, idx)      # noqa: E731
+    ok_tracks = [T(0, 1, [(0, 1)]), T(588 * 100, 170, [])]
+    return {
+        'cue_legal_cd': [cuesheet(b'', 88200, 1, ok_tracks)],
+        'cue_legal_not_cd': [cuesheet(b'', 0, 0, [T(0, 1, [(0, 0), (5, 1)]), T(1000, 255, [])])],
+        'cue_no_tracks': [cuesheet(b'', 88200, 1, [])],
+        'cue_cd_short_lead_in': [cuesheet(b'', 88199, 1, ok_tracks)],
+        'cue_cd_lead_in_not_cd_frames': [cuesheet(b'', 88200 + 1, 1, ok_tracks)],
+        'cue_cd_last_track_not_170': [cuesheet(b'', 88200, 1, [T(0, 1, [(0, 1)]), T(588 * 100, 2, [])])],
+        'cue_track_zero': [cuesheet(b'', 0, 0, [T(0, 0, [(0, 1)]), T(1000, 255, [])])],
+        'cue_cd_track_100': [cuesheet(b'', 88200, 1, [T(0, 100, [(0, 1)]), T(588 * 100, 170, [])])],
+        'cue_cd_offset_not_cd_frames': [cuesheet(b'', 88200, 1, [T(1, 1, [(0, 1)]), T(588 * 100, 170, [])])],
+        'cue_track_without_index': [cuesheet(b'', 0, 0, [T(0, 1, []), T(1000, 255, [])])],
+        'cue_first_index_2': [cuesheet(b'', 0, 0, [T(0, 1, [(0, 2)]), T(1000, 255, [])])],
+        'cue_cd_index_offset_not_cd_frames': [cuesheet(b'', 88200, 1, [T(0, 1, [(0, 1), (589, 2)]), T(588 * 100, 170, [])])],
+        'cue_index_numbers_skip': [cuesheet(b'', 0, 0, [T(0, 1, [(0, 1), (10, 3)]), T(1000, 255, [])])],
+        'cue_duplicate_track_numbers_ok': [cuesheet(b'', 0, 0, [T(0, 1, [(0, 1)]), T(10, 1, [(0, 1)]), T(1000, 255, [])])],
+        'pic_legal': [picture(3, b'image/png', b'plain', 1, 1, 24, 0, b'x')],
+        'pic_mime_control_char': [picture(3, b'image/\x01png', b'', 1, 1, 24, 0, b'x')],
+        'pic_mime_high_bit': [picture(3, b'image/p\xe9g', b'', 1, 1, 24, 0, b'x')],
+        'pic_description_bad_utf8': [picture(3, b'image/png', b'caf\xe9', 1, 1, 24, 0, b'x')],
+        'pic_description_overlong_utf8': [picture(3, b'image/png', b'\xc0\xaf', 1, 1, 24, 0, b'x')],
+        'pic_description_good_utf8': [picture(3, b'image/png', 'caf\u00e9 \u20ac'.encode('utf-8'), 1, 1, 24, 0, b'x')],
+    }

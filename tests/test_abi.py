@@ -166,3 +166,36 @@ def test_host_frame_index_fuzz_slice(args):
     p = subprocess.run([sys.executable] + args, cwd=root, capture_output=True, text=True, timeout=550)
     out = p.stdout.strip().splitlines()
     assert p.returncode == 0 and out and re.search(r'\b0 bad', out[-1]), (out[-6:], p.stderr[-400:])
+
+
+def test_cuesheet_and_picture_legality_matches_libflac():
+    """FLAC__stream_encoder_init_stream refuses the CUESHEET / PICTURE blocks libFLAC refuses (INVALID_METADATA, before any
+    device is touched) and no others: the statuses were recorded from the reference binary (oracle/gen_golden_setmeta.py,
+    tests/golden/legality_vectors.json).  Without a GPU an acceptable list ends in ENCODER_ERROR instead of OK."""
+    import ctypes as C
+    import json
+    from pyflac_amd import _lib
+    from tests import metadata_build as MB
+    L = _lib.lib()
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'legality_vectors.json')) as f:
+        want = json.load(f)
+    INVALID = 12
+    assert set(want.values()) == {0, INVALID}
+    L.FLAC__stream_encoder_new.restype = C.c_void_p
+    L.FLAC__stream_encoder_set_metadata.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.FLAC__stream_encoder_init_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    wcb = _lib.ENC_WRITE_CB(lambda *a: 0)
+    seen = 0
+    for name, blocks in MB.legality_cases().items():
+        enc = C.c_void_p(L.FLAC__stream_encoder_new())
+        L.FLAC__stream_encoder_set_channels(enc, 2)
+        L.FLAC__stream_encoder_set_bits_per_sample(enc, 16)
+        L.FLAC__stream_encoder_set_sample_rate(enc, 44100)
+        L.FLAC__stream_encoder_set_compression_level(enc, 5)
+        assert L.FLAC__stream_encoder_set_metadata(enc, MB.block_array(blocks), len(blocks))
+        rc = L.FLAC__stream_encoder_init_stream(enc, wcb, None, None, None, None)
+        assert (rc == INVALID) == (want[name] == INVALID), (name, rc, want[name])
+        L.FLAC__stream_encoder_finish(enc)
+        L.FLAC__stream_encoder_delete(enc)
+        seen += 1
+    assert seen == len(want) == 20
