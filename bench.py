@@ -164,6 +164,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # The CPU leg runs FIRST, before anything touches the GPU: it forks one oracle process per host core, and a forked child
+    # must not carry HIP state (torch.cuda.is_available() below initialises the device).
+    cpu_res = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
+        cpu_res = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), args.level, 48000)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
     torch.cuda.set_device(local)
@@ -232,11 +237,13 @@ def main():
     # bit-exactness gate (outside the timed region): the round trip equals the input
     assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
     assert torch.equal(dec[:nsamp], pcm), 'round trip is not bit-exact'
+    # what the GPU wrote, for the byte-for-byte check against the oracle after the timed region: the WHOLE stream (of the batch:
+    # the whole first stream)
     h_chk = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
-        nchk = min(nsamp, 40 * bs) // bs * bs
-        h_offs = offs.cpu().numpy()
-        h_chk = (nchk, out[:int(h_offs[nchk // bs])].cpu().numpy().tobytes())
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nchk = nsamp if single else lengths[0]
+        nfchk = -(-nchk // bs)
+        h_chk = (nchk, nfchk, out[:int(offs[nfchk].item())].cpu().numpy().tobytes())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -354,20 +361,29 @@ def main():
                                     'source': 'profiles/r02_pmc.json'}
         if world == 1 and not args.no_e2e and args.workload == 'stream16':
             res['api_e2e'] = api_e2e(min(args.seconds, 600.0), sr)
-        if world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
-            res['cpu_baseline'] = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), args.level, 48000)
+        if cpu_res is not None:
+            res['cpu_baseline'] = cpu_res
             ratio = committed_profile('r02_cpu_ref_ratio.json')
             if ratio:
                 res['cpu_baseline']['reference_binary_ratio'] = {
                     'encode': ratio['reference_over_oracle_encode'], 'decode': ratio['reference_over_oracle_decode'],
                     'reference_encode_msamples_per_s_build_container': ratio['reference_encode_msamples_per_s'],
                     'measured_by': ratio['command'] + ' (build container; the binary does not travel): profiles/r02_cpu_ref_ratio.json'}
-            # checker use of the same oracle: the first 40 frames the GPU wrote are the oracle's, byte for byte
+        if h_chk is not None:
+            # checker use of the oracle: EVERY frame the GPU wrote (of the batch: every frame of its first stream) is the
+            # oracle's, byte for byte -- a round trip alone would also pass a wrong but decodable choice
+            import hashlib
             from oracle import oracle as O
             cfg, _ = O.config(args.level, ch, bps, sr, bs, True)
+            tc = time.perf_counter()
             ref, _sizes = O.encode_stream(cfg, pcm16[:h_chk[0]].astype(np.int32))
-            assert h_chk[1] == ref[86:86 + len(h_chk[1])], 'encoded frames differ from the oracle'
-            res['cpu_baseline']['checked'] = '%d GPU frames byte-identical to the oracle' % (h_chk[0] // bs)
+            assert len(_sizes) == h_chk[1]
+            got_sha, want_sha = hashlib.sha256(h_chk[2]).hexdigest(), hashlib.sha256(ref[86:]).hexdigest()
+            assert got_sha == want_sha, 'encoded stream differs from the oracle'
+            res['checked'] = {'frames': '%d of %d frames' % (h_chk[1], h_chk[1] if single else est.nblocks),
+                              'what': 'SHA-256 of the GPU stream == SHA-256 of oracle.encode_stream over the same PCM'
+                                      + ('' if single else ' (the first stream of the batch, whole)'),
+                              'sha256': got_sha, 'bytes': len(h_chk[2]), 'oracle_s': round(time.perf_counter() - tc, 1)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -202,11 +202,13 @@ def test_out_of_range_sample_is_flagged(ctx):
         ctx.encode(s, torch.from_numpy(bad).cuda())
 
 
-@pytest.mark.parametrize('seconds,level,kind', [(60.0, 5, 'cfg2'), (20.0, 8, 'cfg4')])
-def test_full_size_round_trip_properties(ctx, seconds, level, kind):
-    """At BASELINE sizes the oracle is too slow to check every byte; use size-independent properties: the GPU
-    decoder restores the input exactly, every frame's CRC-16 verifies, frame sizes sum to the stream size,
-    and a sample of frames equals the oracle byte for byte."""
+@pytest.mark.parametrize('seconds,level,kind', [(600.0, 5, 'cfg2'), (300.0, 8, 'cfg4')])
+def test_full_size_whole_stream_equals_oracle(ctx, seconds, level, kind):
+    """BASELINE sizes (configs[1]: 600 s of 16-bit stereo at level 5; configs[3]: 300 s of 24-bit 96 kHz stereo at level 8), checked
+    in full: the GPU stream is the oracle's stream byte for byte (SHA-256 over all 7032 frames: a round trip alone would also pass
+    a wrong but decodable choice), the decoder restores the input exactly from the bytes alone, every CRC-16 verifies, the frame
+    sizes sum to the stream size."""
+    import hashlib
     import torch
     from pyflac_amd import batch
     from oracle import oracle as O
@@ -218,15 +220,40 @@ def test_full_size_round_trip_properties(ctx, seconds, level, kind):
     t = torch.from_numpy(arr).cuda()
     out, offs, st = ctx.encode(s, t)
     offs_h = offs.cpu().numpy()
+    assert st.nblocks == 7032
     assert int(offs_h[-1]) == st.total_bytes and np.all(np.diff(offs_h) > 0)
-    dec, status, dst = ctx.decode(out[:st.total_bytes], offs_h, 2, bps, len(arr))
+    dec, status, dst = ctx.decode_stream(out[:st.total_bytes], 2, bps, len(arr), nframes=st.nblocks)
     assert int(status[:, 0].max()) == 0
     assert torch.equal(dec, t)
+    del dec
     cfg, _ = O.config(level, 2, bps, sr, 4096, True)
+    want, sizes = O.encode_stream(cfg, arr)
     body = out[:st.total_bytes].cpu().numpy().tobytes()
-    for b in np.linspace(0, st.nblocks - 2, 12).astype(int):
-        want = O.encode_frame(cfg, arr[b * 4096:(b + 1) * 4096], int(b))
-        assert body[int(offs_h[b]):int(offs_h[b + 1])] == want
+    assert len(sizes) == st.nblocks and np.array_equal(np.diff(offs_h).astype(np.int64), np.asarray(sizes, np.int64))
+    assert hashlib.sha256(body).hexdigest() == hashlib.sha256(want[86:]).hexdigest()
+
+
+def test_batch_stream_whole_equals_oracle(ctx):
+    """configs[4] shape at its real stream length: four 60 s streams in one launch; the FIRST AND THE LAST stream whole equal the
+    oracle's streams (SHA-256), and all four decode back from the bytes alone."""
+    import hashlib
+    import torch
+    from pyflac_amd import batch, synth
+    from oracle import oracle as O
+    streams = [synth.config5_stream(s, 60.0) for s in range(4)]
+    s = batch.settings(5, 2, 16, 48000, 4096, True)
+    t = torch.from_numpy(np.concatenate(streams).astype(np.int32)).cuda()
+    out, offs, st = ctx.encode(s, t, stream_lengths=[len(x) for x in streams])
+    h = offs.cpu().numpy().astype(np.int64)
+    nfr = -(-len(streams[0]) // 4096)
+    cfg, _ = O.config(5, 2, 16, 48000, 4096, True)
+    for k in (0, 3):
+        want, sizes = O.encode_stream(cfg, streams[k].astype(np.int32))
+        got = out[int(h[k * nfr]):int(h[(k + 1) * nfr])].cpu().numpy().tobytes()
+        assert len(sizes) == nfr and hashlib.sha256(got).hexdigest() == hashlib.sha256(want[86:]).hexdigest()
+    ranges = [(int(h[(k + 1) * nfr] - h[k * nfr]), nfr) for k in range(4)]
+    dec, status, dst = ctx.decode_streams(out[:st.total_bytes], ranges, 2, 16, t.shape[0])
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec, t)
 
 
 # ---------------------------------------------------------------------------------------------- round-2 additions
