@@ -146,7 +146,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
     ap.add_argument('--no-passes', action='store_true', help='skip the event passes after the timed loop (profiling runs: the trace then holds the timed loop only)')
-    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted'], default='stream16',
+    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted', 'stream32', 'surround6'], default='stream16',
                     help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz level 8; '
                          'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each); '
                          'wasted: the stream16 signal in a 24-bit container (8 wasted bits in every block)')
@@ -184,6 +184,15 @@ def main():
     elif args.workload == 'wasted':
         bps = 24
         pcm16 = synth.config2_stereo16(args.seconds, rank, sr).astype(np.int32) << 8
+    elif args.workload == 'stream32':
+        # pyFLAC's other input type (pyflac/encoder.py:109: int32 arrays): 32-bit samples, the side channel needs 33 bits
+        bps = 32
+        pcm16 = synth.config2_stereo16(args.seconds, rank, sr).astype(np.int64) * 40000 + (np.arange(int(round(sr * args.seconds)))[:, None] % 977)
+        pcm16 = np.clip(pcm16, -(1 << 31), (1 << 31) - 1).astype(np.int32)
+    elif args.workload == 'surround6':
+        # six channels (tests/test_encoder.py:258-273 of the reference: surround.wav), 16 bit: three stereo pairs of the generator family
+        ch = 6
+        pcm16 = np.concatenate([synth.config5_stream(3 * rank + k, args.seconds, sr) for k in range(3)], axis=1)
     elif args.workload == 'batch':
         # configs[4]: this rank's share of the world * streams batch -- stream s runs on rank s mod world
         # (pyflac_amd.shard.streams_for_rank, the mapping batch.MultiContext uses inside one process) -- concatenated in HBM,
@@ -312,15 +321,16 @@ def main():
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int32', 'data': 'synthetic',
-            'config': {'workload': '%s: %s encode, then decode of its output from the bytes%s, stereo %d-bit %d kHz, blocksize 4096, '
+            'config': {'workload': '%s: %s encode, then decode of its output from the bytes%s, %d channels %d-bit %d kHz, blocksize 4096, '
                                    'level %d, %.0f s%s (%d blocks) per GPU, int32 PCM resident in HBM, MD5 off '
                                    '(FLAC__stream_encoder_set_do_md5(0))' %
                                    ({'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]',
-                                     'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)'}[args.workload],
+                                     'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)',
+                                     'stream32': '32-bit samples (33-bit side channel)', 'surround6': 'six channels'}[args.workload],
                                     'single-stream' if single else '%d independent streams in one launch,' % len(lengths),
                                     ' alone (frame index rebuilt on the GPU inside the timed region)' if single else
                                     ' alone (every stream\'s frame index rebuilt on the GPU inside the timed region, one pass over all bytes)',
-                                    bps, sr // 1000, args.level, args.seconds, '' if single else ' each', est.nblocks),
+                                    ch, bps, sr // 1000, args.level, args.seconds, '' if single else ' each', est.nblocks),
                        'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4),
                        'timed_s': round(dt, 3)},
             'ms_per_step_min': round(float(ps[0]), 3), 'ms_per_step_median': round(float(ps[len(ps) // 2]), 3),

@@ -699,10 +699,9 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         uint32_t nmax = n_out;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
-        const bool al = !__any(n_in != 0 && (plane & 3) != 0);
-        // stereo fast output: every frame of the group starts on an even lane (C == 2), 16-byte aligned output rows
-        const bool so = C == 2 && !__any(n_out != 0 && ((out_off & 1) != 0 || (n & 3) != 0)) && (((uintptr_t)out) & 15) == 0;
-        if (lane == 0) { ctl[0] = nmax; ctl[1] = (al && (((uintptr_t)scratch) & 15) == 0) ? 1u : 0u; ctl[2] = so ? 1u : 0u; }
+        // stereo fast output (decided per frame by the writers): C == 2 and a 16-byte aligned output base
+        const bool so = C == 2 && (((uintptr_t)out) & 15) == 0;
+        if (lane == 0) { ctl[0] = nmax; ctl[1] = 1u; ctl[2] = so ? 1u : 0u; }
     }
     __syncthreads();
     // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])
@@ -716,7 +715,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         }
     }
     const uint32_t nmax = ctl[0];
-    const bool planes_al = ctl[1] != 0, stereo_fast = ctl[2] != 0;
+    const bool stereo_fast = ctl[2] != 0;
     const uint32_t T = (nmax + WR_TS - 1) / WR_TS;
     const uint32_t S = T + 1;                  // steps (barriers) of every wave
 
@@ -742,45 +741,33 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         // Planes that are not 16-byte aligned (odd block sizes) go word by word: 64 loads a tile, lane = column.
         u64 rbase[16];
         uint32_t rlen[16], rcol[16];
-        if (planes_al) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t row = 4u * (uint32_t)k + ((uint32_t)lane >> 4);
-                const uint32_t *fm = fa + row * WR_FA;
-                rbase[k] = ((u64)fm[3] << 32) | fm[2];
-                rlen[k] = fm[0];
-                rcol[k] = ((((uint32_t)lane & 15) ^ (row & 15)) << 2);
-            }
+        for (int k = 0; k < 16; k++) {
+            const uint32_t row = 4u * (uint32_t)k + ((uint32_t)lane >> 4);
+            const uint32_t *fm = fa + row * WR_FA;
+            rbase[k] = ((u64)fm[3] << 32) | fm[2];
+            rlen[k] = fm[0];
+            rcol[k] = ((((uint32_t)lane & 15) ^ (row & 15)) << 2);
         }
+        // (the 16-byte reads need no more than the 4-byte alignment every plane has: odd block sizes -- the tail of nearly every
+        // real stream -- take the same path; what a read fetches behind the end of its row is never looked at)
         auto issue = [&](uint32_t t) __attribute__((always_inline)) {
             uint32_t *tb = tiles + (t % WR_NB) * WR_TILE_W;
-            if (planes_al) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t c0 = t * WR_TS + rcol[k];
-                    const int32_t *src = (t < T && c0 < rlen[k]) ? scratch + rbase[k] + c0 : scratch;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(tb + 4 * k * WR_TS), 16, 0, 0);
-                }
-            }
-            else {
-                for (uint32_t row = 0; row < 64; row++) {
-                    const uint32_t *fm = fa + row * WR_FA;
-                    const uint32_t c = (((((uint32_t)lane >> 2) ^ (row & 15)) << 2) | ((uint32_t)lane & 3));
-                    const uint32_t c0 = t * WR_TS + c;
-                    const int32_t *src = (t < T && c0 < fm[0]) ? scratch + (((u64)fm[3] << 32) | fm[2]) + c0 : scratch;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(tb + row * WR_TS), 4, 0, 0);
-                }
+            for (int k = 0; k < 16; k++) {
+                const uint32_t c0 = t * WR_TS + rcol[k];
+                const int32_t *src = (t < T && c0 < rlen[k]) ? scratch + rbase[k] + c0 : scratch;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(tb + 4 * k * WR_TS), 16, 0, 0);
             }
         };
         issue(0); issue(1);
-        if (planes_al) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         for (uint32_t s = 1; s <= S; s++) {
             // barrier s publishes tile s - 1 (and whatever older)
             asm volatile("s_barrier" ::: "memory");
             issue(s + 1);
-            if (planes_al) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -832,14 +819,29 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                     }
                 }
                 int32_t *o = out + w_oo[k] * 2;
+                // whole groups of four at a 16-byte aligned place: two 16-byte stores; the last group of an odd block (the tail of
+                // nearly every real stream) and frames at odd offsets: sample by sample
+                const bool vec = i + 4 <= rn && (w_oo[k] & 1) == 0 && ((interleave & 1) || (rn & 3) == 0);
                 if (interleave & 1) {
-                    int4 *d = (int4 *)(o + (size_t)i * 2);
-                    d[0] = make_int4(a[0], b[0], a[1], b[1]);
-                    d[1] = make_int4(a[2], b[2], a[3], b[3]);
+                    if (vec) {
+                        int4 *d = (int4 *)(o + (size_t)i * 2);
+                        d[0] = make_int4(a[0], b[0], a[1], b[1]);
+                        d[1] = make_int4(a[2], b[2], a[3], b[3]);
+                    }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (i + e < rn) *(int2 *)(o + (size_t)(i + e) * 2) = make_int2(a[e], b[e]);
+                    }
                 }
                 else {
-                    *(int4 *)(o + i) = make_int4(a[0], a[1], a[2], a[3]);
-                    *(int4 *)(o + rn + i) = make_int4(b[0], b[1], b[2], b[3]);
+                    if (vec) {
+                        *(int4 *)(o + i) = make_int4(a[0], a[1], a[2], a[3]);
+                        *(int4 *)(o + rn + i) = make_int4(b[0], b[1], b[2], b[3]);
+                    }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (i + e < rn) { o[i + e] = a[e]; o[rn + i + e] = b[e]; }
+                    }
                 }
             }
             return;
