@@ -369,7 +369,10 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         key.resize(sb + tb + 1);
         memcpy(key.data(), s, sb);
         if (tb) memcpy(key.data() + sb, streams, tb);
-        key[sb + tb] = (unsigned char)(pcm_is_i16 ? 1 : 0);
+        // (the kernel selection switches -- tuning aids read per call -- decide which blocks count as pipeline blocks: part of the key)
+        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (getenv("FLACGPU_NO_FAST") ? 2 : 0) |
+                                       ((getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) ? 4 : 0) |
+                                       ((getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1) ? 8 : 0));
     }
     const bool reuse = !(s->do_mid_side && s->loose_mid_side) && !c->debug && c->dev_descs_ptr == c->descs.p && c->dev_descs_ptr != nullptr &&
                        !c->dev_descs.empty() && key == c->desc_key;
@@ -450,6 +453,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // predictor history, partitions no finer than a lane)
     auto block_fast = [&](const FgBlockDesc &d) -> bool {
         if (!cfg_fast) return false;
+        // (the pipeline has a lane geometry for ragged blocks -- the tail of nearly every real stream --; round 1's single kernel,
+        // FLACGPU_PIPE=0, wants whole lanes of 16 samples)
+        if (use_pipe) return fg_pipe_block_ok(d.n, s->max_partition_order) != 0;
         if (d.n < 64 * 16 || (d.n % 64) != 0) return false;
         uint32_t pm = 0, b = d.n;
         while (!(b & 1)) { pm++; b >>= 1; }
@@ -479,10 +485,17 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         c->desc_key.clear();
         uint32_t period = (uint32_t)((double)s->sample_rate * 0.4 / (double)s->blocksize + 0.5);
         if (period == 0) period = 1;
-        std::vector<FgBlockDesc> dec, decp, decg;      // decision frames: all, pipeline-capable first, generic after
+        std::vector<FgBlockDesc> dec, decp, decr, decg;      // decision frames: all; pipeline (regular, then ragged geometry) first, generic after
         std::vector<uint32_t> decidx;
+        auto is_rag = [&](const FgBlockDesc &d) { return (d.n % 64) != 0 || d.n / 64 < 16; };
         for (uint32_t b = 0; b < nblocks; b++)
-            if (descs[b].frame_number % period == 0) { decidx.push_back(b); (block_fast(descs[b]) && use_pipe ? decp : decg).push_back(descs[b]); }
+            if (descs[b].frame_number % period == 0) {
+                decidx.push_back(b);
+                if (block_fast(descs[b]) && use_pipe) (is_rag(descs[b]) ? decr : decp).push_back(descs[b]);
+                else decg.push_back(descs[b]);
+            }
+        const uint32_t nrag_probe = (uint32_t)decr.size();
+        decp.insert(decp.end(), decr.begin(), decr.end());
         dec = decp; dec.insert(dec.end(), decg.begin(), decg.end());
         for (size_t k = 0; k < dec.size(); k++) dec[k].reserved = dec[k].out_slot;      // remember the block, probe into slot k
         for (size_t k = 0; k < dec.size(); k++) dec[k].out_slot = (uint32_t)k;
@@ -492,9 +505,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             for (FgBlockDesc &d : up) d.reserved = 0;
             if (!upload_descs(up, false)) return false;
             if (!decp.empty()) {
-                PL.nblocks = (uint32_t)decp.size(); PL.stages = 1; PL.dbg = nullptr;
+                PL.nblocks = (uint32_t)decp.size(); PL.nblocks_rag = nrag_probe; PL.stages = 1; PL.dbg = nullptr;
                 if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
-                PL.dbg = dbg;
+                PL.dbg = dbg; PL.nblocks_rag = 0;
             }
             if (!decg.empty() &&
                 fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + decp.size(), (const float *)c->windows.p, &P, (uint32_t)decg.size(),
@@ -524,24 +537,27 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     // blocks the specialised kernels cover go first, the rest to the generic kernel (same bytes either way)
     uint32_t nfast = 0;
-    if (reuse) { nfast = c->desc_nfast; PL.nblocks_ws2 = c->desc_nws2; }
+    if (reuse) { nfast = c->desc_nfast; PL.nblocks_ws2 = c->desc_nws2; PL.nblocks_rag = c->desc_nrag; }
     else {
         std::vector<FgBlockDesc> ordered;
         ordered.reserve(nblocks);
-        std::vector<FgBlockDesc> slow, ws1;
+        std::vector<FgBlockDesc> slow, ws1, rag;
         for (const FgBlockDesc &d : descs) {
             if (!block_fast(d)) slow.push_back(d);
+            else if (use_pipe && ((d.n % 64) != 0 || d.n / 64 < 16)) rag.push_back(d);      // ragged lane geometry (tails, odd sizes; is_rag above)
             else if (use_pipe && block_ws(d) != 2) ws1.push_back(d);
             else ordered.push_back(d);
         }
         PL.nblocks_ws2 = use_pipe ? (uint32_t)ordered.size() : 0;
         ordered.insert(ordered.end(), ws1.begin(), ws1.end());
+        PL.nblocks_rag = (uint32_t)rag.size();
+        ordered.insert(ordered.end(), rag.begin(), rag.end());
         nfast = (uint32_t)ordered.size();
         ordered.insert(ordered.end(), slow.begin(), slow.end());
         descs.swap(ordered);
         c->desc_key.clear();
         if (!upload_descs(descs, true)) return false;
-        if (!(P.do_mid_side && s->loose_mid_side)) { c->desc_key = key; c->desc_nfast = nfast; c->desc_nws2 = PL.nblocks_ws2; }
+        if (!(P.do_mid_side && s->loose_mid_side)) { c->desc_key = key; c->desc_nfast = nfast; c->desc_nws2 = PL.nblocks_ws2; c->desc_nrag = PL.nblocks_rag; }
     }
     // How the call ends and what is timed.  Level 0 (default): no events -- every event record costs a few microseconds of
     // idle GPU between two kernels -- a stamp kernel in front, a signal kernel at the end (fg_signal_kernel: totals and

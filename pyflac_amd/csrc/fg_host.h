@@ -25,6 +25,7 @@ int fg_launch_encode_fast(const void *d_pcm, const FgBlockDesc *d_descs, const f
 // de-fused pipeline (flac_enc_pipe.hip)
 int fg_pipe_supported(const FgEncParams *P);
 uint32_t fg_pipe_block_ws(uint32_t n);
+int fg_pipe_block_ok(uint32_t n, uint32_t max_po);
 size_t fg_pipe_scratch_bytes(const FgEncParams *P, uint32_t nblocks);
 void fg_pipe_carve(const FgEncParams *P, uint32_t nblocks, void *base, FgPipeBufs *B);
 int fg_launch_encode_pipe(const FgPipeLaunch *L);
@@ -115,7 +116,7 @@ struct flacgpu_ctx {
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
         dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe;
     std::vector<unsigned char> desc_key;   // settings + stream list the block list in `dev_descs` was built for
-    uint32_t desc_nfast = 0, desc_nws2 = 0;
+    uint32_t desc_nfast = 0, desc_nws2 = 0, desc_nrag = 0;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`
     const void *dev_descs_ptr = nullptr;
     std::vector<float> h_windows;

@@ -108,6 +108,7 @@ struct FgPipeLaunch {
     uint32_t chunk_cap_words;   // capacity of one wave's chunk inside the block's slot
     uint32_t fbw_words;         // LDS frame-bit window of one packing wave
     uint32_t nblocks_ws2;       // the first nblocks_ws2 blocks are packed by two waves per subframe, the rest by one
+    uint32_t nblocks_rag;       // the LAST nblocks_rag blocks have the ragged lane geometry (flac_enc_pipe_impl.h PipeGeo)
     uint32_t acc64;             // > 16 bit samples
     uint32_t stages;            // bit 0: analysis (K2-K4), bit 1: pack (K5)
     double guard_thr;           // order guesses closer than this many bits are re-done with the correctly rounded log

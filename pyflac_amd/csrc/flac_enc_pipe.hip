@@ -20,13 +20,25 @@ int fg_pipe_supported(const FgEncParams *P)
 }
 
 // Packing waves per subframe for a block of n samples: two when a lane then still walks >= 32 samples (every lane spans
-// at least one output word, which the register-assembled emission needs), one for shorter blocks whose length is a
-// multiple of 64 with at least 16 samples per lane, 0 = not a block for the pipeline.
+// at least one output word, which the register-assembled emission needs), one for everything else (shorter blocks, and the
+// ragged geometry of blocks whose length is no multiple of 64 -- flac_enc_pipe_impl.h PipeGeo).
 uint32_t fg_pipe_block_ws(uint32_t n)
 {
     if (n % 128 == 0 && n / 128 >= 32) return 2;
-    if (n % 64 == 0 && n / 64 >= 16) return 1;
-    return 0;
+    return 1;
+}
+
+// Can the pipeline take a block of n samples?  Every working lane needs 16 samples (the predictor history of a lane then lies in
+// one other lane, the warm-up samples in lane 0): n / 2^pm >= 16 with pm = the finest partition order the block allows, and no
+// more than 64 finest partitions.
+int fg_pipe_block_ok(uint32_t n, uint32_t max_po)
+{
+    uint32_t pm = 0, b = n;
+    if (n < 32) return 0;
+    while (!(b & 1)) { pm++; b >>= 1; }
+    if (pm > max_po) pm = max_po;
+    if (pm > 6) return 0;
+    return (n >> pm) >= 16 ? 1 : 0;
 }
 
 // bytes of scratch the pipeline needs for `nblocks` blocks, and the carve of it

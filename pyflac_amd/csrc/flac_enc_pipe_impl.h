@@ -650,21 +650,94 @@ fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, u
     B.lres[idx] = result;
 }
 
+// ================================================================================================ lane geometry
+// Regular blocks (n a multiple of the lane count, 16 or more samples a lane): lane l owns samples [l seg, (l + 1) seg), row l of
+// the LDS staging holds them, rows are seg + PADE elements apart.  Everything else -- the tail block of nearly every real
+// stream, odd block sizes, short blocks -- takes the RAGGED geometry: the lanes are grouped by the partitions of the finest
+// partition order the block allows (pm = min(max order, trailing zeros of n): G = 2^pm groups of lpg = lanes / G lanes and
+// S = n / G samples), and the S samples of a group are spread over its first A = min(lpg, S / 16) lanes as evenly as they go:
+// `base` samples each, one more for the first `extra` lanes.  So every working lane has 16 or more samples (the predictor
+// history of a lane lies in ONE other lane, and the warm-up samples lie in lane 0), a partition of any order is a run of whole
+// lanes exactly as in the regular geometry -- the Rice search and the packer's partition logic do not change --, and lanes
+// A .. lpg - 1 of a group idle.  Row l of the staging holds lane l's samples, rows are base + 1 + PADE apart.
+// elements of one channel's staging area: the regular rows need sig_stride + 2 a lane, the ragged ones 64 rows of up to 31 + 3
+FGI uint32_t pipe_rows_elems(uint32_t sig_stride, uint32_t lanes) { return (sig_stride > 2048u ? sig_stride : 2048u) + 2u * lanes + 128u; }
+
+struct PipeGeo {
+    uint32_t rag;               // 0: regular
+    uint32_t lpgs;              // log2(lanes per group)
+    uint32_t S, A, base, extra, rstr;
+};
+FGI PipeGeo pipe_geo(uint32_t n, uint32_t lanes_log2, uint32_t max_po, uint32_t pade)
+{
+    PipeGeo g;
+    const uint32_t lanes = 1u << lanes_log2;
+    g.rag = ((n & (lanes - 1)) != 0 || (n >> lanes_log2) < 16) ? 1u : 0u;
+    uint32_t pm = 0;
+    { uint32_t b = n; while (!(b & 1) && pm < 15) { pm++; b >>= 1; } }
+    if (pm > max_po) pm = max_po;
+    if (pm > 6) pm = 6;
+    g.lpgs = lanes_log2 - pm;
+    g.S = n >> pm;
+    const uint32_t lpg = 1u << g.lpgs;
+    uint32_t A = g.S / 16;
+    if (A < 1) A = 1;
+    if (A > lpg) A = lpg;
+    g.A = A; g.base = g.S / A; g.extra = g.S - g.base * A;
+    g.rstr = g.rag ? g.base + 1 + pade : (n >> lanes_log2) + pade;
+    return g;
+}
+FGI PipeGeo pipe_geo_regular(uint32_t seg, uint32_t pade)
+{
+    PipeGeo g;
+    g.rag = 0; g.lpgs = 0; g.S = 1; g.A = 1; g.base = 1; g.extra = 0; g.rstr = seg + pade;
+    return g;
+}
+// what a lane owns, and where the samples in front of its first one lie
+struct PipeLane { uint32_t len, act, hasprev, prow, plen; };
+template <bool RAG>
+FGI PipeLane pipe_lane(const PipeGeo &g, uint32_t Lg, uint32_t seg)
+{
+    PipeLane L;
+    if (!RAG) { L.len = seg; L.act = 1; L.hasprev = Lg > 0; L.prow = Lg - 1; L.plen = seg; return L; }
+    const uint32_t grp = Lg >> g.lpgs, w = Lg & ((1u << g.lpgs) - 1);
+    L.act = w < g.A ? 1u : 0u;
+    L.len = L.act ? g.base + (w < g.extra ? 1u : 0u) : 0u;
+    L.hasprev = Lg > 0;
+    if (w > 0) { L.prow = Lg - 1; L.plen = g.base + ((w - 1) < g.extra ? 1u : 0u); }
+    else { L.prow = ((grp - 1) << g.lpgs) + g.A - 1; L.plen = g.base + ((g.A - 1) < g.extra ? 1u : 0u); }
+    if (!L.act) { L.prow = 0; L.plen = g.base; }       // (idle lanes read row 0: anything that is there)
+    return L;
+}
+// element index of sample i of the block in the staging (ragged geometry)
+FGI uint32_t pipe_rag_addr(const PipeGeo &g, uint32_t i, uint32_t mS, uint32_t mB1, uint32_t mB)
+{
+    const uint32_t grp = __umulhi(i, mS) , r = i - grp * g.S;          // i / S through the magic multiplier (exact for i < 2^16 * S)
+    const uint32_t cut = g.extra * (g.base + 1);
+    uint32_t w, col;
+    if (r < cut) { w = __umulhi(r, mB1); col = r - w * (g.base + 1); }
+    else { const uint32_t r2 = r - cut; const uint32_t w2 = __umulhi(r2, mB); w = g.extra + w2; col = r2 - w2 * g.base; }
+    return ((grp << g.lpgs) + w) * g.rstr + col;
+}
+
 // ================================================================================================ staging: HBM -> LDS rows
 // Cooperative over NT threads.  Rows of `seg` samples (+PADE of skew); g -> element index g + (g / seg) * PADE.
-template <int NCH, bool ACC64, int NT>
+template <int NCH, bool ACC64, int NT, bool RAG>
 FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams &P, LDS typename PipeTypes<ACC64>::samp_t *sL,
-                        LDS typename PipeTypes<ACC64>::samp_t *sR, int tid, uint32_t seg)
+                        LDS typename PipeTypes<ACC64>::samp_t *sR, int tid, uint32_t seg, const PipeGeo &geo)
 {
     typedef typename PipeTypes<ACC64>::samp_t samp_t;
     constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
     const uint32_t n = d.n;
-    const uint32_t magic = 0xFFFFFFFFu / seg + 1;
-#define FGP_SADDR(g) ((g) + __umulhi((g), magic) * PADE)
+    const uint32_t magic = 0xFFFFFFFFu / (seg ? seg : 1) + 1;
+    // (ragged geometry: exact quotients by S, base + 1 and base for indices below 2^16)
+    const uint32_t mS = 0xFFFFFFFFu / geo.S + 1, mB1 = 0xFFFFFFFFu / (geo.base + 1) + 1, mB = 0xFFFFFFFFu / geo.base + 1;
+    constexpr bool rag = RAG;
+#define FGP_SADDR(g) (rag ? pipe_rag_addr(geo, (g), mS, mB1, mB) : ((g) + __umulhi((g), magic) * PADE))
     const int32_t lim = (int32_t)(P.bps - 1);
     uint32_t bad = 0;
     uint32_t istart = 0;
-    if (NCH == 2 && !P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (seg & 1) == 0 && (((uintptr_t)pcm) & 15) == 0) {
+    if (NCH == 2 && !rag && !P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (seg & 1) == 0 && (((uintptr_t)pcm) & 15) == 0) {
         // two inter-channel samples per load; the pair lands in one LDS row (even index, even row length)
         const int4 *src = (const int4 *)((const int2 *)pcm + d.pcm_off);
         for (uint32_t j0 = 0; j0 < n / 2; j0 += 4 * NT) {
@@ -692,7 +765,7 @@ FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams
         }
         istart = n;
     }
-    if (NCH == 2 && P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (seg & 1) == 0 && (((uintptr_t)pcm) & 7) == 0) {
+    if (NCH == 2 && !rag && P.pcm_i16 && (d.pcm_off & 1) == 0 && (n & 127) == 0 && (seg & 1) == 0 && (((uintptr_t)pcm) & 7) == 0) {
         // int16 stereo: two inter-channel samples per 8-byte load, stored as one LDS word per channel
         const int2 *src = (const int2 *)((const short2 *)pcm + d.pcm_off);
         for (uint32_t j0 = 0; j0 < n / 2; j0 += 4 * NT) {
@@ -963,18 +1036,22 @@ FGI bool pipe_rice_search_tree(typename PipeTypes<ACC64>::sum_t psum, int lane, 
     return true;
 }
 
-template <bool MS, int NCH, int MAXO, bool ACC64>
+template <bool MS, int NCH, int MAXO, bool ACC64, bool RAG>
 FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
                         FgDebugRec *mydbg, const LDS typename PipeTypes<ACC64>::samp_t *sL, const LDS typename PipeTypes<ACC64>::samp_t *sR,
-                        int lane, uint32_t range_err)
+                        int lane, uint32_t range_err, const PipeGeo &geo)
 {
     constexpr int NC = MS ? 4 : NCH;
     typedef typename PipeTypes<ACC64>::sum_t sum_t;
     typedef typename PipeTypes<ACC64>::samp_t samp_t;
     constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
     const uint32_t n = d.n;
-    const uint32_t seg = n >> 6, rstr = seg + PADE;
+    // `seg`: the samples every working lane has (RAG: `base`; the first `extra` lanes of a group have one more -- ln.len)
+    const uint32_t seg = RAG ? geo.base : n >> 6, rstr = RAG ? geo.rstr : seg + PADE;
+    (void)PADE;
+    const PipeLane ln = pipe_lane<RAG>(geo, (uint32_t)lane, seg);
     const LDS samp_t *rowL = sL + (uint32_t)lane * rstr, *rowR = sR + (uint32_t)lane * rstr;
+    const LDS samp_t *prvL = sL + ln.prow * rstr + ln.plen, *prvR = sR + ln.prow * rstr + ln.plen;      // one past the samples in front
     const uint32_t wst = rfl(B.wasted[bi * NC + C]);
     const uint32_t nominal = P.bps + ((MS && C == 3) ? 1u : 0u);
     const uint32_t sb = nominal - wst;
@@ -985,6 +1062,11 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     const uint32_t csh = ccs + wst;
     auto samp = [&](int s) __attribute__((always_inline)) -> int32_t {
         return pipe_cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, cca, ccb, csh);
+    };
+    // the k-th sample in front of this lane's first one (k >= 1)
+    auto hsamp = [&](int k) __attribute__((always_inline)) -> int32_t {
+        if (!RAG) return samp((int)seg - k - (int)rstr);
+        return pipe_cand(prvL[-k], (NCH == 2) ? (int32_t)prvR[-k] : 0, cca, ccb, csh);
     };
 
     uint32_t pmax0 = 0;
@@ -1012,7 +1094,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         for (int s = -4; s < 4; s++) {
             int32_t v = 0;
             if (s >= 0) v = samp(s);
-            else if (lane > 0) v = samp((int)seg + s - (int)rstr);
+            else if (lane > 0) v = hsamp(-s);
             const uint32_t vb = (uint32_t)v + FB;
             const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
             if (s >= 0) {
@@ -1047,8 +1129,65 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         }
 #pragma unroll 1
         for (; s4 < (int)seg; s4++) fstep(s4);
+        if (RAG) {
+            // the one sample more that the first lanes of a group have; idle lanes have walked over whatever row 0 holds
+            sum_t keep[5];
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) keep[kk] = facc[kk];
+            fstep((int)seg);
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) { if (ln.len <= seg) facc[kk] = keep[kk]; if (!ln.act) { facc[kk] = 0; fwarm[kk] = 0; } }
+        }
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) tot[kk] = ACC64 ? wave_sum64((u64)facc[kk]) : (u64)wave_sum((uint32_t)facc[kk]);
+        if constexpr (RAG) {
+            // The reference binary sums these errors with its AVX2 routine whenever 32-bit accumulators might overflow
+            // (sb + ilog2((n - 4) * 17) >= 32, stream_encoder.c process_subframe_): four lanes of q = len / 4 samples that start
+            // at (j len) / 4 but take their history from j q.  With len % 4 != 0 lanes 2 and 3 start one or two samples late
+            // against their history, a sample or two between the lanes and the len % 4 samples at the end are not counted
+            // (oracle/flac_oracle.c avx2_lane_sums has the derivation; regular blocks have len % 4 == 0).  The sums above are
+            // the exact ones: take out what the routine skips, and swap the first four errors of a shifted lane for what it
+            // computes -- a dozen samples, done by every lane alike.
+            const uint32_t len = n - 4, qq = len >> 2, rr = len & 3;
+            if (rr != 0 && sb + ilog2_32(len * 17) >= 32) {
+                const uint32_t mS = 0xFFFFFFFFu / geo.S + 1, mB1 = 0xFFFFFFFFu / (geo.base + 1) + 1, mB = 0xFFFFFFFFu / geo.base + 1;
+                auto xat = [&](uint32_t g) -> i64 {          // candidate value of sample g of the block
+                    const uint32_t ad = pipe_rag_addr(geo, g, mS, mB1, mB);
+                    return (i64)pipe_cand(sL[ad], (NCH == 2) ? (int32_t)sR[ad] : 0, cca, ccb, csh);
+                };
+                auto aabs = [](i64 v) -> u64 { return (u64)(v < 0 ? -v : v); };
+                // exact errors of orders 0..4 at d[i] (= sample i + 4 of the block)
+                auto exact = [&](uint32_t i, u64 (&e)[5]) {
+                    const i64 a = xat(i + 4), b = xat(i + 3), c = xat(i + 2), dd = xat(i + 1), ee = xat(i);
+                    e[0] = aabs(a); e[1] = aabs(a - b); e[2] = aabs(a - 2 * b + c); e[3] = aabs(a - 3 * b + 3 * c - dd);
+                    e[4] = aabs(a - 4 * b + 6 * c - 4 * dd + ee);
+                };
+                i64 adj[5] = {0, 0, 0, 0, 0};
+                const uint32_t st2 = len >> 1, st3 = (3 * len) >> 2;
+                auto skip = [&](uint32_t lo, uint32_t hi) {
+                    for (uint32_t i = lo; i < hi; i++) { u64 e[5]; exact(i, e); for (int k = 0; k < 5; k++) adj[k] -= (i64)e[k]; }
+                };
+                skip(2 * qq, st2); skip(st2 + qq, st3); skip(st3 + qq, len);
+                auto shifted = [&](uint32_t j, uint32_t st) {
+                    const uint32_t hb = j * qq;
+                    if (st == hb) return;
+                    // state from the history at hb, data from st
+                    const i64 h1 = xat(hb + 3), h2 = xat(hb + 2), h3 = xat(hb + 1), h4 = xat(hb);
+                    i64 p0 = h1, p1 = h1 - h2, p2 = p1 - (h2 - h3), p3 = p2 - (h2 - 2 * h3 + h4);
+                    for (uint32_t i = 0; i < 4 && i < qq; i++) {
+                        const i64 e0 = xat(st + i + 4), e1 = e0 - p0, e2 = e1 - p1, e3 = e2 - p2, e4 = e3 - p3;
+                        u64 ex[5];
+                        exact(st + i, ex);
+                        adj[0] += (i64)aabs(e0) - (i64)ex[0]; adj[1] += (i64)aabs(e1) - (i64)ex[1]; adj[2] += (i64)aabs(e2) - (i64)ex[2];
+                        adj[3] += (i64)aabs(e3) - (i64)ex[3]; adj[4] += (i64)aabs(e4) - (i64)ex[4];
+                        p3 = e3; p2 = e2; p1 = e1; p0 = e0;
+                    }
+                };
+                shifted(2, st2); shifted(3, st3);
+#pragma unroll
+                for (int kk = 0; kk < 5; kk++) tot[kk] = (u64)((i64)tot[kk] + adj[kk]);
+            }
+        }
         // fixed order guess (fixed.c: the smallest total error wins, lower order on ties)
         const u64 m34 = tot[3] < tot[4] ? tot[3] : tot[4];
         const u64 m234 = tot[2] < m34 ? tot[2] : m34;
@@ -1086,7 +1225,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             const int32_t x0 = pipe_cand(sL[0], (NCH == 2) ? (int32_t)sR[0] : 0, cca, ccb, csh);
             uint32_t ne = 0;
 #pragma unroll 1
-            for (uint32_t s = 0; s < seg; s++) ne |= (samp((int)s) != x0);
+            for (uint32_t s = 0; s < seg + (RAG ? 1u : 0u); s++) ne |= ((!RAG || s < ln.len) && samp((int)s) != x0);
             constant = !__any(ne != 0);
         }
         if (mydbg && lane == 0) {
@@ -1104,7 +1243,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                 const int32_t l0 = sL[0];
                 uint32_t ne = 0;
 #pragma unroll 1
-                for (uint32_t s = 0; s < seg; s++) ne |= ((int32_t)rowL[s] != l0);
+                for (uint32_t s = 0; s < seg + (RAG ? 1u : 0u); s++) ne |= ((!RAG || s < ln.len) && (int32_t)rowL[s] != l0);
                 forbid = !__any(ne != 0);
             }
             if (forbid) constant = false;
@@ -1160,7 +1299,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
-                if (lane > 0) x = samp((int)seg - 1 - j - (int)rstr);
+                if (lane > 0) x = hsamp(1 + j);
                 h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
                 if constexpr (FGP_F64 && ACC64) hd[(MAXO - 1 - j) % MAXO] = (double)x;
             }
@@ -1196,15 +1335,31 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 #pragma unroll
                 for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
             }
+            if (!RAG) {
 #pragma unroll
-            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+                for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+            }
+            else {
+                // the rest of the lane (the common `seg` samples and the one more of the first lanes of a group); sample
+                // s0 + u sits in history slot u
+                // (at most MAXO of them: seg - s0 < MAXO, plus one)
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) if (s0 + u < ln.len) step(u, s0 + u, s0 == 0);
+                if (!ln.act) { psum = 0; ovf = 0; }
+            }
         }
         const bool dead = ACC64 && __any(ovf != 0);
         uint32_t best_bits, bpo, kb;
         uint32_t kpart;
         bool kvalid;
-        if (!pipe_rice_search_tree<ACC64>(psum, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb, kpart, kvalid)) {
-            pipe_rice_search<ACC64>(psum, dead, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb);
+        // (format.c FLAC__format_get_max_rice_partition_order_from_blocksize_limited_max_and_predictor_order: a partition must
+        // be longer than the predictor order -- never binding with 16 or more samples in the finest partition, i.e. for
+        // regular blocks; short blocks of the ragged geometry meet it)
+        uint32_t pmax_p = pmax0;
+        if (RAG) while (pmax_p > 0 && (n >> pmax_p) <= order) pmax_p--;
+        const uint32_t pmin_p = pmin0 < pmax_p ? pmin0 : pmax_p;
+        if (!pipe_rice_search_tree<ACC64>(psum, lane, n, order, sb, pmin_p, pmax_p, limit, best_bits, bpo, kb, kpart, kvalid)) {
+            pipe_rice_search<ACC64>(psum, dead, lane, n, order, sb, pmin_p, pmax_p, limit, best_bits, bpo, kb);
             kvalid = ((uint32_t)lane & ((64u >> bpo) - 1)) == 0;
             kpart = (uint32_t)lane >> (6 - bpo);
         }
@@ -1273,30 +1428,32 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 
 // (samples above 16 bits are staged as int32: 33 KB of LDS per stereo block let four workgroups share a CU, so those forms
 // may use 128 registers -- the 64 that eight workgroups per CU allow cost them 25 spilled vector registers)
-template <bool MS, int NCH, int MAXO, bool ACC64>
-__global__ void __launch_bounds__((MS ? 4 : NCH) * 64, ACC64 ? 4 : 8)
-fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, FgBlockResult *results, FgDebugRec *dbg)
+template <bool MS, int NCH, int MAXO, bool ACC64, bool RAG>
+__global__ void __launch_bounds__((MS ? 4 : NCH) * 64, (ACC64 || RAG) ? 4 : 8)
+fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, FgBlockResult *results, FgDebugRec *dbg, uint32_t bi0)
 {
     constexpr int NC = MS ? 4 : NCH;
     constexpr int NT = NC * 64;
     typedef typename PipeTypes<ACC64>::samp_t samp_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t bi = blockIdx.x;
+    const uint32_t bi = blockIdx.x + bi0;
     const FgBlockDesc d = descs[bi];
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = rfl((uint32_t)tid >> 6);
-    const uint32_t sbytes = (((P.sig_stride + 128) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
+    const uint32_t sbytes = ((pipe_rows_elems(P.sig_stride, 64) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
     LDS samp_t *sL = (LDS samp_t *)smem;
     LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
     LDS uint32_t *xch = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes);
     if (tid == 0) xch[0] = 0;
     __syncthreads();
-    const uint32_t bad = pipe_stage<NCH, ACC64, NT>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, d.n >> 6);
+    const PipeGeo geo = RAG ? pipe_geo(d.n, 6, P.max_po, PipeTypes<ACC64>::PADE) : pipe_geo_regular(d.n >> 6, PipeTypes<ACC64>::PADE);
+    const uint32_t bad = pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, d.n >> 6, geo);
     if (bad) xch[0] = 1;            // (benign race: every writer stores the same value)
     __syncthreads();
     const uint32_t range_err = xch[0] ? FG_ERR_RANGE : 0;
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
-    pipe_eval_cand<MS, NCH, MAXO, ACC64>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, sL, sR, lane, range_err);
+    // (the ragged geometry -- tail blocks, odd block sizes -- is a kernel of its own: the regular one keeps its loops and registers)
+    pipe_eval_cand<MS, NCH, MAXO, ACC64, RAG>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, sL, sR, lane, range_err, geo);
 }
 
 // ================================================================================================ K5: pack
@@ -1344,8 +1501,8 @@ FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
     if (bitpos + bits - (b.wbase << 5) > 32u * b.fbw - 64u) cb_flush(b, lane, bitpos, false);
 }
 
-template <bool MS, int NCH, int MAXO, bool ACC64, int WS>
-__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : 5)
+template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG>
+__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : (RAG ? 4 : 5))
 fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
                     uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
 {
@@ -1365,13 +1522,16 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const uint32_t ws = (WS == 2 && n % 128 == 0 && n / 128 >= 32) ? 2u : 1u;
     const uint32_t LPS = 64 * ws;           // lanes (segments) per subframe
     const uint32_t si = wv / ws, hf = wv % ws;
-    const uint32_t seg = n / LPS, rstr = seg + PADE;
-    const uint32_t sbytes = (((P.sig_stride + 2 * 64 * WS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
+    // lane geometry (see PipeGeo): ragged blocks are packed by one wave per subframe
+    const PipeGeo geo = RAG ? pipe_geo(n, 6, P.max_po, PADE) : pipe_geo_regular(n / LPS, PADE);
+    constexpr bool rag = RAG;
+    const uint32_t seg = rag ? geo.base : n / LPS, rstr = geo.rstr;
+    const uint32_t sbytes = ((pipe_rows_elems(P.sig_stride, 64 * WS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
     LDS samp_t *sL = (LDS samp_t *)smem;
     LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
     LDS uint32_t *fbw = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes) + wv * (fbw_words + 2 + 64);
     LDS uint32_t *misc = fbw + fbw_words + 2;                 // 64 words per wave: header bytes, then the packer's scratch words
-    (void)pipe_stage<NCH, ACC64, NT>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg);
+    (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo);
     for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0;
     __syncthreads();
     if (wv >= (uint32_t)NCH * ws) return;           // (no barrier after this point)
@@ -1400,6 +1560,8 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
     const uint32_t Lg = hf * 64 + (uint32_t)lane;         // this lane's segment of the subframe
     const LDS samp_t *rowL = sL + Lg * rstr, *rowR = sR + Lg * rstr;
+    const PipeLane ln = pipe_lane<RAG>(geo, Lg, seg);
+    const LDS samp_t *prvL = sL + ln.prow * rstr + ln.plen, *prvR = sR + ln.prow * rstr + ln.plen;      // one past the samples in front
 
     ChunkBits fb;
     fb.w = fbw; fb.fbw = fbw_words; fb.cap_words = chunk_cap_words; fb.wbase = 0; fb.err = 0;
@@ -1542,7 +1704,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
-                if (Lg > 0) x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                if (Lg > 0) {
+                    if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
+                    else x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                }
                 h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
                 if constexpr (FGP_F64P && ACC64) hd[(MAXO - 1 - j) % MAXO] = (double)x;
             }
@@ -1616,8 +1781,9 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 #pragma unroll
                 for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
             }
+            // (ragged geometry: the first lanes of a group have one sample more than `seg`; at most MAXO steps either way)
 #pragma unroll
-            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+            for (int u = 0; u < MAXO; u++) if (s0 + u < (RAG ? ln.len : seg)) step(u, s0 + u, s0 == 0);
             if (emit && !atom) {
                 wave_lds_fence();
                 if (inrange) fb.w[cw] |= cur;
@@ -1629,11 +1795,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             typedef std::integral_constant<bool, true> T;
             typedef std::integral_constant<bool, false> F;
             if (!emit) return type == 1 ? walk_t(T(), F(), F(), F(), p0, inrange) : walk_t(F(), F(), F(), F(), p0, inrange);
-            if (seg < 32) return type == 1 ? walk_t(T(), T(), T(), F(), p0, inrange) : walk_t(F(), T(), T(), F(), p0, inrange);
+            if (rag || seg < 32) return type == 1 ? walk_t(T(), T(), T(), F(), p0, inrange) : walk_t(F(), T(), T(), F(), p0, inrange);
             if (all) return type == 1 ? walk_t(T(), T(), F(), T(), p0, true) : walk_t(F(), T(), F(), T(), p0, true);
             return type == 1 ? walk_t(T(), T(), F(), F(), p0, inrange) : walk_t(F(), T(), F(), F(), p0, inrange);
         };
-        const uint32_t mylen = walk(false, 0, false, false);
+        const uint32_t mylen0 = walk(false, 0, false, false);
+        const uint32_t mylen = ln.act ? mylen0 : 0u;                 // (idle lanes of the ragged geometry code nothing)
         if (__any(mylen > (1u << 24))) redo = true;                  // absurd code lengths: the generic kernel copes
         if (!redo) {
             const uint32_t incl = wave_scan_add(mylen);
@@ -1649,7 +1816,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 const uint32_t cnt = (~shifted) ? (uint32_t)__builtin_ctzll(~shifted) : 64u - a;
                 if (cnt == 0) { redo = true; break; }
                 const uint32_t b = a + cnt;
-                (void)walk(true, mystart, (uint32_t)lane >= a && (uint32_t)lane < b, a == 0 && b == 64);
+                (void)walk(true, mystart, ln.act && (uint32_t)lane >= a && (uint32_t)lane < b, a == 0 && b == 64 && !rag);
                 wave_lds_fence();
                 a = b;
             }
