@@ -133,6 +133,46 @@ def api_e2e(seconds, sr):
         out['md5_on' if md5 else 'md5_off'] = {'encode_msamples_per_s': round(pcm.size / best_e / 1e6, 1),
                                                'decode_msamples_per_s': round(pcm.size / best_d / 1e6, 1)}
     out['sample'] = '%.0f s stereo 16-bit numpy array through pyflac_amd.StreamEncoder / StreamDecoder, best of 2' % seconds
+    # ---- the streaming use of the class (pyflac/encoder.py:234-330, examples/stream.py): process() in small calls.  Every call is
+    # a launch of the encoder's kernels and a wait; rate and per-call latency for calls of 1024 .. 65536 frames (MD5 on, as
+    # pyFLAC has it), over 20 s of the stream
+    small = {}
+    part = pcm[:min(len(pcm), 20 * sr)]
+    for frames in (1024, 4096, 16384, 65536):
+        enc = pyflac_amd.StreamEncoder(sr, lambda b, n, s, f: None, compression_level=5, blocksize=4096)
+        enc.process(part[:frames])          # (initialisation and the first launch stay outside)
+        lat = []
+        t0 = time.perf_counter()
+        for a in range(frames, len(part) - frames + 1, frames):
+            tc = time.perf_counter()
+            enc.process(part[a:a + frames])
+            lat.append(time.perf_counter() - tc)
+        dt = time.perf_counter() - t0
+        enc.finish()
+        lat.sort()
+        small[str(frames)] = {'encode_msamples_per_s': round(len(lat) * frames * 2 / dt / 1e6, 1), 'calls': len(lat),
+                              'call_ms_median': round(lat[len(lat) // 2] * 1e3, 3), 'call_ms_p95': round(lat[int(len(lat) * 0.95)] * 1e3, 3)}
+    out['process_call_size'] = small
+    # ---- many streams at once: MD5 is serial per stream (0.4 G samples/s), so the class scales with the number of streams:
+    # 16 StreamEncoders on 16 threads, MD5 on, 60 s each (the library calls release the GIL)
+    import threading
+    nthreads, secs = 16, min(seconds, 60.0)
+    parts = [synth.config5_stream(k, secs, sr) for k in range(nthreads)]
+    encs = [pyflac_amd.StreamEncoder(sr, lambda b, n, s, f: None, compression_level=5, blocksize=4096) for _ in range(nthreads)]
+    for e, x in zip(encs, parts):
+        e.process(x[:4096])
+    def work(e, x):
+        e.process(x[4096:])
+        e.finish()
+    th = [threading.Thread(target=work, args=(e, x)) for e, x in zip(encs, parts)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    out['many_streams'] = {'streams': nthreads, 'seconds_each': secs, 'md5': 'on',
+                           'encode_msamples_per_s': round(sum(x[4096:].size for x in parts) / dt / 1e6, 1)}
     return out
 
 

@@ -482,11 +482,13 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
 __device__ __forceinline__ uint32_t wr_goff(uint32_t g, uint32_t xr) { return (g << 4) ^ xr; }
 
 // Eight steps of the 8-tap recurrence as one block of assembly: per sample v_mul_i32_i24 + 7 v_mad_i32_i24 (one chain -- a lone
-// wave issues an instruction every ~4.5 cycles whether or not it depends on the last one), the shift, the add that makes the
-// sample and puts it into its history slot.  Ten instructions a sample.  Written out because the compiler does not: left
-// alone it builds the sum from v_mul_i32_i24 and v_add3_u32 (three instructions for two taps), and a mad given to it one
-// asm statement at a time is followed by a pad s_nop each.
-__device__ __forceinline__ void wr_group8_asm(int32_t (&h)[16], const int32_t (&q)[16], int shift, const int32_t (&r)[8])
+// wave issues an instruction every ~4.5 cycles whether or not it depends on the last one), the shift, the add that turns the
+// residual into the sample IN PLACE.  Ten instructions a sample.  n[0..7] come in as the eight residuals (the registers of two
+// 16-byte LDS reads) and go out as the eight samples (the registers of two 16-byte LDS writes, and the history of the next
+// group): no register moves around the block.  Written out because the compiler does not: left alone it builds the sum from
+// v_mul_i32_i24 and v_add3_u32 (three instructions for two taps), and a mad given to it one asm statement at a time is
+// followed by a pad s_nop each.
+__device__ __forceinline__ void wr_group8_asm(const int32_t (&h)[16], const int32_t (&q)[16], int shift, int32_t (&n)[8])
 {
     int32_t t;
     asm volatile("v_mul_i32_i24 %[t], %[q7], %[h0]\n"
@@ -498,7 +500,7 @@ __device__ __forceinline__ void wr_group8_asm(int32_t (&h)[16], const int32_t (&
                  "v_mad_i32_i24 %[t], %[q1], %[h6], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q0], %[h7], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h0], %[r0], %[t]\n"
+                 "v_add_u32 %[n0], %[n0], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h1]\n"
                  "v_mad_i32_i24 %[t], %[q6], %[h2], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q5], %[h3], %[t]\n"
@@ -506,74 +508,74 @@ __device__ __forceinline__ void wr_group8_asm(int32_t (&h)[16], const int32_t (&
                  "v_mad_i32_i24 %[t], %[q3], %[h5], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q2], %[h6], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q1], %[h7], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n0], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h1], %[r1], %[t]\n"
+                 "v_add_u32 %[n1], %[n1], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h2]\n"
                  "v_mad_i32_i24 %[t], %[q6], %[h3], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q5], %[h4], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q4], %[h5], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q3], %[h6], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q2], %[h7], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q1], %[h0], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n1], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h2], %[r2], %[t]\n"
+                 "v_add_u32 %[n2], %[n2], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h3]\n"
                  "v_mad_i32_i24 %[t], %[q6], %[h4], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q5], %[h5], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q4], %[h6], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q3], %[h7], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q2], %[h0], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q1], %[h1], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n2], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h3], %[r3], %[t]\n"
+                 "v_add_u32 %[n3], %[n3], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h4]\n"
                  "v_mad_i32_i24 %[t], %[q6], %[h5], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q5], %[h6], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q4], %[h7], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q3], %[h0], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q2], %[h1], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q1], %[h2], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n3], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h4], %[r4], %[t]\n"
+                 "v_add_u32 %[n4], %[n4], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h5]\n"
                  "v_mad_i32_i24 %[t], %[q6], %[h6], %[t]\n"
                  "v_mad_i32_i24 %[t], %[q5], %[h7], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q4], %[h0], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q3], %[h1], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q2], %[h2], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q1], %[h3], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n4], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h5], %[r5], %[t]\n"
+                 "v_add_u32 %[n5], %[n5], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h6]\n"
                  "v_mad_i32_i24 %[t], %[q6], %[h7], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q5], %[h0], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q4], %[h1], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q3], %[h2], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q2], %[h3], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q1], %[h4], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n5], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h6], %[r6], %[t]\n"
+                 "v_add_u32 %[n6], %[n6], %[t]\n"
                  "v_mul_i32_i24 %[t], %[q7], %[h7]\n"
-                 "v_mad_i32_i24 %[t], %[q6], %[h0], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q5], %[h1], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q4], %[h2], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q3], %[h3], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q2], %[h4], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q1], %[h5], %[t]\n"
-                 "v_mad_i32_i24 %[t], %[q0], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n6], %[t]\n"
                  "v_ashrrev_i32 %[t], %[sh], %[t]\n"
-                 "v_add_u32 %[h7], %[r7], %[t]\n"
-                 : [t] "=&v"(t), [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [h4] "+v"(h[4]), [h5] "+v"(h[5]),
-                   [h6] "+v"(h[6]), [h7] "+v"(h[7])
+                 "v_add_u32 %[n7], %[n7], %[t]\n"
+                 : [t] "=&v"(t), [n0] "+v"(n[0]), [n1] "+v"(n[1]), [n2] "+v"(n[2]), [n3] "+v"(n[3]), [n4] "+v"(n[4]), [n5] "+v"(n[5]),
+                   [n6] "+v"(n[6]), [n7] "+v"(n[7])
                  : [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [q4] "v"(q[4]), [q5] "v"(q[5]), [q6] "v"(q[6]), [q7] "v"(q[7]),
-                   [sh] "v"(shift), [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [r4] "v"(r[4]), [r5] "v"(r[5]),
-                   [r6] "v"(r[6]), [r7] "v"(r[7]));
+                   [sh] "v"(shift), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]),
+                   [h6] "v"(h[6]), [h7] "v"(h[7]));
 }
 
 // MAXO samples from sample index i0 of the tile (a multiple of MAXO)
@@ -588,10 +590,12 @@ __device__ __forceinline__ void wr_group(int32_t (&h)[16], const int32_t (&q)[16
         r[u] = (int32_t)t.x; r[u + 1] = (int32_t)t.y; r[u + 2] = (int32_t)t.z; r[u + 3] = (int32_t)t.w;
     }
     if constexpr (MAXO == 8 && !WIDE && !GATE) {
-        const int32_t r8[8] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
-        wr_group8_asm(h, q, shift, r8);
-        *(uint4 *)(rowb + wr_goff(i0 >> 2, xr)) = make_uint4((uint32_t)h[0], (uint32_t)h[1], (uint32_t)h[2], (uint32_t)h[3]);
-        *(uint4 *)(rowb + wr_goff((i0 + 4) >> 2, xr)) = make_uint4((uint32_t)h[4], (uint32_t)h[5], (uint32_t)h[6], (uint32_t)h[7]);
+        int32_t n8[8] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]};
+        wr_group8_asm(h, q, shift, n8);
+#pragma unroll
+        for (int u = 0; u < 8; u++) h[u] = n8[u];
+        *(uint4 *)(rowb + wr_goff(i0 >> 2, xr)) = make_uint4((uint32_t)n8[0], (uint32_t)n8[1], (uint32_t)n8[2], (uint32_t)n8[3]);
+        *(uint4 *)(rowb + wr_goff((i0 + 4) >> 2, xr)) = make_uint4((uint32_t)n8[4], (uint32_t)n8[5], (uint32_t)n8[6], (uint32_t)n8[7]);
         return;
     }
 #pragma unroll
@@ -637,10 +641,12 @@ __device__ __forceinline__ void wr_tile(int32_t (&h)[16], const int32_t (&q)[16]
         for (int g = 0; g < 8; g++) {
             uint4 na = ra, nb = rb;
             if (g < 7) { na = *(const uint4 *)(rowb + wr_goff(2 * g + 2, xr)); nb = *(const uint4 *)(rowb + wr_goff(2 * g + 3, xr)); }
-            const int32_t r8[8] = {(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y, (int32_t)rb.z, (int32_t)rb.w};
-            wr_group8_asm(h, q, shift, r8);
-            *(uint4 *)(rowb + wr_goff(2 * g, xr)) = make_uint4((uint32_t)h[0], (uint32_t)h[1], (uint32_t)h[2], (uint32_t)h[3]);
-            *(uint4 *)(rowb + wr_goff(2 * g + 1, xr)) = make_uint4((uint32_t)h[4], (uint32_t)h[5], (uint32_t)h[6], (uint32_t)h[7]);
+            int32_t n8[8] = {(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, (int32_t)ra.w, (int32_t)rb.x, (int32_t)rb.y, (int32_t)rb.z, (int32_t)rb.w};
+            wr_group8_asm(h, q, shift, n8);
+#pragma unroll
+            for (int u = 0; u < 8; u++) h[u] = n8[u];
+            *(uint4 *)(rowb + wr_goff(2 * g, xr)) = make_uint4((uint32_t)n8[0], (uint32_t)n8[1], (uint32_t)n8[2], (uint32_t)n8[3]);
+            *(uint4 *)(rowb + wr_goff(2 * g + 1, xr)) = make_uint4((uint32_t)n8[4], (uint32_t)n8[5], (uint32_t)n8[6], (uint32_t)n8[7]);
             ra = na; rb = nb;
         }
     }
@@ -677,7 +683,8 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
             const FgDecFrame fr = frames[f];
             if (fr.bytes != 0 && fr.channels == C) {
                 n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off;
-                const uint32_t cw = results[f].crc;
+                // (interleave bit 11: the CRC pass is still running beside this kernel, fg_dec_fix_kernel merges its verdict)
+                const uint32_t cw = (interleave & 0x800) ? 0u : results[f].crc;
                 if (status == 0 && (cw & 0x80000000u)) status = 2;          // CRC-16 mismatch (fg_dec_crc_kernel)
             }
         }
@@ -705,7 +712,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     }
     __syncthreads();
     // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])
-    if (wave == 0 && mine && ch == 0) {
+    if (wave == 0 && mine && ch == 0 && !(interleave & 0x800)) {
         const FgDecFrame fr = frames[f];
         if (fr.bytes != 0 && fr.channels == C && fr.n != 0) {
             uint32_t status = results[f].err;

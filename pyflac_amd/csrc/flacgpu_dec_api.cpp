@@ -463,11 +463,24 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         d_prof = (unsigned long long *)c->dec_prof.p;
         (void)hipMemsetAsync(d_prof, 0, (size_t)npad * 2 * 8 * 8, c->stream);
     }
-    // the CRC-16 pass only needs the stream and the frame table: it runs on the side stream beside the parse kernel
-    bool forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
-    if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
-                             (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
-    if (forked && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
+    // The CRC-16 pass only needs the stream and the frame table: it runs on the side stream beside the parse kernel.
+    static const int wave_parse = getenv("FLACGPU_DEC_WAVE") ? atoi(getenv("FLACGPU_DEC_WAVE")) : 1;     // 0: the lane-serial fused kernel of round 2
+    static const bool old_restore = getenv("FLACGPU_DEC_WRESTORE") && atoi(getenv("FLACGPU_DEC_WRESTORE")) == 0;
+    static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
+    static const bool prof_fused = getenv("FLACGPU_DEC_PROF") && atoi(getenv("FLACGPU_DEC_PROF")) == 2;
+    const bool fused = !wave_parse && !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
+    // (measured: beside the restore kernel the CRC pass slows that kernel's lone recurrence waves down by more than it gave
+    // the parse kernel back -- 136 + 159 us against 123 + 163 --, so it stays beside the parse kernel; FLACGPU_DEC_CRC_LATE=1 tries
+    // the other order)
+    static const bool crc_late_on = getenv("FLACGPU_DEC_CRC_LATE") && atoi(getenv("FLACGPU_DEC_CRC_LATE")) != 0;
+    const bool crc_late = crc_late_on && wave_parse && !old_restore && !fused;
+    bool forked = false;
+    if (!crc_late) {
+        forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
+        if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
+                                 (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+        if (forked && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
+    }
     uint16_t *d_rparams = nullptr;
     if (detail && detail->level >= 1) {
         if (!c->dec_rparams.ensure((size_t)npad * C * FG_DEC_RPARAMS * 2) || !c->dec_warm.ensure((size_t)npad * C * 32 * 4)) return false;
@@ -477,10 +490,6 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     }
     // One fused kernel (parse -> residuals -> recurrence -> output through LDS), or, when the residual planes themselves are
     // wanted (subframe detail level 2) or with FLACGPU_DEC_FUSED=0, the two-kernel version with the plane in HBM.
-    static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
-    static const bool prof_fused = getenv("FLACGPU_DEC_PROF") && atoi(getenv("FLACGPU_DEC_PROF")) == 2;
-    static const int wave_parse = getenv("FLACGPU_DEC_WAVE") ? atoi(getenv("FLACGPU_DEC_WAVE")) : 1;     // 0: the lane-serial fused kernel of round 2
-    const bool fused = !wave_parse && !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
     if (fused) {
         if (fg_launch_decode_fused((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
                                    (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams,
@@ -512,11 +521,27 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             fg_set_error("decode kernel launch failed"); return false;
         }
         if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-        static const bool old_restore = getenv("FLACGPU_DEC_WRESTORE") && atoi(getenv("FLACGPU_DEC_WRESTORE")) == 0;
-        if (wave_parse && !old_restore) {
+        if (wave_parse && !old_restore && !crc_late) {
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
                                           (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, interleave ? 1u : 0u, wide, c->stream) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
+            }
+        }
+        else if (crc_late) {
+            // parse done: the CRC pass starts on the side stream, the restore kernel (told not to look at the verdict) beside it
+            const bool fk = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
+            if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
+                                     (const uint16_t *)c->crctab.p, fk ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+            if (fk && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
+            if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream) != 0) {
+                fg_set_error("decode kernel launch failed"); return false;
+            }
+            if (fk) {
+                if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+                if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
+                    fg_set_error("decode kernel launch failed"); return false;
+                }
             }
         }
         else if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,

@@ -44,6 +44,38 @@ BENCH_BEGIN(k_dep_mad24)
     asm volatile(".rept " STR(REP) "\n v_mad_i32_i24 %0, %1, %2, %0\n .endr" : "+v"(a) : "v"(b), "v"(c));
 BENCH_END
 
+
+BENCH_BEGIN(k_indep_mad24)
+    asm volatile(".rept " STR(REP) "\n v_mad_i32_i24 %0, %2, %3, %0\n v_mad_i32_i24 %1, %2, %3, %1\n .endr" : "+v"(a), "+v"(d) : "v"(b), "v"(c));
+BENCH_END
+
+BENCH_BEGIN(k_dep_mad_i32_i16)
+    asm volatile(".rept " STR(REP) "\n v_mad_i32_i16 %0, %1, %2, %0\n .endr" : "+v"(a) : "v"(b), "v"(c));
+BENCH_END
+
+BENCH_BEGIN(k_dep_dot2_i32_i16)
+    asm volatile(".rept " STR(REP) "\n v_dot2_i32_i16 %0, %1, %2, %0\n .endr" : "+v"(a) : "v"(b), "v"(c));
+BENCH_END
+
+BENCH_BEGIN(k_dep_fma_f32)
+    float fx = (float)a;
+    asm volatile(".rept " STR(REP) "\n v_fma_f32 %0, %1, %2, %0\n .endr" : "+v"(fx) : "v"(b), "v"(c));
+    a = (uint32_t)fx;
+BENCH_END
+
+BENCH_BEGIN(k_recur8)
+    // one sample of the decoder's 8-tap recurrence: mul + 7 mad (24-bit) + shift + add
+    asm volatile(".rept " STR(REP) "\n v_mul_i32_i24 %1, %2, %0\n v_mad_i32_i24 %1, %3, %0, %1\n v_mad_i32_i24 %1, %2, %0, %1\n v_mad_i32_i24 %1, %3, %0, %1\n"
+                 " v_mad_i32_i24 %1, %2, %0, %1\n v_mad_i32_i24 %1, %3, %0, %1\n v_mad_i32_i24 %1, %2, %0, %1\n v_mad_i32_i24 %1, %3, %0, %1\n"
+                 " v_ashrrev_i32 %1, 14, %1\n v_add_u32 %0, %0, %1\n .endr" : "+v"(a), "+v"(d) : "v"(b), "v"(c));
+BENCH_END
+
+BENCH_BEGIN(k_recur8_dot2)
+    // the same with v_dot2_i32_i16: 4 dot2 + shift + add
+    asm volatile(".rept " STR(REP) "\n v_dot2_i32_i16 %1, %2, %0, 0\n v_dot2_i32_i16 %1, %3, %0, %1\n v_dot2_i32_i16 %1, %2, %0, %1\n v_dot2_i32_i16 %1, %3, %0, %1\n"
+                 " v_ashrrev_i32 %1, 14, %1\n v_add_u32 %0, %0, %1\n .endr" : "+v"(a), "+v"(d) : "v"(b), "v"(c));
+BENCH_END
+
 BENCH_BEGIN(k_dep_mul_lo)
     asm volatile(".rept " STR(REP) "\n v_mul_lo_u32 %0, %0, %1\n .endr" : "+v"(a) : "v"(b));
 BENCH_END
@@ -373,6 +405,7 @@ int main()
     struct { const char *name; kern_t k; int per; } tests[] = {
         {"dependent v_add_u32", k_dep_add, 1}, {"independent v_add_u32 (x2)", k_indep_add, 2},
         {"dependent alignbit+ffbh (x2)", k_dep_alignbit_ffbh, 2}, {"dependent v_mad_i32_i24", k_dep_mad24, 1},
+        {"independent v_mad_i32_i24 (x2)", k_indep_mad24, 2}, {"dependent v_mad_i32_i16", k_dep_mad_i32_i16, 1}, {"dependent v_dot2_i32_i16", k_dep_dot2_i32_i16, 1}, {"dependent v_fma_f32", k_dep_fma_f32, 1}, {"recurrence sample: mul + 7 mad24 + shift + add (x10)", k_recur8, 10}, {"recurrence sample: 4 dot2 + shift + add (x6)", k_recur8_dot2, 6},
         {"dependent v_mul_lo_u32", k_dep_mul_lo, 1}, {"dependent v_mad_u64_u32", k_dep_mad_u64_u32, 1},
         {"dependent v_lshlrev_b64", k_dep_lshl64, 1}, {"dependent v_fma_f64", k_dep_fma64, 1}, {"independent v_fma_f64 (x2)", k_indep_fma64, 2},
         {"v_cmp + v_cndmask (x2)", k_cmp_cndmask, 2}, {"v_cmp + saveexec + v_add + s_or (x4)", k_cmp_saveexec, 4},
