@@ -637,6 +637,15 @@ FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *e
 int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uint64_t *frame_offsets, uint64_t capacity,
                              FLAC__StreamMetadata_StreamInfo *streaminfo, uint64_t *audio_offset);
 
+/* Diagnostic (host only, no GPU): what libFLAC 1.4.3's serial reader makes of a possibly damaged stream when its read
+ * callback answers with at most read_size bytes -- the replay the stream decoder runs wherever the GPU pass rejects a frame
+ * (csrc/fg_refwalk.h; stream_decoder.c frame_sync_ / read_frame_, bitreader.c's 8 KiB buffer and its
+ * FLAC__bitreader_rewind_to_after_last_seen_framesync).  errors: the FLAC__StreamDecoderErrorStatus sequence; frames: pairs
+ * {first sample number, block size} of the frames that decode.  Returns the number of error statuses, negative without a
+ * readable metadata section. */
+int64_t flacgpu_refwalk_probe(const uint8_t *stream, uint64_t len, uint32_t read_size, uint32_t *errors, uint64_t errors_cap,
+                              uint64_t *frames, uint64_t frames_cap, uint64_t *nframes);
+
 #ifdef __cplusplus
 }
 #endif

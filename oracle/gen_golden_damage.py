@@ -20,20 +20,33 @@ from oracle import libflac_ref as R  # noqa: E402
 from tests import cases  # noqa: E402
 
 
+def record(data, read_size):
+    """What the callbacks see, in order: per delivered frame its sample number, block size and a hash of the samples; the
+    error statuses; and `events`, the two interleaved ('f<sample number>' / 'e<status>')."""
+    pcm, frames, st = R.decode(data, read_size=read_size)
+    pos = 0
+    fr = []
+    for f in frames:
+        blk = pcm[pos:pos + f['blocksize']]
+        pos += f['blocksize']
+        fr.append([int(f['sample_number']), int(f['blocksize']),
+                   hashlib.sha256(np.ascontiguousarray(blk, np.int32).tobytes()).hexdigest()[:16]])
+    return {'errors': [int(e) for e in st['errors']], 'frames': fr, 'state': int(st['state']), 'events': st['events']}
+
+
 def main():
     out = {}
     for name in sorted(cases.DAMAGE_CASES):
         data = cases.damaged_stream(name)
-        pcm, frames, st = R.decode(data)
-        pos = 0
-        fr = []
-        for f in frames:
-            blk = pcm[pos:pos + f['blocksize']]
-            pos += f['blocksize']
-            fr.append([int(f['sample_number']), int(f['blocksize']),
-                       hashlib.sha256(np.ascontiguousarray(blk, np.int32).tobytes()).hexdigest()[:16]])
-        out[name] = {'errors': [int(e) for e in st['errors']], 'frames': fr, 'state': int(st['state'])}
-        print('%-28s frames %3d errors %s' % (name, len(fr), out[name]['errors']))
+        for rs in cases.DAMAGE_READ_SIZES:
+            key = name if rs == 8192 else '%s@%d' % (name, rs)
+            out[key] = record(data, rs)
+            print('%-28s frames %3d errors %s' % (key, len(out[key]['frames']), out[key]['errors']))
+    for seed in cases.DAMAGE_FUZZ_SEEDS:
+        src, data, rs = cases.fuzz_damaged_stream(seed)
+        out['fuzz%d' % seed] = record(data, rs)
+        out['fuzz%d' % seed]['sha'] = hashlib.sha256(data).hexdigest()[:16]      # (the damaged stream itself, to pin the generator)
+        print('%-28s %-8s read %5d frames %3d errors %s' % ('fuzz%d' % seed, src, rs, len(out['fuzz%d' % seed]['frames']), out['fuzz%d' % seed]['errors']))
     md5 = {}
     for name in sorted(cases.MD5_CASES):
         _pcm, frames, st = R.decode(cases.md5_stream(name), md5_checking=cases.MD5_CASES[name][2])

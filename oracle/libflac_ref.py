@@ -262,7 +262,7 @@ def decode(data, read_size=8192, want_frames=True, md5_checking=False):
     L = lib()
     dec = C.c_void_p(L.FLAC__stream_decoder_new())
     pos = [0]
-    blocks, frames, errors = [], [], []
+    blocks, frames, errors, events = [], [], [], []
 
     def _r(d, buf, pn, cd):
         n = min(pn[0], len(data) - pos[0], read_size)
@@ -280,6 +280,7 @@ def decode(data, read_size=8192, want_frames=True, md5_checking=False):
         ch = [np.ctypeslib.as_array(bufs[c], shape=(h.blocksize,)).copy()
               for c in range(h.channels)]
         blocks.append(np.stack(ch, axis=1))
+        events.append('f%d' % h.number.sample_number)
         if want_frames:
             frames.append({
                 'blocksize': h.blocksize, 'sample_rate': h.sample_rate,
@@ -293,6 +294,7 @@ def decode(data, read_size=8192, want_frames=True, md5_checking=False):
 
     def _e(d, status, cd):
         errors.append(status)
+        events.append('e%d' % status)
 
     rcb, wcb, ecb = DEC_READ_CB(_r), DEC_WRITE_CB(_w), DEC_ERROR_CB(_e)
     if md5_checking:
@@ -305,4 +307,4 @@ def decode(data, read_size=8192, want_frames=True, md5_checking=False):
     fin = L.FLAC__stream_decoder_finish(dec)
     L.FLAC__stream_decoder_delete(dec)
     pcm = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, 1), np.int32)
-    return pcm, frames, {'errors': errors, 'ok': bool(ok), 'state': state, 'finish': bool(fin)}
+    return pcm, frames, {'errors': errors, 'ok': bool(ok), 'state': state, 'finish': bool(fin), 'events': events}

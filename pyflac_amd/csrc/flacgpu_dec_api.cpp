@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "fg_host.h"
+#include "fg_refwalk.h"
 
 extern "C" {
 const char *const FLAC__StreamDecoderStateString[] = {
@@ -319,6 +320,45 @@ struct Indexer {
 extern "C" int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *d_frame_offsets,
                                          uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,
                                          uint64_t pcm_capacity_samples, void *h_frame_status, flacgpu_decode_stats *stats);
+
+// Test entry of fg_refwalk.h (no device involved): the error statuses and the frames libFLAC 1.4.3 would deliver for a whole
+// stream read in answers of `read_size` bytes.  frames[2 i] = sample number, frames[2 i + 1] = block size of the i-th frame
+// that decodes; returns the number of errors (negative: not a FLAC stream), *nframes the number of frames.
+extern "C" int64_t flacgpu_refwalk_probe(const uint8_t *stream, uint64_t len, uint32_t read_size, uint32_t *errors, uint64_t errors_cap,
+                                         uint64_t *frames, uint64_t frames_cap, uint64_t *nframes)
+{
+    FLAC__StreamMetadata_StreamInfo si;
+    memset(&si, 0, sizeof si);
+    bool have = false;
+    const int64_t a = parse_metadata(stream, len, &si, &have);
+    if (a <= 0) return -1;
+    fgref::RefWindows win;
+    for (uint64_t e = read_size; e < len; e += read_size) win.chunk_end.push_back(e);
+    win.chunk_end.push_back(len);
+    win.eof = true;
+    fgref::Walker w;
+    w.d = stream; w.len = len; w.abs0 = 0; w.final = true; w.win = &win;
+    w.si.have = have; w.si.min_blocksize = si.min_blocksize; w.si.max_blocksize = si.max_blocksize; w.si.sample_rate = si.sample_rate;
+    w.si.channels = si.channels; w.si.bps = si.bits_per_sample; w.si.total_samples = si.total_samples;
+    std::vector<uint32_t> errs;
+    uint64_t p = (uint64_t)a, nf = 0, decoded = 0;
+    for (;;) {
+        if (have && si.total_samples && decoded >= si.total_samples) break;
+        fgref::Header h;
+        bool ended = false;
+        uint64_t fend = 0;
+        const uint64_t s = w.run(p, false, errs, &h, &ended, &fend);
+        if (ended || s >= len) break;
+        if (nf < frames_cap / 2) { frames[2 * nf] = h.sample_number; frames[2 * nf + 1] = h.blocksize; }
+        nf++;
+        if (!w.fixed_blocksize && !h.is_sample_number) w.fixed_blocksize = (have && si.min_blocksize == si.max_blocksize) ? si.min_blocksize : h.blocksize;
+        decoded = h.sample_number + h.blocksize;
+        p = fend;
+    }
+    *nframes = nf;
+    for (size_t i = 0; i < errs.size() && i < errors_cap; i++) errors[i] = errs[i];
+    return (int64_t)errs.size();
+}
 
 extern "C" int64_t flacgpu_index_frames(const uint8_t *stream, uint64_t len, uint64_t *frame_offsets, uint64_t capacity,
                                         FLAC__StreamMetadata_StreamInfo *streaminfo, uint64_t *audio_offset)
@@ -762,7 +802,6 @@ struct DecImpl {
     bool have_meta, have_si;
     FLAC__StreamMetadata_StreamInfo si;
     Indexer ix;
-    size_t errors_reported;
     uint64_t frames_delivered_bound;  // index into ix.bounds of the next frame to decode
     uint64_t samples_decoded;
     // decoded frames waiting for delivery
@@ -783,6 +822,15 @@ struct DecImpl {
     // FLAC__Frame.subframes[] of the frame being delivered
     int subframe_detail = 1;      // flacgpu_stream_decoder_set_subframe_detail
     DecDetail detail;
+    // Damaged data (fg_refwalk.h): where the index or the GPU pass finds anything irregular, the frames before that place are
+    // delivered and libFLAC's serial reader is replayed on the host from there -- its error statuses, in order, and the frame it
+    // decodes next, where the index takes over again.
+    fgref::RefWindows win;        // the answers of the read callback, as the refills of libFLAC's 8 KiB reader would have seen them
+    fgref::Walker walker;         // (its state at the end of the stream)
+    bool walk_pending = false;
+    uint64_t walk_from = 0;       // offset in buf
+    uint64_t ix_origin = 0;       // offset in buf where the index last started outside a frame
+    uint64_t walk_stuck_at = UINT64_MAX;
     FLAC__EntropyCodingMethod_PartitionedRiceContents rice_contents[8];
     std::vector<uint32_t> rice_prm[8], rice_raw[8];
 };
@@ -795,10 +843,11 @@ void reset_stream(DecImpl *d)
     d->buf.clear(); d->consumed_total = 0; d->eof = false; d->have_meta = false; d->have_si = false;
     memset(&d->si, 0, sizeof d->si);
     d->ix = Indexer();
-    d->errors_reported = 0; d->frames_delivered_bound = 0; d->samples_decoded = 0;
+    d->frames_delivered_bound = 0; d->samples_decoded = 0;
     d->frames.clear(); d->status.clear(); d->next_frame = 0; d->last_blocksize = 0; d->last_ca = 0;
     d->do_md5 = d->md5_checking != 0; d->md5.init();
     d->first_pos = 0; d->fixed_blocksize = 0; d->last_set = false; memset(&d->last_hdr, 0, sizeof d->last_hdr);
+    d->win = fgref::RefWindows(); d->walker = fgref::Walker(); d->walk_pending = false; d->walk_from = 0; d->ix_origin = 0; d->walk_stuck_at = UINT64_MAX;
 }
 
 // Pull more bytes.  Returns false on abort.  Sets d->eof at end of stream.  `short_read` reports that the
@@ -814,6 +863,7 @@ bool pull(DecImpl *d, bool *short_read)
         got = fread(d->buf.data() + old, 1, want, d->file);
         d->buf.resize(old + got);
         if (got == 0) d->eof = true;
+        else d->win.chunk_end.push_back(d->consumed_total + d->buf.size());
         *short_read = false;
         return true;
     }
@@ -831,17 +881,10 @@ bool pull(DecImpl *d, bool *short_read)
     if (rs == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { d->buf.resize(old); d->state = FLAC__STREAM_DECODER_ABORTED; return false; }
     if (got > want) got = want;
     d->buf.resize(old + got);
+    if (got) d->win.chunk_end.push_back(d->consumed_total + d->buf.size());
     if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || got == 0) d->eof = true;
     *short_read = got < want;
     return true;
-}
-
-void report_errors(DecImpl *d)
-{
-    while (d->errors_reported < d->ix.errors.size()) {
-        if (d->error_cb) d->error_cb(&d->pub, (FLAC__StreamDecoderErrorStatus)d->ix.errors[d->errors_reported], d->client);
-        d->errors_reported++;
-    }
 }
 
 // Hand the metadata blocks of d[4 .. end) to the metadata callback, in stream order, filtered the way libFLAC's
@@ -1007,6 +1050,7 @@ bool ensure_metadata(DecImpl *d)
         if (a < 0) {
             // libFLAC keeps searching for "fLaC" and reports LOST_SYNC; a stream that never shows it ends in error
             if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
+            d->consumed_total += d->buf.size();
             d->buf.clear();
             if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
             if (d->state == FLAC__STREAM_DECODER_ABORTED) return false;
@@ -1118,32 +1162,21 @@ bool write_frame(DecImpl *d, const FLAC__Frame &f, const int32_t *const chan[])
 
 // Deliver one queued frame.  Returns false when the client aborted.
 //
-// Damage handling follows what clients of libFLAC 1.4.3 observe (tests/golden/damage_vectors.json, recorded from the
-// reference's binary): a frame that fails its CRC-16 or does not parse is reported through the error callback and NOT
-// delivered; when the next good frame's sample number shows a gap behind the last delivered frame, frames of silence
-// with the last frame's header fill it (at most 5 s / 50 frames, only between frames of the same format), so the time
-// line is kept.  Nothing is filled before the first delivered frame or after the last one.
+// Damage handling is libFLAC 1.4.3's, callback for callback (tests/golden/damage_vectors.json, recorded from the reference's
+// binary): fill_queue ends the queue in front of the first place the index or the GPU pass rejects and replays libFLAC's serial
+// reader from there on the host (walk_damage, fg_refwalk.h) -- which error statuses it reports, in which order, and which frame it
+// decodes next.  A damaged frame is NOT delivered; when the next good frame's sample number shows a gap behind the last delivered
+// frame, frames of silence with the last frame's header fill it (at most 5 s / 50 frames, only between frames of the same
+// format), so the time line is kept.  Nothing is filled before the first delivered frame or after the last one.
 bool deliver_one(DecImpl *d)
 {
     const FgDecFrame &fr = d->frames[d->next_frame];
     const FgDecResult &rs = d->status[d->next_frame];
     d->next_frame++;
     const uint64_t fpos = d->first_pos + fr.byte_off;
-    if (rs.err == 1 || rs.err == 5) {
-        // header or contents malformed: a region that starts with a sync code was tried as a header first
-        const bool synced = fpos + 1 < d->buf.size() && d->buf[fpos] == 0xFF && (d->buf[fpos + 1] & 0xFE) == 0xF8;
-        if (d->error_cb && !fr.n && synced) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER, d->client);
+    if (rs.err != 0 && rs.err != 3) {
+        // (not reached: fill_queue ends the queue in front of a frame the GPU pass rejects and replays libFLAC's reader from there)
         if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
-        return true;
-    }
-    if (rs.err == 4 && d->eof && fpos + fr.bytes >= d->buf.size()) return true;     // cut short by the end of the stream: libFLAC just ends
-    if (rs.err == 2 || rs.err == 4) {
-        // (a frame whose residual is damaged still parses to some end, where libFLAC finds a CRC-16 that does not match)
-        // libFLAC re-searches from just behind the damaged frame's sync code, which reports a loss of sync as well
-        if (d->error_cb) {
-            d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, d->client);
-            d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
-        }
         return true;
     }
     FLAC__Frame f;
@@ -1261,12 +1294,75 @@ void fill_subframes(DecImpl *d, FLAC__Frame &f, const FgDecFrame &fr, uint32_t f
     }
 }
 
+// Replay libFLAC's reader from d->walk_from (fg_refwalk.h): report what it reports, and let the index take over at the frame it
+// decodes next.  Returns false when the stream ended (or the client aborted).
+bool walk_damage(DecImpl *d)
+{
+    std::vector<uint32_t> errs;
+    fgref::Header h;
+    bool ended = false;
+    uint64_t s = 0, fend = 0;
+    fgref::Walker w;
+    for (;;) {
+        errs.clear();
+        w = d->walker;
+        w.d = d->buf.data(); w.len = d->buf.size(); w.abs0 = d->consumed_total; w.final = d->eof; w.win = &d->win;
+        w.si.have = d->have_si; w.si.min_blocksize = d->si.min_blocksize; w.si.max_blocksize = d->si.max_blocksize;
+        w.si.sample_rate = d->si.sample_rate; w.si.channels = d->si.channels; w.si.bps = d->si.bits_per_sample;
+        w.si.total_samples = d->si.total_samples;
+        w.fixed_blocksize = d->fixed_blocksize;
+        s = w.run(d->walk_from, false, errs, &h, &ended, &fend);
+        if (s != UINT64_MAX) break;
+        // the reader would have read on: more data (a damaged frame can parse on for megabytes)
+        bool short_read = false;
+        const size_t had = d->buf.size();
+        if (!pull(d, &short_read)) return false;
+        while (!short_read && !d->eof && d->buf.size() - had < (1u << 20)) if (!pull(d, &short_read)) return false;
+    }
+    d->walker = w;
+    d->walk_pending = false;
+    if (getenv("FG_REFWALK_DEBUG"))
+        fprintf(stderr, "walk_damage: from %llu (abs %llu) -> s=%llu fend=%llu ended=%d errs=%zu buf=%zu eof=%d\n", (unsigned long long)d->walk_from,
+                (unsigned long long)(d->consumed_total + d->walk_from), (unsigned long long)s, (unsigned long long)fend, (int)ended, errs.size(), d->buf.size(), (int)d->eof);
+    if (d->error_cb) for (uint32_t e : errs) d->error_cb(&d->pub, (FLAC__StreamDecoderErrorStatus)e, d->client);
+    if (!ended && errs.empty() && d->consumed_total + s == d->walk_stuck_at) {
+        // (not reached: a frame libFLAC's rules accept and the GPU pass rejects.  Report it and go on behind it.)
+        if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, d->client);
+        d->walk_pending = true; d->walk_from = fend; d->walk_stuck_at = UINT64_MAX;
+        return true;
+    }
+    d->walk_stuck_at = ended ? UINT64_MAX : d->consumed_total + s;
+    d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
+    d->ix = Indexer(); d->ix.fast = false;
+    if (ended) {
+        d->consumed_total += d->buf.size(); d->buf.clear(); d->ix_origin = 0;
+        d->state = FLAC__STREAM_DECODER_END_OF_STREAM;
+        return false;
+    }
+    // the frame [s, fend) decodes: it is the next one the GPU pass sees, and the index goes on behind it
+    d->buf.erase(d->buf.begin(), d->buf.begin() + (size_t)s);
+    d->consumed_total += s;
+    d->ix.bounds.push_back(0); d->ix.bounds.push_back(fend - s);
+    d->ix.scan = fend - s; d->ix.in_frame = false;
+    d->ix_origin = fend - s;
+    return true;
+}
+
 // Make progress: after this call either at least one frame is queued, or the stream has ended / aborted.
 bool fill_queue(DecImpl *d)
 {
     for (;;) {
+        // (frame_sync_: a stream whose STREAMINFO says how many samples it holds ends there)
+        if (d->have_meta && d->have_si && d->si.total_samples && d->samples_decoded >= d->si.total_samples) {
+            d->state = FLAC__STREAM_DECODER_END_OF_STREAM;
+            return false;
+        }
         if (d->next_frame < d->frames.size()) return true;
         if (!ensure_metadata(d)) return false;
+        if (d->walk_pending) {
+            if (!walk_damage(d)) return false;
+            if (d->walk_pending) continue;
+        }
         // drop the bytes of delivered frames
         if (d->frames_delivered_bound > 0 && !d->ix.bounds.empty()) {
             const uint64_t cut = d->ix.bounds[d->frames_delivered_bound];
@@ -1278,6 +1374,7 @@ bool fill_queue(DecImpl *d)
                 d->ix.bounds.swap(nbnd);
                 d->ix.scan -= cut; d->ix.frame_start -= cut; d->ix.crc_pos -= cut;
                 for (auto &p : d->ix.error_pos) p = p >= cut ? p - cut : 0;
+                d->ix_origin = d->ix_origin >= cut ? d->ix_origin - cut : 0;
                 d->frames_delivered_bound = 0;
             }
         }
@@ -1295,7 +1392,7 @@ bool fill_queue(DecImpl *d)
                 fprintf(stderr, "[flacgpu api prof] index feed %8.3f ms (%zu bytes, %s)\n",
                         std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tf0).count() / 1000.0, d->buf.size(),
                         d->ix.fast ? "fast" : "careful");
-            bool redo = d->ix.fast && d->ix.fast_failed;
+            bool redo = d->ix.fast && (d->ix.fast_failed || !d->ix.errors.empty());
             if (!redo && d->ix.bounds.size() >= 2 && d->frames_delivered_bound + 1 < d->ix.bounds.size()) {
                 if (!decode_available(d)) return false;
                 if (d->ix.fast) for (const FgDecResult &r : d->status) if (r.err != 0 && r.err != 3) { redo = true; break; }
@@ -1304,8 +1401,25 @@ bool fill_queue(DecImpl *d)
             d->ix = snap; d->ix.fast = false; d->ix.fast_failed = false;
             d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = fdb;
         }
-        report_errors(d);
+        // Anything irregular: bytes that are no frame where the index looked for one (from ix_origin on), or a frame the GPU pass
+        // rejects.  The frames before that place are delivered, then libFLAC's reader is replayed from there.
+        {
+            uint64_t trouble = UINT64_MAX;
+            if (!d->ix.errors.empty()) trouble = d->ix_origin;
+            for (size_t i = 0; i < d->frames.size(); i++)
+                if (d->status[i].err != 0 && d->status[i].err != 3) { trouble = std::min<uint64_t>(trouble, d->first_pos + d->frames[i].byte_off); break; }
+            if (trouble != UINT64_MAX && getenv("FG_REFWALK_DEBUG"))
+                fprintf(stderr, "fill_queue: trouble at %llu (abs %llu), %zu frames in the round, index errors %zu, origin %llu\n", (unsigned long long)trouble,
+                        (unsigned long long)(d->consumed_total + trouble), d->frames.size(), d->ix.errors.size(), (unsigned long long)d->ix_origin);
+            if (trouble != UINT64_MAX) {
+                size_t keep = 0;
+                while (keep < d->frames.size() && d->first_pos + d->frames[keep].byte_off < trouble) keep++;       // (both are frame boundaries)
+                d->frames.resize(keep); d->status.resize(keep);
+                d->walk_pending = true; d->walk_from = trouble;
+            }
+        }
         if (!d->frames.empty()) return true;
+        if (d->walk_pending) continue;
         if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
         // need more data; keep pulling while the callback keeps filling the request (drains what is available)
         bool short_read = false;
@@ -1511,7 +1625,9 @@ FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *dec)
 {
     DecImpl *d = impl(dec);
     if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+ d->consumed_total += d->buf.size();
     d->buf.clear(); d->ix = Indexer(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
+    d->win.restart(d->consumed_total); d->walker = fgref::Walker(); d->walk_pending = false; d->ix_origin = 0; d->walk_stuck_at = UINT64_MAX;
     d->do_md5 = false;       // stream_decoder.h:1357-1359: a flush turns MD5 checking off
     d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
     return 1;

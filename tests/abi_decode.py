@@ -12,7 +12,7 @@ def decode(data, read_size=8192, md5_checking=False):
     L = _lib.lib()
     dec = C.c_void_p(L.FLAC__stream_decoder_new())
     pos = [0]
-    frames, blocks, errors = [], [], []
+    frames, blocks, errors, events = [], [], [], []
 
     def _r(d, buf, pn, cd):
         n = min(pn[0], len(data) - pos[0], read_size)
@@ -30,10 +30,12 @@ def decode(data, read_size=8192, md5_checking=False):
         blocks.append(blk)
         frames.append([int(h.number.sample_number), int(h.blocksize),
                        hashlib.sha256(np.ascontiguousarray(blk, np.int32).tobytes()).hexdigest()[:16]])
+        events.append('f%d' % h.number.sample_number)
         return 0
 
     def _e(d, status, cd):
         errors.append(int(status))
+        events.append('e%d' % int(status))
 
     rcb, wcb, ecb = _lib.DEC_READ_CB(_r), _lib.DEC_WRITE_CB(_w), _lib.DEC_ERROR_CB(_e)
     if md5_checking:
@@ -44,7 +46,7 @@ def decode(data, read_size=8192, md5_checking=False):
     state = L.FLAC__stream_decoder_get_state(dec)
     fin = L.FLAC__stream_decoder_finish(dec)
     L.FLAC__stream_decoder_delete(dec)
-    return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'blocks': blocks, 'finish': bool(fin)}
+    return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'blocks': blocks, 'finish': bool(fin), 'events': events}
 
 
 # ---- FLAC__StreamMetadata mirror (pyflac/builder/encoder.py:129-248) for metadata-callback tests -------------------

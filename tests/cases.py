@@ -198,6 +198,34 @@ def damaged_stream(name):
     return bytes(data)
 
 
+# Random damage: seed -> (fixture, damaged stream, size of the read callback's answers).  One to four edits (bit flips, deletions,
+# insertions of random bytes, stretches of zeros) anywhere behind the first 8300 bytes, and a read size that puts the refills of
+# libFLAC's 8 KiB reader in different places.
+DAMAGE_FUZZ_SEEDS = list(range(1000, 1200)) + [1225, 1250, 1285, 1309, 5003, 5077, 5210, 5388]
+DAMAGE_READ_SIZES = [8192, 1000]
+
+
+def fuzz_damaged_stream(seed):
+    r = np.random.default_rng(seed)
+    name = ['stereo', 'mono', 'surround', '32bit'][int(r.integers(0, 4))]
+    with open(os.path.join(GOLDEN, 'data', name + '.flac'), 'rb') as f:
+        data = bytearray(f.read())
+    for _ in range(int(r.integers(1, 5))):
+        kind = int(r.integers(0, 4))
+        p = int(r.integers(8300, len(data) - 10))
+        if kind == 0:
+            data[p] ^= 1 << int(r.integers(0, 8))
+        elif kind == 1:
+            del data[p:p + int(r.integers(1, 300))]
+        elif kind == 2:
+            data[p:p] = r.integers(0, 256, int(r.integers(1, 600)), dtype=np.uint8).tobytes()
+        else:
+            n = int(r.integers(1, 200))
+            data[p:p + n] = bytes(n)
+    rs = int(r.choice([8192, 1000, 4096, 333, 65536]))
+    return name, bytes(data), rs
+
+
 # MD5 checking on decode (FLAC__stream_decoder_set_md5_checking): name -> (damage case or fixture, STREAMINFO md5 edit,
 # checking enabled).  The signature sits at bytes 26..41 of a stream whose STREAMINFO is the first block.
 MD5_CASES = {

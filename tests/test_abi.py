@@ -199,3 +199,47 @@ def test_cuesheet_and_picture_legality_matches_libflac():
         L.FLAC__stream_encoder_delete(enc)
         seen += 1
     assert seen == len(want) == 20
+
+
+def _refwalk(L, data, read_size):
+    import ctypes as C
+    import numpy as np
+    buf = np.frombuffer(data, np.uint8)
+    errs = np.zeros(1024, np.uint32)
+    frames = np.zeros(2 * 1024, np.uint64)
+    nf = C.c_uint64(0)
+    ne = L.flacgpu_refwalk_probe(buf.ctypes.data, buf.size, read_size, errs.ctypes.data, errs.size, frames.ctypes.data, frames.size, C.byref(nf))
+    assert ne >= 0
+    return [int(e) for e in errs[:ne]], [(int(frames[2 * i]), int(frames[2 * i + 1])) for i in range(nf.value)]
+
+
+def _check_refwalk(L, want, data, read_size):
+    """The host replay of libFLAC's reader (csrc/fg_refwalk.h) against the reference's recorded behaviour: the same error
+    statuses in the same order; the frames it decodes are frames the reference delivered (the rest of the reference's
+    frames are the silence it fills gaps with), and every frame the reference delivered with a signal in it is among them."""
+    import hashlib
+    import numpy as np
+    errs, frames = _refwalk(L, data, read_size)
+    assert errs == want['errors']
+    delivered = {(f[0], f[1]): f[2] for f in want['frames']}
+    assert all(f in delivered for f in frames)
+    decoded = set(frames)
+    for (sn, bs), h in delivered.items():
+        if (sn, bs) in decoded:
+            continue
+        # a frame the reference delivered and the replay did not decode must be one of the reference's frames of silence
+        assert any(h == hashlib.sha256(np.zeros((bs, ch), np.int32).tobytes()).hexdigest()[:16] for ch in range(1, 9)), (sn, bs)
+
+
+@pytest.mark.parametrize('name', sorted(__import__('tests.cases', fromlist=['x']).DAMAGE_CASES))
+@pytest.mark.parametrize('read_size', __import__('tests.cases', fromlist=['x']).DAMAGE_READ_SIZES)
+def test_reader_replay_matches_reference_on_damage(L, damage_golden, name, read_size):
+    from tests import cases
+    _check_refwalk(L, damage_golden[name if read_size == 8192 else '%s@%d' % (name, read_size)], cases.damaged_stream(name), read_size)
+
+
+@pytest.mark.parametrize('seed', __import__('tests.cases', fromlist=['x']).DAMAGE_FUZZ_SEEDS)
+def test_reader_replay_matches_reference_on_random_damage(L, damage_golden, seed):
+    from tests import cases
+    _src, data, read_size = cases.fuzz_damaged_stream(seed)
+    _check_refwalk(L, damage_golden['fuzz%d' % seed], data, read_size)

@@ -295,42 +295,34 @@ class TestDamagedStreams:
     """Decoder resynchronisation against tests/golden/damage_vectors.json, recorded from the
     reference's libFLAC 1.4.3 binary by oracle/gen_golden_damage.py.
 
-    libFLAC resumes its search for the next frame wherever its serial bit reader happened to stop (and can only step
-    back to the damaged frame's sync code while that is still inside its 8 KiB read buffer), so which undamaged frames
-    it loses BEHIND a damaged one depends on its buffering.  The bar here: every frame the reference delivers intact is
-    delivered identically; where the reference delivers silence we deliver silence or the intact frame it skipped;
-    same frame numbering and block sizes throughout (the time line is identical); errors are reported whenever the
-    reference reports any, with the same first status (two exceptions below).  EXACT lists the cases where the whole callback sequence
-    (frames and error statuses) is identical."""
-    EXACT = ['body_flip', 'body_flip_adjacent', 'crc16_flip', 'header_blocksize', 'header_crc8', 'header_sync',
-             'delete_header', 'insert_between', 'last_frame_body', 'truncated', 'truncated_at_frame']
-    # a parse that runs off the end of a damaged frame is reported as a CRC mismatch here; libFLAC reads on into the
-    # next frame's bytes and reports whatever it trips over there
-    OTHER_FIRST_STATUS = ['delete_in_body', 'first_frame_body']
+    libFLAC resumes its search for the next frame wherever its serial bit reader happened to stop, and steps back to the
+    damaged frame's sync code only while no refill of its 8 KiB read buffer has dropped it (to the front of that buffer
+    otherwise), so which undamaged frames it loses behind a damaged one depends on the sizes of the read callback's
+    answers.  The decoder replays that reader on the host wherever the GPU pass rejects a frame (csrc/fg_refwalk.h): the
+    whole callback sequence -- every frame (number, block size, samples, silence included) and every error status, in
+    order and interleaved the same way -- must be identical, per read size."""
+
+    @staticmethod
+    def check(want, data, read_size):
+        from tests import abi_decode
+        got = abi_decode.decode(data, read_size)
+        assert got['state'] == want['state'] and got['ok']
+        assert got['errors'] == want['errors']
+        assert got['frames'] == want['frames']
+        assert got['events'] == want['events']
 
     @pytest.mark.parametrize('name', sorted(cases.DAMAGE_CASES))
-    @pytest.mark.parametrize('read_size', [8192, 1000])
+    @pytest.mark.parametrize('read_size', cases.DAMAGE_READ_SIZES)
     def test_against_reference(self, damage_golden, name, read_size):
-        from tests import abi_decode
-        from oracle import oracle as O
-        src = cases.DAMAGE_CASES[name][0]
-        with open(os.path.join(cases.GOLDEN, 'data', src + '.flac'), 'rb') as f:
-            clean, _ = O.decode_stream(f.read())
-        ch = clean.shape[1] if clean.ndim > 1 else 1
-        clean = clean.reshape(-1, ch)
-        want = damage_golden[name]
-        got = abi_decode.decode(cases.damaged_stream(name), read_size)
-        assert got['state'] == want['state'] and got['ok']
-        assert [f[:2] for f in got['frames']] == [f[:2] for f in want['frames']]
-        for (sn, bs, h), (_sn, _bs, wh), blk in zip(got['frames'], want['frames'], got['blocks']):
-            if h != wh:
-                assert np.array_equal(blk, clean[sn:sn + bs]), (name, sn)       # a frame the reference lost
-                assert wh == abi_decode.hashlib.sha256(np.zeros((bs, ch), np.int32).tobytes()).hexdigest()[:16]
-        assert bool(got['errors']) == bool(want['errors'])
-        if want['errors'] and name not in self.OTHER_FIRST_STATUS:
-            assert got['errors'][0] == want['errors'][0], (got['errors'], want['errors'])
-        if name in self.EXACT:
-            assert got['frames'] == want['frames'] and got['errors'] == want['errors']
+        self.check(damage_golden[name if read_size == 8192 else '%s@%d' % (name, read_size)], cases.damaged_stream(name), read_size)
+
+    @pytest.mark.parametrize('seed', cases.DAMAGE_FUZZ_SEEDS)
+    def test_random_damage_against_reference(self, damage_golden, seed):
+        _src, data, read_size = cases.fuzz_damaged_stream(seed)
+        want = damage_golden['fuzz%d' % seed]
+        import hashlib
+        assert hashlib.sha256(data).hexdigest()[:16] == want['sha']          # the generator made the stream the vector was recorded on
+        self.check(want, data, read_size)
 
 
 class TestMd5Checking:
