@@ -352,7 +352,8 @@ def main():
 
     if rank == 0:
         ps = np.sort(np.array(per_step)) * 1e3
-        pmc = committed_profile('r02_pmc.json') or {}
+        pmc_name = 'r03_pmc.json' if committed_profile('r03_pmc.json') else 'r02_pmc.json'
+        pmc = committed_profile(pmc_name) or {}
         same = pmc.get('workload') == args.workload and pmc.get('level') == args.level and pmc.get('blocks') == int(est.nblocks)
         enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
         dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
@@ -386,7 +387,7 @@ def main():
                                 'assembly + CRC-16': round(float(stage[3]), 3)},
             # the encoder is six kernels back to back (fg_pipe_autoc / levinson / eval / pack, the size scan, fg_pipe_assemble):
             # one encode = PCM read once, frames written once; time = HIP events around all of them on the library's stream.
-            # The per-kernel durations are in profiles/r02_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command).
+            # The per-kernel durations are in profiles/r03_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command).
             'roofline': {'bound': 'hbm', 'kernel': 'encode pipeline (fg_pipe_autoc_kernel .. fg_pipe_assemble_kernel; dominant: '
                                                    'fg_pipe_autoc_kernel)',
                          'achieved': round(enc_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(enc_ach / 8000.0, 5),
@@ -408,7 +409,7 @@ def main():
                                     'decode_valu_insts_per_launch': pmc.get('decode_valu_insts_per_launch'),
                                     'decode_frac': (round(pmc['decode_valu_insts_per_launch'] / (dec_t * 1e-3) / slots, 4)
                                                     if pmc.get('decode_valu_insts_per_launch') else None),
-                                    'source': 'profiles/r02_pmc.json'}
+                                    'source': 'profiles/' + pmc_name}
         if world == 1 and not args.no_e2e and args.workload == 'stream16':
             res['api_e2e'] = api_e2e(min(args.seconds, 600.0), sr)
         if cpu_res is not None:

@@ -1,16 +1,17 @@
-"""Turn the PMC passes of tools/rocprof_run.sh into profiles/r02_pmc.json: HBM traffic and VALU instruction counts per
+"""Turn the PMC passes of tools/rocprof_run.sh into profiles/<round>_pmc.json: HBM traffic and VALU instruction counts per
 encode launch (all fg_pipe_* kernels + sizes/scan) and per decode launch (all fg_dec_* kernels).
 
 Units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of coalesced streaming reads, so it is doubled (round 1 checked this against a kernel with a known
 230 MB input); WRITE_SIZE is taken as is.  Counter values are per dispatch; a "launch" is one dispatch of every kernel of
 the group (the short-block packing kernel included).
-usage: python tools/rocprof_pmc.py gpurun_out/prof_<tag> <workload> <blocks> <level>
+usage: python tools/rocprof_pmc.py gpurun_out/prof_<tag> <workload> <blocks> <level> [round prefix, default r03]
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 root, workload, blocks, level = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+RND = sys.argv[5] if len(sys.argv) > 5 else 'r03'
 
 
 def per_kernel(sub, name):
@@ -39,6 +40,6 @@ out = {'workload': workload, 'blocks': blocks, 'level': level, 'fetch_correction
        'kernels': rows,
        'source': os.path.basename(root.rstrip('/')) + ' (rocprofv3 --pmc, separate passes: SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE)'}
 os.makedirs('profiles', exist_ok=True)
-name = 'profiles/r02_pmc.json' if workload == 'stream16' else 'profiles/r02_pmc_%s.json' % workload
+name = 'profiles/%s_pmc.json' % RND if workload == 'stream16' else 'profiles/%s_pmc_%s.json' % (RND, workload)
 json.dump(out, open(name, 'w'), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}))
