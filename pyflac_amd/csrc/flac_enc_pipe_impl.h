@@ -6,12 +6,14 @@
 // budgets, and HBM bandwidth is nowhere near a limit here (the encoder moves ~0.3 GB per launch), so the stages are
 // separate kernels that hand small records through HBM and re-read the PCM (it stays in the Infinity Cache):
 //
-//   K2 fg_pipe_autoc_kernel     wave = block.  Windowed signal straight from HBM, staged per 128-sample chunk as doubles,
-//                               libFLAC's order-preserving fp64 chains (lane = candidate x lag).  5.4 KB of LDS and < 64
-//                               VGPRs per wave: 7-8 waves per SIMD hide the dependent-FMA and LDS latency.  Also ORs the
-//                               samples: wasted bits per candidate.  The autocorrelation of the shifted signal is the
-//                               autocorrelation of the unshifted one times 2^-2w, exactly (power-of-two scaling commutes
-//                               with every rounding on the way), so the chain never waits for the wasted-bits result.
+//   K2 fg_pipe_autoc_kernel     wave = block.  Windowed signal straight from HBM, staged per 128-sample chunk as doubles;
+//                               libFLAC's order-preserving fp64 chains run on the matrix core: one
+//                               v_mfma_f64_4x4x4_4b_f64 adds four steps to the chains of 16 lags of all four candidates
+//                               (its k-sum is a chain of fused multiply-adds in ascending k, bit-equal to v_fma_f64).
+//                               5.2 KB of LDS and <= 64 VGPRs per wave: 7-8 waves per SIMD.  Also ORs the samples: wasted
+//                               bits per candidate.  The autocorrelation of the shifted signal is the autocorrelation
+//                               of the unshifted one times 2^-2w, exactly (power-of-two scaling commutes with every
+//                               rounding on the way), so the chain never waits for the wasted-bits result.
 //   K3 fg_pipe_levinson_kernel  lane = (block, candidate, window): Levinson-Durbin, order guess, quantiser.  The round-1
 //                               kernel ran this on 4 of 64 lanes.
 //   K4 fg_pipe_eval_kernel      workgroup = block, wave = candidate (L, R, M, S).  Samples staged once in LDS (lane =
@@ -43,11 +45,11 @@
 #define FGP_F64 1                        // evaluation: residuals of 17..25-bit samples through fp64 FMAs (pfir_f64; 0 = pfir48)
 #define FGP_DH 16                        // autocorrelation: history doubles kept in front of each chunk (>= max lag + 1)
 #define FGP_CK 128                       // autocorrelation: chunk length
-// doubles per candidate row: 288 words, i.e. 32 banks (of 64) from row to row -- the two candidate rows that share a
-// ds_read_b64 lane group ({0-31} / {32-63}) read up to 14 consecutive doubles each and never meet on a bank.  No slack at
-// the end: the chain's read-ahead past a chunk lands in the next row (or the arrays behind the last one) and is not used.
-// 4.9 KB of LDS per wave keeps 28+ waves on a CU: the 7032 blocks of the headline stream are resident in one round.
-#define FGP_CSTR (FGP_DH + FGP_CK)
+// doubles per candidate row: 304 words, i.e. 48 banks (of 64) from row to row -- the four candidate rows that share a
+// ds_read_b64 lane group read 7 consecutive doubles each (d[t + k - i], 14 banks) and never meet on a bank.
+// 5.2 KB of LDS per wave keeps 28+ waves on a CU: the 7032 blocks of the headline stream are resident in one round.
+#define FGP_SLK 8                        // zeros behind a chunk: the chains run up to 7 steps past the end of the signal
+#define FGP_CSTR (FGP_DH + FGP_CK + FGP_SLK)
 
 using namespace fgdev;
 
@@ -220,12 +222,8 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
         }
     }
     else {
-        // Lane p of a 16-lane row handles lag p - 1: lanes 1 .. mo+1 carry the chains of lags 0 .. mo, lane 0 is a helper
-        // one sample ahead of lag 0 (see the chain below).
-        const uint32_t cl = lane >> 4, pl = lane & 15;
-        const bool on = cl < (uint32_t)NC && pl <= mo + 1;
-        const uint32_t l = pl - 1;                       // lag (lane 0: "-1")
-        const LDS double *hist = dbuf + (cl < (uint32_t)NC ? cl : 0) * FGP_CSTR + FGP_DH + 1 - (on ? pl : 1);
+        // (matrix-core chains, see below: lane -> candidate row; lanes of candidates this shape does not have read row 0)
+        const uint32_t mrow = ((lane >> 2) & 3) < (uint32_t)NC ? ((lane >> 2) & 3) : 0;
         uint32_t vb_ = 1, vc_ = 0;
         bool more = true;
         while (more) {
@@ -239,11 +237,22 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
             if (!skip && !punch) {
                 double acc = 0.0;
                 for (uint32_t j = lane; j < NC * FGP_DH; j += 64) dbuf[(j / FGP_DH) * FGP_CSTR + (j % FGP_DH)] = 0.0;
+                for (uint32_t j = lane; j < NC * FGP_SLK; j += 64) dbuf[(j / FGP_SLK) * FGP_CSTR + FGP_DH + FGP_CK + (j % FGP_SLK)] = 0.0;
                 wave_lds_fence();
                 // window value and samples of the next chunk travel while the chain of the current one runs
                 float wv[FGP_CK / 64];
                 int32_t xl[FGP_CK / 64], xr[FGP_CK / 64];
                 auto fetch = [&](uint32_t k0) __attribute__((always_inline)) {
+                    if (part == 0 && k0 + FGP_CK <= vec_len) {
+                        // (the whole block under one window, a full chunk: nearly every call)
+#pragma unroll
+                        for (int u = 0; u < FGP_CK / 64; u++) {
+                            const uint32_t i = k0 + u * 64 + lane;
+                            wv[u] = window[i];
+                            ldsamp(i, xl[u], xr[u]);
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int u = 0; u < FGP_CK / 64; u++) {
                         const uint32_t i = k0 + u * 64 + lane;
@@ -264,87 +273,122 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                 fetch(0);
                 for (uint32_t k0 = 0; k0 < vec_len; k0 += FGP_CK) {
                     const uint32_t kn = (vec_len - k0) < FGP_CK ? (vec_len - k0) : FGP_CK;
+                    if (part == 0) {
 #pragma unroll
-                    for (int u = 0; u < FGP_CK / 64; u++) {
-                        const uint32_t j = u * 64 + lane;
-                        if (j < kn && P.debug != 102) {
-                            const int32_t L = xl[u], R = xr[u];
-                            const bool zero = part != 0 && (k0 + j) >= 2 * part;
+                        for (int u = 0; u < FGP_CK / 64; u++) {
+                            const uint32_t j = u * 64 + lane;
+                            if (P.debug != 102) {       // (behind the end of the signal the fetch gave zeros: the chains run on a little)
+                                const int32_t L = xl[u], R = xr[u];
 #pragma unroll
-                            for (int c = 0; c < NC; c++) {
-                                const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
-                                if (nv == 0) orv[c] |= (uint32_t)x;
-                                const float dd = zero ? 0.0f : (float)x * wv[u];
-                                dbuf[c * FGP_CSTR + FGP_DH + j] = (double)dd;
+                                for (int c = 0; c < NC; c++) {
+                                    const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
+                                    if (nv == 0) orv[c] |= (uint32_t)x;
+                                    dbuf[c * FGP_CSTR + FGP_DH + j] = (double)((float)x * wv[u]);
+                                }
+                            }
+                        }
+                    }
+                    else {
+#pragma unroll
+                        for (int u = 0; u < FGP_CK / 64; u++) {
+                            const uint32_t j = u * 64 + lane;
+                            if (P.debug != 102) {
+                                const int32_t L = xl[u], R = xr[u];
+                                const bool zero = (k0 + j) >= 2 * part;
+#pragma unroll
+                                for (int c = 0; c < NC; c++) {
+                                    const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
+                                    if (nv == 0) orv[c] |= (uint32_t)x;
+                                    const float dd = zero ? 0.0f : (float)x * wv[u];
+                                    dbuf[c * FGP_CSTR + FGP_DH + j] = (double)dd;
+                                }
                             }
                         }
                     }
                     if (k0 + FGP_CK < vec_len) fetch(k0 + FGP_CK);
                     wave_lds_fence();
-                    if (on && P.debug != 101) {
-                        // The chain.  Step j of lag l needs d[j] * d[j - l]; lane p = l + 1 reads x_p = d[j + 1 - p] from LDS on
-                        // EVEN steps only: on the odd step that follows, what it needs, d[j + 2 - p], is what lane p - 1 just
-                        // read, and comes over with a DPP row shift (two 32-bit moves) -- the helper lane 0 reads the sample
-                        // one ahead for that.  The d[j] operand of a step is lane 1's value, broadcast inside the FMA
-                        // (row_newbcast:1).  That halves the LDS reads, which bound this kernel (ds_read_b64, 2 LDS cycles a
-                        // wave-instruction; the compiler's ds_read2_b64 would take 4 per value).  Groups of eight steps (four
-                        // reads), requested two groups ahead of their FMAs; one asm block with its own s_waitcnt.
-                        // (Reads past the chunk stay inside the row and are not used.)
-#define FG_L4(x, o) "ds_read_b64 %[" #x "0], %[ad] offset:" #o "\n\tds_read_b64 %[" #x "1], %[ad] offset:" #o "+16\n\t" \
-                    "ds_read_b64 %[" #x "2], %[ad] offset:" #o "+32\n\tds_read_b64 %[" #x "3], %[ad] offset:" #o "+48\n\t"
-                        // (the y pairs are declared as four doubles whose halves the moves write one by one)
-                        double ha[4], hb[4], hc[4], ya = 0.0, yb = 0.0, yc = 0.0, yd = 0.0;
-                        uint32_t ad = (uint32_t)(size_t)hist;
-                        uint32_t j = 0;
-                        asm volatile(FG_L4(a, 0) FG_L4(b, 64)
-                                     : [a0] "=&v"(ha[0]), [a1] "=&v"(ha[1]), [a2] "=&v"(ha[2]), [a3] "=&v"(ha[3]),
-                                       [b0] "=&v"(hb[0]), [b1] "=&v"(hb[1]), [b2] "=&v"(hb[2]), [b3] "=&v"(hb[3])
-                                     : [ad] "v"(ad));
-                        hc[0] = hc[1] = hc[2] = hc[3] = 0.0;
-#define FG_YOPS [ya] "+v"(ya), [yb] "+v"(yb), [yc] "+v"(yc), [yd] "+v"(yd)
-#define FG_G8C(h) do { \
-        uint32_t y0_, y1_, y2_, y3_, y4_, y5_, y6_, y7_; \
-        asm volatile("v_mov_b32_dpp %[y0], %[l0] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y1], %[h0] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_mov_b32_dpp %[y2], %[l1] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y3], %[h1] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_mov_b32_dpp %[y4], %[l2] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y5], %[h2] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_mov_b32_dpp %[y6], %[l3] row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %[y7], %[h3] row_shr:1 row_mask:0xf bank_mask:0xf" \
-                     : [y0] "=&v"(y0_), [y1] "=&v"(y1_), [y2] "=&v"(y2_), [y3] "=&v"(y3_), [y4] "=&v"(y4_), [y5] "=&v"(y5_), [y6] "=&v"(y6_), [y7] "=&v"(y7_) \
-                     : [l0] "v"(__double2loint(h[0])), [h0] "v"(__double2hiint(h[0])), [l1] "v"(__double2loint(h[1])), [h1] "v"(__double2hiint(h[1])), \
-                       [l2] "v"(__double2loint(h[2])), [h2] "v"(__double2hiint(h[2])), [l3] "v"(__double2loint(h[3])), [h3] "v"(__double2hiint(h[3]))); \
-        const double ya_ = __hiloint2double((int)y1_, (int)y0_), yb_ = __hiloint2double((int)y3_, (int)y2_); \
-        const double yc_ = __hiloint2double((int)y5_, (int)y4_), yd_ = __hiloint2double((int)y7_, (int)y6_); \
-        asm volatile("v_fmac_f64_dpp %[acc], %[x0], %[x0] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[ya], %[ya] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[x1], %[x1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[yb], %[yb] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[x2], %[x2] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[yc], %[yc] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[x3], %[x3] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
-                     "v_fmac_f64_dpp %[acc], %[yd], %[yd] row_newbcast:1 row_mask:0xf bank_mask:0xf" \
-                     : [acc] "+v"(acc) : [x0] "v"(h[0]), [x1] "v"(h[1]), [x2] "v"(h[2]), [x3] "v"(h[3]), [ya] "v"(ya_), [yb] "v"(yb_), [yc] "v"(yc_), [yd] "v"(yd_)); \
-    } while (0)
-                        (void)ya; (void)yb; (void)yc; (void)yd;
-                        for (; j + 24 <= kn; j += 24) {
-                            asm volatile(FG_L4(c, 128) "s_waitcnt lgkmcnt(8)" : [c0] "=&v"(hc[0]), [c1] "=&v"(hc[1]), [c2] "=&v"(hc[2]), [c3] "=&v"(hc[3]),
-                                         "+v"(ha[0]), "+v"(ha[1]), "+v"(ha[2]), "+v"(ha[3]) : [ad] "v"(ad));
-                            FG_G8C(ha);
-                            asm volatile(FG_L4(a, 192) "s_waitcnt lgkmcnt(8)" : [a0] "=&v"(ha[0]), [a1] "=&v"(ha[1]), [a2] "=&v"(ha[2]), [a3] "=&v"(ha[3]),
-                                         "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]) : [ad] "v"(ad));
-                            FG_G8C(hb);
-                            asm volatile(FG_L4(b, 256) "s_waitcnt lgkmcnt(8)" : [b0] "=&v"(hb[0]), [b1] "=&v"(hb[1]), [b2] "=&v"(hb[2]), [b3] "=&v"(hb[3]),
-                                         "+v"(hc[0]), "+v"(hc[1]), "+v"(hc[2]), "+v"(hc[3]) : [ad] "v"(ad));
-                            FG_G8C(hc);
-                            ad += 192;
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ha[0]), "+v"(ha[1]), "+v"(ha[2]), "+v"(ha[3]), "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]));
-                        if (j + 8 <= kn) { FG_G8C(ha); j += 8; if (j + 8 <= kn) { FG_G8C(hb); j += 8; } }
-                        for (; j < kn; j++) {
-                            const double h0 = hist[j];
-                            asm("v_fmac_f64_dpp %0, %1, %1 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h0));
-                        }
-#undef FG_G8C
-#undef FG_YOPS
-#undef FG_L4
+                    if (P.debug != 101) {
+                        // The chains on the matrix core.  v_mfma_f64_4x4x4_4b_f64 computes, for four independent blocks b,
+                        // D[i][j] += sum_k A[i][k] * B[k][j] with one fused multiply-add per k, in ascending k, each rounded like
+                        // v_fma_f64 (tools/ubench/mfma64.hip: 262144 random cases bit-equal to that chain and to no other
+                        // order).  Lanes: A and B in lane k*16 + b*4 + x (x = i resp. j), D in lane i*16 + b*4 + j.  With
+                        //     A[i][k] = d[t + k - i]        B[k][j] = d[t + k - 4j]
+                        // one instruction adds steps t .. t+3, in order, to the chains of lags 4j - i = -3 .. 12 of the four
+                        // candidates b: 256 of libFLAC's fused multiply-adds, in libFLAC's order per lag (row i runs i steps
+                        // behind; zeros in front of the signal and behind it add nothing; lags -1 .. -3 repeat 1 .. 3 and are
+                        // dropped).  A comes from LDS (one ds_read_b64 per instruction).  B of the next step group is B of this
+                        // one moved up a lane inside each quad, with the A just read entering at j = 0 (the same d[t + k]):
+                        // two v_cndmask_b32_dpp.
+                        const uint32_t kend = (k0 + kn < vec_len) ? FGP_CK : ((kn + 3) & ~3u) + 4;
+                        const LDS double *pa = dbuf + mrow * FGP_CSTR + FGP_DH + (lane >> 4) - (lane & 3);
+                        // One asm block per chunk (fixed registers v40..v59: A of two groups of four instructions in flight,
+                        // B alternating between two pairs so that no instruction overwrites an operand of the one before it).
+                        // Wait states by hand -- the compiler's hazard recogniser does not look inside: a dependent
+                        // v_mfma_f64_4x4x4 needs 4 after the one that wrote its accumulator (two v_cndmask + s_nop 1), its
+                        // result 9+ before anything else reads it (the s_nop at the end).
+                        uint32_t ad = (uint32_t)(size_t)pa;
+                        const uint32_t adb = ad - 8u * (4u + 3u * (lane & 3));        // d[-4 + k - 4j]: B of the step group before the chunk
+                        uint32_t n4 = kend >> 4, n1 = (kend >> 2) & 3;
+                        const u64 m0 = 0x1111111111111111ull;                          // lanes with j = 0
+#define FG_DPPQ " quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+#define FG_STEP(a0, a1, s0, s1, d0, d1) \
+    "v_cndmask_b32_dpp v" #d0 ", v" #s0 ", v" #a0 ", vcc" FG_DPPQ \
+    "v_cndmask_b32_dpp v" #d1 ", v" #s1 ", v" #a1 ", vcc" FG_DPPQ \
+    "s_nop 1\n\t" \
+    "v_mfma_f64_4x4x4_4b_f64 %[acc], v[" #a0 ":" #a1 "], v[" #d0 ":" #d1 "], %[acc]\n\t"
+#define FG_RD4(r0, r1, r2, r3, r4, r5, r6, r7, o) \
+    "ds_read_b64 v[" #r0 ":" #r1 "], %[ad] offset:" #o "\n\tds_read_b64 v[" #r2 ":" #r3 "], %[ad] offset:" #o "+32\n\t" \
+    "ds_read_b64 v[" #r4 ":" #r5 "], %[ad] offset:" #o "+64\n\tds_read_b64 v[" #r6 ":" #r7 "], %[ad] offset:" #o "+96\n\t"
+#define FG_EVEN(a0, a1) FG_STEP(a0, a1, 56, 57, 58, 59)
+#define FG_ODD(a0, a1) FG_STEP(a0, a1, 58, 59, 56, 57)
+                        asm volatile(
+                            "s_mov_b64 vcc, %[m0]\n\t"
+                            "ds_read_b64 v[56:57], %[adb]\n\t"
+                            "s_cmp_eq_u32 %[n4], 0\n\t"
+                            "s_cbranch_scc1 2f\n\t"
+                            FG_RD4(40, 41, 42, 43, 44, 45, 46, 47, 0)
+                            "1:\n\t"
+                            FG_RD4(48, 49, 50, 51, 52, 53, 54, 55, 128)
+                            "s_waitcnt lgkmcnt(4)\n\t"
+                            FG_EVEN(40, 41) FG_ODD(42, 43) FG_EVEN(44, 45) FG_ODD(46, 47)
+                            "v_add_u32 %[ad], 0x80, %[ad]\n\t"
+                            "s_sub_u32 %[n4], %[n4], 1\n\t"
+                            "s_cmp_eq_u32 %[n4], 0\n\t"
+                            "s_cbranch_scc1 2f\n\t"
+                            FG_RD4(40, 41, 42, 43, 44, 45, 46, 47, 128)
+                            "s_waitcnt lgkmcnt(4)\n\t"
+                            FG_EVEN(48, 49) FG_ODD(50, 51) FG_EVEN(52, 53) FG_ODD(54, 55)
+                            "v_add_u32 %[ad], 0x80, %[ad]\n\t"
+                            "s_sub_u32 %[n4], %[n4], 1\n\t"
+                            "s_cmp_eq_u32 %[n4], 0\n\t"
+                            "s_cbranch_scc0 1b\n\t"
+                            "2:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cmp_eq_u32 %[n1], 0\n\t"
+                            "s_cbranch_scc1 4f\n\t"
+                            "3:\n\t"
+                            "ds_read_b64 v[40:41], %[ad]\n\t"
+                            "v_add_u32 %[ad], 32, %[ad]\n\t"
+                            "s_sub_u32 %[n1], %[n1], 1\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            FG_EVEN(40, 41)
+                            "v_mov_b32 v56, v58\n\t"
+                            "v_mov_b32 v57, v59\n\t"
+                            "s_nop 1\n\t"
+                            "s_cmp_eq_u32 %[n1], 0\n\t"
+                            "s_cbranch_scc0 3b\n\t"
+                            "4:\n\t"
+                            "s_nop 7\n\t"
+                            "s_nop 3"
+                            : [acc] "+v"(acc), [ad] "+v"(ad), [n4] "+s"(n4), [n1] "+s"(n1)
+                            : [adb] "v"(adb), [m0] "s"(m0)
+                            : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+                              "v54", "v55", "v56", "v57", "v58", "v59");
+#undef FG_EVEN
+#undef FG_ODD
+#undef FG_RD4
+#undef FG_STEP
+#undef FG_DPPQ
                     }
                     wave_lds_fence();
                     if (k0 + kn < vec_len && P.debug != 103) {
@@ -363,7 +407,11 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                         wave_lds_fence();
                     }
                 }
-                if (on && pl >= 1) autoc[(cl * P.nvec + nv) * (MAXO + 1) + l] = acc;
+                {
+                    const uint32_t oc = (lane >> 2) & 3;
+                    const int ol = 4 * (int)(lane & 3) - (int)(lane >> 4);
+                    if (oc < (uint32_t)NC && ol >= 0 && ol <= (int)mo) autoc[(oc * P.nvec + nv) * (MAXO + 1) + ol] = acc;
+                }
                 wave_lds_fence();
             }
             else if (punch) {
