@@ -627,6 +627,26 @@ int flacgpu_decode_streams_dev(flacgpu_ctx *ctx, const void *d_bytes, uint64_t l
  * no subframe details. */
 void flacgpu_stream_decoder_set_subframe_detail(FLAC__StreamDecoder *decoder, int level);
 
+/* Extension: block delivery.  With a block callback set (before FLAC__stream_decoder_init_*), the decoder hands over every
+ * round of decoded frames in ONE call instead of one write callback per frame (stream_decoder.h:463-500): `pcm` holds the
+ * frames back to back, channels interleaved, as int16 when no frame of the round has more than 16 bits per sample
+ * (bytes_per_sample 2) and int32 otherwise (4); blocks[i] describes frame i -- `offset` is where it starts in `pcm`, in
+ * inter-channel samples, or FLACGPU_BLOCK_SILENCE for a frame of silence the decoder fills a gap with (stream damage).  The
+ * order of blocks and of error callbacks is the order of the write and error callbacks without it.  A caller that turns the
+ * blocks into arrays of its own (pyflac_amd.StreamDecoder) saves the per-frame crossing into its language and the widening
+ * to FLAC__int32.  `pcm` is valid during the call.  Not used while MD5 checking is on (the write callback serves then).
+ * FLAC__stream_decoder_process_single delivers one block per call. */
+typedef struct {
+    uint64_t sample_number;       /* of the frame's first sample */
+    uint64_t offset;              /* start in `pcm`, in inter-channel samples */
+    uint32_t blocksize, channels, bits_per_sample, sample_rate;
+} flacgpu_block;
+#define FLACGPU_BLOCK_SILENCE (~(uint64_t)0)
+typedef FLAC__StreamDecoderWriteStatus (*flacgpu_block_callback)(const FLAC__StreamDecoder *decoder, const flacgpu_block *blocks,
+                                                                 uint32_t nblocks, const void *pcm, uint32_t bytes_per_sample,
+                                                                 void *client_data);
+FLAC__bool flacgpu_stream_decoder_set_block_callback(FLAC__StreamDecoder *decoder, flacgpu_block_callback callback);
+
 /* FLAC__stream_encoder_process_interleaved for 16-bit interleaved input (an extension beside the libFLAC entry point,
  * stream_encoder.h:1777-1824: same buffering, same return value): saves the caller the widening copy to FLAC__int32. */
 FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *encoder, const int16_t *buffer, uint32_t samples);

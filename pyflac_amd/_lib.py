@@ -84,6 +84,8 @@ DEC_READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.POINTER(C
 DEC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Frame), C.POINTER(C.POINTER(C.c_int32)), C.c_void_p)
 DEC_META_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(StreamMetadata), C.c_void_p)
 DEC_ERROR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+# flacgpu_block_callback (include/flacgpu.h): decoder, blocks, nblocks, pcm, bytes per sample, client data
+DEC_BLOCK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p)
 
 ENCODER_FUNCTIONS = [
     'new', 'delete', 'set_verify', 'set_channels', 'set_bits_per_sample', 'set_sample_rate',
@@ -114,7 +116,7 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
-                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_stream_decoder_set_subframe_detail']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
 
@@ -163,6 +165,8 @@ def lib():
     L.FLAC__stream_decoder_get_state.restype = C.c_int
     L.FLAC__stream_decoder_init_stream.argtypes = [vp, DEC_READ_CB, vp, vp, vp, vp, DEC_WRITE_CB, DEC_META_CB, DEC_ERROR_CB, vp]
     L.FLAC__stream_decoder_init_stream.restype = C.c_int
+    L.flacgpu_stream_decoder_set_block_callback.argtypes = [vp, DEC_BLOCK_CB]
+    L.flacgpu_stream_decoder_set_block_callback.restype = C.c_int
     L.FLAC__stream_decoder_init_file.argtypes = [vp, C.c_char_p, DEC_WRITE_CB, DEC_META_CB, DEC_ERROR_CB, vp]
     L.FLAC__stream_decoder_init_file.restype = C.c_int
     for n in ('finish', 'process_single', 'process_until_end_of_stream', 'process_until_end_of_metadata', 'flush', 'reset'):

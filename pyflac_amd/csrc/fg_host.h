@@ -72,6 +72,7 @@ int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const F
 int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results, int32_t *d_pcm, hipStream_t stream);
 int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const FgDecSub *d_subs,
                             const int32_t *d_scratch, int32_t *d_warm, hipStream_t stream);
+int fg_launch_narrow16(const int32_t *d_in, int16_t *d_out, uint64_t n, hipStream_t stream);
 int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream);
 int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
                          const uint16_t *d_crctab, hipStream_t stream);

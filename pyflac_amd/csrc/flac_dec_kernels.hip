@@ -815,7 +815,33 @@ fg_compare_kernel(const int32_t *a, const int32_t *b, u64 n, unsigned long long 
     if (best != ~(u64)0) atomicMin(first, (unsigned long long)best);
 }
 
+// int32 samples -> int16 (the stream decoder's block delivery for streams of at most 16 bits per sample): eight per thread
+__global__ void __launch_bounds__(256) fg_narrow16_kernel(const int32_t *in, int16_t *out, u64 n)
+{
+    const u64 stride = (u64)gridDim.x * 256 * 8;
+    for (u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const int4 a = *(const int4 *)(in + i), b = *(const int4 *)(in + i + 4);
+            uint4 o;
+            o.x = ((uint32_t)a.x & 0xFFFFu) | ((uint32_t)a.y << 16); o.y = ((uint32_t)a.z & 0xFFFFu) | ((uint32_t)a.w << 16);
+            o.z = ((uint32_t)b.x & 0xFFFFu) | ((uint32_t)b.y << 16); o.w = ((uint32_t)b.z & 0xFFFFu) | ((uint32_t)b.w << 16);
+            *(uint4 *)(out + i) = o;
+        }
+        else for (u64 j = i; j < n; j++) out[j] = (int16_t)in[j];
+    }
+}
+
 }  // namespace
+
+// (both buffers 16-byte aligned)
+extern "C" int fg_launch_narrow16(const int32_t *d_in, int16_t *d_out, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    uint64_t nb = (n + 2047) / 2048;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(fg_narrow16_kernel, dim3((uint32_t)nb), dim3(256), 0, stream, d_in, d_out, (u64)n);
+    return (int)hipGetLastError();
+}
 
 extern "C" int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream)
 {

@@ -778,6 +778,92 @@ struct HostPcm {
     int32_t *data() const { return p; }
 };
 
+// The bytes not yet consumed.  What the decoder needs of std::vector<uint8_t>, without its value-initialisation: the read callback
+// is handed up to 16 MiB of room at a time, and zeroing that room first cost as much as the whole decode of a 600 s stream.
+struct ByteBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf &) = delete;
+    ByteBuf &operator=(const ByteBuf &) = delete;
+    ~ByteBuf() { free(p); }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint8_t *begin() { return p; }
+    uint8_t &operator[](size_t i) { return p[i]; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+    // one allocation of a finished decoder is kept for the next one (its pages are already there)
+    static std::mutex &pool_mu() { static std::mutex m; return m; }
+    static ByteBuf &pool() { static ByteBuf spare; return spare; }
+    void give_back()
+    {
+        std::lock_guard<std::mutex> lk(pool_mu());
+        ByteBuf &sp = pool();
+        if (cap > sp.cap) { free(sp.p); sp.p = p; sp.cap = cap; p = nullptr; cap = 0; n = 0; }
+        else if (cap > (1u << 20)) { free(p); p = nullptr; cap = 0; n = 0; }
+        else n = 0;
+    }
+    void resize(size_t m)          // (new bytes are NOT initialised)
+    {
+        if (m > cap && cap < (1u << 20)) {
+            std::lock_guard<std::mutex> lk(pool_mu());
+            ByteBuf &sp = pool();
+            if (sp.cap >= m && sp.cap > cap) {
+                if (n) memcpy(sp.p, p, n);
+                free(p); p = sp.p; cap = sp.cap; sp.p = nullptr; sp.cap = 0;
+            }
+        }
+        if (m > cap) {
+            size_t nc = cap ? cap : 65536;
+            while (nc < m) nc *= 2;
+            uint8_t *np = (uint8_t *)realloc(p, nc);
+            if (!np) throw std::bad_alloc();
+            p = np; cap = nc;
+        }
+        n = m;
+    }
+    void erase(uint8_t *a, uint8_t *b) { memmove(a, b, (size_t)(p + n - b)); n -= (size_t)(b - a); }
+};
+
+// Device buffers of finished stream decoders, kept for the next one (hipMalloc / hipFree of a few hundred megabytes cost
+// milliseconds): a handful of slots, the largest buffers stay.
+struct DevPool {
+    struct Slot { DevBuf b; int device = -1; };
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static Slot *slots() { static Slot s[4]; return s; }
+    static bool take(DevBuf &into, size_t bytes, int device)
+    {
+        std::lock_guard<std::mutex> lk(mu());
+        Slot *s = slots();
+        int best = -1;
+        for (int i = 0; i < 4; i++) if (s[i].b.p && s[i].device == device && s[i].b.cap >= bytes && (best < 0 || s[i].b.cap < s[best].b.cap)) best = i;
+        if (best < 0) return false;
+        into.release();
+        into = s[best].b; s[best].b.p = nullptr; s[best].b.cap = 0; s[best].device = -1;
+        return true;
+    }
+    static void give(DevBuf &from, int device)
+    {
+        if (!from.p) return;
+        std::lock_guard<std::mutex> lk(mu());
+        Slot *s = slots();
+        int at = -1;
+        for (int i = 0; i < 4; i++) if (!s[i].b.p) { at = i; break; }
+        if (at < 0) { for (int i = 0; i < 4; i++) if (at < 0 || s[i].b.cap < s[at].b.cap) at = i; if (s[at].b.cap >= from.cap) { from.release(); return; } s[at].b.release(); }
+        s[at].b = from; s[at].device = device;
+        from.p = nullptr; from.cap = 0;
+    }
+};
+inline bool dev_ensure(DevBuf &b, size_t bytes, int device)
+{
+    if (b.cap >= bytes) return true;
+    if (DevPool::take(b, bytes, device)) return true;
+    return b.ensure(bytes);
+}
+
 struct DecImpl;
 void fill_subframes(DecImpl *d, FLAC__Frame &f, const FgDecFrame &fr, uint32_t fi);
 
@@ -796,7 +882,7 @@ struct DecImpl {
     std::vector<uint32_t> app_ids;              // APPLICATION ids whose filter is the opposite of respond[APPLICATION]
     flacgpu_ctx *ctx;
     // stream state
-    std::vector<uint8_t> buf;       // bytes not yet consumed (from `base` on)
+    ByteBuf buf;                    // bytes not yet consumed (from `base` on)
     uint64_t consumed_total;        // stream offset of buf[0]
     bool eof;
     bool have_meta, have_si;
@@ -830,6 +916,14 @@ struct DecImpl {
     bool walk_pending = false;
     uint64_t walk_from = 0;       // offset in buf
     uint64_t ix_origin = 0;       // offset in buf where the index last started outside a frame
+    size_t pull_want = 1 << 16;
+    double prof_ms[6] = {0, 0, 0, 0, 0, 0};     // FLACGPU_API_PROF: pull, index, decode_available, delivery, erase, metadata
+    // block delivery (flacgpu_stream_decoder_set_block_callback)
+    flacgpu_block_callback block_cb = nullptr;
+    bool round_blocks = false;    // the queued round was decoded for block delivery: pcm holds it interleaved
+    uint32_t round_bytes = 4;     // ... as int16 (2) or int32 (4)
+    std::vector<flacgpu_block> blocks;
+    DevBuf d_pcm16;
     uint64_t walk_stuck_at = UINT64_MAX;
     FLAC__EntropyCodingMethod_PartitionedRiceContents rice_contents[8];
     std::vector<uint32_t> rice_prm[8], rice_raw[8];
@@ -848,13 +942,22 @@ void reset_stream(DecImpl *d)
     d->do_md5 = d->md5_checking != 0; d->md5.init();
     d->first_pos = 0; d->fixed_blocksize = 0; d->last_set = false; memset(&d->last_hdr, 0, sizeof d->last_hdr);
     d->win = fgref::RefWindows(); d->walker = fgref::Walker(); d->walk_pending = false; d->walk_from = 0; d->ix_origin = 0; d->walk_stuck_at = UINT64_MAX;
+    d->pull_want = 1 << 16; d->round_blocks = false;
 }
 
 // Pull more bytes.  Returns false on abort.  Sets d->eof at end of stream.  `short_read` reports that the
 // callback returned fewer bytes than requested (everything currently available has been delivered).
+struct ProfSpan {
+    double *acc; std::chrono::steady_clock::time_point t0;
+    explicit ProfSpan(double *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~ProfSpan() { *acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() / 1e6; }
+};
+
 bool pull(DecImpl *d, bool *short_read)
 {
-    const size_t want = 1 << 16;
+    ProfSpan span(&d->prof_ms[0]);
+    // (a client that keeps filling the request is asked for more at a time: 64 KiB .. 16 MiB)
+    const size_t want = d->pull_want;
     const size_t old = d->buf.size();
     d->buf.resize(old + want);
     size_t got = want;
@@ -864,6 +967,7 @@ bool pull(DecImpl *d, bool *short_read)
         d->buf.resize(old + got);
         if (got == 0) d->eof = true;
         else d->win.chunk_end.push_back(d->consumed_total + d->buf.size());
+        if (got == want && d->pull_want < (16u << 20)) d->pull_want *= 2;
         *short_read = false;
         return true;
     }
@@ -884,6 +988,7 @@ bool pull(DecImpl *d, bool *short_read)
     if (got) d->win.chunk_end.push_back(d->consumed_total + d->buf.size());
     if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || got == 0) d->eof = true;
     *short_read = got < want;
+    if (got == want && d->pull_want < (16u << 20)) d->pull_want *= 2;
     return true;
 }
 
@@ -1096,7 +1201,7 @@ bool decode_available(DecImpl *d)
     auto tl = tp0;
     std::vector<uint64_t> offs(nframes + 1);
     for (uint32_t i = 0; i <= nframes; i++) offs[i] = d->ix.bounds[d->frames_delivered_bound + i] - first;
-    if (!d->d_stream.ensure((size_t)(last - first) + 64)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+    if (!dev_ensure(d->d_stream, (size_t)(last - first) + 64, c->device)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     if (!HIPOK(hipMemcpy(d->d_stream.p, d->buf.data() + first, (size_t)(last - first), hipMemcpyHostToDevice))) {
         d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
     }
@@ -1105,27 +1210,42 @@ bool decode_available(DecImpl *d)
     // upper bound of the sample count: 65535 per frame is wasteful; use the STREAMINFO max block size when known
     uint64_t cap = (uint64_t)nframes * ((d->have_si && d->si.max_blocksize) ? d->si.max_blocksize : 65535);
     const uint32_t Cb = C ? C : 8;
-    if (!d->d_pcm.ensure((size_t)cap * Cb * 4)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+    if (!dev_ensure(d->d_pcm, (size_t)cap * Cb * 4, c->device)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     flacgpu_decode_stats st;
     std::vector<FgDecResult> status(nframes);
     std::vector<FgDecFrame> frames;
     d->detail.level = d->subframe_detail;
+    // block delivery: channels interleaved (one buffer for the whole round), no per-subframe records
+    const bool blocks = d->block_cb != nullptr && !d->do_md5 && C != 0;
+    DecDetail *const detail = (C && d->subframe_detail > 0 && !blocks) ? &d->detail : nullptr;
     bool ok = decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
-                                 cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr);
+                                 cap, blocks ? 1 : 0, status.data(), &frames, &st, false, 0, nullptr, detail);
     if (!ok && st.total_samples > cap && st.total_samples <= (uint64_t)nframes * 65535) {
         // A frame header that names a larger block than STREAMINFO's maximum (damage that the CRC-8 let through, or a stream
         // that lies about itself): libFLAC decodes such a frame all the same.  Once more with room for what the headers say.
         cap = st.total_samples;
-        if (!d->d_pcm.ensure((size_t)cap * Cb * 4)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
+        if (!dev_ensure(d->d_pcm, (size_t)cap * Cb * 4, c->device)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
         ok = decode_frames_impl(c, d->d_stream.p, last - first, offs.data(), nframes, C, d->have_si ? d->si.bits_per_sample : 0, d->d_pcm.p,
-                                cap, 0, status.data(), &frames, &st, false, 0, nullptr, (C && d->subframe_detail > 0) ? &d->detail : nullptr);
+                                cap, blocks ? 1 : 0, status.data(), &frames, &st, false, 0, nullptr, detail);
     }
     if (!ok) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     lap("decode", tl);
     const size_t npcm = (size_t)st.total_samples * (C ? C : 2);
     if (!d->pcm.ensure(npcm)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     lap("buffer", tl);
-    if (st.total_samples && !HIPOK(hipMemcpy(d->pcm.data(), d->d_pcm.p, npcm * 4, hipMemcpyDeviceToHost))) {
+    d->round_blocks = blocks; d->round_bytes = 4;
+    if (blocks) {
+        bool narrow = true;
+        for (const FgDecFrame &fr : frames) if (fr.bps > 16) { narrow = false; break; }
+        if (narrow && npcm) {
+            if (!dev_ensure(d->d_pcm16, npcm * 2 + 16, c->device) || fg_launch_narrow16((const int32_t *)d->d_pcm.p, (int16_t *)d->d_pcm16.p, npcm, c->stream) != 0 ||
+                !HIPOK(hipMemcpyAsync(d->pcm.data(), d->d_pcm16.p, npcm * 2, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+                d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
+            }
+            d->round_bytes = 2;
+        }
+    }
+    if (d->round_bytes == 4 && st.total_samples && !HIPOK(hipMemcpy(d->pcm.data(), d->d_pcm.p, npcm * 4, hipMemcpyDeviceToHost))) {
         d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false;
     }
     lap("download", tl);
@@ -1230,6 +1350,62 @@ bool deliver_one(DecImpl *d)
     d->last_hdr = f.header; d->last_set = true;
     d->samples_decoded = number + fr.n;
     return write_frame(d, f, chan);
+}
+
+// Block delivery: up to `limit` queued frames in one call of the block callback (the same headers, numbering and gap filling as
+// deliver_one).
+bool deliver_blocks(DecImpl *d, size_t limit)
+{
+    d->blocks.clear();
+    const size_t left = d->frames.size() - d->next_frame;
+    const size_t end = d->next_frame + std::min(left, limit);
+    for (; d->next_frame < end; d->next_frame++) {
+        const FgDecFrame &fr = d->frames[d->next_frame];
+        const FgDecResult &rs = d->status[d->next_frame];
+        if (rs.err != 0 && rs.err != 3) continue;          // (not reached, see deliver_one)
+        const uint64_t fpos = d->first_pos + fr.byte_off;
+        FLAC__FrameHeader h;
+        memset(&h, 0, sizeof h);
+        h.blocksize = fr.n; h.sample_rate = d->si.sample_rate;
+        HostHeader hh;
+        uint64_t number = d->samples_decoded;
+        if (fpos < d->buf.size() && parse_header(d->buf.data() + fpos, d->buf.size() - fpos, d->have_si ? &d->si : nullptr, &hh)) {
+            if (hh.sample_rate) h.sample_rate = hh.sample_rate;
+            if (hh.variable) number = hh.number;
+            else {
+                const uint32_t fixed = (d->have_si && d->si.min_blocksize == d->si.max_blocksize && d->si.min_blocksize) ? d->si.min_blocksize
+                                       : (d->fixed_blocksize ? d->fixed_blocksize : fr.n);
+                if (!d->fixed_blocksize) d->fixed_blocksize = fixed;
+                number = hh.number * (uint64_t)fixed;
+            }
+        }
+        h.channels = fr.channels; h.channel_assignment = (FLAC__ChannelAssignment)fr.ca; h.bits_per_sample = fr.bps;
+        h.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER; h.number.sample_number = number;
+        if (d->last_set && d->last_hdr.number.sample_number + d->last_hdr.blocksize < number && d->last_hdr.sample_rate == h.sample_rate &&
+            d->last_hdr.channels == h.channels && d->last_hdr.bits_per_sample == h.bits_per_sample && d->last_hdr.blocksize >= 16) {
+            uint64_t need = number - (d->last_hdr.number.sample_number + d->last_hdr.blocksize);
+            FLAC__FrameHeader e = d->last_hdr;
+            if (need > 5ull * e.sample_rate) need = 5ull * e.sample_rate;
+            if (need > 50ull * e.blocksize) need = 50ull * e.blocksize;
+            while (need) {
+                e.number.sample_number += e.blocksize;
+                if (need < e.blocksize) e.blocksize = (uint32_t)need;
+                need -= e.blocksize;
+                d->blocks.push_back(flacgpu_block{e.number.sample_number, FLACGPU_BLOCK_SILENCE, e.blocksize, e.channels, e.bits_per_sample, e.sample_rate});
+            }
+        }
+        d->blocks.push_back(flacgpu_block{number, fr.out_off, fr.n, fr.channels, fr.bps, h.sample_rate});
+        d->last_blocksize = fr.n; d->last_ca = fr.ca;
+        d->last_hdr = h; d->last_set = true;
+        d->samples_decoded = number + fr.n;
+    }
+    if (d->blocks.empty()) return true;
+    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+    if (d->block_cb(&d->pub, d->blocks.data(), (uint32_t)d->blocks.size(), d->pcm.data(), d->round_bytes, d->client) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) {
+        d->state = FLAC__STREAM_DECODER_ABORTED;
+        return false;
+    }
+    return true;
 }
 
 // FLAC__Frame.subframes[] of a delivered frame (format.h:285-396, pyflac/builder/decoder.py:146-231): what the parse kernel
@@ -1367,7 +1543,7 @@ bool fill_queue(DecImpl *d)
         if (d->frames_delivered_bound > 0 && !d->ix.bounds.empty()) {
             const uint64_t cut = d->ix.bounds[d->frames_delivered_bound];
             if (cut > 0) {
-                d->buf.erase(d->buf.begin(), d->buf.begin() + (size_t)cut);
+                { ProfSpan span(&d->prof_ms[4]); d->buf.erase(d->buf.begin(), d->buf.begin() + (size_t)cut); }
                 d->consumed_total += cut;
                 std::vector<uint64_t> nbnd;
                 for (size_t i = d->frames_delivered_bound; i < d->ix.bounds.size(); i++) nbnd.push_back(d->ix.bounds[i] - cut);
@@ -1387,14 +1563,14 @@ bool fill_queue(DecImpl *d)
         const uint64_t fdb = d->frames_delivered_bound;
         for (int attempt = 0; attempt < 2; attempt++) {
             const auto tf0 = std::chrono::steady_clock::now();
-            d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr);
+            { ProfSpan span(&d->prof_ms[1]); d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr); }
             if (getenv("FLACGPU_API_PROF"))
                 fprintf(stderr, "[flacgpu api prof] index feed %8.3f ms (%zu bytes, %s)\n",
                         std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tf0).count() / 1000.0, d->buf.size(),
                         d->ix.fast ? "fast" : "careful");
             bool redo = d->ix.fast && (d->ix.fast_failed || !d->ix.errors.empty());
             if (!redo && d->ix.bounds.size() >= 2 && d->frames_delivered_bound + 1 < d->ix.bounds.size()) {
-                if (!decode_available(d)) return false;
+                { ProfSpan span(&d->prof_ms[2]); if (!decode_available(d)) return false; }
                 if (d->ix.fast) for (const FgDecResult &r : d->status) if (r.err != 0 && r.err != 3) { redo = true; break; }
             }
             if (!redo) break;
@@ -1461,7 +1637,7 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *dec)
     DecImpl *d = impl(dec);
     if (d->file && d->own_file) fclose(d->file);
     if (d->ctx) (void)hipSetDevice(d->ctx->device);
-    d->d_stream.release(); d->d_pcm.release();
+    d->d_stream.release(); d->d_pcm.release(); d->d_pcm16.release();
     d->pcm.give_back();
     delete d;
 }
@@ -1469,6 +1645,14 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *dec)
 // Extension: how much of FLAC__Frame.subframes[] the write callback sees.  0: nothing (type fields stay zero), 1 (default):
 // type, wasted bits, order, precision, shift, coefficients, warm-up, partition order and Rice parameters, 2: also the
 // `residual` / verbatim `data` sample arrays (one more device-to-host copy of the size of the PCM).
+FLAC__bool flacgpu_stream_decoder_set_block_callback(FLAC__StreamDecoder *dec, flacgpu_block_callback callback)
+{
+    DecImpl *d = impl(dec);
+    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    d->block_cb = callback;
+    return 1;
+}
+
 void flacgpu_stream_decoder_set_subframe_detail(FLAC__StreamDecoder *dec, int level) { impl(dec)->subframe_detail = level < 0 ? 0 : level > 2 ? 2 : level; }
 
 FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *dec, FLAC__bool value)
@@ -1616,6 +1800,15 @@ FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *dec)
         if (memcmp(d->si.md5sum, zero, 16) != 0 && memcmp(d->si.md5sum, got, 16) != 0) md5_ok = 0;
     }
     d->md5_checking = 0;
+    d->block_cb = nullptr;
+    if (getenv("FLACGPU_API_PROF"))
+        fprintf(stderr, "[flacgpu api prof] decoder totals: read callback + buffer %.3f ms, index %.3f, upload/decode/download %.3f, delivery %.3f, buffer compaction %.3f\n",
+                d->prof_ms[0], d->prof_ms[1], d->prof_ms[2], d->prof_ms[3], d->prof_ms[4]);
+    for (double &v : d->prof_ms) v = 0;
+    // the large buffers go to the next decoder (a finished decoder may live on for a while, e.g. until a garbage collector runs)
+    d->pcm.give_back();
+    d->buf.give_back();
+    if (d->ctx) { DevPool::give(d->d_stream, d->ctx->device); DevPool::give(d->d_pcm, d->ctx->device); DevPool::give(d->d_pcm16, d->ctx->device); }
     reset_stream(d);
     memset(d->respond, 0, sizeof d->respond); d->respond[FLAC__METADATA_TYPE_STREAMINFO] = true; d->app_ids.clear();
     d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
@@ -1653,6 +1846,7 @@ FLAC__bool FLAC__stream_decoder_process_single(FLAC__StreamDecoder *dec)
         return 1;                                    // one call consumes the metadata, like libFLAC
     }
     if (!fill_queue(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
+    if (d->round_blocks) return deliver_blocks(d, 1) ? 1 : 0;
     return deliver_one(d) ? 1 : 0;
 }
 
@@ -1673,7 +1867,9 @@ FLAC__bool FLAC__stream_decoder_process_until_end_of_stream(FLAC__StreamDecoder 
         if (d->state == FLAC__STREAM_DECODER_END_OF_STREAM) return 1;
         if (d->state == FLAC__STREAM_DECODER_ABORTED) return 0;
         if (!fill_queue(d)) return d->state == FLAC__STREAM_DECODER_END_OF_STREAM;
-        while (d->next_frame < d->frames.size())
+        ProfSpan span(&d->prof_ms[3]);
+        if (d->round_blocks) { if (!deliver_blocks(d, ~(size_t)0)) return 0; }
+        else while (d->next_frame < d->frames.size())
             if (!deliver_one(d)) return 0;
     }
 }

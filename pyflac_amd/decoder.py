@@ -20,6 +20,10 @@ from . import _lib
 from . import wav
 
 _L = _lib.lib()
+# flacgpu_block (include/flacgpu.h)
+_BLOCK_DTYPE = np.dtype([('sample_number', '<u8'), ('offset', '<u8'), ('blocksize', '<u4'), ('channels', '<u4'),
+                         ('bits_per_sample', '<u4'), ('sample_rate', '<u4')])
+_BLOCK_SILENCE = 0xFFFFFFFFFFFFFFFF
 
 
 class DecoderState(Enum):
@@ -86,7 +90,6 @@ class _Decoder:
                     num_bytes[0] = 0
                     return 1   # END_OF_STREAM: a one-shot buffer has nothing more to come
                 maximum_bytes = int(num_bytes[0])
-                data = bytearray()
                 while True:
                     # wait until there is something in the buffer, an error occurred, or finish() was called
                     self._event.wait()
@@ -102,13 +105,14 @@ class _Decoder:
                     self._lock.release()
                     num_bytes[0] = 0
                     return 1   # END_OF_STREAM
+                taken = []
                 try:
                     # whole queued items while they fit, then the head of the next one; items are memoryviews, so taking
                     # a head is O(1) (slicing a bytes object here would copy the remainder on every call)
                     while self._buffer and maximum_bytes > 0:
                         head = self._buffer[0]
                         take = min(len(head), maximum_bytes)
-                        data += head[:take]
+                        taken.append(head[:take])
                         maximum_bytes -= take
                         if take == len(head):
                             self._buffer.popleft()
@@ -118,10 +122,13 @@ class _Decoder:
                         self._event.clear()
                 finally:
                     self._lock.release()
-                actual_bytes = len(data)
+                # straight from each item into the decoder's buffer (outside the lock)
+                dst = C.cast(byte_buffer, C.c_void_p).value
+                actual_bytes = 0
+                for part in taken:
+                    C.memmove(dst + actual_bytes, np.frombuffer(part, np.uint8).ctypes.data, len(part))
+                    actual_bytes += len(part)
                 num_bytes[0] = actual_bytes
-                if actual_bytes:
-                    C.memmove(byte_buffer, (C.c_char * actual_bytes).from_buffer(data), actual_bytes)
                 return 0   # CONTINUE
             except Exception:   # noqa: BLE001  (def_extern(error=ABORT) in the reference)
                 return 2
@@ -148,6 +155,33 @@ class _Decoder:
             except Exception:   # noqa: BLE001  (def_extern(error=ABORT) in the reference)
                 return 1
 
+        def _blocks(_dec, blocks, nblocks, pcm, bytes_per_sample, _client):
+            # libflacgpu's block delivery (include/flacgpu.h, flacgpu_block_callback): a whole round of decoded frames at once,
+            # interleaved and already int16 for streams of up to 16 bits.  One copy into an array of ours, then a view of it
+            # per frame for the write callback -- what _write produces, without the per-frame crossing through ctypes.
+            try:
+                rec = np.frombuffer((C.c_uint8 * (32 * nblocks)).from_address(blocks), dtype=_BLOCK_DTYPE)
+                nch = int(rec['channels'][0])
+                bps = rec['bits_per_sample']
+                if not getattr(self, '_allow_any_bps', False) and not np.all((bps == 16) | (bps == 32)):
+                    raise ValueError('Only int16/int32 data type is supported')
+                if not np.all(rec['channels'] == nch):
+                    raise ValueError('channel count changes inside a round')
+                offs, sizes, rates = rec['offset'].tolist(), rec['blocksize'].tolist(), rec['sample_rate'].tolist()
+                real = rec['offset'] != _BLOCK_SILENCE
+                total = int((rec['offset'][real] + rec['blocksize'][real]).max()) if real.any() else 0
+                ctype = C.c_int16 if bytes_per_sample == 2 else C.c_int32
+                audio = np.frombuffer((ctype * (total * nch)).from_address(pcm), dtype=np.int16 if bytes_per_sample == 2 else np.int32)
+                audio = audio.reshape(total, nch).copy()
+                if bytes_per_sample == 2 and not np.all(bps == 16):
+                    audio = audio.astype(np.int32)            # (the per-frame path hands out int16 for 16-bit frames only)
+                cb = self.write_callback
+                for o, n, sr in zip(offs, sizes, rates):
+                    cb(audio[o:o + n] if o != _BLOCK_SILENCE else np.zeros((n, nch), audio.dtype), sr, nch, n)
+                return 0   # CONTINUE
+            except Exception:   # noqa: BLE001
+                return 1
+
         def _error(_dec, status, _client):
             message = _lib.string_table('FLAC__StreamDecoderErrorStatusString', 5)[status].decode()
             self.logger.error(f'Error in libFLAC decoder: {message}')
@@ -159,9 +193,11 @@ class _Decoder:
         self._c_read = _lib.DEC_READ_CB(_read)
         self._c_write = _lib.DEC_WRITE_CB(_write)
         self._c_error = _lib.DEC_ERROR_CB(_error)
+        self._c_blocks = _lib.DEC_BLOCK_CB(_blocks)
         self._c_meta_null = C.cast(None, _lib.DEC_META_CB)
 
     def _init_stream(self):
+        _L.flacgpu_stream_decoder_set_block_callback(self._decoder, self._c_blocks)
         rc = _L.FLAC__stream_decoder_init_stream(self._decoder, self._c_read, None, None, None, None, self._c_write,
                                                  self._c_meta_null, self._c_error, None)
         if rc != 0:
@@ -233,6 +269,7 @@ class FileDecoder(_Decoder):
         else:
             self.__tmp = tempfile.NamedTemporaryFile(suffix='.wav')
             self.__output_file = Path(self.__tmp.name)
+        _L.flacgpu_stream_decoder_set_block_callback(self._decoder, self._c_blocks)
         rc = _L.FLAC__stream_decoder_init_file(self._decoder, str(input_file).encode('utf-8'), self._c_write,
                                                self._c_meta_null, self._c_error, None)
         if rc != 0:
@@ -277,7 +314,8 @@ class OneShotDecoder(_Decoder):
         self.write_callback = write_callback
         self._init_stream()
         while len(self._buffer) > 0:
-            _L.FLAC__stream_decoder_process_single(self._decoder)
+            if not _L.FLAC__stream_decoder_process_single(self._decoder):
+                break       # (aborted: nothing will read the rest)
         self._done = True
         self._event.set()
         # The reference stops here (pyflac/decoder.py:387-391), which drops the frames libFLAC still holds in its

@@ -49,6 +49,60 @@ def decode(data, read_size=8192, md5_checking=False):
     return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'blocks': blocks, 'finish': bool(fin), 'events': events}
 
 
+def decode_blocks(data, read_size=8192):
+    """The same through libflacgpu's block delivery (include/flacgpu.h, flacgpu_block_callback): what the callbacks see, in the
+    form decode() records it."""
+    from pyflac_amd import _lib
+    L = _lib.lib()
+    dec = C.c_void_p(L.FLAC__stream_decoder_new())
+    pos = [0]
+    frames, errors, events, calls = [], [], [], [0]
+    dt = np.dtype([('sample_number', '<u8'), ('offset', '<u8'), ('blocksize', '<u4'), ('channels', '<u4'), ('bits_per_sample', '<u4'),
+                   ('sample_rate', '<u4')])
+
+    def _r(d, buf, pn, cd):
+        n = min(pn[0], len(data) - pos[0], read_size)
+        if n <= 0:
+            pn[0] = 0
+            return 1
+        C.memmove(buf, data[pos[0]:pos[0] + n], n)
+        pos[0] += n
+        pn[0] = n
+        return 0
+
+    def _w(d, fr, bufs, cd):
+        raise AssertionError('the write callback must not be used beside the block callback')
+
+    def _b(d, blocks, n, pcm, nbytes, cd):
+        calls[0] += 1
+        rec = np.frombuffer((C.c_uint8 * (32 * n)).from_address(blocks), dtype=dt)
+        for r in rec:
+            ch, bs = int(r['channels']), int(r['blocksize'])
+            if int(r['offset']) == 0xFFFFFFFFFFFFFFFF:
+                blk = np.zeros((bs, ch), np.int32)
+            else:
+                ct = C.c_int16 if nbytes == 2 else C.c_int32
+                blk = np.frombuffer((ct * (bs * ch)).from_address(pcm + int(r['offset']) * ch * nbytes),
+                                    dtype=np.int16 if nbytes == 2 else np.int32).reshape(bs, ch).astype(np.int32)
+            frames.append([int(r['sample_number']), bs, hashlib.sha256(np.ascontiguousarray(blk, np.int32).tobytes()).hexdigest()[:16]])
+            events.append('f%d' % int(r['sample_number']))
+        return 0
+
+    def _e(d, status, cd):
+        errors.append(int(status))
+        events.append('e%d' % int(status))
+
+    rcb, wcb, ecb, bcb = _lib.DEC_READ_CB(_r), _lib.DEC_WRITE_CB(_w), _lib.DEC_ERROR_CB(_e), _lib.DEC_BLOCK_CB(_b)
+    assert L.flacgpu_stream_decoder_set_block_callback(dec, bcb)
+    rc = L.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb, C.cast(None, _lib.DEC_META_CB), ecb, None)
+    assert rc == 0, rc
+    ok = L.FLAC__stream_decoder_process_until_end_of_stream(dec)
+    state = L.FLAC__stream_decoder_get_state(dec)
+    fin = L.FLAC__stream_decoder_finish(dec)
+    L.FLAC__stream_decoder_delete(dec)
+    return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'finish': bool(fin), 'events': events, 'calls': calls[0]}
+
+
 # ---- FLAC__StreamMetadata mirror (pyflac/builder/encoder.py:129-248) for metadata-callback tests -------------------
 class _SI(C.Structure):
     _fields_ = [('min_blocksize', C.c_uint32), ('max_blocksize', C.c_uint32), ('min_framesize', C.c_uint32),

@@ -316,6 +316,17 @@ class TestDamagedStreams:
     def test_against_reference(self, damage_golden, name, read_size):
         self.check(damage_golden[name if read_size == 8192 else '%s@%d' % (name, read_size)], cases.damaged_stream(name), read_size)
 
+    @pytest.mark.parametrize('name', sorted(cases.DAMAGE_CASES))
+    def test_block_delivery_gives_the_same_sequence(self, damage_golden, name):
+        """flacgpu_stream_decoder_set_block_callback (include/flacgpu.h): a round of frames per call instead of a frame per
+        call -- the same frames (the silence that fills gaps included), numbers, samples and error statuses, in the same order."""
+        from tests import abi_decode
+        want = damage_golden[name]
+        got = abi_decode.decode_blocks(cases.damaged_stream(name))
+        assert got['state'] == want['state'] and got['ok']
+        assert got['frames'] == want['frames'] and got['errors'] == want['errors'] and got['events'] == want['events']
+        assert got['calls'] < max(2, len(want['frames']))
+
     @pytest.mark.parametrize('seed', cases.DAMAGE_FUZZ_SEEDS)
     def test_random_damage_against_reference(self, damage_golden, seed):
         _src, data, read_size = cases.fuzz_damaged_stream(seed)
