@@ -569,10 +569,10 @@ def test_multi_context_returns_streams_in_order():
 
 # ---------------------------------------------------------------------------------------------- FLAC__Frame.subframes[]
 def _decode_with_subframes(data, detail=1):
-    """FLAC__stream_decoder_* through the C ABI with the FULL FLAC__Frame layout (oracle/libflac_ref.py mirrors
+    """FLAC__stream_decoder_* through the C ABI with the FULL FLAC__Frame layout (tests/flac_frame.py mirrors
     pyflac/builder/decoder.py:146-231): what a libFLAC client reads in its write callback."""
     import ctypes as C
-    from oracle import libflac_ref as R
+    from tests import flac_frame as R
     from pyflac_amd import _lib
     L = _lib.lib()
     dec = C.c_void_p(L.FLAC__stream_decoder_new())
