@@ -201,7 +201,8 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->descs, &c->slots, &c->results, &c->dbg, &c->crctab, &c->windows, &c->offsets, &c->scratch_pcm,
-                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_rparams, &c->dec_warm, &c->dec_ranges, &c->pipe};
+                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_rparams, &c->dec_warm, &c->dec_ranges, &c->pipe,
+                      &c->mc_tmp, &c->mc_offs, &c->mc_map, &c->mc_sizes, &c->mc_res, &c->mc_foffs};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -348,11 +349,14 @@ extern "C" int flacgpu_copy_block_results(flacgpu_ctx *c, void *dst, uint32_t n)
     return hipMemcpy(dst, c->results.p, (size_t)n * sizeof(FgBlockResult), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 
+// `view` > 0: the streams are ONE-channel views of streams of `view` interleaved channels -- entry j stands for channel j % view of
+// the caller's stream j / view (its pcm_offset in inter-channel samples as usual): FgBlockDesc.pcm_off becomes an element offset
+// and FgBlockDesc.reserved the element stride (encode_multichannel below).
 static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const void *d_pcm, int pcm_is_i16,
                                 const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_cap,
-                                void *d_offsets, flacgpu_encode_stats *st)
+                                void *d_offsets, flacgpu_encode_stats *st, uint32_t view = 0)
 {
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     if (s->blocksize < 16 || s->blocksize > 65535) { fg_set_error("invalid blocksize"); return false; }
     if (s->max_partition_order > 8) { fg_set_error("max_residual_partition_order > 8 is not supported by the GPU path"); return false; }
@@ -370,7 +374,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         memcpy(key.data(), s, sb);
         if (tb) memcpy(key.data() + sb, streams, tb);
         // (the kernel selection switches -- tuning aids read per call -- decide which blocks count as pipeline blocks: part of the key)
-        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (getenv("FLACGPU_NO_FAST") ? 2 : 0) |
+        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (getenv("FLACGPU_NO_FAST") ? 2 : 0) | (view << 4) |
                                        ((getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) ? 4 : 0) |
                                        ((getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1) ? 8 : 0));
     }
@@ -387,14 +391,14 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         while (pos < streams[i].nsamples) {
             FgBlockDesc d;
             const uint64_t left = streams[i].nsamples - pos;
-            d.pcm_off = streams[i].pcm_offset + pos;
+            d.pcm_off = view ? (streams[i].pcm_offset + pos) * view + (i % view) : streams[i].pcm_offset + pos;
             d.n = (uint32_t)std::min<uint64_t>(left, s->blocksize);
             d.frame_number = fn++;
             if (s->max_lpc_order && d.n != win_n) { win_n = d.n; win_off = c->window_offset(d.n, s->apod_parts); }
             d.win_off = s->max_lpc_order ? win_off : 0;
             d.forced_ca = 0xFF;
             d.out_slot = (uint32_t)built.size();
-            d.reserved = 0;
+            d.reserved = view;
             built.push_back(d);
             pos += d.n;
         }
@@ -419,6 +423,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // FLACGPU_PIPE=0, the generic kernel for everything else
     const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
     const bool use_pipe = cfg_fast && !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) && fg_pipe_supported(&P);
+    if (view && !use_pipe && cfg_fast) { fg_set_error("one-channel views need the pipeline or the generic kernel"); return false; }
     const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
     const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
     uint32_t chunk_cap_words = 0, fbw_words = s->bits_per_sample <= 16 ? 800 : 1280;   // 16-bit stereo: 5 workgroups per CU
@@ -691,6 +696,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         st->lpc_order_min_margin = mm;
     }
     c->last_nblocks = nblocks;
+    c->last_chunk_bits = piped ? PL.B.chunk_bits : nullptr;
     if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
     if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);    // (encode_kernel_ms: levels 1, 2)
     else {
@@ -704,6 +710,70 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     return true;
 }
 
+// Streams of three to eight channels.  libFLAC codes their channels independently, so the pipeline's one-channel shape encodes
+// every channel as a strided view of the interleaved PCM -- C complete one-channel frames per block, in a scratch stream -- and
+// flac_enc_merge.hip splices them into the C-channel frames (one header, the C subframes, one CRC-16).
+static bool encode_multichannel(flacgpu_ctx *c, const flacgpu_settings *s, const void *d_pcm, int pcm_is_i16,
+                                const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_cap,
+                                void *d_offsets, flacgpu_encode_stats *st)
+{
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t C = s->channels;
+    flacgpu_settings s1 = *s;
+    s1.channels = 1; s1.do_mid_side = 0; s1.loose_mid_side = 0;
+    std::vector<flacgpu_stream_desc> views((size_t)nstreams * C);
+    std::vector<uint32_t> map;                       // [frame] first view frame, then [frame] distance between the channels' frames
+    uint64_t nframes = 0;
+    for (uint32_t i = 0; i < nstreams; i++) nframes += (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+    if (nframes > 0x7FFFFFFFull / C) { fg_set_error("too many frames"); return false; }
+    map.resize((size_t)nframes * 2);
+    uint64_t fb = 0;
+    for (uint32_t i = 0; i < nstreams; i++) {
+        for (uint32_t ch = 0; ch < C; ch++) { views[(size_t)i * C + ch] = streams[i]; views[(size_t)i * C + ch].prev_channel_assignment = 0; }
+        const uint64_t nb = (streams[i].nsamples + s->blocksize - 1) / s->blocksize;
+        for (uint64_t b = 0; b < nb; b++) { map[fb + b] = (uint32_t)(C * fb + b); map[nframes + fb + b] = (uint32_t)nb; }
+        fb += nb;
+    }
+    memset(st, 0, sizeof *st);
+    st->lpc_order_min_margin = INFINITY;
+    if (nframes == 0) return true;
+    uint32_t nviewblocks = 0;
+    const uint64_t bound = flacgpu_encode_bound(&s1, views.data(), (uint32_t)views.size(), &nviewblocks);
+    if (!c->mc_tmp.ensure((size_t)bound + 64) || !c->mc_offs.ensure(((size_t)nviewblocks + 4) * 8)) return false;
+    flacgpu_encode_stats st1;
+    if (!encode_streams_impl(c, &s1, d_pcm, pcm_is_i16, views.data(), (uint32_t)views.size(), c->mc_tmp.p, bound, c->mc_offs.p, &st1, C)) return false;
+    const uint32_t nf = (uint32_t)nframes;
+    if (!c->mc_map.ensure((size_t)nf * 8) || !c->mc_sizes.ensure((size_t)nf * 8) || !c->mc_res.ensure((size_t)nf * sizeof(FgBlockResult)) ||
+        !c->mc_foffs.ensure(((size_t)nf + 4) * 8) || !c->ensure_pinned_res(64)) return false;
+    HIPCHK(hipEventRecord(c->evs[6], c->stream));
+    HIPCHK(hipMemcpyAsync(c->mc_map.p, map.data(), (size_t)nf * 8, hipMemcpyHostToDevice, c->stream));
+    if (fg_launch_merge((const FgBlockResult *)c->results.p, c->last_chunk_bits, (const unsigned long long *)c->mc_offs.p, (const uint8_t *)c->mc_tmp.p,
+                        (const uint32_t *)c->mc_map.p, (const uint32_t *)c->mc_map.p + nf, C, nf, (uint32_t *)c->mc_sizes.p, (uint32_t *)c->mc_sizes.p + nf,
+                        (unsigned long long *)c->mc_foffs.p, (uint8_t *)d_out, out_cap, (FgBlockResult *)c->mc_res.p, (unsigned long long *)d_offsets,
+                        c->stream) != 0) {
+        fg_set_error("frame merge kernel launch failed"); return false;
+    }
+    unsigned long long *tail = (unsigned long long *)c->h_res;
+    HIPCHK(hipMemcpyAsync(tail, (const char *)c->mc_foffs.p + (size_t)nf * 8, 16, hipMemcpyDeviceToHost, c->stream));
+    // (flacgpu_copy_block_results: one record per frame of the caller's streams)
+    HIPCHK(hipMemcpyAsync(c->results.p, c->mc_res.p, (size_t)nf * sizeof(FgBlockResult), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->evs[7], c->stream));
+    if (fg_stream_wait(c->stream) != hipSuccess) { fg_set_error("frame merge failed"); return false; }
+    float merge_ms = 0.0f;
+    (void)hipEventElapsedTime(&merge_ms, c->evs[6], c->evs[7]);
+    *st = st1;
+    st->nblocks = nf;
+    st->total_bytes = tail[0];
+    st->error_flags = ((uint32_t)tail[1] & ~FG_ERR_REDO) | st1.error_flags | (((uint32_t)tail[1] & FG_ERR_REDO) ? FG_ERR_INTERNAL : 0u);
+    st->total_gpu_ms = st1.total_gpu_ms + merge_ms;
+    st->last_channel_assignment = 0;
+    c->last_nblocks = nf;
+    c->desc_key.clear();                              // (the results buffer no longer matches the cached block list's slots)
+    if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
+    return true;
+}
+
 extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s, const void *d_pcm, int pcm_is_i16,
                                       const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_cap,
                                       void *d_offsets, flacgpu_encode_stats *st)
@@ -711,6 +781,11 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
     flacgpu_encode_stats local;
     if (!st) st = &local;
     if (!c) { fg_set_error("null context"); return -1; }
+    // more than two channels: one-channel views through the pipeline where its shape applies (limit_min_bitrate looks across the
+    // channels of a frame, large blocks and wide samples stay with the generic kernel)
+    if (s->channels > 2 && s->channels <= 8 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12 && !s->limit_min_bitrate && !c->debug &&
+        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0))
+        return encode_multichannel(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
     return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
 }
 

@@ -29,6 +29,10 @@ int fg_pipe_block_ok(uint32_t n, uint32_t max_po);
 size_t fg_pipe_scratch_bytes(const FgEncParams *P, uint32_t nblocks);
 void fg_pipe_carve(const FgEncParams *P, uint32_t nblocks, void *base, FgPipeBufs *B);
 int fg_launch_encode_pipe(const FgPipeLaunch *L);
+int fg_launch_merge(const FgBlockResult *d_res, const uint32_t *d_chunk_bits, const unsigned long long *d_moffs, const uint8_t *d_mtmp,
+                    const uint32_t *d_fbase, const uint32_t *d_fstr, uint32_t channels, uint32_t nframes, uint32_t *d_sizes, uint32_t *d_errs,
+                    unsigned long long *d_offsets, uint8_t *d_dst, unsigned long long dst_cap, FgBlockResult *d_fres,
+                    unsigned long long *d_user_offsets, hipStream_t stream);
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
@@ -113,9 +117,11 @@ struct flacgpu_ctx {
     DevBuf stamp;
     bool wait_signal(unsigned long long seq);   // poll h_sig[0] (bounded), then hipStreamSynchronize; false on a device error
     double log_guard_thr = 1e-6;
-    std::mutex mu;
+    std::recursive_mutex mu;    // (the batch entry points nest: streams of more than two channels run the one-channel encode inside)
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe;
+        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe,
+        mc_tmp, mc_offs, mc_map, mc_sizes, mc_res, mc_foffs;   // streams of more than two channels (fg_ctx.cpp encode_multichannel)
+    const uint32_t *last_chunk_bits = nullptr;   // the pipeline's chunk bit counts of the last encode call (device), or null
     std::vector<unsigned char> desc_key;   // settings + stream list the block list in `dev_descs` was built for
     uint32_t desc_nfast = 0, desc_nws2 = 0, desc_nrag = 0;
     std::vector<FgBlockDesc> dev_descs;   // copy of the block list currently in `descs`

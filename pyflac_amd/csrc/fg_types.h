@@ -42,14 +42,16 @@ struct FgBlockDesc {
                            // evaluated all four candidates there, so limit_min_bitrate applies to mid and side as in any
                            // full frame -- a follower's mid/side are never limited)
     uint32_t out_slot;     // index of the output slot / result / debug record of this block
-    uint32_t reserved;
+    uint32_t reserved;     // 0: the block's samples lie back to back (all channels interleaved); C > 0: a ONE-channel view of a
+                           // stream of C interleaved channels -- pcm_off is then the ELEMENT offset of the view's first sample,
+                           // the next one lies C elements on (fg_ctx.cpp: streams of more than two channels)
 };
 
 struct FgBlockResult {
     uint32_t bytes;
     uint32_t ca;
     uint32_t err;
-    uint32_t best_bits[4];
+    uint32_t best_bits[4];  // (one-channel blocks of the generic kernel: [3] = the frame's bits in front of its padding)
     uint32_t reserved;
 };
 

@@ -126,6 +126,8 @@ struct Enc {
     uint32_t err;
     // bit writer
     uint32_t bitpos, wbase;
+    uint32_t payload_bits = 0;   // the frame's bits in front of its padding
+    uint32_t view = 0;           // FgBlockDesc.reserved: one-channel view of a stream of `view` interleaved channels
     uint32_t *outw;
     uint32_t slot_words;
 
@@ -167,6 +169,28 @@ struct Enc {
     __device__ void stage(const void *pcm, u64 pcm_off, uint32_t ch0, uint32_t nch)
     {
         const uint32_t C = P.channels;
+        if (view) {
+            // a one-channel view of a stream of `view` interleaved channels (FgBlockDesc.reserved): element offset, element stride
+            const i64 lo_ = -((i64)1 << (P.bps - 1)), hi_ = ((i64)1 << (P.bps - 1)) - 1;
+            uint32_t bad_ = 0;
+            if (P.sig_stride == 0) {
+                int32_t *base = (int32_t *)pcm + pcm_off;
+                s0 = base; s1 = base; sstr = view;
+                for (uint32_t i = lane; i < n; i += 64) { const int32_t v = base[(size_t)i * view]; if ((i64)v < lo_ || (i64)v > hi_) bad_ = 1; }
+            }
+            else {
+                sstr = 1;
+                for (uint32_t i = lane; i < n; i += 64) {
+                    const u64 idx = pcm_off + (u64)i * view;
+                    const int32_t v = P.pcm_i16 ? (int32_t)((const int16_t *)pcm)[idx] : ((const int32_t *)pcm)[idx];
+                    if ((i64)v < lo_ || (i64)v > hi_) bad_ = 1;
+                    s0[i] = v;
+                }
+            }
+            if (__any(bad_)) err |= FG_ERR_RANGE;
+            lds_fence();
+            return;
+        }
         const i64 lo = -((i64)1 << (P.bps - 1)), hi = ((i64)1 << (P.bps - 1)) - 1;
         uint32_t bad = 0;
         if (P.sig_stride == 0) {
@@ -1063,6 +1087,7 @@ struct Enc {
     // ---------------------------------------------------------------- frame footer: pad + CRC-16
     __device__ uint32_t finish_frame()
     {
+        payload_bits = bitpos;
         if (bitpos & 7) bitpos += 8 - (bitpos & 7);
         bw_flush(bitpos);
         bw_flush_all();
@@ -1128,6 +1153,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
     e.P = P;
     e.lane = threadIdx.x;
     e.n = d.n;
+    e.view = d.reserved;
     e.err = 0;
     e.lmb_forced = false; e.lmb_forced_ca = d.forced_ca;
     e.window = windows + d.win_off;
@@ -1222,6 +1248,7 @@ fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows
     if (e.lane == 0) {
         FgBlockResult *r = &results[d.out_slot];
         r->bytes = bytes; r->ca = ca; r->err = e.err; r->reserved = 0;
+        if (C == 1) r->best_bits[3] = e.payload_bits;
     }
 }
 

@@ -205,8 +205,10 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
             else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; L = v.x; R = v.y; }
         }
         else {
-            if (P.pcm_i16) L = ((const int16_t *)pcm)[d.pcm_off + i];
-            else L = ((const int32_t *)pcm)[d.pcm_off + i];
+            // (one channel of an interleaved stream of more channels: the block is a view with a stride, see FgBlockDesc)
+            const u64 at = d.pcm_off + (u64)i * (d.reserved ? d.reserved : 1u);
+            if (P.pcm_i16) L = ((const int16_t *)pcm)[at];
+            else L = ((const int32_t *)pcm)[at];
             R = 0;
         }
     };
@@ -859,8 +861,9 @@ FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams
                         else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; a[u] = v.x; b[u] = v.y; }
                     }
                     else {
-                        if (i16) a[u] = ((const int16_t *)pcm)[d.pcm_off + i];
-                        else a[u] = ((const int32_t *)pcm)[d.pcm_off + i];
+                        const u64 at = d.pcm_off + (u64)i * (d.reserved ? d.reserved : 1u);
+                        if (i16) a[u] = ((const int16_t *)pcm)[at];
+                        else a[u] = ((const int32_t *)pcm)[at];
                     }
                 }
             }
@@ -1353,24 +1356,27 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             }
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
                 const int32_t x = samp((int)s);
+                // warm-up samples (the first `order` of the block, all in lane 0) are not residuals: they neither count nor can
+                // they overflow (a predictor with large coefficients -- a square wave under a punched window -- sends the
+                // 'residual' of a sample whose history is still zeros far beyond 32 bits; libFLAC never forms it)
+                const bool real = !guard || lane > 0 || s >= order;
                 int32_t res;
                 if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
                 else if constexpr (FGP_F64) {
                     // x - (sum >> shift): the scaling by 2^-shift is exact, floor() is the arithmetic shift
                     const double xd = (double)x;
                     const double rr = xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl);
-                    if (rr <= -2147483648.0 || rr > 2147483647.0) ovf = 1;
+                    if ((rr <= -2147483648.0 || rr > 2147483647.0) && real) ovf = 1;
                     res = (int32_t)rr;
                     hd[u] = xd;
                 }
                 else {
                     const i64 rr = (i64)x - (pfir48<MAXO>(q, h, u) >> shift);
-                    if (rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) ovf = 1;
+                    if ((rr <= (i64)INT32_MIN || rr > (i64)INT32_MAX) && real) ovf = 1;
                     res = (int32_t)rr;
                 }
                 h[u] = ACC64 ? ppack(x) : x;
-                // warm-up samples (the first `order` of the block, all in lane 0) are not residuals
-                if (!guard || lane > 0 || s >= order) psum += pabs32(res);
+                if (real) psum += pabs32(res);
             };
             uint32_t s0 = 0;
             if (seg >= (uint32_t)MAXO) {

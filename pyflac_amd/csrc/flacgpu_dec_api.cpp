@@ -403,7 +403,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                DecDetail *detail = nullptr, uint64_t status_capacity = ~0ull, const FgDecRange *h_ranges = nullptr,
                                uint32_t nranges = 0)
 {
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     memset(st, 0, sizeof *st);
     if (!HIPOK(hipSetDevice(c->device))) { fg_set_error("hipSetDevice failed"); return false; }
     const bool index_here = h_offsets == nullptr;

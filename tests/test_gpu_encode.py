@@ -464,3 +464,77 @@ def test_loose_mid_side_decision_frame_with_limit_min_bitrate(ctx, seed):
     want, _ = O.encode_stream(cfg, a32)
     out, offs, st = ctx.encode(s, torch.from_numpy(a32).cuda())
     assert stream_header_bytes(s) + out[:st.total_bytes].cpu().numpy().tobytes() == want
+
+
+def _multichannel_pcm(seed, channels, n, bps):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    amp = (1 << (bps - 2)) * 0.5
+    cols = []
+    for c in range(channels):
+        x = amp * np.sin(0.003 * (c + 2) * t + c) + rng.normal(0, amp / 40, n)
+        if c == channels - 1:
+            x = np.full(n, 123.0)                       # a constant channel
+        if c == 1:
+            x = np.round(x / 16) * 16                   # four wasted bits
+        cols.append(np.clip(np.round(x), -(1 << (bps - 1)), (1 << (bps - 1)) - 1))
+    return np.stack(cols, axis=1).astype(np.int32)
+
+
+@pytest.mark.parametrize('channels,bps,level,bs,n', [(3, 16, 5, 4096, 4096 * 5 + 777), (6, 16, 5, 4096, 4096 * 9), (8, 16, 8, 4096, 4096 * 3 + 100),
+                                                     (4, 24, 8, 4096, 4096 * 4 + 63), (6, 16, 0, 1152, 1152 * 7 + 1), (5, 8, 3, 576, 576 * 11 + 17)])
+def test_more_than_two_channels_through_the_pipeline(ctx, monkeypatch, channels, bps, level, bs, n):
+    """Streams of three to eight channels: every channel a one-channel view through the pipeline, the frames spliced by
+    flac_enc_merge.hip (fg_ctx.cpp encode_multichannel).  Bytes equal the oracle's and the generic kernel's (FLACGPU_MC=0),
+    frame index included."""
+    from oracle import oracle as O
+    pcm = _multichannel_pcm(channels * 100 + level, channels, n, bps)
+    got, offs, s = _gpu_stream(ctx, pcm, 48000, bps, level, bs, True)
+    cfg, _ = O.config(level, channels, bps, 48000, bs, True)
+    want, sizes = O.encode_stream(cfg, pcm)
+    assert got[86:] == want[86:]
+    assert list(np.diff(offs)) == list(sizes)
+    monkeypatch.setenv('FLACGPU_MC', '0')
+    ref, offs2, _ = _gpu_stream(ctx, pcm, 48000, bps, level, bs, True)
+    assert ref == got and np.array_equal(offs, offs2)
+
+
+def test_more_than_two_channels_many_streams_int16(ctx):
+    """Several six-channel streams of different lengths in one launch, 16-bit ingest: stream by stream the oracle's bytes."""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    lens = [4096 * 3 + 5, 4096, 17, 4096 * 2 + 2048]
+    streams = [_multichannel_pcm(40 + i, 6, n, 16) for i, n in enumerate(lens)]
+    s = batch.settings(5, 6, 16, 48000, 4096, True)
+    t = torch.from_numpy(np.concatenate(streams).astype(np.int16)).cuda()
+    out, offs, st = ctx.encode(s, t, stream_lengths=lens)
+    body = out[:st.total_bytes].cpu().numpy().tobytes()
+    offs = offs.cpu().numpy()
+    cfg, _ = O.config(5, 6, 16, 48000, 4096, True)
+    fi = 0
+    for x in streams:
+        want, sizes = O.encode_stream(cfg, x)
+        assert body[int(offs[fi]):int(offs[fi + len(sizes)])] == want[86:]
+        fi += len(sizes)
+    assert int(offs[fi]) == len(body) and st.error_flags == 0
+
+
+def test_large_coefficients_do_not_overflow_the_warm_up(ctx):
+    """Fuzz seed 754506 (24-bit square wave, level 8): under a punched subdivide_tukey window the order-9 predictor has
+    coefficients near -9005 at shift 0.  Its residual is zero, but the 'residual' of a warm-up sample -- formed over a history
+    of zeros, which libFLAC never does -- exceeds 32 bits; the evaluation must not count that as an overflow of the candidate."""
+    from oracle import oracle as O
+    from tests import fuzzgen
+    c = fuzzgen.case(754506)
+    assert (c['ch'], c['bps'], c['level'], c['kind']) == (2, 24, 8, 'square')
+    import torch
+    from pyflac_amd import batch
+    s = batch.settings(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+    s.limit_min_bitrate = 1 if c['limit_min_bitrate'] else 0
+    cfg, _ = O.config(c['level'], c['ch'], c['bps'], c['sr'], c['bs'], c['subset'])
+    cfg.limit_min_bitrate = s.limit_min_bitrate
+    arr = c['pcm'].astype(np.int32).reshape(-1, c['ch'])
+    out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+    want, sizes = O.encode_stream(cfg, arr)
+    assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
