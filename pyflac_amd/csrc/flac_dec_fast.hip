@@ -655,60 +655,81 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
 }
 
 // CRC-16 (poly 0x8005, init 0) of frame bytes [0, bytes-2), compared with the stored big-endian CRC.
+//
+// No tables (round 3): the polynomial x^16 + x^15 + x^2 + 1 is sparse enough for a closed form -- for a 16-bit u,
+//     u * x^16 mod P = (u << 1 ^ u << 2) & 0xFFFF ^ parity(u) * 0x8003 ^ u[15] * 0x000A ^ u[14] * 0x8005
+// (checked over all 65536 values), so a 32-bit word w takes the state c to S(S(c ^ w >> 16) ^ (w & 0xFFFF)) in ~30 VALU
+// instructions and no LDS look-up; the table version did six look-ups per word, at random addresses, beside a parser whose
+// walks live on LDS.  Lanes own interleaved 16-byte granules (one unaligned 16-byte load a step): state * x^8192 + crc(granule),
+// folded at the end with x^(128 (63 - lane)) (six conditional multiplications by constants).
+typedef uint32_t fg_crc_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint32_t crc16_s(uint32_t u)          // u * x^16 mod P, u < 65536
+{
+    const uint32_t p = (uint32_t)__popc(u) & 1u;
+    return (((u << 1) ^ (u << 2)) & 0xFFFFu) ^ (0u - p & 0x8003u) ^ (0u - ((u >> 15) & 1u) & 0x000Au) ^ (0u - ((u >> 14) & 1u) & 0x8005u);
+}
+__device__ __forceinline__ uint32_t crc16_word(uint32_t c, uint32_t w) { return crc16_s(crc16_s(c ^ (w >> 16)) ^ (w & 0xFFFFu)); }
+__device__ __forceinline__ uint32_t crc16_byte(uint32_t c, uint32_t b)
+{
+    const uint32_t v = ((c >> 8) ^ b) & 0xFFu;
+    return ((c << 8) & 0xFFFFu) ^ (0u - ((uint32_t)__popc(v) & 1u) & 0x8003u) ^ (v << 1) ^ (v << 2);
+}
+
 __global__ void __launch_bounds__(256)
 fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, const uint16_t *crctab)
 {
-    __shared__ uint16_t crct[768];
-    __shared__ uint32_t mult[64];
-    for (int j = threadIdx.x; j < 768; j += 256) crct[j] = crctab[j];
-    if (threadIdx.x < 64) mult[threadIdx.x] = crctab[768 + threadIdx.x];
-    __syncthreads();
+    (void)crctab;
     const int lane = threadIdx.x & 63;
     const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= nframes) return;
     const uint32_t fb = frames[f].bytes;
     if (fb < 3) return;
     const uint8_t *fp = stream + frames[f].byte_off;
-    const uint16_t *t0 = crct, *thi = crct + 256, *tlo = crct + 512;
     const uint32_t nbytes = fb - 2;
-    // process from the first 4-byte aligned address: head bytes serially, then interleaved words, then the tail
+    // from the first 4-byte aligned address: head bytes serially, then interleaved granules of four words, then what is left
     const uint32_t mis = (uint32_t)((uintptr_t)fp & 3);
     const uint32_t head = mis ? (4 - mis) : 0;
     const uint32_t hb = head < nbytes ? head : nbytes;
     const uint32_t W = (nbytes - hb) >> 2, tail = (nbytes - hb) & 3;
+    const uint32_t G = W >> 2, Wr = W & 3;
     const uint32_t *wptr = (const uint32_t *)(fp + hb);
-    const uint32_t pad = (64 - (W & 63)) & 63, T = (W + pad) >> 6;
+    const uint32_t pad = (64 - (G & 63)) & 63, T = (G + pad) >> 6;
     uint32_t s = 0;
     for (uint32_t t = 0; t < T; t++) {
         const int qi = (int)(t * 64 + lane) - (int)pad;
-        uint32_t wv = 0;
-        if (qi >= 0) wv = be32(wptr[qi]);
-        s = thi[s >> 8] ^ tlo[s & 0xFF];
-        uint32_t cw = 0;
-        cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 24)) & 0xFF];
-        cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 16)) & 0xFF];
-        cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ (wv >> 8)) & 0xFF];
-        cw = ((cw << 8) & 0xFFFF) ^ t0[((cw >> 8) ^ wv) & 0xFF];
-        s ^= cw;
+        fg_crc_u32x4 g = {0, 0, 0, 0};
+        if (qi >= 0) g = *(const fg_crc_u32x4 *)(wptr + 4 * qi);
+        s = gf16_mul(s, 0x0112u);                                 // x^8192: the 64 granules of a step
+        uint32_t c = crc16_word(0, be32(g.x));
+        c = crc16_word(c, be32(g.y)); c = crc16_word(c, be32(g.z)); c = crc16_word(c, be32(g.w));
+        s ^= c;
     }
-    s = gf16_mul(s, mult[63 - lane]);
+    {
+        // x^(128 (63 - lane)): the granules behind this lane's last one
+        const uint32_t e = 63 - (uint32_t)lane;
+        const uint32_t bp[6] = {0x0106u, 0x8011u, 0x8107u, 0x0016u, 0x0114u, 0x8115u};      // x^128, x^256, ... x^4096
+        uint32_t m = 1;
+#pragma unroll
+        for (int b = 0; b < 6; b++) if ((e >> b) & 1) m = m == 1 ? bp[b] : gf16_mul(m, bp[b]);
+        if (e) s = gf16_mul(s, m);
+    }
     uint32_t body = wave_xor32(s);
-    // crc(head || body) = crc(head) * x^(32 W) + crc(body): fold the head in by running it through W zero words
+    // crc(head || body) = crc(head) * x^(128 G) + crc(body): fold the head in by running it through G zero granules
     uint32_t crc = 0;
-    for (uint32_t b = 0; b < hb; b++) crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ fp[b]) & 0xFF];
-    if (hb) {
-        // multiply crc by x^(32 W) with square-and-multiply over x^32 powers
-        uint32_t base = mult[1], e = W, acc = 1;     // mult[1] = x^32
+    for (uint32_t b = 0; b < hb; b++) crc = crc16_byte(crc, fp[b]);
+    if (hb && G) {
+        uint32_t base = 0x0106u, e = G, acc = 1;     // x^128
         bool first = true;
         while (e) {
             if (e & 1) { acc = first ? base : gf16_mul(acc, base); first = false; }
             base = gf16_mul(base, base);
             e >>= 1;
         }
-        if (W) crc = gf16_mul(crc, acc);
+        crc = gf16_mul(crc, acc);
     }
     crc ^= body;
-    for (uint32_t b = 0; b < tail; b++) crc = ((crc << 8) & 0xFFFF) ^ t0[((crc >> 8) ^ fp[hb + W * 4 + b]) & 0xFF];
+    for (uint32_t k = 0; k < Wr; k++) crc = crc16_word(crc, be32(wptr[4 * G + k]));
+    for (uint32_t b = 0; b < tail; b++) crc = crc16_byte(crc, fp[hb + W * 4 + b]);
     const uint32_t stored = ((uint32_t)fp[nbytes] << 8) | fp[nbytes + 1];
     if (lane == 0) {
         // runs beside the parse kernel (which owns `err`): the mismatch travels in bit 31, the restore kernel merges it

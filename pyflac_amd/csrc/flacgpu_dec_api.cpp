@@ -512,8 +512,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // (measured: beside the restore kernel the CRC pass slows that kernel's lone recurrence waves down by more than it gave
     // the parse kernel back -- 136 + 159 us against 123 + 163 --, so it stays beside the parse kernel; FLACGPU_DEC_CRC_LATE=1 tries
     // the other order)
-    static const bool crc_late_on = getenv("FLACGPU_DEC_CRC_LATE") && atoi(getenv("FLACGPU_DEC_CRC_LATE")) != 0;
-    const bool crc_late = crc_late_on && wave_parse && !old_restore && !fused;
+    static const int crc_late_mode = getenv("FLACGPU_DEC_CRC_LATE") ? atoi(getenv("FLACGPU_DEC_CRC_LATE")) : 2;
+    const bool crc_late = crc_late_mode == 1 && wave_parse && !old_restore && !fused;
+    // (mode 2, the default: the CRC pass beside the parse kernel, but the restore kernel does not wait for its last frames -- the
+    // pass lives on the wave slots the parser leaves and ends some 12 us after it --: it ignores the verdict, and
+    // fg_dec_fix_kernel merges it behind both.  0.363 -> 0.348 ms per decode launch.  Mode 0: the restore kernel waits and merges.)
+    const bool crc_join_late = crc_late_mode == 2 && wave_parse && !old_restore && !fused;
     bool forked = false;
     if (!crc_late) {
         forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
@@ -560,11 +564,18 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                   (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, d_rparams, c->stream) != 0) {
             fg_set_error("decode kernel launch failed"); return false;
         }
-        if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+        if (forked && !crc_join_late && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
         if (wave_parse && !old_restore && !crc_late) {
+            const bool late = crc_join_late && forked;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, interleave ? 1u : 0u, wide, c->stream) != 0) {
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
+            }
+            if (late) {
+                if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+                if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
+                    fg_set_error("decode kernel launch failed"); return false;
+                }
             }
         }
         else if (crc_late) {
