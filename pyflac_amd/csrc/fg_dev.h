@@ -101,4 +101,19 @@ __device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
     return r;
 }
 
+// CRC-16 steps without tables: x^16 + x^15 + x^2 + 1 is sparse enough for a closed form.  For a 16-bit u,
+//     u * x^16 mod P = (u << 1 ^ u << 2) & 0xFFFF ^ parity(u) * 0x8003 ^ u[15] * 0x000A ^ u[14] * 0x8005
+// (checked over all 65536 values); a byte v = (crc >> 8) ^ b takes crc to crc << 8 ^ parity(v) * 0x8003 ^ v << 1 ^ v << 2.
+__device__ __forceinline__ uint32_t crc16_s(uint32_t u)          // u * x^16 mod P, u < 65536
+{
+    const uint32_t p = (uint32_t)__popc(u) & 1u;
+    return (((u << 1) ^ (u << 2)) & 0xFFFFu) ^ ((0u - p) & 0x8003u) ^ ((0u - ((u >> 15) & 1u)) & 0x000Au) ^ ((0u - ((u >> 14) & 1u)) & 0x8005u);
+}
+__device__ __forceinline__ uint32_t crc16_word(uint32_t c, uint32_t w) { return crc16_s(crc16_s(c ^ (w >> 16)) ^ (w & 0xFFFFu)); }
+__device__ __forceinline__ uint32_t crc16_byte(uint32_t c, uint32_t b)
+{
+    const uint32_t v = ((c >> 8) ^ b) & 0xFFu;
+    return ((c << 8) & 0xFFFFu) ^ ((0u - ((uint32_t)__popc(v) & 1u)) & 0x8003u) ^ (v << 1) ^ (v << 2);
+}
+
 }  // namespace fgdev

@@ -663,18 +663,6 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
 // walks live on LDS.  Lanes own interleaved 16-byte granules (one unaligned 16-byte load a step): state * x^8192 + crc(granule),
 // folded at the end with x^(128 (63 - lane)) (six conditional multiplications by constants).
 typedef uint32_t fg_crc_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ uint32_t crc16_s(uint32_t u)          // u * x^16 mod P, u < 65536
-{
-    const uint32_t p = (uint32_t)__popc(u) & 1u;
-    return (((u << 1) ^ (u << 2)) & 0xFFFFu) ^ (0u - p & 0x8003u) ^ (0u - ((u >> 15) & 1u) & 0x000Au) ^ (0u - ((u >> 14) & 1u) & 0x8005u);
-}
-__device__ __forceinline__ uint32_t crc16_word(uint32_t c, uint32_t w) { return crc16_s(crc16_s(c ^ (w >> 16)) ^ (w & 0xFFFFu)); }
-__device__ __forceinline__ uint32_t crc16_byte(uint32_t c, uint32_t b)
-{
-    const uint32_t v = ((c >> 8) ^ b) & 0xFFu;
-    return ((c << 8) & 0xFFFFu) ^ (0u - ((uint32_t)__popc(v) & 1u) & 0x8003u) ^ (v << 1) ^ (v << 2);
-}
-
 __global__ void __launch_bounds__(256)
 fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, const uint16_t *crctab)
 {

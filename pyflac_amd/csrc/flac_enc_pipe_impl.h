@@ -1963,7 +1963,7 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
             ((U32 *)out)[j].v = __builtin_bswap32(v);
             uint32_t s = crc;
             s = tab[256 + (s >> 8)] ^ tab[512 + (s & 0xFF)];
-            crc = s ^ tab[1536 + (v >> 24)] ^ tab[1280 + ((v >> 16) & 0xFF)] ^ tab[1024 + ((v >> 8) & 0xFF)] ^ tab[v & 0xFF];
+            crc = s ^ crc16_word(0, v);           // (closed form: no look-ups at data-dependent addresses)
         }
     };
     // the chunk a run of rows [row, row + cnt) lies inside entirely (every word of it two loads and a funnel shift), or -1
