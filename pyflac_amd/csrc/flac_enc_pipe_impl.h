@@ -1320,6 +1320,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         int32_t q[MAXO];
         sum_t psum;
         uint32_t ovf = 0;
+        double psumd = 0.0, pmaxd = 0.0;        // (fp64 forms: the lane's sum and maximum of |residual|; the sum is exact below 2^53)
         const int kind = pass == 0 ? 0 : 1;
         if (pass == 0) {
             if (!do_fixed) continue;
@@ -1364,10 +1365,13 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                 if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
                 else if constexpr (FGP_F64) {
                     // x - (sum >> shift): the scaling by 2^-shift is exact, floor() is the arithmetic shift
+                    // The lane's sum and maximum of |residual| stay in fp64 -- v_add_f64 and v_max_f64 with the |x| modifier instead of
+                    // a conversion, an absolute value, a 64-bit integer add and the two-sided range test of every residual; a residual
+                    // is outside the 32-bit range exactly when its magnitude reaches 2^31 (libFLAC's _limit_residual test)
                     const double xd = (double)x;
                     const double rr = xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl);
-                    if ((rr <= -2147483648.0 || rr > 2147483647.0) && real) ovf = 1;
-                    res = (int32_t)rr;
+                    if (real) { psumd += __builtin_fabs(rr); pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
+                    res = 0;
                     hd[u] = xd;
                 }
                 else {
@@ -1376,7 +1380,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                     res = (int32_t)rr;
                 }
                 h[u] = ACC64 ? ppack(x) : x;
-                if (real) psum += pabs32(res);
+                if constexpr (!(FGP_F64 && ACC64)) { if (real) psum += pabs32(res); }
             };
             uint32_t s0 = 0;
             if (seg >= (uint32_t)MAXO) {
@@ -1399,7 +1403,11 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                 // (at most MAXO of them: seg - s0 < MAXO, plus one)
 #pragma unroll
                 for (int u = 0; u < MAXO; u++) if (s0 + u < ln.len) step(u, s0 + u, s0 == 0);
-                if (!ln.act) { psum = 0; ovf = 0; }
+                if (!ln.act) { psum = 0; ovf = 0; psumd = 0.0; pmaxd = 0.0; }
+            }
+            if constexpr (FGP_F64 && ACC64) {
+                if (!(pmaxd < 2147483648.0)) ovf = 1;
+                psum = ovf ? (sum_t)0 : (sum_t)psumd;
             }
         }
         const bool dead = ACC64 && __any(ovf != 0);
