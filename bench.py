@@ -190,7 +190,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
     ap.add_argument('--no-passes', action='store_true', help='skip the event passes after the timed loop (profiling runs: the trace then holds the timed loop only)')
-    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted', 'stream32', 'surround6'], default='stream16',
+    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted', 'stream32', 'stream32w', 'surround6'], default='stream16',
                     help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz level 8; '
                          'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each); '
                          'wasted: the stream16 signal in a 24-bit container (8 wasted bits in every block)')
@@ -233,6 +233,11 @@ def main():
         bps = 32
         pcm16 = synth.config2_stereo16(args.seconds, rank, sr).astype(np.int64) * 40000 + (np.arange(int(round(sr * args.seconds)))[:, None] % 977)
         pcm16 = np.clip(pcm16, -(1 << 31), (1 << 31) - 1).astype(np.int32)
+    elif args.workload == 'stream32w':
+        # what pyFLAC makes of a 24-bit WAV file: soundfile reads it as left-justified int32, pyflac/encoder.py:109 sets 32 bits per
+        # sample -- a 32-bit stream whose samples share eight wasted bits (the configs[3] signal in a 32-bit container)
+        sr, bps = 96000, 32
+        pcm16 = (synth.config4_stereo24(args.seconds, 1 + rank, sr).astype(np.int64) << 8).astype(np.int32)
     elif args.workload == 'surround6':
         # six channels (tests/test_encoder.py:258-273 of the reference: surround.wav), 16 bit: three stereo pairs of the generator family
         ch = 6
@@ -371,7 +376,7 @@ def main():
                                    '(FLAC__stream_encoder_set_do_md5(0))' %
                                    ({'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]',
                                      'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)',
-                                     'stream32': '32-bit samples (33-bit side channel)', 'surround6': 'six channels'}[args.workload],
+                                     'stream32': '32-bit samples (33-bit side channel)', 'stream32w': '24-bit material in a 32-bit container (int32 arrays as pyFLAC gets them from a 24-bit WAV: eight wasted bits)', 'surround6': 'six channels'}[args.workload],
                                     'single-stream' if single else '%d independent streams in one launch,' % len(lengths),
                                     ' alone (frame index rebuilt on the GPU inside the timed region)' if single else
                                     ' alone (every stream\'s frame index rebuilt on the GPU inside the timed region, one pass over all bytes)',

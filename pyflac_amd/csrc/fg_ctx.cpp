@@ -421,7 +421,10 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     // ---- which kernels: the de-fused pipeline (flac_enc_pipe_impl.h) where it applies, round 1's single kernel with
     // FLACGPU_PIPE=0, the generic kernel for everything else
-    const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12;
+    const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->max_lpc_order <= 12 &&
+                          // (32-bit streams: blocks whose channels share eight wasted bits, flac_enc_pipe_impl.h pipe_preshift; the rest is handed
+                          // to the generic kernel block by block, which the decision probe of loose mid-side does not expect)
+                          (s->bits_per_sample <= 24 || (s->bits_per_sample == 32 && !(s->do_mid_side && s->loose_mid_side)));
     const bool use_pipe = cfg_fast && !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) && fg_pipe_supported(&P);
     if (view && !use_pipe && cfg_fast) { fg_set_error("one-channel views need the pipeline or the generic kernel"); return false; }
     const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
@@ -783,7 +786,7 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
     if (!c) { fg_set_error("null context"); return -1; }
     // more than two channels: one-channel views through the pipeline where its shape applies (limit_min_bitrate looks across the
     // channels of a frame, large blocks and wide samples stay with the generic kernel)
-    if (s->channels > 2 && s->channels <= 8 && s->bits_per_sample <= 24 && s->max_lpc_order <= 12 && !s->limit_min_bitrate && !c->debug &&
+    if (s->channels > 2 && s->channels <= 8 && (s->bits_per_sample <= 24 || s->bits_per_sample == 32) && s->max_lpc_order <= 12 && !s->limit_min_bitrate && !c->debug &&
         s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0))
         return encode_multichannel(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
     return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;

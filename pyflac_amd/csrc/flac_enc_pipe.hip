@@ -15,7 +15,7 @@ FG_DECLP(ms_o8) FG_DECLP(ms_o12) FG_DECLP(st_o8) FG_DECLP(st_o12) FG_DECLP(mono_
 // samples per packing lane; partitions no finer than a lane.)
 int fg_pipe_supported(const FgEncParams *P)
 {
-    if (P->channels < 1 || P->channels > 2 || P->max_lpc_order > 12 || P->bps > 24 || P->sig_stride == 0) return 0;
+    if (P->channels < 1 || P->channels > 2 || P->max_lpc_order > 12 || (P->bps > 24 && P->bps != 32) || P->sig_stride == 0) return 0;
     return 1;
 }
 

@@ -212,6 +212,17 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
             R = 0;
         }
     };
+    // candidate c of a sample as the float libFLAC windows (FLAC__lpc_window_data: the integer converted to float, one rounding)
+    // and the bits its wasted-bits count looks at.  32-bit input: mid needs a 33-bit sum and the side channel IS 33 bits wide
+    // (libFLAC keeps it in 64 bits and windows it with FLAC__lpc_window_data_wide); the low 32 bits decide the trailing zeros.
+    auto cval = [&](int c, int32_t L, int32_t R, float &fx, uint32_t &ob) __attribute__((always_inline)) {
+        if (MS && P.bps == 32 && c == 2) { const int32_t m_ = (int32_t)(((i64)L + (i64)R) >> 1); fx = (float)m_; ob = (uint32_t)m_; }
+        else if (MS && P.bps == 32 && c == 3) { fx = (float)((double)L - (double)R); ob = (uint32_t)L - (uint32_t)R; }
+        else {
+            const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
+            fx = (float)x; ob = (uint32_t)x;
+        }
+    };
     uint32_t nv = 0;
     const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
     if (mo == 0) {
@@ -220,7 +231,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
             int32_t L, R;
             ldsamp(i, L, R);
 #pragma unroll
-            for (int c = 0; c < NC; c++) orv[c] |= (uint32_t)(c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R));
+            for (int c = 0; c < NC; c++) { float fx; uint32_t ob; cval(c, L, R, fx, ob); orv[c] |= ob; }
         }
     }
     else {
@@ -275,7 +286,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                 fetch(0);
                 for (uint32_t k0 = 0; k0 < vec_len; k0 += FGP_CK) {
                     const uint32_t kn = (vec_len - k0) < FGP_CK ? (vec_len - k0) : FGP_CK;
-                    if (part == 0) {
+                    if (part == 0 && P.bps < 32) {
 #pragma unroll
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t j = u * 64 + lane;
@@ -296,12 +307,14 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                             const uint32_t j = u * 64 + lane;
                             if (P.debug != 102) {
                                 const int32_t L = xl[u], R = xr[u];
-                                const bool zero = (k0 + j) >= 2 * part;
+                                const bool zero = part != 0 && (k0 + j) >= 2 * part;
 #pragma unroll
                                 for (int c = 0; c < NC; c++) {
-                                    const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
-                                    if (nv == 0) orv[c] |= (uint32_t)x;
-                                    const float dd = zero ? 0.0f : (float)x * wv[u];
+                                    float fx;
+                                    uint32_t ob;
+                                    cval(c, L, R, fx, ob);
+                                    if (nv == 0) orv[c] |= ob;
+                                    const float dd = zero ? 0.0f : fx * wv[u];
                                     dbuf[c * FGP_CSTR + FGP_DH + j] = (double)dd;
                                 }
                             }
@@ -446,7 +459,12 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
         uint32_t w = o ? (uint32_t)__builtin_ctz(o) : 0;
         const uint32_t nominal = P.bps + ((MS && c == 3) ? 1u : 0u);
         if (w > nominal) w = nominal;
-        if (lane == 0) { wl[c] = w; B.wasted[bi * NC + c] = w; }
+        // (stream_encoder.c get_wasted_bits_wide_: an all-zero 33-bit side channel counts ONE wasted bit -- its constant then fits
+        // the 32-bit field)
+        if (MS && c == 3 && P.bps == 32 && o == 0) w = 1;
+        // (bit 8: every sample of the candidate is zero -- libFLAC counts no wasted bits then, and the 32-bit path must not take
+        // that 0 for 'no bits to spare')
+        if (lane == 0) { wl[c] = w; B.wasted[bi * NC + c] = w | (o ? 0u : 0x100u); }
     }
     if (lane == 0) B.nv[bi] = nv;
     wave_lds_fence();
@@ -554,7 +572,7 @@ fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, u
 #pragma unroll
         for (int j = 0; j <= MAXO; j++) A[j] = 0.0;
     }
-    const uint32_t sb = P.bps + ((ms && c == 3) ? 1u : 0u) - B.wasted[bi * NC + c];
+    const uint32_t sb = P.bps + ((ms && c == 3) ? 1u : 0u) - (B.wasted[bi * NC + c] & 0xFFu);
     const double a0 = on ? A[0] : 1.0;
     const uint32_t overhead = sb + P.qlp_precision;
     const double scale = 0.5 / (double)n;
@@ -770,11 +788,34 @@ FGI uint32_t pipe_rag_addr(const PipeGeo &g, uint32_t i, uint32_t mS, uint32_t m
     return ((grp << g.lpgs) + w) * g.rstr + col;
 }
 
+// 32-bit streams.  The forms of the 17..25-bit path (24-bit multiplies for the candidate, fp64 FIR, 32-bit error terms) hold for a
+// 32-bit stream whose channels share at least eight wasted bits -- 24-bit material in a 32-bit container, what pyFLAC makes of a
+// 24-bit WAV file (soundfile reads it as left-justified int32, pyflac/encoder.py:109 sets 32 bits per sample): the samples are
+// staged shifted down by the shared count `pre`, every later shift is by (wasted - pre), and all widths -- subframe bits per
+// sample, warm-up fields, the wasted-bits field itself -- come out as libFLAC's, which shifts by the whole count.  A block whose
+// channels share fewer bits (true 32-bit content) goes to the generic kernel (ok = false).  Channels that are all zero have no
+// say.  B.wasted: bits 0..7 the count, bit 8 all-zero (fg_pipe_autoc_kernel).
+template <int NCH, int NC>
+FGI uint32_t pipe_preshift(const FgEncParams &P, const FgPipeBufs &B, uint32_t bi, bool &ok)
+{
+    ok = true;
+    if (P.bps != 32) return 0;
+    uint32_t m = 64;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const uint32_t w = rfl(B.wasted[bi * NC + c]);
+        if (!(w & 0x100u)) m = (w & 0xFFu) < m ? (w & 0xFFu) : m;
+    }
+    if (m == 64) m = 8;
+    if (m < 8) { ok = false; return 0; }
+    return m > 16 ? 16 : m;
+}
+
 // ================================================================================================ staging: HBM -> LDS rows
 // Cooperative over NT threads.  Rows of `seg` samples (+PADE of skew); g -> element index g + (g / seg) * PADE.
 template <int NCH, bool ACC64, int NT, bool RAG>
 FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams &P, LDS typename PipeTypes<ACC64>::samp_t *sL,
-                        LDS typename PipeTypes<ACC64>::samp_t *sR, int tid, uint32_t seg, const PipeGeo &geo)
+                        LDS typename PipeTypes<ACC64>::samp_t *sR, int tid, uint32_t seg, const PipeGeo &geo, uint32_t pre = 0)
 {
     typedef typename PipeTypes<ACC64>::samp_t samp_t;
     constexpr uint32_t PADE = PipeTypes<ACC64>::PADE;
@@ -809,7 +850,7 @@ FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams
                         *(LDS uint32_t *)(sL + ad) = ((uint32_t)l0 & 0xFFFFu) | ((uint32_t)l1 << 16);
                         *(LDS uint32_t *)(sR + ad) = ((uint32_t)r0 & 0xFFFFu) | ((uint32_t)r1 << 16);
                     }
-                    else { sL[ad] = (samp_t)l0; sL[ad + 1] = (samp_t)l1; sR[ad] = (samp_t)r0; sR[ad + 1] = (samp_t)r1; }
+                    else { sL[ad] = (samp_t)(l0 >> pre); sL[ad + 1] = (samp_t)(l1 >> pre); sR[ad] = (samp_t)(r0 >> pre); sR[ad + 1] = (samp_t)(r1 >> pre); }
                 }
             }
         }
@@ -873,8 +914,8 @@ FGI uint32_t pipe_stage(const void *pcm, const FgBlockDesc &d, const FgEncParams
                 if (i < n) {
                     if (P.bps < 32) bad |= (uint32_t)(((a[u] ^ (a[u] >> 31)) >> lim) | ((b[u] ^ (b[u] >> 31)) >> lim));
                     const uint32_t ad = FGP_SADDR(i);
-                    sL[ad] = (samp_t)a[u];
-                    if (NCH == 2) sR[ad] = (samp_t)b[u];
+                    sL[ad] = (samp_t)(a[u] >> pre);
+                    if (NCH == 2) sR[ad] = (samp_t)(b[u] >> pre);
                 }
             }
         }
@@ -1090,7 +1131,7 @@ FGI bool pipe_rice_search_tree(typename PipeTypes<ACC64>::sum_t psum, int lane, 
 template <bool MS, int NCH, int MAXO, bool ACC64, bool RAG>
 FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
                         FgDebugRec *mydbg, const LDS typename PipeTypes<ACC64>::samp_t *sL, const LDS typename PipeTypes<ACC64>::samp_t *sR,
-                        int lane, uint32_t range_err, const PipeGeo &geo)
+                        int lane, uint32_t range_err, const PipeGeo &geo, uint32_t pre = 0, bool pre_ok = true)
 {
     constexpr int NC = MS ? 4 : NCH;
     typedef typename PipeTypes<ACC64>::sum_t sum_t;
@@ -1103,14 +1144,33 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     const PipeLane ln = pipe_lane<RAG>(geo, (uint32_t)lane, seg);
     const LDS samp_t *rowL = sL + (uint32_t)lane * rstr, *rowR = sR + (uint32_t)lane * rstr;
     const LDS samp_t *prvL = sL + ln.prow * rstr + ln.plen, *prvR = sR + ln.prow * rstr + ln.plen;      // one past the samples in front
-    const uint32_t wst = rfl(B.wasted[bi * NC + C]);
+    const uint32_t wraw = rfl(B.wasted[bi * NC + C]);
+    const uint32_t wst = wraw & 0xFFu;
     const uint32_t nominal = P.bps + ((MS && C == 3) ? 1u : 0u);
     const uint32_t sb = nominal - wst;
+    // (32-bit streams, pipe_preshift: a block the staged forms cannot hold goes to the generic kernel -- bit 31 of the decision's
+    // size tells the packing kernel)
+    const bool unsupported = ACC64 && P.bps == 32 && (!pre_ok || (sb > 25 && !(wraw & 0x100u)));
+    if (unsupported) {
+        if (lane == 0) {
+            FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
+            dec->bits = 0x80000000u; dec->type = 1; dec->order = 0; dec->prec = 0; dec->shift = 0; dec->porder = 0; dec->method = 0; dec->wasted = wraw;
+            FgBlockResult *r = &results[d.out_slot];
+            r->best_bits[C] = 0;
+            if (C == 0) {
+                r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
+#pragma unroll
+                for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
+                for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)d.out_slot * 4 + w] = 0;
+            }
+        }
+        return;
+    }
     // candidate value of sample s of this lane's row (row offset `ro` = 0 or -rstr for the left neighbour)
     int32_t cca, ccb;
     uint32_t ccs;
     pipe_cand_coef(MS, C, cca, ccb, ccs);
-    const uint32_t csh = ccs + wst;
+    const uint32_t csh = (wraw & 0x100u) ? ccs : ccs + wst - pre;       // (staged samples are already down by `pre`)
     auto samp = [&](int s) __attribute__((always_inline)) -> int32_t {
         return pipe_cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, cca, ccb, csh);
     };
@@ -1457,7 +1517,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     {
         // the 20 header words of the record in one coalesced store (lane j = word j; everything here is wave-uniform)
         uint32_t wv_ = 0;
-        const uint32_t hw[8] = {best, d_type, d_order, d_prec, (uint32_t)d_shift, d_porder, d_method, wst};
+        const uint32_t hw[8] = {best, d_type, d_order, d_prec, (uint32_t)d_shift, d_porder, d_method, wraw};
 #pragma unroll
         for (int j = 0; j < 8; j++) wv_ = lane == j ? hw[j] : wv_;
 #pragma unroll
@@ -1509,13 +1569,15 @@ fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     if (tid == 0) xch[0] = 0;
     __syncthreads();
     const PipeGeo geo = RAG ? pipe_geo(d.n, 6, P.max_po, PipeTypes<ACC64>::PADE) : pipe_geo_regular(d.n >> 6, PipeTypes<ACC64>::PADE);
-    const uint32_t bad = pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, d.n >> 6, geo);
+    bool pre_ok = true;
+    const uint32_t pre = ACC64 ? pipe_preshift<NCH, NC>(P, B, bi, pre_ok) : 0u;
+    const uint32_t bad = pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, d.n >> 6, geo, pre);
     if (bad) xch[0] = 1;            // (benign race: every writer stores the same value)
     __syncthreads();
     const uint32_t range_err = xch[0] ? FG_ERR_RANGE : 0;
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
     // (the ragged geometry -- tail blocks, odd block sizes -- is a kernel of its own: the regular one keeps its loops and registers)
-    pipe_eval_cand<MS, NCH, MAXO, ACC64, RAG>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, sL, sR, lane, range_err, geo);
+    pipe_eval_cand<MS, NCH, MAXO, ACC64, RAG>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, sL, sR, lane, range_err, geo, pre, pre_ok);
 }
 
 // ================================================================================================ K5: pack
@@ -1593,13 +1655,29 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
     LDS uint32_t *fbw = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes) + wv * (fbw_words + 2 + 64);
     LDS uint32_t *misc = fbw + fbw_words + 2;                 // 64 words per wave: header bytes, then the packer's scratch words
-    (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo);
+    bool pre_ok = true;
+    const uint32_t pre = ACC64 ? pipe_preshift<NCH, NC>(P, B, bi, pre_ok) : 0u;
+    (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo, pre);
     for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0;
     __syncthreads();
     if (wv >= (uint32_t)NCH * ws) return;           // (no barrier after this point)
 
     // ---- channel assignment from the four candidate totals (every wave computes it; wave-uniform)
     uint32_t ca = 0, c = si;
+    // (32-bit streams: bit 31 of a candidate's size = the evaluation could not take this block -- pipe_preshift --: generic kernel)
+    bool unsure = false;
+    if (ACC64 && P.bps == 32) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) unsure = unsure || (rfl(B.dec[(size_t)bi * NC + k].bits) >> 31) != 0;
+    }
+    if (unsure) {
+        if (lane == 0) {
+            B.chunk_bits[(size_t)d.out_slot * 4 + wv] = 0;
+            atomicOr(&results[d.out_slot].err, FG_ERR_REDO);
+            if (B.guard) atomicOr(&B.guard[2], (unsigned long long)FG_ERR_REDO);
+        }
+        return;
+    }
     if (MS) {
         if (d.forced_ca != 0xFF) ca = d.forced_ca & 0x7F;       // (bit 7: a loose mid-side DECISION frame, see FgBlockDesc)
         else {
@@ -1616,7 +1694,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     }
     const FgPipeDec *dec = B.dec + (size_t)bi * NC + c;
     const uint32_t type = rfl(dec->type), order = rfl(dec->order), prec = rfl(dec->prec), po = rfl(dec->porder), method = rfl(dec->method);
-    const uint32_t wst = rfl(dec->wasted);
+    const uint32_t wraw = rfl(dec->wasted), wst = wraw & 0xFFu;
     int shift = (int)rfl((uint32_t)dec->shift);
     const uint32_t sb = P.bps + ((MS && c == 3) ? 1u : 0u) - wst;
     const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
@@ -1695,7 +1773,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     int32_t cca, ccb;
     uint32_t ccs;
     pipe_cand_coef(MS, c, cca, ccb, ccs);
-    const uint32_t csh = ccs + wst;
+    const uint32_t csh = (wraw & 0x100u) ? ccs : ccs + wst - pre;
     auto cand = [&](int32_t l, int32_t r) -> int32_t { return pipe_cand(l, r, cca, ccb, csh); };
     if (hf == 0) {
         // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes

@@ -538,3 +538,76 @@ def test_large_coefficients_do_not_overflow_the_warm_up(ctx):
     out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
     want, sizes = O.encode_stream(cfg, arr)
     assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
+
+
+def _in32(pcm24, shift=8):
+    return (pcm24.astype(np.int64) << shift).astype(np.int32)
+
+
+@pytest.mark.parametrize('level', [0, 3, 5, 8])
+def test_24_bit_material_in_32_bit_container_stays_in_the_pipeline(ctx, level):
+    """pyFLAC encodes an int32 array as a 32-bit stream (pyflac/encoder.py:109), and soundfile hands a 24-bit WAV over as
+    left-justified int32: 32-bit FLAC whose samples share eight wasted bits.  The pipeline stages them shifted down (pipe_preshift);
+    bytes equal the oracle's, no block goes to the generic kernel."""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    from pyflac_amd import synth
+    pcm24 = synth.config4_stereo24(0.7, 3)                 # (BASELINE config 3/4 signal: 24-bit stereo, 96 kHz)
+    assert pcm24.shape[1] == 2 and int(np.abs(pcm24).max()) < (1 << 23)
+    arr = _in32(pcm24)
+    n = (len(arr) // 4096) * 4096 + 333
+    arr = np.ascontiguousarray(arr[:n])
+    s = batch.settings(level, 2, 32, 96000, 4096, True)
+    cfg, _ = O.config(level, 2, 32, 96000, 4096, True)
+    out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+    want, sizes = O.encode_stream(cfg, arr)
+    assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
+    assert st.redo_blocks == 0
+
+
+def test_32_bit_streams_mixed_content(ctx):
+    """A 32-bit stereo stream whose blocks differ: 24-bit material (pipeline), one channel silent, both silent, 16-bit material
+    (sixteen shared wasted bits), true 32-bit noise (generic kernel), L == R (a zero side channel).  Every frame the oracle's;
+    exactly the two blocks of true 32-bit content are handed over."""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    bs = 4096
+    t = np.arange(bs)
+    tone = lambda a, f, ph: np.round(a * np.sin(2 * np.pi * f * t / 48000 + ph) + rng.normal(0, a / 300, bs)).astype(np.int64)
+    blocks = []
+    b24 = np.stack([tone(3e6, 440, 0), tone(2e6, 660, 1)], axis=1)
+    blocks.append(b24 << 8)                                                     # 24-bit material
+    blocks.append(np.stack([tone(3e6, 440, 0) << 8, np.zeros(bs, np.int64)], axis=1))    # right channel silent
+    blocks.append(np.zeros((bs, 2), np.int64))                                  # digital silence
+    blocks.append(np.stack([tone(2e4, 300, 0), tone(1e4, 500, 2)], axis=1) << 16)        # 16-bit material
+    blocks.append(rng.integers(-2**31, 2**31, (bs, 2)))                          # true 32-bit content
+    x = tone(2.5e6, 880, 0) << 8
+    blocks.append(np.stack([x, x], axis=1))                                     # L == R
+    blocks.append(np.stack([tone(3e6, 100, 0) << 8, tone(3e6, 150, 0) << 9], axis=1))    # different counts per channel
+    blocks.append(rng.integers(-2**31, 2**31, (777, 2)))                         # a true 32-bit tail
+    arr = np.concatenate(blocks).astype(np.int32)
+    for level in (5, 8):
+        s = batch.settings(level, 2, 32, 48000, bs, True)
+        cfg, _ = O.config(level, 2, 32, 48000, bs, True)
+        out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+        want, sizes = O.encode_stream(cfg, arr)
+        assert list(np.diff(offs.cpu().numpy())) == list(sizes)
+        assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
+        assert st.redo_blocks == 2                       # (the block and the tail of true 32-bit content)
+
+
+def test_32_bit_mono_and_many_channels_with_shared_wasted_bits(ctx):
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    for channels in (1, 3):
+        pcm = _multichannel_pcm(7 + channels, channels, 4096 * 3 + 100, 24)
+        arr = _in32(pcm)
+        s = batch.settings(5, channels, 32, 48000, 4096, True)
+        cfg, _ = O.config(5, channels, 32, 48000, 4096, True)
+        out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+        want, sizes = O.encode_stream(cfg, arr)
+        assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]

@@ -7,4 +7,5 @@ print('$*: value %.1f ms/step %.3f enc_gpu %.3f dec_gpu %.3f' % (d['value'], d['
 run --workload stream16
 run --workload stream16 --seconds 600.0162
 run --workload stream32 --seconds 120
+run --workload stream32w --seconds 300
 run --workload surround6 --seconds 120
