@@ -361,7 +361,10 @@ def main():
 
     if rank == 0:
         ps = np.sort(np.array(per_step)) * 1e3
-        pmc_name = 'r03_pmc.json' if committed_profile('r03_pmc.json') else 'r02_pmc.json'
+        # (the committed PMC passes: profiles/r03_pmc.json for the headline, profiles/r03_pmc_<workload>.json for the others)
+        pmc_name = 'r03_pmc.json' if args.workload == 'stream16' else 'r03_pmc_%s.json' % args.workload
+        if not committed_profile(pmc_name):
+            pmc_name = 'r02_pmc.json'
         pmc = committed_profile(pmc_name) or {}
         same = pmc.get('workload') == args.workload and pmc.get('level') == args.level and pmc.get('blocks') == int(est.nblocks)
         enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
