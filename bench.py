@@ -157,6 +157,18 @@ def api_e2e(seconds, sr):
         small[str(frames)] = {'encode_msamples_per_s': round(len(lat) * frames * 2 / dt / 1e6, 1), 'calls': len(lat),
                               'call_ms_median': round(lat[len(lat) // 2] * 1e3, 3), 'call_ms_p95': round(lat[int(len(lat) * 0.95)] * 1e3, 3)}
     out['process_call_size'] = small
+    # the same 1024-frame calls with the launch held back until 16 blocks are buffered (an extension, include/flacgpu.h
+    # flacgpu_stream_encoder_set_launch_blocks: the frames then come in bursts of 16, the bytes are the same)
+    enc = pyflac_amd.StreamEncoder(sr, lambda b, n, s, f: None, compression_level=5, blocksize=4096, launch_blocks=16)
+    enc.process(part[:1024])
+    t0 = time.perf_counter()
+    ncalls = 0
+    for a in range(1024, len(part) - 1024 + 1, 1024):
+        enc.process(part[a:a + 1024])
+        ncalls += 1
+    dt = time.perf_counter() - t0
+    enc.finish()
+    out['process_call_size']['1024_launch_blocks_16'] = {'encode_msamples_per_s': round(ncalls * 1024 * 2 / dt / 1e6, 1), 'calls': ncalls}
     # ---- many streams at once: MD5 is serial per stream (0.4 G samples/s), so the class scales with the number of streams:
     # 16 StreamEncoders on 16 threads, MD5 on, 60 s each (the library calls release the GIL)
     import threading

@@ -651,6 +651,13 @@ FLAC__bool flacgpu_stream_decoder_set_block_callback(FLAC__StreamDecoder *decode
  * stream_encoder.h:1777-1824: same buffering, same return value): saves the caller the widening copy to FLAC__int32. */
 FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *encoder, const int16_t *buffer, uint32_t samples);
 
+/* Extension: a process call encodes nothing until at least `blocks` complete blocks are buffered (default 1: a frame is
+ * written as soon as blocksize + 1 samples are there, libFLAC's timing, stream_encoder.h:1777-1824).  Every launch is six
+ * kernels and a wait (about 0.17 ms) whatever it carries, so a caller that feeds small pieces and can take its frames in bursts
+ * trades latency for throughput with this.  The bytes do not change; FLAC__stream_encoder_finish encodes what is left.  May be
+ * set at any time. */
+FLAC__bool flacgpu_stream_encoder_set_launch_blocks(FLAC__StreamEncoder *encoder, uint32_t blocks);
+
 /* Host-side frame indexer: parses metadata and frame headers of a complete FLAC stream in host memory and
  * returns frame byte offsets (validated by header CRC-8 and chained by frame CRC-16).  Returns the number
  * of frames, or a negative value on error. */

@@ -115,7 +115,7 @@ DATA_SYMBOLS = ['FLAC__StreamEncoderStateString', 'FLAC__StreamEncoderInitStatus
 EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu_ctx_create', 'flacgpu_ctx_destroy',
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
-                 'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
+                 'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_stream_encoder_set_launch_blocks', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
                  'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
@@ -211,6 +211,8 @@ def lib():
     L.flacgpu_set_stage_timing.restype = None
     L.flacgpu_stream_encoder_process_interleaved_i16.argtypes = [vp, vp, C.c_uint32]
     L.flacgpu_stream_encoder_process_interleaved_i16.restype = C.c_int
+    L.flacgpu_stream_encoder_set_launch_blocks.argtypes = [vp, C.c_uint32]
+    L.flacgpu_stream_encoder_set_launch_blocks.restype = C.c_int
     L.flacgpu_index_frames.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(StreamInfo), C.POINTER(C.c_uint64)]
     L.flacgpu_index_frames.restype = C.c_int64
     L.flacgpu_refwalk_probe.argtypes = [vp, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64)]

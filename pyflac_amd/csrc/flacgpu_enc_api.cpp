@@ -179,6 +179,7 @@ struct EncImpl {
     bool own_file;
     uint64_t bytes_written;
     std::vector<int32_t> pending;   // interleaved samples not yet encoded
+    uint32_t launch_blocks = 1;     // flacgpu_stream_encoder_set_launch_blocks: complete blocks to wait for before a launch
     uint32_t frame_number;
     uint32_t last_ca = 0;          // loose mid-side: channel assignment the previous process call ended on
     std::vector<FLAC__StreamMetadata *> metadata;   // FLAC__stream_encoder_set_metadata: the caller's blocks (pointers only)
@@ -497,7 +498,9 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
     uint64_t take;
     if (flush_all) take = have;
     else take = have >= 1 ? ((have - 1) / bs) * bs : 0;   // libFLAC emits a frame once blocksize+1 samples are buffered
-    if (take == 0) { keep_input(0); return true; }
+    // (extension, flacgpu_stream_encoder_set_launch_blocks: fewer, larger launches for callers that feed small pieces and can
+    // take their frames in bursts -- every launch is six kernels and a wait, whatever it carries)
+    if (take == 0 || (!flush_all && take < (uint64_t)e->launch_blocks * bs)) { keep_input(0); return true; }
     const uint64_t from_pend = std::min<uint64_t>(take, pend), from_in = take - from_pend;
     flacgpu_ctx *c = e->ctx;
     (void)hipSetDevice(c->device);
@@ -835,6 +838,14 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *enc, co
 // Extension (include/flacgpu.h): the same with 16-bit interleaved input.  pyFLAC widens int16 arrays to int32 in numpy before
 // the call (pyflac/encoder.py:112); taking them as they are saves that pass and halves the bytes that cross PCIe (the device
 // widens them).
+FLAC__bool flacgpu_stream_encoder_set_launch_blocks(FLAC__StreamEncoder *enc, uint32_t blocks)
+{
+    EncImpl *e = impl(enc);
+    if (!e) return 0;
+    e->launch_blocks = blocks < 1 ? 1 : blocks;
+    return 1;
+}
+
 FLAC__bool flacgpu_stream_encoder_process_interleaved_i16(FLAC__StreamEncoder *enc, const int16_t *buffer, uint32_t samples)
 {
     EncImpl *e = impl(enc);

@@ -165,8 +165,13 @@ class StreamEncoder(_Encoder):
                  streamable_subset: bool = True,
                  verify: bool = False,
                  limit_min_bitrate: bool = False,
-                 bits_per_sample: int = None):
+                 bits_per_sample: int = None,
+                 launch_blocks: int = 1):
         super().__init__()
+        # (not in the reference: complete blocks to buffer before the GPU is launched -- include/flacgpu.h
+        # flacgpu_stream_encoder_set_launch_blocks; 1 = a frame as soon as libFLAC would write it)
+        if launch_blocks > 1:
+            _L.flacgpu_stream_encoder_set_launch_blocks(self._encoder, int(launch_blocks))
         self.write_callback = write_callback
         self.seek_callback = seek_callback
         self.tell_callback = tell_callback

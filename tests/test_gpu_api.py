@@ -252,6 +252,34 @@ class TestFileEncoderDecoder:
             dec.process()
 
 
+class TestLaunchBlocks:
+    """flacgpu_stream_encoder_set_launch_blocks (include/flacgpu.h): the launch waits for that many complete blocks; the bytes are
+    those of the default timing, only the write callbacks come in bursts."""
+
+    def test_same_bytes_fewer_launches(self):
+        import pyflac_amd
+        from pyflac_amd import synth
+        pcm = synth.config2_stereo16(1.5, 21)
+        out = {}
+        for lb in (1, 4):
+            chunks, when = [], []
+            enc = pyflac_amd.StreamEncoder(48000, lambda b, n, s, f: (chunks.append(b), when.append(calls[0])), compression_level=5,
+                                           blocksize=1024, launch_blocks=lb)
+            calls = [0]
+            for a in range(0, len(pcm), 700):
+                calls[0] += 1
+                enc.process(pcm[a:a + 700])
+            calls[0] = -1
+            enc.finish()
+            out[lb] = (b''.join(chunks), when)
+        assert out[1][0] == out[4][0]
+        # default: a frame in the call that completes its block; with 4: bursts of at least four frames per call that writes any
+        from collections import Counter
+        bursts = Counter(w for w in out[4][1][3:] if w > 0)
+        assert bursts and min(bursts.values()) >= 4
+        assert len(set(out[1][1][3:])) > len(set(out[4][1][3:]))
+
+
 class TestStreamDecoder:
     def _data(self):
         with open(os.path.join(cases.GOLDEN, 'data', 'stereo.flac'), 'rb') as f:
