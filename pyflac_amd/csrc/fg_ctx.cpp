@@ -787,7 +787,8 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
     // more than two channels: one-channel views through the pipeline where its shape applies (limit_min_bitrate looks across the
     // channels of a frame, large blocks and wide samples stay with the generic kernel)
     if (s->channels > 2 && s->channels <= 8 && (s->bits_per_sample <= 24 || s->bits_per_sample == 32) && s->max_lpc_order <= 12 && !s->limit_min_bitrate && !c->debug &&
-        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0))
+        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0) &&
+        !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0))
         return encode_multichannel(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
     return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
 }
