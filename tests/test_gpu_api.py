@@ -807,3 +807,25 @@ class TestEncoderSetMetadata:
         assert np.array_equal(want.reshape(-1, 2), pcm)
         got = abi_decode.decode(stream)
         assert np.array_equal(np.concatenate(got['blocks']), pcm)
+
+
+class TestMinFramesizeHint:
+    """STREAMINFO's min_framesize is a hint nothing may depend on: a stream that states a wrong value decodes all the same.  (Starting
+    the host index's search that far into every frame was tried and dropped: the smallest frame of a real stream is its tail or
+    a quiet passage, far below the typical frame, and the jumps cost the sequential scan more than they save.)"""
+
+    @pytest.mark.parametrize('claim', ['true', 'too_large', 'absurd', 'zero'])
+    def test_wrong_min_framesize_does_not_matter(self, claim):
+        from tests import abi_decode
+        from oracle import oracle as O
+        with open(os.path.join(cases.GOLDEN, 'data', 'stereo.flac'), 'rb') as f:
+            data = bytearray(f.read())
+        want, _ = O.decode_stream(bytes(data))
+        true_min = int.from_bytes(data[12:15], 'big')
+        assert true_min > 100
+        v = {'true': true_min, 'too_large': true_min + 2000, 'absurd': 0xFFFFFF, 'zero': 0}[claim]
+        data[12:15] = v.to_bytes(3, 'big')
+        got = abi_decode.decode(bytes(data))
+        assert got['errors'] == [] and got['ok']
+        pcm = np.concatenate(got['blocks'])
+        assert np.array_equal(pcm, want.reshape(pcm.shape))

@@ -12,6 +12,15 @@ enc = pyflac_amd.StreamEncoder(48000, lambda b, n, s, f: chunks.append(b), compr
 _lib.lib().FLAC__stream_encoder_set_do_md5(enc._encoder, 0)
 enc.process(pcm); enc.finish()
 stream = b''.join(chunks)
+if os.environ.get('FILEMODE'):
+    # what a finished file holds (FLAC__stream_encoder_finish seeks back and fills STREAMINFO in): min / max frame size
+    from pyflac_amd import batch
+    offs, _si = batch.index_frames(stream)
+    sz = np.diff(np.asarray(offs, np.int64))
+    stream = bytearray(stream)
+    stream[12:15] = int(sz.min()).to_bytes(3, 'big'); stream[15:18] = int(sz.max()).to_bytes(3, 'big')
+    stream = bytes(stream)
+    print('file mode: min/max frame size', int(sz.min()), int(sz.max()), file=sys.stderr)
 if os.environ.get('PYPROF'):
     threading.setprofile(None)
     prof = cProfile.Profile()
