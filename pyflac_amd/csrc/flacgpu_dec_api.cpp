@@ -817,7 +817,7 @@ struct ByteBuf {
         else if (cap > (1u << 20)) { free(p); p = nullptr; cap = 0; n = 0; }
         else n = 0;
     }
-    void resize(size_t m)          // (new bytes are NOT initialised)
+    bool resize(size_t m)          // (new bytes are NOT initialised; false: out of memory, nothing changed)
     {
         if (m > cap && cap < (1u << 20)) {
             std::lock_guard<std::mutex> lk(pool_mu());
@@ -831,10 +831,11 @@ struct ByteBuf {
             size_t nc = cap ? cap : 65536;
             while (nc < m) nc *= 2;
             uint8_t *np = (uint8_t *)realloc(p, nc);
-            if (!np) throw std::bad_alloc();
+            if (!np) return false;
             p = np; cap = nc;
         }
         n = m;
+        return true;
     }
     void erase(uint8_t *a, uint8_t *b) { memmove(a, b, (size_t)(p + n - b)); n -= (size_t)(b - a); }
 };
@@ -970,7 +971,7 @@ bool pull(DecImpl *d, bool *short_read)
     // (a client that keeps filling the request is asked for more at a time: 64 KiB .. 16 MiB)
     const size_t want = d->pull_want;
     const size_t old = d->buf.size();
-    d->buf.resize(old + want);
+    if (!d->buf.resize(old + want)) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return false; }
     size_t got = want;
     *short_read = true;
     if (d->file) {
