@@ -47,6 +47,11 @@ def main():
         out['fuzz%d' % seed] = record(data, rs)
         out['fuzz%d' % seed]['sha'] = hashlib.sha256(data).hexdigest()[:16]      # (the damaged stream itself, to pin the generator)
         print('%-28s %-8s read %5d frames %3d errors %s' % ('fuzz%d' % seed, src, rs, len(out['fuzz%d' % seed]['frames']), out['fuzz%d' % seed]['errors']))
+    for seed in cases.SMALL_DAMAGE_SEEDS:
+        data, rs = cases.small_damaged_stream(seed)
+        out['small%d' % seed] = record(data, rs)
+        out['small%d' % seed]['sha'] = hashlib.sha256(data).hexdigest()[:16]
+        print('%-28s %4d B  read %5d frames %3d errors %s' % ('small%d' % seed, len(data), rs, len(out['small%d' % seed]['frames']), out['small%d' % seed]['errors']))
     md5 = {}
     for name in sorted(cases.MD5_CASES):
         _pcm, frames, st = R.decode(cases.md5_stream(name), md5_checking=cases.MD5_CASES[name][2])

@@ -333,26 +333,24 @@ extern "C" int64_t flacgpu_refwalk_probe(const uint8_t *stream, uint64_t len, ui
     const int64_t a = parse_metadata(stream, len, &si, &have);
     if (a <= 0) return -1;
     fgref::RefWindows win;
-    for (uint64_t e = read_size; e < len; e += read_size) win.chunk_end.push_back(e);
-    win.chunk_end.push_back(len);
+    win.max_read = read_size ? read_size : 1;      // (the test harness answers min(request, read_size) from wherever it stands)
+    win.data_end = len;
     win.eof = true;
     fgref::Walker w;
     w.d = stream; w.len = len; w.abs0 = 0; w.final = true; w.win = &win;
     w.si.have = have; w.si.min_blocksize = si.min_blocksize; w.si.max_blocksize = si.max_blocksize; w.si.sample_rate = si.sample_rate;
     w.si.channels = si.channels; w.si.bps = si.bits_per_sample; w.si.total_samples = si.total_samples;
     std::vector<uint32_t> errs;
-    uint64_t p = (uint64_t)a, nf = 0, decoded = 0;
+    uint64_t p = (uint64_t)a, nf = 0;
     for (;;) {
-        if (have && si.total_samples && decoded >= si.total_samples) break;
         fgref::Header h;
         bool ended = false;
         uint64_t fend = 0;
-        const uint64_t s = w.run(p, false, errs, &h, &ended, &fend);
+        const uint64_t s = w.run(p, errs, &h, &ended, &fend);
         if (ended || s >= len) break;
         if (nf < frames_cap / 2) { frames[2 * nf] = h.sample_number; frames[2 * nf + 1] = h.blocksize; }
         nf++;
         if (!w.fixed_blocksize && !h.is_sample_number) w.fixed_blocksize = (have && si.min_blocksize == si.max_blocksize) ? si.min_blocksize : h.blocksize;
-        decoded = h.sample_number + h.blocksize;
         p = fend;
     }
     *nframes = nf;
@@ -924,7 +922,9 @@ struct DecImpl {
     // delivered and libFLAC's serial reader is replayed on the host from there -- its error statuses, in order, and the frame it
     // decodes next, where the index takes over again.
     fgref::RefWindows win;        // the answers of the read callback, as the refills of libFLAC's 8 KiB reader would have seen them
-    fgref::Walker walker;         // (its state at the end of the stream)
+    fgref::Walker walker;         // (the reader's buffer as the last walk left it)
+    uint8_t pre[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // the last bytes dropped from the front of buf (libFLAC's buffer front may lie a few bytes before buf[0])
+    uint32_t npre = 0;
     bool walk_pending = false;
     uint64_t walk_from = 0;       // offset in buf
     uint64_t ix_origin = 0;       // offset in buf where the index last started outside a frame
@@ -944,8 +944,26 @@ struct DecImpl {
 inline DecImpl *impl(FLAC__StreamDecoder *d) { return reinterpret_cast<DecImpl *>(d); }
 inline const DecImpl *impl(const FLAC__StreamDecoder *d) { return reinterpret_cast<const DecImpl *>(d); }
 
+// Drop the first n bytes of buf (they are consumed); the last eight dropped stay readable for the replay of libFLAC's reader.
+void drop_front(DecImpl *d, size_t n)
+{
+    if (n == 0) return;
+    uint8_t t[16];
+    uint32_t k = 0;
+    if (n >= 8) { memcpy(d->pre, d->buf.data() + n - 8, 8); d->npre = 8; }
+    else {
+        const uint32_t keep = d->npre < 8 - (uint32_t)n ? d->npre : 8 - (uint32_t)n;
+        memcpy(t, d->pre + d->npre - keep, keep); k = keep;
+        memcpy(t + k, d->buf.data(), n); k += (uint32_t)n;
+        memcpy(d->pre, t, k); d->npre = k;
+    }
+    if (n >= d->buf.size()) d->buf.clear(); else d->buf.erase(d->buf.begin(), d->buf.begin() + n);
+    d->consumed_total += n;
+}
+
 void reset_stream(DecImpl *d)
 {
+    d->npre = 0;
     d->buf.clear(); d->consumed_total = 0; d->eof = false; d->have_meta = false; d->have_si = false;
     memset(&d->si, 0, sizeof d->si);
     d->ix = Indexer();
@@ -977,8 +995,9 @@ bool pull(DecImpl *d, bool *short_read)
     if (d->file) {
         got = fread(d->buf.data() + old, 1, want, d->file);
         d->buf.resize(old + got);
-        if (got == 0) d->eof = true;
-        else d->win.chunk_end.push_back(d->consumed_total + d->buf.size());
+        if (got == 0) { d->eof = true; d->win.eof = true; }
+        d->win.data_end = d->consumed_total + d->buf.size();
+        if (got && got < want) d->win.chunk_end.push_back(d->win.data_end);
         if (got == want && d->pull_want < (16u << 20)) d->pull_want *= 2;
         *short_read = false;
         return true;
@@ -997,8 +1016,10 @@ bool pull(DecImpl *d, bool *short_read)
     if (rs == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { d->buf.resize(old); d->state = FLAC__STREAM_DECODER_ABORTED; return false; }
     if (got > want) got = want;
     d->buf.resize(old + got);
-    if (got) d->win.chunk_end.push_back(d->consumed_total + d->buf.size());
-    if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || got == 0) d->eof = true;
+    // (an answer that fills the request leaves no mark: libFLAC's smaller requests would have been filled as well)
+    d->win.data_end = d->consumed_total + d->buf.size();
+    if (got && got < want) d->win.chunk_end.push_back(d->win.data_end);
+    if (rs == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || got == 0) { d->eof = true; d->win.eof = true; }
     *short_read = got < want;
     if (got == want && d->pull_want < (16u << 20)) d->pull_want *= 2;
     return true;
@@ -1167,8 +1188,7 @@ bool ensure_metadata(DecImpl *d)
         if (a < 0) {
             // libFLAC keeps searching for "fLaC" and reports LOST_SYNC; a stream that never shows it ends in error
             if (d->error_cb) d->error_cb(&d->pub, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client);
-            d->consumed_total += d->buf.size();
-            d->buf.clear();
+            drop_front(d, d->buf.size());
             if (d->eof) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return false; }
             if (d->state == FLAC__STREAM_DECODER_ABORTED) return false;
             bool sr;
@@ -1185,8 +1205,7 @@ bool ensure_metadata(DecImpl *d)
         d->have_meta = true;
         d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
         if (d->meta_cb) deliver_metadata(d, d->buf.data(), (uint64_t)a);
-        d->buf.erase(d->buf.begin(), d->buf.begin() + a);
-        d->consumed_total += (uint64_t)a;
+        drop_front(d, (size_t)a);
     }
     return true;
 }
@@ -1411,11 +1430,12 @@ bool deliver_blocks(DecImpl *d, size_t limit)
         d->last_hdr = h; d->last_set = true;
         d->samples_decoded = number + fr.n;
     }
-    if (d->blocks.empty()) return true;
-    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
-    if (d->block_cb(&d->pub, d->blocks.data(), (uint32_t)d->blocks.size(), d->pcm.data(), d->round_bytes, d->client) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) {
-        d->state = FLAC__STREAM_DECODER_ABORTED;
-        return false;
+    if (!d->blocks.empty()) {
+        d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+        if (d->block_cb(&d->pub, d->blocks.data(), (uint32_t)d->blocks.size(), d->pcm.data(), d->round_bytes, d->client) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) {
+            d->state = FLAC__STREAM_DECODER_ABORTED;
+            return false;
+        }
     }
     return true;
 }
@@ -1495,11 +1515,12 @@ bool walk_damage(DecImpl *d)
         errs.clear();
         w = d->walker;
         w.d = d->buf.data(); w.len = d->buf.size(); w.abs0 = d->consumed_total; w.final = d->eof; w.win = &d->win;
+        w.npre = d->npre; memcpy(w.pre, d->pre, 8);
         w.si.have = d->have_si; w.si.min_blocksize = d->si.min_blocksize; w.si.max_blocksize = d->si.max_blocksize;
         w.si.sample_rate = d->si.sample_rate; w.si.channels = d->si.channels; w.si.bps = d->si.bits_per_sample;
         w.si.total_samples = d->si.total_samples;
         w.fixed_blocksize = d->fixed_blocksize;
-        s = w.run(d->walk_from, false, errs, &h, &ended, &fend);
+        s = w.run(d->walk_from, errs, &h, &ended, &fend);
         if (s != UINT64_MAX) break;
         // the reader would have read on: more data (a damaged frame can parse on for megabytes)
         bool short_read = false;
@@ -1523,13 +1544,12 @@ bool walk_damage(DecImpl *d)
     d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
     d->ix = Indexer(); d->ix.fast = false;
     if (ended) {
-        d->consumed_total += d->buf.size(); d->buf.clear(); d->ix_origin = 0;
+        drop_front(d, d->buf.size()); d->ix_origin = 0;
         d->state = FLAC__STREAM_DECODER_END_OF_STREAM;
         return false;
     }
     // the frame [s, fend) decodes: it is the next one the GPU pass sees, and the index goes on behind it
-    d->buf.erase(d->buf.begin(), d->buf.begin() + (size_t)s);
-    d->consumed_total += s;
+    drop_front(d, (size_t)s);
     d->ix.bounds.push_back(0); d->ix.bounds.push_back(fend - s);
     d->ix.scan = fend - s; d->ix.in_frame = false;
     d->ix_origin = fend - s;
@@ -1540,11 +1560,9 @@ bool walk_damage(DecImpl *d)
 bool fill_queue(DecImpl *d)
 {
     for (;;) {
-        // (frame_sync_: a stream whose STREAMINFO says how many samples it holds ends there)
-        if (d->have_meta && d->have_si && d->si.total_samples && d->samples_decoded >= d->si.total_samples) {
-            d->state = FLAC__STREAM_DECODER_END_OF_STREAM;
-            return false;
-        }
+        // (libFLAC 1.4.3 does NOT end a stream where STREAMINFO's sample count is reached -- the reference binary delivers every
+        // frame of a stream that claims fewer and reports LOST_SYNC for bytes behind the last frame, in stream and in file mode:
+        // tests/test_gpu_api.py::TestStreamEnd; round 3 had such a test here, on one of three delivery paths)
         if (d->next_frame < d->frames.size()) return true;
         if (!ensure_metadata(d)) return false;
         if (d->walk_pending) {
@@ -1555,8 +1573,7 @@ bool fill_queue(DecImpl *d)
         if (d->frames_delivered_bound > 0 && !d->ix.bounds.empty()) {
             const uint64_t cut = d->ix.bounds[d->frames_delivered_bound];
             if (cut > 0) {
-                { ProfSpan span(&d->prof_ms[4]); d->buf.erase(d->buf.begin(), d->buf.begin() + (size_t)cut); }
-                d->consumed_total += cut;
+                { ProfSpan span(&d->prof_ms[4]); drop_front(d, (size_t)cut); }
                 std::vector<uint64_t> nbnd;
                 for (size_t i = d->frames_delivered_bound; i < d->ix.bounds.size(); i++) nbnd.push_back(d->ix.bounds[i] - cut);
                 d->ix.bounds.swap(nbnd);
@@ -1830,10 +1847,15 @@ FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *dec)
 {
     DecImpl *d = impl(dec);
     if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
- d->consumed_total += d->buf.size();
-    d->buf.clear(); d->ix = Indexer(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
+    drop_front(d, d->buf.size()); d->npre = 0;
+    d->ix = Indexer(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
     d->win.restart(d->consumed_total); d->walker = fgref::Walker(); d->walk_pending = false; d->ix_origin = 0; d->walk_stuck_at = UINT64_MAX;
+    d->eof = false;          // (the client may have moved its source: ask again)
     d->do_md5 = false;       // stream_decoder.h:1357-1359: a flush turns MD5 checking off
+    // libFLAC's flush also forgets how far the stream has been decoded and the last frame's header (stream_decoder.h:1353-1366:
+    // "the decoder's state is reset for the next frame"): nothing is filled with silence across a flush, and a STREAMINFO sample
+    // count does not end a stream the client has rewound
+    d->samples_decoded = 0; d->last_set = false;
     d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
     return 1;
 }

@@ -161,23 +161,34 @@ class _Decoder:
             # per frame for the write callback -- what _write produces, without the per-frame crossing through ctypes.
             try:
                 rec = np.frombuffer((C.c_uint8 * (32 * nblocks)).from_address(blocks), dtype=_BLOCK_DTYPE)
-                nch = int(rec['channels'][0])
-                bps = rec['bits_per_sample']
-                if not getattr(self, '_allow_any_bps', False) and not np.all((bps == 16) | (bps == 32)):
-                    raise ValueError('Only int16/int32 data type is supported')
-                if not np.all(rec['channels'] == nch):
-                    raise ValueError('channel count changes inside a round')
-                offs, sizes, rates = rec['offset'].tolist(), rec['blocksize'].tolist(), rec['sample_rate'].tolist()
                 real = rec['offset'] != _BLOCK_SILENCE
-                total = int((rec['offset'][real] + rec['blocksize'][real]).max()) if real.any() else 0
-                ctype = C.c_int16 if bytes_per_sample == 2 else C.c_int32
-                audio = np.frombuffer((ctype * (total * nch)).from_address(pcm), dtype=np.int16 if bytes_per_sample == 2 else np.int32)
-                audio = audio.reshape(total, nch).copy()
-                if bytes_per_sample == 2 and not np.all(bps == 16):
-                    audio = audio.astype(np.int32)            # (the per-frame path hands out int16 for 16-bit frames only)
-                cb = self.write_callback
-                for o, n, sr in zip(offs, sizes, rates):
-                    cb(audio[o:o + n] if o != _BLOCK_SILENCE else np.zeros((n, nch), audio.dtype), sr, nch, n)
+                # the round's layout follows its decoded frames (a silence block repeats the header of the frame before it)
+                nch = int(rec['channels'][int(np.argmax(real))]) if real.any() else int(rec['channels'][0])
+                bps = rec['bits_per_sample']
+                good = rec['channels'] == nch
+                if not getattr(self, '_allow_any_bps', False):
+                    good &= (bps == 16) | (bps == 32)
+                # a frame this class cannot hand out ends the stream where the per-frame path would end it: the frames in front
+                # of it are delivered first, then the decoder is told to abort
+                count = int(nblocks) if good.all() else int(np.argmin(good))
+                if count:
+                    rec = rec[:count]
+                    real = real[:count]
+                    offs, sizes, rates = rec['offset'].tolist(), rec['blocksize'].tolist(), rec['sample_rate'].tolist()
+                    # one copy of the samples this call delivers -- [first, last) of the round's buffer, not its whole prefix
+                    lo = int(rec['offset'][real].min()) if real.any() else 0
+                    hi = int((rec['offset'][real] + rec['blocksize'][real]).max()) if real.any() else 0
+                    ctype = C.c_int16 if bytes_per_sample == 2 else C.c_int32
+                    audio = np.frombuffer((ctype * ((hi - lo) * nch)).from_address(pcm + lo * nch * bytes_per_sample),
+                                          dtype=np.int16 if bytes_per_sample == 2 else np.int32)
+                    audio = audio.reshape(hi - lo, nch).copy()
+                    if bytes_per_sample == 2 and not np.all(rec['bits_per_sample'] == 16):
+                        audio = audio.astype(np.int32)            # (the per-frame path hands out int16 for 16-bit frames only)
+                    cb = self.write_callback
+                    for o, n, sr in zip(offs, sizes, rates):
+                        cb(audio[o - lo:o - lo + n] if o != _BLOCK_SILENCE else np.zeros((n, nch), audio.dtype), sr, nch, n)
+                if count != int(nblocks):
+                    raise ValueError('Only int16/int32 data type is supported (or the channel count changes inside a round)')
                 return 0   # CONTINUE
             except Exception:   # noqa: BLE001
                 return 1

@@ -49,6 +49,69 @@ def decode(data, read_size=8192, md5_checking=False):
     return {'frames': frames, 'errors': errors, 'state': int(state), 'ok': bool(ok), 'blocks': blocks, 'finish': bool(fin), 'events': events}
 
 
+def decode_script(data, script, read_size=8192, blocks=False):
+    """Run a list of steps on one decoder: ('until',) process_until_end_of_stream; ('single',) process_single until the state is
+    END_OF_STREAM; ('flush',) FLAC__stream_decoder_flush; ('source', offset) move the client's read position.  Returns the
+    (sample number, block size) pairs delivered and the error statuses, per step."""
+    from pyflac_amd import _lib
+    L = _lib.lib()
+    dec = C.c_void_p(L.FLAC__stream_decoder_new())
+    pos = [0]
+    frames, errors = [], []
+    dt = np.dtype([('sample_number', '<u8'), ('offset', '<u8'), ('blocksize', '<u4'), ('channels', '<u4'), ('bits_per_sample', '<u4'),
+                   ('sample_rate', '<u4')])
+
+    def _r(d, buf, pn, cd):
+        n = min(pn[0], len(data) - pos[0], read_size)
+        if n <= 0:
+            pn[0] = 0
+            return 1
+        C.memmove(buf, data[pos[0]:pos[0] + n], n)
+        pos[0] += n
+        pn[0] = n
+        return 0
+
+    def _w(d, fr, bufs, cd):
+        h = fr.contents.header
+        frames.append((int(h.number.sample_number), int(h.blocksize)))
+        return 0
+
+    def _b(d, blks, n, pcm, nbytes, cd):
+        for r in np.frombuffer((C.c_uint8 * (32 * n)).from_address(blks), dtype=dt):
+            frames.append((int(r['sample_number']), int(r['blocksize'])))
+        return 0
+
+    def _e(d, status, cd):
+        errors.append(int(status))
+
+    rcb, wcb, ecb, bcb = _lib.DEC_READ_CB(_r), _lib.DEC_WRITE_CB(_w), _lib.DEC_ERROR_CB(_e), _lib.DEC_BLOCK_CB(_b)
+    if blocks:
+        assert L.flacgpu_stream_decoder_set_block_callback(dec, bcb)
+    rc = L.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb, C.cast(None, _lib.DEC_META_CB), ecb, None)
+    assert rc == 0, rc
+    out = []
+    for step in script:
+        nf, ne = len(frames), len(errors)
+        ok = 1
+        if step[0] == 'until':
+            ok = L.FLAC__stream_decoder_process_until_end_of_stream(dec)
+        elif step[0] == 'single':
+            for _ in range(100000):
+                if L.FLAC__stream_decoder_get_state(dec) == 4:
+                    break
+                ok = L.FLAC__stream_decoder_process_single(dec)
+                if not ok:
+                    break
+        elif step[0] == 'flush':
+            ok = L.FLAC__stream_decoder_flush(dec)
+        elif step[0] == 'source':
+            pos[0] = step[1]
+        out.append({'ok': bool(ok), 'state': int(L.FLAC__stream_decoder_get_state(dec)), 'frames': frames[nf:], 'errors': errors[ne:]})
+    L.FLAC__stream_decoder_finish(dec)
+    L.FLAC__stream_decoder_delete(dec)
+    return out
+
+
 def decode_blocks(data, read_size=8192):
     """The same through libflacgpu's block delivery (include/flacgpu.h, flacgpu_block_callback): what the callbacks see, in the
     form decode() records it."""

@@ -226,6 +226,54 @@ def fuzz_damaged_stream(seed):
     return name, bytes(data), rs
 
 
+# Small streams: frames of 10..60 bytes read in answers of a few bytes to a few hundred, so that the refills of libFLAC's reader
+# fall everywhere around the damaged frames (round 3's replay walked in a circle when a refill fell 2..7 bytes behind a damaged
+# frame's sync code; tests/tools/refwalk_small_fuzz.py found 44 such seeds and 8 wrong sequences in its first 3000).  The
+# streams come from the oracle's encoder; the vectors pin them by hash.
+SMALL_DAMAGE_SEEDS = sorted(set(list(range(0, 152)) + [
+    82, 95, 417, 433, 499, 501, 531, 570, 651, 721, 885, 909, 929, 966, 1012, 1066, 1114, 1142, 1152, 1174, 1255, 1274, 1275, 1285,
+    1398, 1455, 1473, 1574, 1595, 1831, 1837, 1867, 1884, 1926, 2071, 2103, 2248, 2323, 2412, 2446, 2471, 2564, 2615, 2638, 2694,
+    2754, 2798, 2991]))
+
+
+def small_damaged_stream(seed):
+    """(stream bytes, read size) of seed: a short stream of small frames with one to three edits behind the metadata."""
+    from oracle import oracle as O
+    r = np.random.default_rng(seed)
+    ch = int(r.integers(1, 3))
+    bps = int(r.choice([8, 16]))
+    blk = int(r.choice([16, 16, 24, 32, 64, 192]))
+    nfr = int(r.integers(2, 9))
+    n = blk * nfr - int(r.integers(0, blk // 2))
+    kind = int(r.integers(0, 3))
+    amp = (1 << (bps - 1)) - 1
+    if kind == 0:
+        pcm = np.full((n, ch), int(r.integers(-amp, amp)), np.int32)          # constant frames: 11..14 bytes each
+    elif kind == 1:
+        pcm = r.integers(-3, 4, (n, ch)).astype(np.int32)
+    else:
+        pcm = r.integers(-amp, amp, (n, ch)).astype(np.int32)
+    cfg, _ = O.config(int(r.integers(0, 9)), ch, bps, 44100, blk, subset=False)
+    data, _sizes = O.encode_stream(cfg, pcm, finalize=bool(r.integers(0, 2)))
+    data = bytearray(data)
+    for _ in range(int(r.integers(1, 4))):
+        k = int(r.integers(0, 5))
+        p = int(r.integers(86, max(87, len(data) - 1)))
+        if k == 0:
+            data[p] ^= 1 << int(r.integers(0, 8))
+        elif k == 1:
+            del data[p:p + int(r.integers(1, 12))]
+        elif k == 2:
+            data[p:p] = r.integers(0, 256, int(r.integers(1, 20)), dtype=np.uint8).tobytes()
+        elif k == 3:
+            data[p:p + 2] = b'\xff\xf8'
+        else:
+            n0 = int(r.integers(1, 10))
+            data[p:p + n0] = bytes(n0)
+    rs = int(r.choice([int(r.integers(1, 130)), int(r.integers(1, 40)), 8192, int(r.integers(100, 1000))]))
+    return bytes(data), rs
+
+
 # MD5 checking on decode (FLAC__stream_decoder_set_md5_checking): name -> (damage case or fixture, STREAMINFO md5 edit,
 # checking enabled).  The signature sits at bytes 26..41 of a stream whose STREAMINFO is the first block.
 MD5_CASES = {

@@ -364,6 +364,17 @@ class TestDamagedStreams:
         self.check(want, data, read_size)
 
 
+    @pytest.mark.parametrize('seed', cases.SMALL_DAMAGE_SEEDS)
+    def test_small_streams_read_in_small_answers(self, damage_golden, seed):
+        """Frames of a few bytes, answers of a few bytes (tests/cases.py small_damaged_stream): refills of libFLAC's reader fall
+        everywhere around the damage.  Round 3's decoder hung on some of these (the replay walked in a circle)."""
+        import hashlib
+        data, read_size = cases.small_damaged_stream(seed)
+        want = damage_golden['small%d' % seed]
+        assert hashlib.sha256(data).hexdigest()[:16] == want['sha']
+        self.check(want, data, read_size)
+
+
 class TestMd5Checking:
     """FLAC__stream_decoder_set_md5_checking: what FLAC__stream_decoder_finish returns, against
     the reference binary's answers recorded in tests/golden/damage_vectors.json['__md5__']."""
@@ -829,3 +840,42 @@ class TestMinFramesizeHint:
         assert got['errors'] == [] and got['ok']
         pcm = np.concatenate(got['blocks'])
         assert np.array_equal(pcm, want.reshape(pcm.shape))
+
+
+class TestStreamEnd:
+    """Where a stream ends and what a flush forgets -- as the reference's libFLAC 1.4.3 binary behaves (probed in the build container;
+    ADVICE round 3 item 2).  It does NOT stop where STREAMINFO's sample count is reached: a stream that claims fewer samples than it
+    holds is delivered to its last frame, bytes behind the last frame are searched (one LOST_SYNC), in every delivery mode.  A flush
+    forgets how far the stream was decoded and the last frame's header: a client that rewinds its source gets the frames again, one
+    that jumps ahead gets no silence for the gap."""
+
+    ALL = [(i * 4096, 4096) for i in range(16)] + [(65536, 614)]
+
+    @staticmethod
+    def stream(total=None, tail=b''):
+        with open(os.path.join(cases.GOLDEN, 'data', 'stereo.flac'), 'rb') as f:
+            data = bytearray(f.read())
+        if total is not None:
+            b = int.from_bytes(data[18:26], 'big')
+            data[18:26] = ((b & ~((1 << 36) - 1)) | total).to_bytes(8, 'big')
+        return bytes(data) + tail
+
+    @pytest.mark.parametrize('mode', ['until', 'single', 'blocks'])
+    @pytest.mark.parametrize('case', ['short_total', 'garbage_tail', 'both'])
+    def test_sample_count_of_streaminfo_does_not_end_the_stream(self, mode, case):
+        from tests import abi_decode
+        data = self.stream(3 * 4096 + 1 if case != 'garbage_tail' else None, bytes(range(1, 200)) if case != 'short_total' else b'')
+        r = abi_decode.decode_script(data, [('single',) if mode == 'single' else ('until',)], blocks=mode == 'blocks')[0]
+        assert r['ok'] and r['state'] == 4
+        assert r['frames'] == self.ALL
+        assert r['errors'] == ([] if case == 'short_total' else [0])        # (recorded from the reference binary)
+
+    @pytest.mark.parametrize('mode', ['until', 'single', 'blocks'])
+    def test_flush_forgets_position_and_last_frame(self, mode):
+        from tests import abi_decode
+        run = ('single',) if mode == 'single' else ('until',)
+        r = abi_decode.decode_script(self.stream(), [run, ('flush',), ('source', 8304), run, ('flush',), ('source', 39273), run], blocks=mode == 'blocks')
+        assert [x['ok'] for x in r] == [True] * 7 and all(x['errors'] == [] for x in r)
+        assert r[0]['frames'] == self.ALL
+        assert r[3]['frames'] == self.ALL                      # rewound to the first frame: everything again
+        assert r[6]['frames'] == self.ALL[6:]                  # jumped to frame 6: no silence in front of it
