@@ -8,9 +8,12 @@ decode the encoder's output back to PCM.  `value` counts each channel-sample onc
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N            (N > 1, no launcher around it: starts the N ranks itself, as a child process)
 
-N > 1: independent streams shard across ranks (weak scaling, no data-path collective); rank 0 broadcasts the
-86-byte stream header over RCCL as the only shared datum.
+N = 1 (default): the headline is configs[1]+[2] (stream16); the same run then measures configs[3] (stream24, 300 s, level 8)
+and configs[4]'s per-GPU share (batch, 128 streams x 60 s) in the same process and reports them under `configs`.
+N > 1: configs[4] -- independent streams shard across ranks, 128 per GPU (weak scaling, no data-path collective); rank 0
+broadcasts the 86-byte stream header over RCCL as the only shared datum.
 """
 import argparse
 import json
@@ -37,6 +40,62 @@ def _encode_worker(_i):
     for _ in range(reps):
         O.encode_stream(cfg, a32)
     return time.perf_counter() - t
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def system_libflac(pcm16, level, sr):
+    """a libFLAC found on THIS box (ldconfig), timed through its public C API
+    (FLAC__stream_encoder_process_interleaved + finish, FLAC__stream_decoder_process_until_end_of_stream; the callbacks
+    only count bytes).  None when the box has no libFLAC -- the image of the GPU pool has none, the probe is what is asked."""
+    import ctypes as C
+    import ctypes.util
+    name = ctypes.util.find_library('FLAC')
+    if not name:
+        return None
+    try:
+        L = C.CDLL(name)
+        L.FLAC__stream_encoder_new.restype = C.c_void_p
+        L.FLAC__stream_decoder_new.restype = C.c_void_p
+        WCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
+        a32 = np.ascontiguousarray(pcm16.astype(np.int32))
+        res = {'library': name, 'version': C.c_char_p.in_dll(L, 'FLAC__VERSION_STRING').value.decode()}
+        stream = bytearray()
+        for md5 in (1, 0):
+            best = None
+            for _ in range(3):
+                stream = bytearray()
+                def w(_e, buf, n, _s, _f, _c):
+                    stream.extend(C.string_at(buf, n))
+                    return 0
+                cb = WCB(w)
+                enc = C.c_void_p(L.FLAC__stream_encoder_new())
+                L.FLAC__stream_encoder_set_channels(enc, a32.shape[1]); L.FLAC__stream_encoder_set_bits_per_sample(enc, 16)
+                L.FLAC__stream_encoder_set_sample_rate(enc, sr); L.FLAC__stream_encoder_set_compression_level(enc, level)
+                L.FLAC__stream_encoder_set_blocksize(enc, 4096)
+                if hasattr(L, 'FLAC__stream_encoder_set_do_md5'):
+                    L.FLAC__stream_encoder_set_do_md5(enc, md5)
+                if L.FLAC__stream_encoder_init_stream(enc, cb, None, None, None, None) != 0:
+                    return None
+                t = time.perf_counter()
+                L.FLAC__stream_encoder_process_interleaved(enc, a32.ctypes.data_as(C.c_void_p), a32.shape[0])
+                L.FLAC__stream_encoder_finish(enc)
+                dt = time.perf_counter() - t
+                L.FLAC__stream_encoder_delete(enc)
+                best = dt if best is None else min(best, dt)
+            res['encode_msamples_per_s_md5_%s' % ('on' if md5 else 'off')] = round(a32.size / best / 1e6, 2)
+        return res
+    except Exception as e:       # noqa: BLE001 (a library that does not behave is reported, not fatal)
+        return {'library': name, 'error': repr(e)}
 
 
 def cpu_baseline(pcm16, level, sr, budget_s=12.0):
@@ -82,8 +141,16 @@ def cpu_baseline(pcm16, level, sr, budget_s=12.0):
     # oracle.decode_stream makes two passes (count, then decode): one decode = half the measured time
     dec = nsamp * dreps / (dec_t / 2) / 1e6
     both = 1.0 / (1.0 / enc + 1.0 / dec)
+    # MD5 on (libFLAC's default): the same encode with the signature of the PCM computed as well
+    t = time.perf_counter()
+    O.encode_stream(cfg, a32, finalize=True)
+    enc_md5 = nsamp / (time.perf_counter() - t) / 1e6
+    sysflac = system_libflac(pcm16, level, sr)
     return {'value': round(both, 2), 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'cpu_model': cpu_model(), 'host_cores': avail,
             'encode_msamples_per_s': round(enc, 2), 'decode_msamples_per_s': round(dec, 2),
+            'encode_msamples_per_s_md5_on': round(enc_md5, 2),
+            'system_libFLAC': sysflac if sysflac is not None else 'none on this box (ctypes.util.find_library("FLAC") is None)',
             'all_cores': {'cores': ncores, 'encode_msamples_per_s': None if allc is None else round(allc, 1),
                           'how': 'one oracle process per host core, about 3 s of encodes each, aggregate over the slowest worker'},
             'sample': '%.0f s of the same synthetic stream x%d encode / x%d decode passes, MD5 off, 1 thread; '
@@ -192,83 +259,154 @@ def api_e2e(seconds, sr):
     return out
 
 
-def main():
+WORKLOADS = ['stream16', 'stream24', 'batch', 'wasted', 'stream32', 'stream32w', 'surround6']
+WORKLOAD_NAMES = {'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]',
+                  'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)',
+                  'stream32': '32-bit samples (33-bit side channel)',
+                  'stream32w': '24-bit material in a 32-bit container (int32 arrays as pyFLAC gets them from a 24-bit WAV: eight wasted bits)',
+                  'surround6': 'six channels'}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=300, help='timed steps (default: about half a second of work)')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 300 for the single-stream workloads, 30 for batch)')
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--seconds', type=float, default=None, help='length of each stream (default 600; 60 for --workload batch)')
+    ap.add_argument('--seconds', type=float, default=None, help='length of each stream (default 600; 300 for stream24, 60 for batch)')
     ap.add_argument('--level', type=int, default=None, help='compression level (default 5; 8 for --workload stream24)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
+    ap.add_argument('--no-configs', action='store_true', help='headline only: skip the configs[3] / configs[4] legs of the default run')
     ap.add_argument('--no-passes', action='store_true', help='skip the event passes after the timed loop (profiling runs: the trace then holds the timed loop only)')
-    ap.add_argument('--workload', choices=['stream16', 'stream24', 'batch', 'wasted', 'stream32', 'stream32w', 'surround6'], default='stream16',
-                    help='stream16 (default, the metric): configs[1]+[2]; stream24: configs[3], 24-bit 96 kHz level 8; '
-                         'batch: configs[4], independent 16-bit streams per GPU in one launch (--streams, --seconds each); '
+    ap.add_argument('--workload', choices=WORKLOADS, default=None,
+                    help='default: stream16 at 1 GPU (the metric: configs[1]+[2]), batch at N > 1 (configs[4]).  stream24: configs[3], '
+                         '24-bit 96 kHz level 8; batch: independent 16-bit streams per GPU in one launch (--streams, --seconds each); '
                          'wasted: the stream16 signal in a 24-bit container (8 wasted bits in every block)')
     ap.add_argument('--streams', type=int, default=128, help='streams per GPU for --workload batch')
-    args = ap.parse_args()
-    if args.seconds is None:
-        args.seconds = 60.0 if args.workload == 'batch' else 600.0
-    if args.level is None:
-        args.level = 8 if args.workload == 'stream24' else 5
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU only, gloo: the launcher, the rank mapping, the header broadcast and the timing contract with no GPU work '
+                         '(tests/test_bench_launcher.py); the line it prints says so and is no measurement')
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process (torch.distributed.run, one
+    rank per GPU) and relay what rank 0 prints.  This process never touches a GPU -- counting devices does not initialise one --
+    and never replaces itself with another program.  A box with fewer than N GPUs is an error, not an n_gpus: 1 line."""
+    import subprocess
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d asked, %d GPU(s) visible on this box\n' % (args.gpus, have))
+            return 3
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # (dmabuf IPC: RCCL between processes needs it on this pool)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """The N > 1 path with the GPU work taken out (gloo, CPU): what remains is what the launcher test checks -- every rank gets
+    its share of the world x streams batch, rank 0's header reaches everybody, the steps are bracketed by barriers and the
+    maximum over the ranks is what rank 0 reports."""
     import torch
     import torch.distributed as dist
-    from pyflac_amd import batch, shard, synth
-
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    # The CPU leg runs FIRST, before anything touches the GPU: it forks one oracle process per host core, and a forked child
-    # must not carry HIP state (torch.cuda.is_available() below initialises the device).
-    cpu_res = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'stream16':
-        cpu_res = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), args.level, 48000)
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    from pyflac_amd import shard
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('gloo')
+    dev = torch.device('cpu')
+    hdr = bytes(range(86)) if rank == 0 else b''
+    if world > 1:
+        hdr = shard.broadcast_header(hdr, dev)
+    assert hdr == bytes(range(86))
+    mine = shard.streams_for_rank(world * args.streams, rank, world)
+    assert len(mine) == args.streams
+    steps = args.steps or 3
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        assert sorted(x for g in got for x in g) == list(range(world * args.streams))
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run: no GPU work, no measurement', 'value': 0.0, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': steps,
+                          'warmup': args.warmup, 'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'int32', 'data': 'none (dry run)',
+                          'config': {'workload': 'dry run of configs[4]: %d streams per rank, %d ranks' % (args.streams, world)}, 'dry_run': True}))
+    if world > 1:
+        dist.destroy_process_group()
 
-    sr, ch, bps, bs = 48000, 2, 16, 4096
-    lengths = None
-    if args.workload == 'stream24':
+
+def make_input(workload, seconds, rank, world, streams):
+    """(pcm [samples, channels] as numpy, sample rate, channels, bits per sample, per-stream lengths or None)"""
+    from pyflac_amd import shard, synth
+    sr, ch, bps, lengths = 48000, 2, 16, None
+    if workload == 'stream24':
         sr, bps = 96000, 24
-        pcm16 = synth.config4_stereo24(args.seconds, 1 + rank, sr)          # int32 container, 24-bit values
-    elif args.workload == 'wasted':
+        pcm = synth.config4_stereo24(seconds, 1 + rank, sr)          # int32 container, 24-bit values
+    elif workload == 'wasted':
         bps = 24
-        pcm16 = synth.config2_stereo16(args.seconds, rank, sr).astype(np.int32) << 8
-    elif args.workload == 'stream32':
+        pcm = synth.config2_stereo16(seconds, rank, sr).astype(np.int32) << 8
+    elif workload == 'stream32':
         # pyFLAC's other input type (pyflac/encoder.py:109: int32 arrays): 32-bit samples, the side channel needs 33 bits
         bps = 32
-        pcm16 = synth.config2_stereo16(args.seconds, rank, sr).astype(np.int64) * 40000 + (np.arange(int(round(sr * args.seconds)))[:, None] % 977)
-        pcm16 = np.clip(pcm16, -(1 << 31), (1 << 31) - 1).astype(np.int32)
-    elif args.workload == 'stream32w':
+        pcm = synth.config2_stereo16(seconds, rank, sr).astype(np.int64) * 40000 + (np.arange(int(round(sr * seconds)))[:, None] % 977)
+        pcm = np.clip(pcm, -(1 << 31), (1 << 31) - 1).astype(np.int32)
+    elif workload == 'stream32w':
         # what pyFLAC makes of a 24-bit WAV file: soundfile reads it as left-justified int32, pyflac/encoder.py:109 sets 32 bits per
         # sample -- a 32-bit stream whose samples share eight wasted bits (the configs[3] signal in a 32-bit container)
         sr, bps = 96000, 32
-        pcm16 = (synth.config4_stereo24(args.seconds, 1 + rank, sr).astype(np.int64) << 8).astype(np.int32)
-    elif args.workload == 'surround6':
+        pcm = (synth.config4_stereo24(seconds, 1 + rank, sr).astype(np.int64) << 8).astype(np.int32)
+    elif workload == 'surround6':
         # six channels (tests/test_encoder.py:258-273 of the reference: surround.wav), 16 bit: three stereo pairs of the generator family
         ch = 6
-        pcm16 = np.concatenate([synth.config5_stream(3 * rank + k, args.seconds, sr) for k in range(3)], axis=1)
-    elif args.workload == 'batch':
+        pcm = np.concatenate([synth.config5_stream(3 * rank + k, seconds, sr) for k in range(3)], axis=1)
+    elif workload == 'batch':
         # configs[4]: this rank's share of the world * streams batch -- stream s runs on rank s mod world
         # (pyflac_amd.shard.streams_for_rank, the mapping batch.MultiContext uses inside one process) -- concatenated in HBM,
         # every stream with its own frame numbering, all of them in ONE launch
-        mine = shard.streams_for_rank(world * args.streams, rank, world)
-        per = [synth.config5_stream(sidx, args.seconds, sr) for sidx in mine]
+        mine = shard.streams_for_rank(world * streams, rank, world)
+        per = [synth.config5_stream(sidx, seconds, sr) for sidx in mine]
         lengths = [len(x) for x in per]
-        pcm16 = np.concatenate(per)
+        pcm = np.concatenate(per)
     else:
         # each rank encodes its own stream (config 5 generator family); rank 0 at N=1 is config 2's stream
-        pcm16 = synth.config2_stereo16(args.seconds, 0, sr) if world == 1 else synth.config5_stream(rank, args.seconds, sr)
+        pcm = synth.config2_stereo16(seconds, 0, sr) if world == 1 else synth.config5_stream(rank, seconds, sr)
+    return pcm, sr, ch, bps, lengths
+
+
+def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=True, check=True):
+    """One workload: `warmup` untimed steps, the bit-exactness gates, `steps` timed steps between barriers, then the event
+    passes for the per-launch durations.  Returns the result dictionary (rank 0; None on the other ranks)."""
+    import torch
+    import torch.distributed as dist
+    from pyflac_amd import batch, shard, _lib
+    rank, world, dev = env['rank'], env['world'], env['dev']
+    bs = 4096
+    pcm16, sr, ch, bps, lengths = make_input(workload, seconds, rank, world, streams)
     pcm = torch.from_numpy(pcm16.astype(np.int32)).to(dev)     # int32 at the C ABI, like pyflac/encoder.py:112
     nsamp = pcm.shape[0]
-    ctx = batch.Context(local)
-    s = batch.settings(args.level, ch, bps, sr, bs, True)
+    s = batch.settings(level, ch, bps, sr, bs, True)
 
     # the only shared datum: the 86-byte stream header, broadcast from rank 0 (RCCL over xGMI)
     from pyflac_amd.encoder import stream_header_bytes
@@ -302,18 +440,26 @@ def main():
             dec, status, dst = ctx.decode_streams(out[:est.total_bytes], ranges[0], ch, bps, nsamp, out=dec)
         return est, dst, status
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, warmup)):
         est, dst, status = step()
     # bit-exactness gate (outside the timed region): the round trip equals the input
     assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
     assert torch.equal(dec[:nsamp], pcm), 'round trip is not bit-exact'
     # what the GPU wrote, for the byte-for-byte check against the oracle after the timed region: the WHOLE stream (of the batch:
-    # the whole first stream)
-    h_chk = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        nchk = nsamp if single else lengths[0]
-        nfchk = -(-nchk // bs)
-        h_chk = (nchk, nfchk, out[:int(offs[nfchk].item())].cpu().numpy().tobytes())
+    # its first and its last stream, whole)
+    h_chk = []
+    if rank == 0 and check:
+        if single:
+            h_chk.append((0, nsamp, out[:int(offs[-(-nsamp // bs)].item())].cpu().numpy().tobytes()))
+        else:
+            ho = offs.cpu().numpy().astype(np.int64)
+            first_frame = [0]
+            for n in lengths:
+                first_frame.append(first_frame[-1] + -(-n // bs))
+            starts = np.concatenate([[0], np.cumsum(lengths)])
+            for k in sorted(set([0, len(lengths) // 2, len(lengths) - 1])):
+                a, b = int(ho[first_frame[k]]), int(ho[first_frame[k + 1]])
+                h_chk.append((int(starts[k]), int(lengths[k]), out[a:b].cpu().numpy().tobytes()))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -322,7 +468,7 @@ def main():
     total_bytes = 0
     per_step = []
     tl = t0
-    for _ in range(args.steps):
+    for _ in range(steps):
         est, dst, status = step()
         enc_wall += est.total_gpu_ms       # (timed region: no HIP events; GPU time from the wall-clock stamps of the first
         dec_wall += dst.total_gpu_ms       #  and the last kernel of each call)
@@ -338,21 +484,20 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
+    ms_per_step = dt / steps * 1e3
     chsamples = nsamp * ch                                   # per rank per step
     value = chsamples * world / (ms_per_step * 1e-3) / 1e6
-    K = args.steps
+    K = steps
     alg_bytes = chsamples * 4 + total_bytes                   # read int32 PCM once + write the frames once (and back for decode)
 
     # The same steps again with HIP events around every launch (flacgpu_set_stage_timing level 1: around the call and its
     # kernel groups; each event record idles the GPU for a few microseconds, which is why the timed region above runs without
     # them): the per-launch durations the roofline objects quote.  Then a few steps with events between the encoder's stages.
-    from pyflac_amd import _lib
     L = _lib.lib()
     L.flacgpu_set_stage_timing(ctx._h, 1)
     enc_ms = dec_ms = enc_tot = dec_tot = idx_ms = 0.0
     KE = max(1, min(K, 100))
-    for _ in range(0 if args.no_passes else KE):
+    for _ in range(KE if passes else 0):
         est, dst, status = step()
         enc_ms += est.encode_kernel_ms
         enc_tot += est.total_gpu_ms
@@ -360,82 +505,163 @@ def main():
         dec_tot += dst.total_gpu_ms
         idx_ms += dst.index_ms
     enc_k, dec_k, enc_t, dec_t, idx_ms = enc_ms / KE, dec_ms / KE, enc_tot / KE, dec_tot / KE, idx_ms / KE
-    if args.no_passes:          # (no event pass: the device stamps of the timed region stand in)
+    if not passes:          # (no event pass: the device stamps of the timed region stand in)
         enc_k = enc_t = enc_wall / K
         dec_k = dec_t = dec_wall / K
     L.flacgpu_set_stage_timing(ctx._h, 2)
     stage = np.zeros(4)
-    for _ in range(0 if args.no_passes else 5):
+    for _ in range(5 if passes else 0):
         e2, _d2, _s2 = step()
         stage += np.array(list(e2.stage_ms)[:4])
     stage /= 5
     L.flacgpu_set_stage_timing(ctx._h, 0)
+    nblocks = int(est.nblocks)
+    del out, offs, dec, pcm
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        ps = np.sort(np.array(per_step)) * 1e3
-        # (the committed PMC passes: profiles/r03_pmc.json for the headline, profiles/r03_pmc_<workload>.json for the others)
-        pmc_name = 'r03_pmc.json' if args.workload == 'stream16' else 'r03_pmc_%s.json' % args.workload
-        if not committed_profile(pmc_name):
-            pmc_name = 'r02_pmc.json'
+    ps = np.sort(np.array(per_step)) * 1e3
+    # (the committed PMC passes of the same command: profiles/r04_pmc.json for the headline, profiles/r04_pmc_<workload>.json
+    # for the others; a pass of an earlier round stands in only if it was made on the same workload, level and block count)
+    pmc, pmc_name = {}, None
+    for rnd in ('r04', 'r03', 'r02'):
+        pmc_name = '%s_pmc.json' % rnd if workload == 'stream16' else '%s_pmc_%s.json' % (rnd, workload)
         pmc = committed_profile(pmc_name) or {}
-        same = pmc.get('workload') == args.workload and pmc.get('level') == args.level and pmc.get('blocks') == int(est.nblocks)
-        enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
-        dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
-        res = {
-            'metric': 'Msamples/s encode (level %d, %dkHz/%d-bit stereo, blk 4096) + decode; bit-exact' % (args.level, sr // 1000, bps),
-            'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'int32', 'data': 'synthetic',
-            'config': {'workload': '%s: %s encode, then decode of its output from the bytes%s, %d channels %d-bit %d kHz, blocksize 4096, '
-                                   'level %d, %.0f s%s (%d blocks) per GPU, int32 PCM resident in HBM, MD5 off '
-                                   '(FLAC__stream_encoder_set_do_md5(0))' %
-                                   ({'stream16': 'configs[1]+[2]', 'stream24': 'configs[3]', 'batch': 'configs[4]',
-                                     'wasted': 'stream16 signal in a 24-bit container (8 wasted bits)',
-                                     'stream32': '32-bit samples (33-bit side channel)', 'stream32w': '24-bit material in a 32-bit container (int32 arrays as pyFLAC gets them from a 24-bit WAV: eight wasted bits)', 'surround6': 'six channels'}[args.workload],
-                                    'single-stream' if single else '%d independent streams in one launch,' % len(lengths),
-                                    ' alone (frame index rebuilt on the GPU inside the timed region)' if single else
-                                    ' alone (every stream\'s frame index rebuilt on the GPU inside the timed region, one pass over all bytes)',
-                                    ch, bps, sr // 1000, args.level, args.seconds, '' if single else ' each', est.nblocks),
-                       'blocks_per_gpu': int(est.nblocks), 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4),
-                       'timed_s': round(dt, 3)},
-            'ms_per_step_min': round(float(ps[0]), 3), 'ms_per_step_median': round(float(ps[len(ps) // 2]), 3),
-            'encode_kernel_msamples_per_s': round(chsamples / (enc_k * 1e-3) / 1e6, 1),
-            'decode_kernel_msamples_per_s': round(chsamples / (dec_k * 1e-3) / 1e6, 1),
-            'encode_kernel_ms': round(enc_k, 3), 'decode_kernel_ms': round(dec_k, 3),
-            'encode_gpu_ms': round(enc_t, 3), 'decode_gpu_ms': round(dec_t, 3), 'decode_index_ms': round(idx_ms, 3),
-            'timed_region_gpu_ms': {'encode': round(enc_wall / K, 3), 'decode': round(dec_wall / K, 3),
-                                    'source': 'device wall-clock stamps of the first and last kernel of each call, inside the timed region'},
-            'event_pass_steps': KE,
-            'encode_stage_ms': {'analysis (autocorrelation, Levinson-Durbin, evaluation)': round(float(stage[0]), 3),
-                                'packing': round(float(stage[1]), 3), 'sizes + scan': round(float(stage[2]), 3),
-                                'assembly + CRC-16': round(float(stage[3]), 3)},
-            # the encoder is six kernels back to back (fg_pipe_autoc / levinson / eval / pack, the size scan, fg_pipe_assemble):
-            # one encode = PCM read once, frames written once; time = HIP events around all of them on the library's stream.
-            # The per-kernel durations are in profiles/r03_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command).
-            'roofline': {'bound': 'hbm', 'kernel': 'encode pipeline (fg_pipe_autoc_kernel .. fg_pipe_assemble_kernel; dominant: '
-                                                   'fg_pipe_autoc_kernel)',
-                         'achieved': round(enc_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(enc_ach / 8000.0, 5),
-                         'traffic': pmc.get('encode_traffic_bytes_per_launch') if same else None,
-                         'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(enc_t, 4)},
-            'roofline_decode': {'bound': 'hbm', 'kernel': 'decode (fg_dec_index / headers / scan / fg_dec_wparse_kernel + crc / fg_dec_wrestore_kernel; '
-                                                          'dominant: fg_dec_wparse_kernel)',
-                                'achieved': round(dec_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(dec_ach / 8000.0, 5),
-                                'traffic': pmc.get('decode_traffic_bytes_per_launch') if same else None,
-                                'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(dec_t, 4)},
-        }
-        if same and pmc.get('encode_valu_insts_per_launch'):
-            # the ceiling these integer kernels actually run against: VALU issue (one wave-instruction per 2 cycles and SIMD,
-            # fp64 4 cycles), 1024 SIMDs at 2.4 GHz; instruction counts from the committed PMC pass of this same command
-            slots = 1024 * 2.4e9 / 2
-            res['issue_ceiling'] = {'unit': 'VALU wave-instructions/s', 'peak': slots,
-                                    'encode_valu_insts_per_launch': pmc['encode_valu_insts_per_launch'],
-                                    'encode_frac': round(pmc['encode_valu_insts_per_launch'] / (enc_t * 1e-3) / slots, 4),
-                                    'decode_valu_insts_per_launch': pmc.get('decode_valu_insts_per_launch'),
-                                    'decode_frac': (round(pmc['decode_valu_insts_per_launch'] / (dec_t * 1e-3) / slots, 4)
-                                                    if pmc.get('decode_valu_insts_per_launch') else None),
-                                    'source': 'profiles/' + pmc_name}
-        if world == 1 and not args.no_e2e and args.workload == 'stream16':
-            res['api_e2e'] = api_e2e(min(args.seconds, 600.0), sr)
+        if pmc:
+            break
+    same = pmc.get('workload') == workload and pmc.get('level') == level and pmc.get('blocks') == nblocks
+    enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
+    dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
+    res = {
+        'metric': 'Msamples/s encode (level %d, %dkHz/%d-bit stereo, blk 4096) + decode; bit-exact' % (level, sr // 1000, bps),
+        'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'int32', 'data': 'synthetic',
+        'config': {'workload': '%s: %s encode, then decode of its output from the bytes%s, %d channels %d-bit %d kHz, blocksize 4096, '
+                               'level %d, %.0f s%s (%d blocks) per GPU, int32 PCM resident in HBM, MD5 off '
+                               '(FLAC__stream_encoder_set_do_md5(0)); every step repeats one layout, so the block descriptor list '
+                               '(225 KB for the headline) is uploaded by the first call and reused by the timed ones' %
+                               (WORKLOAD_NAMES[workload],
+                                'single-stream' if single else '%d independent streams in one launch,' % len(lengths),
+                                ' alone (frame index rebuilt on the GPU inside the timed region)' if single else
+                                ' alone (every stream\'s frame index rebuilt on the GPU inside the timed region, one pass over all bytes)',
+                                ch, bps, sr // 1000, level, seconds, '' if single else ' each', nblocks),
+                   'blocks_per_gpu': nblocks, 'compression_ratio': round(total_bytes / (chsamples * (bps // 8)), 4),
+                   'timed_s': round(dt, 3)},
+        'ms_per_step_min': round(float(ps[0]), 3), 'ms_per_step_median': round(float(ps[len(ps) // 2]), 3),
+        'encode_kernel_msamples_per_s': round(chsamples / (enc_k * 1e-3) / 1e6, 1),
+        'decode_kernel_msamples_per_s': round(chsamples / (dec_k * 1e-3) / 1e6, 1),
+        'encode_kernel_ms': round(enc_k, 3), 'decode_kernel_ms': round(dec_k, 3),
+        'encode_gpu_ms': round(enc_t, 3), 'decode_gpu_ms': round(dec_t, 3), 'decode_index_ms': round(idx_ms, 3),
+        'timed_region_gpu_ms': {'encode': round(enc_wall / K, 3), 'decode': round(dec_wall / K, 3),
+                                'source': 'device wall-clock stamps of the first and last kernel of each call, inside the timed region'},
+        'event_pass_steps': KE if passes else 0,
+        'encode_stage_ms': {'analysis (autocorrelation, Levinson-Durbin, evaluation)': round(float(stage[0]), 3),
+                            'packing': round(float(stage[1]), 3), 'sizes + scan': round(float(stage[2]), 3),
+                            'assembly + CRC-16': round(float(stage[3]), 3)},
+        # the encoder is a handful of kernels back to back: one encode = PCM read once, frames written once; time = HIP events
+        # around all of them on the library's stream.  Per-kernel durations: profiles/r04_*_kernel_stats.csv (rocprofv3
+        # --kernel-trace --stats of the same command).
+        'roofline': {'bound': 'hbm', 'kernel': 'encode launch (all kernels of flacgpu_encode_streams; per-kernel times in profiles/)',
+                     'achieved': round(enc_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(enc_ach / 8000.0, 5),
+                     'traffic': pmc.get('encode_traffic_bytes_per_launch') if same else None,
+                     'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(enc_t, 4)},
+        'roofline_decode': {'bound': 'hbm', 'kernel': 'decode launch (all kernels of flacgpu_decode_stream_dev: index, headers, scan, parse, CRC-16, restore)',
+                            'achieved': round(dec_ach, 2), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(dec_ach / 8000.0, 5),
+                            'traffic': pmc.get('decode_traffic_bytes_per_launch') if same else None,
+                            'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(dec_t, 4)},
+    }
+    if same:
+        res['roofline']['traffic_source'] = res['roofline_decode']['traffic_source'] = 'profiles/' + pmc_name + ' (committed PMC pass of this command, not measured in this run)'
+    if same and pmc.get('encode_valu_insts_per_launch'):
+        # the ceiling these integer kernels actually run against: VALU issue (one wave-instruction per 2 cycles and SIMD,
+        # fp64 4 cycles), 1024 SIMDs at 2.4 GHz; instruction counts from the committed PMC pass of this same command
+        slots = 1024 * 2.4e9 / 2
+        res['issue_ceiling'] = {'unit': 'VALU wave-instructions/s', 'peak': slots,
+                                'encode_valu_insts_per_launch': pmc['encode_valu_insts_per_launch'],
+                                'encode_frac': round(pmc['encode_valu_insts_per_launch'] / (enc_t * 1e-3) / slots, 4),
+                                'decode_valu_insts_per_launch': pmc.get('decode_valu_insts_per_launch'),
+                                'decode_frac': (round(pmc['decode_valu_insts_per_launch'] / (dec_t * 1e-3) / slots, 4)
+                                                if pmc.get('decode_valu_insts_per_launch') else None),
+                                'source': 'profiles/' + pmc_name}
+    if h_chk:
+        # checker use of the oracle: EVERY frame the GPU wrote (of the batch: every frame of its first, middle and last stream)
+        # is the oracle's, byte for byte -- a round trip alone would also pass a wrong but decodable choice
+        import hashlib
+        from oracle import oracle as O
+        cfg, _ = O.config(level, ch, bps, sr, bs, True)
+        tc = time.perf_counter()
+        shas, nfr_chk, nbytes = [], 0, 0
+        for start, n, got in h_chk:
+            ref, sizes = O.encode_stream(cfg, pcm16[start:start + n].astype(np.int32))
+            got_sha, want_sha = hashlib.sha256(got).hexdigest(), hashlib.sha256(ref[86:]).hexdigest()
+            assert got_sha == want_sha, 'encoded stream differs from the oracle'
+            shas.append(got_sha)
+            nfr_chk += len(sizes)
+            nbytes += len(got)
+        res['checked'] = {'frames': '%d of %d frames' % (nfr_chk, nblocks),
+                          'what': 'SHA-256 of the GPU stream == SHA-256 of oracle.encode_stream over the same PCM'
+                                  + ('' if single else ' (first, middle and last stream of the batch, whole)'),
+                          'sha256': shas[0] if single else shas, 'bytes': nbytes, 'oracle_s': round(time.perf_counter() - tc, 1)}
+    return res
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    under_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if not under_launcher and args.gpus > 1:
+        # decided before anything touches a GPU: the ranks are a child process of this one
+        sys.exit(launch_ranks(args, argv))
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    workload = args.workload or ('stream16' if world == 1 else 'batch')
+    defaults = {'batch': (60.0, 5, 30), 'stream24': (300.0, 8, 100)}.get(workload, (600.0, 5, 300))
+    seconds = args.seconds if args.seconds is not None else defaults[0]
+    level = args.level if args.level is not None else defaults[1]
+    steps = args.steps if args.steps is not None else defaults[2]
+
+    from pyflac_amd import synth
+    # The CPU leg runs FIRST, before anything touches the GPU: it forks one oracle process per host core, and a forked child
+    # must not carry HIP state (torch.cuda.is_available() below initialises the device).
+    cpu_res = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == 'stream16':
+        cpu_res = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), level, 48000)
+    import torch
+    import torch.distributed as dist
+    from pyflac_amd import batch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    if local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU (local rank %d, %d visible)' % (rank, local, torch.cuda.device_count()))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    env = {'rank': rank, 'world': world, 'dev': dev}
+    ctx = batch.Context(local)
+
+    res = measure(env, ctx, workload, seconds, level, steps, args.warmup, args.streams, passes=not args.no_passes,
+                  check=world == 1 and not args.no_cpu_baseline)
+    if rank == 0:
+        if world == 1 and workload == 'stream16' and not args.no_configs and args.seconds is None and args.level is None:
+            # the other single-GPU configurations of BASELINE.json, in the same process: each with its own warm-up, bit-exactness
+            # gates (round trip; whole stream against the oracle), >= 20 timed steps and event passes
+            res['configs'] = {}
+            for wl, secs, lvl, k in (('stream24', 300.0, 8, 40), ('batch', 60.0, 5, 20)):
+                r = measure(env, ctx, wl, secs, lvl, k, 2, args.streams, passes=True, check=not args.no_cpu_baseline)
+                res['configs'][wl] = {key: r[key] for key in ('metric', 'value', 'unit', 'steps', 'ms_per_step', 'ms_per_step_min', 'encode_gpu_ms',
+                                                               'decode_gpu_ms', 'encode_stage_ms', 'config', 'checked') if key in r}
+                res['configs'][wl]['roofline'] = {k2: r['roofline'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
+                res['configs'][wl]['roofline_decode'] = {k2: r['roofline_decode'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
+        if world == 1 and not args.no_e2e and workload == 'stream16':
+            res['api_e2e'] = api_e2e(min(seconds, 600.0), 48000)
         if cpu_res is not None:
             res['cpu_baseline'] = cpu_res
             ratio = committed_profile('r02_cpu_ref_ratio.json')
@@ -444,21 +670,6 @@ def main():
                     'encode': ratio['reference_over_oracle_encode'], 'decode': ratio['reference_over_oracle_decode'],
                     'reference_encode_msamples_per_s_build_container': ratio['reference_encode_msamples_per_s'],
                     'measured_by': ratio['command'] + ' (build container; the binary does not travel): profiles/r02_cpu_ref_ratio.json'}
-        if h_chk is not None:
-            # checker use of the oracle: EVERY frame the GPU wrote (of the batch: every frame of its first stream) is the
-            # oracle's, byte for byte -- a round trip alone would also pass a wrong but decodable choice
-            import hashlib
-            from oracle import oracle as O
-            cfg, _ = O.config(args.level, ch, bps, sr, bs, True)
-            tc = time.perf_counter()
-            ref, _sizes = O.encode_stream(cfg, pcm16[:h_chk[0]].astype(np.int32))
-            assert len(_sizes) == h_chk[1]
-            got_sha, want_sha = hashlib.sha256(h_chk[2]).hexdigest(), hashlib.sha256(ref[86:]).hexdigest()
-            assert got_sha == want_sha, 'encoded stream differs from the oracle'
-            res['checked'] = {'frames': '%d of %d frames' % (h_chk[1], h_chk[1] if single else est.nblocks),
-                              'what': 'SHA-256 of the GPU stream == SHA-256 of oracle.encode_stream over the same PCM'
-                                      + ('' if single else ' (the first stream of the batch, whole)'),
-                              'sha256': got_sha, 'bytes': len(h_chk[2]), 'oracle_s': round(time.perf_counter() - tc, 1)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

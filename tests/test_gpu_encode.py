@@ -256,6 +256,32 @@ def test_batch_stream_whole_equals_oracle(ctx):
     assert int(status[:, 0].max()) == 0 and torch.equal(dec, t)
 
 
+def test_batch_128_streams_whole(ctx):
+    """configs[4] at its per-GPU size: 128 independent 60 s streams (90 112 blocks: tiled scans, the decoder's frame index over all
+    streams) in ONE launch.  The first, the middle and the last stream whole equal the oracle's streams (SHA-256), and everything
+    decodes back from the bytes alone (one decode launch over all streams)."""
+    import hashlib
+    import torch
+    from pyflac_amd import batch, synth
+    from oracle import oracle as O
+    nstreams = 128
+    streams = [synth.config5_stream(s, 60.0) for s in range(nstreams)]
+    s = batch.settings(5, 2, 16, 48000, 4096, True)
+    t = torch.from_numpy(np.concatenate(streams).astype(np.int32)).cuda()
+    out, offs, st = ctx.encode(s, t, stream_lengths=[len(x) for x in streams])
+    h = offs.cpu().numpy().astype(np.int64)
+    nfr = -(-len(streams[0]) // 4096)
+    assert st.nblocks == nstreams * nfr == 90112
+    cfg, _ = O.config(5, 2, 16, 48000, 4096, True)
+    for k in (0, nstreams // 2, nstreams - 1):
+        want, sizes = O.encode_stream(cfg, streams[k].astype(np.int32))
+        got = out[int(h[k * nfr]):int(h[(k + 1) * nfr])].cpu().numpy().tobytes()
+        assert len(sizes) == nfr and hashlib.sha256(got).hexdigest() == hashlib.sha256(want[86:]).hexdigest(), k
+    ranges = [(int(h[(k + 1) * nfr] - h[k * nfr]), nfr) for k in range(nstreams)]
+    dec, status, dst = ctx.decode_streams(out[:st.total_bytes], ranges, 2, 16, t.shape[0])
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec, t)
+
+
 # ---------------------------------------------------------------------------------------------- round-2 additions
 def test_log_guard_forced_keeps_bytes_and_counts(golden):
     """Near-tie guard of the LPC order guess (flacgpu_set_log_guard): with the threshold forced above every margin all order
