@@ -577,6 +577,8 @@ typedef struct {
     float decode_kernel_ms;
     float total_gpu_ms;
     float index_ms;               /* flacgpu_decode_stream_dev: HIP-event time of the frame index pass (part of total_gpu_ms) */
+    uint32_t plane_bits;          /* width of the residual plane between the parse and the restore kernel: 16 for streams of up to 16 bits
+                                   * (0 where no plane is used); 32 after a frame showed a value beyond 16 bits and the call was repeated */
 } flacgpu_decode_stats;
 
 /* Decode the audio frames of one FLAC stream held in device memory.  d_stream/len: the frame data (device);

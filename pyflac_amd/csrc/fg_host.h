@@ -66,10 +66,10 @@ int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const Fg
                           uint16_t *d_rparams, hipStream_t stream);
 int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                             int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                            unsigned long long *d_counters, hipStream_t stream);
+                            unsigned long long *d_counters, hipStream_t stream, int plane16);
 int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                               const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                              hipStream_t stream);
+                              hipStream_t stream, int plane16);
 int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                            int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
                            int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream);
@@ -103,6 +103,7 @@ struct WindowEntry {
 struct flacgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    uint32_t dec_p16_hold = 0;       // decode calls that still take 32-bit residual planes (a stream showed values beyond 16 bits)
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
     hipStream_t stream3 = nullptr;   // short blocks of the pipeline's packing stage
     hipEvent_t evp[2] = {nullptr, nullptr};

@@ -140,8 +140,16 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__b
 #define WP_WAVE_W (WP_ROWS_W + WP_OUT_W)
 typedef uint32_t wp_u32x4 __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte accesses at 4-byte alignment
 typedef int32_t wp_i32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t wp_u32x4h __attribute__((ext_vector_type(4), aligned(2)));      // ... at 2-byte alignment (global memory only)
 
-template <bool WIDE>
+// P16 (streams of up to 16 bits, round 4): the residual plane is 16 bits wide.  The plane of a subframe keeps its place -- byte
+// offset 4 (out_off C + ch n) of the scratch area -- and uses the first half of its space: the parser writes and the restore
+// kernel reads half the bytes (0.23 GB less traffic per launch of the headline stream).  A frame with a value that does not fit
+// -- a side channel's warm-up sample beyond 16 bits, a residual of a predictor gone wild, wide escape codes, Rice parameters of
+// 13 and more with large quotients -- ends with status 6, and the host repeats the call with 32-bit planes (decode_frames_impl;
+// it remembers the outcome for the stream).  No second attempt inside the kernel: the state it needs to start a subframe again
+// cost this kernel, which lives on exactly 64 registers, forty spilled ones.
+template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256, 8)
 fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch,
                      FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters)
@@ -174,8 +182,13 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
     uint32_t n_batches = 0, n_rounds = 0, n_hard = 0;   // (counters: tuning aid)
 
     for (uint32_t ch = 0; ch < C && !err; ch++) {
+      {
         FgDecSub *sd = &subs[(size_t)f * C + ch];
         int32_t *pl = scratch + fr.out_off * C + (u64)ch * n;
+        int16_t *const pl16 = (int16_t *)pl;
+        constexpr bool nar = P16;
+        uint32_t ovf = 0;                    // a value of this subframe does not fit 16 bits
+        auto fits = [](int32_t v) -> uint32_t { return v != (int32_t)(int16_t)v ? 1u : 0u; };
         uint32_t sb = fr.bps;
         if ((fr.ca == 1 && ch == 1) || (fr.ca == 2 && ch == 0) || (fr.ca == 3 && ch == 1)) sb++;
         const uint32_t hdr = wr_bits(rd, pos, 8);
@@ -212,15 +225,33 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
         if (mode == 0) {
             cval = wr_sbits(rd, pos, sb);
             pos += sb;
-            for (uint32_t i = lane; i < n; i += 64) pl[i] = cval;
+            if (nar) {
+                ovf |= fits(cval);
+                const uint32_t two = ((uint32_t)cval & 0xFFFFu) * 0x10001u;
+                for (uint32_t i = lane; i < n / 2; i += 64) ((uint32_t *)pl16)[i] = two;
+                if ((n & 1) && lane == 0) pl16[n - 1] = (int16_t)cval;
+            }
+            else for (uint32_t i = lane; i < n; i += 64) pl[i] = cval;
         }
         else if (mode == 1) {
-            for (uint32_t i = lane; i < n; i += 64) pl[i] = wr_sbits(rd, pos + i * sb, sb);
+            if (nar) {
+                for (uint32_t i = lane; i < (n + 1) / 2; i += 64) {
+                    const int32_t a = wr_sbits(rd, pos + 2 * i * sb, sb), b = 2 * i + 1 < n ? wr_sbits(rd, pos + (2 * i + 1) * sb, sb) : 0;
+                    ovf |= fits(a) | fits(b);
+                    if (2 * i + 1 < n) ((uint32_t *)pl16)[i] = ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+                    else pl16[2 * i] = (int16_t)a;
+                }
+            }
+            else for (uint32_t i = lane; i < n; i += 64) pl[i] = wr_sbits(rd, pos + i * sb, sb);
             pos += n * sb;
         }
         else {
             // warm-up samples: lane = sample
-            if ((uint32_t)lane < order) pl[lane] = wr_sbits(rd, pos + (uint32_t)lane * sb, sb);
+            if ((uint32_t)lane < order) {
+                const int32_t wv_ = wr_sbits(rd, pos + (uint32_t)lane * sb, sb);
+                if (nar) { pl16[lane] = (int16_t)wv_; ovf |= fits(wv_); }
+                else pl[lane] = wv_;
+            }
             pos += order * sb;
             if (t >= 32) {
                 const uint32_t ps = wr_bits(rd, pos, 9);
@@ -262,7 +293,11 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                     const uint32_t raw = wr_bits(rd, pos, 5);
                     pos += 5;
                     if (rparams && part < FG_DEC_RPARAMS && lane == 0) rparams[((size_t)f * C + ch) * FG_DEC_RPARAMS + part] = (uint16_t)(0x8000u | (raw << 8));
-                    for (uint32_t i = lane; i < R; i += 64) pl[si + i] = wr_sbits(rd, pos + i * raw, raw);
+                    for (uint32_t i = lane; i < R; i += 64) {
+                        const int32_t ev = wr_sbits(rd, pos + i * raw, raw);
+                        if (nar) { pl16[si + i] = (int16_t)ev; ovf |= fits(ev); }
+                        else pl[si + i] = ev;
+                    }
                     pos += R * raw;
                     si = pend;
                     if (pos > end_bits) err = 4;
@@ -273,8 +308,11 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                 // Residuals that fit 16 bits go through the output buffer as such (twice the codes per batch, so chunks of up to 256
                 // bits and fewer sync rounds): with k <= 12 a value outgrows 16 bits only through a quotient of 2^(16 - k) or more,
                 // and those codes take the bit-by-bit path that codes of 32 and more leading zeros take anyway.
-                const bool o16 = k <= 12;
-                const uint32_t hardlz = k == 12 ? 16u : 32u;
+                // (16-bit plane: every batch goes through the buffer as 16-bit values)
+                // (with k > 12 a value fits 16 bits while its quotient stays below 2^(16 - k): the test that sends long codes to the bit-by-bit
+                // path finds the others, and such a subframe takes the 32-bit form)
+                const bool o16 = nar || k <= 12;
+                const uint32_t hardlz = k < 12 ? 32u : ((nar || k == 12) ? (k >= 16 ? 0u : 1u << (16 - k)) : 32u);
                 const uint32_t outcap = o16 ? 2u * WP_OUT_W : WP_OUT_W;
                 while (R > 0) {
                     n_batches++;
@@ -356,7 +394,18 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                         const uint32_t nout = hmin < lim ? hmin : lim;
                         int32_t *const dst = pl + si;
                         wave_lds_fence();
-                        if (o16) {
+                        if (nar) {
+                            // the buffer's halfwords are the plane's: eight samples a lane and store.  A batch may start at an odd sample
+                            // (an odd predictor order, a code read bit by bit in front of it): the stores are then 2-byte aligned 16-byte
+                            // stores, which global memory takes (the compiler emits them as such: unaligned access mode)
+                            int16_t *const d16 = pl16 + si;
+                            const int16_t *const oh = (const int16_t *)outb;
+                            for (uint32_t j = 8u * (uint32_t)lane; j < nout; j += 512) {
+                                if (j + 8 <= nout) *(wp_u32x4h *)(d16 + j) = *(const wp_u32x4 *)(oh + j);
+                                else for (uint32_t e = j; e < nout; e++) d16[e] = oh[e];
+                            }
+                        }
+                        else if (o16) {
                             const uint2 *const o2 = (const uint2 *)outb;
                             for (uint32_t j = 4u * (uint32_t)lane; j < nout; j += 256) {
                                 const uint2 w = o2[j >> 2];
@@ -375,6 +424,7 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                         }
                     }
                     if (hmin < lim) {
+                        if (nar && k > 12) { err = 6; break; }       // (a value beyond 16 bits: the call is repeated with 32-bit planes)
                         // a code with too many leading zeros for the window (or the 16-bit buffer): everything in front of it stands;
                         // read it bit by bit, resume behind it
                         n_hard++;
@@ -391,7 +441,11 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                         if (!found) { err = 4; break; }
                         const uint32_t rem = wr_bits(rd, hp, k);
                         hp += k;
-                        if (lane == 0) pl[si + hmin] = unzig((z << k) | rem);
+                        {
+                            const int32_t hv = unzig((z << k) | rem);
+                            if (nar) { if (lane == 0) pl16[si + hmin] = (int16_t)hv; ovf |= fits(hv); }
+                            else if (lane == 0) pl[si + hmin] = hv;
+                        }
                         si += hmin + 1; R -= hmin + 1; pos = hp;
                     }
                     else if (total >= Rb) {
@@ -421,6 +475,7 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
             if (err) break;
         }
         // what FLAC__Frame.subframes[] reports (fg_types.h FgDecSub): type, coefficient precision, partition order, method
+        if (nar && !err && __any(ovf != 0)) { err = 6; break; }      // (the call is repeated with 32-bit planes)
         if (lane == 0) {
             const uint32_t stype = mode == 0 ? 0u : mode == 1 ? 1u : (t >= 32 ? 3u : 2u);
             sd->order = order; sd->shift = shift; sd->wasted = wasted;
@@ -428,6 +483,7 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
             if (mode == 0) sd->q[0] = cval;
         }
         if (pos > end_bits) err = 4;
+      }
     }
     if (!err) {
         const uint32_t endb = (pos + 7) & ~7u;
@@ -656,13 +712,190 @@ __device__ __forceinline__ void wr_tile(int32_t (&h)[16], const int32_t (&q)[16]
     }
 }
 
-template <bool WIDE>
+// ---- 16-bit residual tiles (P16).  Row r of an input tile = 64 halfwords = 32 words; the eight-sample group g (16 bytes) of row r
+// sits at slot g ^ (r & 7): the eight lanes of one LDS access cycle -- eight different rows, same g -- then cover all 64 banks
+// (rows 128 bytes apart alternate between the two halves of the banks, the slot picks the place inside a half).  The samples leave
+// the recurrence as 32-bit values in a tile of the usual form (wr_goff), which the writers read.
+#define WR_IN16_W (64 * 32)
+__device__ __forceinline__ uint32_t wr16_goff(uint32_t g8, uint32_t xr8) { return (g8 << 4) ^ xr8; }      // xr8 = (row & 7) << 4
+__device__ __forceinline__ void wr16_unpack(const uint4 t, int32_t (&r)[8])
+{
+    r[0] = (int32_t)(t.x << 16) >> 16; r[1] = (int32_t)t.x >> 16; r[2] = (int32_t)(t.y << 16) >> 16; r[3] = (int32_t)t.y >> 16;
+    r[4] = (int32_t)(t.z << 16) >> 16; r[5] = (int32_t)t.z >> 16; r[6] = (int32_t)(t.w << 16) >> 16; r[7] = (int32_t)t.w >> 16;
+}
+// wr_group8_asm with the residuals packed two to a register: the add that turns a residual into its sample takes its halfword
+// through SDWA (sign-extended), so the narrower plane costs the recurrence -- the one serial chain of the decoder -- nothing.
+__device__ __forceinline__ void wr16_group8_asm(const int32_t (&h)[16], const int32_t (&q)[16], int shift, const uint4 p, int32_t (&n)[8])
+{
+    int32_t t;
+#define WR16_ADD(ni, pj, half) "v_add_u32_sdwa %[" #ni "], sext(%[" #pj "]), %[t] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_" #half " src1_sel:DWORD\n"
+    asm volatile("v_mul_i32_i24 %[t], %[q7], %[h0]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[h7], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n0, p0, 0)
+                 "v_mul_i32_i24 %[t], %[q7], %[h1]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n0], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n1, p0, 1)
+                 "v_mul_i32_i24 %[t], %[q7], %[h2]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n1], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n2, p1, 0)
+                 "v_mul_i32_i24 %[t], %[q7], %[h3]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n2], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n3, p1, 1)
+                 "v_mul_i32_i24 %[t], %[q7], %[h4]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n3], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n4, p2, 0)
+                 "v_mul_i32_i24 %[t], %[q7], %[h5]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h6], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n4], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n5, p2, 1)
+                 "v_mul_i32_i24 %[t], %[q7], %[h6]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[h7], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n5], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n6, p3, 0)
+                 "v_mul_i32_i24 %[t], %[q7], %[h7]\n"
+                 "v_mad_i32_i24 %[t], %[q6], %[n0], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q5], %[n1], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q4], %[n2], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q3], %[n3], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q2], %[n4], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q1], %[n5], %[t]\n"
+                 "v_mad_i32_i24 %[t], %[q0], %[n6], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n7, p3, 1)
+                 : [t] "=&v"(t), [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3]), [n4] "=&v"(n[4]), [n5] "=&v"(n[5]),
+                   [n6] "=&v"(n[6]), [n7] "=&v"(n[7])
+                 : [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [q3] "v"(q[3]), [q4] "v"(q[4]), [q5] "v"(q[5]), [q6] "v"(q[6]), [q7] "v"(q[7]),
+                   [sh] "v"(shift), [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]),
+                   [h6] "v"(h[6]), [h7] "v"(h[7]), [p0] "v"(p.x), [p1] "v"(p.y), [p2] "v"(p.z), [p3] "v"(p.w));
+#undef WR16_ADD
+}
+
+// MAXO samples from sample index i0 of the tile (a multiple of MAXO): residuals from the 16-bit row, samples to the 32-bit row
+template <int MAXO, bool GATE>
+__device__ __forceinline__ void wr16_group(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, uint32_t i0, const char *rin,
+                                           char *rout, uint32_t xr8, uint32_t xr)
+{
+    constexpr int TAPS = MAXO == 16 ? 12 : MAXO;
+    int32_t r[MAXO];
+    if constexpr (MAXO == 4) {
+        const uint2 t = *(const uint2 *)(rin + wr16_goff(i0 >> 3, xr8) + ((i0 & 4) ? 8u : 0u));
+        r[0] = (int32_t)(t.x << 16) >> 16; r[1] = (int32_t)t.x >> 16; r[2] = (int32_t)(t.y << 16) >> 16; r[3] = (int32_t)t.y >> 16;
+    }
+    else {
+#pragma unroll
+        for (int u = 0; u < MAXO; u += 8) {
+            int32_t r8[8];
+            wr16_unpack(*(const uint4 *)(rin + wr16_goff((i0 + u) >> 3, xr8)), r8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) r[u + e] = r8[e];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u++) {
+        int32_t sum = 0;
+#pragma unroll
+        for (int j = TAPS - 1; j >= 0; j--) sum += __mul24(q[j], h[(u - 1 - j + 2 * MAXO) % MAXO]);
+        int32_t v = r[u] + (sum >> shift);
+        if (GATE) v = (i0 + (uint32_t)u >= order) ? v : r[u];
+        h[u] = v;
+        r[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXO; u += 4)
+        *(uint4 *)(rout + wr_goff((i0 + u) >> 2, xr)) = make_uint4((uint32_t)r[u], (uint32_t)r[u + 1], (uint32_t)r[u + 2], (uint32_t)r[u + 3]);
+}
+
+template <int MAXO>
+__device__ __forceinline__ void wr16_tile(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, bool first, const char *rin, char *rout,
+                                          uint32_t xr8, uint32_t xr)
+{
+    if (first) {
+        // (the warm-up samples, at most 12, lie in the first 16)
+#pragma unroll
+        for (int g = 0; g < 16 / MAXO; g++) wr16_group<MAXO, true>(h, q, shift, order, g * MAXO, rin, rout, xr8, xr);
+#pragma unroll
+        for (int g = 16 / MAXO; g < WR_TS / MAXO; g++) wr16_group<MAXO, false>(h, q, shift, order, g * MAXO, rin, rout, xr8, xr);
+    }
+    else if constexpr (MAXO == 8) {
+        // the residuals of group g + 1 are requested before group g is computed (one 16-byte read a group)
+        uint4 ra = *(const uint4 *)(rin + wr16_goff(0, xr8));
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            uint4 na = ra;
+            if (g < 7) na = *(const uint4 *)(rin + wr16_goff(g + 1, xr8));
+            int32_t n8[8];
+            wr16_group8_asm(h, q, shift, ra, n8);
+#pragma unroll
+            for (int u = 0; u < 8; u++) h[u] = n8[u];
+            *(uint4 *)(rout + wr_goff(2 * g, xr)) = make_uint4((uint32_t)n8[0], (uint32_t)n8[1], (uint32_t)n8[2], (uint32_t)n8[3]);
+            *(uint4 *)(rout + wr_goff(2 * g + 1, xr)) = make_uint4((uint32_t)n8[4], (uint32_t)n8[5], (uint32_t)n8[6], (uint32_t)n8[7]);
+            ra = na;
+        }
+    }
+    else {
+#pragma unroll
+        for (int g = 0; g < WR_TS / MAXO; g++) wr16_group<MAXO, false>(h, q, shift, order, g * MAXO, rin, rout, xr8, xr);
+    }
+}
+
+template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256)
 fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
                        int32_t *out, FgDecResult *results, uint32_t interleave)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
     uint32_t *const tiles = wsm;                                   // WR_NB x 64 rows x 64 words
+    // (P16: three tiles of 16-bit residuals -- two landing, one being computed -- and two tiles of samples -- one being computed,
+    // one being written out: 56 KB)
+    uint32_t *const in16 = wsm;                                    // 3 x WR_IN16_W
+    uint32_t *const otile = wsm + 3 * WR_IN16_W;                   // 2 x WR_TILE_W
     uint32_t *const fa = wsm + WR_NB * WR_TILE_W;                  // 64 x WR_FA: n_in, n_out, plane lo/hi, out_off lo/hi, ca, wasted, n
     uint32_t *const ctl = fa + 64 * WR_FA;                         // [0] nmax, [1] all planes 16-byte aligned, [2] stereo fast output
     const int lane = threadIdx.x & 63;
@@ -723,12 +956,27 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     }
     const uint32_t nmax = ctl[0];
     const bool stereo_fast = ctl[2] != 0;
+    constexpr bool narrow = P16;
     const uint32_t T = (nmax + WR_TS - 1) / WR_TS;
     const uint32_t S = T + 1;                  // steps (barriers) of every wave
 
     if (wave == 0) {
         const bool big = __any(order > 8), small = !__any(order > 4);
         const uint32_t xr = ((uint32_t)lane & 15) << 4;
+        if (P16 && narrow) {
+            const uint32_t xr8 = ((uint32_t)lane & 7) << 4;
+            for (uint32_t s = 1; s <= S; s++) {
+                __syncthreads();
+                if (s > T) continue;
+                const uint32_t t = s - 1;
+                const char *rin = (const char *)(in16 + (t % 3) * WR_IN16_W + (uint32_t)lane * 32);
+                char *rout = (char *)(otile + (t & 1) * WR_TILE_W + (uint32_t)lane * WR_TS);
+                if (big) wr16_tile<16>(h, q, shift, order, t == 0, rin, rout, xr8, xr);
+                else if (small) wr16_tile<4>(h, q, shift, order, t == 0, rin, rout, xr8, xr);
+                else wr16_tile<8>(h, q, shift, order, t == 0, rin, rout, xr8, xr);
+            }
+            return;
+        }
         for (uint32_t s = 1; s <= S; s++) {
             __syncthreads();
             if (s > T || (interleave & 0x200)) continue;
@@ -741,6 +989,41 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         return;
     }
 
+    if (P16 && wave == 1) {
+        {
+            // ---- loader of 16-bit tiles: instruction k of a tile fills rows 8k .. 8k + 7 (128 bytes each): lane L writes slot L & 7 of
+            // row 8k + (L >> 3), i.e. it fetches the eight-sample group (L & 7) ^ (row & 7).  Eight instructions a tile, two tiles in flight.
+            u64 rbase[8];
+            uint32_t rlen[8], rcol[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t row = 8u * (uint32_t)k + ((uint32_t)lane >> 3);
+                const uint32_t *fm = fa + row * WR_FA;
+                rbase[k] = ((u64)fm[3] << 32) | fm[2];
+                rlen[k] = fm[0];
+                rcol[k] = ((((uint32_t)lane & 7) ^ (row & 7)) << 3);
+            }
+            auto issue = [&](uint32_t t) __attribute__((always_inline)) {
+                uint32_t *tb = in16 + (t % 3) * WR_IN16_W;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t c0 = t * WR_TS + rcol[k];
+                    const int16_t *src = (t < T && c0 < rlen[k]) ? (const int16_t *)(scratch + rbase[k]) + c0 : (const int16_t *)scratch;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(tb + 8 * k * 32), 16, 0, 0);
+                }
+            };
+            issue(0); issue(1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            for (uint32_t s = 1; s <= S; s++) {
+                asm volatile("s_barrier" ::: "memory");
+                issue(s + 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+    }
     if (wave == 1) {
         // ---- loader.  Instruction k of a tile fills rows 4k .. 4k + 3: lane L writes slot L & 15 of row 4k + (L >> 4), i.e. it
         // fetches group (L & 15) ^ (row & 15).  Lanes behind the end of their row (and all lanes past the last tile) fetch from
@@ -791,7 +1074,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         w_oo[k] = ((u64)fm[5] << 32) | fm[4];
     }
     auto writeout = [&](uint32_t t) __attribute__((always_inline)) {
-        const uint32_t *tb = tiles + (t % WR_NB) * WR_TILE_W;
+        const uint32_t *tb = (P16 && narrow) ? otile + (t & 1) * WR_TILE_W : tiles + (t % WR_NB) * WR_TILE_W;
         const uint32_t i0 = t * WR_TS;
         if (stereo_fast) {
             // task = (frame pair of rows, group): 32 x 16, four per lane -- always the same four frames, whose facts sit in registers
@@ -896,19 +1179,20 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
 // Same contract as fg_launch_decode_fast (flac_dec_fast.hip): residual plane, subframe records, parse status.
 extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                                        int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                                       unsigned long long *d_counters, hipStream_t stream)
+                                       unsigned long long *d_counters, hipStream_t stream, int plane16)
 {
     if (nframes == 0) return 0;
     const dim3 grid((nframes + 3) / 4);
-    if (wide) hipLaunchKernelGGL(fg_dec_wparse_kernel<true>, grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
-    else hipLaunchKernelGGL(fg_dec_wparse_kernel<false>, grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
+    if (wide) hipLaunchKernelGGL((fg_dec_wparse_kernel<true, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
+    else if (plane16) hipLaunchKernelGGL((fg_dec_wparse_kernel<false, true>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
+    else hipLaunchKernelGGL((fg_dec_wparse_kernel<false, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
     return (int)hipGetLastError();
 }
 
 // Same contract as fg_launch_decode_finish (flac_dec_fast.hip), without the profile words.
 extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                                          const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                                         hipStream_t stream)
+                                         hipStream_t stream, int plane16)
 {
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
@@ -917,9 +1201,11 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     const uint32_t G = 64 / C;
     const dim3 grid((nframes + G - 1) / G);
     const size_t lds = ((size_t)WR_NB * WR_TILE_W + 64 * WR_FA + 8) * 4;
-    const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true> : (const void *)fg_dec_wrestore_kernel<false>;
+    const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true, false>
+                          : (plane16 ? (const void *)fg_dec_wrestore_kernel<false, true> : (const void *)fg_dec_wrestore_kernel<false, false>);
     if (fg_func_set_lds(fn, lds) != 0) return -1;
-    if (wide) hipLaunchKernelGGL(fg_dec_wrestore_kernel<true>, grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
-    else hipLaunchKernelGGL(fg_dec_wrestore_kernel<false>, grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
+    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
+    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
+    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
     return (int)hipGetLastError();
 }

@@ -516,6 +516,13 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // pass lives on the wave slots the parser leaves and ends some 12 us after it --: it ignores the verdict, and
     // fg_dec_fix_kernel merges it behind both.  0.363 -> 0.348 ms per decode launch.  Mode 0: the restore kernel waits and merges.)
     const bool crc_join_late = crc_late_mode == 2 && wave_parse && !old_restore && !fused;
+    // 16-bit residual plane between the wave parser and its restore kernel (streams of up to 16 bits; flac_dec_wave.hip P16).  Not
+    // when the planes themselves are handed out (subframe detail: FLAC__Frame.subframes[].residual) or read by the warm-up kernel.
+    static const bool p16_off = getenv("FLACGPU_DEC_P16") && atoi(getenv("FLACGPU_DEC_P16")) == 0;
+    // A frame with a value beyond 16 bits ends the parse with status 6: the call is repeated with 32-bit planes, and so are the
+    // next calls of this context (a stream that does it once does it again: full-scale noise, a side channel at full scale).
+    const int plane16 = (!wide && wave_parse && !old_restore && !fused && !detail && !p16_off && c->dec_p16_hold == 0) ? 1 : 0;
+    if (c->dec_p16_hold) c->dec_p16_hold--;
     bool forked = false;
     if (!crc_late) {
         forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
@@ -549,7 +556,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             unsigned long long *d_cnt = nullptr;
             if (wave_parse >= 2 && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
             if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                                        (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream) != 0) {
+                                        (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (d_cnt) {
@@ -566,7 +573,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (wave_parse && !old_restore && !crc_late) {
             const bool late = crc_join_late && forked;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream) != 0) {
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream, plane16) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (late) {
@@ -583,7 +590,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                      (const uint16_t *)c->crctab.p, fk ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
             if (fk && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream) != 0) {
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream, plane16) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (fk) {
@@ -639,6 +646,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         detail->planes.resize((size_t)tot[0] * C);
         if (!HIPOK(hipMemcpy(detail->planes.data(), c->dec_scratch.p, detail->planes.size() * 4, hipMemcpyDeviceToHost))) return false;
     }
+    if (plane16) {
+        bool wide_values = false;
+        for (uint32_t i = 0; i < nframes; i++) if (res[i].err == 6) { wide_values = true; break; }
+        if (wide_values) {
+            c->dec_p16_hold = 256;
+            return decode_frames_impl(c, d_stream, len, h_offsets, nframes, channels_hint, bps_hint, d_pcm, cap_samples, interleave, h_status, h_frames, st,
+                                      offsets_on_device, first_number, d_offsets_out, detail, status_capacity, h_ranges, nranges);
+        }
+    }
     {
         // frames outside the register-resident decoder's envelope (predictor order > 12, ...) go through the generic kernel
         std::vector<uint32_t> redo;
@@ -678,6 +694,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     uint32_t bad = 0;
     for (uint32_t i = 0; i < nframes; i++) if (res[i].err) bad++;
     st->error_frames = bad;
+    st->plane_bits = (wave_parse && !old_restore && !fused) ? (plane16 ? 16u : 32u) : 0u;
     if (index_here && bad == nframes && ((unsigned long long *)((char *)c->h_res + 32))[2]) {
         // nothing was found under the fixed-block-size sync code, but headers with the variable-block-size one were
         fg_set_error("variable block size stream: use flacgpu_index_frames"); return false;

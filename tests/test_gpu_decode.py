@@ -381,3 +381,57 @@ def test_count_mode_with_frames_shorter_than_any_guess(ctx):
                                               None, C.byref(st2))
     assert rc == 0 and st2.nframes == 400
     assert (rows[:3, 0] == 0).all() and (rows[3:] == 0xAAAAAAAA).all()
+
+
+class TestResidualPlaneWidth:
+    """Round 4: for streams of up to 16 bits the residual plane between the wave parser and the restore kernel is 16 bits wide
+    (flac_dec_wave.hip P16; flacgpu_decode_stats.plane_bits).  A frame with a value beyond 16 bits -- a side channel at full scale,
+    residuals of loud noise under Rice parameters of 13 and more -- ends the parse with status 6, the call is repeated with 32-bit
+    planes and the context keeps them for its next calls.  Same samples either way."""
+
+    @staticmethod
+    def roundtrip(pcm16, level=5):
+        import torch
+        from pyflac_amd import batch
+        ctx = batch.Context(0)            # (a context of its own: the hold-off of one case must not reach the next)
+        s = batch.settings(level, 2, 16, 48000, 4096, True)
+        t = torch.from_numpy(pcm16.astype(np.int32)).cuda()
+        out, offs, est = ctx.encode(s, t)
+        dec, status, dst = ctx.decode_stream(out[:est.total_bytes], 2, 16, t.shape[0], nframes=est.nblocks)
+        assert int(status[:, 0].max()) == 0 and torch.equal(dec, t)
+        dec2, status2, dst2 = ctx.decode_stream(out[:est.total_bytes], 2, 16, t.shape[0], nframes=est.nblocks)
+        assert int(status2[:, 0].max()) == 0 and torch.equal(dec2, t)
+        return dst.plane_bits, dst2.plane_bits
+
+    def test_ordinary_material_keeps_the_16_bit_plane(self):
+        from pyflac_amd import synth
+        assert self.roundtrip(synth.config2_stereo16(2.0, 3)) == (16, 16)
+        assert self.roundtrip(synth.config2_hard16(2.0, 7), level=8) == (16, 16)
+
+    def test_side_channel_at_full_scale_takes_32_bit_planes(self):
+        """R = -L - 1 near full scale: mid is constant and the side channel 2 L + 1 -- odd, so no wasted bit takes its 17th bit away."""
+        r = np.random.default_rng(5)
+        left = (r.integers(-32000, 32000, 48000)).astype(np.int32)
+        pcm = np.stack([left, -left - 1], axis=1).astype(np.int16)
+        assert self.roundtrip(pcm) == (32, 32)
+
+    def test_full_scale_noise_takes_32_bit_planes(self):
+        """Uniform noise over the whole 16-bit range, channels independent: Rice parameters of 13 and 14, verbatim subframes."""
+        r = np.random.default_rng(6)
+        pcm = r.integers(-32768, 32768, (60000, 2)).astype(np.int16)
+        bits = self.roundtrip(pcm)
+        assert bits[1] == bits[0] and bits[0] in (16, 32)          # (whatever the material needs; the samples are checked above)
+
+    def test_odd_block_sizes_and_orders_with_the_16_bit_plane(self):
+        """Batches that start at odd samples (odd predictor orders, odd block sizes): 2-byte aligned 16-byte stores."""
+        import torch
+        from pyflac_amd import batch, synth
+        ctx = batch.Context(0)
+        pcm = synth.config2_stereo16(1.5, 11)
+        for level, bs in ((3, 1153), (5, 4095), (8, 2047), (2, 777)):
+            s = batch.settings(level, 2, 16, 48000, bs, False)
+            t = torch.from_numpy(pcm.astype(np.int32)).cuda()
+            out, offs, est = ctx.encode(s, t)
+            dec, status, dst = ctx.decode_stream(out[:est.total_bytes], 2, 16, t.shape[0], nframes=est.nblocks)
+            assert int(status[:, 0].max()) == 0 and torch.equal(dec, t), (level, bs)
+            assert dst.plane_bits == 16

@@ -10,7 +10,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 WORK=${4:-stream16}
 EXTRA=${5:-}
-CMD="python3 bench.py --workload $WORK --seconds $SECS --steps 5 --warmup 1 --level $LEVEL --no-cpu-baseline --no-e2e $EXTRA"
+CMD="python3 bench.py --workload $WORK --seconds $SECS --steps 5 --warmup 1 --level $LEVEL --no-cpu-baseline --no-e2e --no-configs $EXTRA"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/bench_pmc1.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM -d $OUT/pmc2 -o pmc2 -- $CMD > $OUT/bench_pmc2.log 2>&1

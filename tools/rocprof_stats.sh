@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/stats_$1
 mkdir -p $OUT
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o p -- python3 bench.py --seconds ${2:-600} --steps 5 --warmup 2 --no-cpu-baseline > $OUT/log.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o p -- python3 bench.py --seconds ${2:-600} --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-configs --no-passes > $OUT/log.txt 2>&1
 tail -1 $OUT/log.txt | cut -c1-400
 f=$(find $OUT -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'EOF'
