@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libflacgpu.so')
+# (FLACGPU_LIBRARY: another build of the same library -- tools/ab.sh compares two builds on one GPU box this way)
+LIB_PATH = os.environ.get('FLACGPU_LIBRARY') or os.path.join(_HERE, 'libflacgpu.so')
 
 
 class StreamInfo(C.Structure):
