@@ -170,6 +170,8 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&c->gstream[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->gev_join[i], hipEventDisableTiming)); }
+    HIPCHK(hipEventCreateWithFlags(&c->gev_fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->evs[i]));
@@ -212,6 +214,8 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     for (int i = 0; i < 8; i++) if (c->evs[i]) (void)hipEventDestroy(c->evs[i]);
     for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     for (int i = 0; i < 2; i++) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
+    for (int i = 0; i < 3; i++) { if (c->gev_join[i]) (void)hipEventDestroy(c->gev_join[i]); if (c->gstream[i]) (void)hipStreamDestroy(c->gstream[i]); }
+    if (c->gev_fork) (void)hipEventDestroy(c->gev_fork);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -475,6 +479,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     PL.slots = (uint8_t *)c->slots.p; PL.results = (FgBlockResult *)c->results.p; PL.dbg = dbg;
     PL.chunk_cap_words = chunk_cap_words; PL.fbw_words = fbw_words; PL.acc64 = s->bits_per_sample > 16 ? 1 : 0;
     PL.stream = (void *)c->stream; PL.stream2 = (void *)c->stream3; PL.ev_fork = (void *)c->evp[0]; PL.ev_join = (void *)c->evp[1];
+    for (int i = 0; i < 3; i++) { PL.gstream[i] = (void *)c->gstream[i]; PL.gev_join[i] = (void *)c->gev_join[i]; }
+    PL.gev_fork = (void *)c->gev_fork;
     // the block list goes to the device once per distinct layout (repeated calls with the same streams skip the copy)
     auto upload_descs = [&](const std::vector<FgBlockDesc> &v, bool cache) -> bool {
         const size_t bytes = v.size() * sizeof(FgBlockDesc);
@@ -603,7 +609,12 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         }
         else {
             PL.stages = 3;
+            // (groups: flac_enc_pipe_impl.h / pipe_shape.inc; a launch of a few hundred blocks does not fill the chip once)
+            static const int groups_env = getenv("FLACGPU_GROUPS") ? atoi(getenv("FLACGPU_GROUPS")) : 0;
+            PL.ngroups = groups_env > 0 ? (uint32_t)groups_env : (nfast >= 4096 ? 2u : 1u);
+            if (c->debug) PL.ngroups = 1;
             if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
+            PL.ngroups = 1;
         }
         piped = true;
     }

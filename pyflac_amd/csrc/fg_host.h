@@ -107,6 +107,8 @@ struct flacgpu_ctx {
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
     hipStream_t stream3 = nullptr;   // short blocks of the pipeline's packing stage
     hipEvent_t evp[2] = {nullptr, nullptr};
+    hipStream_t gstream[3] = {nullptr, nullptr, nullptr};      // the encoder pipeline's groups 1..3 (FgPipeLaunch.ngroups)
+    hipEvent_t gev_fork = nullptr, gev_join[3] = {nullptr, nullptr, nullptr};
     hipEvent_t evx[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing

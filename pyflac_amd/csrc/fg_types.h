@@ -117,6 +117,13 @@ struct FgPipeLaunch {
     void *stream;               // hipStream_t
     void *stream2;              // side stream for the (few) blocks packed by one wave per subframe; events to fork and join
     void *ev_fork, *ev_join;
+    // Round 4: the blocks of a launch are cut into `ngroups` contiguous groups, each with its own chain autocorrelation ->
+    // Levinson-Durbin -> evaluation -> packing on its own stream (group 0 on `stream`): the kernels of different stages then
+    // run beside each other where their ends and starts meet, and nobody's last, half-empty round of workgroups leaves the chip idle
+    // (two groups: 0.485 -> 0.474 ms on the headline stream; more groups lose to their synchronisation, pipe_shape.inc).
+    uint32_t ngroups;           // 0, 1: one chain on `stream`
+    void *gstream[3];           // streams of groups 1..3
+    void *gev_fork, *gev_join[3];
 };
 
 // ---- decoder ----

@@ -166,6 +166,16 @@ FGI double p_ebps(double e, double scale)
     return 0.0;
 }
 
+// ================================================================================================ K1: start of a launch
+// The device stamp of the call and the counters the later kernels add to: near-tie guard of the LPC order guess (count 0,
+// smallest margin +infinity) and the OR of the error flags of the pipeline's blocks.  A kernel of its own since the groups of
+// a launch run on several streams (FgPipeLaunch.ngroups): everything that touches the counters is ordered behind it.
+__global__ void fg_pipe_begin_kernel(FgPipeBufs B)
+{
+    if (B.stamp) B.stamp[0] = wall_clock64();
+    if (B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }
+}
+
 // ================================================================================================ K2: autocorrelation + OR
 // (<= 80 SGPRs: above that the scalar file allows only 7 waves per SIMD, 7168 on the chip -- the 7032 blocks of the headline
 // stream would then only fit with a perfectly even spread over the CUs, and the stragglers would double the kernel's time)
@@ -175,17 +185,12 @@ FGI double p_ebps(double e, double scale)
 template <bool MS, int NCH, int MAXO>
 __global__ void __launch_bounds__(64 * FGP_AWPB, 8) __attribute__((amdgpu_num_sgpr(72)))
 fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, FgPipeBufs B, FgDebugRec *dbg,
-                     uint32_t nblocks, uint32_t lds_per_wave)
+                     uint32_t nblocks, uint32_t lds_per_wave, uint32_t bi0)
 {
     constexpr int NC = MS ? 4 : NCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wv = rfl(threadIdx.x >> 6);
-    const uint32_t bi = blockIdx.x * FGP_AWPB + wv;
-    // near-tie guard of the LPC order guess (Levinson-Durbin kernel, next launch): count 0, smallest margin +infinity
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (B.stamp) B.stamp[0] = wall_clock64();
-        if (B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }     // ([2]: OR of the error flags of the pipeline's blocks)
-    }
+    const uint32_t bi = bi0 + blockIdx.x * FGP_AWPB + wv;           // (blocks [bi0, nblocks) of the list: one group of the launch)
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
     const int lane = threadIdx.x & 63;
@@ -553,10 +558,11 @@ FGI double p_ebps_cr(double e, double scale)
 // same order as lpc.c (the file is compiled with -ffp-contract=off), so the same doubles.
 template <int MAXO>
 __global__ void __launch_bounds__(64)
-fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint32_t nblocks, uint32_t NC, uint32_t ms, double guard_thr)
+fg_pipe_levinson_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint32_t nblocks, uint32_t NC, uint32_t ms, double guard_thr,
+                        uint32_t bi0)
 {
-    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
     const uint32_t per = NC * P.nvec;
+    const uint32_t idx = bi0 * per + blockIdx.x * 64 + threadIdx.x;     // (blocks [bi0, nblocks))
     if (idx >= nblocks * per) return;
     const uint32_t bi = idx / per, r_ = idx % per, c = r_ / P.nvec, v = r_ % P.nvec;
     const uint32_t n = descs[bi].n;
