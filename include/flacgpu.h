@@ -560,6 +560,12 @@ void flacgpu_set_log_guard(flacgpu_ctx *ctx, double threshold_bits);
 /* Window self-check: empty string, or a note that this host's cosf produced a tukey taper different from the committed one
  * (the committed one is then used; the note is also left in flacgpu_last_error() when it happens). */
 const char *flacgpu_window_note(flacgpu_ctx *ctx);
+/* Start-up self-check of the encoder's matrix-core autocorrelation (run by flacgpu_ctx_create): the number of
+ * v_mfma_f64_4x4x4_4b_f64 results that differed from the chain of v_fma_f64 the bit-exactness of stage L6 rests on; 0 on
+ * a device that behaves like the MI355X this was written on.  Non-zero: every block is encoded by the generic kernel (same bytes,
+ * slower), *note says so.  flacgpu_force_selfcheck_result overrides the outcome (tests of that fallback). */
+int flacgpu_selfcheck(flacgpu_ctx *ctx, const char **note);
+void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad);
 /* What the batch calls time, and how they end.  level 0 (default): no HIP events (each record idles the GPU for a few
  * microseconds between two kernels); the call ends with a kernel that writes totals and wall-clock stamps into pinned memory,
  * which the host polls; total_gpu_ms comes from the stamps, the *_kernel_ms / index_ms / stage_ms fields stay 0.

@@ -128,7 +128,7 @@ bool flacgpu_ctx::sync_windows()
 // ------------------------------------------------------------------ context
 hipError_t fg_stream_wait(hipStream_t stream)
 {
-    static const long spin_us = getenv("FLACGPU_SPIN_US") ? atol(getenv("FLACGPU_SPIN_US")) : 3000;
+    static const long spin_us = fg_tune("FLACGPU_SPIN_US") ? atol(fg_tune("FLACGPU_SPIN_US")) : 3000;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
@@ -142,7 +142,7 @@ hipError_t fg_stream_wait(hipStream_t stream)
 
 bool flacgpu_ctx::wait_signal(unsigned long long seq)
 {
-    static const long spin_us = getenv("FLACGPU_SPIN_US") ? atol(getenv("FLACGPU_SPIN_US")) : 3000;
+    static const long spin_us = fg_tune("FLACGPU_SPIN_US") ? atol(fg_tune("FLACGPU_SPIN_US")) : 3000;
     volatile unsigned long long *flag = h_sig;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -186,6 +186,15 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     if (!c->crctab.ensure(2048 * sizeof(uint16_t))) return false;
     if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
     HIPCHK(hipStreamSynchronize(c->stream));
+    // The encoder pipeline's autocorrelation runs its fp64 chains on the matrix core and is bit-exact only while that instruction
+    // sums in v_fma_f64's order (flac_enc_pipe.hip fg_mfma_selfcheck): checked here, once per context.  A device that does it
+    // differently keeps the byte-exact output -- every block then takes the generic kernel, whose chains are v_fma_f64 -- and says so.
+    c->mfma_bad = fg_mfma_selfcheck(c->stream);
+    if (c->mfma_bad != 0) {
+        c->selfcheck_note = c->mfma_bad < 0 ? "matrix-core self-check could not run; the encoder uses its generic kernel"
+                                            : "v_mfma_f64_4x4x4_4b_f64 does not sum like a v_fma_f64 chain on this device; the encoder uses its generic kernel";
+        fg_set_error(c->selfcheck_note);
+    }
     return true;
 }
 
@@ -316,7 +325,7 @@ void fg_fill_params(const flacgpu_settings &s, uint32_t max_n, bool pcm_i16, boo
     P->nvec = nvec;
     P->pcm_i16 = pcm_i16 ? 1 : 0;
     P->debug = debug ? 1 : 0;
-    if (getenv("FLACGPU_STOP")) P->debug = 100 + atoi(getenv("FLACGPU_STOP"));
+    if (fg_tune("FLACGPU_STOP")) P->debug = 100 + atoi(fg_tune("FLACGPU_STOP"));
     const uint32_t mo = s.max_lpc_order ? s.max_lpc_order : 1;
     uint32_t dbuf = 4 * (FG_DH + FG_DK) * 8;
     const uint32_t lev = FG_MAX_CAND * nvec * mo * 12 + 64;
@@ -336,6 +345,17 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
 extern "C" const char *flacgpu_window_note(flacgpu_ctx *ctx) { return ctx->window_note.c_str(); }
+extern "C" int flacgpu_selfcheck(flacgpu_ctx *ctx, const char **note)
+{
+    if (note) *note = ctx->selfcheck_note.c_str();
+    return ctx->mfma_bad;
+}
+extern "C" void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad)
+{
+    ctx->mfma_bad = mfma_bad;
+    ctx->selfcheck_note = mfma_bad ? "matrix-core self-check overridden (flacgpu_force_selfcheck_result); the encoder uses its generic kernel" : "";
+    ctx->desc_key.clear();       // (the kernel choice is part of what a cached block list stands for)
+}
 extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level) { ctx->stage_timing = level < 0 ? 0 : level > 2 ? 2 : level; }
 extern "C" void flacgpu_set_log_guard(flacgpu_ctx *ctx, double thr) { ctx->log_guard_thr = thr; }
 
@@ -425,7 +445,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     // ---- which kernels: the de-fused pipeline (flac_enc_pipe_impl.h) where it applies, round 1's single kernel with
     // FLACGPU_PIPE=0, the generic kernel for everything else
-    const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && P.sig_stride != 0 && s->channels <= 2 && s->max_lpc_order <= 12 &&
+    const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && c->mfma_bad == 0 && P.sig_stride != 0 && s->channels <= 2 && s->max_lpc_order <= 12 &&
                           // (32-bit streams: blocks whose channels share eight wasted bits, flac_enc_pipe_impl.h pipe_preshift; the rest is handed
                           // to the generic kernel block by block, which the decision probe of loose mid-side does not expect)
                           (s->bits_per_sample <= 24 || (s->bits_per_sample == 32 && !(s->do_mid_side && s->loose_mid_side)));
@@ -434,7 +454,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
     const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
     uint32_t chunk_cap_words = 0, fbw_words = s->bits_per_sample <= 16 ? 800 : 1280;   // 16-bit stereo: 5 workgroups per CU
-    if (getenv("FLACGPU_FBW")) fbw_words = (uint32_t)atoi(getenv("FLACGPU_FBW"));
+    if (fg_tune("FLACGPU_FBW")) fbw_words = (uint32_t)atoi(fg_tune("FLACGPU_FBW"));
     if (use_pipe) {
         // a chunk holds at most a whole subframe (all of a subframe's bits may sit in one half) plus the frame header
         const uint64_t per = ((uint64_t)s->blocksize * (s->bits_per_sample + 2)) / 8 + 512 + 64;
@@ -798,7 +818,7 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
     // more than two channels: one-channel views through the pipeline where its shape applies (limit_min_bitrate looks across the
     // channels of a frame, large blocks and wide samples stay with the generic kernel)
     if (s->channels > 2 && s->channels <= 8 && (s->bits_per_sample <= 24 || s->bits_per_sample == 32) && s->max_lpc_order <= 12 && !s->limit_min_bitrate && !c->debug &&
-        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0) &&
+        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && c->mfma_bad == 0 && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0) &&
         !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0))
         return encode_multichannel(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
     return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;

@@ -33,6 +33,7 @@ int fg_launch_merge(const FgBlockResult *d_res, const uint32_t *d_chunk_bits, co
                     const uint32_t *d_fbase, const uint32_t *d_fstr, uint32_t channels, uint32_t nframes, uint32_t *d_sizes, uint32_t *d_errs,
                     unsigned long long *d_offsets, uint8_t *d_dst, unsigned long long dst_cap, FgBlockResult *d_fres,
                     unsigned long long *d_user_offsets, hipStream_t stream);
+int fg_mfma_selfcheck(hipStream_t stream);
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
@@ -133,6 +134,8 @@ struct flacgpu_ctx {
     std::vector<WindowEntry> win_index;
     bool windows_dirty = false;
     std::string window_note;      // set when the window self-check replaced a table (see window_offset)
+    int mfma_bad = 0;             // results of the matrix-core self-check that differed from the v_fma_f64 chain (fg_mfma_selfcheck)
+    std::string selfcheck_note;
     bool debug = false;
     uint32_t last_nblocks = 0;
     // pinned staging for the stream (callback) API

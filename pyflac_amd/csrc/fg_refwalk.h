@@ -500,7 +500,7 @@ struct Walker {
             if (s == last_s) { if (++same > 64) { br.marker = NONE; br.B = s + 2; } } else { last_s = s; same = 0; }
             // ---- read_frame_
             const int r = read_frame(br, s, si, fixed_blocksize, errs, h);
-            if (getenv("FG_REFWALK_DEBUG"))
+            if (fg_tune("FG_REFWALK_DEBUG"))
                 fprintf(stderr, "refwalk: sync %llu r=%d stands %llu.%u B=%llu E=%llu marker=%lld eof=%d nerr=%zu\n", (unsigned long long)s, r,
                         (unsigned long long)(br.pos / 8), (unsigned)(br.pos & 7), (unsigned long long)br.B, (unsigned long long)br.E, (long long)br.marker, (int)br.at_eof, errs.size());
             if (r == 4) { if (!final) return UINT64_MAX; *ended = true; return len; }

@@ -2,6 +2,26 @@
 #pragma once
 #include <stdint.h>
 
+// ---- environment switches --------------------------------------------------------------------------------------------------------
+// Read by every build: FLACGPU_DEVICE (configuration: which GPU the default context uses), the kernel SELECTORS that choose among
+// implementations with identical results and exist for the cross-check tests (FLACGPU_NO_FAST, FLACGPU_PIPE, FLACGPU_MC, FLACGPU_WS,
+// FLACGPU_GROUPS, FLACGPU_DEC_WAVE, FLACGPU_DEC_WRESTORE, FLACGPU_DEC_FUSED, FLACGPU_DEC_P16, FLACGPU_DEC_G1 / G2 / WPS) and two
+// test hooks (FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST).  Everything that skips work, reorders it for an experiment or
+// prints diagnostics (FLACGPU_DEC_SKIP, FLACGPU_STOP, FLACGPU_DEC_CRC_LATE, FLACGPU_FBW, FLACGPU_LDS_PAD, FLACGPU_SPIN_US,
+// FLACGPU_DEC_PROF, FLACGPU_API_PROF, FG_REFWALK_DEBUG) is read through fg_tune(), which answers "unset" unless the library was built
+// with `make TUNING=1` (-DFG_TUNING): the release library cannot be talked into skipping a stage.
+#include <stdlib.h>
+static inline const char *fg_tune(const char *name)
+{
+#ifdef FG_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return (const char *)0;
+#endif
+}
+
+
 #define FG_MAX_ORDER 32
 #define FG_MAX_VEC 16    // autocorrelation vectors per candidate; subdivide_tukey(3) needs 9
 #define FG_MAX_CAND 4    // L, R, M, S

@@ -1646,7 +1646,7 @@ extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_l
     const void *fn = which == 0 ? (const void *)fg_dec_fused_kernel<false, 2> : which == 1 ? (const void *)fg_dec_fused_kernel<true, 2>
                    : which == 2 ? (const void *)fg_dec_fused_kernel<false, 3> : (const void *)fg_dec_fused_kernel<true, 3>;
     if (fg_func_set_lds(fn, lds) != 0) return -1;
-    if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 = no output wave, 2 = no recurrence
+    if (fg_tune("FLACGPU_DEC_SKIP")) interleave |= ((uint32_t)atoi(fg_tune("FLACGPU_DEC_SKIP")) & 3u) << 8;     // experiments: 1 = no output wave, 2 = no recurrence
     const dim3 grid((nframes + G - 1) / G);
 #define FG_FUSED_LAUNCH(W, N) hipLaunchKernelGGL((fg_dec_fused_kernel<W, N>), grid, dim3(256), lds, stream, d_stream, (u64)stream_len, d_frames, nframes, G, \
                                                  W ? 0u : 1u, d_scratch, d_subs, d_results, d_rparams, d_warm, d_pcm, interleave, (u64 *)d_prof)

@@ -1197,7 +1197,7 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
     if (C > 64) return -1;
-    if (getenv("FLACGPU_DEC_SKIP")) interleave |= (uint32_t)atoi(getenv("FLACGPU_DEC_SKIP")) << 8;     // experiments: 1 no output, 2 no recurrence
+    if (fg_tune("FLACGPU_DEC_SKIP")) interleave |= ((uint32_t)atoi(fg_tune("FLACGPU_DEC_SKIP")) & 3u) << 8;     // experiments: 1 no output, 2 no recurrence
     const uint32_t G = 64 / C;
     const dim3 grid((nframes + G - 1) / G);
     const size_t lds = ((size_t)WR_NB * WR_TILE_W + 64 * WR_FA + 8) * 4;

@@ -45,7 +45,7 @@ int fg_launch_encode_fast(const void *d_pcm, const FgBlockDesc *d_descs, const f
     const int maxo = P->max_lpc_order <= 8 ? 8 : 12;
     const int acc64 = P->bps > 16 ? 1 : 0;
     size_t lds = fg_fast_lds_bytes(P, nch, ms, maxo);
-    if (getenv("FLACGPU_LDS_PAD")) lds += (size_t)atoi(getenv("FLACGPU_LDS_PAD"));   // occupancy experiments
+    if (fg_tune("FLACGPU_LDS_PAD")) lds += (size_t)atoi(fg_tune("FLACGPU_LDS_PAD"));   // occupancy experiments
     if (lds > 160 * 1024) return -1;
 #define FG_CALL(name) return fg_fast_launch_##name(d_pcm, d_descs, d_windows, P, nblocks, d_slots, d_results, d_dbg, d_crctab, lds, acc64, stream)
     if (nch == 2 && ms) { if (maxo == 8) FG_CALL(ms_o8); else FG_CALL(ms_o12); }

@@ -6,7 +6,62 @@
 
 #include "flac_enc_pipe_impl.h"
 
+namespace {
+// Start-up self-check of the matrix-core chain.  The autocorrelation's bit-exactness rests on a property
+// of v_mfma_f64_4x4x4_4b_f64 no manual states: its sum over k is a chain of fused multiply-adds in ascending k, each rounded like
+// v_fma_f64 (tools/ubench/mfma64.hip found it).  This kernel checks that on the device at hand: random operands of the kind the
+// kernel uses -- floats widened to double, exponents spread over 40 binades, signs mixed --, 64 dependent instructions a wave (the
+// accumulator carries on, as in the chains), every result compared bit for bit with the v_fma_f64 chain over the same operands in
+// the layout fg_pipe_autoc_kernel relies on (A[i][k] in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
+// 16 i + 4 b + j).  A few microseconds at flacgpu_ctx_create.
+__global__ void __launch_bounds__(64) fg_mfma_selfcheck_kernel(unsigned int *bad, unsigned int rounds)
+{
+    __shared__ double sa[64], sbv[64];
+    const int lane = threadIdx.x;
+    unsigned int x = 0x9E3779B9u * (blockIdx.x * 64u + (unsigned)lane + 1u);
+    auto rnd = [&]() -> double {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const float m = 1.0f + (float)(x & 0x7FFFFF) * (1.0f / 8388608.0f);
+        const int e = (int)((x >> 23) % 41u) - 20;
+        const float v = ldexpf((x >> 31) ? -m : m, e);
+        return (double)v;
+    };
+    double acc_m = 0.0, acc_v = 0.0;
+    unsigned int nbad = 0;
+    const int i_ = lane >> 4, b_ = (lane >> 2) & 3, j_ = lane & 3;
+    for (unsigned int r = 0; r < rounds; r++) {
+        const double a = rnd(), b = rnd();
+        sa[lane] = a; sbv[lane] = b;
+        __syncthreads();
+        acc_m = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc_m, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc_v = __builtin_fma(sa[16 * k + 4 * b_ + i_], sbv[16 * k + 4 * b_ + j_], acc_v);
+        if (__double_as_longlong(acc_m) != __double_as_longlong(acc_v)) nbad++;
+        acc_v = acc_m;                      // (after a difference the chains would part for good: count instructions, not their wake)
+        __syncthreads();
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+}  // namespace
+
 extern "C" {
+
+// returns the number of matrix-core results that differ from the v_fma_f64 chain (0 = the encoder's autocorrelation is bit-exact
+// on this device), negative on a launch failure
+int fg_mfma_selfcheck(hipStream_t stream)
+{
+    unsigned int *d_bad = nullptr, h_bad = 0;
+    if (hipMalloc(&d_bad, 4) != hipSuccess) return -1;
+    int rc = -1;
+    if (hipMemsetAsync(d_bad, 0, 4, stream) == hipSuccess) {
+        hipLaunchKernelGGL(fg_mfma_selfcheck_kernel, dim3(16), dim3(64), 0, stream, d_bad, 64u);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipStreamSynchronize(stream) == hipSuccess)
+            rc = (int)(h_bad > 0x7FFFFFFFu ? 0x7FFFFFFFu : h_bad);
+    }
+    (void)hipFree(d_bad);
+    return rc;
+}
 
 #define FG_DECLP(name) int fg_pipe_launch_##name(const FgPipeLaunch *L);
 FG_DECLP(ms_o8) FG_DECLP(ms_o12) FG_DECLP(st_o8) FG_DECLP(st_o12) FG_DECLP(mono_o8) FG_DECLP(mono_o12)

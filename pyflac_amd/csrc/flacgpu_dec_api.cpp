@@ -447,7 +447,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     unsigned long long *d_tot = d_off + nframes + 1;
     // end of call and timing as in the encoder (fg_ctx.cpp): level 0 = stamp kernel in front, export kernel at the end (status
     // words, totals and stamps into pinned memory, the host polls a sequence number), no events; levels 1, 2 = HIP events
-    static const bool want_prof = getenv("FLACGPU_DEC_PROF") != nullptr;
+    static const bool want_prof = fg_tune("FLACGPU_DEC_PROF") != nullptr;
     const bool lean = c->stage_timing == 0 && !h_frames && !detail && !want_prof;
     if (lean) {     // (with the index made here, its first kernel takes the stamp)
         if (!index_here && fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; }
@@ -505,12 +505,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     static const int wave_parse = getenv("FLACGPU_DEC_WAVE") ? atoi(getenv("FLACGPU_DEC_WAVE")) : 1;     // 0: the lane-serial fused kernel of round 2
     static const bool old_restore = getenv("FLACGPU_DEC_WRESTORE") && atoi(getenv("FLACGPU_DEC_WRESTORE")) == 0;
     static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
-    static const bool prof_fused = getenv("FLACGPU_DEC_PROF") && atoi(getenv("FLACGPU_DEC_PROF")) == 2;
+    static const bool prof_fused = fg_tune("FLACGPU_DEC_PROF") && atoi(fg_tune("FLACGPU_DEC_PROF")) == 2;
     const bool fused = !wave_parse && !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
     // (measured: beside the restore kernel the CRC pass slows that kernel's lone recurrence waves down by more than it gave
     // the parse kernel back -- 136 + 159 us against 123 + 163 --, so it stays beside the parse kernel; FLACGPU_DEC_CRC_LATE=1 tries
     // the other order)
-    static const int crc_late_mode = getenv("FLACGPU_DEC_CRC_LATE") ? atoi(getenv("FLACGPU_DEC_CRC_LATE")) : 2;
+    static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 2;
     const bool crc_late = crc_late_mode == 1 && wave_parse && !old_restore && !fused;
     // (mode 2, the default: the CRC pass beside the parse kernel, but the restore kernel does not wait for its last frames -- the
     // pass lives on the wave slots the parser leaves and ends some 12 us after it --: it ignores the verdict, and
@@ -1237,7 +1237,7 @@ bool decode_available(DecImpl *d)
     flacgpu_ctx *c = d->ctx;
     (void)hipSetDevice(c->device);
     // FLACGPU_API_PROF=1: wall time of the phases of this call on stderr (tuning aid)
-    static const bool api_prof = getenv("FLACGPU_API_PROF") != nullptr;
+    static const bool api_prof = fg_tune("FLACGPU_API_PROF") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t) {
         if (!api_prof) return;
@@ -1547,7 +1547,7 @@ bool walk_damage(DecImpl *d)
     }
     d->walker = w;
     d->walk_pending = false;
-    if (getenv("FG_REFWALK_DEBUG"))
+    if (fg_tune("FG_REFWALK_DEBUG"))
         fprintf(stderr, "walk_damage: from %llu (abs %llu) -> s=%llu fend=%llu ended=%d errs=%zu buf=%zu eof=%d\n", (unsigned long long)d->walk_from,
                 (unsigned long long)(d->consumed_total + d->walk_from), (unsigned long long)s, (unsigned long long)fend, (int)ended, errs.size(), d->buf.size(), (int)d->eof);
     if (d->error_cb) for (uint32_t e : errs) d->error_cb(&d->pub, (FLAC__StreamDecoderErrorStatus)e, d->client);
@@ -1610,7 +1610,7 @@ bool fill_queue(DecImpl *d)
         for (int attempt = 0; attempt < 2; attempt++) {
             const auto tf0 = std::chrono::steady_clock::now();
             { ProfSpan span(&d->prof_ms[1]); d->ix.feed(d->buf.data(), d->buf.size(), d->eof, d->have_si ? &d->si : nullptr); }
-            if (getenv("FLACGPU_API_PROF"))
+            if (fg_tune("FLACGPU_API_PROF"))
                 fprintf(stderr, "[flacgpu api prof] index feed %8.3f ms (%zu bytes, %s)\n",
                         std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tf0).count() / 1000.0, d->buf.size(),
                         d->ix.fast ? "fast" : "careful");
@@ -1630,7 +1630,7 @@ bool fill_queue(DecImpl *d)
             if (!d->ix.errors.empty()) trouble = d->ix_origin;
             for (size_t i = 0; i < d->frames.size(); i++)
                 if (d->status[i].err != 0 && d->status[i].err != 3) { trouble = std::min<uint64_t>(trouble, d->first_pos + d->frames[i].byte_off); break; }
-            if (trouble != UINT64_MAX && getenv("FG_REFWALK_DEBUG"))
+            if (trouble != UINT64_MAX && fg_tune("FG_REFWALK_DEBUG"))
                 fprintf(stderr, "fill_queue: trouble at %llu (abs %llu), %zu frames in the round, index errors %zu, origin %llu\n", (unsigned long long)trouble,
                         (unsigned long long)(d->consumed_total + trouble), d->frames.size(), d->ix.errors.size(), (unsigned long long)d->ix_origin);
             if (trouble != UINT64_MAX) {
@@ -1847,7 +1847,7 @@ FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *dec)
     }
     d->md5_checking = 0;
     d->block_cb = nullptr;
-    if (getenv("FLACGPU_API_PROF"))
+    if (fg_tune("FLACGPU_API_PROF"))
         fprintf(stderr, "[flacgpu api prof] decoder totals: read callback + buffer %.3f ms, index %.3f, upload/decode/download %.3f, delivery %.3f, buffer compaction %.3f\n",
                 d->prof_ms[0], d->prof_ms[1], d->prof_ms[2], d->prof_ms[3], d->prof_ms[4]);
     for (double &v : d->prof_ms) v = 0;

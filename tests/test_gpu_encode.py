@@ -637,3 +637,33 @@ def test_32_bit_mono_and_many_channels_with_shared_wasted_bits(ctx):
         out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
         want, sizes = O.encode_stream(cfg, arr)
         assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
+
+
+def test_matrix_core_selfcheck_and_its_fallback(golden):
+    """flacgpu_ctx_create checks that v_mfma_f64_4x4x4_4b_f64 sums like a chain of v_fma_f64 -- what the bit-exactness of the
+    pipeline's autocorrelation rests on -- with random operands against the VALU chain.  On the MI355X the count of
+    differing results is 0.  A device where it is not keeps the bytes: every block then takes the generic kernel, and the context
+    says so (the outcome is overridden here to drive that path)."""
+    from pyflac_amd import batch, _lib
+    L = _lib.lib()
+    c = batch.Context(0)
+    note = C.c_char_p()
+    assert L.flacgpu_selfcheck(c._h, C.byref(note)) == 0 and note.value == b''
+    names = ('cfg2_20s_l5', 'cfg4_10s_l8')
+
+    def encode_all():
+        out = {}
+        for name in names:
+            spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
+            pcm, bps = cases.make_pcm(spec)
+            stream, _offs, _s = _gpu_stream(c, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
+            out[name] = hashlib.sha256(stream).hexdigest()
+        return out
+    want = {n: golden[n]['sha256'] for n in names}
+    assert encode_all() == want
+    L.flacgpu_force_selfcheck_result(c._h, 7)
+    assert L.flacgpu_selfcheck(c._h, C.byref(note)) == 7 and b'generic kernel' in note.value
+    assert encode_all() == want                   # same bytes through the generic kernel
+    L.flacgpu_force_selfcheck_result(c._h, 0)
+    assert L.flacgpu_selfcheck(c._h, C.byref(note)) == 0
+    assert encode_all() == want
