@@ -560,6 +560,9 @@ void flacgpu_set_log_guard(flacgpu_ctx *ctx, double threshold_bits);
 /* Window self-check: empty string, or a note that this host's cosf produced a tukey taper different from the committed one
  * (the committed one is then used; the note is also left in flacgpu_last_error() when it happens). */
 const char *flacgpu_window_note(flacgpu_ctx *ctx);
+/* How the library was built: bit 0 = `make TUNING=1` (experiment and diagnostic environment switches are read), bit 1 = `make LEGACY=1`
+ * (the superseded kernels of rounds 1 and 2 are present and selectable: FLACGPU_PIPE=0, FLACGPU_DEC_WAVE=0, FLACGPU_DEC_FUSED=0). */
+unsigned int flacgpu_build_flags(void);
 /* Start-up self-check of the encoder's matrix-core autocorrelation (run by flacgpu_ctx_create): the number of
  * v_mfma_f64_4x4x4_4b_f64 results that differed from the chain of v_fma_f64 the bit-exactness of stage L6 rests on; 0 on
  * a device that behaves like the MI355X this was written on.  Non-zero: every block is encoded by the generic kernel (same bytes,

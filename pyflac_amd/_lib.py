@@ -117,7 +117,7 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_stream_encoder_set_launch_blocks', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
-                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
 

@@ -345,6 +345,17 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
 extern "C" const char *flacgpu_window_note(flacgpu_ctx *ctx) { return ctx->window_note.c_str(); }
+extern "C" unsigned int flacgpu_build_flags(void)
+{
+    unsigned int f = 0;
+#ifdef FG_TUNING
+    f |= 1u;
+#endif
+#ifdef FG_LEGACY
+    f |= 2u;
+#endif
+    return f;
+}
 extern "C" int flacgpu_selfcheck(flacgpu_ctx *ctx, const char **note)
 {
     if (note) *note = ctx->selfcheck_note.c_str();
@@ -449,7 +460,12 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
                           // (32-bit streams: blocks whose channels share eight wasted bits, flac_enc_pipe_impl.h pipe_preshift; the rest is handed
                           // to the generic kernel block by block, which the decision probe of loose mid-side does not expect)
                           (s->bits_per_sample <= 24 || (s->bits_per_sample == 32 && !(s->do_mid_side && s->loose_mid_side)));
+#ifdef FG_LEGACY
     const bool use_pipe = cfg_fast && !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) && fg_pipe_supported(&P);
+#else
+    // (round 1's one-kernel-per-block encoder, FLACGPU_PIPE=0, is built with `make LEGACY=1` only)
+    const bool use_pipe = cfg_fast && fg_pipe_supported(&P);
+#endif
     if (view && !use_pipe && cfg_fast) { fg_set_error("one-channel views need the pipeline or the generic kernel"); return false; }
     const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
     const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
@@ -632,18 +648,24 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             // (groups: flac_enc_pipe_impl.h / pipe_shape.inc; a launch of a few hundred blocks does not fill the chip once)
             static const int groups_env = getenv("FLACGPU_GROUPS") ? atoi(getenv("FLACGPU_GROUPS")) : 0;
             PL.ngroups = groups_env > 0 ? (uint32_t)groups_env : (nfast >= 4096 ? 2u : 1u);
+            static const bool keep_off = getenv("FLACGPU_KEEP") && atoi(getenv("FLACGPU_KEEP")) == 0;
+            PL.no_keep = keep_off ? 1u : 0u;
             if (c->debug) PL.ngroups = 1;
             if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
             PL.ngroups = 1;
         }
         piped = true;
     }
+#ifdef FG_LEGACY
     else if (nfast) {
         const int rc = fg_launch_encode_fast(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nfast, (uint8_t *)c->slots.p,
                                              (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream);
         if (rc == -1) nfast = 0;
         else if (rc != 0) { fg_set_error("fast encode kernel launch failed"); return false; }
     }
+#else
+    else if (nfast) nfast = 0;       // (not reached: without the pipeline no block counts as fast)
+#endif
     if (nblocks > nfast) {
         hipStream_t ss = (side && nfast) ? c->stream2 : c->stream;
         if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + nfast, (const float *)c->windows.p, &P, nblocks - nfast, (uint8_t *)c->slots.p,

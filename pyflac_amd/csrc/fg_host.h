@@ -44,9 +44,9 @@ int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *
 int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream);
 int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
                      const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream);
-int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
+int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
                      const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
-                     unsigned long long seq, hipStream_t stream);
+                     unsigned long long seq, hipStream_t stream, const FgDecFrame *fix_frames = nullptr, int32_t *fix_out = nullptr);
 size_t fg_scan_words(uint32_t nblocks);
 int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, int all_pipe,
                    const unsigned long long *d_errs, hipStream_t stream);

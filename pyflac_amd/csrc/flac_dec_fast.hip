@@ -232,6 +232,8 @@ struct BitRd {
 
 __device__ __forceinline__ int32_t unzig(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
 
+typedef uint32_t fg_crc_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#ifdef FG_LEGACY        // (make LEGACY=1) round 1 / round 2 parse kernels: fg_dec_rice_kernel, and the walk the fused kernel shares with it
 // ------------------------------------------------------------------------------------------------ parse
 // Tile protocol (LDS): tile[row][col] holds either a finished value or the 32-bit window at the start of a Rice code
 // ("window form": leading zeros = quotient, then the stop bit, then k remainder bits).  rowk[row] = k when the tile is in
@@ -662,7 +664,7 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
 // instructions and no LDS look-up; the table version did six look-ups per word, at random addresses, beside a parser whose
 // walks live on LDS.  Lanes own interleaved 16-byte granules (one unaligned 16-byte load a step): state * x^8192 + crc(granule),
 // folded at the end with x^(128 (63 - lane)) (six conditional multiplications by constants).
-typedef uint32_t fg_crc_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#endif  // FG_LEGACY
 __global__ void __launch_bounds__(256)
 fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, const uint16_t *crctab)
 {
@@ -726,6 +728,7 @@ fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfra
 }
 
 
+#ifdef FG_LEGACY        // round 1 restore kernel and round 2 fused decoder
 // ------------------------------------------------------------------------------------------------ restore
 #define FG_TR 192           // samples per tile and chain: a multiple of both history lengths (8 and 12) and of the pass width
 #define FG_TRS 196          // LDS row stride in words (16-byte aligned rows, rows of neighbouring lanes on different banks)
@@ -1522,6 +1525,7 @@ fg_dec_fused_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fra
 #undef FG_PROF_END
 }
 
+#endif  // FG_LEGACY
 // Settle the frames after the fused kernel and the CRC-16 kernel: merge the CRC verdict into the status, and write silence
 // for frames that failed (libFLAC delivers silence on a CRC mismatch; status 3 = the generic kernel decodes it next).
 __global__ void __launch_bounds__(256)
@@ -1588,6 +1592,16 @@ static uint32_t fg_dec_group(uint32_t nframes, uint32_t per_frame_lanes, uint32_
     return g;
 }
 
+#ifndef FG_LEGACY
+// The lane-serial decoders of rounds 1 and 2 (fg_dec_rice_kernel + fg_dec_restore_kernel, fg_dec_fused_kernel) are built with
+// `make LEGACY=1` only; the wave-parallel parser and its restore kernel (flac_dec_wave.hip) replace them.
+extern "C" int fg_launch_decode_fast(const uint8_t *, uint64_t, const FgDecFrame *, uint32_t, int32_t *, FgDecSub *, FgDecResult *, int,
+                                     unsigned long long *, uint16_t *, hipStream_t) { return -3; }
+extern "C" int fg_launch_decode_finish(const uint8_t *, const FgDecFrame *, uint32_t, uint32_t, const int32_t *, const FgDecSub *, int32_t *,
+                                       FgDecResult *, const uint16_t *, uint32_t, int, unsigned long long *, hipStream_t) { return -3; }
+extern "C" int fg_launch_decode_fused(const uint8_t *, uint64_t, const FgDecFrame *, uint32_t, int32_t *, FgDecSub *, FgDecResult *, int,
+                                      uint16_t *, int32_t *, int32_t *, uint32_t, unsigned long long *, hipStream_t) { return -3; }
+#else
 extern "C" int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                                      int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
                                      uint16_t *d_rparams, hipStream_t stream)
@@ -1660,6 +1674,7 @@ extern "C" int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_l
     return (int)hipGetLastError();
 }
 
+#endif  // FG_LEGACY
 extern "C" int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results, int32_t *d_pcm, hipStream_t stream)
 {
     if (nframes == 0) return 0;

@@ -374,12 +374,19 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
 
 // ---------------------------------------------------------------- frame header parse (format.h:418-462)
 // lane = frame.  offsets[f] .. offsets[f+1] delimit the frame.  Fills FgDecFrame except out_off.
+__device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t f, uint32_t si_channels,
+                                                    uint32_t si_bps, FgDecFrame *frames, FgDecResult *results);
 __global__ void __launch_bounds__(256)
 fg_dec_headers_kernel(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t nframes, uint32_t si_channels, uint32_t si_bps,
                       FgDecFrame *frames, FgDecResult *results)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nframes) return;
+    fg_dec_parse_header(stream, stream_len, offsets, f, si_channels, si_bps, frames, results);
+}
+__device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t f, uint32_t si_channels,
+                                                    uint32_t si_bps, FgDecFrame *frames, FgDecResult *results)
+{
     // the index may come from the device (the index kernel leaves ~0 in the slot of a frame it did not find; a caller's table
     // is not looked at by the host): nothing is read through an offset that does not lie inside the stream
     const u64 o0 = offsets[f], o1 = offsets[f + 1];
@@ -861,10 +868,13 @@ extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long
                                      unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream)
 {
     if (nframes == 0) return 0;
+    // (the header pass inside the one-workgroup scan kernel was tried in round 4 and costs far more than the launch it saves: a header
+    // is a chain of dependent byte loads, and 7032 of them want 7032 threads, not 1024 -- decode launch 0.342 -> 0.405 ms)
     hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, (u64)stream_len, d_offsets, nframes,
                        si_channels, si_bps, d_frames, d_results);
     const uint32_t ntiles = (nframes + FG_DSCAN_TILE - 1) / FG_DSCAN_TILE;
-    if (ntiles == 1) hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
+    if (ntiles == 1)
+        hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
     else {
         // (the tile totals lie behind the three totals: the caller sizes the array with fg_dec_scan_words())
         u64 *tsum = (u64 *)d_totals + 4;

@@ -1440,11 +1440,36 @@ __global__ void fg_signal_kernel(const u64 *src0, uint32_t n0, const u64 *src1, 
 
 // the decoder's variant: the per-frame status words travel too (16-byte units, a few workgroups; the last one to finish --
 // counter in stamp[1] -- raises the flag)
+// With `fix_frames` (the decoder's wave path, round 4): the rows are the frames' FgDecResult words and this kernel also does what
+// fg_dec_fix_kernel did in a launch of its own -- the CRC-16 verdict (bit 31 of the crc word, left by fg_dec_crc_kernel beside the
+// parse kernel) becomes status 2, and a frame that failed (not status 3: the generic decoder writes those) is silence.  A failed
+// frame is rare; the thread that meets one zeroes it alone.
 __global__ void __launch_bounds__(1024)
-fg_export_kernel(const uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1,
-                 u64 *stamp, u64 *host, u64 seq)
+fg_export_kernel(uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1,
+                 u64 *stamp, u64 *host, u64 seq, const FgDecFrame *fix_frames, uint32_t fix_nframes, int32_t *fix_out)
 {
-    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < nquads; i += gridDim.x * 1024) host_rows[i] = rows[i];
+    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < nquads; i += gridDim.x * 1024) {
+        uint4 r = rows[i];
+        if (fix_frames) {
+            uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t f = 2 * i + k;
+                if (f >= fix_nframes) continue;
+                const FgDecFrame fr = fix_frames[f];
+                uint32_t status = 1, crcw = 0;
+                if (fr.bytes != 0) { status = w[2 * k]; crcw = w[2 * k + 1]; if (status == 0 && (crcw & 0x80000000u)) status = 2; }
+                if (fr.n != 0) { w[2 * k] = status; w[2 * k + 1] = crcw & 0xFFFFu; }
+                if (status != 0 && status != 3 && fr.n != 0 && fr.channels != 0 && fix_out) {
+                    int32_t *o = fix_out + fr.out_off * fr.channels;
+                    for (uint32_t j = 0; j < fr.n * fr.channels; j++) o[j] = 0;
+                }
+            }
+            r = make_uint4(w[0], w[1], w[2], w[3]);
+            rows[i] = r;
+        }
+        host_rows[i] = r;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1496,16 +1521,16 @@ int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned
     return (int)hipGetLastError();
 }
 
-int fg_launch_export(const void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
+int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
                      const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
-                     unsigned long long seq, hipStream_t stream)
+                     unsigned long long seq, hipStream_t stream, const FgDecFrame *fix_frames, int32_t *fix_out)
 {
     // rows of 8 bytes, moved as 16-byte units (both buffers are padded past nrows)
     const uint32_t nquads = (nrows + 1) / 2;
     uint32_t wgs = (nquads + 1023) / 1024;
     wgs = wgs < 1 ? 1 : wgs > 8 ? 8 : wgs;
-    hipLaunchKernelGGL(fg_export_kernel, dim3(wgs), dim3(1024), 0, stream, (const uint4 *)d_rows, nquads, (uint4 *)h_rows, (const u64 *)src0, n0,
-                       (const u64 *)src1, n1, (u64 *)d_stamp, (u64 *)h_sig, (u64)seq);
+    hipLaunchKernelGGL(fg_export_kernel, dim3(wgs), dim3(1024), 0, stream, (uint4 *)d_rows, nquads, (uint4 *)h_rows, (const u64 *)src0, n0,
+                       (const u64 *)src1, n1, (u64 *)d_stamp, (u64 *)h_sig, (u64)seq, fix_frames, fix_frames ? nrows : 0u, fix_out);
     return (int)hipGetLastError();
 }
 

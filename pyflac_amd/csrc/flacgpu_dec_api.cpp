@@ -502,8 +502,14 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         (void)hipMemsetAsync(d_prof, 0, (size_t)npad * 2 * 8 * 8, c->stream);
     }
     // The CRC-16 pass only needs the stream and the frame table: it runs on the side stream beside the parse kernel.
+#ifdef FG_LEGACY
     static const int wave_parse = getenv("FLACGPU_DEC_WAVE") ? atoi(getenv("FLACGPU_DEC_WAVE")) : 1;     // 0: the lane-serial fused kernel of round 2
     static const bool old_restore = getenv("FLACGPU_DEC_WRESTORE") && atoi(getenv("FLACGPU_DEC_WRESTORE")) == 0;
+#else
+    // (the lane-serial decoders of rounds 1 and 2 are built with `make LEGACY=1` only: the selectors have nothing to select)
+    static const int wave_parse = (getenv("FLACGPU_DEC_WAVE") && atoi(getenv("FLACGPU_DEC_WAVE")) >= 2) ? 2 : 1;
+    static const bool old_restore = false;
+#endif
     static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
     static const bool prof_fused = fg_tune("FLACGPU_DEC_PROF") && atoi(fg_tune("FLACGPU_DEC_PROF")) == 2;
     const bool fused = !wave_parse && !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
@@ -523,7 +529,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // next calls of this context (a stream that does it once does it again: full-scale noise, a side channel at full scale).
     const int plane16 = (!wide && wave_parse && !old_restore && !fused && !detail && !p16_off && c->dec_p16_hold == 0) ? 1 : 0;
     if (c->dec_p16_hold) c->dec_p16_hold--;
-    bool forked = false;
+    bool forked = false, fix_in_export = false;
     if (!crc_late) {
         forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
         if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
@@ -578,7 +584,9 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             }
             if (late) {
                 if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-                if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
+                // (without events the call ends with fg_export_kernel, which merges the verdict itself: one launch less)
+                if (lean) fix_in_export = true;
+                else if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
                     fg_set_error("decode kernel launch failed"); return false;
                 }
             }
@@ -620,7 +628,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (lean) {
         const unsigned long long seq = ++c->sig_seq;
         if (fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
-                             index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream) != 0 ||
+                             index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
+                             fix_in_export ? (const FgDecFrame *)c->dec_frames.p : nullptr, fix_in_export ? (int32_t *)d_pcm : nullptr) != 0 ||
             !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
         tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
         for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
