@@ -949,6 +949,15 @@ struct DecImpl {
     // decodes next, where the index takes over again.
     fgref::RefWindows win;        // the answers of the read callback, as the refills of libFLAC's 8 KiB reader would have seen them
     fgref::Walker walker;         // (the reader's buffer as the last walk left it)
+    // seeking (FLAC__stream_decoder_seek_absolute): possible on a FILE of the library's own and with the client's four callbacks
+    FLAC__StreamDecoderSeekCallback seek_cb = nullptr;
+    FLAC__StreamDecoderTellCallback tell_cb = nullptr;
+    FLAC__StreamDecoderLengthCallback length_cb = nullptr;
+    FLAC__StreamDecoderEofCallback eof_cb = nullptr;
+    uint64_t audio_start = 0;         // stream offset of the first frame (behind the metadata)
+    bool seeking = false;             // frames in front of seek_target are dropped, the frame that holds it is delivered from there
+    uint64_t seek_target = 0;
+    bool seek_done = false;
     uint8_t pre[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // the last bytes dropped from the front of buf (libFLAC's buffer front may lie a few bytes before buf[0])
     uint32_t npre = 0;
     bool walk_pending = false;
@@ -1232,6 +1241,7 @@ bool ensure_metadata(DecImpl *d)
         d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
         if (d->meta_cb) deliver_metadata(d, d->buf.data(), (uint64_t)a);
         drop_front(d, (size_t)a);
+        d->audio_start = d->consumed_total;
     }
     return true;
 }
@@ -1406,6 +1416,19 @@ bool deliver_one(DecImpl *d)
     d->last_blocksize = fr.n; d->last_ca = fr.ca;
     d->last_hdr = f.header; d->last_set = true;
     d->samples_decoded = number + fr.n;
+    if (d->seeking) {
+        // FLAC__stream_decoder_seek_absolute (stream_decoder.h:1412-1450; the reference binary, tests/test_gpu_api.py TestSeek): frames
+        // in front of the target are not delivered; the frame that holds it is delivered from the target sample on, under the
+        // target's sample number
+        if (number + fr.n <= d->seek_target) return true;
+        d->seeking = false; d->seek_done = true;
+        if (number < d->seek_target) {
+            const uint32_t skip = (uint32_t)(d->seek_target - number);
+            for (uint32_t c = 0; c < fr.channels; c++) chan[c] += skip;
+            f.header.blocksize = fr.n - skip;
+            f.header.number.sample_number = d->seek_target;
+        }
+    }
     return write_frame(d, f, chan);
 }
 
@@ -1450,6 +1473,15 @@ bool deliver_blocks(DecImpl *d, size_t limit)
                 need -= e.blocksize;
                 d->blocks.push_back(flacgpu_block{e.number.sample_number, FLACGPU_BLOCK_SILENCE, e.blocksize, e.channels, e.bits_per_sample, e.sample_rate});
             }
+        }
+        if (d->seeking) {
+            // (FLAC__stream_decoder_seek_absolute, see deliver_one)
+            d->last_blocksize = fr.n; d->last_ca = fr.ca; d->last_hdr = h; d->last_set = true; d->samples_decoded = number + fr.n;
+            if (number + fr.n <= d->seek_target) continue;
+            d->seeking = false; d->seek_done = true;
+            const uint32_t skip = number < d->seek_target ? (uint32_t)(d->seek_target - number) : 0u;
+            d->blocks.push_back(flacgpu_block{number + skip, fr.out_off + skip, fr.n - skip, fr.channels, fr.bps, h.sample_rate});
+            continue;
         }
         d->blocks.push_back(flacgpu_block{number, fr.out_off, fr.n, fr.channels, fr.bps, h.sample_rate});
         d->last_blocksize = fr.n; d->last_ca = fr.ca;
@@ -1794,6 +1826,7 @@ FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_stream(FLAC__StreamDecod
     if (!read_callback || !write_callback || !error_callback || (seek_callback && (!tell_callback || !length_callback || !eof_callback)))
         return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
     d->read_cb = read_callback; d->write_cb = write_callback; d->meta_cb = metadata_callback; d->error_cb = error_callback;
+    d->seek_cb = seek_callback; d->tell_cb = tell_callback; d->length_cb = length_callback; d->eof_cb = eof_callback;
     d->client = client_data; d->file = nullptr; d->own_file = false;
     return init_common(d);
 }
@@ -1945,12 +1978,40 @@ FLAC__bool FLAC__stream_decoder_skip_single_frame(FLAC__StreamDecoder *dec)
     return 1;
 }
 
-FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *dec, FLAC__uint64)
+// Seeking (stream_decoder.h:1412-1450).  pyFLAC declares the entry point and never calls it; libFLAC seeks when it was given a
+// file or all four of the seek / tell / length / eof callbacks.  What a client of the reference binary sees (probed in the build
+// container, tests/test_gpu_api.py TestSeek): the call itself delivers the frame that holds the target, from the target sample on
+// and under the target's sample number, returns true and leaves the decoder ready for the frame behind it; a target at or behind
+// STREAMINFO's sample count returns false and changes nothing; MD5 checking is off from then on.  Here the source is put back to
+// the first frame and the frames in front of the target are decoded and dropped -- the GPU decodes a ten-minute stream in a few
+// milliseconds, a search for the right place in the bytes would save little and add the resync cases of libFLAC's search.
+FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *dec, FLAC__uint64 sample)
 {
-    // pyFLAC declares but never calls seek; without seek callbacks libFLAC fails the same way
     DecImpl *d = impl(dec);
-    if (d->state != FLAC__STREAM_DECODER_UNINITIALIZED) d->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-    return 0;
+    if (d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+    const bool seekable = d->file != nullptr || (d->seek_cb && d->tell_cb && d->length_cb && d->eof_cb);
+    if (!seekable) { d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }      // (libFLAC without seek callbacks: the same)
+    if (d->state == FLAC__STREAM_DECODER_ABORTED) return 0;
+    if (!d->have_meta && !ensure_metadata(d)) return 0;
+    if (d->have_si && d->si.total_samples && sample >= d->si.total_samples) return 0;
+    if (d->file) { if (fseeko(d->file, (off_t)d->audio_start, SEEK_SET) != 0) { d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; } }
+    else if (d->seek_cb(&d->pub, d->audio_start, d->client) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) { d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+    d->buf.clear(); d->npre = 0; d->consumed_total = d->audio_start;
+    d->ix = Indexer(); d->frames.clear(); d->status.clear(); d->next_frame = 0; d->frames_delivered_bound = 0;
+    d->win.restart(d->audio_start); d->walker = fgref::Walker(); d->walk_pending = false; d->ix_origin = 0; d->walk_stuck_at = UINT64_MAX;
+    d->eof = false; d->do_md5 = false; d->samples_decoded = 0; d->last_set = false; d->fixed_blocksize = 0;
+    d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+    d->seeking = true; d->seek_target = sample; d->seek_done = false;
+    while (d->seeking) {
+        if (!fill_queue(d)) break;                                  // the stream ended (or the client aborted) in front of the target
+        while (d->next_frame < d->frames.size() && d->seeking) {
+            if (d->round_blocks) { if (!deliver_blocks(d, 1)) { d->seeking = false; return 0; } }
+            else if (!deliver_one(d)) { d->seeking = false; return 0; }
+        }
+    }
+    d->seeking = false;
+    if (!d->seek_done) { d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+    return 1;
 }
 
 }  // extern "C"

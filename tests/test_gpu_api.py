@@ -1,6 +1,7 @@
 """The pyFLAC-compatible classes over the GPU library.  These mirror the reference's own suites
 (tests/test_encoder.py, tests/test_decoder.py: callbacks fire, exception types and messages) and add the
 bit-exactness the reference only asserts in examples/passthrough.py:76."""
+import ctypes as C
 import os
 import pathlib
 import tempfile
@@ -879,3 +880,125 @@ class TestStreamEnd:
         assert r[0]['frames'] == self.ALL
         assert r[3]['frames'] == self.ALL                      # rewound to the first frame: everything again
         assert r[6]['frames'] == self.ALL[6:]                  # jumped to frame 6: no silence in front of it
+
+
+class TestSeek:
+    """FLAC__stream_decoder_seek_absolute (pyflac/builder/decoder.py:475; pyFLAC never calls it).  Expected behaviour recorded from
+    the reference binary on tests/data/stereo.flac (66150 samples, blocks of 4096): the call itself delivers the frame that holds the
+    target from the target sample on (sample number = target), returns true, state SEARCH_FOR_FRAME_SYNC; the frames behind follow
+    with the next process calls; a target at or behind the stream's sample count returns false and changes nothing; finish() is true
+    with MD5 checking on (a seek turns the check off)."""
+
+    @staticmethod
+    def run(target, blocks=False, via_callbacks=False):
+        from pyflac_amd import _lib
+        L = _lib.lib()
+        L.FLAC__stream_decoder_seek_absolute.argtypes = [C.c_void_p, C.c_uint64]
+        path = os.path.join(cases.GOLDEN, 'data', 'stereo.flac')
+        frames, errors = [], []
+        dt = np.dtype([('sample_number', '<u8'), ('offset', '<u8'), ('blocksize', '<u4'), ('channels', '<u4'), ('bits_per_sample', '<u4'), ('sample_rate', '<u4')])
+
+        def _w(d, fr, bufs, cd):
+            h = fr.contents.header
+            a = np.ctypeslib.as_array(bufs[0], shape=(h.blocksize,)).copy()
+            b = np.ctypeslib.as_array(bufs[1], shape=(h.blocksize,)).copy()
+            frames.append((int(h.number.sample_number), int(h.blocksize), np.stack([a, b], axis=1)))
+            return 0
+
+        def _b(d, blks, n, pcm, nbytes, cd):
+            for r in np.frombuffer((C.c_uint8 * (32 * n)).from_address(blks), dtype=dt):
+                bs, ch = int(r['blocksize']), int(r['channels'])
+                ct = C.c_int16 if nbytes == 2 else C.c_int32
+                a = np.frombuffer((ct * (bs * ch)).from_address(pcm + int(r['offset']) * ch * nbytes), dtype=np.int16 if nbytes == 2 else np.int32)
+                frames.append((int(r['sample_number']), bs, a.reshape(bs, ch).astype(np.int32)))
+            return 0
+
+        def _e(d, s, cd):
+            errors.append(int(s))
+
+        with open(path, 'rb') as fh:
+            data = fh.read()
+        pos = [0]
+
+        def _r(d, buf, pn, cd):
+            n = min(pn[0], len(data) - pos[0])
+            if n <= 0:
+                pn[0] = 0
+                return 1
+            C.memmove(buf, data[pos[0]:pos[0] + n], n)
+            pos[0] += n
+            pn[0] = n
+            return 0
+        SEEK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)
+        TELL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+        EOFCB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+        def _seek(d, off, cd):
+            pos[0] = int(off)
+            return 0
+
+        def _tell(d, p, cd):
+            p[0] = pos[0]
+            return 0
+
+        def _len(d, p, cd):
+            p[0] = len(data)
+            return 0
+
+        def _eof(d, cd):
+            return 1 if pos[0] >= len(data) else 0
+        keep = [_lib.DEC_WRITE_CB(_w), _lib.DEC_ERROR_CB(_e), _lib.DEC_BLOCK_CB(_b), _lib.DEC_READ_CB(_r), SEEK(_seek), TELL(_tell), TELL(_len), EOFCB(_eof)]
+        dec = C.c_void_p(L.FLAC__stream_decoder_new())
+        assert L.FLAC__stream_decoder_set_md5_checking(dec, 1)
+        if blocks:
+            assert L.flacgpu_stream_decoder_set_block_callback(dec, keep[2])
+        if via_callbacks:
+            rc = L.FLAC__stream_decoder_init_stream(dec, keep[3], C.cast(keep[4], C.c_void_p), C.cast(keep[5], C.c_void_p), C.cast(keep[6], C.c_void_p),
+                                                    C.cast(keep[7], C.c_void_p), keep[0], C.cast(None, _lib.DEC_META_CB), keep[1], None)
+        else:
+            rc = L.FLAC__stream_decoder_init_file(dec, path.encode(), keep[0], C.cast(None, _lib.DEC_META_CB), keep[1], None)
+        assert rc == 0
+        assert L.FLAC__stream_decoder_process_until_end_of_metadata(dec)
+        ok = L.FLAC__stream_decoder_seek_absolute(dec, target)
+        state = L.FLAC__stream_decoder_get_state(dec)
+        during = list(frames)
+        ok2 = L.FLAC__stream_decoder_process_until_end_of_stream(dec)
+        fin = L.FLAC__stream_decoder_finish(dec)
+        L.FLAC__stream_decoder_delete(dec)
+        return bool(ok), int(state), during, frames[len(during):], bool(ok2), bool(fin), errors
+
+    @pytest.mark.parametrize('mode', ['file', 'file_blocks', 'callbacks'])
+    @pytest.mark.parametrize('target', [0, 1, 4095, 4096, 10000, 40000, 65535, 65536, 66149])
+    def test_seek_delivers_from_the_target_sample(self, mode, target):
+        from oracle import oracle as O
+        with open(os.path.join(cases.GOLDEN, 'data', 'stereo.flac'), 'rb') as fh:
+            want, _ = O.decode_stream(fh.read())
+        ok, state, during, after, ok2, fin, errors = self.run(target, blocks=mode == 'file_blocks', via_callbacks=mode == 'callbacks')
+        assert ok and state == 2 and ok2 and fin and errors == []
+        frame_end = min((target // 4096 + 1) * 4096, 66150)
+        assert [(f[0], f[1]) for f in during] == [(target, frame_end - target)]           # (what the reference binary delivers)
+        assert np.array_equal(during[0][2], want[target:frame_end])
+        rest = [(a, min(4096, 66150 - a)) for a in range(frame_end, 66150, 4096)]
+        assert [(f[0], f[1]) for f in after] == rest
+        if after:
+            assert np.array_equal(np.concatenate([f[2] for f in after]), want[frame_end:])
+
+    @pytest.mark.parametrize('target', [66150, 70000])
+    def test_seek_behind_the_end_fails_and_changes_nothing(self, target):
+        ok, state, during, after, ok2, fin, errors = self.run(target)
+        assert not ok and state == 2 and during == []
+        assert [(f[0], f[1]) for f in after] == [(i * 4096, 4096) for i in range(16)] + [(65536, 614)] and ok2
+
+    def test_seek_without_the_means_is_a_seek_error(self):
+        """init_stream without seek callbacks (what pyFLAC does): false, state SEEK_ERROR (libFLAC: the same)."""
+        from pyflac_amd import _lib
+        L = _lib.lib()
+        L.FLAC__stream_decoder_seek_absolute.argtypes = [C.c_void_p, C.c_uint64]
+        rcb = _lib.DEC_READ_CB(lambda d, b, n, c: 1)
+        wcb = _lib.DEC_WRITE_CB(lambda d, f, b, c: 0)
+        ecb = _lib.DEC_ERROR_CB(lambda d, s, c: None)
+        dec = C.c_void_p(L.FLAC__stream_decoder_new())
+        assert L.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb, C.cast(None, _lib.DEC_META_CB), ecb, None) == 0
+        assert not L.FLAC__stream_decoder_seek_absolute(dec, 5)
+        assert L.FLAC__stream_decoder_get_state(dec) == 6
+        L.FLAC__stream_decoder_delete(dec)
