@@ -820,7 +820,25 @@ FGI uint32_t pipe_preshift(const FgEncParams &P, const FgPipeBufs &B, uint32_t b
     }
     if (m == 64) m = 8;
     if (m < 8) { ok = false; return 0; }
+    // (every candidate must fit the 25-bit forms once its own wasted bits are gone: mid and side may keep more than the channels)
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t w = rfl(B.wasted[bi * NC + c]);
+        const uint32_t nominal = 32u + ((NC == 4 && c == 3) ? 1u : 0u);
+        if (!(w & 0x100u) && nominal - (w & 0xFFu) > 25u) { ok = false; return 0; }
+    }
     return m > 16 ? 16 : m;
+}
+
+// True 32-bit content (round 4): candidate values of up to 33 bits as doubles -- L, R as they are, mid = floor((L + R) / 2), side =
+// L - R, all exact in fp64, and so is the division by 2^wasted.  pipe_eval_cand_w32 / the packing kernel's wide form work on these.
+FGI double pipe_cdbl(int32_t l, int32_t r, uint32_t C, bool ms, double wscale)
+{
+    const double dl = (double)l, dr = (double)r;
+    double v;
+    if (!ms) v = C == 0 ? dl : dr;
+    else v = C == 0 ? dl : (C == 1 ? dr : (C == 2 ? __builtin_floor((dl + dr) * 0.5) : dl - dr));
+    return v * wscale;
 }
 
 // ================================================================================================ staging: HBM -> LDS rows
@@ -1560,6 +1578,290 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     }
 }
 
+// ================================================================================================ K4w: candidates of true 32-bit content
+// pipe_eval_cand for blocks of a 32-bit stream that the shifted 25-bit forms cannot hold (round 4): the same stages with the
+// candidate's samples as doubles (pipe_cdbl: up to 33 bits, exact), regular lane geometry only.
+//   * fixed predictors: differences and |.| sums in fp64 (differences below 2^37, sums below 2^49: exact).  From 28 bits per
+//     sample on libFLAC takes its _limit_residual variants (oracle/flac_oracle.c fixed_best_predictor has the rules as the
+//     reference binary shows them): the sums include the warm-up positions, an order with a residual beyond 31 bits is out, the
+//     order is chosen from k = 4 down with <=, and every order's estimate comes from the order-0 total.
+//   * LPC: the fp64 FIR of the 24-bit path -- products below 2^46, sums of twelve below 2^50 --, |residual| < 2^31 or the
+//     candidate is dropped (libFLAC's _limit_residual FIR).
+template <bool MS, int NCH, int MAXO>
+FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
+                            FgDebugRec *mydbg, const LDS int32_t *sL, const LDS int32_t *sR, int lane, uint32_t range_err)
+{
+    constexpr int NC = MS ? 4 : NCH;
+    constexpr uint32_t PADE = PipeTypes<true>::PADE;
+    const uint32_t n = d.n, seg = n >> 6, rstr = seg + PADE;
+    const LDS int32_t *rowL = sL + (uint32_t)lane * rstr, *rowR = sR + (uint32_t)lane * rstr;
+    const uint32_t wraw = rfl(B.wasted[bi * NC + C]);
+    const uint32_t wst = wraw & 0xFFu;
+    const uint32_t nominal = P.bps + ((MS && C == 3) ? 1u : 0u);
+    const uint32_t sb = nominal - wst;
+    const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);      // 2^-wasted
+    auto samp = [&](int s) __attribute__((always_inline)) -> double { return pipe_cdbl(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, C, MS, wscale); };
+    auto hsamp = [&](int k) __attribute__((always_inline)) -> double { return samp((int)seg - k - (int)rstr); };       // k-th sample in front of the lane
+    auto bcast0 = [&](double v) __attribute__((always_inline)) -> double {
+        return __hiloint2double((int)rl((uint32_t)__double2hiint(v), 0), (int)rl((uint32_t)__double2loint(v), 0));
+    };
+
+    uint32_t pmax0 = 0;
+    { uint32_t b = n; while (!(b & 1)) { pmax0++; b >>= 1; } if (pmax0 > 15) pmax0 = 15; }
+    if (P.max_po < pmax0) pmax0 = P.max_po;
+    const uint32_t pmin0 = P.min_po < pmax0 ? P.min_po : pmax0;
+
+    // ================================================================ fixed-predictor error sums
+    u64 tot[5];
+    u64 fsum = 0;
+    uint32_t guess;
+    float rbg, rb1;
+    {
+        double facc[5], fwarm[5], fmx[5];
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) { facc[kk] = 0.0; fwarm[kk] = 0.0; fmx[kk] = 0.0; }
+        double P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
+#pragma unroll
+        for (int s = -4; s < 4; s++) {
+            double v = 0.0;
+            if (s >= 0) v = samp(s);
+            else if (lane > 0) v = hsamp(-s);
+            const double e1 = v - P0, e2 = e1 - P1, e3 = e2 - P2, e4 = e3 - P3;
+            if (s >= 0) {
+                const double ab[5] = {__builtin_fabs(v), __builtin_fabs(e1), __builtin_fabs(e2), __builtin_fabs(e3), __builtin_fabs(e4)};
+#pragma unroll
+                for (int kk = 0; kk < 5; kk++) {
+                    if (lane > 0) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
+                    else if (s >= kk) { fwarm[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
+                }
+            }
+            P0 = v; P1 = e1; P2 = e2; P3 = e3;
+        }
+#pragma unroll 1
+        for (int s = 4; s < (int)seg; s++) {
+            const double v = samp(s);
+            const double e1 = v - P0, e2 = e1 - P1, e3 = e2 - P2, e4 = e3 - P3;
+            const double ab[5] = {__builtin_fabs(v), __builtin_fabs(e1), __builtin_fabs(e2), __builtin_fabs(e3), __builtin_fabs(e4)};
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
+            P0 = v; P1 = e1; P2 = e2; P3 = e3;
+        }
+        bool over[5];
+        u64 warm0[5];
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) {
+            tot[kk] = wave_sum64((u64)facc[kk]);                   // samples 4 .. n - 1
+            warm0[kk] = (u64)bcast0(fwarm[kk]);                    // lane 0: samples kk .. 3
+            over[kk] = __any(fmx[kk] > 2147483647.0);
+        }
+        const double len = (double)(n - 4);
+        if (sb < 28) {
+            const u64 m34 = tot[3] < tot[4] ? tot[3] : tot[4];
+            const u64 m234 = tot[2] < m34 ? tot[2] : m34;
+            const u64 m1234 = tot[1] < m234 ? tot[1] : m234;
+            if (tot[0] <= m1234) guess = 0;
+            else if (tot[1] <= m234) guess = 1;
+            else if (tot[2] <= m34) guess = 2;
+            else if (tot[3] <= tot[4]) guess = 3;
+            else guess = 4;
+            const u64 tg = guess == 0 ? tot[0] : guess == 1 ? tot[1] : guess == 2 ? tot[2] : guess == 3 ? tot[3] : tot[4];
+            rbg = (float)((tg > 0) ? log(FG_LN2 * (double)tg / len) / FG_LN2 : 0.0);
+            rb1 = tot[1] == 0 ? 0.0f : 1.0f;
+        }
+        else {
+            // the _limit_residual rules (see the comment above): totals with the warm-up positions, orders from 4 down
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) tot[kk] += warm0[kk];
+            const float r0 = (float)((tot[0] > 0) ? log(FG_LN2 * (double)tot[0] / len) / FG_LN2 : 0.0);
+            u64 smallest = ~(u64)0;
+            guess = 0;
+            rbg = 34.0f; rb1 = 34.0f;
+            float rbk[5];
+#pragma unroll
+            for (int kk = 4; kk >= 0; kk--) {
+                if (!over[kk] && tot[kk] <= smallest) { guess = (uint32_t)kk; smallest = tot[kk]; rbk[kk] = r0; }
+                else rbk[kk] = 34.0f;
+            }
+            rbg = guess == 0 ? rbk[0] : guess == 1 ? rbk[1] : guess == 2 ? rbk[2] : guess == 3 ? rbk[3] : rbk[4];
+            rb1 = rbk[1];
+        }
+        const double a = guess == 0 ? facc[0] : guess == 1 ? facc[1] : guess == 2 ? facc[2] : guess == 3 ? facc[3] : facc[4];
+        const double w = guess == 0 ? fwarm[0] : guess == 1 ? fwarm[1] : guess == 2 ? fwarm[2] : guess == 3 ? fwarm[3] : fwarm[4];
+        fsum = (u64)(lane == 0 ? a + w : a);
+    }
+
+    // ---- baseline: verbatim / constant
+    uint32_t best;
+    uint32_t d_type = 1, d_order = 0, d_prec = 0, d_porder = 0, d_method = 0, d_k = 0, d_kpart = 0;
+    bool d_kvalid = false;
+    int d_shift = 0;
+    int32_t bestq[MAXO];
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) bestq[j] = 0;
+    bool do_fixed = false, do_lpc = false;
+    {
+        const u64 vb = (u64)8 + (u64)n * sb;
+        best = vb < 0xFFFFFFFFull ? (uint32_t)vb : 0xFFFFFFFFu;
+        bool constant = false;
+        if (rb1 == 0.0f) {
+            const double x0 = pipe_cdbl(sL[0], (NCH == 2) ? (int32_t)sR[0] : 0, C, MS, wscale);
+            uint32_t ne = 0;
+#pragma unroll 1
+            for (uint32_t s = 0; s < seg; s++) ne |= (samp((int)s) != x0);
+            constant = !__any(ne != 0);
+        }
+        if (mydbg && lane == 0) {
+            for (int kk = 0; kk < 5; kk++) mydbg->cand[C].fixed_tot[kk] = tot[kk];
+            mydbg->cand[C].fixed_guess = guess;
+        }
+        if (P.limit_min_bitrate && C >= (uint32_t)(NCH - 1) && d.forced_ca != 3) {
+            bool forbid = true;
+            if (NCH == 2) {
+                const int32_t l0 = sL[0];
+                uint32_t ne = 0;
+#pragma unroll 1
+                for (uint32_t s = 0; s < seg; s++) ne |= ((int32_t)rowL[s] != l0);
+                forbid = !__any(ne != 0);
+            }
+            if (forbid) constant = false;
+        }
+        if (constant) {
+            const uint32_t cb = 8 + sb;
+            if (cb < best) { best = cb; d_type = 0; }
+        }
+        else {
+            if (!(rbg >= (float)sb)) do_fixed = true;
+            if (P.max_lpc_order > 0) do_lpc = true;
+        }
+    }
+    const uint32_t nv = do_lpc ? rfl(B.nv[bi]) : 0;
+    const uint32_t limit = P.rice_limit;
+
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < 1 + nv; pass++) {
+        uint32_t order, prec = 0;
+        int shift = 0;
+        int32_t q[MAXO];
+#pragma unroll
+        for (int j = 0; j < MAXO; j++) q[j] = 0;
+        u64 psum;
+        uint32_t ovf = 0;
+        const int kind = pass == 0 ? 0 : 1;
+        if (pass == 0) {
+            if (!do_fixed) continue;
+            order = guess;
+            psum = fsum;
+        }
+        else {
+            const uint32_t v = pass - 1;
+            const size_t ridx = ((size_t)bi * NC + C) * P.nvec + v;
+            const uint32_t r = rfl(B.lres[ridx]);
+            order = r & 0xFF; prec = (r >> 8) & 0xFF; shift = (int)(int8_t)((r >> 16) & 0xFF);
+            if (mydbg && lane == 0) mydbg->cand[C].lpc_guess[v] = ((r >> 25) & 1) ? (r & 0xFF) : 0;
+            if (!((r >> 24) & 1)) continue;
+            if (order == 0) order = 1;
+            const int32_t qall = (lane < MAXO) ? B.qres[ridx * MAXO + lane] : 0;
+            double hd[MAXO], qd[MAXO];
+            const double scl = __hiloint2double((int)((1023u - (uint32_t)shift) << 20), 0);      // 2^-shift
+            const double qdl = (double)qall;
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) {
+                q[j] = (int32_t)rl((uint32_t)qall, j);
+                qd[j] = __hiloint2double((int)rl((uint32_t)__double2hiint(qdl), j), (int)rl((uint32_t)__double2loint(qdl), j));
+            }
+#pragma unroll
+            for (int j = 0; j < MAXO; j++) hd[(MAXO - 1 - j) % MAXO] = lane > 0 ? hsamp(1 + j) : 0.0;
+            double psumd = 0.0, pmaxd = 0.0;
+            auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
+                const double xd = samp((int)s);
+                const bool real = !guard || lane > 0 || s >= order;
+                const double rr = xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl);
+                if (real) { psumd += __builtin_fabs(rr); pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
+                hd[u] = xd;
+            };
+            uint32_t s0 = 0;
+            if (seg >= (uint32_t)MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, (uint32_t)u, true);
+                s0 = MAXO;
+            }
+#pragma unroll 1
+            for (; s0 + MAXO <= seg; s0 += MAXO) {
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+            // (a residual must fit int32: libFLAC's test is r <= INT32_MIN || r > INT32_MAX, i.e. |r| < 2^31 passes)
+            if (!(pmaxd < 2147483648.0)) ovf = 1;
+            psum = ovf ? 0ull : (u64)psumd;
+        }
+        const bool dead = __any(ovf != 0);
+        uint32_t best_bits, bpo, kb, kpart;
+        bool kvalid;
+        if (!pipe_rice_search_tree<true>(psum, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb, kpart, kvalid)) {
+            pipe_rice_search<true>(psum, dead, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb);
+            kvalid = ((uint32_t)lane & ((64u >> bpo) - 1)) == 0;
+            kpart = (uint32_t)lane >> (6 - bpo);
+        }
+        uint32_t est = 0;
+        if (!dead) {
+            est = kind == 0 ? (8 + order * sb) : (8 + 4 + 5 + order * (prec + sb));
+            if (best_bits < 0xFFFFFFFFu - est) est += best_bits; else est = 0xFFFFFFFFu;
+            if (est > 0 && est < best) {
+                best = est;
+                d_type = kind == 0 ? 2 : 3; d_order = order; d_prec = prec; d_shift = shift;
+                d_porder = bpo; d_k = kb; d_kpart = kpart; d_kvalid = kvalid;
+                d_method = __any(kvalid && kb >= 15) ? 1 : 0;
+                if (kind == 1) {
+#pragma unroll
+                    for (int j = 0; j < MAXO; j++) bestq[j] = q[j];
+                }
+            }
+        }
+        if (mydbg && lane == 0) {
+            const uint32_t estw = (est == 0 || est > 0xFFFFFFFFu - wst) ? est : est + wst;
+            if (kind == 0) mydbg->cand[C].fixed_bits = estw;
+            else mydbg->cand[C].lpc_bits[pass - 1] = estw;
+        }
+    }
+
+    // ---- the decision record of this candidate (as pipe_eval_cand writes it)
+    best = best > 0xFFFFFFFFu - wst ? 0xFFFFFFFFu : best + wst;
+    FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
+    {
+        uint32_t wv_ = 0;
+        const uint32_t hw[8] = {best, d_type, d_order, d_prec, (uint32_t)d_shift, d_porder, d_method, wraw};
+#pragma unroll
+        for (int j = 0; j < 8; j++) wv_ = lane == j ? hw[j] : wv_;
+#pragma unroll
+        for (int j = 0; j < 12; j++) wv_ = lane == 8 + j ? (j < MAXO ? (uint32_t)bestq[j < MAXO ? j : 0] : 0u) : wv_;
+        if (lane < 20) ((uint32_t *)dec)[lane] = wv_;
+    }
+    if (lane == 0) {
+        FgBlockResult *r = &results[d.out_slot];
+        r->best_bits[C] = best;
+        if (C == 0) {
+            r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
+            if (range_err && B.guard) atomicOr(&B.guard[2], (unsigned long long)range_err);
+#pragma unroll
+            for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
+            for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)d.out_slot * 4 + w] = 0;
+        }
+    }
+    if (d_type >= 2 && d_kvalid) dec->k[d_kpart] = (uint8_t)d_k;
+    if (mydbg) {
+        if (lane == 0) {
+            FgDebugCand *dc = &mydbg->cand[C];
+            dc->wasted = wst; dc->sbps = sb; dc->type = d_type; dc->order = d_type >= 2 ? d_order : 0;
+            dc->precision = d_type == 3 ? d_prec : 0; dc->shift = d_type == 3 ? d_shift : 0;
+            dc->bits = best; dc->porder = d_type >= 2 ? d_porder : 0; dc->rice_method = d_type >= 2 ? d_method : 0;
+            for (uint32_t j = 0; j < FG_MAX_ORDER; j++) dc->qlp[j] = (d_type == 3 && j < d_order && j < (uint32_t)MAXO) ? bestq[j < (uint32_t)MAXO ? j : 0] : 0;
+        }
+        if (d_type >= 2 && d_kvalid) mydbg->cand[C].rice_params[d_kpart] = d_k;
+    }
+}
+
 // (samples above 16 bits are staged as int32: 33 KB of LDS per stereo block let four workgroups share a CU, so those forms
 // may use 128 registers -- the 64 that eight workgroups per CU allow cost them 25 spilled vector registers)
 template <bool MS, int NCH, int MAXO, bool ACC64, bool RAG>
@@ -1589,6 +1891,13 @@ fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const uint32_t range_err = xch[0] ? FG_ERR_RANGE : 0;
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
     // (the ragged geometry -- tail blocks, odd block sizes -- is a kernel of its own: the regular one keeps its loops and registers)
+    if constexpr (ACC64 && !RAG) {
+        // (32-bit streams: a block whose candidates do not fit the shifted 25-bit forms is evaluated in fp64, pipe_eval_cand_w32)
+        if (P.bps == 32 && !pre_ok) {
+            pipe_eval_cand_w32<MS, NCH, MAXO>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, (const LDS int32_t *)sL, (const LDS int32_t *)sR, lane, range_err);
+            return;
+        }
+    }
     pipe_eval_cand<MS, NCH, MAXO, ACC64, RAG>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, sL, sR, lane, range_err, geo, pre, pre_ok);
 }
 
@@ -1792,6 +2101,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     pipe_cand_coef(MS, c, cca, ccb, ccs);
     const uint32_t csh = (wraw & 0x100u) ? ccs : ccs + wst - pre;
     auto cand = [&](int32_t l, int32_t r) -> int32_t { return pipe_cand(l, r, cca, ccb, csh); };
+    // (true 32-bit content, pipe_eval_cand_w32: the candidate's samples as doubles -- up to 33 bits -- instead of 24-bit integer forms)
+    const bool w32 = ACC64 && !RAG && P.bps == 32 && !pre_ok;
+    const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);
+    auto candd = [&](int32_t l, int32_t r) -> double { return pipe_cdbl(l, r, c, MS, wscale); };
     if (hf == 0) {
         // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes
         // 1..order = warm-up samples, then precision/shift, coefficients, coding method + partition order
@@ -1811,7 +2124,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         }
         else if ((uint32_t)lane <= nw) {
             const uint32_t g = (uint32_t)lane - 1;             // sample index (inside segment 0: order <= MAXO <= seg)
-            val = (uint32_t)cand(sL[g], (NCH == 2) ? (int32_t)sR[g] : 0) & mask; vb = sb;
+            if (ACC64 && w32) {
+                const i64 xi = (i64)candd(sL[g], (NCH == 2) ? (int32_t)sR[g] : 0);
+                if (sb == 33) { pv = (uint32_t)((u64)xi >> 32) & 1u; pb = 1; val = (uint32_t)xi; vb = 32; }       // (a 33-bit field: its top bit, then the rest)
+                else { val = (uint32_t)xi & mask; vb = sb; }
+            }
+            else { val = (uint32_t)cand(sL[g], (NCH == 2) ? (int32_t)sR[g] : 0) & mask; vb = sb; }
         }
         else if (type == 3 && (uint32_t)lane == order + 1) { pv = prec - 1; pb = 4; val = (uint32_t)shift & 31; vb = 5; }
         else if (type == 3 && (uint32_t)lane <= 2 * order + 1) { val = (uint32_t)dec->q[lane - order - 2] & ((1u << prec) - 1); vb = prec; }
@@ -1861,12 +2179,16 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
+                double xdh = 0.0;
                 if (Lg > 0) {
                     if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
-                    else x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                    else {
+                        x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                        if (ACC64 && w32) xdh = candd(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                    }
                 }
                 h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
-                if constexpr (FGP_F64P && ACC64) hd[(MAXO - 1 - j) % MAXO] = (double)x;
+                if constexpr (FGP_F64P && ACC64) hd[(MAXO - 1 - j) % MAXO] = w32 ? xdh : (double)x;
             }
             uint32_t pos = p0, len = 0;
             // Emission without LDS atomics: a lane's bits are consecutive, so it keeps the word it is filling in a register
@@ -1899,13 +2221,21 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             const uint32_t kmask = (1u << kr) - 1, kone = 1u << kr;
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
                 const int32_t x = cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
-                uint32_t val, vb, lead;
-                if (verb) { val = (uint32_t)x & mask; vb = sb; lead = 0; }
+                uint32_t val, vb, lead, topv = 0, topb = 0;          // (topv / topb: the 33rd bit of a verbatim sample of a 33-bit side channel)
+                if (verb) {
+                    if (ACC64 && w32) {
+                        const i64 xi = (i64)candd(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
+                        if (sb == 33) { topv = (uint32_t)((u64)xi >> 32) & 1u; topb = 1; val = (uint32_t)xi; vb = 32; }
+                        else { val = (uint32_t)xi & mask; vb = sb; }
+                    }
+                    else { val = (uint32_t)x & mask; vb = sb; }
+                    lead = 0;
+                }
                 else {
                     int32_t res;
                     if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
                     else if constexpr (FGP_F64P) {
-                        const double xd = (double)x;
+                        const double xd = w32 ? candd(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0) : (double)x;
                         res = (int32_t)(xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl));
                         hd[u] = xd;
                     }
@@ -1915,6 +2245,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                     lead = uu >> kr;
                     val = kone | (uu & kmask);
                     vb = kr + 1;
+                }
+                if (ACC64 && topb) {
+                    if (emit) put(pos, topv, 1);
+                    pos += 1; len += 1;
                 }
                 if (guard) {
                     const bool coded = s >= skip;

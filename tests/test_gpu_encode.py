@@ -598,8 +598,8 @@ def test_24_bit_material_in_32_bit_container_stays_in_the_pipeline(ctx, level):
 
 def test_32_bit_streams_mixed_content(ctx):
     """A 32-bit stereo stream whose blocks differ: 24-bit material (pipeline), one channel silent, both silent, 16-bit material
-    (sixteen shared wasted bits), true 32-bit noise (generic kernel), L == R (a zero side channel).  Every frame the oracle's;
-    exactly the two blocks of true 32-bit content are handed over."""
+    (sixteen shared wasted bits), true 32-bit noise (the pipeline's fp64 forms, round 4), L == R (a zero side channel).  Every frame the
+    oracle's; only the ragged tail of true 32-bit content is handed to the generic kernel."""
     import torch
     from pyflac_amd import batch
     from oracle import oracle as O
@@ -626,7 +626,7 @@ def test_32_bit_streams_mixed_content(ctx):
         want, sizes = O.encode_stream(cfg, arr)
         assert list(np.diff(offs.cpu().numpy())) == list(sizes)
         assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
-        assert st.redo_blocks == 2                       # (the block and the tail of true 32-bit content)
+        assert st.redo_blocks == 1                       # (the 777-sample tail of true 32-bit content: ragged geometry)
 
 
 def test_32_bit_mono_and_many_channels_with_shared_wasted_bits(ctx):
