@@ -11,17 +11,26 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root, workload, blocks, level = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-RND = sys.argv[5] if len(sys.argv) > 5 else 'r03'
+RND = sys.argv[5] if len(sys.argv) > 5 else 'r04'
 
 
 def per_kernel(sub, name):
+    """Counter total per LAUNCH and kernel: since round 4 a launch may dispatch a kernel more than once (the encoder's two groups,
+    pipe_shape.inc), so the dispatches of a pass are summed and divided by the number of launches in it -- the dispatch count of a
+    kernel that runs exactly once per launch (the assembly kernel for encode launches, the header pass for decode launches)."""
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(root, sub, '*counter_collection.csv')):
         for row in csv.DictReader(open(f)):
             if row.get('Counter_Name') == name:
                 k = row.get('Kernel_Name', '').split('(anonymous namespace)::')[-1].split('(')[0]
                 acc[k].append(float(row['Counter_Value']))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    once_enc = max([len(v) for k, v in acc.items() if k.startswith('fg_pipe_assemble_kernel')] or [0])
+    once_dec = max([len(v) for k, v in acc.items() if k.startswith('fg_dec_headers_kernel')] or [0])
+    out = {}
+    for k, v in acc.items():
+        launches = once_enc if (k.startswith('fg_pipe_') or k.startswith('fg_scan_') or k.startswith('fg_encode')) else (once_dec if k.startswith('fg_dec') else 0)
+        out[k] = sum(v) / launches if launches else sum(v) / len(v)
+    return out
 
 
 fetch, write, valu = per_kernel('pmc3', 'FETCH_SIZE'), per_kernel('pmc4', 'WRITE_SIZE'), per_kernel('pmc1', 'SQ_INSTS_VALU')
