@@ -223,6 +223,17 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
             R = 0;
         }
     };
+    // The same sample as it lies in memory, no arithmetic on it: what the chunk loop fetches a chunk ahead.  (ldsamp's sign
+    // extension of a 16-bit pair sits right behind the load, and the compiler's s_waitcnt vmcnt(0) with it -- in front of the
+    // chain the load was meant to travel under: every chunk then waited out two HBM latencies.)  unraw() makes L and R of it at
+    // the point of use; zeros stay zeros.
+    auto ldraw = [&](uint32_t i, int32_t &a, int32_t &b) __attribute__((always_inline)) {
+        if (NCH == 2 && P.pcm_i16) { a = ((const int32_t *)pcm)[d.pcm_off + i]; b = 0; }
+        else ldsamp(i, a, b);
+    };
+    auto unraw = [&](int32_t &L, int32_t &R) __attribute__((always_inline)) {
+        if (NCH == 2 && P.pcm_i16) { R = L >> 16; L = (int32_t)(int16_t)L; }
+    };
     // candidate c of a sample as the float libFLAC windows (FLAC__lpc_window_data: the integer converted to float, one rounding)
     // and the bits its wasted-bits count looks at.  32-bit input: mid needs a 33-bit sum and the side channel IS 33 bits wide
     // (libFLAC keeps it in 64 bits and windows it with FLAC__lpc_window_data_wide); the low 32 bits decide the trailing zeros.
@@ -273,7 +284,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t i = k0 + u * 64 + lane;
                             wv[u] = window[i];
-                            ldsamp(i, xl[u], xr[u]);
+                            ldraw(i, xl[u], xr[u]);
                         }
                         return;
                     }
@@ -289,7 +300,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                             else if (i < part) { w = window[i]; s_ = sh + i; }
                             else if (i < 2 * part) { w = window[n - 2 * part + i]; s_ = sh + i; }
                             else any = false;
-                            if (any) ldsamp(s_, L, R);
+                            if (any) ldraw(s_, L, R);
                         }
                         wv[u] = w; xl[u] = L; xr[u] = R;
                     }
@@ -302,11 +313,12 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t j = u * 64 + lane;
                             if (P.debug != 102) {       // (behind the end of the signal the fetch gave zeros: the chains run on a little)
-                                const int32_t L = xl[u], R = xr[u];
+                                int32_t L = xl[u], R = xr[u];
+                                unraw(L, R);
 #pragma unroll
                                 for (int c = 0; c < NC; c++) {
                                     const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
-                                    if (nv == 0) orv[c] |= (uint32_t)x;
+                                    orv[c] |= (uint32_t)x;       // (windows after the first see samples the first has seen: the OR stands)
                                     dbuf[c * FGP_CSTR + FGP_DH + j] = (double)((float)x * wv[u]);
                                 }
                             }
@@ -317,7 +329,8 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t j = u * 64 + lane;
                             if (P.debug != 102) {
-                                const int32_t L = xl[u], R = xr[u];
+                                int32_t L = xl[u], R = xr[u];
+                                unraw(L, R);
                                 const bool zero = part != 0 && (k0 + j) >= 2 * part;
 #pragma unroll
                                 for (int c = 0; c < NC; c++) {
