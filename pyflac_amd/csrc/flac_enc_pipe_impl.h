@@ -42,7 +42,7 @@
 #define FGI __device__ __forceinline__
 
 #define FGP_F64P 1                       // packing: the same (with the 168 registers that three workgroups per CU leave: 24-bit level 8 0.28 -> 0.25 ms)
-#define FGP_F64 1                        // evaluation: residuals of 17..25-bit samples through fp64 FMAs (pfir_f64; 0 = pfir48)
+#define FGP_F64 1                        // evaluation: residuals of 17..25-bit samples through fp64 FMAs (pfir_f64n; 0 = pfir48)
 #define FGP_DH 16                        // autocorrelation: history doubles kept in front of each chunk (>= max lag + 1)
 #define FGP_CK 128                       // autocorrelation: chunk length
 // doubles per candidate row: 304 words, i.e. 48 banks (of 64) from row to row -- the four candidate rows that share a
@@ -144,10 +144,22 @@ template <int MAXO> FGI i64 pfir48(const int32_t (&q)[MAXO], const int32_t (&h)[
 // The same sum in fp64: samples below 2^25 and coefficients below 2^15 give products below 2^40 and sums of twelve below
 // 2^44 -- every fused multiply-add is exact, one instruction per tap (v_fma_f64 runs at the rate of the 32-bit integer
 // operations on this chip; the two 16-bit chains above take two).  Two chains of half the taps each, for the latency.
-template <int MAXO> FGI double pfir_f64(const double (&q)[MAXO], const double (&h)[MAXO], int u)
+// The sum of the taps in fp64 on top of `init`, one chain or two (FGP_F64_CH): the evaluation and the packer start it at -x with the
+// coefficients scaled by 2^-shift -- x - floor(p 2^-shift) = -floor(p 2^-shift - x), x being an integer --, which saves the
+// scaling and the subtraction of every sample.  Everything is a multiple of 2^-shift below 2^44: every step is exact, in any order.
+#ifndef FGP_F64_CH
+#define FGP_F64_CH 1
+#endif
+template <int MAXO> FGI double pfir_f64n(const double (&q)[MAXO], const double (&h)[MAXO], int u, double init)
 {
-    double a = 0.0, b = 0.0;
 #define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
+    if (FGP_F64_CH == 1) {
+        double a = init;
+#pragma unroll
+        for (int j = MAXO - 1; j >= 0; j--) a = __builtin_fma(q[j], FG_H(j), a);
+        return a;
+    }
+    double a = init, b = 0.0;
 #pragma unroll
     for (int j = MAXO - 1; j >= MAXO / 2; j--) a = __builtin_fma(q[j], FG_H(j), a);
 #pragma unroll
@@ -1443,10 +1455,10 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rl((uint32_t)qall, j);
             // ---- FIR over the segment: history in registers, statically indexed (the loop is unrolled by its length)
             int32_t h[MAXO];
-            double hd[MAXO], qd[MAXO];          // (17..25-bit samples: history and coefficients as doubles, pfir_f64)
+            double hd[MAXO], qd[MAXO];          // (17..25-bit samples: history and coefficients as doubles, pfir_f64n)
             const double scl = __hiloint2double((int)((1023u - (uint32_t)shift) << 20), 0);      // 2^-shift
             if constexpr (FGP_F64 && ACC64) {
-                const double qdl = (double)qall;
+                const double qdl = (double)qall * scl;         // (scaled in the lane that holds it: what is read out of it stays in SGPRs)
 #pragma unroll
                 for (int j = 0; j < MAXO; j++) qd[j] = __hiloint2double((int)rl((uint32_t)__double2hiint(qdl), j), (int)rl((uint32_t)__double2loint(qdl), j));
             }
@@ -1471,8 +1483,9 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                     // The lane's sum and maximum of |residual| stay in fp64 -- v_add_f64 and v_max_f64 with the |x| modifier instead of
                     // a conversion, an absolute value, a 64-bit integer add and the two-sided range test of every residual; a residual
                     // is outside the 32-bit range exactly when its magnitude reaches 2^31 (libFLAC's _limit_residual test)
+                    // (qd carries the scaling; the chain starts at -x: what comes out of the floor is minus the residual, pfir_f64n)
                     const double xd = (double)x;
-                    const double rr = xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl);
+                    const double rr = __builtin_floor(pfir_f64n<MAXO>(qd, hd, u, -xd));
                     if (real) { psumd += __builtin_fabs(rr); pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
                     res = 0;
                     hd[u] = xd;
@@ -1776,7 +1789,7 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             const int32_t qall = (lane < MAXO) ? B.qres[ridx * MAXO + lane] : 0;
             double hd[MAXO], qd[MAXO];
             const double scl = __hiloint2double((int)((1023u - (uint32_t)shift) << 20), 0);      // 2^-shift
-            const double qdl = (double)qall;
+            const double qdl = (double)qall * scl;
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 q[j] = (int32_t)rl((uint32_t)qall, j);
@@ -1788,7 +1801,7 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
                 const double xd = samp((int)s);
                 const bool real = !guard || lane > 0 || s >= order;
-                const double rr = xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl);
+                const double rr = __builtin_floor(pfir_f64n<MAXO>(qd, hd, u, -xd));          // (minus the residual)
                 if (real) { psumd += __builtin_fabs(rr); pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
                 hd[u] = xd;
             };
@@ -2177,7 +2190,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         const double scl = __hiloint2double((int)((1023u - (uint32_t)shift) << 20), 0);      // 2^-shift
         if constexpr (FGP_F64P && ACC64) {
 #pragma unroll
-            for (int j = 0; j < MAXO; j++) qd[j] = (double)q[j];
+            for (int j = 0; j < MAXO; j++) qd[j] = (double)q[j] * scl;       // (scaled: pfir_f64n)
         }
         const uint32_t plen = method ? 5 : 4;
         const uint32_t lpp = LPS >> po;                                  // lanes per partition
@@ -2188,7 +2201,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             constexpr bool verb = decltype(VERB)::value, emit = decltype(EMIT)::value, atom = decltype(ATOM)::value;
             const bool inrange = decltype(ALLF)::value ? true : inrange_;
             int32_t h[MAXO];
-            double hd[MAXO];                    // (17..25-bit samples: pfir_f64, as in the evaluation)
+            double hd[MAXO];                    // (17..25-bit samples: pfir_f64n, as in the evaluation)
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
@@ -2249,7 +2262,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                     if constexpr (!ACC64) res = x - (pfir24<MAXO>(q, h, u) >> shift);
                     else if constexpr (FGP_F64P) {
                         const double xd = w32 ? candd(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0) : (double)x;
-                        res = (int32_t)(xd - __builtin_floor(pfir_f64<MAXO>(qd, hd, u) * scl));
+                        res = (int32_t)(-__builtin_floor(pfir_f64n<MAXO>(qd, hd, u, -xd)));
                         hd[u] = xd;
                     }
                     else res = (int32_t)((i64)x - (pfir48<MAXO>(q, h, u) >> shift));
