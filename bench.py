@@ -578,7 +578,15 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
         # the ceiling these integer kernels actually run against: VALU issue (one wave-instruction per 2 cycles and SIMD,
         # fp64 4 cycles), 1024 SIMDs at 2.4 GHz; instruction counts from the committed PMC pass of this same command
         slots = 1024 * 2.4e9 / 2
+        # (tools/ubench/valurate.hip on this chip, 8 waves a SIMD, independent instructions: add / sub / logic / shift / v_mov_b32 /
+        # fp32 FMA issue in 2.5-3.1 cycles a wave-instruction, everything else -- every multiply, the three-operand integer
+        # operations, conversions, min / max, DPP, SDWA, 64-bit moves, fp64 -- in 4.2-4.6: `frac_bounds` prices all instructions
+        # of the launch at 2.5 and at 4.3 cycles)
+        def bounds(n, t_ms):
+            return [round(n * c / (t_ms * 1e-3 * 1024 * 2.4e9), 4) for c in (2.5, 4.3)] if n else None
         res['issue_ceiling'] = {'unit': 'VALU wave-instructions/s', 'peak': slots,
+                                'encode_frac_bounds': bounds(pmc['encode_valu_insts_per_launch'], enc_t),
+                                'decode_frac_bounds': bounds(pmc.get('decode_valu_insts_per_launch'), dec_t),
                                 'encode_valu_insts_per_launch': pmc['encode_valu_insts_per_launch'],
                                 'encode_frac': round(pmc['encode_valu_insts_per_launch'] / (enc_t * 1e-3) / slots, 4),
                                 'decode_valu_insts_per_launch': pmc.get('decode_valu_insts_per_launch'),
