@@ -109,6 +109,14 @@ __device__ __forceinline__ uint32_t crc16_s(uint32_t u)          // u * x^16 mod
     const uint32_t p = (uint32_t)__popc(u) & 1u;
     return (((u << 1) ^ (u << 2)) & 0xFFFFu) ^ ((0u - p) & 0x8003u) ^ ((0u - ((u >> 15) & 1u)) & 0x000Au) ^ ((0u - ((u >> 14) & 1u)) & 0x8005u);
 }
+// s * x^8192 mod P for a 16-bit s: x^8192 = x^8 + x^4 + x (0x0112), so the product has 24 bits and its top byte v folds back the
+// way a byte of data does, v * x^16 = parity(v) * 0x8003 ^ v << 1 ^ v << 2 (checked against gf16_mul over all 65536 values):
+// twelve instructions where the general multiplication takes sixty.
+__device__ __forceinline__ uint32_t crc16_mul_x8192(uint32_t s)
+{
+    const uint32_t t = (s << 8) ^ (s << 4) ^ (s << 1), v = t >> 16;
+    return (t & 0xFFFFu) ^ ((0u - ((uint32_t)__popc(v) & 1u)) & 0x8003u) ^ (v << 1) ^ (v << 2);
+}
 __device__ __forceinline__ uint32_t crc16_word(uint32_t c, uint32_t w) { return crc16_s(crc16_s(c ^ (w >> 16)) ^ (w & 0xFFFFu)); }
 __device__ __forceinline__ uint32_t crc16_byte(uint32_t c, uint32_t b)
 {

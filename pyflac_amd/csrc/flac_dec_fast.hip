@@ -663,7 +663,9 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
 // (checked over all 65536 values), so a 32-bit word w takes the state c to S(S(c ^ w >> 16) ^ (w & 0xFFFF)) in ~30 VALU
 // instructions and no LDS look-up; the table version did six look-ups per word, at random addresses, beside a parser whose
 // walks live on LDS.  Lanes own interleaved 16-byte granules (one unaligned 16-byte load a step): state * x^8192 + crc(granule),
-// folded at the end with x^(128 (63 - lane)) (six conditional multiplications by constants).
+// folded at the end with x^(128 (63 - lane)) (one multiplication by a constant out of a table).  Round 4: the per-step factor
+// x^8192 has a closed form of its own (crc16_mul_x8192), and the remainder of the bytes in front of the first aligned word rides
+// along as a granule in front of granule 0 instead of being raised to x^(128 G) by repeated squaring -- 1200 instructions a frame.
 #endif  // FG_LEGACY
 __global__ void __launch_bounds__(256)
 fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, const uint16_t *crctab)
@@ -683,41 +685,32 @@ fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfra
     const uint32_t W = (nbytes - hb) >> 2, tail = (nbytes - hb) & 3;
     const uint32_t G = W >> 2, Wr = W & 3;
     const uint32_t *wptr = (const uint32_t *)(fp + hb);
-    const uint32_t pad = (64 - (G & 63)) & 63, T = (G + pad) >> 6;
+    // crc(head || body) = crc(head) * x^(128 G) + crc(body): the head's remainder takes the place of a granule in front of granule 0
+    // (lane pad - 1 of the first step; a step more when the granules fill their first step) and rides through the same folds
+    uint32_t hcrc = 0;
+    for (uint32_t b = 0; b < hb; b++) hcrc = crc16_byte(hcrc, fp[b]);
+    const uint32_t pad0 = (64 - (G & 63)) & 63;
+    const uint32_t pad = (hb && G && pad0 == 0) ? 64u : pad0, T = (G + pad) >> 6;
     uint32_t s = 0;
     for (uint32_t t = 0; t < T; t++) {
         const int qi = (int)(t * 64 + lane) - (int)pad;
         fg_crc_u32x4 g = {0, 0, 0, 0};
         if (qi >= 0) g = *(const fg_crc_u32x4 *)(wptr + 4 * qi);
-        s = gf16_mul(s, 0x0112u);                                 // x^8192: the 64 granules of a step
+        s = crc16_mul_x8192(s);                                   // x^8192: the 64 granules of a step
         uint32_t c = crc16_word(0, be32(g.x));
         c = crc16_word(c, be32(g.y)); c = crc16_word(c, be32(g.z)); c = crc16_word(c, be32(g.w));
+        if (qi == -1) c = hcrc;
         s ^= c;
     }
-    {
-        // x^(128 (63 - lane)): the granules behind this lane's last one
-        const uint32_t e = 63 - (uint32_t)lane;
-        const uint32_t bp[6] = {0x0106u, 0x8011u, 0x8107u, 0x0016u, 0x0114u, 0x8115u};      // x^128, x^256, ... x^4096
-        uint32_t m = 1;
-#pragma unroll
-        for (int b = 0; b < 6; b++) if ((e >> b) & 1) m = m == 1 ? bp[b] : gf16_mul(m, bp[b]);
-        if (e) s = gf16_mul(s, m);
-    }
-    uint32_t body = wave_xor32(s);
-    // crc(head || body) = crc(head) * x^(128 G) + crc(body): fold the head in by running it through G zero granules
-    uint32_t crc = 0;
-    for (uint32_t b = 0; b < hb; b++) crc = crc16_byte(crc, fp[b]);
-    if (hb && G) {
-        uint32_t base = 0x0106u, e = G, acc = 1;     // x^128
-        bool first = true;
-        while (e) {
-            if (e & 1) { acc = first ? base : gf16_mul(acc, base); first = false; }
-            base = gf16_mul(base, base);
-            e >>= 1;
-        }
-        crc = gf16_mul(crc, acc);
-    }
-    crc ^= body;
+    // x^(128 (63 - lane)): the granules behind this lane's last one
+    static const uint16_t fold[64] = {
+        0xB7B3, 0x9259, 0x831B, 0x0105, 0xDB58, 0x6481, 0xF3CE, 0x3964, 0xF11D, 0xCACD, 0x5C80, 0xB2F1, 0xA1F5, 0xB59F, 0x348E, 0x033E,
+        0x1164, 0x127C, 0x937A, 0xC821, 0x2CA3, 0x5F6E, 0xE609, 0x9717, 0xDDD9, 0x015A, 0x33A8, 0x125E, 0x27C2, 0x934F, 0x1072, 0x8115,
+        0x136A, 0x0013, 0x4831, 0xE491, 0x3BFC, 0x5DF6, 0x4AE2, 0x1738, 0x9661, 0x25CA, 0xB797, 0x1056, 0x031A, 0x936B, 0x927D, 0x0114,
+        0x8104, 0x4936, 0x2DA4, 0x965B, 0x4BAE, 0x814F, 0x1674, 0x0016, 0xA5DF, 0x924B, 0x021E, 0x8107, 0x926F, 0x8011, 0x0106, 0x0001};
+    if (T) s = gf16_mul(s, fold[lane]);
+    const uint32_t body = wave_xor32(s);
+    uint32_t crc = G ? body : hcrc;
     for (uint32_t k = 0; k < Wr; k++) crc = crc16_word(crc, be32(wptr[4 * G + k]));
     for (uint32_t b = 0; b < tail; b++) crc = crc16_byte(crc, fp[hb + W * 4 + b]);
     const uint32_t stored = ((uint32_t)fp[nbytes] << 8) | fp[nbytes + 1];
