@@ -354,10 +354,14 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                         const u64 chm = __ballot(changed);
                         if (chm == 0) break;
                         if (maybe_end) {
-                            // lanes in front of the first changed one are final: if they cover the rest of the partition, stop
+                            // lanes in front of the first changed one are final: if they cover the rest of the partition, stop.  (A lane
+                            // holds at most ceil(B / (k + 1)) codes: the prefix sum is only worth its fourteen instructions when that
+                            // many codes a lane in front of the first changed one could reach what is left)
                             const uint32_t first = (uint32_t)__builtin_ctzll(chm);
-                            const uint32_t pf = wave_scan_add(cnt) - cnt;
-                            if (rl(pf, (int)first) >= Rb) break;
+                            if (first * (B + k) >= Rb * kp1) {
+                                const uint32_t pf = wave_scan_add(cnt) - cnt;
+                                if (rl(pf, (int)first) >= Rb) break;
+                            }
                         }
                         n_rounds++;
                         if (changed) {
@@ -368,22 +372,45 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                     const uint32_t incl = wave_scan_add(cnt);
                     const uint32_t pfx = incl - cnt;
                     const uint32_t total = rl(incl, 63);
-                    // ---- output walk: residuals into the LDS buffer by sample index
-                    uint32_t hardidx = 0xFFFFFFFFu, hardq = 0;
+                    // ---- output walk: residuals into the LDS buffer by sample index.  Twenty instructions a code: the window from the stop
+                    // bit on (bit 0 = stop bit, bits 1..k = the remainder, first bit lowest) reversed puts the remainder at bits
+                    // 31-k..30 in order -- one v_bfe_u32 --; codes past what the batch delivers (lanes behind the partition's end,
+                    // counts inflated by zero runs) are not walked at all -- a lane stops behind code Rb - 1, which also tells where
+                    // the next partition starts --; of the long codes only the longest run of zeros is tracked here (one v_max_u32), the lane that
+                    // met one walks again below to say which code it was.
+                    uint32_t hardidx = 0xFFFFFFFFu, hardq = 0, endq_out = 0;
                     {
-                        uint32_t q = q0 + e, idx = pfx;
-                        int16_t *const out16 = (int16_t *)outb;
-                        while (q < hi) {
+                        uint32_t q = q0 + e, lzmax = 0;
+                        const uint32_t esz = o16 ? 2u : 4u;
+                        const uint32_t ob = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int32_t *)outb;
+                        uint32_t at = ob + pfx * esz;
+                        const uint32_t atend = ob + Rb * esz;       // (a lane stops behind code Rb - 1: its q is then where the next partition starts)
+                        const uint32_t kw = 31u - k;
+                        while (q < hi && at < atend) {
                             const uint32_t win = row_win(row, q);
                             const uint32_t lz = win ? (uint32_t)__builtin_ctz(win) : 32u;
-                            uint32_t remw = (win >> (lz & 31)) >> 1;                  // the bits behind the stop bit
-                            if (lz + kp1 > 32) remw = row_win(row, q + (lz < 32 ? lz : 31u) + 1);      // ... when they do not lie in the window
-                            const uint32_t rem = (__builtin_bitreverse32(remw) >> 1) >> (31 - k);
+                            const uint32_t adv = lz + kp1;
+                            uint32_t t = win >> (lz & 31);
+                            if (adv > 32) t = row_win(row, q + (lz < 32 ? lz : 31u));          // ... when the remainder does not lie in the window
+                            const uint32_t rem = __builtin_amdgcn_ubfe(__builtin_bitreverse32(t), kw, k);
                             const int32_t val = unzig((lz << k) | rem);
-                            if (lz >= hardlz && hardidx == 0xFFFFFFFFu) { hardidx = idx; hardq = q - q0; }
-                            if (idx < Rb) { if (o16) out16[idx] = (int16_t)val; else outb[idx] = val; }
-                            q += lz + kp1;
-                            idx++;
+                            lzmax = lz > lzmax ? lz : lzmax;
+                            if (o16) *(__attribute__((address_space(3))) int16_t *)(uintptr_t)at = (int16_t)val;
+                            else *(__attribute__((address_space(3))) int32_t *)(uintptr_t)at = val;
+                            q += adv;
+                            at += esz;
+                        }
+                        endq_out = q - q0;
+                        if (__any(lzmax >= hardlz)) {
+                            // (rare: a code of 32 and more zeros, or one whose value outgrows the 16-bit buffer) which code, and where
+                            uint32_t q2 = q0 + e, idx = pfx;
+                            while (q2 < hi) {
+                                const uint32_t win = row_win(row, q2);
+                                const uint32_t lz = win ? (uint32_t)__builtin_ctz(win) : 32u;
+                                if (lz >= hardlz && hardidx == 0xFFFFFFFFu) { hardidx = idx; hardq = q2 - q0; }
+                                q2 += lz + kp1;
+                                idx++;
+                            }
                         }
                     }
                     const uint32_t lim = total < Rb ? total : Rb;
@@ -449,20 +476,11 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
                         si += hmin + 1; R -= hmin + 1; pos = hp;
                     }
                     else if (total >= Rb) {
-                        // the batch reaches the end of the partition (or fills the buffer): the lane that owns code Rb - 1 walks up to
-                        // it once more and says where the next code starts
+                        // the batch reaches the end of the partition (or fills the buffer): the lane that owns code Rb - 1 stopped its
+                        // output walk behind it and says where the next code starts
                         const bool own = pfx < Rb && Rb <= pfx + cnt;
-                        uint32_t endq = 0;
-                        if (own) {
-                            uint32_t q = q0 + e;
-                            for (uint32_t j = pfx; j < Rb; j++) {
-                                const uint32_t win = row_win(row, q);
-                                q += (win ? (uint32_t)__builtin_ctz(win) : 32u) + kp1;
-                            }
-                            endq = q - q0;
-                        }
                         const int L = (int)__builtin_ctzll(__ballot(own));
-                        pos = pos + B * (uint32_t)L + rl(endq, L);
+                        pos = pos + B * (uint32_t)L + rl(endq_out, L);
                         si += Rb; R -= Rb;
                     }
                     else {
