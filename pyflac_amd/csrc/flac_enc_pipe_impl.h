@@ -83,20 +83,21 @@ FGI uint32_t psad(uint32_t a, uint32_t b, uint32_t c)
 // the MAXO coefficients are wave-uniform and fit the scalar file).  History slot of sample s is s mod MAXO.
 template <int MAXO> FGI int32_t pfir24(const int32_t (&q)[MAXO], const int32_t (&h)[MAXO], int u)
 {
-    int32_t sm = 0;
+    // (the first tap is a multiply into a register of its own: a sum that starts as a zero costs a v_mov_b32 a sample)
+    int32_t sm;
 #define FG_H(j) h[(u - 1 - (j) + 2 * MAXO) % MAXO]
     if (MAXO == 8) {
-        asm("v_mad_i32_i24 %0, %1, %9, %0\n\tv_mad_i32_i24 %0, %2, %10, %0\n\tv_mad_i32_i24 %0, %3, %11, %0\n\t"
+        asm("v_mul_i32_i24 %0, %1, %9\n\tv_mad_i32_i24 %0, %2, %10, %0\n\tv_mad_i32_i24 %0, %3, %11, %0\n\t"
             "v_mad_i32_i24 %0, %4, %12, %0\n\tv_mad_i32_i24 %0, %5, %13, %0\n\tv_mad_i32_i24 %0, %6, %14, %0\n\t"
             "v_mad_i32_i24 %0, %7, %15, %0\n\tv_mad_i32_i24 %0, %8, %16, %0"
-            : "+v"(sm)
+            : "=&v"(sm)
             : "s"(q[7 % MAXO]), "s"(q[6 % MAXO]), "s"(q[5 % MAXO]), "s"(q[4 % MAXO]), "s"(q[3 % MAXO]), "s"(q[2 % MAXO]), "s"(q[1 % MAXO]), "s"(q[0]),
               "v"(FG_H(7)), "v"(FG_H(6)), "v"(FG_H(5)), "v"(FG_H(4)), "v"(FG_H(3)), "v"(FG_H(2)), "v"(FG_H(1)), "v"(FG_H(0)));
     }
     else {
-        asm("v_mad_i32_i24 %0, %1, %7, %0\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
+        asm("v_mul_i32_i24 %0, %1, %7\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
             "v_mad_i32_i24 %0, %4, %10, %0\n\tv_mad_i32_i24 %0, %5, %11, %0\n\tv_mad_i32_i24 %0, %6, %12, %0"
-            : "+v"(sm)
+            : "=&v"(sm)
             : "s"(q[11 % MAXO]), "s"(q[10 % MAXO]), "s"(q[9 % MAXO]), "s"(q[8 % MAXO]), "s"(q[7 % MAXO]), "s"(q[6 % MAXO]),
               "v"(FG_H(11)), "v"(FG_H(10)), "v"(FG_H(9)), "v"(FG_H(8)), "v"(FG_H(7)), "v"(FG_H(6)));
         asm("v_mad_i32_i24 %0, %1, %7, %0\n\tv_mad_i32_i24 %0, %2, %8, %0\n\tv_mad_i32_i24 %0, %3, %9, %0\n\t"
