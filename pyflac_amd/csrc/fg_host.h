@@ -70,7 +70,7 @@ int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const 
                             unsigned long long *d_counters, hipStream_t stream, int plane16);
 int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                               const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                              hipStream_t stream, int plane16);
+                              hipStream_t stream, int plane16, FgDecResult *h_rows);
 int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                            int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
                            int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream);

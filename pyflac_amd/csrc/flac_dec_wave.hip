@@ -906,7 +906,7 @@ __device__ __forceinline__ void wr16_tile(int32_t (&h)[16], const int32_t (&q)[1
 template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256)
 fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
-                       int32_t *out, FgDecResult *results, uint32_t interleave)
+                       int32_t *out, FgDecResult *results, uint32_t interleave, FgDecResult *host_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
     uint32_t *const tiles = wsm;                                   // WR_NB x 64 rows x 64 words
@@ -963,14 +963,17 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     }
     __syncthreads();
     // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])
+    // (host_rows: the status words go to the host's pinned copy from here -- the call then ends with the few words of
+    // fg_signal_kernel instead of a pass over all frames' words, fg_export_kernel: 10 us of a decode launch)
     if (wave == 0 && mine && ch == 0 && !(interleave & 0x800)) {
         const FgDecFrame fr = frames[f];
+        uint32_t status = results[f].err, cw = results[f].crc;
         if (fr.bytes != 0 && fr.channels == C && fr.n != 0) {
-            uint32_t status = results[f].err;
-            const uint32_t cw = results[f].crc;
             if (status == 0 && (cw & 0x80000000u)) status = 2;
-            results[f].err = status; results[f].crc = cw & 0xFFFFu;
+            cw &= 0xFFFFu;
+            results[f].err = status; results[f].crc = cw;
         }
+        if (host_rows) { FgDecResult r; r.err = status; r.crc = cw; host_rows[f] = r; }
     }
     const uint32_t nmax = ctl[0];
     const bool stereo_fast = ctl[2] != 0;
@@ -1210,7 +1213,7 @@ extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_
 // Same contract as fg_launch_decode_finish (flac_dec_fast.hip), without the profile words.
 extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                                          const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                                         hipStream_t stream, int plane16)
+                                         hipStream_t stream, int plane16, FgDecResult *h_rows)
 {
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
@@ -1222,8 +1225,8 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true, false>
                           : (plane16 ? (const void *)fg_dec_wrestore_kernel<false, true> : (const void *)fg_dec_wrestore_kernel<false, false>);
     if (fg_func_set_lds(fn, lds) != 0) return -1;
-    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
-    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
-    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave);
+    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows);
+    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows);
+    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows);
     return (int)hipGetLastError();
 }

@@ -516,7 +516,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // (measured: beside the restore kernel the CRC pass slows that kernel's lone recurrence waves down by more than it gave
     // the parse kernel back -- 136 + 159 us against 123 + 163 --, so it stays beside the parse kernel; FLACGPU_DEC_CRC_LATE=1 tries
     // the other order)
-    static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 2;
+    // (round 4, late: the CRC pass lost more than half its instructions and now ends before the parser; waiting for it in front of
+    // the restore kernel is free -- mode 0, the default since --, the restore kernel merges the verdict itself and, in a call
+    // without events, sends the status words to the host on the way)
+    static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 0;
     const bool crc_late = crc_late_mode == 1 && wave_parse && !old_restore && !fused;
     // (mode 2, the default: the CRC pass beside the parse kernel, but the restore kernel does not wait for its last frames -- the
     // pass lives on the wave slots the parser leaves and ends some 12 us after it --: it ignores the verdict, and
@@ -529,7 +532,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // next calls of this context (a stream that does it once does it again: full-scale noise, a side channel at full scale).
     const int plane16 = (!wide && wave_parse && !old_restore && !fused && !detail && !p16_off && c->dec_p16_hold == 0) ? 1 : 0;
     if (c->dec_p16_hold) c->dec_p16_hold--;
-    bool forked = false, fix_in_export = false;
+    bool forked = false, fix_in_export = false, rows_sent = false;
+    FgDecResult *const h_rows_pinned = (FgDecResult *)((char *)c->h_res + 64);
     if (!crc_late) {
         forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
         if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
@@ -578,8 +582,11 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (forked && !crc_join_late && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
         if (wave_parse && !old_restore && !crc_late) {
             const bool late = crc_join_late && forked;
+            // (the status words straight to the host's pinned copy: when this kernel has the last word on them)
+            rows_sent = lean && !late;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream, plane16) != 0) {
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream, plane16,
+                                          rows_sent ? h_rows_pinned : nullptr) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (late) {
@@ -598,7 +605,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                      (const uint16_t *)c->crctab.p, fk ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
             if (fk && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream, plane16) != 0) {
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream, plane16, nullptr) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (fk) {
@@ -627,10 +634,13 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     unsigned long long *hinfo2 = (unsigned long long *)((char *)c->h_res + 32);
     if (lean) {
         const unsigned long long seq = ++c->sig_seq;
-        if (fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
-                             index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
-                             fix_in_export ? (const FgDecFrame *)c->dec_frames.p : nullptr, fix_in_export ? (int32_t *)d_pcm : nullptr) != 0 ||
-            !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
+        const int lrc = rows_sent
+            ? fg_launch_signal(d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr, index_here ? 4 : 0,
+                               (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream)
+            : fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
+                               index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
+                               fix_in_export ? (const FgDecFrame *)c->dec_frames.p : nullptr, fix_in_export ? (int32_t *)d_pcm : nullptr);
+        if (lrc != 0 || !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
         tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
         for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
     }
