@@ -1412,6 +1412,10 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 #pragma unroll 1
                 for (uint32_t s = 0; s < seg + (RAG ? 1u : 0u); s++) ne |= ((!RAG || s < ln.len) && (int32_t)rowL[s] != l0);
                 forbid = !__any(ne != 0);
+                // ("chose CONSTANT", not "is constant": from 28 bits per sample on libFLAC's order guess -- the _limit_residual
+                // forms -- flags only an all-zero signal as constant, oracle fixed_best_predictor)
+                const uint32_t wl = rfl(B.wasted[(size_t)bi * NC]);
+                if (forbid && !(wl & 0x100u) && P.bps - (wl & 0xFFu) >= 28) forbid = false;
             }
             if (forbid) constant = false;
         }
@@ -1749,6 +1753,9 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
 #pragma unroll 1
                 for (uint32_t s = 0; s < seg; s++) ne |= ((int32_t)rowL[s] != l0);
                 forbid = !__any(ne != 0);
+                // ("chose CONSTANT", not "is constant": at 28 bits and more only an all-zero left channel does -- see pipe_eval_cand)
+                const uint32_t wl = rfl(B.wasted[(size_t)bi * NC]);
+                if (forbid && !(wl & 0x100u) && P.bps - (wl & 0xFFu) >= 28) forbid = false;
             }
             if (forbid) constant = false;
         }

@@ -629,6 +629,32 @@ def test_32_bit_streams_mixed_content(ctx):
         assert st.redo_blocks == 1                       # (the 777-sample tail of true 32-bit content: ragged geometry)
 
 
+def test_limit_min_bitrate_and_a_constant_left_channel_of_28_bits_and_more(ctx):
+    """limit_min_bitrate disables CONSTANT for the last independent channel (and then for mid and side) when every earlier channel
+    CHOSE CONSTANT -- and from 28 bits per sample on libFLAC's order guess (the _limit_residual forms) flags only an all-zero signal
+    as constant: a 32-bit stream at a non-zero DC level keeps its CONSTANT mid channel, one whose channels are equal its CONSTANT
+    side channel.  (gpu_fuzz seeds 415128 and 410060 of round 4: the pipeline looked at the samples of the left channel instead of
+    at what the left channel's subframe would be.)"""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    n = 4608 * 3 + 1000
+    dc = np.stack([np.full(n, 1540236309, np.int64), np.full(n, 88344043, np.int64)], axis=1)
+    eq = np.stack([np.full(n, 932007123, np.int64), np.full(n, 932007123, np.int64)], axis=1)
+    zl = np.stack([np.zeros(n, np.int64), np.full(n, 88344043, np.int64)], axis=1)              # an all-zero left channel IS constant
+    w5 = np.stack([np.full(n, 1540236309 & ~63, np.int64), np.full(n, 88344043, np.int64)], axis=1)   # six wasted bits: 26 bits, constant
+    for arr64 in (dc, eq, zl, w5):
+        arr = arr64.astype(np.int32)
+        for level, bs in ((6, 4608), (8, 2048)):
+            s = batch.settings(level, 2, 32, 96000, bs, True)
+            cfg, _ = O.config(level, 2, 32, 96000, bs, True)
+            s.limit_min_bitrate = 1
+            cfg.limit_min_bitrate = 1
+            out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+            want, sizes = O.encode_stream(cfg, arr)
+            assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:], (level, bs)
+
+
 def test_32_bit_mono_and_many_channels_with_shared_wasted_bits(ctx):
     import torch
     from pyflac_amd import batch
