@@ -172,7 +172,7 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming));
     for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&c->gstream[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->gev_join[i], hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&c->gev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->evs[i]));
     if (hipHostMalloc((void **)&c->h_sig, 128, hipHostMallocDefault) != hipSuccess) { fg_set_error("hipHostMalloc failed"); return false; }
@@ -212,7 +212,7 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->descs, &c->slots, &c->results, &c->dbg, &c->crctab, &c->windows, &c->offsets, &c->scratch_pcm,
-                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_rparams, &c->dec_warm, &c->dec_ranges, &c->pipe,
+                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_poff, &c->dec_hrec, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_rparams, &c->dec_warm, &c->dec_ranges, &c->pipe,
                       &c->mc_tmp, &c->mc_offs, &c->mc_map, &c->mc_sizes, &c->mc_res, &c->mc_foffs};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -221,7 +221,7 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     c->stamp.release();
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 8; i++) if (c->evs[i]) (void)hipEventDestroy(c->evs[i]);
-    for (int i = 0; i < 2; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+    for (int i = 0; i < 3; i++) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
     for (int i = 0; i < 2; i++) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
     for (int i = 0; i < 3; i++) { if (c->gev_join[i]) (void)hipEventDestroy(c->gev_join[i]); if (c->gstream[i]) (void)hipStreamDestroy(c->gstream[i]); }
     if (c->gev_fork) (void)hipEventDestroy(c->gev_fork);

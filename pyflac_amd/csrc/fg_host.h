@@ -55,10 +55,10 @@ int fg_launch_copy(const uint8_t *d_slots, uint32_t slot_bytes, const FgBlockRes
 size_t fg_dec_scan_words(uint32_t nframes);
 int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len, const unsigned long long *d_offsets, uint32_t nframes,
                           uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
-                          unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream);
+                          unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream, int write_err);
 int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                         uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream);
+                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec);
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
@@ -67,10 +67,10 @@ int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const Fg
                           uint16_t *d_rparams, hipStream_t stream);
 int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                             int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                            unsigned long long *d_counters, hipStream_t stream, int plane16);
+                            unsigned long long *d_counters, hipStream_t stream, int plane16, const FgDecSelf *self);
 int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                               const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                              hipStream_t stream, int plane16, FgDecResult *h_rows);
+                              hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff);
 int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                            int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
                            int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream);
@@ -80,7 +80,7 @@ int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nframes, uint32
 int fg_launch_narrow16(const int32_t *d_in, int16_t *d_out, uint64_t n, hipStream_t stream);
 int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream);
 int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
-                         const uint16_t *d_crctab, hipStream_t stream);
+                         const uint16_t *d_crctab, hipStream_t stream, const unsigned long long *d_offsets, unsigned long long stream_len);
 int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels,
                             const int32_t *d_scratch, const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results,
                             const uint16_t *d_crctab, uint32_t interleave, int wide, unsigned long long *d_prof, hipStream_t stream);
@@ -110,7 +110,7 @@ struct flacgpu_ctx {
     hipEvent_t evp[2] = {nullptr, nullptr};
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};      // the encoder pipeline's groups 1..3 (FgPipeLaunch.ngroups)
     hipEvent_t gev_fork = nullptr, gev_join[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t evx[2] = {nullptr, nullptr};
+    hipEvent_t evx[3] = {nullptr, nullptr, nullptr};       // [2]: frame table ready (header pass + scan on the side stream)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing
     int stage_timing = 0;            // 0: no events (end of call through the pinned signal area, GPU time from wall-clock stamps),
@@ -123,7 +123,7 @@ struct flacgpu_ctx {
     double log_guard_thr = 1e-6;
     std::recursive_mutex mu;    // (the batch entry points nest: streams of more than two channels run the one-channel encode inside)
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe,
+        dec_scratch, dec_subs, dec_poff, dec_hrec, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe,
         mc_tmp, mc_offs, mc_map, mc_sizes, mc_res, mc_foffs;   // streams of more than two channels (fg_ctx.cpp encode_multichannel)
     const uint32_t *last_chunk_bits = nullptr;   // the pipeline's chunk bit counts of the last encode call (device), or null
     std::vector<unsigned char> desc_key;   // settings + stream list the block list in `dev_descs` was built for

@@ -176,6 +176,21 @@ struct FgDecSub {
     int32_t q[12];         // (constant subframe: q[0] = the value)         // FIR coefficients (quantised LPC, or the binomial coefficients of a fixed predictor)
 };
 
+// What lets the wave parser start from the frame OFFSETS alone (flac_dec_wave.hip): the index pass's resolve kernel leaves a packed
+// header record per frame (fg_dec_hdr.h), the parser takes its frame's fields from it, applies the length rules, and places the
+// frame's part of the residual plane at frame number x stride (stride = the largest block size among the first 64 records: a
+// stream of fixed block size; a frame that does not fit takes the generic decoder) -- `planeoff[f]` tells the restore kernel
+// where.  Header pass and scan of the block sizes then run beside the parser instead of in front of it.
+// offsets == nullptr: the parser starts from the frame table (header pass and scan done), the plane lies in output order.
+struct FgDecSelf {
+    const unsigned long long *offsets;     // nframes + 1 frame positions
+    const uint32_t *hdrrec;                // nframes packed header records (0: none)
+    unsigned long long *planeoff;          // nframes: byte offset of the frame's part of the plane
+    unsigned long long plane_cap_bytes;
+    uint32_t si_bps;                       // STREAMINFO's, or 0
+    uint32_t reserved;
+};
+
 struct FgDecResult {
     uint32_t err;          // 0 ok, 1 malformed (bad header / reserved or inconsistent fields), 2 crc16 mismatch,
                            // 4 contents parse but do not end at the frame boundary (damaged residual or truncation),

@@ -668,15 +668,25 @@ fg_dec_rice_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fram
 // along as a granule in front of granule 0 instead of being raised to x^(128 G) by repeated squaring -- 1200 instructions a frame.
 #endif  // FG_LEGACY
 __global__ void __launch_bounds__(256)
-fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, const uint16_t *crctab)
+fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, const uint16_t *crctab,
+                  const u64 *offsets, u64 stream_len)
 {
     (void)crctab;
     const int lane = threadIdx.x & 63;
     const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= nframes) return;
-    const uint32_t fb = frames[f].bytes;
-    if (fb < 3) return;
-    const uint8_t *fp = stream + frames[f].byte_off;
+    // (offsets: the pass starts from the frame positions alone, beside the header pass -- FgDecSelf; a frame the header pass
+    // turns down is checked for nothing)
+    uint32_t fb;
+    u64 boff;
+    if (offsets) {
+        const u64 o0 = offsets[f], o1 = offsets[f + 1];
+        const bool inside = o0 < stream_len && o1 <= stream_len && o1 > o0 && o1 - o0 < 0x7FFFFFFFull;
+        fb = inside ? (uint32_t)(o1 - o0) : 0; boff = inside ? o0 : 0;
+    }
+    else { fb = frames[f].bytes; boff = frames[f].byte_off; }
+    if (fb < 3) { if (offsets && lane == 0) results[f].crc = 0; return; }      // (on its own the pass owns the word: the header pass leaves it alone)
+    const uint8_t *fp = stream + boff;
     const uint32_t nbytes = fb - 2;
     // from the first 4-byte aligned address: head bytes serially, then interleaved granules of four words, then what is left
     const uint32_t mis = (uint32_t)((uintptr_t)fp & 3);
@@ -1677,9 +1687,10 @@ extern "C" int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes
 
 // CRC-16 of every frame; independent of the parse kernel, so the caller may run it on a second stream beside it
 extern "C" int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
-                                    const uint16_t *d_crctab, hipStream_t stream)
+                                    const uint16_t *d_crctab, hipStream_t stream, const unsigned long long *d_offsets, unsigned long long stream_len)
 {
     if (nframes == 0) return 0;
-    hipLaunchKernelGGL(fg_dec_crc_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_stream, d_frames, nframes, d_results, d_crctab);
+    hipLaunchKernelGGL(fg_dec_crc_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_stream, d_frames, nframes, d_results, d_crctab,
+                       (const u64 *)d_offsets, (u64)stream_len);
     return (int)hipGetLastError();
 }

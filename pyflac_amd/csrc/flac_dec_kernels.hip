@@ -16,6 +16,7 @@
 
 #include "fg_dev.h"
 #include "fg_types.h"
+#include "fg_dec_hdr.h"
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -373,19 +374,11 @@ fg_decode_slow_kernel(const uint8_t *stream, const FgDecFrame *frames_all, const
 }
 
 // ---------------------------------------------------------------- frame header parse (format.h:418-462)
-// lane = frame.  offsets[f] .. offsets[f+1] delimit the frame.  Fills FgDecFrame except out_off.
+// lane = frame.  offsets[f] .. offsets[f+1] delimit the frame.  Fills FgDecFrame except out_off.  (The rules are in fg_dec_hdr.h.)
+// write_err: this pass also leaves the verdict in results[f].err -- for parsers that start from the frame table; the wave parser on
+// its own (FgDecSelf) writes the status of every frame itself, and this pass, running beside it, must not.
 __device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t f, uint32_t si_channels,
-                                                    uint32_t si_bps, FgDecFrame *frames, FgDecResult *results);
-__global__ void __launch_bounds__(256)
-fg_dec_headers_kernel(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t nframes, uint32_t si_channels, uint32_t si_bps,
-                      FgDecFrame *frames, FgDecResult *results)
-{
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
-    fg_dec_parse_header(stream, stream_len, offsets, f, si_channels, si_bps, frames, results);
-}
-__device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t f, uint32_t si_channels,
-                                                    uint32_t si_bps, FgDecFrame *frames, FgDecResult *results)
+                                                    uint32_t si_bps, FgDecFrame *frames, FgDecResult *results, bool write_err)
 {
     // the index may come from the device (the index kernel leaves ~0 in the slot of a frame it did not find; a caller's table
     // is not looked at by the host): nothing is read through an offset that does not lie inside the stream
@@ -395,55 +388,26 @@ __device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 s
     const uint32_t len = inside ? (uint32_t)(o1 - o0) : 0;
     FgDecFrame fr;
     fr.byte_off = inside ? o0 : 0; fr.out_off = 0; fr.bytes = len; fr.n = 0; fr.hdr_bytes = 0; fr.channels = 0; fr.ca = 0; fr.bps = 0;
-    uint32_t bad = 0;
-    if (len < 7 || p[0] != 0xFF || (p[1] & 0xFE) != 0xF8) bad = 1;
-    uint32_t pos = 2, n = 0;
+    const auto pb = [&](uint32_t i) -> uint32_t { return (uint32_t)p[i]; };
+    fgdev::HdrFields h;
+    uint32_t bad = fgdev::fg_dec_header_fields<true>(pb, len, h);
     if (!bad) {
-        const uint32_t bsc = p[2] >> 4, src = p[2] & 15, cac = p[3] >> 4, bpc = (p[3] >> 1) & 7;
-        if (bsc == 0 || src == 15 || cac > 10 || bpc == 3 || (p[3] & 1)) bad = 1;
-        pos = 4;
-        // UTF-8 coded frame/sample number
-        uint32_t x = p[pos++], extra = 0;
-        if (!(x & 0x80)) extra = 0;
-        else if ((x & 0xE0) == 0xC0) extra = 1;
-        else if ((x & 0xF0) == 0xE0) extra = 2;
-        else if ((x & 0xF8) == 0xF0) extra = 3;
-        else if ((x & 0xFC) == 0xF8) extra = 4;
-        else if ((x & 0xFE) == 0xFC) extra = 5;
-        else if (x == 0xFE) extra = 6;
-        else bad = 1;
-        if (pos + extra + 4 > len) bad = 1;
-        if (!bad) {
-            for (uint32_t i = 0; i < extra; i++) if ((p[pos++] & 0xC0) != 0x80) bad = 1;
-            switch (bsc) {
-            case 1: n = 192; break;
-            case 2: case 3: case 4: case 5: n = 576u << (bsc - 2); break;
-            case 6: n = (uint32_t)p[pos] + 1; pos += 1; break;
-            case 7: n = (((uint32_t)p[pos] << 8) | p[pos + 1]) + 1; pos += 2; break;
-            default: n = 256u << (bsc - 8); break;
-            }
-            if (src == 12) pos += 1; else if (src == 13 || src == 14) pos += 2;
-            if (pos + 1 > len) bad = 1;
-        }
-        if (!bad) {
-            uint32_t c8 = 0;
-            for (uint32_t i = 0; i < pos; i++) {
-                c8 ^= p[i];
-                for (int b = 0; b < 8; b++) c8 = (c8 & 0x80) ? (((c8 << 1) ^ 0x07) & 0xFF) : ((c8 << 1) & 0xFF);
-            }
-            if (c8 != p[pos]) bad = 1;
-            pos++;
-            const uint32_t BP[8] = {0, 8, 12, 0, 16, 20, 24, 32};
-            fr.bps = bpc ? BP[bpc] : si_bps;
-            if (cac < 8) { fr.channels = cac + 1; fr.ca = 0; } else { fr.channels = 2; fr.ca = cac - 7; }
-            if (si_channels && fr.channels != si_channels) bad = 1;
-            fr.n = n; fr.hdr_bytes = pos;
-        }
+        fr.bps = fgdev::fg_hdr_bps(h.bpc, si_bps);
+        if (h.cac < 8) { fr.channels = h.cac + 1; fr.ca = 0; } else { fr.channels = 2; fr.ca = h.cac - 7; }
+        if (si_channels && fr.channels != si_channels) bad = 1;
+        fr.n = h.n; fr.hdr_bytes = h.hdr_bytes;
     }
     if (bad) { fr.n = 0; fr.channels = si_channels ? si_channels : 1; fr.bytes = 0; }
     frames[f] = fr;
-    results[f].err = bad ? 1 : 0;
-    results[f].crc = 0;
+    if (write_err) { results[f].err = bad ? 1 : 0; results[f].crc = 0; }      // (else: parser and CRC pass, beside this one, own the words)
+}
+__global__ void __launch_bounds__(256)
+fg_dec_headers_kernel(const uint8_t *stream, u64 stream_len, const u64 *offsets, uint32_t nframes, uint32_t si_channels, uint32_t si_bps,
+                      FgDecFrame *frames, FgDecResult *results, uint32_t write_err)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    fg_dec_parse_header(stream, stream_len, offsets, f, si_channels, si_bps, frames, results, write_err != 0);
 }
 
 // ---------------------------------------------------------------- frame index from the bytes alone
@@ -865,13 +829,13 @@ extern "C" size_t fg_dec_scan_words(uint32_t nframes) { return 4 + 2 * (size_t)(
 
 extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len, const unsigned long long *d_offsets, uint32_t nframes,
                                      uint32_t si_channels, uint32_t si_bps, FgDecFrame *d_frames, FgDecResult *d_results,
-                                     unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream)
+                                     unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream, int write_err)
 {
     if (nframes == 0) return 0;
     // (the header pass inside the one-workgroup scan kernel was tried in round 4 and costs far more than the launch it saves: a header
     // is a chain of dependent byte loads, and 7032 of them want 7032 threads, not 1024 -- decode launch 0.342 -> 0.405 ms)
     hipLaunchKernelGGL(fg_dec_headers_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, d_stream, (u64)stream_len, d_offsets, nframes,
-                       si_channels, si_bps, d_frames, d_results);
+                       si_channels, si_bps, d_frames, d_results, write_err ? 1u : 0u);
     const uint32_t ntiles = (nframes + FG_DSCAN_TILE - 1) / FG_DSCAN_TILE;
     if (ntiles == 1)
         hipLaunchKernelGGL(fg_dec_scan_kernel, dim3(1), dim3(1024), 0, stream, d_frames, nframes, d_totals, (u64)cap_samples);
@@ -888,8 +852,11 @@ extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long
 // A compressed stream holds, by chance, a few byte sequences that pass for a frame header (roughly one per 300 MB for 16-bit
 // stereo), and their one- or two-byte frame number usually names an existing frame.  Frames lie in the stream in the order
 // of their numbers, so of two claims for slot k the true one is the one between the positions of frames k-1 and k+1.
+// hdrrec (when given): the packed header record (fg_dec_hdr.h) of the frame every slot ends up with -- what lets the wave parser
+// start from the offsets alone (FgDecSelf); 0 for an empty or a contested slot.  The index pass has checked the header, CRC-8
+// included, when it filed the claim: the fields are read again here, the length rules wait for the parser (it knows the length).
 __global__ void __launch_bounds__(256)
-fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 len, unsigned long long *info)
+fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 len, unsigned long long *info, const uint8_t *stream, uint32_t *hdrrec)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t *cnt = (const uint32_t *)(alt + nframes);       // claims per slot
@@ -901,18 +868,37 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
         if ((threadIdx.x & 63) == 0 && top) atomicMax(&info[3], (unsigned long long)top);
     }
     if (k >= nframes) return;
+    u64 fin = offsets[k];
+    bool contested = false;
     const uint32_t c = cnt[k];
-    if (c < 2) return;
-    const u64 a = offsets[k], b = alt[k] - 1;              // the smallest and the largest position claiming the slot
-    if (a == b) return;                                     // (one position found twice cannot happen; harmless)
-    if (c > 2) { atomicAdd(&info[1], 1ull); return; }
-    // neighbours with a single claim (a run of contested slots is not resolved here)
-    const bool pv = k == 0 || cnt[k - 1] == 1, nx = k + 1 >= nframes || cnt[k + 1] == 1;
-    const u64 lo = k == 0 ? 0 : offsets[k - 1], hi = k + 1 >= nframes ? len : offsets[k + 1];
-    if (!pv || !nx) { atomicAdd(&info[1], 1ull); return; }
-    const bool aok = (k == 0 || a > lo) && a < hi, bok = (k == 0 || b > lo) && b < hi;
-    if (aok == bok) { atomicAdd(&info[1], 1ull); return; }
-    if (bok) offsets[k] = b;
+    if (c >= 2) {
+        const u64 a = fin, b = alt[k] - 1;                   // the smallest and the largest position claiming the slot
+        if (a != b) {                                         // (one position found twice cannot happen; harmless)
+            if (c > 2) { atomicAdd(&info[1], 1ull); contested = true; }
+            else {
+                // neighbours with a single claim (a run of contested slots is not resolved here)
+                const bool pv = k == 0 || cnt[k - 1] == 1, nx = k + 1 >= nframes || cnt[k + 1] == 1;
+                const u64 lo = k == 0 ? 0 : offsets[k - 1], hi = k + 1 >= nframes ? len : offsets[k + 1];
+                if (!pv || !nx) { atomicAdd(&info[1], 1ull); contested = true; }
+                else {
+                    const bool aok = (k == 0 || a > lo) && a < hi, bok = (k == 0 || b > lo) && b < hi;
+                    if (aok == bok) { atomicAdd(&info[1], 1ull); contested = true; }
+                    else if (bok) { offsets[k] = b; fin = b; }
+                }
+            }
+        }
+    }
+    if (hdrrec) {
+        uint32_t rec = 0;
+        if (!contested && fin < len) {
+            const uint8_t *p = stream + fin;
+            const u64 avail = len - fin;
+            const auto pb = [&](uint32_t i) -> uint32_t { return i < avail ? (uint32_t)p[i] : 0u; };
+            fgdev::HdrFields h;
+            if (!fgdev::fg_dec_header_fields<false>(pb, 0x7FFFFFFFu, h)) rec = fgdev::fg_hdr_pack(h);
+        }
+        hdrrec[k] = rec;
+    }
 }
 
 // offsets[0 .. nframes] empty (all ones: identity of the minimum), alt[0 .. nframes) zero (identity of the maximum), the claim
@@ -936,7 +922,7 @@ extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned 
 
 extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                                    uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream)
+                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec)
 {
     if (len == 0) return 0;
     // (every lane takes four groups a step; at most 8 workgroups of 4 waves per CU -- every wave slot of the chip, once --
@@ -950,7 +936,7 @@ extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long l
                        (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt, d_ranges, nranges);
     if (nframes)
         hipLaunchKernelGGL(fg_dec_index_resolve_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (const u64 *)d_alt,
-                           nframes, (u64)len, d_info);
+                           nframes, (u64)len, d_info, d_stream, d_hdrrec);
     return (int)hipGetLastError();
 }
 

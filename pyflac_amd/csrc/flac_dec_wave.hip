@@ -37,6 +37,7 @@
 
 #include "fg_dev.h"
 #include "fg_types.h"
+#include "fg_dec_hdr.h"
 
 using namespace fgdev;
 
@@ -152,7 +153,7 @@ typedef uint32_t wp_u32x4h __attribute__((ext_vector_type(4), aligned(2)));     
 template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256, 8)
 fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch,
-                     FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters)
+                     FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters, FgDecSelf SF)
 {
     __shared__ uint32_t lds[4 * WP_WAVE_W];
     const int lane = threadIdx.x & 63;
@@ -160,8 +161,40 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
     int32_t *const outb = (int32_t *)(rows + WP_ROWS_W);
     const uint32_t f = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (f >= nframes) return;
-    const FgDecFrame fr = frames[f];
-    if (fr.bytes == 0) return;                          // rejected by the header pass
+    FgDecFrame fr;
+    u64 plane_el;                                       // first element (int32) of the frame's part of the plane
+    if (SF.offsets) {
+        // ---- on its own (FgDecSelf): the frame from its offsets and its header record, its part of the plane by its number
+        const u64 o0 = SF.offsets[f], o1 = SF.offsets[f + 1];
+        const bool inside = o0 < stream_len && o1 <= stream_len && o1 > o0 && o1 - o0 < 0x7FFFFFFFull;
+        const uint32_t len = inside ? (uint32_t)(o1 - o0) : 0;
+        const uint32_t rec = rfl(SF.hdrrec[f]);
+        // stride: the largest block size among the first 64 records
+        uint32_t nmax = 0;
+        { const uint32_t r = (uint32_t)lane < nframes ? SF.hdrrec[lane] : 0u; nmax = (r >> 31) ? (r & 0xFFFFu) + 1u : 0u; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
+        nmax = rfl(nmax);
+        const uint32_t hn = (rec & 0xFFFFu) + 1u, hb = (rec >> 16) & 31u, cac = (rec >> 21) & 15u, bpc = (rec >> 25) & 7u, extra = (rec >> 28) & 7u;
+        uint32_t st0 = 0;                               // 1: not a frame (what the header pass says too), 3: the generic decoder's
+        if (!inside) st0 = 1;
+        else if (!(rec >> 31)) st0 = 3;                 // (a contested slot: the header pass decides)
+        else if (!fg_hdr_len_ok(len, extra, hb)) st0 = 1;
+        fr.byte_off = inside ? o0 : 0; fr.out_off = 0; fr.bytes = len; fr.n = hn; fr.hdr_bytes = hb;
+        fr.bps = fg_hdr_bps(bpc, SF.si_bps);
+        if (cac < 8) { fr.channels = cac + 1; fr.ca = 0; } else { fr.channels = 2; fr.ca = cac - 7; }
+        const u64 stride = ((u64)nmax * fr.channels * 4u + 15ull) & ~15ull;
+        const u64 slot = (u64)f * stride;
+        if (!st0 && (hn > nmax || slot + stride > SF.plane_cap_bytes)) st0 = 3;
+        if (lane == 0) SF.planeoff[f] = st0 ? 0ull : slot;
+        if (st0) { if (lane == 0) results[f].err = st0; return; }
+        plane_el = slot >> 2;
+    }
+    else {
+        fr = frames[f];
+        if (fr.bytes == 0) return;                      // rejected by the header pass
+        plane_el = fr.out_off * fr.channels;
+    }
     uint32_t err = 0;
     if (fr.bytes < fr.hdr_bytes + 2) err = 1;
     const uint32_t n = fr.n, C = fr.channels;
@@ -184,7 +217,7 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
     for (uint32_t ch = 0; ch < C && !err; ch++) {
       {
         FgDecSub *sd = &subs[(size_t)f * C + ch];
-        int32_t *pl = scratch + fr.out_off * C + (u64)ch * n;
+        int32_t *pl = scratch + plane_el + (u64)ch * n;
         int16_t *const pl16 = (int16_t *)pl;
         constexpr bool nar = P16;
         uint32_t ovf = 0;                    // a value of this subframe does not fit 16 bits
@@ -906,7 +939,7 @@ __device__ __forceinline__ void wr16_tile(int32_t (&h)[16], const int32_t (&q)[1
 template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256)
 fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
-                       int32_t *out, FgDecResult *results, uint32_t interleave, FgDecResult *host_rows)
+                       int32_t *out, FgDecResult *results, uint32_t interleave, FgDecResult *host_rows, const unsigned long long *planeoff)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
     uint32_t *const tiles = wsm;                                   // WR_NB x 64 rows x 64 words
@@ -950,7 +983,8 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         }
         const uint32_t n_in = ok ? n : 0;
         const uint32_t n_out = (mine && status != 3) ? n : 0;               // status 3: the generic kernel writes the frame
-        const u64 plane = ok ? out_off * C + (u64)ch * n : 0;
+        // (planeoff: the parser placed the frames' parts of the plane itself, FgDecSelf)
+        const u64 plane = ok ? (planeoff ? (u64)(planeoff[f] >> 2) : out_off * C) + (u64)ch * n : 0;
         uint32_t *fm = fa + lane * WR_FA;
         fm[0] = n_in; fm[1] = n_out; fm[2] = (uint32_t)plane; fm[3] = (uint32_t)(plane >> 32);
         fm[4] = (uint32_t)out_off; fm[5] = (uint32_t)(out_off >> 32); fm[6] = ca; fm[7] = wasted; fm[8] = n;
@@ -1200,20 +1234,22 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
 // Same contract as fg_launch_decode_fast (flac_dec_fast.hip): residual plane, subframe records, parse status.
 extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                                        int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                                       unsigned long long *d_counters, hipStream_t stream, int plane16)
+                                       unsigned long long *d_counters, hipStream_t stream, int plane16, const FgDecSelf *self)
 {
     if (nframes == 0) return 0;
     const dim3 grid((nframes + 3) / 4);
-    if (wide) hipLaunchKernelGGL((fg_dec_wparse_kernel<true, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
-    else if (plane16) hipLaunchKernelGGL((fg_dec_wparse_kernel<false, true>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
-    else hipLaunchKernelGGL((fg_dec_wparse_kernel<false, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters);
+    FgDecSelf SF;
+    if (self) SF = *self; else { SF.offsets = nullptr; SF.hdrrec = nullptr; SF.planeoff = nullptr; SF.plane_cap_bytes = 0; SF.si_bps = 0; SF.reserved = 0; }
+    if (wide) hipLaunchKernelGGL((fg_dec_wparse_kernel<true, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
+    else if (plane16) hipLaunchKernelGGL((fg_dec_wparse_kernel<false, true>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
+    else hipLaunchKernelGGL((fg_dec_wparse_kernel<false, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
     return (int)hipGetLastError();
 }
 
 // Same contract as fg_launch_decode_finish (flac_dec_fast.hip), without the profile words.
 extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                                          const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                                         hipStream_t stream, int plane16, FgDecResult *h_rows)
+                                         hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff)
 {
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
@@ -1225,8 +1261,8 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true, false>
                           : (plane16 ? (const void *)fg_dec_wrestore_kernel<false, true> : (const void *)fg_dec_wrestore_kernel<false, false>);
     if (fg_func_set_lds(fn, lds) != 0) return -1;
-    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows);
-    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows);
-    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows);
+    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff);
+    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff);
+    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff);
     return (int)hipGetLastError();
 }

@@ -413,7 +413,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (nframes == 0) {
             // count the candidates (an upper bound of the frames; false candidates are a handful), then see which slots fill
             if (!HIPOK(hipMemsetAsync(d_info, 0, 64, c->stream)) ||
-                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, nullptr, 0, c->stream) != 0 ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, nullptr, 0, c->stream, nullptr) != 0 ||
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 64, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
@@ -428,7 +428,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             if (!c->dec_info.ensure(64 + (size_t)bound * 12 + 16)) return false;       // counters, second claims, claim counts
             d_info = (unsigned long long *)c->dec_info.p;
             if (fg_launch_dec_index_init((unsigned long long *)c->offsets.p, d_info + 8, d_info, bound, nullptr, c->stream) != 0 ||
-                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, nullptr, 0, c->stream) != 0 ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, nullptr, 0, c->stream, nullptr) != 0 ||
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
@@ -453,6 +453,27 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (!index_here && fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; }
     }
     else if (!HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
+    // The wave parser on its own (FgDecSelf): the index pass leaves a header record per frame, the parser starts as soon as the
+    // offsets are settled, header pass and scan of the block sizes move to the side stream in front of the CRC pass, and the
+    // restore kernel waits for the frame table.  For one stream whose index is made here, in a call without events, with a
+    // residual scratch sized by the caller's capacity; not when the planes are handed out (subframe detail).
+    const uint32_t C = channels_hint ? channels_hint : 2;
+    // (+ one block of the largest size: the parts of the plane are placed at frame number x stride, FgDecSelf)
+    const uint64_t cap_bytes = cap_samples * C * 4 + 256 + 65536ull * C * 4;
+    const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20) + 65536ull * C * 4;
+    static const bool self_off = getenv("FLACGPU_DEC_SELF") && atoi(getenv("FLACGPU_DEC_SELF")) == 0;
+    static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 0;
+#ifdef FG_LEGACY
+    bool selfstart = false;              // (the superseded kernels start from the frame table)
+#else
+    bool selfstart = lean && queued && index_here && nranges == 0 && !detail && !self_off && crc_late_mode == 0 && c->stream2 != nullptr;
+#endif
+    uint32_t *d_hrec = nullptr;
+    unsigned long long *d_poff = nullptr;
+    if (selfstart) {
+        if (!c->dec_poff.ensure((size_t)npad * 8) || !c->dec_hrec.ensure((size_t)npad * 4)) return false;
+        d_poff = (unsigned long long *)c->dec_poff.p; d_hrec = (uint32_t *)c->dec_hrec.p;
+    }
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
         if (!c->dec_info.ensure(64 + (size_t)nframes * 12 + 16)) return false;      // counters, second claims, claim counts
@@ -465,7 +486,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             d_ranges = (const FgDecRange *)c->dec_ranges.p;
         }
         if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, lean ? (unsigned long long *)c->stamp.p : nullptr, c->stream) != 0 ||
-            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, d_ranges, nranges, c->stream) != 0) {
+            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, d_ranges, nranges, c->stream, d_hrec) != 0) {
             fg_set_error("frame index kernel launch failed"); return false;
         }
         // (the end of the last frame, offsets[nframes] = len, is set by the index kernel)
@@ -473,17 +494,27 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (!lean) (void)hipEventRecord(c->ev[3], c->stream);
     }
     else if (!HIPOK(hipMemcpyAsync(d_off, h_offsets, ((size_t)nframes + 1) * 8, offsets_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream))) { fg_set_error("copy of the frame offsets failed"); return false; }
-    if (fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
-                              (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream) != 0) { fg_set_error("header kernel launch failed"); return false; }
+    // (a stream of its own for header pass and scan: the CRC pass, on the second stream, starts from the offsets beside them --
+    // queued behind them it found the chip full of parser waves and ended after the parser)
+    // The parser is queued FIRST, header pass, scan and CRC pass behind it in host order (below): queued in front of it the CRC
+    // pass took the wave slots the parser needs to have all its frames resident at once, and the host's calls for the side
+    // streams sat between the index pass and the parser.
+    hipStream_t hstream = c->stream;
+    if (selfstart) {
+        hstream = c->gstream[0] ? c->gstream[0] : c->stream2;
+        selfstart = HIPOK(hipEventRecord(c->evx[0], c->stream));
+        if (!selfstart) hstream = c->stream;
+    }
+    if (!selfstart && fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
+                                            (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream, 1) != 0) {
+        fg_set_error("header kernel launch failed"); return false;
+    }
     if (!c->ensure_pinned_res(64 + ((size_t)nframes + 2) * sizeof(FgDecResult))) return false;
     unsigned long long *tot = (unsigned long long *)c->h_res;
     tot[0] = tot[1] = 0;
-    const uint32_t C = channels_hint ? channels_hint : 2;
     // The residual scratch is sized by the caller's capacity when that is a sane bound (the scan kernel rejects frames past
     // it), so the decode kernels are queued without waiting for the header pass; a wildly generous capacity (no STREAMINFO:
-    // 65535 samples per frame) waits for the real total instead of allocating for it.
-    const uint64_t cap_bytes = cap_samples * C * 4 + 256;
-    const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20);
+    // 65535 samples per frame) waits for the real total instead of allocating for it.  (cap_bytes, queued: above)
     if (!queued) {
         if (!HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
             fg_set_error("header pass failed"); return false;
@@ -519,7 +550,6 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // (round 4, late: the CRC pass lost more than half its instructions and now ends before the parser; waiting for it in front of
     // the restore kernel is free -- mode 0, the default since --, the restore kernel merges the verdict itself and, in a call
     // without events, sends the status words to the host on the way)
-    static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 0;
     const bool crc_late = crc_late_mode == 1 && wave_parse && !old_restore && !fused;
     // (mode 2, the default: the CRC pass beside the parse kernel, but the restore kernel does not wait for its last frames -- the
     // pass lives on the wave slots the parser leaves and ends some 12 us after it --: it ignores the verdict, and
@@ -534,10 +564,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (c->dec_p16_hold) c->dec_p16_hold--;
     bool forked = false, fix_in_export = false, rows_sent = false;
     FgDecResult *const h_rows_pinned = (FgDecResult *)((char *)c->h_res + 64);
-    if (!crc_late) {
+    if (!crc_late && !selfstart) {
         forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
         if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
-                                 (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+                                 (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream, selfstart ? d_off : nullptr, len) != 0) {
+            fg_set_error("decode kernel launch failed"); return false;
+        }
         if (forked && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
     }
     uint16_t *d_rparams = nullptr;
@@ -564,10 +596,31 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (wave_parse) {
             // wave-parallel parse (flac_dec_wave.hip): one frame per wavefront; FLACGPU_DEC_WAVE=2 also counts batches / sync rounds
             unsigned long long *d_cnt = nullptr;
+            FgDecSelf self;
+            self.offsets = d_off; self.hdrrec = d_hrec; self.planeoff = d_poff; self.plane_cap_bytes = c->dec_scratch.cap;
+            self.si_bps = bps_hint; self.reserved = 0;
             if (wave_parse >= 2 && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
             if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                                        (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16) != 0) {
+                                        (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16,
+                                        selfstart ? &self : nullptr) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
+            }
+            if (selfstart) {
+                // beside the parser, from the event behind the index pass: header pass + scan on one stream, the CRC pass (from the
+                // offsets) on another; the restore kernel reads the frame table and the verdicts and waits for both
+                // (one wait in front of the restore kernel, not two: the header stream waits for the CRC stream's event before it
+                // records its own -- every wait on the main stream is some 5 us of idle GPU)
+                if (!HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0)) ||
+                    fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
+                                         (const uint16_t *)c->crctab.p, c->stream2, d_off, len) != 0 ||
+                    !HIPOK(hipEventRecord(c->evx[1], c->stream2))) { fg_set_error("decode kernel launch failed"); return false; }
+                if (!HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0)) ||
+                    fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
+                                          (FgDecResult *)c->dec_results.p, d_tot, cap_samples, hstream, 0) != 0 ||
+                    (hstream != c->stream2 && !HIPOK(hipStreamWaitEvent(hstream, c->evx[1], 0))) ||
+                    !HIPOK(hipEventRecord(c->evx[2], hstream))) { fg_set_error("header kernel launch failed"); return false; }
+                forked = false;            // (evx[2] stands for both)
+                if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[2], 0))) return false;
             }
             if (d_cnt) {
                 unsigned long long hc[3] = {0, 0, 0};
@@ -586,7 +639,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             rows_sent = lean && !late;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
                                           (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream, plane16,
-                                          rows_sent ? h_rows_pinned : nullptr) != 0) {
+                                          rows_sent ? h_rows_pinned : nullptr, selfstart ? d_poff : nullptr) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (late) {
@@ -602,10 +655,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             // parse done: the CRC pass starts on the side stream, the restore kernel (told not to look at the verdict) beside it
             const bool fk = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
             if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
-                                     (const uint16_t *)c->crctab.p, fk ? c->stream2 : c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
+                                     (const uint16_t *)c->crctab.p, fk ? c->stream2 : c->stream, nullptr, len) != 0) { fg_set_error("decode kernel launch failed"); return false; }
             if (fk && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream, plane16, nullptr) != 0) {
+                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream, plane16, nullptr, selfstart ? d_poff : nullptr) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (fk) {
