@@ -490,21 +490,27 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     K = steps
     alg_bytes = chsamples * 4 + total_bytes                   # read int32 PCM once + write the frames once (and back for decode)
 
-    # The same steps again with HIP events around every launch (flacgpu_set_stage_timing level 1: around the call and its
-    # kernel groups; each event record idles the GPU for a few microseconds, which is why the timed region above runs without
-    # them): the per-launch durations the roofline objects quote.  Then a few steps with events between the encoder's stages.
+    # The same steps again with HIP events around every launch: the per-launch durations the roofline objects quote.
+    # flacgpu_set_stage_timing level 3 = the default call with ONE event in front of its first kernel and one behind its last (each
+    # event record idles the GPU for a few microseconds, which is why the timed region above runs without any: the two of level 3
+    # stand outside the kernels they time).  Then a few steps at level 1 (events also around the kernel groups inside a call: the
+    # encode / decode kernels proper, the index pass) and at level 2 (between the encoder's stages) for the break-down fields.
     L = _lib.lib()
-    L.flacgpu_set_stage_timing(ctx._h, 1)
+    L.flacgpu_set_stage_timing(ctx._h, 3)
     enc_ms = dec_ms = enc_tot = dec_tot = idx_ms = 0.0
     KE = max(1, min(K, 100))
     for _ in range(KE if passes else 0):
         est, dst, status = step()
-        enc_ms += est.encode_kernel_ms
         enc_tot += est.total_gpu_ms
-        dec_ms += dst.decode_kernel_ms
         dec_tot += dst.total_gpu_ms
+    L.flacgpu_set_stage_timing(ctx._h, 1)
+    KG = max(1, min(K, 20))
+    for _ in range(KG if passes else 0):
+        est, dst, status = step()
+        enc_ms += est.encode_kernel_ms
+        dec_ms += dst.decode_kernel_ms
         idx_ms += dst.index_ms
-    enc_k, dec_k, enc_t, dec_t, idx_ms = enc_ms / KE, dec_ms / KE, enc_tot / KE, dec_tot / KE, idx_ms / KE
+    enc_k, dec_k, enc_t, dec_t, idx_ms = enc_ms / KG, dec_ms / KG, enc_tot / KE, dec_tot / KE, idx_ms / KG
     if not passes:          # (no event pass: the device stamps of the timed region stand in)
         enc_k = enc_t = enc_wall / K
         dec_k = dec_t = dec_wall / K

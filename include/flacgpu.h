@@ -573,7 +573,8 @@ void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad);
  * microseconds between two kernels); the call ends with a kernel that writes totals and wall-clock stamps into pinned memory,
  * which the host polls; total_gpu_ms comes from the stamps, the *_kernel_ms / index_ms / stage_ms fields stay 0.
  * level 1: HIP events around the call and around its kernel groups (all *_ms fields but stage_ms).  level 2: also between the
- * encoder's stages (stage_ms). */
+ * encoder's stages (stage_ms).  level 3: as level 0, plus one event in front of the call's first kernel and one behind its last:
+ * total_gpu_ms is the HIP-event time of exactly the kernels, in exactly the order, the default call runs. */
 void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level);
 int flacgpu_copy_debug(flacgpu_ctx *ctx, void *host_dst, uint32_t first_block, uint32_t nblocks);
 int flacgpu_copy_block_results(flacgpu_ctx *ctx, void *host_dst, uint32_t nblocks);

@@ -367,7 +367,7 @@ extern "C" void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad)
     ctx->selfcheck_note = mfma_bad ? "matrix-core self-check overridden (flacgpu_force_selfcheck_result); the encoder uses its generic kernel" : "";
     ctx->desc_key.clear();       // (the kernel choice is part of what a cached block list stands for)
 }
-extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level) { ctx->stage_timing = level < 0 ? 0 : level > 2 ? 2 : level; }
+extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level) { ctx->stage_timing = level < 0 ? 0 : level > 3 ? 3 : level; }
 extern "C" void flacgpu_set_log_guard(flacgpu_ctx *ctx, double thr) { ctx->log_guard_thr = thr; }
 
 extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
@@ -613,11 +613,15 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // idle GPU between two kernels -- a stamp kernel in front, a signal kernel at the end (fg_signal_kernel: totals and
     // stamps into pinned memory, the host polls the sequence number).  Level 1: HIP events around the call and the
     // encode kernels.  Level 2: also between the pipeline's stages.
-    const bool lean = c->stage_timing == 0;
-    const bool timing = c->stage_timing >= 2 && use_pipe;
+    // Level 3: as level 0, plus ONE event in front of the call's first kernel and one behind its last (in front of the signal
+    // kernel): total_gpu_ms is then the HIP-event time of exactly the kernels the default call runs.
+    const bool lean = c->stage_timing == 0 || c->stage_timing == 3;
+    const bool ev2 = c->stage_timing == 3;
+    const bool timing = c->stage_timing == 2 && use_pipe;
     int nev = 0;
     auto mark = [&]() { if (timing && nev < 8) (void)hipEventRecord(c->evs[nev++], c->stream); };
     PL.B.stamp = nullptr;
+    if (ev2) HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (lean) {
         // (the pipeline's first kernel takes the stamp itself)
         if (nfast && use_pipe) PL.B.stamp = (unsigned long long *)c->stamp.p;
@@ -708,6 +712,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             const unsigned long long seq = ++c->sig_seq;
             const unsigned long long *tl = (const unsigned long long *)c->offsets.p + nblocks;
             const bool sep = use_pipe && !asm_here;
+            if (ev2 && hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
             if (fg_launch_signal(tl, asm_here ? 4 : 2, sep ? PL.B.guard : nullptr, sep ? 2 : 0, (const unsigned long long *)c->stamp.p,
                                  c->h_sig, seq, c->stream) != 0) return false;
             if (!c->wait_signal(seq)) return false;
@@ -754,7 +759,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     c->last_nblocks = nblocks;
     c->last_chunk_bits = piped ? PL.B.chunk_bits : nullptr;
     if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
-    if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);    // (encode_kernel_ms: levels 1, 2)
+    if (lean && !ev2) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);    // (encode_kernel_ms: levels 1, 2)
+    else if (ev2) HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
     else {
         HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
         HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));

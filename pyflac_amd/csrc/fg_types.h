@@ -5,7 +5,7 @@
 // ---- environment switches --------------------------------------------------------------------------------------------------------
 // Read by every build: FLACGPU_DEVICE (configuration: which GPU the default context uses), the kernel SELECTORS that choose among
 // implementations with identical results and exist for the cross-check tests (FLACGPU_NO_FAST, FLACGPU_PIPE, FLACGPU_MC, FLACGPU_WS,
-// FLACGPU_GROUPS, FLACGPU_DEC_WAVE, FLACGPU_DEC_WRESTORE, FLACGPU_DEC_FUSED, FLACGPU_DEC_P16, FLACGPU_DEC_G1 / G2 / WPS) and two
+// FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_DEC_WAVE, FLACGPU_DEC_WRESTORE, FLACGPU_DEC_FUSED, FLACGPU_DEC_P16, FLACGPU_DEC_SELF, FLACGPU_DEC_G1 / G2 / WPS) and two
 // test hooks (FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST).  Everything that skips work, reorders it for an experiment or
 // prints diagnostics (FLACGPU_DEC_SKIP, FLACGPU_STOP, FLACGPU_DEC_CRC_LATE, FLACGPU_FBW, FLACGPU_LDS_PAD, FLACGPU_SPIN_US,
 // FLACGPU_DEC_PROF, FLACGPU_API_PROF, FG_REFWALK_DEBUG) is read through fg_tune(), which answers "unset" unless the library was built

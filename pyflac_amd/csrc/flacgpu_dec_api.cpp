@@ -448,7 +448,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // end of call and timing as in the encoder (fg_ctx.cpp): level 0 = stamp kernel in front, export kernel at the end (status
     // words, totals and stamps into pinned memory, the host polls a sequence number), no events; levels 1, 2 = HIP events
     static const bool want_prof = fg_tune("FLACGPU_DEC_PROF") != nullptr;
-    const bool lean = c->stage_timing == 0 && !h_frames && !detail && !want_prof;
+    // (level 3: as level 0, plus one event in front of the first kernel and one behind the last -- fg_ctx.cpp)
+    const bool lean = (c->stage_timing == 0 || c->stage_timing == 3) && !h_frames && !detail && !want_prof;
+    const bool ev2 = lean && c->stage_timing == 3;
+    if (ev2 && !HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (lean) {     // (with the index made here, its first kernel takes the stamp)
         if (!index_here && fg_launch_stamp((unsigned long long *)c->stamp.p, c->stream) != 0) { fg_set_error("stamp kernel launch failed"); return false; }
     }
@@ -687,6 +690,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     unsigned long long *hinfo2 = (unsigned long long *)((char *)c->h_res + 32);
     if (lean) {
         const unsigned long long seq = ++c->sig_seq;
+        if (ev2 && !HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
         const int lrc = rows_sent
             ? fg_launch_signal(d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr, index_here ? 4 : 0,
                                (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream)
@@ -758,7 +762,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             }
         }
     }
-    if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);     // (decode_kernel_ms, index_ms: levels 1, 2)
+    if (ev2) (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);
+    else if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);     // (decode_kernel_ms, index_ms: levels 1, 2)
     else {
         (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);

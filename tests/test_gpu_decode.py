@@ -436,3 +436,45 @@ class TestResidualPlaneWidth:
             dec, status, dst = ctx.decode_stream(out[:est.total_bytes], 2, 16, t.shape[0], nframes=est.nblocks)
             assert int(status[:, 0].max()) == 0 and torch.equal(dec, t), (level, bs)
             assert dst.plane_bits == 16
+
+
+_SELF_SCRIPT = r'''
+import sys, hashlib, json
+import numpy as np, torch
+sys.path.insert(0, %r)
+from pyflac_amd import batch, synth
+ctx = batch.Context(0)
+res = []
+pcm = synth.config2_stereo16(3.0, 21)
+for level, bs, damage in ((5, 4096, None), (8, 1152, None), (5, 4096, 'header'), (5, 4096, 'payload'), (5, 4096, 'cut'), (3, 4095, None)):
+    s = batch.settings(level, 2, 16, 48000, bs, bs != 4095)
+    t = torch.from_numpy(pcm.astype(np.int32)).cuda()
+    out, offs, est = ctx.encode(s, t)
+    data = out[:est.total_bytes].clone()
+    o = offs.cpu().numpy()
+    if damage == 'header': data[int(o[5]) + 2] ^= 0x40           # the block size code of frame 5
+    if damage == 'payload': data[int(o[7]) + 40] ^= 0x10         # a residual bit of frame 7: CRC-16 mismatch or a parse error
+    if damage == 'cut': data = data[:int(o[est.nblocks - 1]) + 20].clone()     # the last frame cut short
+    dec, status, dst = ctx.decode_stream(data, 2, 16, t.shape[0], nframes=est.nblocks)
+    res.append([hashlib.sha256(dec.cpu().numpy().tobytes()).hexdigest(), status[:, 0].tolist(), int(dst.total_samples)])
+print('RESULT ' + json.dumps(res))
+'''
+
+
+@pytest.mark.skipif(os.environ.get('FLACGPU_DEC_WAVE') == '0', reason='the wave parser is switched off (legacy cross-check run)')
+def test_parser_on_its_own_equals_parser_behind_the_header_pass():
+    """Round 4 (FgDecSelf): decoding one stream from its bytes, the wave parser starts from the frame offsets and the header records
+    of the index pass, header pass + scan and the CRC pass beside it.  Same samples and the same status of every frame as with the
+    parser queued behind header pass and scan (FLACGPU_DEC_SELF=0, a child process each: the selector is read once) -- whole
+    streams, a damaged header, a damaged payload, a last frame cut short, an odd block size."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ('1', '0'):
+        env = dict(os.environ, FLACGPU_DEC_SELF=v)
+        p = subprocess.run([sys.executable, '-c', _SELF_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
+        outs.append(json.loads(line[7:]))
+    assert outs[0] == outs[1]
+    assert any(any(x != 0 for x in case[1]) for case in outs[0])         # (the damaged streams do report something)

@@ -418,6 +418,13 @@ def test_timing_levels_and_repeated_layouts(ctx):
             assert (sum(st.stage_ms) > 0) == (level == 2)
             dec, status, dst = ctx.decode_stream(torch.from_numpy(np.frombuffer(b, np.uint8).copy()).cuda(), 2, 16, pcm.shape[0], nframes=st.nblocks)
             assert torch.equal(dec[:pcm.shape[0]], pcm) and dst.total_gpu_ms > 0 and dst.decode_kernel_ms > 0
+        # level 3: the default call between two events -- same bytes, the total from the events, no break-down
+        L.flacgpu_set_stage_timing(ctx._h, 3)
+        b, o, st = enc(s5, pcm)
+        assert b == ref and np.array_equal(o, roffs)
+        assert st.total_gpu_ms > 0 and st.encode_kernel_ms == 0 and sum(st.stage_ms) == 0
+        dec, status, dst = ctx.decode_stream(torch.from_numpy(np.frombuffer(b, np.uint8).copy()).cuda(), 2, 16, pcm.shape[0], nframes=st.nblocks)
+        assert torch.equal(dec[:pcm.shape[0]], pcm) and dst.total_gpu_ms > 0 and dst.decode_kernel_ms == 0
     finally:
         L.flacgpu_set_stage_timing(ctx._h, 0)
     other8, _o, _s = enc(s8, pcm)
