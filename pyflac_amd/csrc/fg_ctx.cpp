@@ -484,9 +484,14 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (!c->offsets.ensure(fg_scan_words(nblocks) * 8)) return false;
     FgPipeLaunch PL;
     memset(&PL, 0, sizeof PL);
+    bool guard_was_clean = false;
     if (use_pipe) {
         if (!c->pipe.ensure(fg_pipe_scratch_bytes(&P, nblocks))) return false;
         fg_pipe_carve(&P, nblocks, c->pipe.p, &PL.B);
+        // (were the counters the kernels add to left reset by the last call's signal kernel?  Whatever this call launches first
+        // -- a loose mid-side probe, the launch proper -- uses that up: FgPipeLaunch.guard_clean)
+        guard_was_clean = PL.B.guard && c->guard_clean_ptr == PL.B.guard;
+        c->guard_clean_ptr = nullptr;            // (set again by a call that ends through the signal kernel)
         // near-tie guard of the LPC order guess: count, smallest margin (as the bits of a positive double); the
         // autocorrelation kernel resets both
         PL.guard_thr = c->log_guard_thr;
@@ -555,6 +560,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             for (FgBlockDesc &d : up) d.reserved = 0;
             if (!upload_descs(up, false)) return false;
             if (!decp.empty()) {
+                guard_was_clean = false;                 // (the probe adds to the counters; it starts with the begin kernel itself)
                 PL.nblocks = (uint32_t)decp.size(); PL.nblocks_rag = nrag_probe; PL.stages = 1; PL.dbg = nullptr;
                 if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
                 PL.dbg = dbg; PL.nblocks_rag = 0;
@@ -622,6 +628,11 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     auto mark = [&]() { if (timing && nev < 8) (void)hipEventRecord(c->evs[nev++], c->stream); };
     PL.B.stamp = nullptr;
     if (ev2) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    // (several groups: no begin kernel when the last call's signal kernel left the counters reset, no fork event when nothing this
+    // call put on the main stream concerns the other groups -- FgPipeLaunch.guard_clean / no_fork)
+    static const bool quick_off = getenv("FLACGPU_QUICK_START") && atoi(getenv("FLACGPU_QUICK_START")) == 0;
+    PL.guard_clean = (lean && use_pipe && !quick_off && guard_was_clean) ? 1u : 0u;
+    PL.no_fork = (PL.guard_clean && reuse && !c->debug && !ev2) ? 1u : 0u;
     if (lean) {
         // (the pipeline's first kernel takes the stamp itself)
         if (nfast && use_pipe) PL.B.stamp = (unsigned long long *)c->stamp.p;
@@ -714,8 +725,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             const bool sep = use_pipe && !asm_here;
             if (ev2 && hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
             if (fg_launch_signal(tl, asm_here ? 4 : 2, sep ? PL.B.guard : nullptr, sep ? 2 : 0, (const unsigned long long *)c->stamp.p,
-                                 c->h_sig, seq, c->stream) != 0) return false;
+                                 c->h_sig, seq, c->stream, (use_pipe && !quick_off) ? PL.B.guard : nullptr) != 0) return false;
             if (!c->wait_signal(seq)) return false;
+            c->guard_clean_ptr = (use_pipe && !quick_off) ? PL.B.guard : nullptr;
             for (int k = 0; k < 4; k++) tail[k] = c->h_sig[2 + k];
             return true;
         }

@@ -43,7 +43,8 @@ int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *
 // end-of-call hand-over through pinned memory (flac_enc_kernels.hip)
 int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream);
 int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
-                     const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream);
+                     const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream,
+                     unsigned long long *d_reset = nullptr);
 int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
                      const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
                      unsigned long long seq, hipStream_t stream, const FgDecFrame *fix_frames = nullptr, int32_t *fix_out = nullptr);
@@ -113,6 +114,7 @@ struct flacgpu_ctx {
     hipEvent_t evx[3] = {nullptr, nullptr, nullptr};       // [2]: frame table ready (header pass + scan on the side stream)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing
+    unsigned long long *guard_clean_ptr = nullptr;      // the pipeline guard counters the last call's signal kernel reset (FgPipeLaunch.guard_clean)
     int stage_timing = 0;            // 0: no events (end of call through the pinned signal area, GPU time from wall-clock stamps),
                                      // 1: HIP events around the call and its kernel groups, 2: also between the encoder's stages
     unsigned long long *h_sig = nullptr;   // pinned: [0] sequence number, [2..10) payload, [10] start stamp, [11] end stamp

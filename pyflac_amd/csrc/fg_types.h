@@ -5,7 +5,7 @@
 // ---- environment switches --------------------------------------------------------------------------------------------------------
 // Read by every build: FLACGPU_DEVICE (configuration: which GPU the default context uses), the kernel SELECTORS that choose among
 // implementations with identical results and exist for the cross-check tests (FLACGPU_NO_FAST, FLACGPU_PIPE, FLACGPU_MC, FLACGPU_WS,
-// FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_DEC_WAVE, FLACGPU_DEC_WRESTORE, FLACGPU_DEC_FUSED, FLACGPU_DEC_P16, FLACGPU_DEC_SELF, FLACGPU_DEC_G1 / G2 / WPS) and two
+// FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_DEC_WAVE, FLACGPU_DEC_WRESTORE, FLACGPU_DEC_FUSED, FLACGPU_DEC_P16, FLACGPU_DEC_SELF, FLACGPU_QUICK_START, FLACGPU_DEC_G1 / G2 / WPS) and two
 // test hooks (FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST).  Everything that skips work, reorders it for an experiment or
 // prints diagnostics (FLACGPU_DEC_SKIP, FLACGPU_STOP, FLACGPU_DEC_CRC_LATE, FLACGPU_FBW, FLACGPU_LDS_PAD, FLACGPU_SPIN_US,
 // FLACGPU_DEC_PROF, FLACGPU_API_PROF, FG_REFWALK_DEBUG) is read through fg_tune(), which answers "unset" unless the library was built
@@ -145,6 +145,12 @@ struct FgPipeLaunch {
     uint32_t ngroups;           // 0, 1: one chain on `stream`
     void *gstream[3];           // streams of groups 1..3
     void *gev_fork, *gev_join[3];
+    // The start of a launch of several groups.  guard_clean: the counters the kernels add to were reset by the signal kernel of the
+    // previous call (fg_signal_kernel `reset`), so no fg_pipe_begin_kernel runs in front of the groups -- group 0's
+    // autocorrelation kernel takes the call's stamp --; no_fork: nothing this call queued on `stream` concerns the other groups
+    // (same block list as the last call, no debug records to clear), so their streams do not wait for an event on it.  Kernel,
+    // event record and waits were 14 us of idle GPU in front of the first autocorrelation kernel.
+    uint32_t guard_clean, no_fork;
 };
 
 // ---- decoder ----

@@ -1423,19 +1423,22 @@ __global__ void fg_stamp_kernel(u64 *stamp)
     if (threadIdx.x == 0) stamp[0] = wall_clock64();
 }
 
-__device__ __forceinline__ void fg_signal_tail(const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1, const u64 *stamp, u64 *host, u64 seq)
+__device__ __forceinline__ void fg_signal_tail(const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1, const u64 *stamp, u64 *host, u64 seq,
+                                               u64 *reset = nullptr)
 {
     for (uint32_t i = 0; i < n0; i++) host[2 + i] = src0[i];
     for (uint32_t i = 0; i < n1; i++) host[2 + n0 + i] = src1[i];
+    // (reset: the encoder pipeline's guard counters, read by now, go back to their start values for the next call -- FgPipeLaunch.guard_clean)
+    if (reset) { reset[0] = 0ull; reset[1] = 0x7FF0000000000000ull; reset[2] = 0ull; }
     host[10] = stamp ? stamp[0] : 0;
     host[11] = wall_clock64();
     __threadfence_system();
     __hip_atomic_store(&host[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void fg_signal_kernel(const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1, const u64 *stamp, u64 *host, u64 seq)
+__global__ void fg_signal_kernel(const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1, const u64 *stamp, u64 *host, u64 seq, u64 *reset)
 {
-    if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
+    if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq, reset);
 }
 
 // the decoder's variant: the per-frame status words travel too (16-byte units, a few workgroups; the last one to finish --
@@ -1514,10 +1517,11 @@ int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream)
 }
 
 int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
-                     const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream)
+                     const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream,
+                     unsigned long long *d_reset)
 {
     hipLaunchKernelGGL(fg_signal_kernel, dim3(1), dim3(64), 0, stream, (const u64 *)src0, n0, (const u64 *)src1, n1, (const u64 *)d_stamp,
-                       (u64 *)h_sig, (u64)seq);
+                       (u64 *)h_sig, (u64)seq, (u64 *)d_reset);
     return (int)hipGetLastError();
 }
 

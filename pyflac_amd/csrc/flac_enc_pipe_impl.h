@@ -203,12 +203,13 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     constexpr int NC = MS ? 4 : NCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wv = rfl(threadIdx.x >> 6);
-    const uint32_t bi = (bi0 & 0x7FFFFFFFu) + blockIdx.x * FGP_AWPB + wv;           // (blocks [bi0, nblocks) of the list: one group of the launch)
+    const uint32_t bi = (bi0 & 0x3FFFFFFFu) + blockIdx.x * FGP_AWPB + wv;           // (blocks [bi0, nblocks) of the list: one group of the launch)
     // (bit 31 of bi0: this is the only group of the launch -- the first workgroup does what fg_pipe_begin_kernel does otherwise, and a
-    // call of one block, StreamEncoder.process with libFLAC's timing, has one kernel less to wait for)
-    if ((bi0 >> 31) && blockIdx.x == 0 && threadIdx.x == 0) {
+    // call of one block, StreamEncoder.process with libFLAC's timing, has one kernel less to wait for.  Bit 30: the first group of
+    // several, the counters already reset by the previous call's signal kernel: only the stamp is taken)
+    if ((bi0 >> 30) && blockIdx.x == 0 && threadIdx.x == 0) {
         if (B.stamp) B.stamp[0] = wall_clock64();
-        if (B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }
+        if ((bi0 >> 31) && B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }
     }
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
