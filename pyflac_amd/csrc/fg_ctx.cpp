@@ -772,7 +772,12 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     c->last_chunk_bits = piped ? PL.B.chunk_bits : nullptr;
     if (d_out && tail[0] > out_cap) { fg_set_error("output buffer too small"); return false; }
     if (lean && !ev2) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);    // (encode_kernel_ms: levels 1, 2)
-    else if (ev2) HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
+    else if (ev2) {
+        // (the host saw the signal kernel's word in pinned memory; the runtime may not have looked at the event in front of that
+        // kernel yet -- hipEventElapsedTime then answers "not ready", one call in a dozen)
+        HIPCHK(hipEventSynchronize(c->ev[2]));
+        HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));
+    }
     else {
         HIPCHK(hipEventElapsedTime(&st->encode_kernel_ms, c->ev[0], c->ev[1]));
         HIPCHK(hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]));

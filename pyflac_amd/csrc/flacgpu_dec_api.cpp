@@ -762,7 +762,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             }
         }
     }
-    if (ev2) (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]);
+    if (ev2) { (void)hipEventSynchronize(c->ev[2]); (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]); }      // (see fg_ctx.cpp)
     else if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);     // (decode_kernel_ms, index_ms: levels 1, 2)
     else {
         (void)hipEventElapsedTime(&st->decode_kernel_ms, c->ev[1], c->ev[2]);
