@@ -396,7 +396,7 @@ def make_input(workload, seconds, rank, world, streams):
 
 
 def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=True, check=True):
-    """One workload: `warmup` untimed steps, the bit-exactness gates, `steps` timed steps between barriers, then the event
+    """One workload: `warmup` untimed steps, `steps` timed steps between barriers, the bit-exactness gates, then the event
     passes for the per-launch durations.  Returns the result dictionary (rank 0; None on the other ranks)."""
     import torch
     import torch.distributed as dist
@@ -442,24 +442,6 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
 
     for _ in range(max(1, warmup)):
         est, dst, status = step()
-    # bit-exactness gate (outside the timed region): the round trip equals the input
-    assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
-    assert torch.equal(dec[:nsamp], pcm), 'round trip is not bit-exact'
-    # what the GPU wrote, for the byte-for-byte check against the oracle after the timed region: the WHOLE stream (of the batch:
-    # its first and its last stream, whole)
-    h_chk = []
-    if rank == 0 and check:
-        if single:
-            h_chk.append((0, nsamp, out[:int(offs[-(-nsamp // bs)].item())].cpu().numpy().tobytes()))
-        else:
-            ho = offs.cpu().numpy().astype(np.int64)
-            first_frame = [0]
-            for n in lengths:
-                first_frame.append(first_frame[-1] + -(-n // bs))
-            starts = np.concatenate([[0], np.cumsum(lengths)])
-            for k in sorted(set([0, len(lengths) // 2, len(lengths) - 1])):
-                a, b = int(ho[first_frame[k]]), int(ho[first_frame[k + 1]])
-                h_chk.append((int(starts[k]), int(lengths[k]), out[a:b].cpu().numpy().tobytes()))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -484,6 +466,25 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # bit-exactness gate (outside the timed region, behind it: what is checked is what the timed steps left in the buffers -- and
+    # nothing but the warm-up steps stands between the box's idle time and the first timed step): the round trip equals the input
+    assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
+    assert torch.equal(dec[:nsamp], pcm), 'round trip is not bit-exact'
+    # what the GPU wrote, for the byte-for-byte check against the oracle after the timed region: the WHOLE stream (of the batch:
+    # its first and its last stream, whole)
+    h_chk = []
+    if rank == 0 and check:
+        if single:
+            h_chk.append((0, nsamp, out[:int(offs[-(-nsamp // bs)].item())].cpu().numpy().tobytes()))
+        else:
+            ho = offs.cpu().numpy().astype(np.int64)
+            first_frame = [0]
+            for n in lengths:
+                first_frame.append(first_frame[-1] + -(-n // bs))
+            starts = np.concatenate([[0], np.cumsum(lengths)])
+            for k in sorted(set([0, len(lengths) // 2, len(lengths) - 1])):
+                a, b = int(ho[first_frame[k]]), int(ho[first_frame[k + 1]])
+                h_chk.append((int(starts[k]), int(lengths[k]), out[a:b].cpu().numpy().tobytes()))
     ms_per_step = dt / steps * 1e3
     chsamples = nsamp * ch                                   # per rank per step
     value = chsamples * world / (ms_per_step * 1e-3) / 1e6
@@ -661,19 +662,24 @@ def main():
     env = {'rank': rank, 'world': world, 'dev': dev}
     ctx = batch.Context(local)
 
+    # The other single-GPU configurations of BASELINE.json, in the same process: each with its own warm-up, bit-exactness gates
+    # (round trip; whole stream against the oracle), >= 20 timed steps and event passes.  They run in FRONT of the headline
+    # measurement: the CPU leg above ends with one oracle process on every host core, and the host thread that drives the steps
+    # needs a few seconds to get its clocks and caches back -- a 20-step run right behind that burst showed 0.11 ms of host time
+    # a step where a run without the CPU leg shows 0.05.
+    cfgs = {}
+    if rank == 0 and world == 1 and workload == 'stream16' and not args.no_configs and args.seconds is None and args.level is None:
+        for wl, secs, lvl, k in (('stream24', 300.0, 8, 40), ('batch', 60.0, 5, 20)):
+            r = measure(env, ctx, wl, secs, lvl, k, 2, args.streams, passes=True, check=not args.no_cpu_baseline)
+            cfgs[wl] = {key: r[key] for key in ('metric', 'value', 'unit', 'steps', 'ms_per_step', 'ms_per_step_min', 'encode_gpu_ms',
+                                                'decode_gpu_ms', 'encode_stage_ms', 'config', 'checked') if key in r}
+            cfgs[wl]['roofline'] = {k2: r['roofline'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
+            cfgs[wl]['roofline_decode'] = {k2: r['roofline_decode'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
     res = measure(env, ctx, workload, seconds, level, steps, args.warmup, args.streams, passes=not args.no_passes,
                   check=world == 1 and not args.no_cpu_baseline)
     if rank == 0:
-        if world == 1 and workload == 'stream16' and not args.no_configs and args.seconds is None and args.level is None:
-            # the other single-GPU configurations of BASELINE.json, in the same process: each with its own warm-up, bit-exactness
-            # gates (round trip; whole stream against the oracle), >= 20 timed steps and event passes
-            res['configs'] = {}
-            for wl, secs, lvl, k in (('stream24', 300.0, 8, 40), ('batch', 60.0, 5, 20)):
-                r = measure(env, ctx, wl, secs, lvl, k, 2, args.streams, passes=True, check=not args.no_cpu_baseline)
-                res['configs'][wl] = {key: r[key] for key in ('metric', 'value', 'unit', 'steps', 'ms_per_step', 'ms_per_step_min', 'encode_gpu_ms',
-                                                               'decode_gpu_ms', 'encode_stage_ms', 'config', 'checked') if key in r}
-                res['configs'][wl]['roofline'] = {k2: r['roofline'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
-                res['configs'][wl]['roofline_decode'] = {k2: r['roofline_decode'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
+        if cfgs:
+            res['configs'] = cfgs
         if world == 1 and not args.no_e2e and workload == 'stream16':
             res['api_e2e'] = api_e2e(min(seconds, 600.0), 48000)
         if cpu_res is not None:

@@ -632,7 +632,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // call put on the main stream concerns the other groups -- FgPipeLaunch.guard_clean / no_fork)
     static const bool quick_off = getenv("FLACGPU_QUICK_START") && atoi(getenv("FLACGPU_QUICK_START")) == 0;
     PL.guard_clean = (lean && use_pipe && !quick_off && guard_was_clean) ? 1u : 0u;
-    PL.no_fork = (PL.guard_clean && reuse && !c->debug && !ev2) ? 1u : 0u;
+    PL.no_fork = (PL.guard_clean && reuse && !c->debug) ? 1u : 0u;
     if (lean) {
         // (the pipeline's first kernel takes the stamp itself)
         if (nfast && use_pipe) PL.B.stamp = (unsigned long long *)c->stamp.p;
