@@ -704,3 +704,46 @@ def test_matrix_core_selfcheck_and_its_fallback(golden):
     L.flacgpu_force_selfcheck_result(c._h, 0)
     assert L.flacgpu_selfcheck(c._h, C.byref(note)) == 0
     assert encode_all() == want
+
+
+_QUICK_SCRIPT = r'''
+import sys, hashlib, json
+import numpy as np, torch
+sys.path.insert(0, %r)
+from pyflac_amd import batch, synth
+ctx = batch.Context(0)
+pcm = synth.config2_stereo16(100.0, 5)[:4608 * 1024]
+t = torch.from_numpy(pcm.astype(np.int32)).cuda()
+res = []
+for level, bs in ((5, 1024), (5, 1024), (5, 1024), (8, 1024), (5, 1024)):          # (repeated layouts: the second call of a layout starts quick)
+    s = batch.settings(level, 2, 16, 48000, bs, True)
+    out, offs, st = ctx.encode(s, t)
+    res.append([hashlib.sha256(out[:st.total_bytes].cpu().numpy().tobytes()).hexdigest(), int(st.nblocks), int(st.log_guard_subframes),
+                float(st.lpc_order_min_margin), int(st.error_flags)])
+print('RESULT ' + json.dumps(res))
+'''
+
+
+def test_grouped_launch_starts_the_same_with_and_without_its_begin_kernel():
+    """Round 4: a launch of several groups (4096 blocks and more) starts without fg_pipe_begin_kernel and without the fork event when
+    the previous call's signal kernel left the guard counters reset and the block list is the last call's (FgPipeLaunch.guard_clean,
+    no_fork).  Same bytes and the same guard statistics as with the begin kernel in front of every launch (FLACGPU_QUICK_START=0, a
+    child process each), over repeated and changing layouts -- and the first stream equals the oracle's."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ('1', '0'):
+        env = dict(os.environ, FLACGPU_QUICK_START=v)
+        p = subprocess.run([sys.executable, '-c', _QUICK_SCRIPT % root], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
+        outs.append(json.loads(line[7:]))
+    assert outs[0] == outs[1]
+    assert outs[0][0] == outs[0][1] == outs[0][2] == outs[0][4] and outs[0][0][1] >= 4096 and outs[0][0][4] == 0
+    from pyflac_amd import synth
+    from oracle import oracle as O
+    pcm = synth.config2_stereo16(100.0, 5)[:4608 * 1024]
+    cfg, _ = O.config(5, 2, 16, 48000, 1024, True)
+    want, sizes = O.encode_stream(cfg, pcm.astype(np.int32))
+    import hashlib
+    assert hashlib.sha256(want[86:]).hexdigest() == outs[0][0][0]
