@@ -277,6 +277,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
     ap.add_argument('--no-configs', action='store_true', help='headline only: skip the configs[3] / configs[4] legs of the default run')
+    ap.add_argument('--no-direct', action='store_true', help='A/B: the chunk form of the packing stage (rounds 2-4) instead of the direct path')
     ap.add_argument('--no-passes', action='store_true', help='skip the event passes after the timed loop (profiling runs: the trace then holds the timed loop only)')
     ap.add_argument('--workload', choices=WORKLOADS, default=None,
                     help='default: stream16 at 1 GPU (the metric: configs[1]+[2]), batch at N > 1 (configs[4]).  stream24: configs[3], '
@@ -661,6 +662,10 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     env = {'rank': rank, 'world': world, 'dev': dev}
     ctx = batch.Context(local)
+    if args.no_direct:
+        # (A/B of round 5's direct packing path: chunks through HBM, sizes scan and assembly kernel, as in rounds 2-4)
+        from pyflac_amd import _lib
+        _lib.lib().flacgpu_set_direct(ctx._h, 0)
 
     # The other single-GPU configurations of BASELINE.json, in the same process: each with its own warm-up, bit-exactness gates
     # (round trip; whole stream against the oracle), >= 20 timed steps and event passes.  They run in FRONT of the headline

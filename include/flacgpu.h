@@ -534,7 +534,9 @@ typedef struct {
                                      (HIP events between the kernel groups); else zeros */
     uint32_t log_guard_subframes; /* LPC order guesses that were within the guard threshold of a tie and were re-done with the
                                      correctly rounded logarithm (see flacgpu_set_log_guard) */
-    uint32_t reserved0;
+    uint32_t direct_path;         /* 1: the packing kernel wrote the frames at their final place (round 5; flacgpu_set_direct); 2: it
+                                     tried, a frame could not be placed, and the call repeated packing, scan and assembly in the
+                                     chunk form; 0: chunk form */
     double lpc_order_min_margin;  /* smallest distance (bits) between the best and the second-best order estimate in this call */
 } flacgpu_encode_stats;
 
@@ -557,6 +559,10 @@ void flacgpu_set_debug(flacgpu_ctx *ctx, int on);
  * bit, which can only matter when two orders are within ~1e-10 bits of each other.  Estimates closer than `threshold_bits`
  * (default 1e-6) are re-done with a correctly rounded logarithm and counted in flacgpu_encode_stats.log_guard_subframes. */
 void flacgpu_set_log_guard(flacgpu_ctx *ctx, double threshold_bits);
+/* Direct packing (default on): blocks packed by two waves per subframe assemble their frame in LDS and store it at its final place in
+ * d_out (sizes by decoupled look-back); 0 = every block hands chunks through HBM to the scan and assembly kernels, as in rounds 2-4.
+ * Same bytes either way (tests cross-check the two). */
+void flacgpu_set_direct(flacgpu_ctx *ctx, int on);
 /* Window self-check: empty string, or a note that this host's cosf produced a tukey taper different from the committed one
  * (the committed one is then used; the note is also left in flacgpu_last_error() when it happens). */
 const char *flacgpu_window_note(flacgpu_ctx *ctx);

@@ -61,7 +61,7 @@ class EncodeStats(C.Structure):
     _fields_ = [('nblocks', C.c_uint32), ('error_flags', C.c_uint32), ('total_bytes', C.c_uint64),
                 ('encode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float),
                 ('last_channel_assignment', C.c_uint32), ('redo_blocks', C.c_uint32), ('stage_ms', C.c_float * 8),
-                ('log_guard_subframes', C.c_uint32), ('reserved0', C.c_uint32), ('lpc_order_min_margin', C.c_double)]
+                ('log_guard_subframes', C.c_uint32), ('direct_path', C.c_uint32), ('lpc_order_min_margin', C.c_double)]
 
 
 class StreamRange(C.Structure):
@@ -117,7 +117,7 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_stream_encoder_set_launch_blocks', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
-                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_set_direct', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
 
@@ -207,6 +207,8 @@ def lib():
     L.flacgpu_set_stage_timing.argtypes = [vp, C.c_int]
     L.flacgpu_set_log_guard.argtypes = [vp, C.c_double]
     L.flacgpu_set_log_guard.restype = None
+    L.flacgpu_set_direct.argtypes = [vp, C.c_int]
+    L.flacgpu_set_direct.restype = None
     L.flacgpu_window_note.argtypes = [vp]
     L.flacgpu_window_note.restype = C.c_char_p
     L.flacgpu_selfcheck.argtypes = [vp, C.POINTER(C.c_char_p)]

@@ -172,6 +172,7 @@ static bool ctx_init(flacgpu_ctx *c, int device)
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming));
     for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&c->gstream[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->gev_join[i], hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&c->gev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) HIPCHK(hipEventCreateWithFlags(&c->gev_eval[i], hipEventDisableTiming));
     for (int i = 0; i < 3; i++) HIPCHK(hipEventCreateWithFlags(&c->evx[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->evs[i]));
@@ -183,7 +184,7 @@ static bool ctx_init(flacgpu_ctx *c, int device)
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_khz = (double)khz;
     }
-    if (!c->crctab.ensure(2048 * sizeof(uint16_t))) return false;
+    if (!c->crctab.ensure((2048 + 2 * 5632) * sizeof(uint16_t))) return false;      // (2048 entries of round 1-2 tables, then the direct packing path's two sets)
     if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
     HIPCHK(hipStreamSynchronize(c->stream));
     // The encoder pipeline's autocorrelation runs its fp64 chains on the matrix core and is bit-exact only while that instruction
@@ -225,6 +226,8 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     for (int i = 0; i < 2; i++) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
     for (int i = 0; i < 3; i++) { if (c->gev_join[i]) (void)hipEventDestroy(c->gev_join[i]); if (c->gstream[i]) (void)hipStreamDestroy(c->gstream[i]); }
     if (c->gev_fork) (void)hipEventDestroy(c->gev_fork);
+    for (int i = 0; i < 3; i++) if (c->gev_eval[i]) (void)hipEventDestroy(c->gev_eval[i]);
+    c->lb.release();
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -369,6 +372,7 @@ extern "C" void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad)
 }
 extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level) { ctx->stage_timing = level < 0 ? 0 : level > 3 ? 3 : level; }
 extern "C" void flacgpu_set_log_guard(flacgpu_ctx *ctx, double thr) { ctx->log_guard_thr = thr; }
+extern "C" void flacgpu_set_direct(flacgpu_ctx *ctx, int on) { ctx->direct = on ? 1 : 0; }
 
 extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
 {
@@ -593,7 +597,10 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     // blocks the specialised kernels cover go first, the rest to the generic kernel (same bytes either way)
     uint32_t nfast = 0;
-    if (reuse) { nfast = c->desc_nfast; PL.nblocks_ws2 = c->desc_nws2; PL.nblocks_rag = c->desc_nrag; }
+    // (direct packing, FgPackDirect: does a block that keeps the chunk form / takes the generic kernel lie in front of a block of two
+    // packing waves per subframe in the output?  Its size is then waited for: FgPipeLaunch.side_first)
+    uint32_t side_first = 0, slow_first = 0;
+    if (reuse) { nfast = c->desc_nfast; PL.nblocks_ws2 = c->desc_nws2; PL.nblocks_rag = c->desc_nrag; side_first = c->desc_side_first; slow_first = c->desc_slow_first; }
     else {
         std::vector<FgBlockDesc> ordered;
         ordered.reserve(nblocks);
@@ -604,6 +611,14 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             else if (use_pipe && block_ws(d) != 2) ws1.push_back(d);
             else ordered.push_back(d);
         }
+        if (use_pipe && (!ordered.empty() || !ws1.empty())) {
+            // (direct: the blocks of the regular lane geometry; every class keeps the output order)
+            uint32_t last_direct = 0;
+            if (!ordered.empty()) last_direct = ordered.back().out_slot;
+            if (!ws1.empty() && ws1.back().out_slot > last_direct) last_direct = ws1.back().out_slot;
+            if (!rag.empty() && rag.front().out_slot < last_direct) side_first = 1;
+            if (!slow.empty() && slow.front().out_slot < last_direct) slow_first = 1;
+        }
         PL.nblocks_ws2 = use_pipe ? (uint32_t)ordered.size() : 0;
         ordered.insert(ordered.end(), ws1.begin(), ws1.end());
         PL.nblocks_rag = (uint32_t)rag.size();
@@ -613,7 +628,30 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         descs.swap(ordered);
         c->desc_key.clear();
         if (!upload_descs(descs, true)) return false;
-        if (!(P.do_mid_side && s->loose_mid_side)) { c->desc_key = key; c->desc_nfast = nfast; c->desc_nws2 = PL.nblocks_ws2; c->desc_nrag = PL.nblocks_rag; }
+        if (!(P.do_mid_side && s->loose_mid_side)) {
+            c->desc_key = key; c->desc_nfast = nfast; c->desc_nws2 = PL.nblocks_ws2; c->desc_nrag = PL.nblocks_rag;
+            c->desc_side_first = side_first; c->desc_slow_first = slow_first;
+        }
+    }
+    // ---- direct packing (round 5): the blocks packed by two waves per subframe assemble their frames in LDS and write them at their
+    // final place; no sizes scan, no chunks through HBM, no assembly kernel for them.  <= 16 bit and blocks of up to 4608 samples (the
+    // frame buffer beside the staged samples leaves four workgroups a CU), not for one-channel views (the splice wants the chunks).
+    bool direct = use_pipe && c->direct != 0 && d_out != nullptr && view == 0 && s->bits_per_sample <= 16 && s->blocksize <= 4608 &&
+                  nfast > PL.nblocks_rag && !slow_first && !ws1_only;
+    uint32_t direct_fcap = 0;
+    bool lb_cleared = false;           // (queued on the main stream: the other streams of the launch wait for it)
+    if (direct) {
+        const uint64_t fbits = 16 * 8 + (uint64_t)s->channels * (8 + 32 + (uint64_t)s->blocksize * (s->bits_per_sample + 1));
+        direct_fcap = (uint32_t)(((fbits + 31) / 32 + 2 + 3) & ~3ull);
+        const void *before = c->lb.p;
+        if (!c->lb.ensure((size_t)nblocks * 8)) return false;
+        // (a word counts only with this call's epoch: a fresh buffer, or the epoch counter back at its start, is cleared)
+        c->lb_epoch = (c->lb_epoch + 1) & 0xFFFFFu;
+        if (c->lb.p != before || c->lb_epoch == 0) {
+            HIPCHK(hipMemsetAsync(c->lb.p, 0, c->lb.cap, c->stream));
+            if (c->lb_epoch == 0) c->lb_epoch = 1;
+            lb_cleared = true;
+        }
     }
     // How the call ends and what is timed.  Level 0 (default): no events -- every event record costs a few microseconds of
     // idle GPU between two kernels -- a stamp kernel in front, a signal kernel at the end (fg_signal_kernel: totals and
@@ -632,7 +670,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // call put on the main stream concerns the other groups -- FgPipeLaunch.guard_clean / no_fork)
     static const bool quick_off = getenv("FLACGPU_QUICK_START") && atoi(getenv("FLACGPU_QUICK_START")) == 0;
     PL.guard_clean = (lean && use_pipe && !quick_off && guard_was_clean) ? 1u : 0u;
-    PL.no_fork = (PL.guard_clean && reuse && !c->debug) ? 1u : 0u;
+    PL.no_fork = (PL.guard_clean && reuse && !c->debug && !lb_cleared) ? 1u : 0u;
     if (lean) {
         // (the pipeline's first kernel takes the stamp itself)
         if (nfast && use_pipe) PL.B.stamp = (unsigned long long *)c->stamp.p;
@@ -645,6 +683,17 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         HIPCHK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
     }
     bool piped = false;
+    auto set_direct = [&](bool on) {
+        PL.nblocks_direct = on ? nfast - PL.nblocks_rag : 0;        // (the blocks of the regular lane geometry, whether one or two waves pack a subframe)
+        PL.side_first = on ? side_first : 0;
+        PL.side_stream = (void *)c->stream3; PL.side_ev = (void *)c->evp[0];
+        for (int i = 0; i < 3; i++) PL.gev_eval[i] = (void *)c->gev_eval[i];
+        PL.D.lb = (unsigned long long *)c->lb.p; PL.D.offsets = (unsigned long long *)c->offsets.p;
+        PL.D.user_offsets = (unsigned long long *)d_offsets; PL.D.dst = (uint8_t *)d_out; PL.D.dst_cap = out_cap;
+        PL.D.crcx = (const uint16_t *)c->crctab.p + 2048; PL.D.epoch = c->lb_epoch; PL.D.nblocks = nblocks; PL.D.fcap_words = direct_fcap;
+        PL.D.reserved = fg_tune("FLACGPU_DIRECT_X") ? (uint32_t)atoi(fg_tune("FLACGPU_DIRECT_X")) : 0u;
+    };
+    set_direct(direct);
     if (nfast && use_pipe) {
         PL.nblocks = nfast;
         if (timing) {
@@ -699,6 +748,43 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (!c->ensure_pinned_res(64)) return false;
     unsigned long long *tail = (unsigned long long *)c->h_res;   // total bytes, OR of error flags
     auto finish_pass = [&](bool first) -> bool {
+        if (direct && first) {
+            // direct packing: the frames of the direct blocks are in place.  The blocks that kept the chunk form (and the frames of the
+            // generic kernel, whose sizes are published here) find their places through the look-back words and are assembled now;
+            // the first wave of that kernel also leaves the error flags beside the total.
+            const uint32_t nd = PL.nblocks_direct;
+            if (nblocks > nfast && fg_launch_pipe_publish((const FgBlockDesc *)c->descs.p, nfast, nblocks - nfast, (const FgBlockResult *)c->results.p,
+                                                          PL.B.chunk_bits, &PL.D, c->stream) != 0) { fg_set_error("publish kernel launch failed"); return false; }
+            mark();
+            const bool rest = nd < nblocks;          // (no block in the chunk form: the signal kernel fetches flags and counters itself)
+            if (rest && fg_launch_pipe_assemble((const FgBlockDesc *)c->descs.p, nblocks, (const uint8_t *)c->slots.p, P.slot_bytes, chunk_cap_words, nw,
+                                                PL.B.chunk_bits, (FgBlockResult *)c->results.p, (unsigned long long *)c->offsets.p, (uint8_t *)d_out, out_cap,
+                                                (const uint16_t *)c->crctab.p, (unsigned long long *)d_offsets, PL.B.guard, c->stream, nd, &PL.D) != 0) {
+                fg_set_error("frame assembly kernel launch failed"); return false;
+            }
+            mark();
+            const unsigned long long *tl = (const unsigned long long *)c->offsets.p + nblocks;
+            if (lean) {
+                const unsigned long long seq = ++c->sig_seq;
+                if (ev2 && hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
+                if (!rest) {
+                    if (fg_launch_signal_direct(tl, PL.B.guard, (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
+                                                !quick_off ? PL.B.guard : nullptr) != 0) return false;
+                }
+                else if (fg_launch_signal(tl, 2, PL.B.guard, 2, (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
+                                          !quick_off ? PL.B.guard : nullptr) != 0) return false;
+                if (!c->wait_signal(seq)) return false;
+                c->guard_clean_ptr = !quick_off ? PL.B.guard : nullptr;
+                for (int k = 0; k < 4; k++) tail[k] = c->h_sig[2 + k];
+                return true;
+            }
+            tail[0] = tail[1] = 0;
+            if (hipMemcpyAsync(tail, tl, rest ? 16 : 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+            if (!rest && hipMemcpyAsync(tail + 1, PL.B.guard + 2, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+            if (hipMemcpyAsync(tail + 2, PL.B.guard, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+            if (hipEventRecord(c->ev[2], c->stream) != hipSuccess) return false;
+            return fg_stream_wait(c->stream) == hipSuccess;
+        }
         // (frame sizes of the pipeline's blocks: from the chunk bit counts, inside the scan)
         if (fg_launch_scan((FgBlockResult *)c->results.p, piped ? PL.B.chunk_bits : nullptr, nblocks, (unsigned long long *)c->offsets.p,
                            (piped && first && nfast == nblocks && d_out) ? 1 : 0, piped ? PL.B.guard + 2 : nullptr, c->stream) != 0) {
@@ -710,7 +796,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             const int rc = piped ? fg_launch_pipe_assemble((const FgBlockDesc *)c->descs.p, nblocks, (const uint8_t *)c->slots.p, P.slot_bytes,
                                                            chunk_cap_words, nw, PL.B.chunk_bits, (FgBlockResult *)c->results.p,
                                                            (unsigned long long *)c->offsets.p, (uint8_t *)d_out, out_cap,
-                                                           (const uint16_t *)c->crctab.p, (unsigned long long *)d_offsets, PL.B.guard, c->stream)
+                                                           (const uint16_t *)c->crctab.p, (unsigned long long *)d_offsets, PL.B.guard, c->stream, 0, nullptr)
                                  : fg_launch_copy((const uint8_t *)c->slots.p, P.slot_bytes, (const FgBlockResult *)c->results.p, nblocks,
                                                   (const unsigned long long *)c->offsets.p, (uint8_t *)d_out, c->stream, out_cap);
             if (rc != 0) { fg_set_error("frame assembly kernel launch failed"); return false; }
@@ -738,6 +824,21 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         return fg_stream_wait(c->stream) == hipSuccess;
     };
     if (!finish_pass(true)) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
+    // (what the near-tie guard counted belongs to the analysis: a repeated packing or a redo pass ends through a signal kernel that
+    // finds the counters reset)
+    const unsigned long long guard_count = tail[2], guard_margin = tail[3];
+    st->direct_path = direct ? 1u : 0u;
+    const uint32_t first_flags = direct ? ((uint32_t)tail[1] & ~(FG_ERR_REDO | FG_ERR_CHAIN)) : 0u;      // (range errors: the repeated pass does not see them again)
+    if (direct && ((uint32_t)tail[1] & (FG_ERR_CHAIN | FG_ERR_REDO))) {
+        // a frame the direct path could not place (FG_ERR_CHAIN): pack again in the chunk form -- the decisions of the analysis are
+        // all there --, then sizes, scan and assembly as in rounds 2-4
+        direct = false;
+        st->direct_path = 2;
+        set_direct(false);
+        PL.stages = 2; PL.ngroups = 1; PL.nblocks = nfast;
+        if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
+        if (!finish_pass(true)) { if (!*flacgpu_last_error()) fg_set_error("encode pass failed"); return false; }
+    }
     if ((uint32_t)tail[1] & FG_ERR_REDO) {
         // blocks the specialised kernels declined (absurd code lengths; wasted bits in round 1's kernel): encode them with the
         // generic kernel, then scan and assemble again
@@ -762,10 +863,10 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         }
     }
     st->total_bytes = tail[0];
-    st->error_flags = (uint32_t)tail[1] & ~FG_ERR_REDO;
+    st->error_flags = ((uint32_t)tail[1] & ~(FG_ERR_REDO | FG_ERR_CHAIN)) | first_flags;
     if (piped) {        // (the autocorrelation kernel resets the counters: they mean something only when the pipeline ran)
-        st->log_guard_subframes = (uint32_t)tail[2];
-        double mm; memcpy(&mm, &tail[3], 8);
+        st->log_guard_subframes = (uint32_t)guard_count;
+        double mm; memcpy(&mm, &guard_margin, 8);
         st->lpc_order_min_margin = mm;
     }
     c->last_nblocks = nblocks;

@@ -37,7 +37,10 @@ int fg_mfma_selfcheck(hipStream_t stream);
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
-                            unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream);
+                            unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream, uint32_t first,
+                            const FgPackDirect *direct);
+int fg_launch_pipe_publish(const FgBlockDesc *d_descs, uint32_t first, uint32_t count, const FgBlockResult *d_results, const uint32_t *d_chunk_bits,
+                           const FgPackDirect *direct, hipStream_t stream);
 int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes,
                              unsigned long long *d_stamp, hipStream_t stream);
 // end-of-call hand-over through pinned memory (flac_enc_kernels.hip)
@@ -45,6 +48,8 @@ int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream);
 int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
                      const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream,
                      unsigned long long *d_reset = nullptr);
+int fg_launch_signal_direct(const unsigned long long *d_total, const unsigned long long *d_guard, const unsigned long long *d_stamp,
+                            unsigned long long *h_sig, unsigned long long seq, hipStream_t stream, unsigned long long *d_reset);
 int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
                      const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
                      unsigned long long seq, hipStream_t stream, const FgDecFrame *fix_frames = nullptr, int32_t *fix_out = nullptr);
@@ -111,6 +116,13 @@ struct flacgpu_ctx {
     hipEvent_t evp[2] = {nullptr, nullptr};
     hipStream_t gstream[3] = {nullptr, nullptr, nullptr};      // the encoder pipeline's groups 1..3 (FgPipeLaunch.ngroups)
     hipEvent_t gev_fork = nullptr, gev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t gev_eval[3] = {nullptr, nullptr, nullptr};      // behind the evaluation of groups 0..2 (direct packing: FgPipeLaunch.gev_eval)
+    // direct packing path (round 5, FgPackDirect): look-back words of the frames of a call, the epoch that tells one call's words from
+    // another's, and the switch (flacgpu_set_direct: 0 = chunks through HBM, scan and assembly kernel as in rounds 2-4)
+    DevBuf lb;
+    uint32_t lb_epoch = 0;
+    int direct = 1;
+    uint32_t desc_side_first = 0, desc_slow_first = 0;         // (cached with the block list: a block that keeps the chunk form / takes the generic kernel lies in front of a direct block)
     hipEvent_t evx[3] = {nullptr, nullptr, nullptr};       // [2]: frame table ready (header pass + scan on the side stream)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage timing

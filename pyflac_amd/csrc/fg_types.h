@@ -36,6 +36,9 @@ static inline const char *fg_tune(const char *name)
 #define FG_ERR_SIDE33 4u       // (unused since the generic kernel handles the 33-bit side channel; value kept reserved)
 #define FG_ERR_INTERNAL 8u
 #define FG_ERR_REDO 16u         // not an error: the specialised kernel hands this block to the generic kernel
+#define FG_ERR_CHAIN 32u        // not an error: a frame of the direct packing path could not be placed (a block handed back, a frame beyond
+                                // the LDS frame buffer, a look-back that ran out of time): the call repeats packing, scan and assembly the
+                                // round-2 way (chunks through HBM)
 
 struct FgEncParams {
     uint32_t channels, bps, sample_rate, blocksize;
@@ -117,6 +120,28 @@ struct FgPipeBufs {
     unsigned long long *stamp;   // when set: K2 leaves the start-of-call wall-clock stamp here (fg_signal_kernel reads it)
 };
 
+// Round 5, the direct packing path (fg_pipe_pack_kernel<..., DIRECT>): a workgroup assembles its whole frame in LDS, takes the CRC-16
+// there and writes the bytes at the frame's final place in the output stream; the place comes from a decoupled look-back over the
+// frame sizes (`lb`: one 64-bit word per output slot -- epoch of the call, state, value; a workgroup publishes its size as soon
+// as it knows it, then the sum of everything up to and including itself once it has looked back).  Sizes scan, chunk round trip
+// through HBM and the assembly kernel disappear from a launch.
+struct FgPackDirect {
+    unsigned long long *lb;             // [nblocks] look-back words
+    unsigned long long *offsets;        // the context's offsets array: [slot] frame offset, [nblocks] total
+    unsigned long long *user_offsets;   // the caller's frame index, or null
+    uint8_t *dst;
+    unsigned long long dst_cap;
+    const uint16_t *crcx;               // CRC-16 constants for a pass of NT threads over 16-byte granules (fg_crc_tables_kernel)
+    uint32_t epoch;                     // 20 bits, never 0 ... (a word of another call counts as empty)
+    uint32_t nblocks;                   // blocks of the call (all kinds)
+    uint32_t fcap_words;                // LDS frame buffer
+    uint32_t reserved;
+};
+#define FG_LB_AGG 1ull                  // value = size of this frame
+#define FG_LB_PFX 2ull                  // value = sum of the sizes up to and including this frame
+#define FG_LB_POISON 3ull               // the chain is broken here (FG_ERR_CHAIN)
+#define FG_LB_VBITS 42
+
 struct FgPipeLaunch {
     const void *pcm;
     const FgBlockDesc *descs;
@@ -151,6 +176,16 @@ struct FgPipeLaunch {
     // (same block list as the last call, no debug records to clear), so their streams do not wait for an event on it.  Kernel,
     // event record and waits were 14 us of idle GPU in front of the first autocorrelation kernel.
     uint32_t guard_clean, no_fork;
+    // direct packing path: blocks [0, nblocks_direct) of the list (all packed by two waves per subframe) write their frames
+    // themselves; the others (short blocks, ragged geometry) keep the chunk form, publish their sizes (fg_pipe_publish_kernel) and
+    // are assembled by fg_pipe_assemble_kernel once everything is placed.  side_first: one of those others lies in front of a
+    // direct block in the output, so their whole chain runs on `side_stream` beside the analysis of the direct blocks and the
+    // direct packing kernels wait for `side_ev`; otherwise they ride at the end of the last group as before.
+    uint32_t nblocks_direct;
+    uint32_t side_first;
+    void *side_stream, *side_ev;
+    void *gev_eval[3];          // recorded behind the direct packing kernel of groups 0..2: the one of the next group waits for it
+    FgPackDirect D;
 };
 
 // ---- decoder ----

@@ -1141,6 +1141,24 @@ __global__ void fg_crc_tables_kernel(uint16_t *tab)
     tab[1024 + i] = (uint16_t)crc16_mulx(c, 8);
     tab[1280 + i] = (uint16_t)crc16_mulx(c, 16);
     tab[1536 + i] = (uint16_t)crc16_mulx(c, 24);
+    // the direct packing path (fg_pipe_pack_kernel<DIRECT>): a pass of NT threads over 16-byte granules, NT = 256 (set 0, at 2048) and
+    // 128 (set 1, at 2048 + 5632): [0,256) (i x^8) x^(128 NT), [256,512) i x^(128 NT); [512,1536) byte i followed by 3, 2, 1, 0 zero
+    // bytes; [1536 + rem NT + t) x^(128 (NT - 1 - t) + 8 rem) for rem = 0..15
+    for (int set = 0; set < 2; set++) {
+        const int nt = set == 0 ? 256 : 128;
+        uint16_t *x = tab + 2048 + 5632 * set;
+        x[i] = (uint16_t)crc16_mulx((uint32_t)i << 8, 128 * nt);
+        x[256 + i] = (uint16_t)crc16_mulx((uint32_t)i, 128 * nt);
+        x[512 + i] = (uint16_t)crc16_mulx(c, 24);
+        x[768 + i] = (uint16_t)crc16_mulx(c, 16);
+        x[1024 + i] = (uint16_t)crc16_mulx(c, 8);
+        x[1280 + i] = (uint16_t)c;
+        if (i < nt) {
+            uint32_t e = crc16_mulx(1, 128 * (nt - 1 - i));
+            for (int rem = 0; rem < 16; rem++) { x[1536 + rem * nt + i] = (uint16_t)e; e = crc16_mulx(e, 8); }
+        }
+    }
+}
 }
 
 __global__ void __launch_bounds__(64)
@@ -1440,6 +1458,14 @@ __global__ void fg_signal_kernel(const u64 *src0, uint32_t n0, const u64 *src1, 
 {
     if (threadIdx.x == 0) fg_signal_tail(src0, n0, src1, n1, stamp, host, seq, reset);
 }
+// end of a direct-packing call without blocks in the chunk form: total from the last frame's workgroup, the error flags and the guard
+// counters straight from the pipeline's words (guard[2], [0], [1])
+__global__ void fg_signal_direct_kernel(const u64 *total, const u64 *guard, const u64 *stamp, u64 *host, u64 seq, u64 *reset)
+{
+    if (threadIdx.x != 0) return;
+    host[2] = total[0]; host[3] = guard[2]; host[4] = guard[0]; host[5] = guard[1];
+    fg_signal_tail(nullptr, 0, nullptr, 0, stamp, host, seq, reset);
+}
 
 // the decoder's variant: the per-frame status words travel too (16-byte units, a few workgroups; the last one to finish --
 // counter in stamp[1] -- raises the flag)
@@ -1521,6 +1547,14 @@ int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned
                      unsigned long long *d_reset)
 {
     hipLaunchKernelGGL(fg_signal_kernel, dim3(1), dim3(64), 0, stream, (const u64 *)src0, n0, (const u64 *)src1, n1, (const u64 *)d_stamp,
+                       (u64 *)h_sig, (u64)seq, (u64 *)d_reset);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_signal_direct(const unsigned long long *d_total, const unsigned long long *d_guard, const unsigned long long *d_stamp,
+                            unsigned long long *h_sig, unsigned long long seq, hipStream_t stream, unsigned long long *d_reset)
+{
+    hipLaunchKernelGGL(fg_signal_direct_kernel, dim3(1), dim3(64), 0, stream, (const u64 *)d_total, (const u64 *)d_guard, (const u64 *)d_stamp,
                        (u64 *)h_sig, (u64)seq, (u64 *)d_reset);
     return (int)hipGetLastError();
 }

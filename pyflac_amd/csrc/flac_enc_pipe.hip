@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <string.h>
 #include "flac_enc_pipe_impl.h"
 
 namespace {
@@ -142,16 +143,32 @@ int fg_launch_encode_pipe(const FgPipeLaunch *L)
     else { if (maxo == 8) FG_CALLP(mono_o8); else FG_CALLP(mono_o12); }
 }
 
+// `direct` set (behind a direct launch, FgPackDirect): only the blocks [first, nblocks) of the list, placed through the look-back words;
+// the kernel runs even without such blocks -- its first wave hands the error flags to the host's words.
 int fg_launch_pipe_assemble(const FgBlockDesc *d_descs, uint32_t nblocks, const uint8_t *d_slots, uint32_t slot_bytes,
                             uint32_t chunk_cap_words, uint32_t nw, const uint32_t *d_chunk_bits, FgBlockResult *d_results,
                             unsigned long long *d_offsets, uint8_t *d_dst, uint64_t dst_cap, const uint16_t *d_crctab,
-                            unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream)
+                            unsigned long long *d_user_offsets, const unsigned long long *d_guard, hipStream_t stream, uint32_t first,
+                            const FgPackDirect *direct)
 {
     if (nblocks == 0) return 0;
     constexpr int WPB = 4;
-    hipLaunchKernelGGL((fg_pipe_assemble_kernel<WPB>), dim3((nblocks + WPB - 1) / WPB), dim3(WPB * 64), 0, stream, d_descs, nblocks, d_slots,
+    FgPackDirect D;
+    memset(&D, 0, sizeof D);
+    if (direct) D = *direct; else first = 0;
+    const uint32_t cnt = nblocks - first;
+    hipLaunchKernelGGL((fg_pipe_assemble_kernel<WPB>), dim3(cnt ? (cnt + WPB - 1) / WPB : 1), dim3(WPB * 64), 0, stream, d_descs, nblocks, d_slots,
                        slot_bytes, chunk_cap_words, nw, d_chunk_bits, d_results, (u64 *)d_offsets, d_dst, (u64)dst_cap, d_crctab,
-                       (u64 *)d_user_offsets, d_guard);
+                       (u64 *)d_user_offsets, d_guard, first, D);
+    return (int)hipGetLastError();
+}
+
+// sizes of the blocks descs[first, first + count) into the look-back words of a direct launch (frames of the generic kernel)
+int fg_launch_pipe_publish(const FgBlockDesc *d_descs, uint32_t first, uint32_t count, const FgBlockResult *d_results, const uint32_t *d_chunk_bits,
+                           const FgPackDirect *direct, hipStream_t stream)
+{
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(fg_pipe_publish_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_descs, first, count, d_results, d_chunk_bits, *direct);
     return (int)hipGetLastError();
 }
 

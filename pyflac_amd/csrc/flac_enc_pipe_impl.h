@@ -1945,13 +1945,21 @@ struct ChunkBits {
     uint32_t wbase, cap_words, fbw, err;
 };
 
+// (WG: the window is shared by the waves of the workgroup -- the direct packing path)
+template <bool WG = false>
 FGI void cb_or(const ChunkBits &b, uint32_t pos, uint32_t val, uint32_t vbits)
 {
     const uint32_t rel = pos - (b.wbase << 5);
     const uint32_t word = rel >> 5, sh = rel & 31;
     const u64 x = (u64)val << ((64 - sh - vbits) & 63);
-    __hip_atomic_fetch_or(&b.w[word], (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_fetch_or(&b.w[word + 1], (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if constexpr (WG) {
+        __hip_atomic_fetch_or(&b.w[word], (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(&b.w[word + 1], (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    else {
+        __hip_atomic_fetch_or(&b.w[word], (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_or(&b.w[word + 1], (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
 }
 
 // write out the complete words below bit position `upto` (and, with `all`, the partial word that follows)
@@ -1981,15 +1989,78 @@ FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
     if (bitpos + bits - (b.wbase << 5) > 32u * b.fbw - 64u) cb_flush(b, lane, bitpos, false);
 }
 
+
+// ---- decoupled look-back over the frame sizes of a call (FgPackDirect, fg_types.h).  Words are written and read whole (64-bit
+// relaxed atomics at device scope: the L2 caches of the eight XCDs are not coherent for plain accesses), so a word is either of
+// this call -- then state and value belong together -- or counts as empty.
+FGI u64 lb_word(uint32_t epoch, u64 state, u64 value) { return ((u64)(epoch & 0xFFFFFu) << 44) | (state << FG_LB_VBITS) | (value & ((1ull << FG_LB_VBITS) - 1)); }
+FGI void lb_publish(u64 *lb, uint32_t k, u64 w) { __hip_atomic_store(&lb[k], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Sum of the sizes of frames 0 .. k - 1 (one wave, all lanes; the result is wave-uniform).  Lane l looks at frame pos - l; the
+// window moves back by 64 until it holds a prefix.  An empty word in front of the first prefix is waited for (its workgroup runs, or
+// will: workgroups start in the order of their numbers); false: a poisoned word, or the wait ran out (5 ms -- a whole call takes less).
+FGI bool lb_lookback(const u64 *lb, uint32_t k, uint32_t epoch, int lane, u64 &excl, bool spin)
+{
+    u64 acc = 0;
+    int64_t pos = (int64_t)k - 1;
+    const u64 t0 = wall_clock64();
+    while (pos >= 0) {
+        const int64_t idx = pos - lane;
+        u64 v = lb_word(epoch, FG_LB_PFX, 0);                       // in front of frame 0: nothing
+        if (idx >= 0) v = __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = ((uint32_t)(v >> 44) == (epoch & 0xFFFFFu)) ? ((uint32_t)(v >> FG_LB_VBITS) & 3u) : 0u;
+        const u64 m_inv = __ballot(st == 0), m_pfx = __ballot(st == (uint32_t)FG_LB_PFX), m_poi = __ballot(st == (uint32_t)FG_LB_POISON);
+        const uint32_t p = m_pfx ? (uint32_t)__builtin_ctzll(m_pfx) : 64u;
+        const u64 upto = p >= 63 ? ~0ull : ((2ull << p) - 1);
+        if (m_poi & upto) return false;
+        if (m_inv & upto) {
+            if (!spin || wall_clock64() - t0 > 500000ull) return false;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        const u64 mine = ((uint32_t)lane <= p) ? (v & ((1ull << FG_LB_VBITS) - 1)) : 0ull;
+        acc += wave_sum64(mine);
+        if (p < 64) break;
+        pos -= 64;
+    }
+    excl = acc;
+    return true;
+}
+
+// Blocks that keep the chunk form beside a direct launch (short blocks, the ragged geometry, frames of the generic kernel) publish
+// their sizes here, in front of the direct packing kernels that will look them up.  Thread = block of descs[first, first + count).
+__global__ void __launch_bounds__(256)
+fg_pipe_publish_kernel(const FgBlockDesc *descs, uint32_t first, uint32_t count, const FgBlockResult *results, const uint32_t *chunk_bits,
+                       FgPackDirect D)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t k = descs[first + i].out_slot;
+    const FgBlockResult r = results[k];
+    u64 w;
+    if (r.err & FG_ERR_REDO) w = lb_word(D.epoch, FG_LB_POISON, 0);
+    else {
+        uint32_t nb = r.bytes;
+        if (r.reserved == 4) {
+            const uint4 cb = *(const uint4 *)&chunk_bits[(size_t)k * 4];
+            nb = ((cb.x + cb.y + cb.z + cb.w + 7) >> 3) + 2;
+        }
+        w = lb_word(D.epoch, k == 0 ? FG_LB_PFX : FG_LB_AGG, nb);
+    }
+    lb_publish(D.lb, k, w);
+}
+
 // KEEP (round 4; <= 16-bit input, two waves per subframe, blocks of 4096: 32 samples a lane): the first walk over a lane's samples --
 // the one that measures the codes -- keeps the zig-zagged residuals, two to a register, and the second walk writes the codes from
 // them: the FIR, the candidate arithmetic and the LDS reads of the samples happen once instead of twice (51 -> 38 instructions a
 // sample).  Sixteen more registers: four workgroups per CU instead of five.  A residual beyond 16 bits, a verbatim subframe or a
 // frame-bit window too small for all 64 lanes at once takes the two-walk form as before.
-template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG, bool KEEP = false>
-__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : ((RAG || KEEP) ? 4 : 5))
+// DIRECT (round 5): the workgroup's waves write into ONE frame buffer in LDS at their final bit positions (the four chunk lengths
+// are exchanged behind the measuring walk), take the CRC-16 of the frame there and store the bytes at the frame's final place in
+// the output stream, which a decoupled look-back over the frame sizes supplies (FgPackDirect).  Two waves per subframe only.
+template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG, bool KEEP = false, bool DIRECT = false>
+__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : ((RAG || KEEP || DIRECT) ? 4 : 5))
 fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
-                    uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0)
+                    uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0, FgPackDirect D)
 {
     constexpr int NC = MS ? 4 : NCH;
     constexpr int NW = NCH * WS;            // waves launched per block
@@ -2006,7 +2077,9 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     // tail blocks of the streams -- ride in the same launch; their spare waves leave after the staging)
     const uint32_t ws = (WS == 2 && n % 128 == 0 && n / 128 >= 32) ? 2u : 1u;
     const uint32_t LPS = 64 * ws;           // lanes (segments) per subframe
-    const uint32_t si = wv / ws, hf = wv % ws;
+    // (DIRECT: the spare waves of a block packed by one wave per subframe stay for the barriers and the CRC pass; they code nothing)
+    const bool spare = DIRECT && wv >= (uint32_t)NCH * ws;
+    const uint32_t si = spare ? 0u : wv / ws, hf = spare ? 1u : wv % ws;
     // lane geometry (see PipeGeo): ragged blocks are packed by one wave per subframe
     const PipeGeo geo = RAG ? pipe_geo(n, 6, P.max_po, PADE) : pipe_geo_regular(n / LPS, PADE);
     constexpr bool rag = RAG;
@@ -2014,14 +2087,24 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const uint32_t sbytes = ((pipe_rows_elems(P.sig_stride, 64 * WS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
     LDS samp_t *sL = (LDS samp_t *)smem;
     LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
-    LDS uint32_t *fbw = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes) + wv * (fbw_words + 2 + 64);
-    LDS uint32_t *misc = fbw + fbw_words + 2;                 // 64 words per wave: header bytes, then the packer's scratch words
+    // (DIRECT: ONE window of fbw_words = the whole frame, shared by the waves; behind it the waves' scratch words, the words the waves
+    // exchange and the two look-up tables of the CRC pass)
+    LDS uint32_t *const area = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes);
+    LDS uint32_t *fbw = DIRECT ? area : area + wv * (fbw_words + 2 + 64);
+    LDS uint32_t *misc = DIRECT ? area + (fbw_words + 2) + wv * 64 : fbw + fbw_words + 2;     // 64 words per wave: header bytes, then the packer's scratch words
+    LDS uint32_t *const xch = area + (fbw_words + 2) + NW * 64;                             // (DIRECT) 16 words
+    LDS uint16_t *const ctab = (LDS uint16_t *)(xch + 16);                                   // (DIRECT) 1536 entries
     bool pre_ok = true;
     const uint32_t pre = ACC64 ? pipe_preshift<NCH, NC>(P, B, bi, pre_ok) : 0u;
     (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo, pre);
-    for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0;
+    if constexpr (DIRECT) {
+        for (uint32_t j = tid; j < fbw_words + 2; j += NT) fbw[j] = 0;
+        for (uint32_t j = tid; j < 1536; j += NT) ctab[j] = D.crcx[j];
+        if (tid < 16) xch[tid] = 0;
+    }
+    else { for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0; }
     __syncthreads();
-    if (wv >= (uint32_t)NCH * ws) return;           // (no barrier after this point)
+    if (!DIRECT && wv >= (uint32_t)NCH * ws) return;           // (no barrier after this point)
 
     // ---- channel assignment from the four candidate totals (every wave computes it; wave-uniform)
     uint32_t ca = 0, c = si;
@@ -2054,7 +2137,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         c = si == 0 ? sub0 : sub1;
     }
     const FgPipeDec *dec = B.dec + (size_t)bi * NC + c;
-    const uint32_t type = rfl(dec->type), order = rfl(dec->order), prec = rfl(dec->prec), po = rfl(dec->porder), method = rfl(dec->method);
+    const uint32_t type = spare ? 0u : rfl(dec->type), order = rfl(dec->order), prec = rfl(dec->prec), po = rfl(dec->porder), method = rfl(dec->method);
     const uint32_t wraw = rfl(dec->wasted), wst = wraw & 0xFFu;
     int shift = (int)rfl((uint32_t)dec->shift);
     const uint32_t sb = P.bps + ((MS && c == 3) ? 1u : 0u) - wst;
@@ -2067,13 +2150,13 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     ChunkBits fb;
     fb.w = fbw; fb.fbw = fbw_words; fb.cap_words = chunk_cap_words; fb.wbase = 0; fb.err = 0;
     const uint32_t chunk = si * 2 + hf;            // chunk slots in bit order: (subframe 0, half 0), (0, 1), (1, 0), (1, 1)
-    fb.outw = (uint32_t *)(slots + (size_t)d.out_slot * P.slot_bytes) + (size_t)chunk * chunk_cap_words;
+    fb.outw = DIRECT ? nullptr : (uint32_t *)(slots + (size_t)d.out_slot * P.slot_bytes) + (size_t)chunk * chunk_cap_words;
     uint32_t bitpos = 0;
     bool redo = false;
 
+    uint32_t hl = 0;            // bytes of the frame header (wave 0)
     if (wv == 0) {   // frame header: assembled by lane 0 in LDS, emitted one byte per lane
         LDS uint8_t *hb = (LDS uint8_t *)misc;
-        uint32_t hl = 0;
         if (lane == 0) {
             uint32_t u, bs_hint = 0, sr_hint = 0;
             hb[hl++] = 0xFF; hb[hl++] = 0xF8;
@@ -2124,11 +2207,13 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         }
         hl = rfl(hl);
         wave_lds_fence();
-        const uint32_t v = (uint32_t)lane < hl ? hb[lane] : 0, b = (uint32_t)lane < hl ? 8 : 0;
-        wave_lds_fence();
-        cb_or(fb, (uint32_t)lane * 8, v, b);
-        bitpos = hl * 8;
-        wave_lds_fence();
+        if constexpr (!DIRECT) {
+            const uint32_t v = (uint32_t)lane < hl ? hb[lane] : 0, b = (uint32_t)lane < hl ? 8 : 0;
+            wave_lds_fence();
+            cb_or(fb, (uint32_t)lane * 8, v, b);
+            bitpos = hl * 8;
+            wave_lds_fence();
+        }
         if (lane == 0) results[d.out_slot].ca = ca;
     }
     int32_t cca, ccb;
@@ -2140,9 +2225,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const bool w32 = ACC64 && !RAG && P.bps == 32 && !pre_ok;
     const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);
     auto candd = [&](int32_t l, int32_t r) -> double { return pipe_cdbl(l, r, c, MS, wscale); };
-    if (hf == 0) {
-        // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes
-        // 1..order = warm-up samples, then precision/shift, coefficients, coding method + partition order
+    // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes
+    // 1..order = warm-up samples, then precision/shift, coefficients, coding method + partition order.  Returns the bits; with
+    // `emit` they are written from bit `at` on (DIRECT measures first and writes behind the exchange of the chunk lengths).
+    auto sub_header = [&](bool emit, uint32_t at) __attribute__((always_inline)) -> uint32_t {
         uint32_t hdr;
         switch (type) {
         case 0: hdr = 0x00; break;
@@ -2172,13 +2258,62 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         const uint32_t mine = pb + vb;
         const uint32_t incl = wave_scan_add(mine);
         const uint32_t total = rl(incl, 63);
-        cb_reserve(fb, lane, bitpos, total);
-        const uint32_t o = bitpos + incl - mine;
-        cb_or(fb, o, pv, pb);
-        cb_or(fb, o + pb, val, vb);
-        bitpos += total;
-        wave_lds_fence();
+        if (emit) {
+            if constexpr (!DIRECT) cb_reserve(fb, lane, at, total);
+            const uint32_t o = at + incl - mine;
+            cb_or<DIRECT>(fb, o, pv, pb);
+            cb_or<DIRECT>(fb, o + pb, val, vb);
+            wave_lds_fence();
+        }
+        return total;
+    };
+    uint32_t sub_bits = 0;          // (DIRECT) bits of this wave's subframe header
+    if (hf == 0) {
+        if constexpr (DIRECT) sub_bits = sub_header(false, 0);
+        else bitpos += sub_header(true, bitpos);
     }
+    // ---- DIRECT: the waves exchange their chunk lengths (0xFFFFFFFF: this wave hands the block back); every wave learns where
+    // its chunk starts in the frame and how long the frame is.  Then the headers go in with LDS atomics -- all of them, in front of a
+    // barrier: the first word of a wave's residual is read and later stored whole by its lane 0, and may hold header bits of any wave.
+    uint32_t d_start = 0, d_total = 0;
+    bool d_poison = false;
+    auto direct_sync = [&](uint32_t chunk_bits_, bool handback) __attribute__((always_inline)) {
+        if (lane == 0) xch[wv] = handback ? 0xFFFFFFFFu : chunk_bits_;
+        __syncthreads();
+        uint32_t T = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t b = xch[w];
+            d_poison = d_poison || b == 0xFFFFFFFFu;
+            if ((uint32_t)w < wv) d_start += b;
+            T += b;
+        }
+        d_total = T;
+        if (T + 64u > 32u * fb.fbw) d_poison = true;             // (a frame beyond the buffer: nothing of the kind comes out of 16-bit input)
+        if (d_poison) { d_start = 0; d_total = 0; }
+        const uint32_t nb = ((d_total + 7) >> 3) + 2;
+        if (wv == 0 && lane == 0) {
+            if (d_poison) {
+                atomicOr(&results[d.out_slot].err, FG_ERR_REDO);
+                if (B.guard) atomicOr(&B.guard[2], (unsigned long long)(FG_ERR_REDO | FG_ERR_CHAIN));
+                lb_publish(D.lb, d.out_slot, lb_word(D.epoch, FG_LB_POISON, 0));
+            }
+            else lb_publish(D.lb, d.out_slot, lb_word(D.epoch, d.out_slot == 0 ? FG_LB_PFX : FG_LB_AGG, nb));
+        }
+        if (!d_poison) {
+            if (wv == 0) {
+                const LDS uint8_t *hb = (const LDS uint8_t *)misc;
+                const uint32_t v = (uint32_t)lane < hl ? hb[lane] : 0, b = (uint32_t)lane < hl ? 8 : 0;
+                wave_lds_fence();
+                cb_or<true>(fb, (uint32_t)lane * 8, v, b);
+                wave_lds_fence();
+            }
+            if (hf == 0) (void)sub_header(true, d_start + hl * 8);
+        }
+        __syncthreads();
+    };
+    uint32_t fin_cw = 0, fin_cur = 0;       // (DIRECT) the word a lane ends in and its bits there: merged behind a barrier
+    bool fin_has = false;
     if (type != 0) {
         // ---- body: pass A = exact bit length of every lane's segment, prefix sum = its start, pass B = the codes
         int32_t q[MAXO];
@@ -2235,7 +2370,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             uint32_t cw = (p0 >> 5) - fb.wbase;
             uint32_t cur = (emit && !atom && inrange) ? fb.w[cw] : 0;
             auto put = [&](uint32_t at, uint32_t val, uint32_t vb) __attribute__((always_inline)) {
-                if (atom) { cb_or(fb, inrange ? at : (fb.wbase << 5), inrange ? val : 0, vb); return; }
+                if (atom) { cb_or<DIRECT>(fb, inrange ? at : (fb.wbase << 5), inrange ? val : 0, vb); return; }
                 const uint32_t rel = at - (fb.wbase << 5);
                 const uint32_t wi = rel >> 5, sh = rel & 31;
                 const u64 x = (u64)val << ((64 - sh - vb) & 63);
@@ -2311,9 +2446,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 #pragma unroll
             for (int u = 0; u < MAXO; u++) if (s0 + u < (RAG ? ln.len : seg)) step(u, s0 + u, s0 == 0);
             if (emit && !atom) {
-                wave_lds_fence();
-                if (inrange) fb.w[cw] |= cur;
-                wave_lds_fence();
+                if constexpr (DIRECT) { fin_cw = cw; fin_cur = cur; fin_has = inrange; }
+                else {
+                    wave_lds_fence();
+                    if (inrange) fb.w[cw] |= cur;
+                    wave_lds_fence();
+                }
             }
             return len;
         };
@@ -2389,9 +2527,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 else { put(pos + lead, val, vb); pos += lead + vb; }
                 if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
-            wave_lds_fence();
-            fb.w[cw] |= cur;
-            wave_lds_fence();
+            if constexpr (DIRECT) { fin_cw = cw; fin_cur = cur; fin_has = true; }
+            else {
+                wave_lds_fence();
+                fb.w[cw] |= cur;
+                wave_lds_fence();
+            }
         };
         const bool use_keep = KEEP && !ACC64 && !RAG && WS == 2 && ws == 2 && seg == 32 && type >= 2;
         uint32_t mylen0;
@@ -2399,7 +2540,18 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         else mylen0 = walk(false, 0, false, false);
         const uint32_t mylen = ln.act ? mylen0 : 0u;                 // (idle lanes of the ragged geometry code nothing)
         if (__any(mylen > (1u << 24))) redo = true;                  // absurd code lengths: the generic kernel copes
-        if (!redo) {
+        if constexpr (DIRECT) {
+            const uint32_t incl = wave_scan_add(redo ? 0u : mylen);
+            const uint32_t body = rl(incl, 63);
+            direct_sync(hl * 8 + sub_bits + body, redo);
+            if (!d_poison) {
+                const uint32_t mystart = d_start + hl * 8 + sub_bits + incl - mylen;
+                if (KEEP && use_keep && keep_ok) emit_keep(mystart);
+                else (void)walk(true, mystart, true, true);
+            }
+            bitpos = hl * 8 + sub_bits + body;
+        }
+        else if (!redo) {
             const uint32_t incl = wave_scan_add(mylen);
             const uint32_t mystart = bitpos + incl - mylen, myend = bitpos + incl;
             const uint32_t subend = bitpos + rl(incl, 63);
@@ -2426,6 +2578,99 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             bitpos = subend;
         }
     }
+    else if constexpr (DIRECT) {
+        direct_sync(hl * 8 + sub_bits, false);
+        bitpos = hl * 8 + sub_bits;
+    }
+    if constexpr (DIRECT) {
+        __syncthreads();                    // every whole word of the residual walks is stored: now the words two lanes (or waves) share
+        if (fin_has && !d_poison) __hip_atomic_fetch_or(&fb.w[fin_cw], fin_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) B.chunk_bits[(size_t)d.out_slot * 4 + chunk] = d_poison ? 0 : bitpos;
+        const uint32_t nbytes = (d_total + 7) >> 3, nb = nbytes + 2;            // frame without / with its CRC-16
+        if (wv == 0) {
+            // where the frame goes: the sizes in front of it
+            u64 excl = 0;
+            bool ok = !d_poison;
+            if (D.reserved & 1u) excl = (u64)d.out_slot * 11000ull;          // (tuning builds, FLACGPU_DIRECT_X: timing experiments, wrong places)
+            else if (ok && d.out_slot != 0) {
+                ok = lb_lookback(D.lb, d.out_slot, D.epoch, lane, excl, true);
+                if (lane == 0) {
+                    if (ok) lb_publish(D.lb, d.out_slot, lb_word(D.epoch, FG_LB_PFX, excl + nb));
+                    else {
+                        lb_publish(D.lb, d.out_slot, lb_word(D.epoch, FG_LB_POISON, 0));
+                        atomicOr(&results[d.out_slot].err, FG_ERR_REDO);
+                        if (B.guard) atomicOr(&B.guard[2], (unsigned long long)(FG_ERR_REDO | FG_ERR_CHAIN));
+                    }
+                }
+            }
+            if (lane == 0) { xch[8] = (uint32_t)excl; xch[9] = (uint32_t)(excl >> 32); xch[10] = ok ? 1u : 0u; }
+        }
+        __syncthreads();
+        if (xch[10] == 0 || (D.reserved & 2u)) return;           // (the whole workgroup: the call falls back to the chunk form)
+        const u64 excl = (u64)xch[8] | ((u64)xch[9] << 32);
+        const bool fits = excl + nb <= D.dst_cap;                   // (the host reports the short buffer once it has read the total)
+        uint8_t *out = D.dst + excl;
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        // CRC-16 and bytes: thread t owns the 16-byte granules t, t + NT, ... (zero granules in front so that the last step is full):
+        // state * x^(128 NT) + crc(granule), everything through look-up tables in LDS (the closed form of the polynomial costs forty
+        // instructions a word, four look-ups seventeen): ctab [0,512) the multiplication, [512,1536) a byte followed by 3, 2, 1, 0 zero
+        // bytes.  Folded at the end with x^(128 (NT - 1 - t) + 8 rem), rem = the bytes behind the last whole granule, which the last
+        // thread takes meanwhile.  Words in the window are most significant bit first; bytes leave through a byte swap.
+        const LDS uint16_t *T3 = ctab + 512, *T2 = ctab + 768, *T1 = ctab + 1024, *T0 = ctab + 1280;
+        auto crcw = [&](uint32_t c, uint32_t w) __attribute__((always_inline)) -> uint32_t {
+            return (uint32_t)T3[(c >> 8) ^ (w >> 24)] ^ (uint32_t)T2[(c & 0xFF) ^ ((w >> 16) & 0xFF)] ^ (uint32_t)T1[(w >> 8) & 0xFF] ^ (uint32_t)T0[w & 0xFF];
+        };
+        const uint32_t W = nbytes >> 2, tail = nbytes & 3, G = W >> 2, Wr = W & 3, rem = nbytes & 15;
+        const uint32_t pad = (NT - (G % NT)) % NT, Tn = (G + pad) / NT;
+        const uint32_t foldc = D.crcx[1536 + rem * NT + tid];
+        uint32_t st = 0;
+        for (uint32_t t = 0; t < Tn; t++) {
+            const int qi = (int)(t * NT + (uint32_t)tid) - (int)pad;
+            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+            u32x4 g = {0, 0, 0, 0};
+            if (qi >= 0) g = *(const LDS u32x4 *)(fb.w + 4 * qi);
+            st = (uint32_t)ctab[st >> 8] ^ (uint32_t)ctab[256 + (st & 0xFF)];
+            uint32_t cc = crcw(0, g.x);
+            cc = crcw(cc, g.y); cc = crcw(cc, g.z); cc = crcw(cc, g.w);
+            st ^= cc;
+            if (qi >= 0 && fits) {
+                U32 *o = (U32 *)(out + 16 * (size_t)qi);
+                o[0].v = __builtin_bswap32(g.x); o[1].v = __builtin_bswap32(g.y); o[2].v = __builtin_bswap32(g.z); o[3].v = __builtin_bswap32(g.w);
+            }
+        }
+        if (Tn) st = gf16_mul(st, foldc);
+        if (tid == NT - 1) {
+            uint32_t cr = 0;
+            for (uint32_t k = 0; k < Wr; k++) {
+                const uint32_t w = fb.w[4 * G + k];
+                cr = crcw(cr, w);
+                if (fits) ((U32 *)out)[4 * G + k].v = __builtin_bswap32(w);
+            }
+            const uint32_t wvl = fb.w[W];
+            for (uint32_t b = 0; b < tail; b++) {
+                const uint32_t byte = (wvl >> (24 - 8 * b)) & 0xFF;
+                cr = ((cr << 8) & 0xFFFF) ^ (uint32_t)T0[((cr >> 8) ^ byte) & 0xFF];
+                if (fits) out[W * 4 + b] = (uint8_t)byte;
+            }
+            st ^= cr;
+        }
+        st = wave_xor32(st);
+        // (no barrier: the wave that arrives last finishes the frame)
+        uint32_t arrived = 0;
+        if (lane == 0) {
+            __hip_atomic_fetch_xor(&xch[12], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            arrived = __hip_atomic_fetch_add(&xch[13], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (arrived == (uint32_t)NW - 1) {
+                const uint32_t crc = __hip_atomic_load(&xch[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (fits) { out[nbytes] = (uint8_t)(crc >> 8); out[nbytes + 1] = (uint8_t)crc; }
+                results[d.out_slot].bytes = nb;
+                D.offsets[d.out_slot] = excl;
+                if (D.user_offsets) D.user_offsets[d.out_slot] = excl;
+                if (d.out_slot + 1 == D.nblocks) { D.offsets[D.nblocks] = excl + nb; if (D.user_offsets) D.user_offsets[D.nblocks] = excl + nb; }
+            }
+        }
+        return;
+    }
     if (!redo) cb_flush(fb, lane, bitpos, true);
     if (lane == 0) {
         B.chunk_bits[(size_t)d.out_slot * 4 + chunk] = redo ? 0 : bitpos;
@@ -2443,13 +2688,16 @@ template <int WPB>
 __global__ void __launch_bounds__(WPB * 64)
 fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_t *slots, uint32_t slot_bytes, uint32_t chunk_cap_words,
                         uint32_t nw, const uint32_t *chunk_bits, FgBlockResult *results, u64 *offsets, uint8_t *dst,
-                        u64 dst_cap, const uint16_t *crctab, u64 *user_offsets, const unsigned long long *guard)
+                        u64 dst_cap, const uint16_t *crctab, u64 *user_offsets, const unsigned long long *guard, uint32_t first, FgPackDirect D)
 {
     __shared__ uint16_t tab[1792];           // [0,256) byte table, [256,768) x^2048 tables, [768,832) x^(32k), [1024,1792) slicing tables
     for (uint32_t j = threadIdx.x; j < 1792; j += WPB * 64) tab[j] = crctab[j];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t bi = blockIdx.x * WPB + (threadIdx.x >> 6);
+    // (behind a direct launch, D.lb set: the blocks [first, nblocks) of the list that kept the chunk form; their places come from
+    // the look-back words -- everything is published by now --, and the first wave hands the error flags to the host's words)
+    const uint32_t bi = first + blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (D.lb && lane == 0 && bi == first) offsets[D.nblocks + 1] = guard ? guard[2] : 0ull;
     if (bi >= nblocks) return;
     const FgBlockDesc d = descs[bi];
     const FgBlockResult res = results[d.out_slot];
@@ -2466,14 +2714,26 @@ fg_pipe_assemble_kernel(const FgBlockDesc *descs, uint32_t nblocks, const uint8_
     }
     const uint32_t nb = res.reserved == 4 ? ((res.err & FG_ERR_REDO) ? 0u : ((T + 7) >> 3) + 2) : res.bytes;
     if (lane == 0 && res.reserved == 4) results[d.out_slot].bytes = nb;        // (the scan no longer writes the pipeline's sizes back)
-    // the frame index for the caller (saves a device-to-device copy), and the guard counters beside the totals the host reads
-    if (lane == 0 && user_offsets) {
-        user_offsets[d.out_slot] = offsets[d.out_slot];
-        if (bi == 0) user_offsets[nblocks] = offsets[nblocks];
+    u64 myoff;
+    if (D.lb) {
+        if (!lb_lookback(D.lb, d.out_slot, D.epoch, lane, myoff, false)) return;       // (a broken chain: the direct kernels have said so, FG_ERR_CHAIN)
+        if (lane == 0) {
+            offsets[d.out_slot] = myoff;
+            if (user_offsets) user_offsets[d.out_slot] = myoff;
+            if (d.out_slot + 1 == D.nblocks) { offsets[D.nblocks] = myoff + nb; if (user_offsets) user_offsets[D.nblocks] = myoff + nb; }
+        }
     }
-    if (lane == 0 && bi == 0 && guard) { offsets[nblocks + 2] = guard[0]; offsets[nblocks + 3] = guard[1]; }
-    if (nb == 0 || offsets[d.out_slot] + nb > dst_cap) return;      // the host reports the short buffer once it has read the total
-    uint8_t *out = dst + offsets[d.out_slot];
+    else {
+        myoff = offsets[d.out_slot];
+        // the frame index for the caller (saves a device-to-device copy), and the guard counters beside the totals the host reads
+        if (lane == 0 && user_offsets) {
+            user_offsets[d.out_slot] = myoff;
+            if (bi == 0) user_offsets[nblocks] = offsets[nblocks];
+        }
+        if (lane == 0 && bi == 0 && guard) { offsets[nblocks + 2] = guard[0]; offsets[nblocks + 3] = guard[1]; }
+    }
+    if (nb == 0 || myoff + nb > dst_cap) return;      // the host reports the short buffer once it has read the total
+    uint8_t *out = dst + myoff;
     struct __attribute__((packed)) U32 { uint32_t v; };
     if (res.reserved != 4) {
         const uint32_t *sw = (const uint32_t *)(slots + (size_t)d.out_slot * slot_bytes);
