@@ -277,6 +277,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the drop-in API end-to-end leg')
     ap.add_argument('--no-configs', action='store_true', help='headline only: skip the configs[3] / configs[4] legs of the default run')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='test aid for --gpus N on a box with ONE GPU: every rank works on cuda:0, the collectives run over gloo on host tensors '
+                         '(tests/test_gpu_dist.py: rank 1\'s data path, the barriers and the MAX reduction on real kernels)')
     ap.add_argument('--no-direct', action='store_true', help='A/B: the chunk form of the packing stage (rounds 2-4) instead of the direct path')
     ap.add_argument('--no-passes', action='store_true', help='skip the event passes after the timed loop (profiling runs: the trace then holds the timed loop only)')
     ap.add_argument('--workload', choices=WORKLOADS, default=None,
@@ -301,10 +304,11 @@ def _free_port():
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process (torch.distributed.run, one
-    rank per GPU) and relay what rank 0 prints.  This process never touches a GPU -- counting devices does not initialise one --
-    and never replaces itself with another program.  A box with fewer than N GPUs is an error, not an n_gpus: 1 line."""
+    rank per GPU) and relay what rank 0 prints.  This process runs no GPU work and never replaces itself with another program
+    (torch.cuda.device_count() may initialise the HIP runtime here on builds of torch without amdsmi; the ranks are a fresh child
+    either way).  A box with fewer than N GPUs is an error, not an n_gpus: 1 line."""
     import subprocess
-    if not args.dry_run:
+    if not args.dry_run and not args.share_gpu:
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -403,6 +407,7 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     import torch.distributed as dist
     from pyflac_amd import batch, shard, _lib
     rank, world, dev = env['rank'], env['world'], env['dev']
+    cdev = env.get('coll', dev)          # where the collectives' tensors live (the GPU under RCCL; the host under --share-gpu / gloo)
     bs = 4096
     pcm16, sr, ch, bps, lengths = make_input(workload, seconds, rank, world, streams)
     pcm = torch.from_numpy(pcm16.astype(np.int32)).to(dev)     # int32 at the C ABI, like pyflac/encoder.py:112
@@ -413,7 +418,7 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     from pyflac_amd.encoder import stream_header_bytes
     hdr = stream_header_bytes(s) if rank == 0 else b''
     if world > 1:
-        hdr = shard.broadcast_header(hdr, dev)
+        hdr = shard.broadcast_header(hdr, cdev)
     assert len(hdr) == 86
 
     out = offs = dec = None
@@ -463,18 +468,25 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        mine_t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(every, mine_t)
+        rank_ms = [float(x.item()) / steps * 1e3 for x in every]
+        t = mine_t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # bit-exactness gate (outside the timed region, behind it: what is checked is what the timed steps left in the buffers -- and
     # nothing but the warm-up steps stands between the box's idle time and the first timed step): the round trip equals the input
-    assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
-    assert torch.equal(dec[:nsamp], pcm), 'round trip is not bit-exact'
+    rt_ok = int(status[:, 0].max()) == 0 and bool(torch.equal(dec[:nsamp], pcm))
+    if world == 1:
+        assert int(status[:, 0].max()) == 0, 'decoder reported frame errors'
+        assert rt_ok, 'round trip is not bit-exact'
     # what the GPU wrote, for the byte-for-byte check against the oracle after the timed region: the WHOLE stream (of the batch:
     # its first and its last stream, whole)
     h_chk = []
-    if rank == 0 and check:
+    if check:            # (every rank: at N > 1 each checks the first and the last stream of ITS share)
         if single:
             h_chk.append((0, nsamp, out[:int(offs[-(-nsamp // bs)].item())].cpu().numpy().tobytes()))
         else:
@@ -483,7 +495,7 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
             for n in lengths:
                 first_frame.append(first_frame[-1] + -(-n // bs))
             starts = np.concatenate([[0], np.cumsum(lengths)])
-            for k in sorted(set([0, len(lengths) // 2, len(lengths) - 1])):
+            for k in sorted(set([0, len(lengths) // 2, len(lengths) - 1] if world == 1 else [0, len(lengths) - 1])):
                 a, b = int(ho[first_frame[k]]), int(ho[first_frame[k + 1]])
                 h_chk.append((int(starts[k]), int(lengths[k]), out[a:b].cpu().numpy().tobytes()))
     ms_per_step = dt / steps * 1e3
@@ -526,6 +538,45 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     nblocks = int(est.nblocks)
     del out, offs, dec, pcm
     torch.cuda.empty_cache()
+    # checker use of the oracle: EVERY frame the GPU wrote (of the batch: every frame of its first, middle and last stream; at N > 1
+    # every rank's first and last stream) is the oracle's, byte for byte -- a round trip alone would also pass a wrong but decodable
+    # choice.  At N > 1 the verdicts are reduced over the ranks before anybody raises: a rank that stopped alone would leave the
+    # others waiting in the next collective.
+    checked = None
+    ok = rt_ok
+    if h_chk:
+        import hashlib
+        from oracle import oracle as O
+        cfg, _ = O.config(level, ch, bps, sr, bs, True)
+        tc = time.perf_counter()
+        shas, nfr_chk, nbytes = [], 0, 0
+        for start, n, got in h_chk:
+            ref, sizes = O.encode_stream(cfg, pcm16[start:start + n].astype(np.int32))
+            got_sha, want_sha = hashlib.sha256(got).hexdigest(), hashlib.sha256(ref[86:]).hexdigest()
+            ok = ok and got_sha == want_sha
+            shas.append(got_sha)
+            nfr_chk += len(sizes)
+            nbytes += len(got)
+        checked = {'frames': '%d of %d frames' % (nfr_chk, nblocks),
+                   'what': 'SHA-256 of the GPU stream == SHA-256 of oracle.encode_stream over the same PCM'
+                           + ('' if single else (' (first, middle and last stream of the batch, whole)' if world == 1 else
+                                                 ' (first and last stream of every rank\'s share, whole); round trip of every rank bit-exact')),
+                   'sha256': shas[0] if single and world == 1 else shas, 'bytes': nbytes, 'oracle_s': round(time.perf_counter() - tc, 1)}
+    if world > 1:
+        v = torch.tensor([1 if ok else 0, 1 if rt_ok else 0, int(checked['frames'].split()[0]) if checked else 0,
+                          checked['bytes'] if checked else 0], device=cdev, dtype=torch.int64)
+        every = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(every, v)
+        bad = [r for r in range(world) if int(every[r][0]) == 0]
+        if bad:
+            raise SystemExit('bench.py: rank(s) %s: %s' % (bad, 'round trip is not bit-exact' if any(int(every[r][1]) == 0 for r in bad)
+                                                           else 'encoded stream differs from the oracle'))
+        if checked:
+            checked['ranks'] = world
+            checked['frames'] = '%d frames over %d ranks (%d of %d on rank 0)' % (sum(int(e[2]) for e in every), world, int(every[0][2]), nblocks)
+            checked['bytes'] = sum(int(e[3]) for e in every)
+    else:
+        assert ok, 'encoded stream differs from the oracle'
     if rank != 0:
         return None
 
@@ -601,25 +652,10 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
                                 'decode_frac': (round(pmc['decode_valu_insts_per_launch'] / (dec_t * 1e-3) / slots, 4)
                                                 if pmc.get('decode_valu_insts_per_launch') else None),
                                 'source': 'profiles/' + pmc_name}
-    if h_chk:
-        # checker use of the oracle: EVERY frame the GPU wrote (of the batch: every frame of its first, middle and last stream)
-        # is the oracle's, byte for byte -- a round trip alone would also pass a wrong but decodable choice
-        import hashlib
-        from oracle import oracle as O
-        cfg, _ = O.config(level, ch, bps, sr, bs, True)
-        tc = time.perf_counter()
-        shas, nfr_chk, nbytes = [], 0, 0
-        for start, n, got in h_chk:
-            ref, sizes = O.encode_stream(cfg, pcm16[start:start + n].astype(np.int32))
-            got_sha, want_sha = hashlib.sha256(got).hexdigest(), hashlib.sha256(ref[86:]).hexdigest()
-            assert got_sha == want_sha, 'encoded stream differs from the oracle'
-            shas.append(got_sha)
-            nfr_chk += len(sizes)
-            nbytes += len(got)
-        res['checked'] = {'frames': '%d of %d frames' % (nfr_chk, nblocks),
-                          'what': 'SHA-256 of the GPU stream == SHA-256 of oracle.encode_stream over the same PCM'
-                                  + ('' if single else ' (first, middle and last stream of the batch, whole)'),
-                          'sha256': shas[0] if single else shas, 'bytes': nbytes, 'oracle_s': round(time.perf_counter() - tc, 1)}
+    if checked:
+        res['checked'] = checked
+    if world > 1:
+        res['ms_per_step_rank'] = [round(x, 3) for x in rank_ms]
     return res
 
 
@@ -654,13 +690,19 @@ def main():
     from pyflac_amd import batch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    if args.share_gpu:
+        local = 0                       # (every rank on cuda:0: the one GPU of a test box)
     if local >= torch.cuda.device_count():
         raise SystemExit('bench.py: rank %d has no GPU (local rank %d, %d visible)' % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
     env = {'rank': rank, 'world': world, 'dev': dev}
+    if world > 1:
+        if args.share_gpu:
+            dist.init_process_group('gloo')
+            env['coll'] = torch.device('cpu')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     ctx = batch.Context(local)
     if args.no_direct:
         # (A/B of round 5's direct packing path: chunks through HBM, sizes scan and assembly kernel, as in rounds 2-4)
@@ -681,7 +723,7 @@ def main():
             cfgs[wl]['roofline'] = {k2: r['roofline'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
             cfgs[wl]['roofline_decode'] = {k2: r['roofline_decode'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
     res = measure(env, ctx, workload, seconds, level, steps, args.warmup, args.streams, passes=not args.no_passes,
-                  check=world == 1 and not args.no_cpu_baseline)
+                  check=not args.no_cpu_baseline)
     if rank == 0:
         if cfgs:
             res['configs'] = cfgs

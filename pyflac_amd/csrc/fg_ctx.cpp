@@ -643,6 +643,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (direct) {
         const uint64_t fbits = 16 * 8 + (uint64_t)s->channels * (8 + 32 + (uint64_t)s->blocksize * (s->bits_per_sample + 1));
         direct_fcap = (uint32_t)(((fbits + 31) / 32 + 2 + 3) & ~3ull);
+        if (fg_tune("FLACGPU_FCAP")) direct_fcap = (uint32_t)atoi(fg_tune("FLACGPU_FCAP")) & ~3u;      // (occupancy experiments: larger frames fall back)
         const void *before = c->lb.p;
         if (!c->lb.ensure((size_t)nblocks * 8)) return false;
         // (a word counts only with this call's epoch: a fresh buffer, or the epoch counter back at its start, is cleared)
@@ -711,7 +712,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             PL.stages = 3;
             // (groups: flac_enc_pipe_impl.h / pipe_shape.inc; a launch of a few hundred blocks does not fill the chip once)
             static const int groups_env = getenv("FLACGPU_GROUPS") ? atoi(getenv("FLACGPU_GROUPS")) : 0;
-            PL.ngroups = groups_env > 0 ? (uint32_t)groups_env : (nfast >= 4096 ? 2u : 1u);
+            // (direct packing: the packing kernels of two groups run one behind the other anyway -- pipe_shape.inc --, and one chain of
+            // whole-launch kernels then is the faster form: 0.431-0.444 ms against 0.448-0.458 on the headline stream)
+            PL.ngroups = groups_env > 0 ? (uint32_t)groups_env : ((nfast >= 4096 && !direct) ? 2u : 1u);
             static const bool keep_off = getenv("FLACGPU_KEEP") && atoi(getenv("FLACGPU_KEEP")) == 0;
             PL.no_keep = keep_off ? 1u : 0u;
             if (c->debug) PL.ngroups = 1;

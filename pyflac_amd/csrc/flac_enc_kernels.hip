@@ -1159,7 +1159,6 @@ __global__ void fg_crc_tables_kernel(uint16_t *tab)
         }
     }
 }
-}
 
 __global__ void __launch_bounds__(64)
 fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, uint8_t *out,

@@ -41,6 +41,16 @@
 #define LDS __attribute__((address_space(3)))
 #define FGI __device__ __forceinline__
 
+#ifndef FGX_MERGE
+// evaluation (<= 16 bit, regular geometry): fixed-predictor sums and the first LPC vector's residual in ONE walk over the samples (the
+// candidate's samples formed once instead of twice: 3 instructions a sample fewer).  Measured slower on the MI355X, 124.4 -> 128.1 us
+// for the kernel on its own (gpurun_exp m0c0 / m1c0, one group): the merged loop spills four registers at the kernel's 64, and the
+// two short loops it replaces interleave better.  Off; kept for the A/B.
+#define FGX_MERGE 0
+#endif
+#ifndef FGX_CRCTAB
+#define FGX_CRCTAB 1                     // direct packing: CRC-16 of the frame through look-up tables in LDS (0: the closed form)
+#endif
 #define FGP_F64P 1                       // packing: the same (with the 168 registers that three workgroups per CU leave: 24-bit level 8 0.28 -> 0.25 ms)
 #define FGP_F64 1                        // evaluation: residuals of 17..25-bit samples through fp64 FMAs (pfir_f64n; 0 = pfir48)
 #define FGP_DH 16                        // autocorrelation: history doubles kept in front of each chunk (>= max lag + 1)
@@ -1224,17 +1234,24 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         return;
     }
     // candidate value of sample s of this lane's row (row offset `ro` = 0 or -rstr for the left neighbour)
+    // Round 5: candidate = (a + cb b) >> shift with the channels picked per candidate -- L: a = left, cb = 0; R: a = right, cb = 0;
+    // M: a = left, b = right, cb = 1, shift 1; S: cb = -1 -- one multiply-add and one shift where (ca l + cb r) >> shift took a select more.
     int32_t cca, ccb;
     uint32_t ccs;
     pipe_cand_coef(MS, C, cca, ccb, ccs);
+    (void)cca;
+    const bool cplain = !MS || C < 2;
+    const int32_t cvb = cplain ? 0 : ccb;
+    const LDS samp_t *const baseA = (NCH == 2 && C == 1) ? sR : sL, *const baseB = cplain ? baseA : sR;
+    const LDS samp_t *const rowA = baseA + (uint32_t)lane * rstr, *const rowB = baseB + (uint32_t)lane * rstr;
+    const LDS samp_t *const prvA = baseA + ln.prow * rstr + ln.plen, *const prvB = baseB + ln.prow * rstr + ln.plen;
     const uint32_t csh = (wraw & 0x100u) ? ccs : ccs + wst - pre;       // (staged samples are already down by `pre`)
-    auto samp = [&](int s) __attribute__((always_inline)) -> int32_t {
-        return pipe_cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, cca, ccb, csh);
-    };
+    auto cv = [&](int32_t a, int32_t b) __attribute__((always_inline)) -> int32_t { return (a + __mul24(b, cvb)) >> csh; };
+    auto samp = [&](int s) __attribute__((always_inline)) -> int32_t { return cv(rowA[s], rowB[s]); };
     // the k-th sample in front of this lane's first one (k >= 1)
     auto hsamp = [&](int k) __attribute__((always_inline)) -> int32_t {
         if (!RAG) return samp((int)seg - k - (int)rstr);
-        return pipe_cand(prvL[-k], (NCH == 2) ? (int32_t)prvR[-k] : 0, cca, ccb, csh);
+        return cv(prvA[-k], prvB[-k]);
     };
 
     uint32_t pmax0 = 0;
@@ -1249,6 +1266,30 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
     u64 tot[5];
     sum_t fsum = 0;            // per-lane sum of |residual| of the fixed predictor of the guessed order (set below)
     uint32_t guess;
+    // Round 5 (<= 16 bit, regular geometry): ONE walk over the lane's samples serves the fixed-predictor sums and the residual of the
+    // first LPC vector -- its quantised coefficients are there when the kernel starts --, so the candidate's samples are formed once
+    // where two walks formed them twice.  m_*: that vector's facts and the lane's sum of |residual|, picked up by pass 1 below.
+    bool m_have = false;
+    uint32_t m_order = 0, m_prec = 0;
+    int m_shift = 0;
+    int32_t m_q[MAXO];
+    sum_t m_psum = 0;
+#pragma unroll
+    for (int j = 0; j < MAXO; j++) m_q[j] = 0;
+    if constexpr (!ACC64 && !RAG) {
+        if (FGX_MERGE && P.max_lpc_order > 0 && P.nvec > 0 && seg >= (uint32_t)MAXO && rfl(B.nv[bi]) > 0) {
+            const size_t ridx = ((size_t)bi * NC + C) * P.nvec;
+            const uint32_t r = rfl(B.lres[ridx]);
+            if ((r >> 24) & 1) {
+                m_have = true;
+                m_order = r & 0xFF; m_prec = (r >> 8) & 0xFF; m_shift = (int)(int8_t)((r >> 16) & 0xFF);
+                if (m_order == 0) m_order = 1;
+                const int32_t qall = (lane < MAXO) ? B.qres[ridx * MAXO + lane] : 0;
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) m_q[j] = (int32_t)rl((uint32_t)qall, j);
+            }
+        }
+    }
     {
         sum_t facc[5], fwarm[5];
         // Everything carries a bias FB (values and differences stay far below it), so |a - b| is one v_sad_u32 on the biased
@@ -1258,6 +1299,65 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         uint32_t P0 = FB, P1 = FB, P2 = FB, P3 = FB;      // previous value and previous 1st..3rd differences (of zeros)
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) { facc[kk] = 0; fwarm[kk] = 0; }
+        bool merged_walk = false;
+        if constexpr (!ACC64 && !RAG) {
+            if (m_have) {
+                merged_walk = true;
+                // the MAXO samples in front of the lane's first one (zeros for lane 0): history of the filter, and of the differences
+                int32_t h[MAXO];
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) {
+                    int32_t x = 0;
+                    if (lane > 0) x = hsamp(1 + j);
+                    h[(MAXO - 1 - j) % MAXO] = x;
+                }
+#pragma unroll
+                for (int k = 4; k >= 1; k--) {
+                    const uint32_t vb = (uint32_t)h[(MAXO - k) % MAXO] + FB;
+                    const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
+                    P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
+                }
+                uint32_t psum = 0;
+                auto mstep = [&](int u, uint32_t s, auto PRO, bool guard) __attribute__((always_inline)) {
+                    constexpr bool pro = decltype(PRO)::value;      // samples 0..3 of the lane: the sums tell warm-up positions apart
+                    const int32_t x = samp((int)s);
+                    const int32_t res = x - (pfir24<MAXO>(m_q, h, u) >> m_shift);
+                    h[u] = x;
+                    const bool real = !guard || lane > 0 || s >= m_order;
+                    if (real) psum += pabs32(res);
+                    const uint32_t vb = (uint32_t)x + FB;
+                    const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
+                    if (pro) {
+                        const uint32_t ab[5] = {psad(vb, FB, 0), psad(vb, P0, 0), psad(e1b, P1, 0), psad(e2b, P2, 0), psad(e3b, P3, 0)};
+#pragma unroll
+                        for (int kk = 0; kk < 5; kk++) {
+                            facc[kk] += (lane > 0) ? ab[kk] : 0u;
+                            if ((int)s >= kk) fwarm[kk] += ab[kk];
+                        }
+                    }
+                    else {
+                        facc[0] = (sum_t)psad(vb, FB, (uint32_t)facc[0]); facc[1] = (sum_t)psad(vb, P0, (uint32_t)facc[1]);
+                        facc[2] = (sum_t)psad(e1b, P1, (uint32_t)facc[2]); facc[3] = (sum_t)psad(e2b, P2, (uint32_t)facc[3]);
+                        facc[4] = (sum_t)psad(e3b, P3, (uint32_t)facc[4]);
+                    }
+                    P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
+                };
+                typedef std::integral_constant<bool, true> TT;
+                typedef std::integral_constant<bool, false> FF;
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) { if (u < 4) mstep(u, (uint32_t)u, TT(), true); else mstep(u, (uint32_t)u, FF(), true); }
+                uint32_t s0 = MAXO;
+#pragma unroll 1
+                for (; s0 + MAXO <= seg; s0 += MAXO) {
+#pragma unroll
+                    for (int u = 0; u < MAXO; u++) mstep(u, s0 + u, FF(), false);
+                }
+#pragma unroll
+                for (int u = 0; u < MAXO; u++) if (s0 + u < seg) mstep(u, s0 + u, FF(), false);
+                m_psum = (sum_t)psum;
+            }
+        }
+        if (!merged_walk) {
 #pragma unroll
         for (int s = -4; s < 4; s++) {
             int32_t v = 0;
@@ -1275,6 +1375,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             }
             P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
         }
+        }
         auto fstep = [&](int s) __attribute__((always_inline)) {
             const uint32_t vb = (uint32_t)samp(s) + FB;
             const uint32_t e1b = vb - P0 + FB, e2b = e1b - P1 + FB, e3b = e2b - P2 + FB;
@@ -1290,6 +1391,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             P0 = vb; P1 = e1b; P2 = e2b; P3 = e3b;
         };
         int s4 = 4;
+        if (merged_walk) s4 = (int)seg;
 #pragma unroll 1
         for (; s4 + 4 <= (int)seg; s4 += 4) {
 #pragma unroll
@@ -1321,7 +1423,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                 const uint32_t mS = 0xFFFFFFFFu / geo.S + 1, mB1 = 0xFFFFFFFFu / (geo.base + 1) + 1, mB = 0xFFFFFFFFu / geo.base + 1;
                 auto xat = [&](uint32_t g) -> i64 {          // candidate value of sample g of the block
                     const uint32_t ad = pipe_rag_addr(geo, g, mS, mB1, mB);
-                    return (i64)pipe_cand(sL[ad], (NCH == 2) ? (int32_t)sR[ad] : 0, cca, ccb, csh);
+                    return (i64)cv(baseA[ad], baseB[ad]);
                 };
                 auto aabs = [](i64 v) -> u64 { return (u64)(v < 0 ? -v : v); };
                 // exact errors of orders 0..4 at d[i] (= sample i + 4 of the block)
@@ -1387,10 +1489,21 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
         const uint32_t g = guess;
         const u64 tg = g == 0 ? tot[0] : g == 1 ? tot[1] : g == 2 ? tot[2] : g == 3 ? tot[3] : tot[4];
         const double len = (double)(n - 4);
-        const float rbg = (float)((tg > 0) ? log(FG_LN2 * (double)tg / len) / FG_LN2 : 0.0);
+        // libFLAC: bits per sample of the guessed fixed predictor, rbg = (float)(log(ln2 * total / len) / ln2); the fixed predictor is
+        // evaluated unless rbg >= bits per sample.  Far below 2^(sb - 1) the answer needs no logarithm (its two hundred instructions
+        // ran on every wave): ln2 total < len 2^(sb - 2) leaves log2 of the ratio more than a bit under sb - 1.
+        bool fixed_worth;
+        {
+            const double num = FG_LN2 * (double)tg;
+            if (tg > 0 && sb >= 3 && num < len * __hiloint2double((int)((1023u + sb - 2u) << 20), 0)) fixed_worth = true;
+            else {
+                const float rbg = (float)((tg > 0) ? log(num / len) / FG_LN2 : 0.0);
+                fixed_worth = !(rbg >= (float)sb);
+            }
+        }
         bool constant = false;
         if (tot[1] == 0) {
-            const int32_t x0 = pipe_cand(sL[0], (NCH == 2) ? (int32_t)sR[0] : 0, cca, ccb, csh);
+            const int32_t x0 = cv(baseA[0], baseB[0]);
             uint32_t ne = 0;
 #pragma unroll 1
             for (uint32_t s = 0; s < seg + (RAG ? 1u : 0u); s++) ne |= ((!RAG || s < ln.len) && samp((int)s) != x0);
@@ -1425,7 +1538,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             if (cb < best) { best = cb; d_type = 0; }
         }
         else {
-            if (!(rbg >= (float)sb)) do_fixed = true;
+            if (fixed_worth) do_fixed = true;
             if (P.max_lpc_order > 0) do_lpc = true;
         }
     }
@@ -1456,6 +1569,13 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             if (mydbg && lane == 0) mydbg->cand[C].lpc_guess[v] = ((r >> 25) & 1) ? (r & 0xFF) : 0;
             if (!((r >> 24) & 1)) continue;
             if (order == 0) order = 1;
+            const bool from_merged = !ACC64 && !RAG && pass == 1 && m_have;      // (the walk above has this vector's sums)
+            if (from_merged) {
+#pragma unroll
+                for (int j = 0; j < MAXO; j++) q[j] = m_q[j];
+                psum = m_psum;
+            }
+            else {
             const int32_t qall = (lane < MAXO) ? B.qres[ridx * MAXO + lane] : 0;
 #pragma unroll
             for (int j = 0; j < MAXO; j++) q[j] = (int32_t)rl((uint32_t)qall, j);
@@ -1530,6 +1650,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
             if constexpr (FGP_F64 && ACC64) {
                 if (!(pmaxd < 2147483648.0)) ovf = 1;
                 psum = ovf ? (sum_t)0 : (sum_t)psumd;
+            }
             }
         }
         const bool dead = ACC64 && __any(ovf != 0);
@@ -1995,35 +2116,73 @@ FGI void cb_reserve(ChunkBits &b, int lane, uint32_t bitpos, uint32_t bits)
 // this call -- then state and value belong together -- or counts as empty.
 FGI u64 lb_word(uint32_t epoch, u64 state, u64 value) { return ((u64)(epoch & 0xFFFFFu) << 44) | (state << FG_LB_VBITS) | (value & ((1ull << FG_LB_VBITS) - 1)); }
 FGI void lb_publish(u64 *lb, uint32_t k, u64 w) { __hip_atomic_store(&lb[k], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Sum of the sizes of frames 0 .. k - 1 (one wave, all lanes; the result is wave-uniform).  Lane l looks at frame pos - l; the
-// window moves back by 64 until it holds a prefix.  An empty word in front of the first prefix is waited for (its workgroup runs, or
-// will: workgroups start in the order of their numbers); false: a poisoned word, or the wait ran out (5 ms -- a whole call takes less).
-FGI bool lb_lookback(const u64 *lb, uint32_t k, uint32_t epoch, int lane, u64 &excl, bool spin)
+// Sum of the sizes of frames 0 .. k - 1 (one wave, all lanes; the result is wave-uniform).  A trip to memory fetches FG_LB_NWIN
+// windows of 64 frames (lane l: frames pos - l, pos - 64 - l, ...), examined nearest first; lb_fetch only issues the loads -- the
+// packing kernel does so ahead of its CRC pass and looks at the words behind it, so the first trip costs nothing.  The workgroups of
+// a launch are resident a thousand at a time and publish their prefix late in their lives, so the nearest prefix usually lies a few
+// windows back and the later trips are waited for.  More windows a trip do NOT pay: the loads go past the L2 (device scope), and on
+// the headline stream the encode launch took 0.432 / 0.434 / 0.451 / 0.449 / 0.451 ms with 1 / 2 / 4 / 8 / 16 windows a trip (same
+// box, gpurun_exp w1..w8); 0.443 with one window and no fetch ahead, 0.426 with no look-back at all (a tuning build: wrong places).
+// An empty word in front of the first prefix is waited for (its workgroup runs, or will: workgroups start in the order of their
+// numbers); a poisoned word, or a wait of more than 5 ms (a whole call takes less), gives up.
+#ifndef FG_LB_NWIN
+#define FG_LB_NWIN 1
+#endif
+FGI void lb_fetch(const u64 *lb, int64_t pos, uint32_t epoch, int lane, u64 (&v)[FG_LB_NWIN])
 {
-    u64 acc = 0;
-    int64_t pos = (int64_t)k - 1;
-    const u64 t0 = wall_clock64();
-    while (pos >= 0) {
-        const int64_t idx = pos - lane;
-        u64 v = lb_word(epoch, FG_LB_PFX, 0);                       // in front of frame 0: nothing
-        if (idx >= 0) v = __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t st = ((uint32_t)(v >> 44) == (epoch & 0xFFFFFu)) ? ((uint32_t)(v >> FG_LB_VBITS) & 3u) : 0u;
+#pragma unroll
+    for (int w = 0; w < FG_LB_NWIN; w++) {
+        const int64_t idx = pos - 64 * w - lane;
+        v[w] = lb_word(epoch, FG_LB_PFX, 0);                       // in front of frame 0: nothing
+        if (idx >= 0) v[w] = __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// 0: done (acc has the sum); 1: sizes only, look further back (acc and pos moved); 2: an empty word in the way (nothing moved: fetch
+// again); 3: poisoned
+FGI int lb_examine(const u64 (&v)[FG_LB_NWIN], uint32_t epoch, int lane, u64 &acc, int64_t &pos)
+{
+    const u64 vmask = (1ull << FG_LB_VBITS) - 1;
+    u64 mine = 0;
+#pragma unroll
+    for (int w = 0; w < FG_LB_NWIN; w++) {
+        const uint32_t st = ((uint32_t)(v[w] >> 44) == (epoch & 0xFFFFFu)) ? ((uint32_t)(v[w] >> FG_LB_VBITS) & 3u) : 0u;
         const u64 m_inv = __ballot(st == 0), m_pfx = __ballot(st == (uint32_t)FG_LB_PFX), m_poi = __ballot(st == (uint32_t)FG_LB_POISON);
         const uint32_t p = m_pfx ? (uint32_t)__builtin_ctzll(m_pfx) : 64u;
         const u64 upto = p >= 63 ? ~0ull : ((2ull << p) - 1);
-        if (m_poi & upto) return false;
-        if (m_inv & upto) {
+        if (m_poi & upto) return 3;
+        if (m_inv & upto) return 2;
+        mine += ((uint32_t)lane <= p) ? (v[w] & vmask) : 0ull;
+        if (p < 64) { acc += wave_sum64(mine); return 0; }
+    }
+    acc += wave_sum64(mine);
+    pos -= 64 * FG_LB_NWIN;
+    return 1;
+}
+// the rest of a look-back whose first fetch is in `v`
+FGI bool lb_finish(const u64 *lb, uint32_t epoch, int lane, u64 (&v)[FG_LB_NWIN], int64_t pos, u64 &excl, bool spin)
+{
+    u64 acc = 0;
+    const u64 t0 = wall_clock64();
+    for (;;) {
+        const int r = lb_examine(v, epoch, lane, acc, pos);
+        if (r == 0 || pos < 0) break;
+        if (r == 3) return false;
+        if (r == 2) {
             if (!spin || wall_clock64() - t0 > 500000ull) return false;
             __builtin_amdgcn_s_sleep(4);
-            continue;
         }
-        const u64 mine = ((uint32_t)lane <= p) ? (v & ((1ull << FG_LB_VBITS) - 1)) : 0ull;
-        acc += wave_sum64(mine);
-        if (p < 64) break;
-        pos -= 64;
+        lb_fetch(lb, pos, epoch, lane, v);
     }
     excl = acc;
     return true;
+}
+FGI bool lb_lookback(const u64 *lb, uint32_t k, uint32_t epoch, int lane, u64 &excl, bool spin)
+{
+    u64 v[FG_LB_NWIN];
+    excl = 0;
+    if (k == 0) return true;
+    lb_fetch(lb, (int64_t)k - 1, epoch, lane, v);
+    return lb_finish(lb, epoch, lane, v, (int64_t)k - 1, excl, spin);
 }
 
 // Blocks that keep the chunk form beside a direct launch (short blocks, the ragged geometry, frames of the generic kernel) publish
@@ -2587,19 +2746,58 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         if (fin_has && !d_poison) __hip_atomic_fetch_or(&fb.w[fin_cw], fin_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0) B.chunk_bits[(size_t)d.out_slot * 4 + chunk] = d_poison ? 0 : bitpos;
         const uint32_t nbytes = (d_total + 7) >> 3, nb = nbytes + 2;            // frame without / with its CRC-16
+        // where the frame goes: the sizes in front of it.  Wave 0 sends for them now and looks at them behind the CRC pass
+        u64 lbv[FG_LB_NWIN];
+        const bool look = wv == 0 && !d_poison && d.out_slot != 0 && !(D.reserved & 1u);
+        if (look) lb_fetch(D.lb, (int64_t)d.out_slot - 1, D.epoch, lane, lbv);
+        __syncthreads();
+        // CRC-16: thread t owns the 16-byte granules t, t + NT, ... (zero granules in front so that the last step is full):
+        // state * x^(128 NT) + crc(granule), everything through look-up tables in LDS (the closed form of the polynomial costs forty
+        // instructions a word, four look-ups seventeen): ctab [0,512) the multiplication, [512,1536) a byte followed by 3, 2, 1, 0 zero
+        // bytes.  Folded at the end with x^(128 (NT - 1 - t) + 8 rem), rem = the bytes behind the last whole granule, which the last
+        // thread takes meanwhile.  Words in the window are most significant bit first.
+        const LDS uint16_t *T3 = ctab + 512, *T2 = ctab + 768, *T1 = ctab + 1024, *T0 = ctab + 1280;
+        auto crcw = [&](uint32_t c, uint32_t w) __attribute__((always_inline)) -> uint32_t {
+            if (!FGX_CRCTAB) return crc16_word(c, w);
+            return (uint32_t)T3[(c >> 8) ^ (w >> 24)] ^ (uint32_t)T2[(c & 0xFF) ^ ((w >> 16) & 0xFF)] ^ (uint32_t)T1[(w >> 8) & 0xFF] ^ (uint32_t)T0[w & 0xFF];
+        };
+        const uint32_t W = nbytes >> 2, tail = nbytes & 3, G = W >> 2, Wr = W & 3, rem = nbytes & 15;
+        if (!d_poison && !(D.reserved & 2u)) {
+            const uint32_t pad = (NT - (G % NT)) % NT, Tn = (G + pad) / NT;
+            const uint32_t foldc = D.crcx[1536 + rem * NT + tid];
+            uint32_t st = 0;
+            for (uint32_t t = 0; t < Tn; t++) {
+                const int qi = (int)(t * NT + (uint32_t)tid) - (int)pad;
+                typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+                u32x4 g = {0, 0, 0, 0};
+                if (qi >= 0) g = *(const LDS u32x4 *)(fb.w + 4 * qi);
+                st = (uint32_t)ctab[st >> 8] ^ (uint32_t)ctab[256 + (st & 0xFF)];
+                uint32_t cc = crcw(0, g.x);
+                cc = crcw(cc, g.y); cc = crcw(cc, g.z); cc = crcw(cc, g.w);
+                st ^= cc;
+            }
+            if (Tn) st = gf16_mul(st, foldc);
+            if (tid == NT - 1) {
+                uint32_t cr = 0;
+                for (uint32_t k = 0; k < Wr; k++) cr = crcw(cr, fb.w[4 * G + k]);
+                const uint32_t wvl = fb.w[W];
+                for (uint32_t b = 0; b < tail; b++) cr = ((cr << 8) & 0xFFFF) ^ (uint32_t)T0[((cr >> 8) ^ (wvl >> (24 - 8 * b))) & 0xFF];
+                st ^= cr;
+            }
+            st = wave_xor32(st);
+            if (lane == 0) __hip_atomic_fetch_xor(&xch[12], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (wv == 0) {
-            // where the frame goes: the sizes in front of it
             u64 excl = 0;
             bool ok = !d_poison;
             if (D.reserved & 1u) excl = (u64)d.out_slot * 11000ull;          // (tuning builds, FLACGPU_DIRECT_X: timing experiments, wrong places)
-            else if (ok && d.out_slot != 0) {
-                ok = lb_lookback(D.lb, d.out_slot, D.epoch, lane, excl, true);
+            else if (look) {
+                ok = lb_finish(D.lb, D.epoch, lane, lbv, (int64_t)d.out_slot - 1, excl, true);
                 if (lane == 0) {
                     if (ok) lb_publish(D.lb, d.out_slot, lb_word(D.epoch, FG_LB_PFX, excl + nb));
                     else {
                         lb_publish(D.lb, d.out_slot, lb_word(D.epoch, FG_LB_POISON, 0));
-                        atomicOr(&results[d.out_slot].err, FG_ERR_REDO);
-                        if (B.guard) atomicOr(&B.guard[2], (unsigned long long)(FG_ERR_REDO | FG_ERR_CHAIN));
+                        if (B.guard) atomicOr(&B.guard[2], (unsigned long long)FG_ERR_CHAIN);
                     }
                 }
             }
@@ -2608,66 +2806,30 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         __syncthreads();
         if (xch[10] == 0 || (D.reserved & 2u)) return;           // (the whole workgroup: the call falls back to the chunk form)
         const u64 excl = (u64)xch[8] | ((u64)xch[9] << 32);
-        const bool fits = excl + nb <= D.dst_cap;                   // (the host reports the short buffer once it has read the total)
-        uint8_t *out = D.dst + excl;
-        struct __attribute__((packed)) U32 { uint32_t v; };
-        // CRC-16 and bytes: thread t owns the 16-byte granules t, t + NT, ... (zero granules in front so that the last step is full):
-        // state * x^(128 NT) + crc(granule), everything through look-up tables in LDS (the closed form of the polynomial costs forty
-        // instructions a word, four look-ups seventeen): ctab [0,512) the multiplication, [512,1536) a byte followed by 3, 2, 1, 0 zero
-        // bytes.  Folded at the end with x^(128 (NT - 1 - t) + 8 rem), rem = the bytes behind the last whole granule, which the last
-        // thread takes meanwhile.  Words in the window are most significant bit first; bytes leave through a byte swap.
-        const LDS uint16_t *T3 = ctab + 512, *T2 = ctab + 768, *T1 = ctab + 1024, *T0 = ctab + 1280;
-        auto crcw = [&](uint32_t c, uint32_t w) __attribute__((always_inline)) -> uint32_t {
-            return (uint32_t)T3[(c >> 8) ^ (w >> 24)] ^ (uint32_t)T2[(c & 0xFF) ^ ((w >> 16) & 0xFF)] ^ (uint32_t)T1[(w >> 8) & 0xFF] ^ (uint32_t)T0[w & 0xFF];
-        };
-        const uint32_t W = nbytes >> 2, tail = nbytes & 3, G = W >> 2, Wr = W & 3, rem = nbytes & 15;
-        const uint32_t pad = (NT - (G % NT)) % NT, Tn = (G + pad) / NT;
-        const uint32_t foldc = D.crcx[1536 + rem * NT + tid];
-        uint32_t st = 0;
-        for (uint32_t t = 0; t < Tn; t++) {
-            const int qi = (int)(t * NT + (uint32_t)tid) - (int)pad;
-            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-            u32x4 g = {0, 0, 0, 0};
-            if (qi >= 0) g = *(const LDS u32x4 *)(fb.w + 4 * qi);
-            st = (uint32_t)ctab[st >> 8] ^ (uint32_t)ctab[256 + (st & 0xFF)];
-            uint32_t cc = crcw(0, g.x);
-            cc = crcw(cc, g.y); cc = crcw(cc, g.z); cc = crcw(cc, g.w);
-            st ^= cc;
-            if (qi >= 0 && fits) {
-                U32 *o = (U32 *)(out + 16 * (size_t)qi);
-                o[0].v = __builtin_bswap32(g.x); o[1].v = __builtin_bswap32(g.y); o[2].v = __builtin_bswap32(g.z); o[3].v = __builtin_bswap32(g.w);
-            }
-        }
-        if (Tn) st = gf16_mul(st, foldc);
-        if (tid == NT - 1) {
-            uint32_t cr = 0;
-            for (uint32_t k = 0; k < Wr; k++) {
-                const uint32_t w = fb.w[4 * G + k];
-                cr = crcw(cr, w);
-                if (fits) ((U32 *)out)[4 * G + k].v = __builtin_bswap32(w);
-            }
-            const uint32_t wvl = fb.w[W];
-            for (uint32_t b = 0; b < tail; b++) {
-                const uint32_t byte = (wvl >> (24 - 8 * b)) & 0xFF;
-                cr = ((cr << 8) & 0xFFFF) ^ (uint32_t)T0[((cr >> 8) ^ byte) & 0xFF];
-                if (fits) out[W * 4 + b] = (uint8_t)byte;
-            }
-            st ^= cr;
-        }
-        st = wave_xor32(st);
-        // (no barrier: the wave that arrives last finishes the frame)
-        uint32_t arrived = 0;
-        if (lane == 0) {
-            __hip_atomic_fetch_xor(&xch[12], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            arrived = __hip_atomic_fetch_add(&xch[13], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (arrived == (uint32_t)NW - 1) {
-                const uint32_t crc = __hip_atomic_load(&xch[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (fits) { out[nbytes] = (uint8_t)(crc >> 8); out[nbytes + 1] = (uint8_t)crc; }
+        if (excl + nb > D.dst_cap) {                                 // (the host reports the short buffer once it has read the total)
+            if (tid == 0) {
                 results[d.out_slot].bytes = nb;
                 D.offsets[d.out_slot] = excl;
                 if (D.user_offsets) D.user_offsets[d.out_slot] = excl;
                 if (d.out_slot + 1 == D.nblocks) { D.offsets[D.nblocks] = excl + nb; if (D.user_offsets) D.user_offsets[D.nblocks] = excl + nb; }
             }
+            return;
+        }
+        uint8_t *out = D.dst + excl;
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        // the bytes: consecutive lanes store consecutive words -- 256 contiguous bytes an instruction, wherever the frame starts
+        for (uint32_t j = (uint32_t)tid; j < W; j += NT) ((U32 *)out)[j].v = __builtin_bswap32(fb.w[j]);
+        if (tid == NT - 1) {
+            const uint32_t wvl = fb.w[W];
+            for (uint32_t b = 0; b < tail; b++) out[W * 4 + b] = (uint8_t)(wvl >> (24 - 8 * b));
+        }
+        if (tid == 0) {
+            const uint32_t crc = xch[12];
+            out[nbytes] = (uint8_t)(crc >> 8); out[nbytes + 1] = (uint8_t)crc;
+            results[d.out_slot].bytes = nb;
+            D.offsets[d.out_slot] = excl;
+            if (D.user_offsets) D.user_offsets[d.out_slot] = excl;
+            if (d.out_slot + 1 == D.nblocks) { D.offsets[D.nblocks] = excl + nb; if (D.user_offsets) D.user_offsets[D.nblocks] = excl + nb; }
         }
         return;
     }

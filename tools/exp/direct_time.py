@@ -7,6 +7,9 @@ secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 direct = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pcm = synth.config2_stereo16(secs, 3)
+import os
+if os.environ.get('QUIET'):
+    pcm = pcm >> int(os.environ['QUIET'])
 t = torch.from_numpy(pcm.astype(np.int32)).cuda()
 a = batch.Context(0)
 _lib.lib().flacgpu_set_direct(a._h, direct)
@@ -17,4 +20,4 @@ for r in range(reps):
     o, f, st = a.encode(s, t, out=o, offsets=f)
     ms.append(st.total_gpu_ms)
 ms = sorted(ms[3:])
-print('direct %d path %d  encode gpu ms: min %.3f median %.3f' % (direct, st.direct_path, ms[0], ms[len(ms) // 2]))
+print('direct %d path %d  encode gpu ms: min %.3f median %.3f  bytes/frame %.0f' % (direct, st.direct_path, ms[0], ms[len(ms) // 2], st.total_bytes / st.nblocks))
