@@ -2216,8 +2216,15 @@ fg_pipe_publish_kernel(const FgBlockDesc *descs, uint32_t first, uint32_t count,
 // DIRECT (round 5): the workgroup's waves write into ONE frame buffer in LDS at their final bit positions (the four chunk lengths
 // are exchanged behind the measuring walk), take the CRC-16 of the frame there and store the bytes at the frame's final place in
 // the output stream, which a decoupled look-back over the frame sizes supplies (FgPackDirect).  Two waves per subframe only.
-template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG, bool KEEP = false, bool DIRECT = false>
-__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : ((RAG || KEEP || DIRECT) ? 4 : 5))
+// ALIAS (with DIRECT and KEEP; blocks of 4096 samples): the frame buffer lies OVER the staged samples.  The measuring walk keeps the
+// residuals in registers, so behind it nobody needs the samples any more -- 22 KB of LDS a workgroup instead of 39.5, and the
+// registers then allow five workgroups a CU instead of four.  A wave that has to walk its samples a second time (a verbatim
+// subframe, a residual beyond 16 bits, a short block) reads them from memory there: rare, and then slow.
+template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG, bool KEEP = false, bool DIRECT = false, bool ALIAS = false>
+#ifndef FGX_ALIAS_WAVES
+#define FGX_ALIAS_WAVES 5
+#endif
+__global__ void __launch_bounds__(NCH * WS * 64, ACC64 ? 3 : (ALIAS ? FGX_ALIAS_WAVES : ((RAG || KEEP || DIRECT) ? 4 : 5)))
 fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint8_t *slots, FgBlockResult *results,
                     uint32_t chunk_cap_words, uint32_t fbw_words, uint32_t bi0, FgPackDirect D)
 {
@@ -2249,15 +2256,18 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     // (DIRECT: ONE window of fbw_words = the whole frame, shared by the waves; behind it the waves' scratch words, the words the waves
     // exchange and the two look-up tables of the CRC pass)
     LDS uint32_t *const area = (LDS uint32_t *)((LDS unsigned char *)smem + (NCH == 2 ? 2 : 1) * sbytes);
-    LDS uint32_t *fbw = DIRECT ? area : area + wv * (fbw_words + 2 + 64);
-    LDS uint32_t *misc = DIRECT ? area + (fbw_words + 2) + wv * 64 : fbw + fbw_words + 2;     // 64 words per wave: header bytes, then the packer's scratch words
-    LDS uint32_t *const xch = area + (fbw_words + 2) + NW * 64;                             // (DIRECT) 16 words
-    LDS uint16_t *const ctab = (LDS uint16_t *)(xch + 16);                                   // (DIRECT) 1536 entries
+    // (ALIAS: the frame buffer starts where the staged samples do; the rest lies behind the longer of the two)
+    const uint32_t stg_words = (uint32_t)(((NCH == 2 ? 2 : 1) * sbytes) >> 2);
+    LDS uint32_t *const tailbase = ALIAS ? (LDS uint32_t *)smem + (stg_words > fbw_words + 2 ? stg_words : fbw_words + 2) : area + (fbw_words + 2);
+    LDS uint32_t *fbw = ALIAS ? (LDS uint32_t *)smem : (DIRECT ? area : area + wv * (fbw_words + 2 + 64));
+    LDS uint32_t *misc = DIRECT ? tailbase + wv * 64 : fbw + fbw_words + 2;     // 64 words per wave: header bytes, then the packer's scratch words
+    LDS uint32_t *const xch = tailbase + NW * 64;                             // (DIRECT) 16 words
+    LDS uint16_t *const ctab = (LDS uint16_t *)(xch + 16);                     // (DIRECT) 1536 entries
     bool pre_ok = true;
     const uint32_t pre = ACC64 ? pipe_preshift<NCH, NC>(P, B, bi, pre_ok) : 0u;
     (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo, pre);
     if constexpr (DIRECT) {
-        for (uint32_t j = tid; j < fbw_words + 2; j += NT) fbw[j] = 0;
+        if constexpr (!ALIAS) { for (uint32_t j = tid; j < fbw_words + 2; j += NT) fbw[j] = 0; }
         for (uint32_t j = tid; j < 1536; j += NT) ctab[j] = D.crcx[j];
         if (tid < 16) xch[tid] = 0;
     }
@@ -2387,7 +2397,8 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes
     // 1..order = warm-up samples, then precision/shift, coefficients, coding method + partition order.  Returns the bits; with
     // `emit` they are written from bit `at` on (DIRECT measures first and writes behind the exchange of the chunk lengths).
-    auto sub_header = [&](bool emit, uint32_t at) __attribute__((always_inline)) -> uint32_t {
+    uint32_t s_pv = 0, s_pb = 0, s_val = 0, s_vb = 0, s_off = 0;      // this lane's field(s) of the subframe header and where they start in it
+    auto sub_fields = [&]() __attribute__((always_inline)) -> uint32_t {
         uint32_t hdr;
         switch (type) {
         case 0: hdr = 0x00; break;
@@ -2416,27 +2427,33 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         else if (pred && (uint32_t)lane == (type == 3 ? 2 * order + 2 : order + 1)) { val = (method << 4) | po; vb = 6; }
         const uint32_t mine = pb + vb;
         const uint32_t incl = wave_scan_add(mine);
-        const uint32_t total = rl(incl, 63);
-        if (emit) {
-            if constexpr (!DIRECT) cb_reserve(fb, lane, at, total);
-            const uint32_t o = at + incl - mine;
-            cb_or<DIRECT>(fb, o, pv, pb);
-            cb_or<DIRECT>(fb, o + pb, val, vb);
-            wave_lds_fence();
-        }
-        return total;
+        s_pv = pv; s_pb = pb; s_val = val; s_vb = vb; s_off = incl - mine;
+        return rl(incl, 63);
+    };
+    auto sub_emit = [&](uint32_t at) __attribute__((always_inline)) {
+        cb_or<DIRECT>(fb, at + s_off, s_pv, s_pb);
+        cb_or<DIRECT>(fb, at + s_off + s_pb, s_val, s_vb);
+        wave_lds_fence();
     };
     uint32_t sub_bits = 0;          // (DIRECT) bits of this wave's subframe header
-    if (hf == 0) {
-        if constexpr (DIRECT) sub_bits = sub_header(false, 0);
-        else bitpos += sub_header(true, bitpos);
+    if constexpr (!DIRECT) {
+        if (hf == 0) {
+            const uint32_t total = sub_fields();
+            cb_reserve(fb, lane, bitpos, total);
+            sub_emit(bitpos);
+            bitpos += total;
+        }
     }
     // ---- DIRECT: the waves exchange their chunk lengths (0xFFFFFFFF: this wave hands the block back); every wave learns where
     // its chunk starts in the frame and how long the frame is.  Then the headers go in with LDS atomics -- all of them, in front of a
     // barrier: the first word of a wave's residual is read and later stored whole by its lane 0, and may hold header bits of any wave.
     uint32_t d_start = 0, d_total = 0;
     bool d_poison = false;
-    auto direct_sync = [&](uint32_t chunk_bits_, bool handback) __attribute__((always_inline)) {
+    auto direct_sync = [&](uint32_t body_bits, bool handback) __attribute__((always_inline)) {
+        // (the fields of the subframe header -- warm-up samples among them -- are read here, in front of the barrier: with ALIAS the
+        // samples are gone behind it)
+        if (hf == 0) sub_bits = sub_fields();
+        const uint32_t chunk_bits_ = hl * 8 + sub_bits + body_bits;
         if (lane == 0) xch[wv] = handback ? 0xFFFFFFFFu : chunk_bits_;
         __syncthreads();
         uint32_t T = 0;
@@ -2459,6 +2476,12 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             }
             else lb_publish(D.lb, d.out_slot, lb_word(D.epoch, d.out_slot == 0 ? FG_LB_PFX : FG_LB_AGG, nb));
         }
+        if constexpr (ALIAS) {
+            // every wave is done with the staged samples: the frame's words take their place, zeroed first
+            const uint32_t zw = ((d_total + 31) >> 5) + 2;
+            for (uint32_t j = tid; j < zw; j += NT) fb.w[j] = 0;
+            __syncthreads();
+        }
         if (!d_poison) {
             if (wv == 0) {
                 const LDS uint8_t *hb = (const LDS uint8_t *)misc;
@@ -2467,7 +2490,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 cb_or<true>(fb, (uint32_t)lane * 8, v, b);
                 wave_lds_fence();
             }
-            if (hf == 0) (void)sub_header(true, d_start + hl * 8);
+            if (hf == 0) sub_emit(d_start + hl * 8);
         }
         __syncthreads();
     };
@@ -2500,8 +2523,19 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         const uint32_t kr = type >= 2 ? (uint32_t)dec->k[Lg / lpp] : 0;   // this lane's Rice parameter
         const bool pstart = type >= 2 && (Lg % lpp) == 0;
         const uint32_t skip = (type >= 2 && Lg == 0) ? order : 0;        // warm-up samples are not coded
+        // (ALIAS: sample g of the block from memory -- the second walk of a wave that could not keep its residuals; the staged copy is gone)
+        auto gcand = [&](uint32_t g) __attribute__((always_inline)) -> int32_t {
+            int32_t l, r = 0;
+            if (NCH == 2) {
+                if (P.pcm_i16) { const short2 v = ((const short2 *)pcm)[d.pcm_off + g]; l = v.x; r = v.y; }
+                else { const int2 v = ((const int2 *)pcm)[d.pcm_off + g]; l = v.x; r = v.y; }
+            }
+            else l = P.pcm_i16 ? (int32_t)((const int16_t *)pcm)[d.pcm_off + g] : ((const int32_t *)pcm)[d.pcm_off + g];
+            return cand(l >> pre, r >> pre);
+        };
         auto walk_t = [&](auto VERB, auto EMIT, auto ATOM, auto ALLF, uint32_t p0, bool inrange_) __attribute__((always_inline)) -> uint32_t {
             constexpr bool verb = decltype(VERB)::value, emit = decltype(EMIT)::value, atom = decltype(ATOM)::value;
+            constexpr bool fromg = ALIAS && emit;
             const bool inrange = decltype(ALLF)::value ? true : inrange_;
             int32_t h[MAXO];
             double hd[MAXO];                    // (17..25-bit samples: pfir_f64n, as in the evaluation)
@@ -2510,7 +2544,8 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 int32_t x = 0;
                 double xdh = 0.0;
                 if (Lg > 0) {
-                    if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
+                    if (fromg) x = gcand(Lg * seg - 1u - (uint32_t)j);
+                    else if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
                     else {
                         x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
                         if (ACC64 && w32) xdh = candd(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
@@ -2549,7 +2584,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             }
             const uint32_t kmask = (1u << kr) - 1, kone = 1u << kr;
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
-                const int32_t x = cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
+                const int32_t x = fromg ? gcand(Lg * seg + s) : cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
                 uint32_t val, vb, lead, topv = 0, topb = 0;          // (topv / topb: the 33rd bit of a verbatim sample of a 33-bit side channel)
                 if (verb) {
                     if (ACC64 && w32) {
@@ -2702,7 +2737,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         if constexpr (DIRECT) {
             const uint32_t incl = wave_scan_add(redo ? 0u : mylen);
             const uint32_t body = rl(incl, 63);
-            direct_sync(hl * 8 + sub_bits + body, redo);
+            direct_sync(body, redo);
             if (!d_poison) {
                 const uint32_t mystart = d_start + hl * 8 + sub_bits + incl - mylen;
                 if (KEEP && use_keep && keep_ok) emit_keep(mystart);
@@ -2738,7 +2773,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         }
     }
     else if constexpr (DIRECT) {
-        direct_sync(hl * 8 + sub_bits, false);
+        direct_sync(0, false);
         bitpos = hl * 8 + sub_bits;
     }
     if constexpr (DIRECT) {

@@ -120,6 +120,24 @@ def test_noise_gives_verbatim_frames_that_fill_the_buffer(ctxs):
     _check_oracle(5, 2, 16, 48000, 4096, pcm, lengths, got)
 
 
+def test_residuals_beyond_16_bits_take_the_second_walk(ctxs):
+    """Full-scale spikes on a quiet signal: the residual of a spike needs 17+ bits, so the wave cannot keep its residuals two to a
+    register and walks its samples a second time -- with the frame buffer over the staged samples (ALIAS) from memory."""
+    from pyflac_amd import batch
+    n = 4096 * 12
+    pcm = (_pcm(21, n, 2) // 40).astype(np.int32)
+    rng = np.random.default_rng(5)
+    for p in rng.integers(10, n - 10, size=40):
+        pcm[p, rng.integers(0, 2)] = -32768
+        pcm[p + 1, rng.integers(0, 2)] = 32767
+    s = batch.settings(5, 2, 16, 48000, 4096)
+    got, offs, st = _both(ctxs, s, pcm, [4096 * 7, 4096 * 5])
+    assert st.direct_path == 1
+    _check_oracle(5, 2, 16, 48000, 4096, pcm, [4096 * 7, 4096 * 5], got)
+    got, offs, st = _both(ctxs, s, pcm, [4096 * 7, 4096 * 5], i16=True)
+    _check_oracle(5, 2, 16, 48000, 4096, pcm, [4096 * 7, 4096 * 5], got)
+
+
 def test_mono_and_small_bit_depths(ctxs):
     from pyflac_amd import batch
     for ch, bps, bs in [(1, 16, 4096), (1, 8, 4096), (2, 12, 4096), (2, 16, 4608), (1, 16, 1152), (2, 16, 2304)]:
