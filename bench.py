@@ -584,12 +584,21 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     # (the committed PMC passes of the same command: profiles/r04_pmc.json for the headline, profiles/r04_pmc_<workload>.json
     # for the others; a pass of an earlier round stands in only if it was made on the same workload, level and block count)
     pmc, pmc_name = {}, None
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         pmc_name = '%s_pmc.json' % rnd if workload == 'stream16' else '%s_pmc_%s.json' % (rnd, workload)
         pmc = committed_profile(pmc_name) or {}
         if pmc:
             break
-    same = pmc.get('workload') == workload and pmc.get('level') == level and pmc.get('blocks') == nblocks
+    # (a counter pass counts only for the build it was measured on: flacgpu_build_id() is a hash over the library's sources, the
+    # pass carries the id of the library that ran under the counters)
+    build_id = L.flacgpu_build_id().decode()
+    same_shape = pmc.get('workload') == workload and pmc.get('level') == level and pmc.get('blocks') == nblocks
+    same = same_shape and pmc.get('build_id') == build_id
+    pmc_note = None
+    if pmc and not same:
+        pmc_note = ('profiles/%s is a pass of build %s on %s / level %s / %s blocks; this run: build %s, %s / level %d / %d blocks -- not quoted' %
+                    (pmc_name, pmc.get('build_id', '(no id: before round 5)'), pmc.get('workload'), pmc.get('level'), pmc.get('blocks'),
+                     build_id, workload, level, nblocks))
     enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
     dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
     res = {
@@ -631,8 +640,11 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
                             'traffic': pmc.get('decode_traffic_bytes_per_launch') if same else None,
                             'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(dec_t, 4)},
     }
+    res['build_id'] = build_id
+    if pmc_note:
+        res['roofline']['traffic_note'] = res['roofline_decode']['traffic_note'] = pmc_note
     if same:
-        res['roofline']['traffic_source'] = res['roofline_decode']['traffic_source'] = 'profiles/' + pmc_name + ' (committed PMC pass of this command, not measured in this run)'
+        res['roofline']['traffic_source'] = res['roofline_decode']['traffic_source'] = 'profiles/' + pmc_name + ' (committed PMC pass of this command and this build, not measured in this run)'
     if same and pmc.get('encode_valu_insts_per_launch'):
         # the ceiling these integer kernels actually run against: VALU issue (one wave-instruction per 2 cycles and SIMD,
         # fp64 4 cycles), 1024 SIMDs at 2.4 GHz; instruction counts from the committed PMC pass of this same command

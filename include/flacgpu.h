@@ -548,6 +548,15 @@ int flacgpu_encode_streams(flacgpu_ctx *ctx, const flacgpu_settings *settings, c
                            const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_out, uint64_t out_capacity,
                            void *d_frame_offsets, flacgpu_encode_stats *stats);
 
+/* STREAMINFO's md5sum (format.h:543) for device-resident streams: MD5 over the samples, little-endian at
+ * (bits_per_sample + 7) / 8 bytes each, channels interleaved -- what libFLAC hashes and what FLAC__stream_encoder_finish writes into
+ * STREAMINFO.  flacgpu_encode_streams does not compute it (the hash is ONE serial chain per stream: the GPU gives it a thread per
+ * stream, about 60 MB/s each, so 128 streams of 60 s take 0.2 s where their encode launch takes 5 ms); this call does, on a
+ * stream of its own, for callers that finalise STREAMINFO themselves.  d_md5: 16 bytes per stream (device).  *gpu_ms: kernel time.
+ * May be called from another thread while an encode call on the same context runs.  0 on success. */
+int flacgpu_md5_streams(flacgpu_ctx *ctx, const void *d_pcm, int pcm_is_i16, uint32_t channels, uint32_t bits_per_sample,
+                        const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_md5, float *gpu_ms);
+
 /* Upper bound of the encoded size of the given batch (for sizing d_out). */
 uint64_t flacgpu_encode_bound(const flacgpu_settings *settings, const flacgpu_stream_desc *streams, uint32_t nstreams,
                               uint32_t *nblocks);
@@ -569,6 +578,9 @@ const char *flacgpu_window_note(flacgpu_ctx *ctx);
 /* How the library was built: bit 0 = `make TUNING=1` (experiment and diagnostic environment switches are read), bit 1 = `make LEGACY=1`
  * (the superseded kernels of rounds 1 and 2 are present and selectable: FLACGPU_PIPE=0, FLACGPU_DEC_WAVE=0, FLACGPU_DEC_FUSED=0). */
 unsigned int flacgpu_build_flags(void);
+/* Sixteen hex digits: a hash over the sources this library was built from.  The committed counter passes (profiles/*_pmc*.json)
+ * name the build they were measured on; bench.py quotes their HBM traffic and instruction counts only when this id matches. */
+const char *flacgpu_build_id(void);
 /* Start-up self-check of the encoder's matrix-core autocorrelation (run by flacgpu_ctx_create): the number of
  * v_mfma_f64_4x4x4_4b_f64 results that differed from the chain of v_fma_f64 the bit-exactness of stage L6 rests on; 0 on
  * a device that behaves like the MI355X this was written on.  Non-zero: every block is encoded by the generic kernel (same bytes,

@@ -117,7 +117,7 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
                  'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_stream_encoder_set_launch_blocks', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
-                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_set_direct', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_set_direct', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_build_id', 'flacgpu_md5_streams', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
 
@@ -155,6 +155,9 @@ def lib():
     L.FLAC__stream_encoder_init_file.restype = C.c_int
     L.FLAC__stream_encoder_process_interleaved.argtypes = [vp, vp, C.c_uint32]
     L.FLAC__stream_encoder_process_interleaved.restype = C.c_int
+    # (planar input, one pointer per channel: pyflac/builder/encoder.py:321; pyFLAC's classes never call it)
+    L.FLAC__stream_encoder_process.argtypes = [vp, C.POINTER(C.POINTER(C.c_int32)), C.c_uint32]
+    L.FLAC__stream_encoder_process.restype = C.c_int
     L.FLAC__stream_encoder_finish.argtypes = [vp]
     L.FLAC__stream_encoder_get_verify_decoder_error_stats.argtypes = [vp] + [vp] * 6
     L.FLAC__stream_encoder_get_verify_decoder_error_stats.restype = None
@@ -207,6 +210,10 @@ def lib():
     L.flacgpu_set_stage_timing.argtypes = [vp, C.c_int]
     L.flacgpu_set_log_guard.argtypes = [vp, C.c_double]
     L.flacgpu_set_log_guard.restype = None
+    L.flacgpu_md5_streams.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)]
+    L.flacgpu_md5_streams.restype = C.c_int
+    L.flacgpu_build_id.argtypes = []
+    L.flacgpu_build_id.restype = C.c_char_p
     L.flacgpu_set_direct.argtypes = [vp, C.c_int]
     L.flacgpu_set_direct.restype = None
     L.flacgpu_window_note.argtypes = [vp]

@@ -95,6 +95,30 @@ class Context:
             raise FlacGpuError('encode error flags 0x%x' % st.error_flags)
         return out, offsets[:st.nblocks + 1], st
 
+    def md5_streams(self, pcm, bits_per_sample, stream_lengths=None):
+        """STREAMINFO's md5sum of every stream of device tensor ``pcm`` ([total_samples, channels] int32 or int16): MD5 over the
+        samples as libFLAC hashes them (little-endian, (bits + 7) // 8 bytes each, interleaved).  One GPU thread per stream --
+        the hash is a serial chain -- on a stream of its own.  Returns ``(list of 16-byte digests, kernel milliseconds)``."""
+        L = _lib.lib()
+        assert pcm.is_cuda and pcm.is_contiguous() and pcm.dtype in (torch.int16, torch.int32)
+        ch = 1 if pcm.dim() == 1 else pcm.shape[1]
+        if stream_lengths is None:
+            stream_lengths = [pcm.shape[0]]
+        descs = (_lib.StreamDesc * len(stream_lengths))()
+        pos = 0
+        for i, n in enumerate(stream_lengths):
+            descs[i].pcm_offset, descs[i].nsamples = pos, int(n)
+            pos += int(n)
+        assert pos == pcm.shape[0]
+        out = torch.empty(16 * len(stream_lengths), dtype=torch.uint8, device=pcm.device)
+        ms = C.c_float(0)
+        torch.cuda.current_stream(pcm.device).synchronize()
+        if L.flacgpu_md5_streams(self._h, pcm.data_ptr(), 1 if pcm.dtype == torch.int16 else 0, ch, bits_per_sample, descs, len(stream_lengths),
+                                 out.data_ptr(), C.byref(ms)) != 0:
+            raise FlacGpuError(_lib.last_error())
+        h = out.cpu().numpy().tobytes()
+        return [h[16 * i:16 * i + 16] for i in range(len(stream_lengths))], float(ms.value)
+
     def debug_records(self, first, n):
         from .debug import DebugRec
         buf = (DebugRec * n)()

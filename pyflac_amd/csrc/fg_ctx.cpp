@@ -228,6 +228,9 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     if (c->gev_fork) (void)hipEventDestroy(c->gev_fork);
     for (int i = 0; i < 3; i++) if (c->gev_eval[i]) (void)hipEventDestroy(c->gev_eval[i]);
     c->lb.release();
+    c->md5_jobs.release();
+    if (c->md5_stream) (void)hipStreamDestroy(c->md5_stream);
+    for (int i = 0; i < 2; i++) if (c->md5_ev[i]) (void)hipEventDestroy(c->md5_ev[i]);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -348,6 +351,13 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
 extern "C" const char *flacgpu_window_note(flacgpu_ctx *ctx) { return ctx->window_note.c_str(); }
+extern "C" const char *flacgpu_build_id(void)
+{
+    static const char id[] =
+#include "fg_build_id.inc"
+        ;
+    return id;
+}
 extern "C" unsigned int flacgpu_build_flags(void)
 {
     unsigned int f = 0;
@@ -976,6 +986,32 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, kernel): one process may drive several devices
 // (batch.MultiContext: one thread per device), so what has been configured is kept per device, behind a mutex.
 #include <map>
+// STREAMINFO MD5 of device-resident streams (the batch entry point leaves STREAMINFO's md5sum to the caller: the hash is a serial
+// chain per stream, format.h:543).  d_md5: 16 bytes per stream, device memory.  One GPU thread per stream on a stream of its own,
+// so a call from another host thread runs beside an encode launch of the same context's data; *gpu_ms gets its duration.
+extern "C" int flacgpu_md5_streams(flacgpu_ctx *c, const void *d_pcm, int pcm_is_i16, uint32_t channels, uint32_t bits_per_sample,
+                                   const flacgpu_stream_desc *streams, uint32_t nstreams, void *d_md5, float *gpu_ms)
+{
+    if (!c || !d_pcm || !d_md5 || channels < 1 || channels > 8 || bits_per_sample < 4 || bits_per_sample > 32) { fg_set_error("flacgpu_md5_streams: bad arguments"); return -1; }
+    if (nstreams == 0) return 0;
+    std::lock_guard<std::mutex> lk(c->md5_mu);
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    std::vector<unsigned long long> jobs(2 * (size_t)nstreams);
+    for (uint32_t i = 0; i < nstreams; i++) { jobs[2 * i] = streams[i].pcm_offset; jobs[2 * i + 1] = streams[i].nsamples; }
+    if (!c->md5_stream && hipStreamCreateWithFlags(&c->md5_stream, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!c->md5_ev[0]) { if (hipEventCreate(&c->md5_ev[0]) != hipSuccess || hipEventCreate(&c->md5_ev[1]) != hipSuccess) return -1; }
+    if (!c->md5_jobs.ensure(jobs.size() * 8)) return -1;
+    if (hipMemcpyAsync(c->md5_jobs.p, jobs.data(), jobs.size() * 8, hipMemcpyHostToDevice, c->md5_stream) != hipSuccess) return -1;
+    (void)hipEventRecord(c->md5_ev[0], c->md5_stream);
+    if (fg_launch_md5_streams(d_pcm, pcm_is_i16 ? 1u : 0u, channels, bits_per_sample, c->md5_jobs.p, nstreams, (uint32_t *)d_md5, c->md5_stream) != 0) {
+        fg_set_error("MD5 kernel launch failed"); return -1;
+    }
+    (void)hipEventRecord(c->md5_ev[1], c->md5_stream);
+    if (hipStreamSynchronize(c->md5_stream) != hipSuccess) { fg_set_error("MD5 kernel failed"); return -1; }
+    if (gpu_ms) (void)hipEventElapsedTime(gpu_ms, c->md5_ev[0], c->md5_ev[1]);
+    return 0;
+}
+
 extern "C" int fg_func_set_lds(const void *fn, size_t bytes)
 {
     static std::mutex mu;

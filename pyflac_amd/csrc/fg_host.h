@@ -48,6 +48,8 @@ int fg_launch_stamp(unsigned long long *d_stamp, hipStream_t stream);
 int fg_launch_signal(const unsigned long long *src0, uint32_t n0, const unsigned long long *src1, uint32_t n1,
                      const unsigned long long *d_stamp, unsigned long long *h_sig, unsigned long long seq, hipStream_t stream,
                      unsigned long long *d_reset = nullptr);
+int fg_launch_md5_streams(const void *d_pcm, uint32_t pcm_i16, uint32_t channels, uint32_t bps, const void *d_jobs, uint32_t njobs,
+                          uint32_t *d_out, hipStream_t stream);
 int fg_launch_signal_direct(const unsigned long long *d_total, const unsigned long long *d_guard, const unsigned long long *d_stamp,
                             unsigned long long *h_sig, unsigned long long seq, hipStream_t stream, unsigned long long *d_reset);
 int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
@@ -119,6 +121,9 @@ struct flacgpu_ctx {
     hipEvent_t gev_eval[3] = {nullptr, nullptr, nullptr};      // behind the evaluation of groups 0..2 (direct packing: FgPipeLaunch.gev_eval)
     // direct packing path (round 5, FgPackDirect): look-back words of the frames of a call, the epoch that tells one call's words from
     // another's, and the switch (flacgpu_set_direct: 0 = chunks through HBM, scan and assembly kernel as in rounds 2-4)
+    hipStream_t md5_stream = nullptr;      // flacgpu_md5_streams: a stream, two events and a lock of its own (it runs beside encode calls)
+    hipEvent_t md5_ev[2] = {nullptr, nullptr};
+    std::mutex md5_mu;
     DevBuf lb;
     uint32_t lb_epoch = 0;
     int direct = 1;
@@ -138,7 +143,8 @@ struct flacgpu_ctx {
     std::recursive_mutex mu;    // (the batch entry points nest: streams of more than two channels run the one-channel encode inside)
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
         dec_scratch, dec_subs, dec_poff, dec_hrec, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe,
-        mc_tmp, mc_offs, mc_map, mc_sizes, mc_res, mc_foffs;   // streams of more than two channels (fg_ctx.cpp encode_multichannel)
+        mc_tmp, mc_offs, mc_map, mc_sizes, mc_res, mc_foffs,   // streams of more than two channels (fg_ctx.cpp encode_multichannel)
+        md5_jobs;
     const uint32_t *last_chunk_bits = nullptr;   // the pipeline's chunk bit counts of the last encode call (device), or null
     std::vector<unsigned char> desc_key;   // settings + stream list the block list in `dev_descs` was built for
     uint32_t desc_nfast = 0, desc_nws2 = 0, desc_nrag = 0;

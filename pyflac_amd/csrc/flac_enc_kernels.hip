@@ -1510,6 +1510,71 @@ fg_export_kernel(uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64 *src0
     }
 }
 
+// ------------------------------------------------------------------ STREAMINFO MD5 of device-resident streams (stage L1, format.h:543)
+// MD5 is a chain over the 64-byte blocks of ONE stream, so the only parallelism is across streams: thread = stream.  The bytes are
+// the samples little-endian at (bits per sample + 7) / 8 bytes each, channels interleaved, exactly what libFLAC hashes; a stream
+// of 60 s of 16-bit stereo is 180 000 blocks of ~550 dependent instructions -- about 0.2 s for any number of streams up to the
+// lanes of the chip, which is why the batch entry point does not do it unasked.
+struct FgMd5Job { unsigned long long pcm_off, nsamples; };      // first inter-channel sample, inter-channel samples
+__global__ void __launch_bounds__(64)
+fg_md5_streams_kernel(const void *pcm, uint32_t pcm_i16, uint32_t channels, uint32_t bps, const FgMd5Job *jobs, uint32_t njobs, uint32_t *out)
+{
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= njobs) return;
+    const uint32_t nbytes = (bps + 7) / 8;
+    const u64 nvalues = jobs[j].nsamples * channels, first = jobs[j].pcm_off * channels;
+    const u64 total = nvalues * nbytes;                 // bytes of the message
+    uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+        0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+        0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+        0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+        0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+        0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const uint8_t R[16] = {7, 12, 17, 22, 5, 9, 14, 20, 4, 11, 16, 23, 6, 10, 15, 21};
+    u64 vi = 0;                    // next value of the stream
+    u64 acc = 0;                   // bytes not yet handed out, lowest first
+    uint32_t have = 0;             // ... and how many
+    auto value = [&](u64 i) -> uint32_t {
+        return pcm_i16 ? (uint32_t)(int32_t)((const int16_t *)pcm)[first + i] : (uint32_t)((const int32_t *)pcm)[first + i];
+    };
+    const u64 nblocks = (total + 8) / 64 + 1;      // message, the 0x80 byte, zeros, eight bytes of length
+    bool pad_done = false;
+    for (u64 blk = 0; blk < nblocks; blk++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            while (have < 4 && vi < nvalues) {
+                const u64 v = (u64)(value(vi) & (nbytes == 4 ? 0xFFFFFFFFu : ((1u << (8 * nbytes)) - 1)));
+                acc |= v << (8 * have);
+                have += nbytes;
+                vi++;
+            }
+            if (have < 4 && !pad_done) { acc |= (u64)0x80 << (8 * have); have = 8; pad_done = true; }    // (the zeros behind it come for free)
+            w[t] = (uint32_t)acc;
+            acc >>= 32;
+            have = have >= 4 ? have - 4 : 0;
+        }
+        if (blk + 1 == nblocks) { w[14] = (uint32_t)(total * 8); w[15] = (uint32_t)((total * 8) >> 32); }
+        uint32_t A = a, Bv = b, Cv = c, Dv = d;
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            uint32_t f, g;
+            if (i < 16) { f = (Bv & Cv) | (~Bv & Dv); g = (uint32_t)i; }
+            else if (i < 32) { f = (Dv & Bv) | (~Dv & Cv); g = (5u * i + 1) & 15; }
+            else if (i < 48) { f = Bv ^ Cv ^ Dv; g = (3u * i + 5) & 15; }
+            else { f = Cv ^ (Bv | ~Dv); g = (7u * i) & 15; }
+            const uint32_t x = A + f + K[i] + w[g];
+            const uint32_t r = R[(i >> 4) * 4 + (i & 3)];
+            A = Dv; Dv = Cv; Cv = Bv;
+            Bv = Bv + ((x << r) | (x >> (32 - r)));
+        }
+        a += A; b += Bv; c += Cv; d += Dv;
+    }
+    out[4 * j] = a; out[4 * j + 1] = b; out[4 * j + 2] = c; out[4 * j + 3] = d;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host-callable launchers (C ABI, used by flacgpu_api.cpp)
@@ -1555,6 +1620,15 @@ int fg_launch_signal_direct(const unsigned long long *d_total, const unsigned lo
 {
     hipLaunchKernelGGL(fg_signal_direct_kernel, dim3(1), dim3(64), 0, stream, (const u64 *)d_total, (const u64 *)d_guard, (const u64 *)d_stamp,
                        (u64 *)h_sig, (u64)seq, (u64 *)d_reset);
+    return (int)hipGetLastError();
+}
+
+int fg_launch_md5_streams(const void *d_pcm, uint32_t pcm_i16, uint32_t channels, uint32_t bps, const void *d_jobs, uint32_t njobs,
+                          uint32_t *d_out, hipStream_t stream)
+{
+    if (njobs == 0) return 0;
+    hipLaunchKernelGGL(fg_md5_streams_kernel, dim3((njobs + 63) / 64), dim3(64), 0, stream, d_pcm, pcm_i16, channels, bps, (const FgMd5Job *)d_jobs,
+                       njobs, d_out);
     return (int)hipGetLastError();
 }
 

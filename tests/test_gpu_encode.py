@@ -636,6 +636,60 @@ def test_32_bit_streams_mixed_content(ctx):
         assert st.redo_blocks == 1                       # (the 777-sample tail of true 32-bit content: ragged geometry)
 
 
+def test_md5_of_device_resident_streams(ctx):
+    """flacgpu_md5_streams: STREAMINFO's md5sum for streams the batch entry point encoded (it leaves the field to the caller) --
+    equal to MD5 over the samples as libFLAC hashes them, for 8 .. 32 bit, 1 .. 6 channels, int16 and int32 input, lengths around
+    the 64-byte block boundaries, and equal to the oracle's md5_pcm."""
+    import hashlib
+    import torch
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    for ch, bps, dt in [(2, 16, np.int32), (2, 16, np.int16), (1, 8, np.int32), (2, 24, np.int32), (6, 16, np.int16), (2, 32, np.int32), (1, 12, np.int32), (3, 20, np.int32)]:
+        lengths = [1, 13, 14, 15, 16, 27, 28, 31, 32, 33, 1000, 4096 * 3 + 5, 7]
+        lim = 1 << (bps - 1)
+        a = rng.integers(-lim, lim, size=(sum(lengths), ch), dtype=np.int64).astype(dt)
+        digs, ms = ctx.md5_streams(torch.from_numpy(a).cuda(), bps, lengths)
+        nb = (bps + 7) // 8
+        pos = 0
+        for n, got in zip(lengths, digs):
+            x = a[pos:pos + n].astype(np.int64)
+            raw = b''.join(int(v & ((1 << (8 * nb)) - 1)).to_bytes(nb, 'little') for v in x.reshape(-1))
+            assert got == hashlib.md5(raw).digest(), (ch, bps, dt, n)
+            assert got == O.md5_pcm(a[pos:pos + n].astype(np.int32), bps), (ch, bps, n)
+            pos += n
+
+
+def test_guard_statistics_survive_a_redo_pass():
+    """a call that hands a block back to the generic kernel (FG_ERR_REDO) ends through a SECOND finish pass, whose
+    signal kernel finds the near-tie counters already reset by the first one: the statistics of the call (log_guard_subframes,
+    lpc_order_min_margin) must be the first pass's -- equal to what the event-timed form of the same call (stage_timing 1, which
+    reads the counters without resetting them) reports, and not 0 / +inf."""
+    import torch
+    from pyflac_amd import batch, _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    bs = 4096
+    t = np.arange(bs)
+    tone = lambda a, f, ph: np.round(a * np.sin(2 * np.pi * f * t / 48000 + ph) + rng.normal(0, a / 300, bs)).astype(np.int64)
+    blocks = [np.stack([tone(3e6, 440 + 10 * k, 0), tone(2e6, 660, k)], axis=1) << 8 for k in range(6)]
+    blocks.append(rng.integers(-2**31, 2**31, (777, 2)))                         # a true 32-bit ragged tail: the generic kernel's
+    arr = np.concatenate(blocks).astype(np.int32)
+    s = batch.settings(5, 2, 32, 48000, bs, True)
+    dev = torch.from_numpy(arr).cuda()
+    got = []
+    for timing in (0, 1, 0):
+        c = batch.Context(0)
+        L.flacgpu_set_log_guard(c._h, 1e30)              # (every order guess counts as a near tie: the counters are busy)
+        L.flacgpu_set_stage_timing(c._h, timing)
+        for _rep in range(2):                            # (the second call starts from counters the first one's signal kernel left)
+            out, offs, st = c.encode(s, dev)
+            assert st.redo_blocks == 1
+            got.append((st.log_guard_subframes, st.lpc_order_min_margin, bytes(out[:st.total_bytes].cpu().numpy().tobytes())))
+        c.close()
+    assert got[0][0] > 0 and np.isfinite(got[0][1])
+    assert all(g == got[0] for g in got)
+
+
 def test_limit_min_bitrate_and_a_constant_left_channel_of_28_bits_and_more(ctx):
     """limit_min_bitrate disables CONSTANT for the last independent channel (and then for mid and side) when every earlier channel
     CHOSE CONSTANT -- and from 28 bits per sample on libFLAC's order guess (the _limit_residual forms) flags only an all-zero signal

@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root, workload, blocks, level = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-RND = sys.argv[5] if len(sys.argv) > 5 else 'r04'
+RND = sys.argv[5] if len(sys.argv) > 5 else 'r05'
 
 
 def per_kernel(sub, name):
@@ -24,8 +24,10 @@ def per_kernel(sub, name):
             if row.get('Counter_Name') == name:
                 k = row.get('Kernel_Name', '').split('(anonymous namespace)::')[-1].split('(')[0]
                 acc[k].append(float(row['Counter_Value']))
-    once_enc = max([len(v) for k, v in acc.items() if k.startswith('fg_pipe_assemble_kernel')] or [0])
+    # (round 5: the direct packing path has no assembly kernel; every step of the bench is one encode and one decode launch, and the
+    # decoder's header pass runs once a launch)
     once_dec = max([len(v) for k, v in acc.items() if k.startswith('fg_dec_headers_kernel')] or [0])
+    once_enc = once_dec or max([len(v) for k, v in acc.items() if k.startswith('fg_pipe_assemble_kernel')] or [0])
     out = {}
     for k, v in acc.items():
         launches = once_enc if (k.startswith('fg_pipe_') or k.startswith('fg_scan_') or k.startswith('fg_encode')) else (once_dec if k.startswith('fg_dec') else 0)
@@ -41,7 +43,10 @@ for k in sorted(set(fetch) | set(write) | set(valu)):
     if enc(k) or dec(k):
         rows[k] = {'FETCH_SIZE_KiB_raw': round(fetch.get(k, 0.0), 1), 'WRITE_SIZE_KiB_raw': round(write.get(k, 0.0), 1),
                    'traffic_bytes': int(fetch.get(k, 0.0) * 2048 + write.get(k, 0.0) * 1024), 'valu_insts': int(valu.get(k, 0))}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyflac_amd import _lib
 out = {'workload': workload, 'blocks': blocks, 'level': level, 'fetch_correction': 2.0,
+       'build_id': _lib.lib().flacgpu_build_id().decode(), 'build_flags': int(_lib.lib().flacgpu_build_flags()),
        'encode_traffic_bytes_per_launch': sum(r['traffic_bytes'] for k, r in rows.items() if enc(k)),
        'decode_traffic_bytes_per_launch': sum(r['traffic_bytes'] for k, r in rows.items() if dec(k)),
        'encode_valu_insts_per_launch': sum(r['valu_insts'] for k, r in rows.items() if enc(k)),
