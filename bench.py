@@ -536,6 +536,22 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     stage /= 5
     L.flacgpu_set_stage_timing(ctx._h, 0)
     nblocks = int(est.nblocks)
+    # STREAMINFO's md5sum for the batch (stage L1; pyFLAC's own path always hashes): the batch entry point leaves it to the caller,
+    # flacgpu_md5_streams computes it on the GPU -- one thread per stream, the hash being one serial chain per stream -- and this is
+    # what a step costs with it (checked against hashlib on the host copy of the first and the last stream)
+    md5_on = None
+    if workload == 'batch' and rank == 0 and world == 1 and passes:
+        import hashlib
+        digs, md5_ms = ctx.md5_streams(pcm, bps, lengths)
+        starts = np.concatenate([[0], np.cumsum(lengths)])
+        for k in (0, len(lengths) - 1):
+            assert digs[k] == hashlib.md5(pcm16[int(starts[k]):int(starts[k + 1])].astype('<i2').tobytes()).digest(), 'GPU MD5 differs'
+        step_ms = dt / steps * 1e3
+        md5_on = {'md5_kernel_ms': round(md5_ms, 2), 'value': round(nsamp * ch / ((step_ms + md5_ms) * 1e-3) / 1e6, 1), 'unit': 'Msamples/s',
+                  'what': 'one step (encode + decode) plus flacgpu_md5_streams over the same %d streams, run one behind the other; MD5 is a '
+                          'serial chain per stream (one GPU thread each, %.0f MB/s a stream), so its time does not depend on the number '
+                          'of streams up to the lanes of the chip and is hidden only behind launches of thousands of streams' %
+                          (len(lengths), lengths[0] * ch * 2 / (md5_ms * 1e-3) / 1e6)}
     del out, offs, dec, pcm
     torch.cuda.empty_cache()
     # checker use of the oracle: EVERY frame the GPU wrote (of the batch: every frame of its first, middle and last stream; at N > 1
@@ -602,7 +618,7 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
     dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
     res = {
-        'metric': 'Msamples/s encode (level %d, %dkHz/%d-bit stereo, blk 4096) + decode; bit-exact' % (level, sr // 1000, bps),
+        'metric': 'Msamples/s encode (level %d, %dkHz/%d-bit %s, blk 4096) + decode; bit-exact' % (level, sr // 1000, bps, 'stereo' if ch == 2 else '%d channels' % ch),
         'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'int32', 'data': 'synthetic',
@@ -666,6 +682,8 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
                                 'source': 'profiles/' + pmc_name}
     if checked:
         res['checked'] = checked
+    if md5_on:
+        res['md5_on'] = md5_on
     if world > 1:
         res['ms_per_step_rank'] = [round(x, 3) for x in rank_ms]
     return res
@@ -728,10 +746,13 @@ def main():
     # a step where a run without the CPU leg shows 0.05.
     cfgs = {}
     if rank == 0 and world == 1 and workload == 'stream16' and not args.no_configs and args.seconds is None and args.level is None:
-        for wl, secs, lvl, k in (('stream24', 300.0, 8, 40), ('batch', 60.0, 5, 20)):
+        # (behind them the shapes off the headline -- pyFLAC's int32 input with true 32-bit content and with 24-bit material in a 32-bit
+        # container, six channels --, two minutes each)
+        for wl, secs, lvl, k in (('stream24', 300.0, 8, 40), ('batch', 60.0, 5, 20), ('stream32', 120.0, 5, 10), ('stream32w', 120.0, 5, 10),
+                                 ('surround6', 120.0, 5, 10)):
             r = measure(env, ctx, wl, secs, lvl, k, 2, args.streams, passes=True, check=not args.no_cpu_baseline)
             cfgs[wl] = {key: r[key] for key in ('metric', 'value', 'unit', 'steps', 'ms_per_step', 'ms_per_step_min', 'encode_gpu_ms',
-                                                'decode_gpu_ms', 'encode_stage_ms', 'config', 'checked') if key in r}
+                                                'decode_gpu_ms', 'encode_stage_ms', 'config', 'checked', 'md5_on') if key in r}
             cfgs[wl]['roofline'] = {k2: r['roofline'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
             cfgs[wl]['roofline_decode'] = {k2: r['roofline_decode'][k2] for k2 in ('achieved', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'ms_per_launch')}
     res = measure(env, ctx, workload, seconds, level, steps, args.warmup, args.streams, passes=not args.no_passes,

@@ -11,6 +11,8 @@
 #include "fg_window_tables.inc"
 
 static thread_local std::string g_err;
+static thread_local bool g_input_on_stream = false;
+void fg_set_input_on_stream(bool on) { g_input_on_stream = on; }
 void fg_set_error(const std::string &msg) { g_err = msg; }
 extern "C" const char *flacgpu_last_error(void) { return g_err.c_str(); }
 
@@ -681,7 +683,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // call put on the main stream concerns the other groups -- FgPipeLaunch.guard_clean / no_fork)
     static const bool quick_off = getenv("FLACGPU_QUICK_START") && atoi(getenv("FLACGPU_QUICK_START")) == 0;
     PL.guard_clean = (lean && use_pipe && !quick_off && guard_was_clean) ? 1u : 0u;
-    PL.no_fork = (PL.guard_clean && reuse && !c->debug && !lb_cleared) ? 1u : 0u;
+    PL.no_fork = (PL.guard_clean && reuse && !c->debug && !lb_cleared && !g_input_on_stream) ? 1u : 0u;
     if (lean) {
         // (the pipeline's first kernel takes the stamp itself)
         if (nfast && use_pipe) PL.B.stamp = (unsigned long long *)c->stamp.p;
@@ -815,7 +817,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
             if (rc != 0) { fg_set_error("frame assembly kernel launch failed"); return false; }
         }
         if (first) mark();
-        if (d_offsets && !asm_here && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return false;
+        if (d_offsets && !asm_here && hipMemcpyAsync(d_offsets, c->offsets.p, ((size_t)nblocks + 1) * 8, hipMemcpyDefault, c->stream) != hipSuccess) return false;
         if (lean) {
             // totals and error flags (offsets[nblocks .. +1]), guard counters (offsets[nblocks + 2 .. +3] when the assembly kernel
             // parked them there, the guard words themselves otherwise)

@@ -170,6 +170,10 @@ struct flacgpu_ctx {
     bool sync_windows();
 };
 
+// The calling thread queued the upload of its next encode call's samples on the context's main stream and did not wait: that call
+// orders every other stream it uses behind the main one (no FgPipeLaunch.no_fork).  Per thread: encoders on several threads share
+// the default context.
+void fg_set_input_on_stream(bool on);
 flacgpu_ctx *fg_default_ctx();   // lazily created context on the current/default device
 
 // End-of-call wait.  The batch calls last one to a few milliseconds; a blocking hipStreamSynchronize adds its wake-up

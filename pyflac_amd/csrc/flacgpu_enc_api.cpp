@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <thread>
+#include <condition_variable>
+#include <functional>
 
 #include "fg_host.h"
 
@@ -153,6 +155,55 @@ uint16_t fg_crc16(const uint8_t *p, size_t n)
 // ------------------------------------------------------------------ encoder object
 namespace {
 
+// The MD5 of a process call runs on a helper thread beside the call's GPU work.  Round 5: ONE thread per encoder, started at the
+// first call and woken through a condition variable -- creating and joining a std::thread inside every call was a third of the host
+// time of a one-block call ("what's weak" 6).
+struct Md5Worker {
+    std::thread t;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+    void submit(std::function<void()> j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!t.joinable()) t = std::thread([this] { run(); });
+            job = std::move(j);
+            busy = true;
+        }
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !busy; });
+    }
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || (bool)job; });
+            if (!job) return;
+            std::function<void()> j = std::move(job);
+            job = nullptr;
+            lk.unlock();
+            j();
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    ~Md5Worker()
+    {
+        if (t.joinable()) {
+            { std::lock_guard<std::mutex> lk(m); quit = true; }
+            cv.notify_all();
+            t.join();
+        }
+    }
+};
+
 struct EncImpl {
     FLAC__StreamEncoder pub;   // must be first: the handle pyFLAC holds points here
     FLAC__StreamEncoderState state;
@@ -188,6 +239,9 @@ struct EncImpl {
     FgMd5 md5;
     void *h_pin = nullptr;          // pinned host copy of the encoded frames (+ offsets) of one call
     size_t h_pin_cap = 0;
+    void *h_in = nullptr;           // pinned staging of the samples of a small call (the upload then is one asynchronous copy)
+    size_t h_in_cap = 0;
+    Md5Worker md5w;
     std::vector<uint64_t> hoffs;
     DevBuf d_pcm, d_out, d_offs;    // per-encoder device staging
     DevBuf d_in16;                  // 16-bit input as uploaded, before the device widens it into d_pcm
@@ -516,8 +570,9 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
     // MD5 of the consumed PCM on a helper thread beside everything else this call does (upload, kernels, download, the
     // client's write callbacks); joined before the samples are dropped from `pending`, on every way out.  16-bit input at 16
     // bits per sample is hashed as it lies in memory (the MD5 is over little-endian samples, format.h:560).
-    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } md5j;
-    if (e->do_md5) md5j.t = std::thread([=] {
+    struct Joiner { Md5Worker *w = nullptr; ~Joiner() { if (w) w->wait(); } } md5j;
+    if (e->do_md5) md5j.w = &e->md5w;
+    if (e->do_md5) e->md5w.submit([=] {
         if (from_pend) e->md5.update_pcm(e->pending.data(), from_pend * C, e->s.bits_per_sample);
         if (from_in) {
             if (in32) e->md5.update_pcm(in32, from_in * C, e->s.bits_per_sample);
@@ -532,7 +587,45 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
             }
         }
     });
-    {
+    // Small calls (the streaming use of the class: a block or a few per call, pyflac/encoder.py:86-119): the samples are gathered in
+    // pinned memory and go up with ONE asynchronous copy queued in front of the encode kernels -- no wait of its own --, and the
+    // frames and their index are written by the kernels straight into pinned host memory, which the call's end-of-call signal makes
+    // visible: no download, no second wait.  (Round 4: three stream synchronisations and up to five copies a call.)
+    const size_t in_bytes = (size_t)from_pend * C * 4 + (size_t)from_in * C * (in16 ? 2 : 4);
+    const bool small = !e->verify && nblocks <= 16 && in_bytes <= ((size_t)1 << 20);
+    bool direct_out = false;
+    if (small) {
+        if (in_bytes + 64 > e->h_in_cap) {
+            if (e->h_in) (void)hipHostFree(e->h_in);
+            e->h_in = nullptr; e->h_in_cap = 0;
+            const size_t want = std::max(in_bytes + 64, (size_t)256 << 10);
+            if (hipHostMalloc(&e->h_in, want, hipHostMallocDefault) == hipSuccess) e->h_in_cap = want;
+        }
+        const size_t need = (((size_t)bound + 63) & ~(size_t)63) + ((size_t)nblocks + 1) * 8;
+        if (need > e->h_pin_cap) {
+            if (e->h_pin) (void)hipHostFree(e->h_pin);
+            e->h_pin = nullptr; e->h_pin_cap = 0;
+            const size_t want = std::max(need, (size_t)1 << 20) * 3 / 2;
+            if (hipHostMalloc(&e->h_pin, want, hipHostMallocDefault) == hipSuccess) e->h_pin_cap = want;
+        }
+        direct_out = e->h_in != nullptr && e->h_pin != nullptr;
+    }
+    if (direct_out) {
+        uint8_t *hp = (uint8_t *)e->h_in;
+        const size_t pb = (size_t)from_pend * C * 4;
+        if (from_pend) memcpy(hp, e->pending.data(), pb);
+        if (from_in) memcpy(hp + pb, in32 ? (const void *)in32 : (const void *)in16, in_bytes - pb);
+        int32_t *d_pcm = (int32_t *)e->d_pcm.p;
+        bool up = true;
+        if (from_pend) up = hipMemcpyAsync(d_pcm, hp, pb, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        if (up && from_in && in32) up = hipMemcpyAsync(d_pcm + (size_t)from_pend * C, hp + pb, in_bytes - pb, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        if (up && from_in && in16)
+            up = hipMemcpyAsync(e->d_in16.p, hp + pb, in_bytes - pb, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                 fg_launch_widen16((const int16_t *)e->d_in16.p, d_pcm + (size_t)from_pend * C, (uint64_t)from_in * C, c->stream) == 0;
+        if (!up) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false; }
+        fg_set_input_on_stream(true);          // (the encode call must order every stream it uses behind what is queued on the main one)
+    }
+    else {
         bool up = true;
         int32_t *d_pcm = (int32_t *)e->d_pcm.p;
         if (from_pend) up = hipMemcpyAsync(d_pcm, e->pending.data(), (size_t)from_pend * C * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess;
@@ -543,7 +636,11 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
         if (!up || hipStreamSynchronize(c->stream) != hipSuccess) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return false; }
     }
     flacgpu_encode_stats st;
-    const int rc = flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, e->d_out.p, e->d_out.cap, e->d_offs.p, &st);
+    uint8_t *const pin_frames = (uint8_t *)e->h_pin;
+    uint64_t *const pin_offs = direct_out ? (uint64_t *)(pin_frames + (((size_t)bound + 63) & ~(size_t)63)) : nullptr;
+    const int rc = direct_out ? flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, pin_frames, bound, pin_offs, &st)
+                              : flacgpu_encode_streams(c, &e->s, e->d_pcm.p, 0, &sd, 1, e->d_out.p, e->d_out.cap, e->d_offs.p, &st);
+    fg_set_input_on_stream(false);
     bool ok = rc == 0;
     if (ok) e->last_ca = st.last_channel_assignment;
     if (ok && st.error_flags) {
@@ -552,7 +649,8 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
     }
     else if (!ok) e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
     const uint8_t *hout = nullptr;
-    if (ok) {
+    if (ok && direct_out) { hout = pin_frames; e->hoffs.assign(pin_offs, pin_offs + st.nblocks + 1); }
+    else if (ok) {
         // frames and their offsets land in pinned memory (per encoder; grown on demand) and are handed out from there
         const size_t need = (((size_t)st.total_bytes + 63) & ~(size_t)63) + ((size_t)st.nblocks + 1) * 8;
         if (need > e->h_pin_cap) {
@@ -624,7 +722,7 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
             e->progress_cb(&e->pub, e->bytes_written, e->samples_done, e->frame_number, est, e->client);
         }
     }
-    if (md5j.t.joinable()) md5j.t.join();
+    if (md5j.w) { md5j.w->wait(); md5j.w = nullptr; }
     e->pending.erase(e->pending.begin(), e->pending.begin() + (size_t)from_pend * C);
     keep_input(from_in);
     return true;
@@ -655,6 +753,7 @@ void FLAC__stream_encoder_delete(FLAC__StreamEncoder *enc)
     if (e->ctx) (void)hipSetDevice(e->ctx->device);
     e->d_pcm.release(); e->d_out.release(); e->d_offs.release(); e->d_verify.release(); e->d_in16.release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
+    if (e->h_in) (void)hipHostFree(e->h_in);
     delete e;
 }
 
