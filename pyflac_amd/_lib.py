@@ -9,8 +9,18 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (FLACGPU_LIBRARY: another build of the same library -- tools/ab.sh compares two builds on one GPU box this way)
-LIB_PATH = os.environ.get('FLACGPU_LIBRARY') or os.path.join(_HERE, 'libflacgpu.so')
+LIB_PATH = os.path.join(_HERE, 'libflacgpu.so')
+# The test-hooks build (csrc/Makefile: the same kernels, the host files with -DFG_TESTHOOKS): the only library that reads the kernel
+# selectors and test hooks of csrc/fg_types.h fg_sel().  Tests get it with testhooks_lib() / batch.Context(testhooks=True); a child
+# process that sets PYFLAC_AMD_TESTHOOKS=1 gets it in place of the release library (for tests of the drop-in classes).
+TESTHOOKS_PATH = os.path.join(_HERE, 'libflacgpu_testhooks.so')
+if os.environ.get('PYFLAC_AMD_TESTHOOKS') == '1':
+    LIB_PATH = TESTHOOKS_PATH
+# A/B of two builds on one GPU box (tools/ab*.sh, tools/kstat_var.sh): another build of the same library, honoured only together with
+# the explicit opt-in FLACGPU_ALLOW_LIBRARY_OVERRIDE=1; what is loaded must export the build identification and says so on stderr.
+_OVERRIDE = os.environ.get('FLACGPU_LIBRARY') if os.environ.get('FLACGPU_ALLOW_LIBRARY_OVERRIDE') == '1' else None
+if _OVERRIDE:
+    LIB_PATH = _OVERRIDE
 
 
 class StreamInfo(C.Structure):
@@ -120,20 +130,40 @@ EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu
                  'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_set_direct', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_build_id', 'flacgpu_md5_streams', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
+_testhooks = None
 
 
 def lib():
     """Load libflacgpu.so and declare the signatures used from Python.  Raises if it is missing."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+        if _OVERRIDE:
+            import sys
+            sys.stderr.write('pyflac_amd: FLACGPU_LIBRARY override: %s (build %s, flags %d)\n' %
+                             (LIB_PATH, _lib.flacgpu_build_id().decode(), _lib.flacgpu_build_flags()))
+    return _lib
+
+
+def testhooks_lib():
+    """The test-hooks build of the library (kernel selectors and test hooks readable from the environment); for the cross-check tests."""
+    global _testhooks
+    if _testhooks is None:
+        L = _load(TESTHOOKS_PATH)
+        if not (L.flacgpu_build_flags() & 4):
+            raise ImportError('%s is not a test-hooks build' % TESTHOOKS_PATH)
+        _testhooks = L
+    return _testhooks
+
+
+def _load(path):
+    if not os.path.exists(path):
         raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
-                          '(there is no CPU fallback)' % LIB_PATH)
+                          '(there is no CPU fallback)' % path)
     # torch carries its own copy of the HIP runtime; whichever copy is loaded first serves the whole process, and a second
     # one finds no device.  torch owns the device memory this package hands to the library, so its runtime goes first.
     import torch  # noqa: F401
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.FLAC__stream_encoder_new.restype = vp
     L.FLAC__stream_encoder_delete.argtypes = [vp]
@@ -231,7 +261,8 @@ def lib():
     L.flacgpu_index_frames.restype = C.c_int64
     L.flacgpu_refwalk_probe.argtypes = [vp, C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.flacgpu_refwalk_probe.restype = C.c_int64
-    _lib = L
+    L.flacgpu_build_flags.argtypes = []
+    L.flacgpu_build_flags.restype = C.c_uint32
     return L
 
 

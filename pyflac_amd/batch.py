@@ -29,18 +29,23 @@ def settings(level=5, channels=2, bits_per_sample=16, sample_rate=48000, blocksi
 class Context:
     """One device context (stream, scratch buffers, tables).  One per process per GPU."""
 
-    def __init__(self, device=0):
-        L = _lib.lib()
+    def __init__(self, device=0, testhooks=False):
+        # (testhooks: the context lives in the test-hooks build of the library, which reads the kernel selectors of
+        # csrc/fg_types.h fg_sel() from the environment -- the cross-check tests)
+        L = self._L = _lib.testhooks_lib() if testhooks else _lib.lib()
         if not torch.cuda.is_available():
             raise FlacGpuError('no GPU visible: pyflac_amd has no CPU fallback')
         self.device = device
         self._h = L.flacgpu_ctx_create(device)
         if not self._h:
-            raise FlacGpuError(_lib.last_error())
+            raise FlacGpuError(self._err())
+
+    def _err(self):
+        return (self._L.flacgpu_last_error() or b'').decode()
 
     def close(self):
         if self._h:
-            _lib.lib().flacgpu_ctx_destroy(self._h)
+            self._L.flacgpu_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -56,7 +61,7 @@ class Context:
         ``stream_lengths``: samples per stream (streams are laid back to back in ``pcm``); default one stream.
         Returns ``(out_bytes_tensor[:total], frame_offsets_tensor[nblocks+1], EncodeStats)``.
         """
-        L = _lib.lib()
+        L = self._L
         assert pcm.is_cuda and pcm.is_contiguous()
         is16 = pcm.dtype == torch.int16
         assert is16 or pcm.dtype == torch.int32
@@ -90,7 +95,7 @@ class Context:
         rc = L.flacgpu_encode_streams(self._h, C.byref(s), pcm.data_ptr(), 1 if is16 else 0, descs, len(stream_lengths),
                                       out.data_ptr(), out.numel(), offsets.data_ptr(), C.byref(st))
         if rc != 0:
-            raise FlacGpuError(_lib.last_error())
+            raise FlacGpuError(self._err())
         if st.error_flags:
             raise FlacGpuError('encode error flags 0x%x' % st.error_flags)
         return out, offsets[:st.nblocks + 1], st
@@ -99,7 +104,7 @@ class Context:
         """STREAMINFO's md5sum of every stream of device tensor ``pcm`` ([total_samples, channels] int32 or int16): MD5 over the
         samples as libFLAC hashes them (little-endian, (bits + 7) // 8 bytes each, interleaved).  One GPU thread per stream --
         the hash is a serial chain -- on a stream of its own.  Returns ``(list of 16-byte digests, kernel milliseconds)``."""
-        L = _lib.lib()
+        L = self._L
         assert pcm.is_cuda and pcm.is_contiguous() and pcm.dtype in (torch.int16, torch.int32)
         ch = 1 if pcm.dim() == 1 else pcm.shape[1]
         if stream_lengths is None:
@@ -115,14 +120,14 @@ class Context:
         torch.cuda.current_stream(pcm.device).synchronize()
         if L.flacgpu_md5_streams(self._h, pcm.data_ptr(), 1 if pcm.dtype == torch.int16 else 0, ch, bits_per_sample, descs, len(stream_lengths),
                                  out.data_ptr(), C.byref(ms)) != 0:
-            raise FlacGpuError(_lib.last_error())
+            raise FlacGpuError(self._err())
         h = out.cpu().numpy().tobytes()
         return [h[16 * i:16 * i + 16] for i in range(len(stream_lengths))], float(ms.value)
 
     def debug_records(self, first, n):
         from .debug import DebugRec
         buf = (DebugRec * n)()
-        if _lib.lib().flacgpu_copy_debug(self._h, buf, first, n) != 0:
+        if self._L.flacgpu_copy_debug(self._h, buf, first, n) != 0:
             raise FlacGpuError('no debug records')
         return buf
 
@@ -133,7 +138,7 @@ class Context:
 
         Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
         """
-        L = _lib.lib()
+        L = self._L
         assert stream.is_cuda and stream.dtype == torch.uint8
         on_dev = isinstance(frame_offsets, torch.Tensor) and frame_offsets.is_cuda
         if on_dev:
@@ -152,7 +157,7 @@ class Context:
         rc = fn(self._h, stream.data_ptr(), stream.numel(), frame_offsets.data_ptr() if on_dev else offs.ctypes.data, nframes,
                 channels, bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, C.byref(st))
         if rc != 0:
-            raise FlacGpuError(_lib.last_error())
+            raise FlacGpuError(self._err())
         return out[:st.total_samples], status[:nframes], st
 
 
@@ -162,7 +167,7 @@ class Context:
 
         Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
         """
-        L = _lib.lib()
+        L = self._L
         assert stream.is_cuda and stream.dtype == torch.uint8 and stream.is_contiguous()
         torch.cuda.current_stream(stream.device).synchronize()      # the library works on its own HIP streams
         if out is None or out.numel() < max_samples * channels:
@@ -176,7 +181,7 @@ class Context:
                                          bits_per_sample, out.data_ptr(), max_samples, status.ctypes.data, status.shape[0],
                                          offsets_out.data_ptr() if offsets_out is not None else None, C.byref(st))
         if rc != 0:
-            raise FlacGpuError(_lib.last_error())
+            raise FlacGpuError(self._err())
         if st.nframes > status.shape[0]:
             # (tiny frames: more of them than the guess) -- decode again with the count now known
             return self.decode_stream(stream, channels, bits_per_sample, max_samples, nframes=st.nframes,
@@ -190,7 +195,7 @@ class Context:
 
         Returns ``(pcm[total_samples, channels] int32 device tensor, status uint32[nframes, 2], DecodeStats)``.
         """
-        L = _lib.lib()
+        L = self._L
         assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
         torch.cuda.current_stream(data.device).synchronize()
         if out is None or out.numel() < max_samples * channels:
@@ -211,7 +216,7 @@ class Context:
                                           out.data_ptr(), max_samples, status.ctypes.data, status.shape[0],
                                           offsets_out.data_ptr() if offsets_out is not None else None, C.byref(st))
         if rc != 0:
-            raise FlacGpuError(_lib.last_error())
+            raise FlacGpuError(self._err())
         return out[:st.total_samples], status[:st.nframes], st
 
 

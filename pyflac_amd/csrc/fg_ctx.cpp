@@ -98,7 +98,7 @@ uint32_t flacgpu_ctx::window_offset(uint32_t n, uint32_t parts)
         const uint32_t *ref = parts >= 3 ? FG_TUKEY4096_P16 : parts == 2 ? FG_TUKEY4096_P25 : FG_TUKEY4096_P50;
         const uint32_t np = parts >= 3 ? FG_TUKEY4096_P16_NP : parts == 2 ? FG_TUKEY4096_P25_NP : FG_TUKEY4096_P50_NP;
         float *w = h_windows.data() + e.off;
-        bool differs = getenv("FLACGPU_WINDOW_SELFTEST") != nullptr;      // (test hook: pretend the host's cosf disagrees)
+        bool differs = fg_sel("FLACGPU_WINDOW_SELFTEST") != nullptr;      // (test hook: pretend the host's cosf disagrees)
         if (differs) for (uint32_t i = 0; i <= np; i++) { w[i] = 0.25f; w[n - np - 1 + i] = 0.25f; }
         for (uint32_t i = 0; i <= np && !differs; i++) {
             uint32_t a, b;
@@ -366,8 +366,8 @@ extern "C" unsigned int flacgpu_build_flags(void)
 #ifdef FG_TUNING
     f |= 1u;
 #endif
-#ifdef FG_LEGACY
-    f |= 2u;
+#ifdef FG_TESTHOOKS
+    f |= 4u;
 #endif
     return f;
 }
@@ -425,9 +425,8 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         memcpy(key.data(), s, sb);
         if (tb) memcpy(key.data() + sb, streams, tb);
         // (the kernel selection switches -- tuning aids read per call -- decide which blocks count as pipeline blocks: part of the key)
-        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (getenv("FLACGPU_NO_FAST") ? 2 : 0) | (view << 4) |
-                                       ((getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) ? 4 : 0) |
-                                       ((getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1) ? 8 : 0));
+        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (fg_sel("FLACGPU_NO_FAST") ? 2 : 0) | (view << 4) | (c->direct ? 4 : 0) |
+                                       ((fg_sel("FLACGPU_WS") && atoi(fg_sel("FLACGPU_WS")) == 1) ? 8 : 0));
     }
     const bool reuse = !(s->do_mid_side && s->loose_mid_side) && !c->debug && c->dev_descs_ptr == c->descs.p && c->dev_descs_ptr != nullptr &&
                        !c->dev_descs.empty() && key == c->desc_key;
@@ -472,18 +471,13 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     }
     // ---- which kernels: the de-fused pipeline (flac_enc_pipe_impl.h) where it applies, round 1's single kernel with
     // FLACGPU_PIPE=0, the generic kernel for everything else
-    const bool cfg_fast = !getenv("FLACGPU_NO_FAST") && c->mfma_bad == 0 && P.sig_stride != 0 && s->channels <= 2 && s->max_lpc_order <= 12 &&
+    const bool cfg_fast = !fg_sel("FLACGPU_NO_FAST") && c->mfma_bad == 0 && P.sig_stride != 0 && s->channels <= 2 && s->max_lpc_order <= 12 &&
                           // (32-bit streams: blocks whose channels share eight wasted bits, flac_enc_pipe_impl.h pipe_preshift; the rest is handed
                           // to the generic kernel block by block, which the decision probe of loose mid-side does not expect)
                           (s->bits_per_sample <= 24 || (s->bits_per_sample == 32 && !(s->do_mid_side && s->loose_mid_side)));
-#ifdef FG_LEGACY
-    const bool use_pipe = cfg_fast && !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0) && fg_pipe_supported(&P);
-#else
-    // (round 1's one-kernel-per-block encoder, FLACGPU_PIPE=0, is built with `make LEGACY=1` only)
     const bool use_pipe = cfg_fast && fg_pipe_supported(&P);
-#endif
     if (view && !use_pipe && cfg_fast) { fg_set_error("one-channel views need the pipeline or the generic kernel"); return false; }
-    const bool ws1_only = getenv("FLACGPU_WS") && atoi(getenv("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
+    const bool ws1_only = fg_sel("FLACGPU_WS") && atoi(fg_sel("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
     const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
     uint32_t chunk_cap_words = 0, fbw_words = s->bits_per_sample <= 16 ? 800 : 1280;   // 16-bit stereo: 5 workgroups per CU
     if (fg_tune("FLACGPU_FBW")) fbw_words = (uint32_t)atoi(fg_tune("FLACGPU_FBW"));
@@ -681,7 +675,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     if (ev2) HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // (several groups: no begin kernel when the last call's signal kernel left the counters reset, no fork event when nothing this
     // call put on the main stream concerns the other groups -- FgPipeLaunch.guard_clean / no_fork)
-    static const bool quick_off = getenv("FLACGPU_QUICK_START") && atoi(getenv("FLACGPU_QUICK_START")) == 0;
+    static const bool quick_off = fg_sel("FLACGPU_QUICK_START") && atoi(fg_sel("FLACGPU_QUICK_START")) == 0;
     PL.guard_clean = (lean && use_pipe && !quick_off && guard_was_clean) ? 1u : 0u;
     PL.no_fork = (PL.guard_clean && reuse && !c->debug && !lb_cleared && !g_input_on_stream) ? 1u : 0u;
     if (lean) {
@@ -723,11 +717,11 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         else {
             PL.stages = 3;
             // (groups: flac_enc_pipe_impl.h / pipe_shape.inc; a launch of a few hundred blocks does not fill the chip once)
-            static const int groups_env = getenv("FLACGPU_GROUPS") ? atoi(getenv("FLACGPU_GROUPS")) : 0;
+            static const int groups_env = fg_sel("FLACGPU_GROUPS") ? atoi(fg_sel("FLACGPU_GROUPS")) : 0;
             // (direct packing: the packing kernels of two groups run one behind the other anyway -- pipe_shape.inc --, and one chain of
             // whole-launch kernels then is the faster form: 0.431-0.444 ms against 0.448-0.458 on the headline stream)
             PL.ngroups = groups_env > 0 ? (uint32_t)groups_env : ((nfast >= 4096 && !direct) ? 2u : 1u);
-            static const bool keep_off = getenv("FLACGPU_KEEP") && atoi(getenv("FLACGPU_KEEP")) == 0;
+            static const bool keep_off = fg_sel("FLACGPU_KEEP") && atoi(fg_sel("FLACGPU_KEEP")) == 0;
             PL.no_keep = keep_off ? 1u : 0u;
             if (c->debug) PL.ngroups = 1;
             if (fg_launch_encode_pipe(&PL) != 0) { fg_set_error("encode pipeline launch failed"); return false; }
@@ -735,16 +729,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         }
         piped = true;
     }
-#ifdef FG_LEGACY
-    else if (nfast) {
-        const int rc = fg_launch_encode_fast(d_pcm, (const FgBlockDesc *)c->descs.p, (const float *)c->windows.p, &P, nfast, (uint8_t *)c->slots.p,
-                                             (FgBlockResult *)c->results.p, dbg, (const uint16_t *)c->crctab.p, c->stream);
-        if (rc == -1) nfast = 0;
-        else if (rc != 0) { fg_set_error("fast encode kernel launch failed"); return false; }
-    }
-#else
     else if (nfast) nfast = 0;       // (not reached: without the pipeline no block counts as fast)
-#endif
     if (nblocks > nfast) {
         hipStream_t ss = (side && nfast) ? c->stream2 : c->stream;
         if (fg_launch_encode(d_pcm, (const FgBlockDesc *)c->descs.p + nfast, (const float *)c->windows.p, &P, nblocks - nfast, (uint8_t *)c->slots.p,
@@ -979,8 +964,7 @@ extern "C" int flacgpu_encode_streams(flacgpu_ctx *c, const flacgpu_settings *s,
     // more than two channels: one-channel views through the pipeline where its shape applies (limit_min_bitrate looks across the
     // channels of a frame, large blocks and wide samples stay with the generic kernel)
     if (s->channels > 2 && s->channels <= 8 && (s->bits_per_sample <= 24 || s->bits_per_sample == 32) && s->max_lpc_order <= 12 && !s->limit_min_bitrate && !c->debug &&
-        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !getenv("FLACGPU_NO_FAST") && c->mfma_bad == 0 && !(getenv("FLACGPU_MC") && atoi(getenv("FLACGPU_MC")) == 0) &&
-        !(getenv("FLACGPU_PIPE") && atoi(getenv("FLACGPU_PIPE")) == 0))
+        s->blocksize >= 16 && s->blocksize <= 16384 && d_out && !fg_sel("FLACGPU_NO_FAST") && c->mfma_bad == 0 && !(fg_sel("FLACGPU_MC") && atoi(fg_sel("FLACGPU_MC")) == 0))
         return encode_multichannel(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
     return encode_streams_impl(c, s, d_pcm, pcm_is_i16, streams, nstreams, d_out, out_cap, d_offsets, st) ? 0 : -1;
 }

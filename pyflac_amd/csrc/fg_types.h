@@ -3,17 +3,29 @@
 #include <stdint.h>
 
 // ---- environment switches --------------------------------------------------------------------------------------------------------
-// Read by every build: FLACGPU_DEVICE (configuration: which GPU the default context uses), the kernel SELECTORS that choose among
-// implementations with identical results and exist for the cross-check tests (FLACGPU_NO_FAST, FLACGPU_PIPE, FLACGPU_MC, FLACGPU_WS,
-// FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_DEC_WAVE, FLACGPU_DEC_WRESTORE, FLACGPU_DEC_FUSED, FLACGPU_DEC_P16, FLACGPU_DEC_SELF, FLACGPU_QUICK_START, FLACGPU_DEC_G1 / G2 / WPS) and two
-// test hooks (FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST).  Everything that skips work, reorders it for an experiment or
-// prints diagnostics (FLACGPU_DEC_SKIP, FLACGPU_STOP, FLACGPU_DEC_CRC_LATE, FLACGPU_FBW, FLACGPU_LDS_PAD, FLACGPU_SPIN_US,
-// FLACGPU_DEC_PROF, FLACGPU_API_PROF, FG_REFWALK_DEBUG) is read through fg_tune(), which answers "unset" unless the library was built
-// with `make TUNING=1` (-DFG_TUNING): the release library cannot be talked into skipping a stage.
+// The release library (`make`: libflacgpu.so) reads ONE environment variable: FLACGPU_DEVICE, which GPU the default context uses.
+//   * fg_sel(): the kernel SELECTORS that choose among implementations with identical results and the two TEST HOOKS that alter
+//     results on purpose (FLACGPU_NO_FAST, FLACGPU_WS, FLACGPU_MC, FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_QUICK_START, FLACGPU_DEC_SELF,
+//     FLACGPU_DEC_P16, FLACGPU_DEC_WAVE; FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST) are read by the test-hooks library only
+//     (libflacgpu_testhooks.so: the same kernel objects, the three host files compiled with -DFG_TESTHOOKS; the cross-check tests
+//     load it explicitly, pyflac_amd/_lib.py testhooks_lib()).
+//   * fg_tune(): everything that skips work, reorders it for an experiment or prints diagnostics (FLACGPU_DEC_SKIP, FLACGPU_STOP,
+//     FLACGPU_DEC_CRC_LATE, FLACGPU_FBW, FLACGPU_LDS_PAD, FLACGPU_FCAP, FLACGPU_ALIAS, FLACGPU_DIRECT_X, FLACGPU_SPIN_US,
+//     FLACGPU_DEC_PROF, FLACGPU_API_PROF, FG_REFWALK_DEBUG, FLACGPU_DEC_WPS) is read by `make TUNING=1` builds only.
+// flacgpu_build_flags() says what a library is: bit 0 tuning, bit 2 test hooks.
 #include <stdlib.h>
 static inline const char *fg_tune(const char *name)
 {
 #ifdef FG_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return (const char *)0;
+#endif
+}
+static inline const char *fg_sel(const char *name)
+{
+#if defined(FG_TESTHOOKS) || defined(FG_TUNING)
     return getenv(name);
 #else
     (void)name;

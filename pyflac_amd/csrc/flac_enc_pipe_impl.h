@@ -41,6 +41,12 @@
 #define LDS __attribute__((address_space(3)))
 #define FGI __device__ __forceinline__
 
+// (P.debug values 101..103 switch parts of the autocorrelation kernel off: timing experiments of round 3, compiled into tuning builds only)
+#ifdef FG_TUNING
+#define FGX_DBG(v) (P.debug == (v))
+#else
+#define FGX_DBG(v) false
+#endif
 #ifndef FGX_MERGE
 // evaluation (<= 16 bit, regular geometry): fixed-predictor sums and the first LPC vector's residual in ONE walk over the samples (the
 // candidate's samples formed once instead of twice: 3 instructions a sample fewer).  Measured slower on the MI355X, 124.4 -> 128.1 us
@@ -336,7 +342,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
 #pragma unroll
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t j = u * 64 + lane;
-                            if (P.debug != 102) {       // (behind the end of the signal the fetch gave zeros: the chains run on a little)
+                            if (!FGX_DBG(102)) {       // (behind the end of the signal the fetch gave zeros: the chains run on a little)
                                 int32_t L = xl[u], R = xr[u];
                                 unraw(L, R);
 #pragma unroll
@@ -352,7 +358,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
 #pragma unroll
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t j = u * 64 + lane;
-                            if (P.debug != 102) {
+                            if (!FGX_DBG(102)) {
                                 int32_t L = xl[u], R = xr[u];
                                 unraw(L, R);
                                 const bool zero = part != 0 && (k0 + j) >= 2 * part;
@@ -370,7 +376,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                     }
                     if (k0 + FGP_CK < vec_len) fetch(k0 + FGP_CK);
                     wave_lds_fence();
-                    if (P.debug != 101) {
+                    if (!FGX_DBG(101)) {
                         // The chains on the matrix core.  v_mfma_f64_4x4x4_4b_f64 computes, for four independent blocks b,
                         // D[i][j] += sum_k A[i][k] * B[k][j] with one fused multiply-add per k, in ascending k, each rounded like
                         // v_fma_f64 (tools/ubench/mfma64.hip: 262144 random cases bit-equal to that chain and to no other
@@ -454,7 +460,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
 #undef FG_DPPQ
                     }
                     wave_lds_fence();
-                    if (k0 + kn < vec_len && P.debug != 103) {
+                    if (k0 + kn < vec_len && !FGX_DBG(103)) {
                         double t[(NC * FGP_DH + 63) / 64];
 #pragma unroll
                         for (int u = 0; u < (NC * FGP_DH + 63) / 64; u++) {

@@ -464,13 +464,9 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // (+ one block of the largest size: the parts of the plane are placed at frame number x stride, FgDecSelf)
     const uint64_t cap_bytes = cap_samples * C * 4 + 256 + 65536ull * C * 4;
     const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20) + 65536ull * C * 4;
-    static const bool self_off = getenv("FLACGPU_DEC_SELF") && atoi(getenv("FLACGPU_DEC_SELF")) == 0;
+    static const bool self_off = fg_sel("FLACGPU_DEC_SELF") && atoi(fg_sel("FLACGPU_DEC_SELF")) == 0;
     static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 0;
-#ifdef FG_LEGACY
-    bool selfstart = false;              // (the superseded kernels start from the frame table)
-#else
     bool selfstart = lean && queued && index_here && nranges == 0 && !detail && !self_off && crc_late_mode == 0 && c->stream2 != nullptr;
-#endif
     uint32_t *d_hrec = nullptr;
     unsigned long long *d_poff = nullptr;
     if (selfstart) {
@@ -536,17 +532,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         (void)hipMemsetAsync(d_prof, 0, (size_t)npad * 2 * 8 * 8, c->stream);
     }
     // The CRC-16 pass only needs the stream and the frame table: it runs on the side stream beside the parse kernel.
-#ifdef FG_LEGACY
-    static const int wave_parse = getenv("FLACGPU_DEC_WAVE") ? atoi(getenv("FLACGPU_DEC_WAVE")) : 1;     // 0: the lane-serial fused kernel of round 2
-    static const bool old_restore = getenv("FLACGPU_DEC_WRESTORE") && atoi(getenv("FLACGPU_DEC_WRESTORE")) == 0;
-#else
-    // (the lane-serial decoders of rounds 1 and 2 are built with `make LEGACY=1` only: the selectors have nothing to select)
-    static const int wave_parse = (getenv("FLACGPU_DEC_WAVE") && atoi(getenv("FLACGPU_DEC_WAVE")) >= 2) ? 2 : 1;
+    // (the lane-serial decoders of rounds 1 and 2 -- fg_dec_rice_kernel + fg_dec_restore_kernel, fg_dec_fused_kernel -- left the
+    // tree in round 5: the wave parser and its restore kernel decode everything the generic kernel does not; FLACGPU_DEC_WAVE=2 in a
+    // test-hooks build counts the parser's rounds)
+    static const int wave_parse = (fg_sel("FLACGPU_DEC_WAVE") && atoi(fg_sel("FLACGPU_DEC_WAVE")) >= 2) ? 2 : 1;
     static const bool old_restore = false;
-#endif
-    static const bool fused_off = getenv("FLACGPU_DEC_FUSED") && atoi(getenv("FLACGPU_DEC_FUSED")) == 0;
-    static const bool prof_fused = fg_tune("FLACGPU_DEC_PROF") && atoi(fg_tune("FLACGPU_DEC_PROF")) == 2;
-    const bool fused = !wave_parse && !fused_off && (!d_prof || prof_fused) && !(detail && detail->level >= 2);
+    const bool fused = false;
     // (measured: beside the restore kernel the CRC pass slows that kernel's lone recurrence waves down by more than it gave
     // the parse kernel back -- 136 + 159 us against 123 + 163 --, so it stays beside the parse kernel; FLACGPU_DEC_CRC_LATE=1 tries
     // the other order)
@@ -560,7 +551,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     const bool crc_join_late = crc_late_mode == 2 && wave_parse && !old_restore && !fused;
     // 16-bit residual plane between the wave parser and its restore kernel (streams of up to 16 bits; flac_dec_wave.hip P16).  Not
     // when the planes themselves are handed out (subframe detail: FLAC__Frame.subframes[].residual) or read by the warm-up kernel.
-    static const bool p16_off = getenv("FLACGPU_DEC_P16") && atoi(getenv("FLACGPU_DEC_P16")) == 0;
+    static const bool p16_off = fg_sel("FLACGPU_DEC_P16") && atoi(fg_sel("FLACGPU_DEC_P16")) == 0;
     // A frame with a value beyond 16 bits ends the parse with status 6: the call is repeated with 32-bit planes, and so are the
     // next calls of this context (a stream that does it once does it again: full-scale noise, a side channel at full scale).
     const int plane16 = (!wide && wave_parse && !old_restore && !fused && !detail && !p16_off && c->dec_p16_hold == 0) ? 1 : 0;

@@ -686,7 +686,7 @@ bool encode_pending(EncImpl *e, bool flush_all, const int32_t *in32 = nullptr, c
             unsigned long long *d_first = (unsigned long long *)((char *)e->d_verify.p + (((size_t)nvals * 4 + 15) & ~(size_t)15));
             unsigned long long first = 0;
             // FLACGPU_VERIFY_SELFTEST: disturb the reference copy so that the mismatch path can be exercised by a test
-            if (getenv("FLACGPU_VERIFY_SELFTEST")) {
+            if (fg_sel("FLACGPU_VERIFY_SELFTEST")) {
                 const int32_t first0 = from_pend ? e->pending[0] : (in32 ? in32[0] : (int32_t)in16[0]);
                 const int32_t poison = first0 ^ 0x55;
                 (void)hipMemcpy(e->d_pcm.p, &poison, 4, hipMemcpyHostToDevice);

@@ -32,6 +32,29 @@ def wavs():
     return out
 
 
+_VERIFY_SCRIPT = '''
+import sys, json, ctypes as C
+sys.path.insert(0, %r)
+import numpy as np
+import pyflac_amd
+from pyflac_amd import _lib
+from tests import cases
+pcm = cases.make_pcm({'kind': 'cfg2', 'seconds': 0.5, 'seed': 2})[0]
+enc = pyflac_amd.StreamEncoder(48000, lambda b, n, s, f: None, blocksize=4096, verify=True)
+err = ''
+try:
+    enc.process(pcm)
+    enc.finish()
+except pyflac_amd.EncoderProcessException as e:
+    err = str(e)
+a, fr, ch, sm = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+ex, got = C.c_int32(), C.c_int32()
+_lib.lib().FLAC__stream_encoder_get_verify_decoder_error_stats(enc._encoder, C.byref(a), C.byref(fr), C.byref(ch), C.byref(sm), C.byref(ex), C.byref(got))
+print('RESULT ' + json.dumps({'flags': int(_lib.lib().flacgpu_build_flags()), 'error': err, 'where': [a.value, fr.value, ch.value, sm.value],
+                              'expected': ex.value, 'got': got.value}))
+'''
+
+
 class TestStreamEncoder:
     def _mk(self, **kw):
         import pyflac_amd
@@ -113,27 +136,28 @@ class TestStreamEncoder:
         enc.finish()
         assert hashlib.sha256(b''.join(chunks)).hexdigest() == limit_golden['lmb_equal_st_l5']['sha256']
 
-    def test_verify_runs_and_reports_a_mismatch(self, monkeypatch):
+    def test_verify_runs_and_reports_a_mismatch(self):
         """verify=True decodes every frame on the GPU and compares it with the input (libFLAC's verify mode); with the
-        self-test hook disturbing the comparison copy the encoder must stop in VERIFY_MISMATCH_IN_AUDIO_DATA."""
-        import pyflac_amd
-        from pyflac_amd import _lib
-        import ctypes as C
+        self-test hook disturbing the comparison copy the encoder must stop in VERIFY_MISMATCH_IN_AUDIO_DATA.  The hook exists in the
+        test-hooks build of the library only: a child process runs the classes on that build (PYFLAC_AMD_TESTHOOKS=1); in this
+        process, on the release library, the variable changes nothing."""
+        import subprocess, sys, json
         pcm = cases.make_pcm({'kind': 'cfg2', 'seconds': 0.5, 'seed': 2})[0]
-        enc = self._mk(sample_rate=48000, blocksize=4096, verify=True)
-        enc.process(pcm)
-        assert enc.finish() and len(self.calls) > 3
-        monkeypatch.setenv('FLACGPU_VERIFY_SELFTEST', '1')
-        enc = self._mk(sample_rate=48000, blocksize=4096, verify=True)
-        with pytest.raises(pyflac_amd.EncoderProcessException, match='VERIFY_MISMATCH_IN_AUDIO_DATA'):
+        os.environ['FLACGPU_VERIFY_SELFTEST'] = '1'
+        try:
+            enc = self._mk(sample_rate=48000, blocksize=4096, verify=True)
             enc.process(pcm)
-            enc.finish()
-        a, fr, ch, sm = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        ex, got = C.c_int32(), C.c_int32()
-        _lib.lib().FLAC__stream_encoder_get_verify_decoder_error_stats(enc._encoder, C.byref(a), C.byref(fr), C.byref(ch),
-                                                                      C.byref(sm), C.byref(ex), C.byref(got))
-        assert (a.value, fr.value, ch.value, sm.value) == (0, 0, 0, 0)
-        assert got.value == int(pcm[0, 0]) and ex.value == (int(pcm[0, 0]) ^ 0x55)
+            assert enc.finish() and len(self.calls) > 3
+        finally:
+            del os.environ['FLACGPU_VERIFY_SELFTEST']
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, FLACGPU_VERIFY_SELFTEST='1', PYFLAC_AMD_TESTHOOKS='1')
+        p = subprocess.run([sys.executable, '-c', _VERIFY_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        r = json.loads([l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
+        assert r['flags'] & 4 and 'VERIFY_MISMATCH_IN_AUDIO_DATA' in r['error']
+        assert r['where'] == [0, 0, 0, 0]
+        assert r['got'] == int(pcm[0, 0]) and r['expected'] == (int(pcm[0, 0]) ^ 0x55)
 
     def test_look_ahead_of_one_sample(self):
         """libFLAC emits a frame only once blocksize+1 samples are buffered."""

@@ -65,14 +65,12 @@ def test_crc_mismatch_gives_silence_and_flag(ctx, small_streams):
     assert np.array_equal(pcm[:3 * 4096, 0], want[:3 * 4096, 0])
 
 
-@pytest.mark.parametrize('wps,seconds,ch', [('1', 330.0, 2), ('2', 330.0, 2), ('1', 200.0, 1), ('8', 40.0, 2)])
-def test_frames_per_wave_shapes(ctx, monkeypatch, wps, seconds, ch):
-    """The parse / restore kernels pack several frames into a wave when a launch has many frames (FLACGPU_DEC_WPS sets
-    the target waves per SIMD): decode of a long stream must stay the identity for every packing (here 1..8 frames per
-    wave), including the short last frame."""
+@pytest.mark.parametrize('seconds,ch', [(330.0, 2), (200.0, 1), (40.0, 2)])
+def test_frames_per_wave_shapes(ctx, seconds, ch):
+    """Decode of long and short streams, stereo and mono, stays the identity, the short last frame included.  (The parameters are
+    those of the frames-per-wave packings of round 2's lane-serial decoder, which left the tree in round 5; the shapes remain.)"""
     import torch
     from pyflac_amd import batch, synth
-    monkeypatch.setenv('FLACGPU_DEC_WPS', wps)
     pcm = synth.config2_stereo16(seconds, 3)[:, :ch].copy()
     pcm = pcm[:len(pcm) - 777]                                   # ragged tail frame
     t = torch.from_numpy(pcm.astype(np.int32)).cuda()
@@ -90,8 +88,6 @@ def test_more_than_32_frames_per_workgroup(ctx, monkeypatch, ch, bps, bs, g1):
     output form), a ragged last frame, and group sizes that leave the last round and the last workgroup part empty."""
     import torch
     from pyflac_amd import batch, synth
-    if g1:
-        monkeypatch.setenv('FLACGPU_DEC_G1', g1)
     nfr = 256 * 36 + 5 if g1 is None else 700
     n = nfr * bs - bs // 3
     pcm = synth.config2_stereo16(n / 48000.0 + 0.01, 11)[:n, :ch].astype(np.int32)
@@ -383,7 +379,6 @@ def test_count_mode_with_frames_shorter_than_any_guess(ctx):
     assert (rows[:3, 0] == 0).all() and (rows[3:] == 0xAAAAAAAA).all()
 
 
-@pytest.mark.skipif(os.environ.get('FLACGPU_DEC_WAVE') == '0', reason='the wave parser is switched off (legacy cross-check run)')
 class TestResidualPlaneWidth:
     """Round 4: for streams of up to 16 bits the residual plane between the wave parser and the restore kernel is 16 bits wide
     (flac_dec_wave.hip P16; flacgpu_decode_stats.plane_bits).  A frame with a value beyond 16 bits -- a side channel at full scale,
@@ -461,7 +456,6 @@ print('RESULT ' + json.dumps(res))
 '''
 
 
-@pytest.mark.skipif(os.environ.get('FLACGPU_DEC_WAVE') == '0', reason='the wave parser is switched off (legacy cross-check run)')
 def test_parser_on_its_own_equals_parser_behind_the_header_pass():
     """Round 4 (FgDecSelf): decoding one stream from its bytes, the wave parser starts from the frame offsets and the header records
     of the index pass, header pass + scan and the CRC pass beside it.  Same samples and the same status of every frame as with the
@@ -471,7 +465,7 @@ def test_parser_on_its_own_equals_parser_behind_the_header_pass():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for v in ('1', '0'):
-        env = dict(os.environ, FLACGPU_DEC_SELF=v)
+        env = dict(os.environ, FLACGPU_DEC_SELF=v, PYFLAC_AMD_TESTHOOKS='1')        # (the selector is read by the test-hooks build only)
         p = subprocess.run([sys.executable, '-c', _SELF_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]

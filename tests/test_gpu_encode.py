@@ -23,6 +23,14 @@ def ctx():
     return batch.Context(0)
 
 
+@pytest.fixture(scope='module')
+def hctx():
+    """A context in the test-hooks build of the library (csrc/Makefile libflacgpu_testhooks.so): the only build that reads the kernel
+    selectors (FLACGPU_NO_FAST, FLACGPU_MC, ...) from the environment -- the cross-checks of two implementations of one result."""
+    from pyflac_amd import batch
+    return batch.Context(0, testhooks=True)
+
+
 def _gpu_stream(ctx, arr, sr, bps, level, bs, subset, i16=False):
     import torch
     from pyflac_amd import batch
@@ -90,7 +98,8 @@ def test_limit_min_bitrate_matches_golden(ctx, limit_golden, name):
     assert hashlib.sha256(stream).hexdigest() == limit_golden[name]['sha256']
 
 
-def test_limit_min_bitrate_generic_kernel(ctx, limit_golden, monkeypatch):
+def test_limit_min_bitrate_generic_kernel(hctx, limit_golden, monkeypatch):
+    ctx = hctx
     import torch
     from pyflac_amd import batch
     from pyflac_amd.encoder import stream_header_bytes
@@ -113,13 +122,23 @@ def test_int16_ingest_equals_int32(ctx):
     assert a == b
 
 
-def test_generic_kernel_equals_fast_kernel(ctx, monkeypatch):
-    """FLACGPU_NO_FAST routes every block through the generic kernel; bytes must not change."""
+def test_generic_kernel_equals_fast_kernel(ctx, hctx, monkeypatch):
+    """FLACGPU_NO_FAST (test-hooks build) routes every block through the generic kernel; bytes must not change -- and the release
+    library does not listen to the variable."""
+    from pyflac_amd import _lib
     pcm, bps = cases.make_pcm({'kind': 'hard16', 'seconds': 1.0})
     a, _, _ = _gpu_stream(ctx, pcm, 48000, 16, 8, 4096, True)
     monkeypatch.setenv('FLACGPU_NO_FAST', '1')
-    b, _, _ = _gpu_stream(ctx, pcm, 48000, 16, 8, 4096, True)
+    b, _, _ = _gpu_stream(hctx, pcm, 48000, 16, 8, 4096, True)
     assert a == b
+    L = _lib.lib()
+    buf = (C.c_uint8 * (32 * 64))()
+    L.flacgpu_copy_block_results.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    for cx, generic in ((hctx, True), (ctx, False)):
+        _gpu_stream(cx, pcm, 48000, 16, 8, 4096, True)
+        assert cx._L.flacgpu_copy_block_results(cx._h, buf, 1) == 0
+        reserved = np.frombuffer(bytes(buf), np.uint32)[7]            # FgBlockResult.reserved: 4 = a block of the pipeline
+        assert (reserved != 4) == generic
 
 
 def test_many_streams_one_launch(ctx):
@@ -346,27 +365,17 @@ def test_window_selfcheck(golden, monkeypatch):
         assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256']
     assert L.flacgpu_window_note(c1._h) == b'', 'this host\'s cosf disagrees with the committed window table'
     monkeypatch.setenv('FLACGPU_WINDOW_SELFTEST', '1')
-    c2 = batch.Context(0)
+    c3 = batch.Context(0)                    # (the release library does not listen to the hook)
+    stream, _o, _s = _gpu_stream(c3, cases.as_int_array(*cases.make_pcm(cases.ENCODE_CASES['cfg2_20s_l5'][0])), 48000, 16, 5, 4096, True)
+    assert L.flacgpu_window_note(c3._h) == b''
+    c2 = batch.Context(0, testhooks=True)
+    L = c2._L
     for name in ('cfg2_20s_l5', 'cfg4_10s_l8'):
         spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
         pcm, bps = cases.make_pcm(spec)
         stream, _o, _s = _gpu_stream(c2, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
         assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256']
     assert b'committed table is used' in L.flacgpu_window_note(c2._h)
-
-
-def test_round1_single_kernel_still_matches_golden(ctx, golden, monkeypatch):
-    """FLACGPU_PIPE=0 selects round 1's one-kernel-per-block encoder; same bytes.  (A kernel of a `make LEGACY=1` build: the
-    default library does not carry the superseded kernels, flacgpu_build_flags bit 1.)"""
-    from pyflac_amd import _lib
-    if not (_lib.lib().flacgpu_build_flags() & 2):
-        pytest.skip('library built without LEGACY=1')
-    monkeypatch.setenv('FLACGPU_PIPE', '0')
-    for name in ('cfg2_20s_l5', 'wasted4_st', 'sines24_l8_bs4608', 'noise16_st'):
-        spec, sr, level, bs, subset = cases.ENCODE_CASES[name]
-        pcm, bps = cases.make_pcm(spec)
-        stream, _o, _s = _gpu_stream(ctx, cases.as_int_array(pcm, bps), sr, bps, level, bs, subset)
-        assert hashlib.sha256(stream).hexdigest() == golden[name]['sha256'], name
 
 
 def test_wasted_bits_stay_in_the_pipeline(ctx):
@@ -520,7 +529,7 @@ def _multichannel_pcm(seed, channels, n, bps):
 
 @pytest.mark.parametrize('channels,bps,level,bs,n', [(3, 16, 5, 4096, 4096 * 5 + 777), (6, 16, 5, 4096, 4096 * 9), (8, 16, 8, 4096, 4096 * 3 + 100),
                                                      (4, 24, 8, 4096, 4096 * 4 + 63), (6, 16, 0, 1152, 1152 * 7 + 1), (5, 8, 3, 576, 576 * 11 + 17)])
-def test_more_than_two_channels_through_the_pipeline(ctx, monkeypatch, channels, bps, level, bs, n):
+def test_more_than_two_channels_through_the_pipeline(ctx, hctx, monkeypatch, channels, bps, level, bs, n):
     """Streams of three to eight channels: every channel a one-channel view through the pipeline, the frames spliced by
     flac_enc_merge.hip (fg_ctx.cpp encode_multichannel).  Bytes equal the oracle's and the generic kernel's (FLACGPU_MC=0),
     frame index included."""
@@ -532,7 +541,7 @@ def test_more_than_two_channels_through_the_pipeline(ctx, monkeypatch, channels,
     assert got[86:] == want[86:]
     assert list(np.diff(offs)) == list(sizes)
     monkeypatch.setenv('FLACGPU_MC', '0')
-    ref, offs2, _ = _gpu_stream(ctx, pcm, 48000, bps, level, bs, True)
+    ref, offs2, _ = _gpu_stream(hctx, pcm, 48000, bps, level, bs, True)
     assert ref == got and np.array_equal(offs, offs2)
 
 
@@ -787,7 +796,7 @@ def test_grouped_launch_starts_the_same_with_and_without_its_begin_kernel():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for v in ('1', '0'):
-        env = dict(os.environ, FLACGPU_QUICK_START=v)
+        env = dict(os.environ, FLACGPU_QUICK_START=v, PYFLAC_AMD_TESTHOOKS='1')       # (the selector is read by the test-hooks build only)
         p = subprocess.run([sys.executable, '-c', _QUICK_SCRIPT % root], env=env, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build a named variant of the library with extra compiler flags, out of tree: bash tools/build_variant2.sh <name> "<flags>" [TUNING=1]
-# -> gpurun_exp/libflacgpu_<name>.so (select it with FLACGPU_LIBRARY=$PWD/gpurun_exp/libflacgpu_<name>.so)
+# -> gpurun_exp/libflacgpu_<name>.so (select it with FLACGPU_ALLOW_LIBRARY_OVERRIDE=1 FLACGPU_LIBRARY=$PWD/gpurun_exp/libflacgpu_<name>.so)
 set -e
 N=$1; F=$2; shift; shift
 D=/tmp/fgvar_$N
