@@ -607,6 +607,9 @@ typedef struct {
     float index_ms;               /* flacgpu_decode_stream_dev: HIP-event time of the frame index pass (part of total_gpu_ms) */
     uint32_t plane_bits;          /* width of the residual plane between the parse and the restore kernel: 16 for streams of up to 16 bits
                                    * (0 where no plane is used); 32 after a frame showed a value beyond 16 bits and the call was repeated */
+    uint32_t generic_frames;      /* frames the wave parser handed to the generic (one lane a frame) decoder: predictor orders above 12,
+                                   * 33-bit subframes, codes of hundreds of bytes, a frame whose part of the residual plane did not fit.
+                                   * Same samples, much slower: a large count on ordinary material is a defect to report */
 } flacgpu_decode_stats;
 
 /* Decode the audio frames of one FLAC stream held in device memory.  d_stream/len: the frame data (device);

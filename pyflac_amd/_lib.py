@@ -83,7 +83,7 @@ class DecodeStats(C.Structure):
     _fields_ = [('nframes', C.c_uint32), ('error_frames', C.c_uint32), ('total_samples', C.c_uint64),
                 ('channels', C.c_uint32), ('bits_per_sample', C.c_uint32), ('sample_rate', C.c_uint32),
                 ('max_blocksize', C.c_uint32), ('decode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float),
-                ('index_ms', C.c_float), ('plane_bits', C.c_uint32)]
+                ('index_ms', C.c_float), ('plane_bits', C.c_uint32), ('generic_frames', C.c_uint32)]
 
 
 ENC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)

@@ -1488,7 +1488,7 @@ fg_export_kernel(uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64 *src0
                 uint32_t status = 1, crcw = 0;
                 if (fr.bytes != 0) { status = w[2 * k]; crcw = w[2 * k + 1]; if (status == 0 && (crcw & 0x80000000u)) status = 2; }
                 if (fr.n != 0) { w[2 * k] = status; w[2 * k + 1] = crcw & 0xFFFFu; }
-                if (status != 0 && status != 3 && fr.n != 0 && fr.channels != 0 && fix_out) {
+                if (status != 0 && status != 3 && fr.n != 0 && fr.channels != 0 && fr.bytes != 0 && fix_out) {       // (bytes == 0: a slot the scan rejected, out_off means nothing)
                     int32_t *o = fix_out + fr.out_off * fr.channels;
                     for (uint32_t j = 0; j < fr.n * fr.channels; j++) o[j] = 0;
                 }

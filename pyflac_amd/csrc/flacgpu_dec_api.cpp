@@ -462,8 +462,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // residual scratch sized by the caller's capacity; not when the planes are handed out (subframe detail).
     const uint32_t C = channels_hint ? channels_hint : 2;
     // (+ one block of the largest size: the parts of the plane are placed at frame number x stride, FgDecSelf)
-    const uint64_t cap_bytes = cap_samples * C * 4 + 256 + 65536ull * C * 4;
-    const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20) + 65536ull * C * 4;
+    // (... and 16 bytes a frame: a frame's part is rounded up to 16 bytes, which adds up when block size x channels is no multiple
+    // of four -- without them the frames behind the point where the sum passes one block's slack all went to the generic decoder)
+    const uint64_t cap_bytes = cap_samples * C * 4 + 256 + 65536ull * C * 4 + (uint64_t)nframes * 16;
+    const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20) + 65536ull * C * 4 + (uint64_t)nframes * 16;
     static const bool self_off = fg_sel("FLACGPU_DEC_SELF") && atoi(fg_sel("FLACGPU_DEC_SELF")) == 0;
     static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 0;
     bool selfstart = lean && queued && index_here && nranges == 0 && !detail && !self_off && crc_late_mode == 0 && c->stream2 != nullptr;
@@ -726,6 +728,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         // frames outside the register-resident decoder's envelope (predictor order > 12, ...) go through the generic kernel
         std::vector<uint32_t> redo;
         for (uint32_t i = 0; i < nframes; i++) if (res[i].err == 3) redo.push_back(i);
+        st->generic_frames = (uint32_t)redo.size();
         if (!redo.empty()) {
             if (!c->dec_redo.ensure(redo.size() * 4)) return false;   // own buffer: `descs` caches the encoder's block list
             if (!HIPOK(hipMemcpyAsync(c->dec_redo.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, c->stream))) return false;

@@ -379,6 +379,25 @@ def test_count_mode_with_frames_shorter_than_any_guess(ctx):
     assert (rows[:3, 0] == 0).all() and (rows[3:] == 0xAAAAAAAA).all()
 
 
+def test_parser_on_its_own_keeps_every_frame_when_the_parts_of_the_plane_are_rounded(ctx):
+    """the parser that starts from the offsets alone places frame f's part of the residual plane at f x stride, the
+    stride rounded up to 16 bytes.  With block size x channels no multiple of four the rounding adds up; the scratch area now has
+    16 bytes a frame for it, so a long stream of odd blocks stays in the wave parser (flacgpu_decode_stats.generic_frames == 0).
+    Before, the frames behind frame ~22 000 of such a stream all went to the generic decoder -- same samples, no sign of it."""
+    import torch
+    from pyflac_amd import batch, synth
+    bs, nfr = 257, 30000
+    n = bs * nfr - 100
+    pcm = synth.config2_stereo16(n / 48000.0 + 0.01, 4)[:n, :1].astype(np.int32)
+    t = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    s = batch.settings(5, 1, 16, 48000, bs)
+    out, offs, st = ctx.encode(s, t)
+    assert st.nblocks == nfr
+    dec, status, dst = ctx.decode_stream(out[:st.total_bytes], 1, 16, n, nframes=nfr)
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec.reshape(-1, 1), t)
+    assert dst.generic_frames == 0
+
+
 class TestResidualPlaneWidth:
     """Round 4: for streams of up to 16 bits the residual plane between the wave parser and the restore kernel is 16 bits wide
     (flac_dec_wave.hip P16; flacgpu_decode_stats.plane_bits).  A frame with a value beyond 16 bits -- a side channel at full scale,
