@@ -47,6 +47,9 @@
 #else
 #define FGX_DBG(v) false
 #endif
+#ifndef FGX_AUTOC_RD2
+#define FGX_AUTOC_RD2 1
+#endif
 #ifndef FGX_MERGE
 // evaluation (<= 16 bit, regular geometry): fixed-predictor sums and the first LPC vector's residual in ONE walk over the samples (the
 // candidate's samples formed once instead of twice: 3 instructions a sample fewer).  Measured slower on the MI355X, 124.4 -> 128.1 us
@@ -84,6 +87,15 @@ template <bool MS, int C> FGI int32_t pcv(int32_t L, int32_t R)
     if (C == 1) return R;
     if (C == 2) return (L + R) >> 1;
     return L - R;
+}
+
+// a pointer the caller knows to be the same in every lane, made so for the compiler too (it then lives in scalar registers and a
+// load takes it as the base beside a 32-bit lane offset)
+template <typename T> FGI const T *uniform_ptr(const T *p)
+{
+    const u64 v = (u64)(uintptr_t)p;
+    const uint32_t lo = rfl((uint32_t)v), hi = rfl((uint32_t)(v >> 32));
+    return (const T *)(uintptr_t)(((u64)hi << 32) | lo);
 }
 
 FGI uint32_t pabs32(int32_t v) { return (uint32_t)(v < 0 ? -v : v); }
@@ -234,7 +246,9 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     LDS double *dbuf = (LDS double *)((LDS unsigned char *)smem + wv * lds_per_wave);   // NC rows of FGP_CSTR doubles
     LDS double *autoc = dbuf + NC * FGP_CSTR;                   // [NC][nvec][MAXO + 1]
     LDS uint32_t *wl = (LDS uint32_t *)(autoc + NC * P.nvec * (MAXO + 1));   // wasted bits per candidate
-    const float *window = windows + d.win_off;
+    // (uniform bases, made so explicitly: the window of this block length and the block's first sample -- see the chunk fetch below)
+    const float *const window = uniform_ptr(windows + d.win_off);
+    const unsigned char *const pcmb = uniform_ptr((const unsigned char *)pcm + d.pcm_off * (NCH == 2 ? (P.pcm_i16 ? 4u : 8u) : (P.pcm_i16 ? 2u : 4u)));
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
     uint32_t orv[NC];
 #pragma unroll
@@ -242,14 +256,14 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     // sample i of the block (both channels)
     auto ldsamp = [&](uint32_t i, int32_t &L, int32_t &R) __attribute__((always_inline)) {
         if (NCH == 2) {
-            if (P.pcm_i16) { const short2 v = ((const short2 *)pcm)[d.pcm_off + i]; L = v.x; R = v.y; }
-            else { const int2 v = ((const int2 *)pcm)[d.pcm_off + i]; L = v.x; R = v.y; }
+            if (P.pcm_i16) { const short2 v = ((const short2 *)pcmb)[i]; L = v.x; R = v.y; }
+            else { const int2 v = ((const int2 *)pcmb)[i]; L = v.x; R = v.y; }
         }
         else {
             // (one channel of an interleaved stream of more channels: the block is a view with a stride, see FgBlockDesc)
-            const u64 at = d.pcm_off + (u64)i * (d.reserved ? d.reserved : 1u);
-            if (P.pcm_i16) L = ((const int16_t *)pcm)[at];
-            else L = ((const int32_t *)pcm)[at];
+            const uint32_t at = i * (d.reserved ? d.reserved : 1u);
+            if (P.pcm_i16) L = ((const int16_t *)pcmb)[at];
+            else L = ((const int32_t *)pcmb)[at];
             R = 0;
         }
     };
@@ -258,7 +272,7 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     // chain the load was meant to travel under: every chunk then waited out two HBM latencies.)  unraw() makes L and R of it at
     // the point of use; zeros stay zeros.
     auto ldraw = [&](uint32_t i, int32_t &a, int32_t &b) __attribute__((always_inline)) {
-        if (NCH == 2 && P.pcm_i16) { a = ((const int32_t *)pcm)[d.pcm_off + i]; b = 0; }
+        if (NCH == 2 && P.pcm_i16) { a = ((const int32_t *)pcmb)[i]; b = 0; }
         else ldsamp(i, a, b);
     };
     auto unraw = [&](int32_t &L, int32_t &R) __attribute__((always_inline)) {
@@ -310,6 +324,24 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                 auto fetch = [&](uint32_t k0) __attribute__((always_inline)) {
                     if (part == 0 && k0 + FGP_CK <= vec_len) {
                         // (the whole block under one window, a full chunk: nearly every call)
+                        // Round 5: the chunk's addresses are a uniform base (scalar registers, made so explicitly) plus the lane's
+                        // offset.  Left to itself the compiler kept a 64-bit pointer per lane, load and loop variant alive across
+                        // the whole kernel -- a dozen vector registers beside the twenty the chain owns -- and spilled 100 bytes a
+                        // lane to scratch: 45 MB written and as much read back per launch of the headline stream.
+                        if (NCH == 2) {
+                            const float *wk = uniform_ptr(window + k0);
+                            if (P.pcm_i16) {
+                                const int32_t *pk = uniform_ptr((const int32_t *)pcmb + k0);
+#pragma unroll
+                                for (int u = 0; u < FGP_CK / 64; u++) { wv[u] = wk[u * 64 + lane]; xl[u] = pk[u * 64 + lane]; xr[u] = 0; }
+                            }
+                            else {
+                                const int2 *pk = uniform_ptr((const int2 *)pcmb + k0);
+#pragma unroll
+                                for (int u = 0; u < FGP_CK / 64; u++) { wv[u] = wk[u * 64 + lane]; const int2 v = pk[u * 64 + lane]; xl[u] = v.x; xr[u] = v.y; }
+                            }
+                            return;
+                        }
 #pragma unroll
                         for (int u = 0; u < FGP_CK / 64; u++) {
                             const uint32_t i = k0 + u * 64 + lane;
@@ -408,8 +440,57 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
 #define FG_RD4(r0, r1, r2, r3, r4, r5, r6, r7, o) \
     "ds_read_b64 v[" #r0 ":" #r1 "], %[ad] offset:" #o "\n\tds_read_b64 v[" #r2 ":" #r3 "], %[ad] offset:" #o "+32\n\t" \
     "ds_read_b64 v[" #r4 ":" #r5 "], %[ad] offset:" #o "+64\n\tds_read_b64 v[" #r6 ":" #r7 "], %[ad] offset:" #o "+96\n\t"
+#define FG_RD2(r0, r1, r2, r3, o) \
+    "ds_read_b64 v[" #r0 ":" #r1 "], %[ad] offset:" #o "\n\tds_read_b64 v[" #r2 ":" #r3 "], %[ad] offset:" #o "+32\n\t"
 #define FG_EVEN(a0, a1) FG_STEP(a0, a1, 56, 57, 58, 59)
 #define FG_ODD(a0, a1) FG_STEP(a0, a1, 58, 59, 56, 57)
+#if FGX_AUTOC_RD2
+                        // (round 5: A of two groups of TWO instructions in flight -- v40..v47 -- instead of two groups of four: eight
+                        // registers fewer are out of the compiler's reach, and the kernel no longer spills -- 100 bytes of scratch a lane
+                        // were 45 MB written and about as much read back per launch)
+                        asm volatile(
+                            "s_mov_b64 vcc, %[m0]\n\t"
+                            "ds_read_b64 v[56:57], %[adb]\n\t"
+                            "s_cmp_eq_u32 %[n4], 0\n\t"
+                            "s_cbranch_scc1 2f\n\t"
+                            FG_RD2(40, 41, 42, 43, 0)
+                            "1:\n\t"
+                            FG_RD2(44, 45, 46, 47, 64)
+                            "s_waitcnt lgkmcnt(2)\n\t"
+                            FG_EVEN(40, 41) FG_ODD(42, 43)
+                            "v_add_u32 %[ad], 0x80, %[ad]\n\t"
+                            "s_sub_u32 %[n4], %[n4], 1\n\t"
+                            "s_cmp_eq_u32 %[n4], 0\n\t"
+                            "s_cbranch_scc1 5f\n\t"
+                            FG_RD2(40, 41, 42, 43, 0)
+                            "s_waitcnt lgkmcnt(2)\n\t"
+                            FG_EVEN(44, 45) FG_ODD(46, 47)
+                            "s_branch 1b\n\t"
+                            "5:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            FG_EVEN(44, 45) FG_ODD(46, 47)
+                            "2:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cmp_eq_u32 %[n1], 0\n\t"
+                            "s_cbranch_scc1 4f\n\t"
+                            "3:\n\t"
+                            "ds_read_b64 v[40:41], %[ad]\n\t"
+                            "v_add_u32 %[ad], 32, %[ad]\n\t"
+                            "s_sub_u32 %[n1], %[n1], 1\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            FG_EVEN(40, 41)
+                            "v_mov_b32 v56, v58\n\t"
+                            "v_mov_b32 v57, v59\n\t"
+                            "s_nop 1\n\t"
+                            "s_cmp_eq_u32 %[n1], 0\n\t"
+                            "s_cbranch_scc0 3b\n\t"
+                            "4:\n\t"
+                            "s_nop 7\n\t"
+                            "s_nop 3"
+                            : [acc] "+v"(acc), [ad] "+v"(ad), [n4] "+s"(n4), [n1] "+s"(n1)
+                            : [adb] "v"(adb), [m0] "s"(m0)
+                            : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v57", "v58", "v59");
+#else
                         asm volatile(
                             "s_mov_b64 vcc, %[m0]\n\t"
                             "ds_read_b64 v[56:57], %[adb]\n\t"
@@ -453,6 +534,8 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
                             : [adb] "v"(adb), [m0] "s"(m0)
                             : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
                               "v54", "v55", "v56", "v57", "v58", "v59");
+#endif
+#undef FG_RD2
 #undef FG_EVEN
 #undef FG_ODD
 #undef FG_RD4
