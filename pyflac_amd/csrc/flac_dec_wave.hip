@@ -580,6 +580,9 @@ fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *fr
 // Replaces fg_dec_restore_kernel (flac_dec_fast.hip: 32 chains per two-wave workgroup, tiles of 192) behind the wave parser;
 // same inputs (residual plane, FgDecSub, parse status + CRC verdict) and the same output contract.
 // Reference path replaced: FLAC__fixed_restore_signal, FLAC__lpc_restore_signal, undo_channel_coding.
+#ifndef FGX_DEC_DOT2
+#define FGX_DEC_DOT2 1             // the 16-bit restore chain through v_dot2_i32_i16 (0: one v_mad_i32_i24 a tap)
+#endif
 #define WR_TS 64
 #define WR_NB 4
 #define WR_FA 12            // words of facts per chain
@@ -868,6 +871,84 @@ __device__ __forceinline__ void wr16_group8_asm(const int32_t (&h)[16], const in
 #undef WR16_ADD
 }
 
+// The same eight steps with the history two samples to a register (round 5): X(k) = (s[k] in the low half, s[k - 1] in the high half),
+// one register per sample, so that step i takes its eight taps as FOUR v_dot2_i32_i16 -- X(i - 1), X(i - 3), X(i - 5), X(i - 7)
+// against the coefficient pairs (q0, q1) .. (q6, q7) -- and makes X(i) with one v_perm_b32: seven instructions a sample where the
+// multiply-add chain takes ten, and this chain is the one thing in the decoder nothing parallelises (4096 steps a block at a lone
+// wave's 4.5 cycles an instruction).  It holds while the SAMPLES fit 16 bits -- left, right and mid of a 16-bit stream always do, a
+// side channel nearly always; the writers look at every sample on its way out, and a frame with a sample beyond 16 bits ends
+// with status 6: the call is repeated with 32-bit planes and the multiply-add chain (flacgpu_dec_api.cpp, dec_p16_hold).
+// xp[1..7] = X(i0 - 7) .. X(i0 - 1) come in, x[0..7] = X(i0) .. X(i0 + 7) and the eight samples n[0..7] go out.
+__device__ __forceinline__ void wr16_group8_dot2_asm(const uint32_t (&xp)[8], const uint32_t (&qq)[4], int shift, uint32_t sel, const uint4 p,
+                                                     int32_t (&n)[8], uint32_t (&x)[8])
+{
+    int32_t t;
+#define WR16_ADD(ni, pj, half) "v_add_u32_sdwa %[" #ni "], sext(%[" #pj "]), %[t] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_" #half " src1_sel:DWORD\n"
+    asm volatile("v_dot2_i32_i16 %[t], %[xp7], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[xp5], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp3], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp1], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n0, p0, 0)
+                 "v_perm_b32 %[x0], %[xp7], %[n0], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x0], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[xp6], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp4], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp2], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n1, p0, 1)
+                 "v_perm_b32 %[x1], %[x0], %[n1], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x1], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[xp7], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp5], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp3], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n2, p1, 0)
+                 "v_perm_b32 %[x2], %[x1], %[n2], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x2], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[x0], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp6], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp4], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n3, p1, 1)
+                 "v_perm_b32 %[x3], %[x2], %[n3], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x3], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[x1], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp7], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp5], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n4, p2, 0)
+                 "v_perm_b32 %[x4], %[x3], %[n4], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x4], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[x2], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[x0], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp6], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n5, p2, 1)
+                 "v_perm_b32 %[x5], %[x4], %[n5], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x5], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[x3], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[x1], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[xp7], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n6, p3, 0)
+                 "v_perm_b32 %[x6], %[x5], %[n6], %[sel]\n"
+                 "v_dot2_i32_i16 %[t], %[x6], %[q01], 0\n"
+                 "v_dot2_i32_i16 %[t], %[x4], %[q23], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[x2], %[q45], %[t]\n"
+                 "v_dot2_i32_i16 %[t], %[x0], %[q67], %[t]\n"
+                 "v_ashrrev_i32 %[t], %[sh], %[t]\n"
+                 WR16_ADD(n7, p3, 1)
+                 "v_perm_b32 %[x7], %[x6], %[n7], %[sel]\n"
+                 : [t] "=&v"(t), [n0] "=&v"(n[0]), [n1] "=&v"(n[1]), [n2] "=&v"(n[2]), [n3] "=&v"(n[3]), [n4] "=&v"(n[4]), [n5] "=&v"(n[5]),
+                   [n6] "=&v"(n[6]), [n7] "=&v"(n[7]), [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]), [x4] "=&v"(x[4]),
+                   [x5] "=&v"(x[5]), [x6] "=&v"(x[6]), [x7] "=&v"(x[7])
+                 : [q01] "v"(qq[0]), [q23] "v"(qq[1]), [q45] "v"(qq[2]), [q67] "v"(qq[3]), [sh] "v"(shift), [sel] "v"(sel),
+                   [xp1] "v"(xp[1]), [xp2] "v"(xp[2]), [xp3] "v"(xp[3]), [xp4] "v"(xp[4]), [xp5] "v"(xp[5]), [xp6] "v"(xp[6]), [xp7] "v"(xp[7]),
+                   [p0] "v"(p.x), [p1] "v"(p.y), [p2] "v"(p.z), [p3] "v"(p.w));
+#undef WR16_ADD
+}
+
 // MAXO samples from sample index i0 of the tile (a multiple of MAXO): residuals from the 16-bit row, samples to the 32-bit row
 template <int MAXO, bool GATE>
 __device__ __forceinline__ void wr16_group(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, uint32_t i0, const char *rin,
@@ -917,6 +998,33 @@ __device__ __forceinline__ void wr16_tile(int32_t (&h)[16], const int32_t (&q)[1
     else if constexpr (MAXO == 8) {
         // the residuals of group g + 1 are requested before group g is computed (one 16-byte read a group)
         uint4 ra = *(const uint4 *)(rin + wr16_goff(0, xr8));
+#if FGX_DEC_DOT2
+        // (the history two samples to a register, wr16_group8_dot2_asm; h[] -- the last eight samples as 32-bit values -- is what the
+        // tiles hand each other)
+        const uint32_t sel = 0x05040100u;
+        auto pk = [](int32_t lo, int32_t hi) -> uint32_t { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); };
+        uint32_t xp[8], qq[4];
+        xp[0] = 0;
+#pragma unroll
+        for (int k = 1; k < 8; k++) xp[k] = pk(h[k], h[k - 1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) qq[k] = pk(q[2 * k], q[2 * k + 1]);
+        int32_t n8[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            uint4 na = ra;
+            if (g < 7) na = *(const uint4 *)(rin + wr16_goff(g + 1, xr8));
+            uint32_t x8[8];
+            wr16_group8_dot2_asm(xp, qq, shift, sel, ra, n8, x8);
+#pragma unroll
+            for (int u = 0; u < 8; u++) xp[u] = x8[u];
+            *(uint4 *)(rout + wr_goff(2 * g, xr)) = make_uint4((uint32_t)n8[0], (uint32_t)n8[1], (uint32_t)n8[2], (uint32_t)n8[3]);
+            *(uint4 *)(rout + wr_goff(2 * g + 1, xr)) = make_uint4((uint32_t)n8[4], (uint32_t)n8[5], (uint32_t)n8[6], (uint32_t)n8[7]);
+            ra = na;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) h[u] = n8[u];
+#else
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             uint4 na = ra;
@@ -929,6 +1037,7 @@ __device__ __forceinline__ void wr16_tile(int32_t (&h)[16], const int32_t (&q)[1
             *(uint4 *)(rout + wr_goff(2 * g + 1, xr)) = make_uint4((uint32_t)n8[4], (uint32_t)n8[5], (uint32_t)n8[6], (uint32_t)n8[7]);
             ra = na;
         }
+#endif
     }
     else {
 #pragma unroll
@@ -1018,6 +1127,8 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     if (wave == 0) {
         const bool big = __any(order > 8), small = !__any(order > 4);
         const uint32_t xr = ((uint32_t)lane & 15) << 4;
+        // (the packed-history chain holds while the samples fit 16 bits: the writers check, ctl[3] tells them to)
+        if (lane == 0) ctl[3] = (P16 && narrow && FGX_DEC_DOT2 && !big && !small) ? 1u : 0u;
         if (P16 && narrow) {
             const uint32_t xr8 = ((uint32_t)lane & 7) << 4;
             for (uint32_t s = 1; s <= S; s++) {
@@ -1128,9 +1239,19 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         w_rn[k] = fm[1]; w_ok[k] = fm[0] != 0; w_cc[k] = fm[6]; w_wa[k] = fm[7]; w_wb[k] = fm[WR_FA + 7];
         w_oo[k] = ((u64)fm[5] << 32) | fm[4];
     }
+    // a sample of a chain (before wasted bits and channel undo) beyond 16 bits while wave 0 runs the packed-history chain: the frame
+    // ends with status 6 and the call is repeated with 32-bit planes and the multiply-add chain (as for a residual beyond 16 bits)
+    auto beyond16 = [&](uint32_t row) __attribute__((always_inline)) {
+        const uint32_t f = blockIdx.x * (64 / C) + row / C;
+        if (f < nframes) {
+            results[f].err = 6;
+            if (host_rows) host_rows[f].err = 6;
+        }
+    };
     auto writeout = [&](uint32_t t) __attribute__((always_inline)) {
         const uint32_t *tb = (P16 && narrow) ? otile + (t & 1) * WR_TILE_W : tiles + (t % WR_NB) * WR_TILE_W;
         const uint32_t i0 = t * WR_TS;
+        const bool chk16 = P16 && ctl[3] != 0;
         if (stereo_fast) {
             // task = (frame pair of rows, group): 32 x 16, four per lane -- always the same four frames, whose facts sit in registers
 #pragma unroll
@@ -1145,6 +1266,12 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                     const uint4 ta = *(const uint4 *)&tb[r0 * WR_TS + ((g ^ (r0 & 15)) << 2)];
                     const uint4 tb4 = *(const uint4 *)&tb[(r0 + 1) * WR_TS + ((g ^ ((r0 + 1) & 15)) << 2)];
                     const uint32_t xa[4] = {ta.x, ta.y, ta.z, ta.w}, xb[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
+                    if (P16) {
+                        uint32_t ov = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (i + e < rn) ov |= (xa[e] + 0x8000u) | (xb[e] + 0x8000u);
+                        if (chk16 && (ov >> 16)) beyond16(r0);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int32_t av = (int32_t)(xa[e] << wa), bv = (int32_t)(xb[e] << wb);
@@ -1206,6 +1333,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                 if (f0[0] != 0) {
                     const uint32_t xa = tb[r0 * WR_TS + ((((col >> 2) ^ (r0 & 15)) << 2) | (col & 3))];
                     const uint32_t xb = tb[(r0 + 1) * WR_TS + ((((col >> 2) ^ ((r0 + 1) & 15)) << 2) | (col & 3))];
+                    if (P16 && chk16 && (((xa + 0x8000u) | (xb + 0x8000u)) >> 16)) beyond16(r0);
                     const uint32_t cc = f0[6], wa = f0[7], wb = f0[WR_FA + 7];
                     const int32_t av = (int32_t)(xa << wa), bv = (int32_t)(xb << wb);
                     const i64 side = WIDE ? (i64)((u64)(i64)(int32_t)xb << wb) : (i64)bv;
@@ -1216,7 +1344,11 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                     v = cch == 0 ? lo : ro;
                 }
             }
-            else if (fm[0] != 0) v = (int32_t)(tb[row * WR_TS + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3))] << fm[7]);
+            else if (fm[0] != 0) {
+                const uint32_t xv = tb[row * WR_TS + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3))];
+                if (P16 && chk16 && ((xv + 0x8000u) >> 16)) beyond16(row);
+                v = (int32_t)(xv << fm[7]);
+            }
             int32_t *o = out + oo * C;
             if (interleave & 1) o[(size_t)i * C + cch] = v;
             else o[(size_t)cch * rn + i] = v;
