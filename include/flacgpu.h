@@ -572,6 +572,8 @@ void flacgpu_set_log_guard(flacgpu_ctx *ctx, double threshold_bits);
  * d_out (sizes by decoupled look-back); 0 = every block hands chunks through HBM to the scan and assembly kernels, as in rounds 2-4.
  * Same bytes either way (tests cross-check the two). */
 void flacgpu_set_direct(flacgpu_ctx *ctx, int on);
+/* (on = 2: direct packing with the evaluation of the candidates inside the same kernel -- blocks of 4096 samples, <= 16 bit: the PCM
+ * is staged and read once for both.  1: direct packing behind a separate evaluation kernel.) */
 /* Window self-check: empty string, or a note that this host's cosf produced a tukey taper different from the committed one
  * (the committed one is then used; the note is also left in flacgpu_last_error() when it happens). */
 const char *flacgpu_window_note(flacgpu_ctx *ctx);

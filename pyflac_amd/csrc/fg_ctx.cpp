@@ -384,7 +384,7 @@ extern "C" void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad)
 }
 extern "C" void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level) { ctx->stage_timing = level < 0 ? 0 : level > 3 ? 3 : level; }
 extern "C" void flacgpu_set_log_guard(flacgpu_ctx *ctx, double thr) { ctx->log_guard_thr = thr; }
-extern "C" void flacgpu_set_direct(flacgpu_ctx *ctx, int on) { ctx->direct = on ? 1 : 0; }
+extern "C" void flacgpu_set_direct(flacgpu_ctx *ctx, int on) { ctx->direct = on < 0 ? 0 : on > 2 ? 2 : on; }
 
 extern "C" int flacgpu_copy_debug(flacgpu_ctx *c, void *dst, uint32_t first, uint32_t n)
 {
@@ -425,7 +425,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         memcpy(key.data(), s, sb);
         if (tb) memcpy(key.data() + sb, streams, tb);
         // (the kernel selection switches -- tuning aids read per call -- decide which blocks count as pipeline blocks: part of the key)
-        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (fg_sel("FLACGPU_NO_FAST") ? 2 : 0) | (view << 4) | (c->direct ? 4 : 0) |
+        key[sb + tb] = (unsigned char)((pcm_is_i16 ? 1 : 0) | (fg_sel("FLACGPU_NO_FAST") ? 2 : 0) | (view << 4) | (c->direct ? 4 : 0) | (c->direct >= 2 ? 128 : 0) |
                                        ((fg_sel("FLACGPU_WS") && atoi(fg_sel("FLACGPU_WS")) == 1) ? 8 : 0));
     }
     const bool reuse = !(s->do_mid_side && s->loose_mid_side) && !c->debug && c->dev_descs_ptr == c->descs.p && c->dev_descs_ptr != nullptr &&
@@ -693,6 +693,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     auto set_direct = [&](bool on) {
         PL.nblocks_direct = on ? nfast - PL.nblocks_rag : 0;        // (the blocks of the regular lane geometry, whether one or two waves pack a subframe)
         PL.side_first = on ? side_first : 0;
+        PL.fused = (on && c->direct >= 2) ? 1u : 0u;
         PL.side_stream = (void *)c->stream3; PL.side_ev = (void *)c->evp[0];
         for (int i = 0; i < 3; i++) PL.gev_eval[i] = (void *)c->gev_eval[i];
         PL.D.lb = (unsigned long long *)c->lb.p; PL.D.offsets = (unsigned long long *)c->offsets.p;

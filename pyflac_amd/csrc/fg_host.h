@@ -126,7 +126,7 @@ struct flacgpu_ctx {
     std::mutex md5_mu;
     DevBuf lb;
     uint32_t lb_epoch = 0;
-    int direct = 1;
+    int direct = 2;            // (2: with the evaluation inside the packing kernel -- flacgpu_set_direct)
     uint32_t desc_side_first = 0, desc_slow_first = 0;         // (cached with the block list: a block that keeps the chunk form / takes the generic kernel lies in front of a direct block)
     hipEvent_t evx[3] = {nullptr, nullptr, nullptr};       // [2]: frame table ready (header pass + scan on the side stream)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

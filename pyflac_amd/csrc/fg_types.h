@@ -195,6 +195,8 @@ struct FgPipeLaunch {
     // direct packing kernels wait for `side_ev`; otherwise they ride at the end of the last group as before.
     uint32_t nblocks_direct;
     uint32_t side_first;
+    uint32_t fused;             // the direct blocks are evaluated inside their packing kernel (fg_pipe_pack_kernel<FUSED>; flacgpu_set_direct(ctx, 2))
+    uint32_t reserved5;
     void *side_stream, *side_ev;
     void *gev_eval[3];          // recorded behind the direct packing kernel of groups 0..2: the one of the next group waits for it
     FgPackDirect D;

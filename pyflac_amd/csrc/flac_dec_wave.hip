@@ -771,6 +771,13 @@ __device__ __forceinline__ void wr_tile(int32_t (&h)[16], const int32_t (&q)[16]
 // (rows 128 bytes apart alternate between the two halves of the banks, the slot picks the place inside a half).  The samples leave
 // the recurrence as 32-bit values in a tile of the usual form (wr_goff), which the writers read.
 #define WR_IN16_W (64 * 32)
+// ring of 16-bit residual tiles: one being computed, WR_R16 - 1 landing.  (Round 5 tried four and five -- the packed-history chain takes
+// a tile in 0.9 us where the multiply-add chain took 1.4, and a trip to the loaded memory system is 2.5 --: decode launch 0.307-0.312 ms
+// with three, four or five, same box.  The loader is not what the kernel waits for.)
+#ifndef WR_R16
+#define WR_R16 3
+#endif
+#define WR_WORDS ((WR_NB * WR_TILE_W) > (WR_R16 * WR_IN16_W + 2 * WR_TILE_W) ? (WR_NB * WR_TILE_W) : (WR_R16 * WR_IN16_W + 2 * WR_TILE_W))
 __device__ __forceinline__ uint32_t wr16_goff(uint32_t g8, uint32_t xr8) { return (g8 << 4) ^ xr8; }      // xr8 = (row & 7) << 4
 __device__ __forceinline__ void wr16_unpack(const uint4 t, int32_t (&r)[8])
 {
@@ -1054,9 +1061,9 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     uint32_t *const tiles = wsm;                                   // WR_NB x 64 rows x 64 words
     // (P16: three tiles of 16-bit residuals -- two landing, one being computed -- and two tiles of samples -- one being computed,
     // one being written out: 56 KB)
-    uint32_t *const in16 = wsm;                                    // 3 x WR_IN16_W
-    uint32_t *const otile = wsm + 3 * WR_IN16_W;                   // 2 x WR_TILE_W
-    uint32_t *const fa = wsm + WR_NB * WR_TILE_W;                  // 64 x WR_FA: n_in, n_out, plane lo/hi, out_off lo/hi, ca, wasted, n
+    uint32_t *const in16 = wsm;                                    // WR_R16 x WR_IN16_W
+    uint32_t *const otile = wsm + WR_R16 * WR_IN16_W;              // 2 x WR_TILE_W
+    uint32_t *const fa = wsm + WR_WORDS;                           // 64 x WR_FA: n_in, n_out, plane lo/hi, out_off lo/hi, ca, wasted, n
     uint32_t *const ctl = fa + 64 * WR_FA;                         // [0] nmax, [1] all planes 16-byte aligned, [2] stereo fast output
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
@@ -1135,7 +1142,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                 __syncthreads();
                 if (s > T) continue;
                 const uint32_t t = s - 1;
-                const char *rin = (const char *)(in16 + (t % 3) * WR_IN16_W + (uint32_t)lane * 32);
+                const char *rin = (const char *)(in16 + (t % WR_R16) * WR_IN16_W + (uint32_t)lane * 32);
                 char *rout = (char *)(otile + (t & 1) * WR_TILE_W + (uint32_t)lane * WR_TS);
                 if (big) wr16_tile<16>(h, q, shift, order, t == 0, rin, rout, xr8, xr);
                 else if (small) wr16_tile<4>(h, q, shift, order, t == 0, rin, rout, xr8, xr);
@@ -1170,7 +1177,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                 rcol[k] = ((((uint32_t)lane & 7) ^ (row & 7)) << 3);
             }
             auto issue = [&](uint32_t t) __attribute__((always_inline)) {
-                uint32_t *tb = in16 + (t % 3) * WR_IN16_W;
+                uint32_t *tb = in16 + (t % WR_R16) * WR_IN16_W;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const uint32_t c0 = t * WR_TS + rcol[k];
@@ -1179,12 +1186,14 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
                                                      (__attribute__((address_space(3))) void *)(tb + 8 * k * 32), 16, 0, 0);
                 }
             };
-            issue(0); issue(1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // (tile s must have landed when barrier s + 1 publishes it: everything but the WR_R16 - 2 tiles requested behind it)
+#pragma unroll
+            for (int t0 = 0; t0 < WR_R16 - 1; t0++) issue((uint32_t)t0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (WR_R16 - 2)) : "memory");
             for (uint32_t s = 1; s <= S; s++) {
                 asm volatile("s_barrier" ::: "memory");
-                issue(s + 1);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                issue(s + WR_R16 - 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (WR_R16 - 2)) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
@@ -1389,7 +1398,7 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     if (fg_tune("FLACGPU_DEC_SKIP")) interleave |= ((uint32_t)atoi(fg_tune("FLACGPU_DEC_SKIP")) & 3u) << 8;     // experiments: 1 no output, 2 no recurrence
     const uint32_t G = 64 / C;
     const dim3 grid((nframes + G - 1) / G);
-    const size_t lds = ((size_t)WR_NB * WR_TILE_W + 64 * WR_FA + 8) * 4;
+    const size_t lds = ((size_t)WR_WORDS + 64 * WR_FA + 8) * 4;
     const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true, false>
                           : (plane16 ? (const void *)fg_dec_wrestore_kernel<false, true> : (const void *)fg_dec_wrestore_kernel<false, false>);
     if (fg_func_set_lds(fn, lds) != 0) return -1;

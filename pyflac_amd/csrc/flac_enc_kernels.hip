@@ -1540,8 +1540,55 @@ fg_md5_streams_kernel(const void *pcm, uint32_t pcm_i16, uint32_t channels, uint
         return pcm_i16 ? (uint32_t)(int32_t)((const int16_t *)pcm)[first + i] : (uint32_t)((const int32_t *)pcm)[first + i];
     };
     const u64 nblocks = (total + 8) / 64 + 1;      // message, the 0x80 byte, zeros, eight bytes of length
+    auto rounds = [&](const uint32_t (&w)[16]) __attribute__((always_inline)) {
+        uint32_t A = a, Bv = b, Cv = c, Dv = d;
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            uint32_t f, g;
+            if (i < 16) { f = (Bv & Cv) | (~Bv & Dv); g = (uint32_t)i; }
+            else if (i < 32) { f = (Dv & Bv) | (~Dv & Cv); g = (5u * i + 1) & 15; }
+            else if (i < 48) { f = Bv ^ Cv ^ Dv; g = (3u * i + 5) & 15; }
+            else { f = Cv ^ (Bv | ~Dv); g = (7u * i) & 15; }
+            const uint32_t x = A + f + K[i] + w[g];
+            const uint32_t r = R[(i >> 4) * 4 + (i & 3)];
+            A = Dv; Dv = Cv; Cv = Bv;
+            Bv = Bv + ((x << r) | (x >> (32 - r)));
+        }
+        a += A; b += Bv; c += Cv; d += Dv;
+    };
+    // The whole 64-byte blocks of 16-bit material in an int32 container -- the batch encoder's input --: 32 values a block, fetched as
+    // eight 16-byte loads, the NEXT block's while this one's 64 rounds run (a lane walks its own stream, so every load is a line of its
+    // own: one value at a time the kernel ran at the latency of a load per value -- 1.9 s for 128 streams of 60 s, 6 MB/s a stream).
+    u64 blk0 = 0;
+    if (nbytes == 2 && !pcm_i16) {
+        struct __attribute__((packed, aligned(4))) V4 { uint32_t v[4]; };
+        const V4 *src = (const V4 *)((const int32_t *)pcm + first);
+        const u64 full = total / 64;
+        V4 cur[8], nxt[8];
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[k] = src[k];
+        }
+        for (u64 blk = 0; blk < full; blk++) {
+            if (blk + 1 < full) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) nxt[k] = src[(blk + 1) * 8 + k];
+            }
+            uint32_t w[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                w[2 * k] = (cur[k].v[0] & 0xFFFFu) | (cur[k].v[1] << 16);
+                w[2 * k + 1] = (cur[k].v[2] & 0xFFFFu) | (cur[k].v[3] << 16);
+            }
+            rounds(w);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+        }
+        blk0 = full;
+        vi = full * 32;
+    }
     bool pad_done = false;
-    for (u64 blk = 0; blk < nblocks; blk++) {
+    for (u64 blk = blk0; blk < nblocks; blk++) {
         uint32_t w[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) {
@@ -1557,20 +1604,7 @@ fg_md5_streams_kernel(const void *pcm, uint32_t pcm_i16, uint32_t channels, uint
             have = have >= 4 ? have - 4 : 0;
         }
         if (blk + 1 == nblocks) { w[14] = (uint32_t)(total * 8); w[15] = (uint32_t)((total * 8) >> 32); }
-        uint32_t A = a, Bv = b, Cv = c, Dv = d;
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-            uint32_t f, g;
-            if (i < 16) { f = (Bv & Cv) | (~Bv & Dv); g = (uint32_t)i; }
-            else if (i < 32) { f = (Dv & Bv) | (~Dv & Cv); g = (5u * i + 1) & 15; }
-            else if (i < 48) { f = Bv ^ Cv ^ Dv; g = (3u * i + 5) & 15; }
-            else { f = Cv ^ (Bv | ~Dv); g = (7u * i) & 15; }
-            const uint32_t x = A + f + K[i] + w[g];
-            const uint32_t r = R[(i >> 4) * 4 + (i & 3)];
-            A = Dv; Dv = Cv; Cv = Bv;
-            Bv = Bv + ((x << r) | (x >> (32 - r)));
-        }
-        a += A; b += Bv; c += Cv; d += Dv;
+        rounds(w);
     }
     out[4 * j] = a; out[4 * j + 1] = b; out[4 * j + 2] = c; out[4 * j + 3] = d;
 }

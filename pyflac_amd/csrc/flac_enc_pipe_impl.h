@@ -2309,7 +2309,11 @@ fg_pipe_publish_kernel(const FgBlockDesc *descs, uint32_t first, uint32_t count,
 // residuals in registers, so behind it nobody needs the samples any more -- 22 KB of LDS a workgroup instead of 39.5, and the
 // registers then allow five workgroups a CU instead of four.  A wave that has to walk its samples a second time (a verbatim
 // subframe, a residual beyond 16 bits, a short block) reads them from memory there: rare, and then slow.
-template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG, bool KEEP = false, bool DIRECT = false, bool ALIAS = false>
+// FUSED (with DIRECT, KEEP and ALIAS): the evaluation of the block's candidates runs in the same workgroup in front of the packing --
+// wave = candidate, as in fg_pipe_eval_kernel --, on ONE staging of the samples in the evaluation's rows (64 rows of n / 64); the
+// packer's lanes then own half rows.  The block's PCM is read once instead of twice and one kernel boundary goes (VERDICT round 4,
+// item 1).  Five workgroups a CU for both parts, where the evaluation alone runs eight.
+template <bool MS, int NCH, int MAXO, bool ACC64, int WS, bool RAG, bool KEEP = false, bool DIRECT = false, bool ALIAS = false, bool FUSED = false>
 #ifndef FGX_ALIAS_WAVES
 #define FGX_ALIAS_WAVES 5
 #endif
@@ -2338,8 +2342,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     // lane geometry (see PipeGeo): ragged blocks are packed by one wave per subframe
     const PipeGeo geo = RAG ? pipe_geo(n, 6, P.max_po, PADE) : pipe_geo_regular(n / LPS, PADE);
     constexpr bool rag = RAG;
-    const uint32_t seg = rag ? geo.base : n / LPS, rstr = geo.rstr;
-    const uint32_t sbytes = ((pipe_rows_elems(P.sig_stride, 64 * WS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
+    // (FUSED: the rows are the evaluation's -- 64 of n / 64 samples, ws lanes of the packer to a row)
+    const PipeGeo geoE = pipe_geo_regular(n >> 6, PADE);
+    const uint32_t seg = rag ? geo.base : n / LPS, rstr = FUSED ? geoE.rstr : geo.rstr;
+    const uint32_t sbytes = ((pipe_rows_elems(P.sig_stride, FUSED ? 64 : 64 * WS) * (uint32_t)sizeof(samp_t)) + 15) & ~15u;
     LDS samp_t *sL = (LDS samp_t *)smem;
     LDS samp_t *sR = (LDS samp_t *)((LDS unsigned char *)smem + sbytes);
     // (DIRECT: ONE window of fbw_words = the whole frame, shared by the waves; behind it the waves' scratch words, the words the waves
@@ -2354,7 +2360,9 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     LDS uint16_t *const ctab = (LDS uint16_t *)(xch + 16);                     // (DIRECT) 1536 entries
     bool pre_ok = true;
     const uint32_t pre = ACC64 ? pipe_preshift<NCH, NC>(P, B, bi, pre_ok) : 0u;
-    (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo, pre);
+    uint32_t stage_bad = 0;
+    if constexpr (FUSED) stage_bad = pipe_stage<NCH, ACC64, NT, false>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, n >> 6, geoE, pre);
+    else (void)pipe_stage<NCH, ACC64, NT, RAG>(pcm, d, P, sL, NCH == 2 ? sR : sL, tid, seg, geo, pre);
     if constexpr (DIRECT) {
         if constexpr (!ALIAS) { for (uint32_t j = tid; j < fbw_words + 2; j += NT) fbw[j] = 0; }
         for (uint32_t j = tid; j < 1536; j += NT) ctab[j] = D.crcx[j];
@@ -2363,6 +2371,15 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     else { for (uint32_t j = lane; j < fbw_words + 2; j += 64) fbw[j] = 0; }
     __syncthreads();
     if (!DIRECT && wv >= (uint32_t)NCH * ws) return;           // (no barrier after this point)
+    if constexpr (FUSED) {
+        // ---- the evaluation (fg_pipe_eval_kernel's body): wave = candidate; its decisions go to B.dec as ever and are read back below
+        if (stage_bad) xch[15] = 1;         // (benign race: every writer stores the same value)
+        __syncthreads();
+        const uint32_t range_err = xch[15] ? FG_ERR_RANGE : 0;
+        if (wv < (uint32_t)NC) pipe_eval_cand<MS, NCH, MAXO, false, false>(NC == 1 ? 0u : wv, d, bi, P, B, results, nullptr, sL, NCH == 2 ? sR : sL, lane, range_err, geoE, 0, true);
+        __threadfence_block();
+        __syncthreads();
+    }
 
     // ---- channel assignment from the four candidate totals (every wave computes it; wave-uniform)
     uint32_t ca = 0, c = si;
@@ -2401,7 +2418,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const uint32_t sb = P.bps + ((MS && c == 3) ? 1u : 0u) - wst;
     const uint32_t mask = sb < 32 ? ((1u << sb) - 1) : 0xFFFFFFFFu;
     const uint32_t Lg = hf * 64 + (uint32_t)lane;         // this lane's segment of the subframe
-    const LDS samp_t *rowL = sL + Lg * rstr, *rowR = sR + Lg * rstr;
+    // (FUSED: ws lanes share one of the evaluation's rows; hoff: where the sample in front of the lane's first one lies, from its row)
+    const LDS samp_t *rowL = FUSED ? sL + (Lg / ws) * rstr + (Lg % ws) * seg : sL + Lg * rstr;
+    const LDS samp_t *rowR = FUSED ? sR + (Lg / ws) * rstr + (Lg % ws) * seg : sR + Lg * rstr;
+    const int hoff = (FUSED && (Lg % ws) != 0) ? -1 : (int)(FUSED ? ws * seg : seg) - 1 - (int)rstr;
     const PipeLane ln = pipe_lane<RAG>(geo, Lg, seg);
     const LDS samp_t *prvL = sL + ln.prow * rstr + ln.plen, *prvR = sR + ln.prow * rstr + ln.plen;      // one past the samples in front
 
@@ -2636,8 +2656,8 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                     if (fromg) x = gcand(Lg * seg - 1u - (uint32_t)j);
                     else if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
                     else {
-                        x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
-                        if (ACC64 && w32) xdh = candd(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                        x = cand(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);
+                        if (ACC64 && w32) xdh = candd(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);
                     }
                 }
                 h[(MAXO - 1 - j) % MAXO] = ACC64 ? ppack(x) : x;
@@ -2754,7 +2774,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
-                if (Lg > 0) x = cand(rowL[(int)seg - 1 - j - (int)rstr], (NCH == 2) ? (int32_t)rowR[(int)seg - 1 - j - (int)rstr] : 0);
+                if (Lg > 0) x = cand(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);
                 h[(MAXO - 1 - j) % MAXO] = x;
             }
             uint32_t len = pstart ? plen : 0u, big = 0;

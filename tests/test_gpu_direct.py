@@ -16,12 +16,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def ctxs():
+@pytest.fixture(scope='module', params=[1, 2], ids=['direct', 'fused'])
+def ctxs(request):
+    """(direct, chunk form).  direct = 1: the packing kernel places its frames behind a separate evaluation kernel; 2: the evaluation
+    runs inside the packing kernel (fg_pipe_pack_kernel<FUSED>, blocks of 4096 samples)."""
     import torch
     from pyflac_amd import batch, _lib
     assert torch.cuda.is_available()
     a, b = batch.Context(0), batch.Context(0)
+    _lib.lib().flacgpu_set_direct(a._h, request.param)
     _lib.lib().flacgpu_set_direct(b._h, 0)
     return a, b
 

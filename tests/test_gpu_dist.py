@@ -41,7 +41,7 @@ def test_two_ranks_on_one_gpu_batch_workload():
     assert len(r['ms_per_step_rank']) == 2 and max(r['ms_per_step_rank']) == pytest.approx(r['ms_per_step'], abs=2e-3)
     # value = the samples of BOTH ranks over the slowest rank's time
     per_rank = 3 * int(2.5 * 48000) * 2
-    assert r['value'] == pytest.approx(per_rank * 2 / (r['ms_per_step'] * 1e-3) / 1e6, rel=1e-3)
+    assert r['value'] == pytest.approx(per_rank * 2 / (r['ms_per_step'] * 1e-3) / 1e6, rel=5e-3)      # (ms_per_step is printed to three decimals)
 
 
 def test_two_ranks_single_stream_workload():
