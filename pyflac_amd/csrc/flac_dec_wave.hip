@@ -32,6 +32,7 @@
 // Reference path replaced: read_subframe_*, read_residual_partitioned_rice_ inside libFLAC (SURVEY.md section 8a row D2,
 // Appendix B; format: /root/reference/pyflac/include/FLAC/format.h:191-396).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -771,11 +772,16 @@ __device__ __forceinline__ void wr_tile(int32_t (&h)[16], const int32_t (&q)[16]
 // (rows 128 bytes apart alternate between the two halves of the banks, the slot picks the place inside a half).  The samples leave
 // the recurrence as 32-bit values in a tile of the usual form (wr_goff), which the writers read.
 #define WR_IN16_W (64 * 32)
-// ring of 16-bit residual tiles: one being computed, WR_R16 - 1 landing.  (Round 5 tried four and five -- the packed-history chain takes
-// a tile in 0.9 us where the multiply-add chain took 1.4, and a trip to the loaded memory system is 2.5 --: decode launch 0.307-0.312 ms
-// with three, four or five, same box.  The loader is not what the kernel waits for.)
+// ring of 16-bit residual tiles: one being computed, WR_R16 - 1 landing (three, four or five: the same decode launch -- the loader is
+// not what the kernel waits for; four, because wr16_chain8 wants an even ring).
+// (timing experiments of the restore kernel -- FLACGPU_DEC_SKIP -- are compiled into tuning builds only)
+#ifdef FG_TUNING
+#define WR_DBG 1
+#else
+#define WR_DBG 0
+#endif
 #ifndef WR_R16
-#define WR_R16 3
+#define WR_R16 4
 #endif
 #define WR_WORDS ((WR_NB * WR_TILE_W) > (WR_R16 * WR_IN16_W + 2 * WR_TILE_W) ? (WR_NB * WR_TILE_W) : (WR_R16 * WR_IN16_W + 2 * WR_TILE_W))
 __device__ __forceinline__ uint32_t wr16_goff(uint32_t g8, uint32_t xr8) { return (g8 << 4) ^ xr8; }      // xr8 = (row & 7) << 4
@@ -1052,6 +1058,79 @@ __device__ __forceinline__ void wr16_tile(int32_t (&h)[16], const int32_t (&q)[1
     }
 }
 
+// One tile of the packed-history chain with the history left packed between tiles: xp[1..7] = X(i0 - 7) .. X(i0 - 1) in and out.
+// ain[g] / aout[j]: this lane's LDS addresses of residual group g and sample quad j in ring slot 0 / output tile 0; in_off and
+// out_off pick the tile.  With constant offsets (wr16_chain8's trips of four tiles) they are the immediates of the LDS instructions:
+// the tile is its 448 chain instructions and 24 LDS instructions, nothing else -- a lone wave pays 2 ns for every instruction, and
+// what the general form (wr16_tile) spends per tile on addresses and on packing and unpacking the history was 0.2 of its 1.3 us.
+__device__ __forceinline__ void wr16_tile8p(uint32_t (&xp)[8], const uint32_t (&qq)[4], int shift, const char *const (&ain)[8], char *const (&aout)[16],
+                                            uint32_t in_off, uint32_t out_off)
+{
+    const uint32_t sel = 0x05040100u;
+    // (requesting the residuals two groups ahead instead of one changes nothing: 0.305 ms either way)
+    uint4 ra = *(const uint4 *)(ain[0] + in_off);
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        uint4 na = ra;
+        if (g < 7) na = *(const uint4 *)(ain[g + 1] + in_off);
+        int32_t n8[8];
+        uint32_t x8[8];
+        wr16_group8_dot2_asm(xp, qq, shift, sel, ra, n8, x8);
+#pragma unroll
+        for (int u = 0; u < 8; u++) xp[u] = x8[u];
+        *(uint4 *)(aout[2 * g] + out_off) = make_uint4((uint32_t)n8[0], (uint32_t)n8[1], (uint32_t)n8[2], (uint32_t)n8[3]);
+        *(uint4 *)(aout[2 * g + 1] + out_off) = make_uint4((uint32_t)n8[4], (uint32_t)n8[5], (uint32_t)n8[6], (uint32_t)n8[7]);
+        ra = na;
+    }
+}
+
+// All steps of the recurrence wave for chains of order 5 .. 8 on 16-bit planes: tile 0 by the general form (its warm-up samples are
+// gated), then trips of WR_R16 tiles with every LDS offset a constant, then what is left.  (WR_R16 is even: the output tile of
+// step s is s & 1.)
+__device__ __forceinline__ void wr16_chain8(int32_t (&h)[16], const int32_t (&q)[16], int shift, uint32_t order, uint32_t T, uint32_t S, uint32_t *in16,
+                                            uint32_t *otile, int lane, bool report)
+{
+    unsigned long long tb0 = 0, tbar = 0;
+    const unsigned long long tall = WR_DBG ? wall_clock64() : 0;
+#define WR_BARRIER() do { if (WR_DBG) tb0 = wall_clock64(); __syncthreads(); if (WR_DBG) tbar += wall_clock64() - tb0; } while (0)
+    static_assert((WR_R16 & 1) == 0 && WR_R16 >= 4, "wr16_chain8: an even ring of at least four tiles");
+    const uint32_t xr = ((uint32_t)lane & 15) << 4, xr8 = ((uint32_t)lane & 7) << 4;
+    WR_BARRIER();
+    if (T == 0) return;
+    wr16_tile<8>(h, q, shift, order, true, (const char *)(in16 + (uint32_t)lane * 32), (char *)(otile + (uint32_t)lane * WR_TS), xr8, xr);
+    auto pk = [](int32_t lo, int32_t hi) -> uint32_t { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); };
+    uint32_t xp[8], qq[4];
+    xp[0] = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) xp[k] = pk(h[k], h[k - 1]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) qq[k] = pk(q[2 * k], q[2 * k + 1]);
+    const char *ain[8];
+    char *aout[16];
+#pragma unroll
+    for (int g = 0; g < 8; g++) ain[g] = (const char *)(in16 + (uint32_t)lane * 32) + wr16_goff((uint32_t)g, xr8);
+#pragma unroll
+    for (int j = 0; j < 16; j++) aout[j] = (char *)(otile + (uint32_t)lane * WR_TS) + wr_goff((uint32_t)j, xr);
+    uint32_t s = 2;
+    // (a trip: steps s .. s + WR_R16 - 1 with s = 2 mod WR_R16, i.e. tiles 1, 2, .. of the ring's slots 1, 2, .., 0)
+    for (; s + WR_R16 - 1 <= T; s += WR_R16) {
+#pragma unroll
+        for (int k = 0; k < WR_R16; k++) {
+            WR_BARRIER();
+            wr16_tile8p(xp, qq, shift, ain, aout, (uint32_t)((1 + k) % WR_R16) * (WR_IN16_W * 4), (uint32_t)((1 + k) & 1) * (WR_TILE_W * 4));
+        }
+    }
+    for (; s <= S; s++) {
+        WR_BARRIER();
+        if (s > T) continue;
+        const uint32_t t = s - 1;
+        wr16_tile8p(xp, qq, shift, ain, aout, (t % WR_R16) * (WR_IN16_W * 4), (t & 1) * (WR_TILE_W * 4));
+    }
+    if (WR_DBG && report && blockIdx.x == 100 && lane == 0)
+        printf("restore wg 100 chain wave: %u steps, %llu ticks of 10 ns, %llu of them at barriers\n", S, wall_clock64() - tall, tbar);
+#undef WR_BARRIER
+}
+
 template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256)
 fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
@@ -1064,7 +1143,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     uint32_t *const in16 = wsm;                                    // WR_R16 x WR_IN16_W
     uint32_t *const otile = wsm + WR_R16 * WR_IN16_W;              // 2 x WR_TILE_W
     uint32_t *const fa = wsm + WR_WORDS;                           // 64 x WR_FA: n_in, n_out, plane lo/hi, out_off lo/hi, ca, wasted, n
-    uint32_t *const ctl = fa + 64 * WR_FA;                         // [0] nmax, [1] all planes 16-byte aligned, [2] stereo fast output
+    uint32_t *const ctl = fa + 64 * WR_FA;                         // [0] nmax, [1] all planes 16-byte aligned, [2] stereo fast output, [3] 16-bit check, [4] regular, [5] wasted bits somewhere
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     // whole frames per workgroup: G = 64 / C frames, lanes G C .. 63 idle (a frame's status is merged by the workgroup that owns it)
@@ -1109,7 +1188,13 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
         // stereo fast output (decided per frame by the writers): C == 2 and a 16-byte aligned output base
         const bool so = C == 2 && (((uintptr_t)out) & 15) == 0;
-        if (lane == 0) { ctl[0] = nmax; ctl[1] = 1u; ctl[2] = so ? 1u : 0u; }
+        // every frame of the workgroup there, good, of the same length, at an even place: the writers' tiles in front of the last one
+        // need no test per sample (ctl[4])
+        const bool reg = n_in == nmax && n_out == nmax && (out_off & 1) == 0 && ((interleave & 1) || (nmax & 3) == 0);
+        const bool allreg = so && G * C == 64 && __all(mine && reg) && !WIDE;
+        // (the packed-history chain holds while the samples fit 16 bits: the writers check, ctl[3] tells them to)
+        const bool dot2 = P16 && FGX_DEC_DOT2 && !__any(order > 8) && __any(order > 4);
+        if (lane == 0) { ctl[0] = nmax; ctl[1] = 1u; ctl[2] = so ? 1u : 0u; ctl[3] = dot2 ? 1u : 0u; ctl[4] = allreg ? 1u : 0u; ctl[5] = __any(wasted != 0) ? 1u : 0u; }
     }
     __syncthreads();
     // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])
@@ -1134,13 +1219,20 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     if (wave == 0) {
         const bool big = __any(order > 8), small = !__any(order > 4);
         const uint32_t xr = ((uint32_t)lane & 15) << 4;
-        // (the packed-history chain holds while the samples fit 16 bits: the writers check, ctl[3] tells them to)
-        if (lane == 0) ctl[3] = (P16 && narrow && FGX_DEC_DOT2 && !big && !small) ? 1u : 0u;
+        if (P16 && narrow && FGX_DEC_DOT2 && !big && !small && !(WR_DBG && (interleave & 0x200))) {
+            wr16_chain8(h, q, shift, order, T, S, in16, otile, lane, (interleave & 0x2000) != 0);
+            return;
+        }
         if (P16 && narrow) {
             const uint32_t xr8 = ((uint32_t)lane & 7) << 4;
+            unsigned long long tb0 = 0, tbar = 0, tall = WR_DBG ? wall_clock64() : 0;
             for (uint32_t s = 1; s <= S; s++) {
+                if (WR_DBG) tb0 = wall_clock64();
                 __syncthreads();
-                if (s > T) continue;
+                if (WR_DBG) tbar += wall_clock64() - tb0;
+                if (WR_DBG && s == S && (interleave & 0x2000) && blockIdx.x == 100 && lane == 0)
+                    printf("restore wg 100 chain wave: %u steps, %llu ticks of 10 ns, %llu of them at barriers\n", S, wall_clock64() - tall, tbar);
+                if (s > T || (WR_DBG && (interleave & 0x200))) continue;
                 const uint32_t t = s - 1;
                 const char *rin = (const char *)(in16 + (t % WR_R16) * WR_IN16_W + (uint32_t)lane * 32);
                 char *rout = (char *)(otile + (t & 1) * WR_TILE_W + (uint32_t)lane * WR_TS);
@@ -1152,7 +1244,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         }
         for (uint32_t s = 1; s <= S; s++) {
             __syncthreads();
-            if (s > T || (interleave & 0x200)) continue;
+            if (s > T || (WR_DBG && (interleave & 0x200))) continue;
             const uint32_t t = s - 1;
             char *rowb = (char *)(tiles + (t % WR_NB) * WR_TILE_W + (uint32_t)lane * WR_TS);
             if (big) wr_tile<16, WIDE>(h, q, shift, order, t == 0, rowb, xr);
@@ -1190,11 +1282,18 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
 #pragma unroll
             for (int t0 = 0; t0 < WR_R16 - 1; t0++) issue((uint32_t)t0);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (WR_R16 - 2)) : "memory");
+            unsigned long long tb0 = 0, tbar = 0, tw0 = 0, twait = 0, tall = WR_DBG ? wall_clock64() : 0;
             for (uint32_t s = 1; s <= S; s++) {
+                if (WR_DBG) tb0 = wall_clock64();
                 asm volatile("s_barrier" ::: "memory");
+                if (WR_DBG) tbar += wall_clock64() - tb0;
                 issue(s + WR_R16 - 2);
+                if (WR_DBG) tw0 = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (WR_R16 - 2)) : "memory");
+                if (WR_DBG) twait += wall_clock64() - tw0;
             }
+            if (WR_DBG && (interleave & 0x2000) && blockIdx.x == 100 && lane == 0)
+                printf("restore wg 100 loader: %llu ticks, %llu at barriers, %llu waiting for tiles\n", wall_clock64() - tall, tbar, twait);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
         }
@@ -1257,10 +1356,89 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
             if (host_rows) host_rows[f].err = 6;
         }
     };
+    const bool whole = ctl[4] != 0, anywaste = ctl[5] != 0, chk16w = P16 && ctl[3] != 0;
+    auto writeout_whole = [&](uint32_t t, auto ILV, auto WASTE) __attribute__((always_inline)) {
+        {
+            const uint32_t *tb = (P16 && narrow) ? otile + (t & 1) * WR_TILE_W : tiles + (t % WR_NB) * WR_TILE_W;
+            const uint32_t i0 = t * WR_TS;
+            // a tile of whole groups of regular stereo frames (all but the last tile of nearly every workgroup): nothing to test
+            // per sample, all eight LDS reads of the lane's four tasks requested before the first is looked at (nothing else runs
+            // on this SIMD to hide them), one range verdict for the four, and the channel undo with the assignment's facts as lane
+            // constants -- mid/side: left = a + ((b + 1) >> 1), right = a - (b >> 1)  [= ((2a | (b & 1)) +- b) >> 1: 2a is even];
+            // in all four assignments left = a + k23 * ((b + k3) >> k3), right = k13 * a + sg * (b >> k3)
+            uint4 ta[4], tb4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t id = (uint32_t)k * 128 + ml;
+                const uint32_t r0 = (id >> 4) * 2, g = id & 15;
+                ta[k] = make_uint4(g, g, g, g); tb4[k] = ta[k];
+                if (!WR_DBG || !(interleave & 0x1000)) {
+                    ta[k] = *(const uint4 *)&tb[r0 * WR_TS + ((g ^ (r0 & 15)) << 2)];
+                    tb4[k] = *(const uint4 *)&tb[(r0 + 1) * WR_TS + ((g ^ ((r0 + 1) & 15)) << 2)];
+                }
+            }
+            uint32_t ov = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + (ml & 15) * 4;
+                uint32_t xa[4] = {ta[k].x, ta[k].y, ta[k].z, ta[k].w}, xb[4] = {tb4[k].x, tb4[k].y, tb4[k].z, tb4[k].w};
+                if (P16) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ov |= (xa[e] + 0x8000u) | (xb[e] + 0x8000u);
+                }
+                if (decltype(WASTE)::value) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { xa[e] <<= w_wa[k]; xb[e] <<= w_wb[k]; }
+                }
+                const uint32_t cc = w_cc[k];
+                const int32_t k3 = cc == 3 ? 1 : 0, k23 = cc >= 2 ? 1 : 0, k13 = (int32_t)(cc & 1), sg = k13 ? -1 : 1;
+                int32_t a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int32_t av = (int32_t)xa[e], bv = (int32_t)xb[e];
+                    const int32_t up = (bv + k3) >> k3, dn = bv >> k3;
+                    if (P16) {
+                        // (streams of up to 16 bits: every value here has at most 17)
+                        a[e] = av + __mul24(up, k23);
+                        b[e] = __mul24(av, k13) + __mul24(dn, sg);
+                    }
+                    else {
+                        a[e] = av + (k23 ? up : 0);
+                        b[e] = k13 ? av - dn : bv;
+                    }
+                }
+                int32_t *o = out + w_oo[k] * 2;
+                if (WR_DBG && (interleave & 0x400)) {
+                    // (experiment: everything but the stores)
+                    asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(o));
+                    continue;
+                }
+                if (decltype(ILV)::value) {
+                    int4 *d = (int4 *)(o + (size_t)i * 2);
+                    d[0] = make_int4(a[0], b[0], a[1], b[1]);
+                    d[1] = make_int4(a[2], b[2], a[3], b[3]);
+                }
+                else {
+                    *(int4 *)(o + i) = make_int4(a[0], a[1], a[2], a[3]);
+                    *(int4 *)(o + nmax + i) = make_int4(b[0], b[1], b[2], b[3]);
+                }
+            }
+            // (a value beyond 16 bits anywhere sends the whole call to the 32-bit planes: which of the lane's four frames says so
+            // does not matter)
+            if (P16 && chk16w && (ov >> 16)) beyond16((ml >> 4) * 2);
+        }
+    };
     auto writeout = [&](uint32_t t) __attribute__((always_inline)) {
         const uint32_t *tb = (P16 && narrow) ? otile + (t & 1) * WR_TILE_W : tiles + (t % WR_NB) * WR_TILE_W;
         const uint32_t i0 = t * WR_TS;
         const bool chk16 = P16 && ctl[3] != 0;
+        if (!WIDE && whole && i0 + WR_TS <= nmax) {
+            // (the output form decided outside: a lone wave pays for every branch, taken or not, with an instruction fetch nothing hides)
+            if (anywaste) { if (interleave & 1) writeout_whole(t, std::true_type(), std::true_type()); else writeout_whole(t, std::false_type(), std::true_type()); }
+            else if (interleave & 1) writeout_whole(t, std::true_type(), std::false_type());
+            else writeout_whole(t, std::false_type(), std::false_type());
+            return;
+        }
         if (stereo_fast) {
             // task = (frame pair of rows, group): 32 x 16, four per lane -- always the same four frames, whose facts sit in registers
 #pragma unroll
@@ -1364,10 +1542,15 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         }
     };
     // (tile T - 1 is computed in step T and leaves in step S = T + 1)
+    unsigned long long tb0 = 0, tbar = 0, tall = WR_DBG ? wall_clock64() : 0;
     for (uint32_t s = 1; s <= S; s++) {
+        if (WR_DBG) tb0 = wall_clock64();
         __syncthreads();
-        if (s >= 2 && !(interleave & 0x100)) writeout(s - 2);
+        if (WR_DBG) tbar += wall_clock64() - tb0;
+        if (s >= 2 && !(WR_DBG && (interleave & 0x100))) writeout(s - 2);
     }
+    if (WR_DBG && (interleave & 0x2000) && blockIdx.x == 100 && ml == 0)
+        printf("restore wg 100 writer: %llu ticks, %llu at barriers\n", wall_clock64() - tall, tbar);
 }
 
 }  // namespace
@@ -1395,7 +1578,11 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
     if (C > 64) return -1;
-    if (fg_tune("FLACGPU_DEC_SKIP")) interleave |= ((uint32_t)atoi(fg_tune("FLACGPU_DEC_SKIP")) & 3u) << 8;     // experiments: 1 no output, 2 no recurrence
+    if (fg_tune("FLACGPU_DEC_SKIP")) {
+        // experiments: 1 no output, 2 no recurrence, 4 the writers without their stores, 8 the writers without their LDS reads
+        const uint32_t v = (uint32_t)atoi(fg_tune("FLACGPU_DEC_SKIP"));
+        interleave |= ((v & 7u) << 8) | ((v & 8u) ? 0x1000u : 0u) | ((v & 16u) ? 0x2000u : 0u);       // 16: where the waves of one workgroup wait
+    }
     const uint32_t G = 64 / C;
     const dim3 grid((nframes + G - 1) / G);
     const size_t lds = ((size_t)WR_WORDS + 64 * WR_FA + 8) * 4;

@@ -2499,6 +2499,11 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     pipe_cand_coef(MS, c, cca, ccb, ccs);
     const uint32_t csh = (wraw & 0x100u) ? ccs : ccs + wst - pre;
     auto cand = [&](int32_t l, int32_t r) -> int32_t { return pipe_cand(l, r, cca, ccb, csh); };
+    // (the walks: candidate = (a + cb b) >> shift with the rows picked per candidate, as in the evaluation -- a select fewer a sample)
+    const bool cplain = !MS || c < 2;
+    const int32_t cvb = cplain ? 0 : ccb;
+    const LDS samp_t *const rowA = (NCH == 2 && c == 1) ? rowR : rowL, *const rowB = cplain ? rowA : rowR;
+    auto cand2 = [&](int32_t a, int32_t b) __attribute__((always_inline)) -> int32_t { return (a + __mul24(b, cvb)) >> csh; };
     // (true 32-bit content, pipe_eval_cand_w32: the candidate's samples as doubles -- up to 33 bits -- instead of 24-bit integer forms)
     const bool w32 = ACC64 && !RAG && P.bps == 32 && !pre_ok;
     const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);
@@ -2656,7 +2661,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                     if (fromg) x = gcand(Lg * seg - 1u - (uint32_t)j);
                     else if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
                     else {
-                        x = cand(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);
+                        x = cand2(rowA[hoff - j], rowB[hoff - j]);
                         if (ACC64 && w32) xdh = candd(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);
                     }
                 }
@@ -2693,7 +2698,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
             }
             const uint32_t kmask = (1u << kr) - 1, kone = 1u << kr;
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
-                const int32_t x = fromg ? gcand(Lg * seg + s) : cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
+                const int32_t x = fromg ? gcand(Lg * seg + s) : cand2(rowA[s], rowB[s]);
                 uint32_t val, vb, lead, topv = 0, topb = 0;          // (topv / topb: the 33rd bit of a verbatim sample of a 33-bit side channel)
                 if (verb) {
                     if (ACC64 && w32) {
@@ -2774,14 +2779,14 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
-                if (Lg > 0) x = cand(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);
+                if (Lg > 0) x = cand2(rowA[hoff - j], rowB[hoff - j]);
                 h[(MAXO - 1 - j) % MAXO] = x;
             }
             uint32_t len = pstart ? plen : 0u, big = 0;
 #pragma unroll
             for (int s = 0; s < 32; s++) {
                 const int u = s % MAXO;
-                const int32_t x = cand(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0);
+                const int32_t x = cand2(rowA[s], rowB[s]);
                 const int32_t res = x - (pfir24<MAXO>(q, h, u) >> shift);
                 h[u] = x;
                 uint32_t uu = ((uint32_t)res << 1) ^ (uint32_t)(res >> 31);
