@@ -215,7 +215,7 @@ extern "C" void flacgpu_ctx_destroy(flacgpu_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->descs, &c->slots, &c->results, &c->dbg, &c->crctab, &c->windows, &c->offsets, &c->scratch_pcm,
-                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_poff, &c->dec_hrec, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_rparams, &c->dec_warm, &c->dec_ranges, &c->pipe,
+                      &c->scratch_out, &c->dec_frames, &c->dec_results, &c->dec_scratch, &c->dec_subs, &c->dec_poff, &c->dec_hrec, &c->dec_prof, &c->dec_redo, &c->dec_info, &c->dec_off, &c->dec_rparams, &c->dec_warm, &c->dec_ranges, &c->pipe,
                       &c->mc_tmp, &c->mc_offs, &c->mc_map, &c->mc_sizes, &c->mc_res, &c->mc_foffs};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pin) (void)hipHostFree(c->h_pin);

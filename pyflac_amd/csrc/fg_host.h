@@ -66,7 +66,7 @@ int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len
                           unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream, int write_err);
 int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                         uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec);
+                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec, unsigned long long *d_stamp);
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
@@ -112,6 +112,9 @@ struct WindowEntry {
 struct flacgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // the decoder's index tables as the last call left them: emptied for `idx_clean_n` frames behind its end-of-call signal (0: not)
+    uint32_t idx_clean_n = 0;
+    void *idx_clean_off = nullptr, *idx_clean_info = nullptr;
     uint32_t dec_p16_hold = 0;       // decode calls that still take 32-bit residual planes (a stream showed values beyond 16 bits)
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
     hipStream_t stream3 = nullptr;   // short blocks of the pipeline's packing stage
@@ -142,7 +145,7 @@ struct flacgpu_ctx {
     double log_guard_thr = 1e-6;
     std::recursive_mutex mu;    // (the batch entry points nest: streams of more than two channels run the one-channel encode inside)
     DevBuf descs, slots, results, dbg, crctab, windows, offsets, scratch_pcm, scratch_out, dec_frames, dec_results,
-        dec_scratch, dec_subs, dec_poff, dec_hrec, dec_prof, dec_redo, dec_info, dec_rparams, dec_warm, dec_ranges, pipe,
+        dec_scratch, dec_subs, dec_poff, dec_hrec, dec_prof, dec_redo, dec_info, dec_off, dec_rparams, dec_warm, dec_ranges, pipe,
         mc_tmp, mc_offs, mc_map, mc_sizes, mc_res, mc_foffs,   // streams of more than two channels (fg_ctx.cpp encode_multichannel)
         md5_jobs;
     const uint32_t *last_chunk_bits = nullptr;   // the pipeline's chunk bit counts of the last encode call (device), or null

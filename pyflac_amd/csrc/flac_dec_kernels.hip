@@ -459,8 +459,10 @@ __device__ __forceinline__ bool fg_idx_header(const Bytes &p, u64 avail, uint32_
 
 __global__ void __launch_bounds__(256)
 fg_dec_index_kernel(const uint8_t *stream, u64 len, uint32_t channels, uint32_t bps, u64 first_number, uint32_t nframes, u64 *offsets,
-                    unsigned long long *info, u64 *alt, const FgDecRange *ranges, uint32_t nranges)
+                    unsigned long long *info, u64 *alt, const FgDecRange *ranges, uint32_t nranges, u64 *stamp)
 {
+    // (stamp: the start-of-call wall-clock stamp when this is the call's first kernel -- the tables were left empty by the last call)
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[0] = wall_clock64();
     // groups of 16 bytes aligned in memory (one 16-byte load per lane and step); a wave walks the stream in steps of
     // gridDim.x * 4 KiB (launching one short-lived wave per KiB would be bound by the dispatch rate, not by HBM)
     const uintptr_t sa = (uintptr_t)stream;
@@ -922,7 +924,7 @@ extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned 
 
 extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                                    uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec)
+                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec, unsigned long long *d_stamp)
 {
     if (len == 0) return 0;
     // (every lane takes four groups a step; at most 8 workgroups of 4 waves per CU -- every wave slot of the chip, once --
@@ -933,7 +935,7 @@ extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long l
     unsigned long long wgs = (need + steps - 1) / steps;
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(fg_dec_index_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, d_stream, (u64)len, channels, bps,
-                       (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt, d_ranges, nranges);
+                       (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt, d_ranges, nranges, (u64 *)d_stamp);
     if (nframes)
         hipLaunchKernelGGL(fg_dec_index_resolve_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (const u64 *)d_alt,
                            nframes, (u64)len, d_info, d_stream, d_hdrrec);

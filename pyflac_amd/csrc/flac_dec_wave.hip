@@ -1192,9 +1192,10 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         // need no test per sample (ctl[4])
         const bool reg = n_in == nmax && n_out == nmax && (out_off & 1) == 0 && ((interleave & 1) || (nmax & 3) == 0);
         const bool allreg = so && G * C == 64 && __all(mine && reg) && !WIDE;
+        const bool anyw = __any(wasted != 0);
         // (the packed-history chain holds while the samples fit 16 bits: the writers check, ctl[3] tells them to)
         const bool dot2 = P16 && FGX_DEC_DOT2 && !__any(order > 8) && __any(order > 4);
-        if (lane == 0) { ctl[0] = nmax; ctl[1] = 1u; ctl[2] = so ? 1u : 0u; ctl[3] = dot2 ? 1u : 0u; ctl[4] = allreg ? 1u : 0u; ctl[5] = __any(wasted != 0) ? 1u : 0u; }
+        if (lane == 0) { ctl[0] = nmax; ctl[1] = 1u; ctl[2] = so ? 1u : 0u; ctl[3] = dot2 ? 1u : 0u; ctl[4] = allreg ? 1u : 0u; ctl[5] = anyw ? 1u : 0u; }
     }
     __syncthreads();
     // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])

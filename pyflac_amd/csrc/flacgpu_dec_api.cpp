@@ -394,6 +394,9 @@ struct DecDetail {
 
 // h_offsets == nullptr: the frame index is made on the device from the bytes (fg_dec_index_kernel); nframes is then the
 // number of frames the stream is known to hold (STREAMINFO: total samples / block size), or 0 to have them counted first.
+#ifndef FG_NO_DEFER_INIT
+#define FG_NO_DEFER_INIT 0
+#endif
 static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
                                uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
                                FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
@@ -411,9 +414,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         if (!c->dec_info.ensure(64)) return false;
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
         if (nframes == 0) {
+            c->idx_clean_n = 0;
             // count the candidates (an upper bound of the frames; false candidates are a handful), then see which slots fill
             if (!HIPOK(hipMemsetAsync(d_info, 0, 64, c->stream)) ||
-                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, nullptr, 0, c->stream, nullptr) != 0 ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, 0, nullptr, d_info, nullptr, nullptr, 0, c->stream, nullptr, nullptr) != 0 ||
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 64, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
@@ -424,11 +428,12 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             if (want > 0x7FFFFFFFull) { fg_set_error("too many frames"); return false; }
             const uint32_t bound = (uint32_t)want;
             if (bound == 0) { st->nframes = 0; return true; }
-            if (!c->offsets.ensure(((size_t)bound + 4) * 8)) return false;
+            c->idx_clean_n = 0;
+            if (!c->dec_off.ensure(((size_t)bound + 4) * 8)) return false;
             if (!c->dec_info.ensure(64 + (size_t)bound * 12 + 16)) return false;       // counters, second claims, claim counts
             d_info = (unsigned long long *)c->dec_info.p;
-            if (fg_launch_dec_index_init((unsigned long long *)c->offsets.p, d_info + 8, d_info, bound, nullptr, c->stream) != 0 ||
-                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->offsets.p, d_info, d_info + 8, nullptr, 0, c->stream, nullptr) != 0 ||
+            if (fg_launch_dec_index_init((unsigned long long *)c->dec_off.p, d_info + 8, d_info, bound, nullptr, c->stream) != 0 ||
+                fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, bound, (unsigned long long *)c->dec_off.p, d_info, d_info + 8, nullptr, 0, c->stream, nullptr, nullptr) != 0 ||
                 !HIPOK(hipMemcpyAsync(hinfo, d_info, 32, hipMemcpyDeviceToHost, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
                 fg_set_error("frame index kernel failed"); return false;
             }
@@ -441,9 +446,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (channels_hint == 0) { fg_set_error("channel count required"); return false; }
     const uint32_t npad = (nframes + 63) & ~63u;
     if (!c->dec_frames.ensure((size_t)npad * sizeof(FgDecFrame)) || !c->dec_results.ensure((size_t)npad * sizeof(FgDecResult)) ||
-        !c->offsets.ensure(((size_t)nframes + 1 + fg_dec_scan_words(nframes)) * 8))
+        !c->dec_off.ensure(((size_t)nframes + 1 + fg_dec_scan_words(nframes)) * 8))
         return false;
-    unsigned long long *d_off = (unsigned long long *)c->offsets.p;
+    unsigned long long *d_off = (unsigned long long *)c->dec_off.p;
+    if (!index_here) c->idx_clean_n = 0;        // (the caller's offsets go into the table)
     unsigned long long *d_tot = d_off + nframes + 1;
     // end of call and timing as in the encoder (fg_ctx.cpp): level 0 = stamp kernel in front, export kernel at the end (status
     // words, totals and stamps into pinned memory, the host polls a sequence number), no events; levels 1, 2 = HIP events
@@ -486,8 +492,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                 !HIPOK(hipMemcpyAsync(c->dec_ranges.p, h_ranges, (size_t)nranges * sizeof(FgDecRange), hipMemcpyHostToDevice, c->stream))) return false;
             d_ranges = (const FgDecRange *)c->dec_ranges.p;
         }
-        if (fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, lean ? (unsigned long long *)c->stamp.p : nullptr, c->stream) != 0 ||
-            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, d_ranges, nranges, c->stream, d_hrec) != 0) {
+        // The tables the index pass files its claims in are emptied by the call that used them last, BEHIND its end-of-call signal
+        // (below): a call that finds them as that call left them starts with the index pass itself (its first workgroup takes the
+        // start-of-call stamp) -- the init kernel and the turn-around behind it were 7 us in front of every decode launch.
+        const bool tables_clean = c->idx_clean_n == nframes && c->idx_clean_off == (void *)d_off && c->idx_clean_info == (void *)d_info;
+        c->idx_clean_n = 0;
+        unsigned long long *const d_stamp = lean ? (unsigned long long *)c->stamp.p : nullptr;
+        if ((!tables_clean && fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, d_stamp, c->stream) != 0) ||
+            fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, d_ranges, nranges, c->stream, d_hrec,
+                                tables_clean ? d_stamp : nullptr) != 0) {
             fg_set_error("frame index kernel launch failed"); return false;
         }
         // (the end of the last frame, offsets[nframes] = len, is set by the index kernel)
@@ -691,6 +704,10 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                                index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
                                fix_in_export ? (const FgDecFrame *)c->dec_frames.p : nullptr, fix_in_export ? (int32_t *)d_pcm : nullptr);
         if (lrc != 0 || !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
+        // (the index tables for the next call of this shape: emptied behind the signal, while the host is on its way back)
+        if (index_here && !FG_NO_DEFER_INIT && fg_launch_dec_index_init(d_off, (unsigned long long *)c->dec_info.p + 8, (unsigned long long *)c->dec_info.p, nframes, nullptr, c->stream) == 0) {
+            c->idx_clean_n = nframes; c->idx_clean_off = (void *)d_off; c->idx_clean_info = c->dec_info.p;
+        }
         tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
         for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
     }

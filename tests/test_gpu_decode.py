@@ -452,6 +452,38 @@ class TestResidualPlaneWidth:
             assert dst.plane_bits == 16
 
 
+@pytest.mark.parametrize('level,bs', [(1, 1152), (3, 576), (5, 4096), (8, 4096)])
+def test_wasted_bits_and_every_channel_assignment_in_whole_regular_tiles(ctx, level, bs):
+    """Workgroups of 32 whole stereo frames take the restore kernel's form without a test per sample (round 5): wasted bits in SOME
+    frames and channels only (the shift is decided per workgroup), all four channel assignments (left/right, left/side, right/side,
+    mid/side), the last workgroup ragged; with the encoder's index and from the bytes alone."""
+    import torch
+    from pyflac_amd import batch, synth
+    n = bs * 70 + 333
+    pcm = synth.config2_stereo16(n / 48000.0 + 0.01, 5)[:n].astype(np.int32)
+    r = np.random.default_rng(7)
+    for f in range(0, 70):
+        a, b = f * bs, (f + 1) * bs
+        k = f % 7
+        if k == 1: pcm[a:b, 0] = (pcm[a:b, 0] >> 2) << 2                     # wasted bits in the left channel
+        elif k == 2: pcm[a:b, 1] = (pcm[a:b, 1] >> 3) << 3                   # ... in the right one
+        elif k == 3: pcm[a:b] = (pcm[a:b] >> 1) << 1                         # ... in both
+        elif k == 4: pcm[a:b, 1] = pcm[a:b, 0] + r.integers(-3, 4, b - a)    # nearly equal channels: a side channel pays
+        elif k == 5: pcm[a:b, 1] = -pcm[a:b, 0]                              # opposite channels: mid is nearly nothing
+        elif k == 6:                                                         # isolated impulses (wasted bits in a sparse signal)
+            pcm[a:b] = 0
+            pcm[a + r.integers(0, bs, 5), :] = (r.integers(-8000, 8000, (5, 1)) << 2)
+    pcm = np.clip(pcm, -32768, 32767)
+    s = batch.settings(level, 2, 16, 48000, bs, False)
+    t = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    out, offs, est = ctx.encode(s, t)
+    data = out[:est.total_bytes].clone()
+    dec, status, dst = ctx.decode_stream(data, 2, 16, n, nframes=est.nblocks)
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec, t)
+    dec, status, dst = ctx.decode(data, offs, 2, 16, n)
+    assert int(status[:, 0].max()) == 0 and torch.equal(dec.reshape(-1, 2), t)
+
+
 _SELF_SCRIPT = r'''
 import sys, hashlib, json
 import numpy as np, torch
