@@ -1677,7 +1677,11 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 #pragma unroll
                 for (int j = 0; j < MAXO; j++) qd[j] = __hiloint2double((int)rl((uint32_t)__double2hiint(qdl), j), (int)rl((uint32_t)__double2loint(qdl), j));
             }
-            psum = 0;
+            // (fp64 forms: the walk runs WITHOUT the running maximum first -- a lane whose sum of |residual| stays below 2^31 holds no
+            // residual that reaches it, and that is every lane of every block of ordinary material; only when a sum gets there the walk is
+            // repeated with the maximum: one instruction of eighteen a sample and window)
+            auto walk = [&](auto TRACK) __attribute__((always_inline)) {
+            psum = 0; psumd = 0.0; pmaxd = 0.0;
 #pragma unroll
             for (int j = 0; j < MAXO; j++) {
                 int32_t x = 0;
@@ -1701,7 +1705,7 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                     // (qd carries the scaling; the chain starts at -x: what comes out of the floor is minus the residual, pfir_f64n)
                     const double xd = (double)x;
                     const double rr = __builtin_floor(pfir_f64n<MAXO>(qd, hd, u, -xd));
-                    if (real) { psumd += __builtin_fabs(rr); pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
+                    if (real) { psumd += __builtin_fabs(rr); if (decltype(TRACK)::value) pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
                     res = 0;
                     hd[u] = xd;
                 }
@@ -1736,6 +1740,12 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
                 for (int u = 0; u < MAXO; u++) if (s0 + u < ln.len) step(u, s0 + u, s0 == 0);
                 if (!ln.act) { psum = 0; ovf = 0; psumd = 0.0; pmaxd = 0.0; }
             }
+            };
+            if constexpr (FGP_F64 && ACC64) {
+                walk(std::false_type());
+                if (__any(!(psumd < 2147483648.0))) walk(std::true_type());
+            }
+            else walk(std::true_type());
             if constexpr (FGP_F64 && ACC64) {
                 if (!(pmaxd < 2147483648.0)) ovf = 1;
                 psum = ovf ? (sum_t)0 : (sum_t)psumd;
@@ -2014,14 +2024,17 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
                 q[j] = (int32_t)rl((uint32_t)qall, j);
                 qd[j] = __hiloint2double((int)rl((uint32_t)__double2hiint(qdl), j), (int)rl((uint32_t)__double2loint(qdl), j));
             }
+            double psumd = 0.0, pmaxd = 0.0;
+            // (without the running maximum first, as in pipe_eval_cand)
+            auto walk = [&](auto TRACK) __attribute__((always_inline)) {
+            psumd = 0.0; pmaxd = 0.0;
 #pragma unroll
             for (int j = 0; j < MAXO; j++) hd[(MAXO - 1 - j) % MAXO] = lane > 0 ? hsamp(1 + j) : 0.0;
-            double psumd = 0.0, pmaxd = 0.0;
             auto step = [&](int u, uint32_t s, bool guard) __attribute__((always_inline)) {
                 const double xd = samp((int)s);
                 const bool real = !guard || lane > 0 || s >= order;
                 const double rr = __builtin_floor(pfir_f64n<MAXO>(qd, hd, u, -xd));          // (minus the residual)
-                if (real) { psumd += __builtin_fabs(rr); pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
+                if (real) { psumd += __builtin_fabs(rr); if (decltype(TRACK)::value) pmaxd = __builtin_fmax(pmaxd, __builtin_fabs(rr)); }
                 hd[u] = xd;
             };
             uint32_t s0 = 0;
@@ -2037,6 +2050,9 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             }
 #pragma unroll
             for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+            };
+            walk(std::false_type());
+            if (__any(!(psumd < 2147483648.0))) walk(std::true_type());
             // (a residual must fit int32: libFLAC's test is r <= INT32_MIN || r > INT32_MAX, i.e. |r| < 2^31 passes)
             if (!(pmaxd < 2147483648.0)) ovf = 1;
             psum = ovf ? 0ull : (u64)psumd;
