@@ -78,7 +78,10 @@ int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const 
                             unsigned long long *d_counters, hipStream_t stream, int plane16, const FgDecSelf *self);
 int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                               const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                              hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff);
+                              hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff,
+                              unsigned long long *d_join = nullptr, unsigned long long epoch = 0);
+int fg_launch_dec_gate(const unsigned long long *d_gate, unsigned long long epoch, unsigned long long *d_err, hipStream_t stream);
+int fg_launch_dec_raise(unsigned long long *d_word, unsigned long long epoch, hipStream_t stream);
 int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                            int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
                            int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream);
@@ -115,6 +118,8 @@ struct flacgpu_ctx {
     // the decoder's index tables as the last call left them: emptied for `idx_clean_n` frames behind its end-of-call signal (0: not)
     uint32_t idx_clean_n = 0;
     void *idx_clean_off = nullptr, *idx_clean_info = nullptr;
+    unsigned long long gate_epoch = 0;      // the decode launch's fork / join words (FgDecSelf.gate): one epoch a call
+    bool gate_off = false;                  // a wait on them timed out once: events from then on
     uint32_t dec_p16_hold = 0;       // decode calls that still take 32-bit residual planes (a stream showed values beyond 16 bits)
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
     hipStream_t stream3 = nullptr;   // short blocks of the pipeline's packing stage

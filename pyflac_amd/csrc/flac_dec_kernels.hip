@@ -382,7 +382,8 @@ __device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 s
 {
     // the index may come from the device (the index kernel leaves ~0 in the slot of a frame it did not find; a caller's table
     // is not looked at by the host): nothing is read through an offset that does not lie inside the stream
-    const u64 o0 = offsets[f], o1 = offsets[f + 1];
+    // (agent-scope loads: this kernel may have been let go by a word in memory, not by an event the runtime knows of -- FgDecSelf.gate)
+    const u64 o0 = __hip_atomic_load(&offsets[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), o1 = __hip_atomic_load(&offsets[f + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool inside = o0 < stream_len && o1 <= stream_len && o1 > o0 && o1 - o0 < 0x7FFFFFFFull;
     const uint8_t *p = stream + (inside ? o0 : 0);
     const uint32_t len = inside ? (uint32_t)(o1 - o0) : 0;
@@ -912,8 +913,36 @@ __global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long l
     if (k == 0 && stamp) stamp[0] = wall_clock64();
     if (k <= nframes) offsets[k] = ~(u64)0;
     if (k < nframes) { alt[k] = 0; ((uint32_t *)(alt + nframes))[k] = 0; }
-    if (k < 4) info[k] = 0;
+    if (k < 6) info[k] = 0;          // (the four counters, the count pass's maximum, the gate's timeout word)
 }
+// The fork and the join of the decode launch through words in memory instead of events (round 5; flacgpu_dec_api.cpp): a one-wave
+// kernel in front of a side stream's work that waits until the parser -- queued behind the resolve kernel on the main stream --
+// has raised gate[0] to the call's epoch, and a one-thread kernel behind the side streams' work that raises join[0] for the restore
+// kernel.  The wait is bounded (FG_GATE_TICKS): a timeout lands in err[0] and the host repeats the call with events.
+__global__ void fg_dec_gate_kernel(const unsigned long long *gate, unsigned long long epoch, unsigned long long *err)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        if (wall_clock64() - t0 > FG_GATE_TICKS) { atomicOr(err, 1ull); break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+__global__ void fg_dec_raise_kernel(unsigned long long *word, unsigned long long epoch)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" int fg_launch_dec_gate(const unsigned long long *d_gate, unsigned long long epoch, unsigned long long *d_err, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_dec_gate_kernel, dim3(1), dim3(64), 0, stream, d_gate, epoch, d_err);
+    return (int)hipGetLastError();
+}
+extern "C" int fg_launch_dec_raise(unsigned long long *d_word, unsigned long long epoch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_dec_raise_kernel, dim3(1), dim3(64), 0, stream, d_word, epoch);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned long long *d_alt, unsigned long long *d_info, uint32_t nframes,
                                         unsigned long long *d_stamp, hipStream_t stream)
 {

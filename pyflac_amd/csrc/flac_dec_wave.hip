@@ -156,6 +156,8 @@ __global__ void __launch_bounds__(256, 8)
 fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch,
                      FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters, FgDecSelf SF)
 {
+    // (FgDecSelf.gate: this kernel is queued behind the resolve kernel, so its start says that the offsets are settled)
+    if (SF.gate && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(SF.gate, SF.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __shared__ uint32_t lds[4 * WP_WAVE_W];
     const int lane = threadIdx.x & 63;
     uint32_t *const rows = lds + (threadIdx.x >> 6) * WP_WAVE_W;
@@ -1134,7 +1136,8 @@ __device__ __forceinline__ void wr16_chain8(int32_t (&h)[16], const int32_t (&q)
 template <bool WIDE, bool P16>
 __global__ void __launch_bounds__(256)
 fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, const FgDecSub *subs, const int32_t *scratch,
-                       int32_t *out, FgDecResult *results, uint32_t interleave, FgDecResult *host_rows, const unsigned long long *planeoff)
+                       int32_t *out, FgDecResult *results, uint32_t interleave, FgDecResult *host_rows, const unsigned long long *planeoff,
+                       unsigned long long *join, unsigned long long epoch)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
     uint32_t *const tiles = wsm;                                   // WR_NB x 64 rows x 64 words
@@ -1155,6 +1158,18 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     uint32_t order = 0;
     int shift = 0;
     if (wave == 0) {
+        // (join: header pass, scan and CRC pass ran beside the parser on streams of their own and the main stream did not wait for
+        // them -- a wait is 5 us of idle GPU in front of this kernel.  Their last kernel raised join[0] to this call's epoch; it has
+        // by the time the parser ends, so this loop does not turn.  Behind it the frame table and the verdicts are read for the first
+        // time by this workgroup: what it reads is what those kernels left when they ended.  join[-2] collects a timeout.)
+        if (join) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+                if (wall_clock64() - t0 > FG_GATE_TICKS) { if (lane == 0) atomicOr(join - 2, 2ull); break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
         // ---- facts of this chain (and the CRC verdict merged into the frame status, as fg_dec_restore_kernel does)
         uint32_t n = 0, status = 1, ca = 0, wasted = 0;
         u64 out_off = 0;
@@ -1564,7 +1579,7 @@ extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_
     if (nframes == 0) return 0;
     const dim3 grid((nframes + 3) / 4);
     FgDecSelf SF;
-    if (self) SF = *self; else { SF.offsets = nullptr; SF.hdrrec = nullptr; SF.planeoff = nullptr; SF.plane_cap_bytes = 0; SF.si_bps = 0; SF.reserved = 0; }
+    if (self) SF = *self; else { SF.offsets = nullptr; SF.hdrrec = nullptr; SF.planeoff = nullptr; SF.plane_cap_bytes = 0; SF.si_bps = 0; SF.reserved = 0; SF.gate = nullptr; SF.epoch = 0; }
     if (wide) hipLaunchKernelGGL((fg_dec_wparse_kernel<true, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
     else if (plane16) hipLaunchKernelGGL((fg_dec_wparse_kernel<false, true>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
     else hipLaunchKernelGGL((fg_dec_wparse_kernel<false, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
@@ -1574,7 +1589,8 @@ extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_
 // Same contract as fg_launch_decode_finish (flac_dec_fast.hip), without the profile words.
 extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const int32_t *d_scratch,
                                          const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
-                                         hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff)
+                                         hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff,
+                                         unsigned long long *d_join, unsigned long long epoch)
 {
     if (nframes == 0) return 0;
     const uint32_t C = channels ? channels : 1;
@@ -1590,8 +1606,8 @@ extern "C" int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nf
     const void *fn = wide ? (const void *)fg_dec_wrestore_kernel<true, false>
                           : (plane16 ? (const void *)fg_dec_wrestore_kernel<false, true> : (const void *)fg_dec_wrestore_kernel<false, false>);
     if (fg_func_set_lds(fn, lds) != 0) return -1;
-    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff);
-    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff);
-    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff);
+    if (wide) hipLaunchKernelGGL((fg_dec_wrestore_kernel<true, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff, d_join, (u64)epoch);
+    else if (plane16) hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, true>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff, d_join, (u64)epoch);
+    else hipLaunchKernelGGL((fg_dec_wrestore_kernel<false, false>), grid, dim3(256), lds, stream, d_frames, nframes, C, d_subs, d_scratch, d_pcm, d_results, interleave, h_rows, d_planeoff, d_join, (u64)epoch);
     return (int)hipGetLastError();
 }

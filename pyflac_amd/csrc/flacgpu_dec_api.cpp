@@ -483,8 +483,11 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     }
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
+        const void *const info_was = c->dec_info.p;
         if (!c->dec_info.ensure(64 + (size_t)nframes * 12 + 16)) return false;      // counters, second claims, claim counts
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
+        // (a new buffer: the fork / join words behind the counters must not hold anything that looks like an epoch)
+        if (c->dec_info.p != info_was && (!HIPOK(hipMemsetAsync(d_info, 0, 64, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream)))) return false;
         const FgDecRange *d_ranges = nullptr;
         if (nranges) {
             // several streams in one buffer: every stream files its frames from its own slot on
@@ -514,10 +517,16 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // pass took the wave slots the parser needs to have all its frames resident at once, and the host's calls for the side
     // streams sat between the index pass and the parser.
     hipStream_t hstream = c->stream;
+    bool use_gate = false;
+    unsigned long long gate_epoch = 0;
     if (selfstart) {
         hstream = c->gstream[0] ? c->gstream[0] : c->stream2;
-        selfstart = HIPOK(hipEventRecord(c->evx[0], c->stream));
-        if (!selfstart) hstream = c->stream;
+        // (round 5: no event on the main stream between the resolve kernel and the parser -- the side streams' kernels are let go by
+        // a word the parser raises, FgDecSelf.gate; FLACGPU_DEC_GATE=0 in a test-hooks build keeps the events)
+        static const bool gate_sel_off = fg_sel("FLACGPU_DEC_GATE") && atoi(fg_sel("FLACGPU_DEC_GATE")) == 0;
+        use_gate = !gate_sel_off && !c->gate_off && index_here;
+        if (!use_gate) selfstart = HIPOK(hipEventRecord(c->evx[0], c->stream));
+        if (!selfstart) { hstream = c->stream; use_gate = false; }
     }
     if (!selfstart && fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                                             (FgDecResult *)c->dec_results.p, d_tot, cap_samples, c->stream, 1) != 0) {
@@ -608,6 +617,13 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             FgDecSelf self;
             self.offsets = d_off; self.hdrrec = d_hrec; self.planeoff = d_poff; self.plane_cap_bytes = c->dec_scratch.cap;
             self.si_bps = bps_hint; self.reserved = 0;
+            unsigned long long *const d_gw = (unsigned long long *)c->dec_info.p;       // [5] timeouts, [6] fork word, [7] join word
+            if (use_gate) gate_epoch = ++c->gate_epoch;
+            self.gate = use_gate ? d_gw + 6 : nullptr; self.epoch = gate_epoch;
+            // (test hook, FLACGPU_DEC_GATE=2 in a test-hooks build: the parser does not raise the word -- the side streams' waits time
+            // out, the call is repeated with events and the context keeps them)
+            static const bool gate_sel_mute = fg_sel("FLACGPU_DEC_GATE") && atoi(fg_sel("FLACGPU_DEC_GATE")) == 2;
+            if (gate_sel_mute) self.gate = nullptr;
             if (wave_parse >= 2 && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
             if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
                                         (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16,
@@ -619,17 +635,18 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                 // offsets) on another; the restore kernel reads the frame table and the verdicts and waits for both
                 // (one wait in front of the restore kernel, not two: the header stream waits for the CRC stream's event before it
                 // records its own -- every wait on the main stream is some 5 us of idle GPU)
-                if (!HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0)) ||
+                if (!(use_gate ? fg_launch_dec_gate(d_gw + 6, gate_epoch, d_gw + 5, c->stream2) == 0 : HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0))) ||
                     fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
                                          (const uint16_t *)c->crctab.p, c->stream2, d_off, len) != 0 ||
                     !HIPOK(hipEventRecord(c->evx[1], c->stream2))) { fg_set_error("decode kernel launch failed"); return false; }
-                if (!HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0)) ||
+                if (!(use_gate ? fg_launch_dec_gate(d_gw + 6, gate_epoch, d_gw + 5, hstream) == 0 : HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0))) ||
                     fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                                           (FgDecResult *)c->dec_results.p, d_tot, cap_samples, hstream, 0) != 0 ||
                     (hstream != c->stream2 && !HIPOK(hipStreamWaitEvent(hstream, c->evx[1], 0))) ||
-                    !HIPOK(hipEventRecord(c->evx[2], hstream))) { fg_set_error("header kernel launch failed"); return false; }
+                    !(use_gate ? fg_launch_dec_raise(d_gw + 7, gate_epoch, hstream) == 0 : HIPOK(hipEventRecord(c->evx[2], hstream)))) { fg_set_error("header kernel launch failed"); return false; }
                 forked = false;            // (evx[2] stands for both)
-                if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[2], 0))) return false;
+                // (with the gate the restore kernel looks at the join word itself: no wait on the main stream)
+                if (!use_gate && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[2], 0))) return false;
             }
             if (d_cnt) {
                 unsigned long long hc[3] = {0, 0, 0};
@@ -648,7 +665,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             rows_sent = lean && !late;
             if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
                                           (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream, plane16,
-                                          rows_sent ? h_rows_pinned : nullptr, selfstart ? d_poff : nullptr) != 0) {
+                                          rows_sent ? h_rows_pinned : nullptr, selfstart ? d_poff : nullptr,
+                                          use_gate ? (unsigned long long *)c->dec_info.p + 7 : nullptr, gate_epoch) != 0) {
                 fg_set_error("decode kernel launch failed"); return false;
             }
             if (late) {
@@ -698,7 +716,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         const unsigned long long seq = ++c->sig_seq;
         if (ev2 && !HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
         const int lrc = rows_sent
-            ? fg_launch_signal(d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr, index_here ? 4 : 0,
+            ? fg_launch_signal(d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr, index_here ? 6 : 0,
                                (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream)
             : fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
                                index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
@@ -710,6 +728,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         }
         tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
         for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
+        if (use_gate && rows_sent && c->h_sig[9] != 0) {
+            // a wait on the fork or the join word timed out (never seen; a side stream starved for 0.2 s): what this call decoded is
+            // not to be trusted -- once more, and from now on, with events
+            c->gate_off = true;
+            if (HIPOK(hipStreamSynchronize(c->stream2)) && HIPOK(hipStreamSynchronize(hstream)) && HIPOK(hipStreamSynchronize(c->stream)))
+                return decode_frames_impl(c, d_stream, len, h_offsets, nframes, channels_hint, bps_hint, d_pcm, cap_samples, interleave, h_status, h_frames, st,
+                                          offsets_on_device, first_number, d_offsets_out, detail, status_capacity, h_ranges, nranges);
+            fg_set_error("decode kernel failed"); return false;
+        }
     }
     else {
         if (queued && !HIPOK(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, c->stream))) return false;

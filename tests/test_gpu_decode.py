@@ -523,3 +523,20 @@ def test_parser_on_its_own_equals_parser_behind_the_header_pass():
         outs.append(json.loads(line[7:]))
     assert outs[0] == outs[1]
     assert any(any(x != 0 for x in case[1]) for case in outs[0])         # (the damaged streams do report something)
+
+
+def test_fork_and_join_through_words_in_memory_equal_the_events_and_survive_a_timeout():
+    """Round 5 (FgDecSelf.gate): the side streams of a decode launch are let go by a word the parser raises, and the restore kernel
+    looks at the word their last kernel raises -- no event record or wait on the main stream.  Same samples and status words as with
+    the events (FLACGPU_DEC_GATE=0, test-hooks build, a child process each); and with the parser's word muted (FLACGPU_DEC_GATE=2) the
+    bounded waits time out, the call is repeated with events and still returns the same."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ('1', '0', '2'):
+        env = dict(os.environ, FLACGPU_DEC_GATE=v, PYFLAC_AMD_TESTHOOKS='1')
+        p = subprocess.run([sys.executable, '-c', _SELF_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
+        outs.append(json.loads(line[7:]))
+    assert outs[0] == outs[1] == outs[2]
