@@ -66,7 +66,8 @@ int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long stream_len
                           unsigned long long *d_totals, unsigned long long cap_samples, hipStream_t stream, int write_err);
 int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                         uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec, unsigned long long *d_stamp);
+                        const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec, unsigned long long *d_stamp,
+                        unsigned long long *d_gate = nullptr, unsigned long long epoch = 0);
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
@@ -80,7 +81,6 @@ int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint
                               const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results, uint32_t interleave, int wide,
                               hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff,
                               unsigned long long *d_join = nullptr, unsigned long long epoch = 0);
-int fg_launch_dec_gate(const unsigned long long *d_gate, unsigned long long epoch, unsigned long long *d_err, hipStream_t stream);
 int fg_launch_dec_raise(unsigned long long *d_word, unsigned long long epoch, hipStream_t stream);
 int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                            int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
@@ -118,7 +118,7 @@ struct flacgpu_ctx {
     // the decoder's index tables as the last call left them: emptied for `idx_clean_n` frames behind its end-of-call signal (0: not)
     uint32_t idx_clean_n = 0;
     void *idx_clean_off = nullptr, *idx_clean_info = nullptr;
-    unsigned long long gate_epoch = 0;      // the decode launch's fork / join words (FgDecSelf.gate): one epoch a call
+    unsigned long long gate_epoch = 0;      // the decode launch's fork / join words (flacgpu_dec_api.cpp decode_frames_impl): one epoch a call
     bool gate_off = false;                  // a wait on them timed out once: events from then on
     uint32_t dec_p16_hold = 0;       // decode calls that still take 32-bit residual planes (a stream showed values beyond 16 bits)
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel

@@ -244,10 +244,6 @@ struct FgDecSelf {
     unsigned long long plane_cap_bytes;
     uint32_t si_bps;                       // STREAMINFO's, or 0
     uint32_t reserved;
-    // round 5: the fork behind the index pass without an event on the main stream -- the parser, the first kernel that stream order
-    // puts behind the resolve kernel, raises gate[0] to `epoch`; fg_dec_gate_kernel in front of the side streams' kernels waits for it
-    unsigned long long *gate;              // or null: the side streams wait for an event
-    unsigned long long epoch;
 };
 
 // how long a wave waits for a word another kernel raises before it gives up and flags the call (wall clock, 100 MHz): 0.2 s

@@ -246,7 +246,7 @@ fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfra
     uint32_t fb;
     u64 boff;
     if (offsets) {
-        // (agent-scope loads, as in the header pass: FgDecSelf.gate)
+        // (agent-scope loads, as in the header pass)
         const u64 o0 = __hip_atomic_load(&offsets[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), o1 = __hip_atomic_load(&offsets[f + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool inside = o0 < stream_len && o1 <= stream_len && o1 > o0 && o1 - o0 < 0x7FFFFFFFull;
         fb = inside ? (uint32_t)(o1 - o0) : 0; boff = inside ? o0 : 0;

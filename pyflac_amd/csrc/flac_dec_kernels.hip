@@ -382,7 +382,7 @@ __device__ __forceinline__ void fg_dec_parse_header(const uint8_t *stream, u64 s
 {
     // the index may come from the device (the index kernel leaves ~0 in the slot of a frame it did not find; a caller's table
     // is not looked at by the host): nothing is read through an offset that does not lie inside the stream
-    // (agent-scope loads: this kernel may have been let go by a word in memory, not by an event the runtime knows of -- FgDecSelf.gate)
+    // (agent-scope loads: this kernel may have been let go by a word in memory, not by an event the runtime knows of: the fork of the decode launch, flacgpu_dec_api.cpp)
     const u64 o0 = __hip_atomic_load(&offsets[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), o1 = __hip_atomic_load(&offsets[f + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool inside = o0 < stream_len && o1 <= stream_len && o1 > o0 && o1 - o0 < 0x7FFFFFFFull;
     const uint8_t *p = stream + (inside ? o0 : 0);
@@ -859,8 +859,15 @@ extern "C" int fg_launch_dec_headers(const uint8_t *d_stream, unsigned long long
 // start from the offsets alone (FgDecSelf); 0 for an empty or a contested slot.  The index pass has checked the header, CRC-8
 // included, when it filed the claim: the fields are read again here, the length rules wait for the parser (it knows the length).
 __global__ void __launch_bounds__(256)
-fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 len, unsigned long long *info, const uint8_t *stream, uint32_t *hdrrec)
+fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 len, unsigned long long *info, const uint8_t *stream, uint32_t *hdrrec,
+                            unsigned long long *gate, unsigned long long epoch)
 {
+    // (gate, round 5: the fork of the decode launch without an event on the main stream -- the workgroup of this kernel that ends
+    // last raises gate[0], a word in the host's pinned memory, to the call's epoch; the host, which has queued the parser behind this
+    // kernel, queues the side streams' kernels when it sees it (flacgpu_dec_api.cpp).  The ticket is the upper half of info[4]; it
+    // wraps to zero with the last workgroup.  What the side streams' kernels read of this kernel's work is the offsets, with
+    // agent-scope loads: the index pass put them there with atomics, and the one store this kernel adds goes through to memory
+    // before its workgroup takes the ticket.  The header records are the parser's, behind the kernel's end.)
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t *cnt = (const uint32_t *)(alt + nframes);       // claims per slot
     // info[3] = highest slot filled + 1 (one atomic per wave)
@@ -870,7 +877,7 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)top, o); top = t > top ? t : top; }
         if ((threadIdx.x & 63) == 0 && top) atomicMax(&info[3], (unsigned long long)top);
     }
-    if (k >= nframes) return;
+    if (k < nframes) {
     u64 fin = offsets[k];
     bool contested = false;
     const uint32_t c = cnt[k];
@@ -886,7 +893,12 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
                 else {
                     const bool aok = (k == 0 || a > lo) && a < hi, bok = (k == 0 || b > lo) && b < hi;
                     if (aok == bok) { atomicAdd(&info[1], 1ull); contested = true; }
-                    else if (bok) { offsets[k] = b; fin = b; }
+                    else if (bok) {
+                        // (the one store of this kernel the side streams' kernels read: through to memory, and there before the ticket)
+                        __hip_atomic_store(&offsets[k], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __threadfence();
+                        fin = b;
+                    }
                 }
             }
         }
@@ -902,6 +914,14 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
         }
         hdrrec[k] = rec;
     }
+    }
+    if (gate) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t *ticket = (uint32_t *)(info + 4) + 1;
+            if (atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1) __hip_atomic_store(gate, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // offsets[0 .. nframes] empty (all ones: identity of the minimum), alt[0 .. nframes) zero (identity of the maximum), the claim
@@ -915,27 +935,12 @@ __global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long l
     if (k < nframes) { alt[k] = 0; ((uint32_t *)(alt + nframes))[k] = 0; }
     if (k < 6) info[k] = 0;          // (the four counters, the count pass's maximum, the gate's timeout word)
 }
-// The fork and the join of the decode launch through words in memory instead of events (round 5; flacgpu_dec_api.cpp): a one-wave
-// kernel in front of a side stream's work that waits until the parser -- queued behind the resolve kernel on the main stream --
-// has raised gate[0] to the call's epoch, and a one-thread kernel behind the side streams' work that raises join[0] for the restore
-// kernel.  The wait is bounded (FG_GATE_TICKS): a timeout lands in err[0] and the host repeats the call with events.
-__global__ void fg_dec_gate_kernel(const unsigned long long *gate, unsigned long long epoch, unsigned long long *err)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-        if (wall_clock64() - t0 > FG_GATE_TICKS) { atomicOr(err, 1ull); break; }
-        __builtin_amdgcn_s_sleep(32);
-    }
-}
+// The join of the decode launch through a word in memory instead of an event (round 5; flacgpu_dec_api.cpp): a one-thread kernel
+// behind the side streams' work raises join[0] to the call's epoch, and the restore kernel looks at it before it reads what that
+// work left (flac_dec_wave.hip).
 __global__ void fg_dec_raise_kernel(unsigned long long *word, unsigned long long epoch)
 {
     if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-extern "C" int fg_launch_dec_gate(const unsigned long long *d_gate, unsigned long long epoch, unsigned long long *d_err, hipStream_t stream)
-{
-    hipLaunchKernelGGL(fg_dec_gate_kernel, dim3(1), dim3(64), 0, stream, d_gate, epoch, d_err);
-    return (int)hipGetLastError();
 }
 extern "C" int fg_launch_dec_raise(unsigned long long *d_word, unsigned long long epoch, hipStream_t stream)
 {
@@ -953,7 +958,8 @@ extern "C" int fg_launch_dec_index_init(unsigned long long *d_offsets, unsigned 
 
 extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_t channels, uint32_t bps, unsigned long long first_number,
                                    uint32_t nframes, unsigned long long *d_offsets, unsigned long long *d_info, unsigned long long *d_alt,
-                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec, unsigned long long *d_stamp)
+                                   const FgDecRange *d_ranges, uint32_t nranges, hipStream_t stream, uint32_t *d_hdrrec, unsigned long long *d_stamp,
+                                   unsigned long long *d_gate, unsigned long long epoch)
 {
     if (len == 0) return 0;
     // (every lane takes four groups a step; at most 8 workgroups of 4 waves per CU -- every wave slot of the chip, once --
@@ -967,7 +973,7 @@ extern "C" int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long l
                        (u64)first_number, nframes, (u64 *)d_offsets, d_info, (u64 *)d_alt, d_ranges, nranges, (u64 *)d_stamp);
     if (nframes)
         hipLaunchKernelGGL(fg_dec_index_resolve_kernel, dim3((nframes + 255) / 256), dim3(256), 0, stream, (u64 *)d_offsets, (const u64 *)d_alt,
-                           nframes, (u64)len, d_info, d_stream, d_hdrrec);
+                           nframes, (u64)len, d_info, d_stream, d_hdrrec, d_gate, epoch);
     return (int)hipGetLastError();
 }
 

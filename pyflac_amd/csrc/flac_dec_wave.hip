@@ -156,8 +156,6 @@ __global__ void __launch_bounds__(256, 8)
 fg_dec_wparse_kernel(const uint8_t *stream, u64 stream_len, const FgDecFrame *frames, uint32_t nframes, int32_t *scratch,
                      FgDecSub *subs, FgDecResult *results, uint16_t *rparams, unsigned long long *counters, FgDecSelf SF)
 {
-    // (FgDecSelf.gate: this kernel is queued behind the resolve kernel, so its start says that the offsets are settled)
-    if (SF.gate && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(SF.gate, SF.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __shared__ uint32_t lds[4 * WP_WAVE_W];
     const int lane = threadIdx.x & 63;
     uint32_t *const rows = lds + (threadIdx.x >> 6) * WP_WAVE_W;
@@ -1161,14 +1159,16 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
         // (join: header pass, scan and CRC pass ran beside the parser on streams of their own and the main stream did not wait for
         // them -- a wait is 5 us of idle GPU in front of this kernel.  Their last kernel raised join[0] to this call's epoch; it has
         // by the time the parser ends, so this loop does not turn.  Behind it the frame table and the verdicts are read for the first
-        // time by this workgroup: what it reads is what those kernels left when they ended.  join[-2] collects a timeout.)
+        // time since this kernel's start emptied the caches, and nobody else reads them: what arrives is what those kernels left
+        // when they ended (an acquire fence here -- 220 workgroups emptying the L2 one after the other -- cost the kernel 5 us).
+        // join[-2] collects a timeout.)
         if (join) {
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
                 if (wall_clock64() - t0 > FG_GATE_TICKS) { if (lane == 0) atomicOr(join - 2, 2ull); break; }
                 __builtin_amdgcn_s_sleep(16);
             }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            asm volatile("" ::: "memory");
         }
         // ---- facts of this chain (and the CRC verdict merged into the frame status, as fg_dec_restore_kernel does)
         uint32_t n = 0, status = 1, ca = 0, wasted = 0;
@@ -1579,7 +1579,7 @@ extern "C" int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_
     if (nframes == 0) return 0;
     const dim3 grid((nframes + 3) / 4);
     FgDecSelf SF;
-    if (self) SF = *self; else { SF.offsets = nullptr; SF.hdrrec = nullptr; SF.planeoff = nullptr; SF.plane_cap_bytes = 0; SF.si_bps = 0; SF.reserved = 0; SF.gate = nullptr; SF.epoch = 0; }
+    if (self) SF = *self; else { SF.offsets = nullptr; SF.hdrrec = nullptr; SF.planeoff = nullptr; SF.plane_cap_bytes = 0; SF.si_bps = 0; SF.reserved = 0; }
     if (wide) hipLaunchKernelGGL((fg_dec_wparse_kernel<true, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
     else if (plane16) hipLaunchKernelGGL((fg_dec_wparse_kernel<false, true>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);
     else hipLaunchKernelGGL((fg_dec_wparse_kernel<false, false>), grid, dim3(256), 0, stream, d_stream, (u64)stream_len, d_frames, nframes, d_scratch, d_subs, d_results, d_rparams, d_counters, SF);

@@ -8,6 +8,7 @@
 // checking and channel reconstruction runs on the GPU; there is no CPU decode fallback.
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <thread>
 
 #include <algorithm>
@@ -477,10 +478,21 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     bool selfstart = lean && queued && index_here && nranges == 0 && !detail && !self_off && crc_late_mode == 0 && c->stream2 != nullptr;
     uint32_t *d_hrec = nullptr;
     unsigned long long *d_poff = nullptr;
+    // (round 5: no event on the main stream between the resolve kernel and the parser, none in front of the restore kernel.  Fork: the
+    // resolve kernel raises a word in pinned memory, and the HOST -- it has the parser queued by then and would only wait for the end
+    // of the call -- queues the side streams' kernels when it sees it: they start some 8 us behind the parser, whose workgroups are
+    // placed by then (let go earlier, the CRC pass takes the wave slots the parser needs to hold all its frames at once; a kernel that
+    // waits for the word on the side streams slows the index pass beside it by half).  Join: the side streams' last kernel raises a
+    // word in device memory that the restore kernel, queued behind all of it, looks at before it reads what they left.
+    // FLACGPU_DEC_GATE=0 in a test-hooks build keeps the events; =2 mutes the join word: the restore kernel's bounded wait times out,
+    // the call is repeated with events and the context keeps them)
+    static const int gate_sel = fg_sel("FLACGPU_DEC_GATE") ? atoi(fg_sel("FLACGPU_DEC_GATE")) : 1;
+    bool use_gate = selfstart && gate_sel != 0 && !c->gate_off;
     if (selfstart) {
         if (!c->dec_poff.ensure((size_t)npad * 8) || !c->dec_hrec.ensure((size_t)npad * 4)) return false;
         d_poff = (unsigned long long *)c->dec_poff.p; d_hrec = (uint32_t *)c->dec_hrec.p;
     }
+    const unsigned long long gate_epoch = use_gate ? ++c->gate_epoch : 0;
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
         const void *const info_was = c->dec_info.p;
@@ -503,7 +515,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         unsigned long long *const d_stamp = lean ? (unsigned long long *)c->stamp.p : nullptr;
         if ((!tables_clean && fg_launch_dec_index_init(d_off, d_info + 8, d_info, nframes, d_stamp, c->stream) != 0) ||
             fg_launch_dec_index((const uint8_t *)d_stream, len, channels_hint, bps_hint, first_number, nframes, d_off, d_info, d_info + 8, d_ranges, nranges, c->stream, d_hrec,
-                                tables_clean ? d_stamp : nullptr) != 0) {
+                                tables_clean ? d_stamp : nullptr, use_gate ? c->h_sig + 1 : nullptr, gate_epoch) != 0) {
             fg_set_error("frame index kernel launch failed"); return false;
         }
         // (the end of the last frame, offsets[nframes] = len, is set by the index kernel)
@@ -517,14 +529,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // pass took the wave slots the parser needs to have all its frames resident at once, and the host's calls for the side
     // streams sat between the index pass and the parser.
     hipStream_t hstream = c->stream;
-    bool use_gate = false;
-    unsigned long long gate_epoch = 0;
     if (selfstart) {
         hstream = c->gstream[0] ? c->gstream[0] : c->stream2;
-        // (round 5: no event on the main stream between the resolve kernel and the parser -- the side streams' kernels are let go by
-        // a word the parser raises, FgDecSelf.gate; FLACGPU_DEC_GATE=0 in a test-hooks build keeps the events)
-        static const bool gate_sel_off = fg_sel("FLACGPU_DEC_GATE") && atoi(fg_sel("FLACGPU_DEC_GATE")) == 0;
-        use_gate = !gate_sel_off && !c->gate_off && index_here;
         if (!use_gate) selfstart = HIPOK(hipEventRecord(c->evx[0], c->stream));
         if (!selfstart) { hstream = c->stream; use_gate = false; }
     }
@@ -617,13 +623,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
             FgDecSelf self;
             self.offsets = d_off; self.hdrrec = d_hrec; self.planeoff = d_poff; self.plane_cap_bytes = c->dec_scratch.cap;
             self.si_bps = bps_hint; self.reserved = 0;
-            unsigned long long *const d_gw = (unsigned long long *)c->dec_info.p;       // [5] timeouts, [6] fork word, [7] join word
-            if (use_gate) gate_epoch = ++c->gate_epoch;
-            self.gate = use_gate ? d_gw + 6 : nullptr; self.epoch = gate_epoch;
-            // (test hook, FLACGPU_DEC_GATE=2 in a test-hooks build: the parser does not raise the word -- the side streams' waits time
-            // out, the call is repeated with events and the context keeps them)
-            static const bool gate_sel_mute = fg_sel("FLACGPU_DEC_GATE") && atoi(fg_sel("FLACGPU_DEC_GATE")) == 2;
-            if (gate_sel_mute) self.gate = nullptr;
+            unsigned long long *const d_gw = (unsigned long long *)c->dec_info.p;       // [5] a timeout of the restore kernel's look at [7], the join word
             if (wave_parse >= 2 && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
             if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
                                         (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16,
@@ -635,15 +635,26 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                 // offsets) on another; the restore kernel reads the frame table and the verdicts and waits for both
                 // (one wait in front of the restore kernel, not two: the header stream waits for the CRC stream's event before it
                 // records its own -- every wait on the main stream is some 5 us of idle GPU)
-                if (!(use_gate ? fg_launch_dec_gate(d_gw + 6, gate_epoch, d_gw + 5, c->stream2) == 0 : HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0))) ||
+                if (use_gate) {
+                    // (the fork: wait here, not on the GPU -- bounded; behind the bound the stream is waited for, which is slower and as good)
+                    volatile unsigned long long *const fw = c->h_sig + 1;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    bool seen = false;
+                    for (unsigned it = 0; !seen; it++) {
+                        seen = __atomic_load_n(fw, __ATOMIC_ACQUIRE) == gate_epoch;
+                        if (!seen && (it & 63) == 63 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 3000) break;
+                    }
+                    if (!seen && !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+                }
+                if (!(use_gate || HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0))) ||
                     fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
                                          (const uint16_t *)c->crctab.p, c->stream2, d_off, len) != 0 ||
                     !HIPOK(hipEventRecord(c->evx[1], c->stream2))) { fg_set_error("decode kernel launch failed"); return false; }
-                if (!(use_gate ? fg_launch_dec_gate(d_gw + 6, gate_epoch, d_gw + 5, hstream) == 0 : HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0))) ||
+                if (!(use_gate || HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0))) ||
                     fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
                                           (FgDecResult *)c->dec_results.p, d_tot, cap_samples, hstream, 0) != 0 ||
                     (hstream != c->stream2 && !HIPOK(hipStreamWaitEvent(hstream, c->evx[1], 0))) ||
-                    !(use_gate ? fg_launch_dec_raise(d_gw + 7, gate_epoch, hstream) == 0 : HIPOK(hipEventRecord(c->evx[2], hstream)))) { fg_set_error("header kernel launch failed"); return false; }
+                    !(use_gate ? (gate_sel == 2 || fg_launch_dec_raise(d_gw + 7, gate_epoch, hstream) == 0) : HIPOK(hipEventRecord(c->evx[2], hstream)))) { fg_set_error("header kernel launch failed"); return false; }
                 forked = false;            // (evx[2] stands for both)
                 // (with the gate the restore kernel looks at the join word itself: no wait on the main stream)
                 if (!use_gate && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[2], 0))) return false;

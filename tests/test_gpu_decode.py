@@ -526,10 +526,11 @@ def test_parser_on_its_own_equals_parser_behind_the_header_pass():
 
 
 def test_fork_and_join_through_words_in_memory_equal_the_events_and_survive_a_timeout():
-    """Round 5 (FgDecSelf.gate): the side streams of a decode launch are let go by a word the parser raises, and the restore kernel
-    looks at the word their last kernel raises -- no event record or wait on the main stream.  Same samples and status words as with
-    the events (FLACGPU_DEC_GATE=0, test-hooks build, a child process each); and with the parser's word muted (FLACGPU_DEC_GATE=2) the
-    bounded waits time out, the call is repeated with events and still returns the same."""
+    """Round 5: no event record or wait on the main stream of a decode launch.  The resolve kernel raises a word in pinned memory and
+    the host queues the side streams' kernels (CRC pass; header pass + scan) when it sees it; their last kernel raises a word the
+    restore kernel looks at before it reads the frame table and the verdicts.  Same samples and status words as with the events
+    (FLACGPU_DEC_GATE=0, test-hooks build, a child process each); and with the join word muted (FLACGPU_DEC_GATE=2) the restore
+    kernel's bounded wait times out, the call is repeated with events and still returns the same."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
