@@ -246,8 +246,11 @@ struct FgDecSelf {
     uint32_t reserved;
 };
 
-// how long a wave waits for a word another kernel raises before it gives up and flags the call (wall clock, 100 MHz): 0.2 s
-#define FG_GATE_TICKS 20000000ull
+// how long a wave waits for a word another kernel raises before it gives up and flags the call (wall clock, 100 MHz): 20 ms.
+// (The side streams' work ends before the parser does; where kernels are serialised across streams -- a profiler collecting
+// counters does that -- the restore kernel is started in front of the kernel that raises its word, waits this long once, and the
+// context goes back to events.)
+#define FG_GATE_TICKS 2000000ull
 
 struct FgDecResult {
     uint32_t err;          // 0 ok, 1 malformed (bad header / reserved or inconsistent fields), 2 crc16 mismatch,

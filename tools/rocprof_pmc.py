@@ -26,12 +26,24 @@ def per_kernel(sub, name):
                 acc[k].append(float(row['Counter_Value']))
     # (round 5: the direct packing path has no assembly kernel; every step of the bench is one encode and one decode launch, and the
     # decoder's header pass runs once a launch)
-    once_dec = max([len(v) for k, v in acc.items() if k.startswith('fg_dec_headers_kernel')] or [0])
-    once_enc = once_dec or max([len(v) for k, v in acc.items() if k.startswith('fg_pipe_assemble_kernel')] or [0])
+    # (later in round 5: the launches of a direction = the smallest dispatch count among its kernels that run in every launch -- the
+    # passes are made with --no-passes, so every launch of a run is alike; a run may hold one decode launch more than encode launches,
+    # the bench's check.  A dispatch far above its kernel's median is replaced by the median: under the profiler's serialisation of
+    # kernels the FIRST decode launch's restore kernel waits for its join word until the bound, 0.2 s of polling -- the call then
+    # falls back to events, as designed, and the other launches are what a launch costs)
+    is_enc = lambda k: k.startswith('fg_pipe_') or k.startswith('fg_scan_') or k.startswith('fg_encode')
+    is_dec = lambda k: k.startswith('fg_dec')
+    def launches_of(pred):
+        n = [len(v) for k, v in acc.items() if pred(k) and len(v) >= 3]
+        return min(n) if n else 0
+    once_enc, once_dec = launches_of(is_enc), launches_of(is_dec)
     out = {}
     for k, v in acc.items():
-        launches = once_enc if (k.startswith('fg_pipe_') or k.startswith('fg_scan_') or k.startswith('fg_encode')) else (once_dec if k.startswith('fg_dec') else 0)
-        out[k] = sum(v) / launches if launches else sum(v) / len(v)
+        launches = once_enc if is_enc(k) else (once_dec if is_dec(k) else 0)
+        if len(v) >= 3:
+            med = sorted(v)[len(v) // 2]
+            v = [med if (med > 0 and x > 5 * med) else x for x in v]
+        out[k] = sum(v) / launches if (launches and len(v) >= 3) else sum(v) / len(v)
     return out
 
 
