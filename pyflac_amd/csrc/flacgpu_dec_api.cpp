@@ -487,7 +487,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // FLACGPU_DEC_GATE=0 in a test-hooks build keeps the events; =2 mutes the join word: the restore kernel's bounded wait times out,
     // the call is repeated with events and the context keeps them)
     static const int gate_sel = fg_sel("FLACGPU_DEC_GATE") ? atoi(fg_sel("FLACGPU_DEC_GATE")) : 1;
-    bool use_gate = selfstart && gate_sel != 0 && !c->gate_off;
+    bool use_gate = selfstart && gate_sel != 0 && !c->gate_off && len != 0;      // (no bytes: no resolve kernel to raise the word)
     if (selfstart) {
         if (!c->dec_poff.ensure((size_t)npad * 8) || !c->dec_hrec.ensure((size_t)npad * 4)) return false;
         d_poff = (unsigned long long *)c->dec_poff.p; d_hrec = (uint32_t *)c->dec_hrec.p;
