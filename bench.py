@@ -169,6 +169,28 @@ def committed_profile(name):
         return None
 
 
+def committed_pmc(workload, level, nblocks, build_id, load=None):
+    """The committed counter pass that may be quoted for this run, and whether it may: (pass, file name, same, note).
+    A pass counts only for the build it was measured on -- flacgpu_build_id() is a hash over the library's sources, the pass carries
+    the id of the library that ran under the counters -- and for the same workload, level and block count; otherwise `same` is False,
+    `traffic` / `issue_ceiling` stay out of the line and `note` says why.  (`load`: committed_profile, replaceable in tests.)"""
+    load = load or committed_profile
+    pmc, pmc_name = {}, None
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
+        pmc_name = '%s_pmc.json' % rnd if workload == 'stream16' else '%s_pmc_%s.json' % (rnd, workload)
+        pmc = load(pmc_name) or {}
+        if pmc:
+            break
+    same_shape = pmc.get('workload') == workload and pmc.get('level') == level and pmc.get('blocks') == nblocks
+    same = bool(pmc) and same_shape and pmc.get('build_id') == build_id
+    note = None
+    if pmc and not same:
+        note = ('profiles/%s is a pass of build %s on %s / level %s / %s blocks; this run: build %s, %s / level %d / %d blocks -- not quoted' %
+                (pmc_name, pmc.get('build_id', '(no id: before round 5)'), pmc.get('workload'), pmc.get('level'), pmc.get('blocks'),
+                 build_id, workload, level, nblocks))
+    return pmc, pmc_name, same, note
+
+
 def api_e2e(seconds, sr):
     """Drop-in API end to end on host buffers (PCIe, callbacks and MD5 included): numpy int16 -> StreamEncoder.process ->
     write callbacks -> bytes -> StreamDecoder -> numpy blocks.  Never part of `value`."""
@@ -599,22 +621,8 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     ps = np.sort(np.array(per_step)) * 1e3
     # (the committed PMC passes of the same command: profiles/r04_pmc.json for the headline, profiles/r04_pmc_<workload>.json
     # for the others; a pass of an earlier round stands in only if it was made on the same workload, level and block count)
-    pmc, pmc_name = {}, None
-    for rnd in ('r05', 'r04', 'r03', 'r02'):
-        pmc_name = '%s_pmc.json' % rnd if workload == 'stream16' else '%s_pmc_%s.json' % (rnd, workload)
-        pmc = committed_profile(pmc_name) or {}
-        if pmc:
-            break
-    # (a counter pass counts only for the build it was measured on: flacgpu_build_id() is a hash over the library's sources, the
-    # pass carries the id of the library that ran under the counters)
     build_id = L.flacgpu_build_id().decode()
-    same_shape = pmc.get('workload') == workload and pmc.get('level') == level and pmc.get('blocks') == nblocks
-    same = same_shape and pmc.get('build_id') == build_id
-    pmc_note = None
-    if pmc and not same:
-        pmc_note = ('profiles/%s is a pass of build %s on %s / level %s / %s blocks; this run: build %s, %s / level %d / %d blocks -- not quoted' %
-                    (pmc_name, pmc.get('build_id', '(no id: before round 5)'), pmc.get('workload'), pmc.get('level'), pmc.get('blocks'),
-                     build_id, workload, level, nblocks))
+    pmc, pmc_name, same, pmc_note = committed_pmc(workload, level, nblocks, build_id)
     enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
     dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
     res = {
