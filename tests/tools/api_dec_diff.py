@@ -1,4 +1,4 @@
-"""Where a StreamDecoder result differs from the input, for one seed of tests/tools/gpu_api_fuzz.py: python tools/exp/api_dec_diff.py <seed>"""
+"""Where a StreamDecoder result differs from the input, for one seed of tests/tools/gpu_api_fuzz.py: python tests/tools/api_dec_diff.py <seed>"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,6 +1,6 @@
 """What the stream decoder delivers for the damage cases that are not byte-identical to the reference's callback sequence."""
 import sys, os, json, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import cases, abi_decode
 from oracle import oracle as O

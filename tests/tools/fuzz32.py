@@ -1,4 +1,4 @@
-"""gpu_fuzz over the 32-bit cases of the corpus only (the wide forms of the pipeline): usage python tools/exp/fuzz32.py first count"""
+"""gpu_fuzz over the 32-bit cases of the corpus only (the wide forms of the pipeline): usage python tests/tools/fuzz32.py first count"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

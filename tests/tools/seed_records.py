@@ -1,7 +1,7 @@
 """One fuzz seed through the pipeline with debug records on: the first stage record that differs from the oracle's (GPU box).
-usage: python tools/seed_records.py <seed>"""
+usage: python tests/tools/seed_records.py <seed>"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import oracle as O
 from pyflac_amd import batch
