@@ -120,6 +120,7 @@ struct flacgpu_ctx {
     void *idx_clean_off = nullptr, *idx_clean_info = nullptr;
     unsigned long long gate_epoch = 0;      // the decode launch's fork / join words (flacgpu_dec_api.cpp decode_frames_impl): one epoch a call
     bool gate_off = false;                  // a wait on them timed out once: events from then on
+    void *gate_words_of = nullptr;          // the dec_info buffer whose header (counters, join word) has been zeroed
     uint32_t dec_p16_hold = 0;       // decode calls that still take 32-bit residual planes (a stream showed values beyond 16 bits)
     hipStream_t stream2 = nullptr;   // tail blocks (generic kernel) run beside the specialised kernel
     hipStream_t stream3 = nullptr;   // short blocks of the pipeline's packing stage

@@ -495,11 +495,15 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     const unsigned long long gate_epoch = use_gate ? ++c->gate_epoch : 0;
     if (index_here) {
         // one pass over the bytes: every frame header found puts its position into the slot of its frame number
-        const void *const info_was = c->dec_info.p;
         if (!c->dec_info.ensure(64 + (size_t)nframes * 12 + 16)) return false;      // counters, second claims, claim counts
         unsigned long long *d_info = (unsigned long long *)c->dec_info.p;
-        // (a new buffer: the fork / join words behind the counters must not hold anything that looks like an epoch)
-        if (c->dec_info.p != info_was && (!HIPOK(hipMemsetAsync(d_info, 0, 64, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream)))) return false;
+        // (a buffer this has not been done for -- a new one, or the 4 KB the count pass's ensure(64) above got on a context's first
+        // call, which a small table then fits into without a new allocation --: the join word behind the counters must not hold
+        // anything that looks like an epoch.  A new buffer never has the address of the one it replaces: DevBuf::ensure allocates first)
+        if (c->dec_info.p != c->gate_words_of) {
+            if (!HIPOK(hipMemsetAsync(d_info, 0, 64, c->stream)) || !HIPOK(hipStreamSynchronize(c->stream))) return false;
+            c->gate_words_of = c->dec_info.p;
+        }
         const FgDecRange *d_ranges = nullptr;
         if (nranges) {
             // several streams in one buffer: every stream files its frames from its own slot on
