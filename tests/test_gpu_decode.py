@@ -541,3 +541,28 @@ def test_fork_and_join_through_words_in_memory_equal_the_events_and_survive_a_ti
         line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
         outs.append(json.loads(line[7:]))
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_a_fresh_context_whose_first_decode_is_small_after_another_context_left_its_memory_behind():
+    """The join word the restore kernel looks at lives behind the index pass's counters; a context's first decode call of few frames
+    keeps the 4 KB its count pass allocated, and that memory may have belonged to a context that is gone (round 5: zeroed for every
+    buffer it has not been zeroed for).  One context works on a long stream and is closed; a new one decodes a short stream from its
+    bytes alone as its first call -- twenty times over, so that some allocation lands on recycled bytes."""
+    import torch
+    from pyflac_amd import batch, synth
+    big = torch.from_numpy(synth.config2_stereo16(20.0, 9).astype(np.int32)).cuda()
+    small = synth.config2_stereo16(0.6, 4).astype(np.int32)                     # 8 frames of 4096
+    ts = torch.from_numpy(small).cuda()
+    s = batch.settings(5, 2, 16, 48000, 4096, False)
+    for _ in range(20):
+        a = batch.Context(0)
+        out, offs, est = a.encode(s, big)
+        dec, status, dst = a.decode_stream(out[:est.total_bytes].clone(), 2, 16, big.shape[0], nframes=est.nblocks)
+        assert int(status[:, 0].max()) == 0 and torch.equal(dec, big)
+        o2, f2, e2 = a.encode(s, ts)
+        data = o2[:e2.total_bytes].clone()
+        a.close()
+        b = batch.Context(0)
+        dec, status, dst = b.decode_stream(data, 2, 16, ts.shape[0], nframes=e2.nblocks)
+        assert int(status[:, 0].max()) == 0 and torch.equal(dec, ts)
+        b.close()
