@@ -98,8 +98,9 @@ def system_libflac(pcm16, level, sr):
         return {'library': name, 'error': repr(e)}
 
 
-def cpu_baseline(pcm16, level, sr, budget_s=12.0):
-    """Time the CPU oracle (oracle/flac_oracle.c, a scalar port of libFLAC 1.4.3) on a bounded sample."""
+def cpu_baseline(pcm16, level, sr, budget_s=12.0, all_cores=True, what='the same synthetic stream'):
+    """Time the CPU oracle (oracle/flac_oracle.c, a scalar port of libFLAC 1.4.3) on a bounded sample.  all_cores=False (the N > 1
+    line: the other ranks are starting up on the same host) leaves the one-process-per-core leg out."""
     from oracle import oracle as O
     ch = pcm16.shape[1]
     cfg, rc = O.config(level, ch, 16, sr, 4096, True)
@@ -128,6 +129,8 @@ def cpu_baseline(pcm16, level, sr, budget_s=12.0):
     ncores = max(1, min(avail, 64))
     allc = None
     try:
+        if not all_cores:
+            raise RuntimeError('left out')
         import multiprocessing as mp
         global _CPU_JOB
         wreps = max(1, int(round(3.0 / max(enc_t / reps, 1e-3))))          # about 3 s of work per core
@@ -152,11 +155,12 @@ def cpu_baseline(pcm16, level, sr, budget_s=12.0):
             'encode_msamples_per_s_md5_on': round(enc_md5, 2),
             'system_libFLAC': sysflac if sysflac is not None else 'none on this box (ctypes.util.find_library("FLAC") is None)',
             'all_cores': {'cores': ncores, 'encode_msamples_per_s': None if allc is None else round(allc, 1),
-                          'how': 'one oracle process per host core, about 3 s of encodes each, aggregate over the slowest worker'},
-            'sample': '%.0f s of the same synthetic stream x%d encode / x%d decode passes, MD5 off, 1 thread; '
+                          'how': 'one oracle process per host core, about 3 s of encodes each, aggregate over the slowest worker'}
+                         if all_cores else 'not run in the N > 1 line (the other ranks start up on the same cores); see the N = 1 line',
+            'sample': '%.0f s of %s x%d encode / x%d decode passes, MD5 off, 1 thread; '
                       'oracle/flac_oracle.c is a scalar restatement of libFLAC 1.4.3 (the reference binary does not '
                       'travel to the GPU box; reference_binary_ratio has what it measured against the oracle)' %
-                      (a32.shape[0] / sr, reps, dreps),
+                      (a32.shape[0] / sr, what, reps, dreps),
             'wall_s': round(time.perf_counter() - t0, 1)}
 
 
@@ -169,25 +173,32 @@ def committed_profile(name):
         return None
 
 
-def committed_pmc(workload, level, nblocks, build_id, load=None):
+def committed_pmc(workload, level, nblocks, kernel_id, load=None, build_id=None):
     """The committed counter pass that may be quoted for this run, and whether it may: (pass, file name, same, note).
-    A pass counts only for the build it was measured on -- flacgpu_build_id() is a hash over the library's sources, the pass carries
-    the id of the library that ran under the counters -- and for the same workload, level and block count; otherwise `same` is False,
-    `traffic` / `issue_ceiling` stay out of the line and `note` says why.  (`load`: committed_profile, replaceable in tests.)"""
+    A pass counts only for the KERNELS it was measured on -- flacgpu_kernel_id() is a hash over the .hip files and the headers they
+    include, the pass carries the id of the library that ran under the counters (round 6: an edit of a host file changes
+    flacgpu_build_id() and flacgpu_host_id() and leaves the pass standing) -- and for the same workload, level and block count;
+    otherwise `same` is False, `traffic` / `issue_ceiling` stay out of the line and `note` says why.  A round-5 pass carries the id
+    of the whole build only and counts for exactly that build (`build_id`).  (`load`: committed_profile, replaceable in tests.)"""
     load = load or committed_profile
     pmc, pmc_name = {}, None
-    for rnd in ('r05', 'r04', 'r03', 'r02'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
         pmc_name = '%s_pmc.json' % rnd if workload == 'stream16' else '%s_pmc_%s.json' % (rnd, workload)
         pmc = load(pmc_name) or {}
         if pmc:
             break
     same_shape = pmc.get('workload') == workload and pmc.get('level') == level and pmc.get('blocks') == nblocks
-    same = bool(pmc) and same_shape and pmc.get('build_id') == build_id
+    if pmc.get('kernel_id'):
+        same_code = pmc.get('kernel_id') == kernel_id
+    else:
+        same_code = bool(pmc.get('build_id')) and build_id is not None and pmc.get('build_id') == build_id
+    same = bool(pmc) and same_shape and same_code
     note = None
     if pmc and not same:
-        note = ('profiles/%s is a pass of build %s on %s / level %s / %s blocks; this run: build %s, %s / level %d / %d blocks -- not quoted' %
-                (pmc_name, pmc.get('build_id', '(no id: before round 5)'), pmc.get('workload'), pmc.get('level'), pmc.get('blocks'),
-                 build_id, workload, level, nblocks))
+        their = ('kernels %s' % pmc['kernel_id']) if pmc.get('kernel_id') else ('build %s' % pmc.get('build_id', '(no id: before round 5)'))
+        note = ('profiles/%s is a pass of %s on %s / level %s / %s blocks; this run: kernels %s%s, %s / level %d / %d blocks -- not quoted' %
+                (pmc_name, their, pmc.get('workload'), pmc.get('level'), pmc.get('blocks'),
+                 kernel_id, (' (build %s)' % build_id) if build_id else '', workload, level, nblocks))
     return pmc, pmc_name, same, note
 
 
@@ -622,7 +633,8 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
     # (the committed PMC passes of the same command: profiles/r04_pmc.json for the headline, profiles/r04_pmc_<workload>.json
     # for the others; a pass of an earlier round stands in only if it was made on the same workload, level and block count)
     build_id = L.flacgpu_build_id().decode()
-    pmc, pmc_name, same, pmc_note = committed_pmc(workload, level, nblocks, build_id)
+    kernel_id, host_id = L.flacgpu_kernel_id().decode(), L.flacgpu_host_id().decode()
+    pmc, pmc_name, same, pmc_note = committed_pmc(workload, level, nblocks, kernel_id, build_id=build_id)
     enc_ach = alg_bytes / (enc_t * 1e-3) / 1e9
     dec_ach = alg_bytes / (dec_t * 1e-3) / 1e9
     res = {
@@ -665,10 +677,11 @@ def measure(env, ctx, workload, seconds, level, steps, warmup, streams, passes=T
                             'algorithmic_bytes_per_launch': int(alg_bytes), 'ms_per_launch': round(dec_t, 4)},
     }
     res['build_id'] = build_id
+    res['kernel_id'], res['host_id'] = kernel_id, host_id
     if pmc_note:
         res['roofline']['traffic_note'] = res['roofline_decode']['traffic_note'] = pmc_note
     if same:
-        res['roofline']['traffic_source'] = res['roofline_decode']['traffic_source'] = 'profiles/' + pmc_name + ' (committed PMC pass of this command and this build, not measured in this run)'
+        res['roofline']['traffic_source'] = res['roofline_decode']['traffic_source'] = 'profiles/' + pmc_name + ' (committed PMC pass of this command and these kernels, not measured in this run)'
     if same and pmc.get('encode_valu_insts_per_launch'):
         # the ceiling these integer kernels actually run against: VALU issue (one wave-instruction per 2 cycles and SIMD,
         # fp64 4 cycles), 1024 SIMDs at 2.4 GHz; instruction counts from the committed PMC pass of this same command
@@ -723,6 +736,11 @@ def main():
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == 'stream16':
         cpu_res = cpu_baseline(synth.config2_stereo16(60.0, 0, 48000), level, 48000)
+    elif rank == 0 and world > 1 and not args.no_cpu_baseline and workload == 'batch':
+        # (the N > 1 line carries the baseline too: rank 0 times the oracle on ONE stream of its share of the batch, one thread, some
+        # eight seconds, before it touches its GPU; the other ranks wait for it in init_process_group)
+        cpu_res = cpu_baseline(synth.config5_stream(0, min(seconds, 60.0), 48000), level, 48000, budget_s=8.0, all_cores=False,
+                               what='stream 0 of the batch (synth.config5_stream)')
     import torch
     import torch.distributed as dist
     from pyflac_amd import batch

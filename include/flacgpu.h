@@ -580,9 +580,13 @@ const char *flacgpu_window_note(flacgpu_ctx *ctx);
 /* How the library was built: bit 0 = `make TUNING=1` (experiment and diagnostic environment switches are read), bit 1 = `make LEGACY=1`
  * (the superseded kernels of rounds 1 and 2 are present and selectable: FLACGPU_PIPE=0, FLACGPU_DEC_WAVE=0, FLACGPU_DEC_FUSED=0). */
 unsigned int flacgpu_build_flags(void);
-/* Sixteen hex digits: a hash over the sources this library was built from.  The committed counter passes (profiles/*_pmc*.json)
- * name the build they were measured on; bench.py quotes their HBM traffic and instruction counts only when this id matches. */
+/* Sixteen hex digits each: hashes over the sources this library was built from -- all of them (build id), the kernel files and the
+ * headers they include (kernel id), the host files and theirs (host id).  The committed counter passes (profiles: the _pmc json
+ * files) name the build they were measured on; bench.py quotes their HBM traffic and instruction counts only when the KERNEL id
+ * matches: an edit of a host file changes the build id and the host id and leaves the counter passes standing. */
 const char *flacgpu_build_id(void);
+const char *flacgpu_kernel_id(void);
+const char *flacgpu_host_id(void);
 /* Start-up self-check of the encoder's matrix-core autocorrelation (run by flacgpu_ctx_create): the number of
  * v_mfma_f64_4x4x4_4b_f64 results that differed from the chain of v_fma_f64 the bit-exactness of stage L6 rests on; 0 on
  * a device that behaves like the MI355X this was written on.  Non-zero: every block is encoded by the generic kernel (same bytes,
@@ -597,6 +601,9 @@ void flacgpu_force_selfcheck_result(flacgpu_ctx *ctx, int mfma_bad);
  * total_gpu_ms is the HIP-event time of exactly the kernels, in exactly the order, the default call runs. */
 void flacgpu_set_stage_timing(flacgpu_ctx *ctx, int level);
 int flacgpu_copy_debug(flacgpu_ctx *ctx, void *host_dst, uint32_t first_block, uint32_t nblocks);
+/* The kernels' CRC-16 tables as the library builds them on the host (13 312 uint16 entries; layout: fg_ctx.cpp fg_crc_tables_host):
+ * needs no GPU, so that a CPU test can hold them against the bit-by-bit definition of FLAC__crc16 (format.h:447). */
+void flacgpu_debug_crc_tables(uint16_t *out);
 int flacgpu_copy_block_results(flacgpu_ctx *ctx, void *host_dst, uint32_t nblocks);
 
 typedef struct {
@@ -612,6 +619,9 @@ typedef struct {
     uint32_t generic_frames;      /* frames the wave parser handed to the generic (one lane a frame) decoder: predictor orders above 12,
                                    * 33-bit subframes, codes of hundreds of bytes, a frame whose part of the residual plane did not fit.
                                    * Same samples, much slower: a large count on ordinary material is a defect to report */
+    uint32_t join_late_workgroups;/* workgroups of the restore kernel whose first look at the join word -- the word the kernel behind header pass,
+                                   * scan and CRC pass raises -- found it not yet raised, i.e. that waited for those kernels (0 in a call
+                                   * that joins through events; normally 0 anyway: they end before the parser does) */
 } flacgpu_decode_stats;
 
 /* Decode the audio frames of one FLAC stream held in device memory.  d_stream/len: the frame data (device);

@@ -83,7 +83,8 @@ class DecodeStats(C.Structure):
     _fields_ = [('nframes', C.c_uint32), ('error_frames', C.c_uint32), ('total_samples', C.c_uint64),
                 ('channels', C.c_uint32), ('bits_per_sample', C.c_uint32), ('sample_rate', C.c_uint32),
                 ('max_blocksize', C.c_uint32), ('decode_kernel_ms', C.c_float), ('total_gpu_ms', C.c_float),
-                ('index_ms', C.c_float), ('plane_bits', C.c_uint32), ('generic_frames', C.c_uint32)]
+                ('index_ms', C.c_float), ('plane_bits', C.c_uint32), ('generic_frames', C.c_uint32),
+                ('join_late_workgroups', C.c_uint32)]
 
 
 ENC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
@@ -125,9 +126,9 @@ DATA_SYMBOLS = ['FLAC__StreamEncoderStateString', 'FLAC__StreamEncoderInitStatus
                 'FLAC__StreamDecoderErrorStatusString']
 EXT_FUNCTIONS = ['flacgpu_settings_from_level', 'flacgpu_device_count', 'flacgpu_ctx_create', 'flacgpu_ctx_destroy',
                  'flacgpu_last_error', 'flacgpu_encode_streams', 'flacgpu_encode_bound', 'flacgpu_set_debug',
-                 'flacgpu_copy_debug', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
+                 'flacgpu_copy_debug', 'flacgpu_debug_crc_tables', 'flacgpu_copy_block_results', 'flacgpu_decode_frames', 'flacgpu_decode_frames_dev',
                  'flacgpu_index_frames', 'flacgpu_refwalk_probe', 'flacgpu_stream_encoder_process_interleaved_i16', 'flacgpu_stream_encoder_set_launch_blocks', 'flacgpu_decode_stream_dev', 'flacgpu_decode_streams_dev',
-                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_set_direct', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_build_id', 'flacgpu_md5_streams', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
+                 'flacgpu_set_stage_timing', 'flacgpu_set_log_guard', 'flacgpu_set_direct', 'flacgpu_window_note', 'flacgpu_selfcheck', 'flacgpu_force_selfcheck_result', 'flacgpu_build_flags', 'flacgpu_build_id', 'flacgpu_kernel_id', 'flacgpu_host_id', 'flacgpu_md5_streams', 'flacgpu_stream_decoder_set_subframe_detail', 'flacgpu_stream_decoder_set_block_callback']
 
 _lib = None
 _testhooks = None
@@ -242,8 +243,9 @@ def _load(path):
     L.flacgpu_set_log_guard.restype = None
     L.flacgpu_md5_streams.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)]
     L.flacgpu_md5_streams.restype = C.c_int
-    L.flacgpu_build_id.argtypes = []
-    L.flacgpu_build_id.restype = C.c_char_p
+    for _n in ('flacgpu_build_id', 'flacgpu_kernel_id', 'flacgpu_host_id'):
+        getattr(L, _n).argtypes = []
+        getattr(L, _n).restype = C.c_char_p
     L.flacgpu_set_direct.argtypes = [vp, C.c_int]
     L.flacgpu_set_direct.restype = None
     L.flacgpu_window_note.argtypes = [vp]

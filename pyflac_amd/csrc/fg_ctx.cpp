@@ -186,9 +186,10 @@ static bool ctx_init(flacgpu_ctx *c, int device)
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_khz = (double)khz;
     }
-    if (!c->crctab.ensure((2048 + 2 * 5632) * sizeof(uint16_t))) return false;      // (2048 entries of round 1-2 tables, then the direct packing path's two sets)
-    if (fg_launch_crc_tables((uint16_t *)c->crctab.p, c->stream) != 0) { fg_set_error("crc table kernel launch failed"); return false; }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->crctab.ensure(FG_CRC_TABLE_WORDS * sizeof(uint16_t))) return false;      // (2048 entries of round 1-2 tables, then the direct packing path's two sets)
+    // (made on the host, once per process, and copied: round 5's table kernel -- four waves walking powers of x bit by bit -- took
+    // 5.5 ms of every context's creation)
+    HIPCHK(hipMemcpy(c->crctab.p, fg_crc_tables_host(), FG_CRC_TABLE_WORDS * sizeof(uint16_t), hipMemcpyHostToDevice));
     // The encoder pipeline's autocorrelation runs its fp64 chains on the matrix core and is bit-exact only while that instruction
     // sums in v_fma_f64's order (flac_enc_pipe.hip fg_mfma_selfcheck): checked here, once per context.  A device that does it
     // differently keeps the byte-exact output -- every block then takes the generic kernel, whose chains are v_fma_f64 -- and says so.
@@ -353,13 +354,73 @@ extern "C" uint64_t flacgpu_encode_bound(const flacgpu_settings *s, const flacgp
 
 extern "C" void flacgpu_set_debug(flacgpu_ctx *ctx, int on) { ctx->debug = on != 0; }
 extern "C" const char *flacgpu_window_note(flacgpu_ctx *ctx) { return ctx->window_note.c_str(); }
-extern "C" const char *flacgpu_build_id(void)
+
+// ---- the CRC-16 tables of the kernels (polynomial x^16 + x^15 + x^2 + 1, format.h:447: FLAC__crc16), built on the host
+// Layout (uint16 entries): [0,256) the CRC of byte i; [256,512) (i x^8) x^2048 and [512,768) i x^2048 -- the contribution of a
+// byte 2048 bits further up --; [768,832) x^(32 k); [1024,1792) byte i followed by 1, 2, 3 zero bytes (slicing by four).  Then, for the
+// direct packing path (fg_pipe_pack_kernel<DIRECT>: a pass of NT threads over 16-byte granules), a set for NT = 256 at 2048 and one
+// for NT = 128 at 2048 + 5632: [0,256) (i x^8) x^(128 NT), [256,512) i x^(128 NT), [512,1536) byte i followed by 3, 2, 1, 0 zero bytes,
+// [1536 + rem NT + t) x^(128 (NT - 1 - t) + 8 rem) for rem = 0..15.
+// Products and powers in GF(2)[x] / P: a power of x by squaring, so the whole table is some 14 000 products of sixteen steps.
+static inline uint32_t fg_gf16_mul(uint32_t a, uint32_t b)
 {
-    static const char id[] =
-#include "fg_build_id.inc"
-        ;
-    return id;
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; i--) {
+        r = (r & 0x8000u) ? (((r << 1) ^ 0x8005u) & 0xFFFFu) : ((r << 1) & 0xFFFFu);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
 }
+static uint32_t fg_gf16_xpow(uint32_t n)
+{
+    uint32_t r = 1, base = 2;           // (the polynomial x)
+    for (; n; n >>= 1) { if (n & 1u) r = fg_gf16_mul(r, base); base = fg_gf16_mul(base, base); }
+    return r;
+}
+const uint16_t *fg_crc_tables_host()
+{
+    static uint16_t tab[FG_CRC_TABLE_WORDS];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        memset(tab, 0, sizeof tab);
+        const uint32_t x8 = fg_gf16_xpow(8), x16 = fg_gf16_xpow(16), x24 = fg_gf16_xpow(24), x2048 = fg_gf16_xpow(2048);
+        uint32_t crc8[256];
+        for (uint32_t i = 0; i < 256; i++) {
+            const uint32_t c = fg_gf16_mul(i << 8, x8);        // byte i, its eight bits shifted out: i x^16 mod P
+            crc8[i] = c;
+            tab[i] = (uint16_t)c;
+            tab[256 + i] = (uint16_t)fg_gf16_mul(i << 8, x2048);
+            tab[512 + i] = (uint16_t)fg_gf16_mul(i, x2048);
+            if (i < 64) tab[768 + i] = (uint16_t)fg_gf16_xpow(32 * i);
+            tab[1024 + i] = (uint16_t)fg_gf16_mul(c, x8);
+            tab[1280 + i] = (uint16_t)fg_gf16_mul(c, x16);
+            tab[1536 + i] = (uint16_t)fg_gf16_mul(c, x24);
+        }
+        for (int set = 0; set < 2; set++) {
+            const uint32_t nt = set == 0 ? 256u : 128u;
+            uint16_t *x = tab + 2048 + 5632 * set;
+            const uint32_t xs = fg_gf16_xpow(128 * nt);
+            for (uint32_t i = 0; i < 256; i++) {
+                const uint32_t c = crc8[i];
+                x[i] = (uint16_t)fg_gf16_mul(i << 8, xs);
+                x[256 + i] = (uint16_t)fg_gf16_mul(i, xs);
+                x[512 + i] = (uint16_t)fg_gf16_mul(c, x24);
+                x[768 + i] = (uint16_t)fg_gf16_mul(c, x16);
+                x[1024 + i] = (uint16_t)fg_gf16_mul(c, x8);
+                x[1280 + i] = (uint16_t)c;
+                if (i < nt)
+                    for (uint32_t rem = 0; rem < 16; rem++) x[1536 + rem * nt + i] = (uint16_t)fg_gf16_xpow(128 * (nt - 1 - i) + 8 * rem);
+            }
+        }
+    });
+    return tab;
+}
+// (for the CPU test that holds this table against the bit-by-bit definition)
+extern "C" void flacgpu_debug_crc_tables(uint16_t *out) { memcpy(out, fg_crc_tables_host(), FG_CRC_TABLE_WORDS * sizeof(uint16_t)); }
+#include "fg_build_id.inc"
+extern "C" const char *flacgpu_build_id(void) { return FG_BUILD_ID; }
+extern "C" const char *flacgpu_kernel_id(void) { return FG_KERNEL_ID; }
+extern "C" const char *flacgpu_host_id(void) { return FG_HOST_ID; }
 extern "C" unsigned int flacgpu_build_flags(void)
 {
     unsigned int f = 0;

@@ -13,7 +13,8 @@
 // ---- kernel launchers (flac_enc_kernels.hip / flac_dec_kernels.hip)
 extern "C" {
 size_t fg_enc_lds_bytes(const FgEncParams *P);
-int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream);
+#define FG_CRC_TABLE_WORDS (2048 + 2 * 5632)
+const uint16_t *fg_crc_tables_host();       // fg_ctx.cpp: the kernels' CRC-16 tables, built once per process
 int fg_launch_widen16(const int16_t *d_src, int32_t *d_dst, unsigned long long n, hipStream_t stream);
 int fg_launch_encode(const void *d_pcm, const FgBlockDesc *d_descs, const float *d_windows, const FgEncParams *P,
                      uint32_t nblocks, uint8_t *d_slots, FgBlockResult *d_results, FgDebugRec *d_dbg,
@@ -52,9 +53,6 @@ int fg_launch_md5_streams(const void *d_pcm, uint32_t pcm_i16, uint32_t channels
                           uint32_t *d_out, hipStream_t stream);
 int fg_launch_signal_direct(const unsigned long long *d_total, const unsigned long long *d_guard, const unsigned long long *d_stamp,
                             unsigned long long *h_sig, unsigned long long seq, hipStream_t stream, unsigned long long *d_reset);
-int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
-                     const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
-                     unsigned long long seq, hipStream_t stream, const FgDecFrame *fix_frames = nullptr, int32_t *fix_out = nullptr);
 size_t fg_scan_words(uint32_t nblocks);
 int fg_launch_scan(FgBlockResult *d_results, const uint32_t *d_chunk_bits, uint32_t nblocks, unsigned long long *d_offsets, int all_pipe,
                    const unsigned long long *d_errs, hipStream_t stream);
@@ -71,9 +69,6 @@ int fg_launch_dec_index(const uint8_t *d_stream, unsigned long long len, uint32_
 int fg_launch_decode_slow(const uint8_t *d_stream, const FgDecFrame *d_frames, const uint32_t *d_frame_list, uint32_t nlist,
                           int32_t *d_pcm, FgDecResult *d_results, const uint16_t *d_crctab, int32_t *d_scratch, uint32_t interleave,
                           hipStream_t stream);
-int fg_launch_decode_fast(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
-                          int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, unsigned long long *d_prof,
-                          uint16_t *d_rparams, hipStream_t stream);
 int fg_launch_decode_wparse(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
                             int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
                             unsigned long long *d_counters, hipStream_t stream, int plane16, const FgDecSelf *self);
@@ -82,19 +77,13 @@ int fg_launch_decode_wrestore(const FgDecFrame *d_frames, uint32_t nframes, uint
                               hipStream_t stream, int plane16, FgDecResult *h_rows, const unsigned long long *d_planeoff,
                               unsigned long long *d_join = nullptr, unsigned long long epoch = 0);
 int fg_launch_dec_raise(unsigned long long *d_word, unsigned long long epoch, hipStream_t stream);
-int fg_launch_decode_fused(const uint8_t *d_stream, uint64_t stream_len, const FgDecFrame *d_frames, uint32_t nframes,
-                           int32_t *d_scratch, FgDecSub *d_subs, FgDecResult *d_results, int wide, uint16_t *d_rparams,
-                           int32_t *d_warm, int32_t *d_pcm, uint32_t interleave, unsigned long long *d_prof, hipStream_t stream);
-int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results, int32_t *d_pcm, hipStream_t stream);
+int fg_launch_dec_spin(unsigned long long ticks, hipStream_t stream);
 int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels, const FgDecSub *d_subs,
                             const int32_t *d_scratch, int32_t *d_warm, hipStream_t stream);
 int fg_launch_narrow16(const int32_t *d_in, int16_t *d_out, uint64_t n, hipStream_t stream);
 int fg_launch_compare(const int32_t *d_a, const int32_t *d_b, uint64_t n, unsigned long long *d_first, hipStream_t stream);
 int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
                          const uint16_t *d_crctab, hipStream_t stream, const unsigned long long *d_offsets, unsigned long long stream_len);
-int fg_launch_decode_finish(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, uint32_t channels,
-                            const int32_t *d_scratch, const FgDecSub *d_subs, int32_t *d_pcm, FgDecResult *d_results,
-                            const uint16_t *d_crctab, uint32_t interleave, int wide, unsigned long long *d_prof, hipStream_t stream);
 }
 
 void fg_set_error(const std::string &msg);

@@ -298,28 +298,6 @@ fg_dec_crc_kernel(const uint8_t *stream, const FgDecFrame *frames, uint32_t nfra
 }
 
 
-// Settle the frames after the fused kernel and the CRC-16 kernel: merge the CRC verdict into the status, and write silence
-// for frames that failed (libFLAC delivers silence on a CRC mismatch; status 3 = the generic kernel decodes it next).
-__global__ void __launch_bounds__(256)
-fg_dec_fix_kernel(const FgDecFrame *frames, uint32_t nframes, FgDecResult *results, int32_t *out)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= nframes) return;
-    const FgDecFrame fr = frames[f];
-    uint32_t status = 1, crcw = 0;
-    if (fr.bytes != 0) {
-        status = results[f].err;
-        crcw = results[f].crc;
-        if (status == 0 && (crcw & 0x80000000u)) status = 2;
-    }
-    if (fr.n != 0 && lane == 0) { results[f].err = status; results[f].crc = crcw & 0xFFFFu; }
-    if (status != 0 && status != 3 && fr.n != 0 && fr.channels != 0) {
-        int32_t *o = out + fr.out_off * fr.channels;
-        for (uint32_t k = lane; k < fr.n * fr.channels; k += 64) o[k] = 0;
-    }
-}
-
 // The first samples of every subframe (the predictor's warm-up, or the start of a verbatim subframe) as they were coded:
 // FLAC__Subframe_Fixed / _LPC.warmup of the frame handed to the write callback.  thread = (subframe, j).
 __global__ void __launch_bounds__(256)
@@ -347,21 +325,8 @@ extern "C" int fg_launch_decode_warmup(const FgDecFrame *d_frames, uint32_t nfra
     return (int)hipGetLastError();
 }
 
-// The lane-serial decoders of rounds 1 and 2 (fg_dec_rice_kernel + fg_dec_restore_kernel, fg_dec_fused_kernel) left the tree in
-// round 5; the wave-parallel parser and its restore kernel (flac_dec_wave.hip) replace them.  Their entry points answer "not there".
-extern "C" int fg_launch_decode_fast(const uint8_t *, uint64_t, const FgDecFrame *, uint32_t, int32_t *, FgDecSub *, FgDecResult *, int,
-                                     unsigned long long *, uint16_t *, hipStream_t) { return -3; }
-extern "C" int fg_launch_decode_finish(const uint8_t *, const FgDecFrame *, uint32_t, uint32_t, const int32_t *, const FgDecSub *, int32_t *,
-                                       FgDecResult *, const uint16_t *, uint32_t, int, unsigned long long *, hipStream_t) { return -3; }
-extern "C" int fg_launch_decode_fused(const uint8_t *, uint64_t, const FgDecFrame *, uint32_t, int32_t *, FgDecSub *, FgDecResult *, int,
-                                      uint16_t *, int32_t *, int32_t *, uint32_t, unsigned long long *, hipStream_t) { return -3; }
-extern "C" int fg_launch_decode_fix(const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results, int32_t *d_pcm, hipStream_t stream)
-{
-    if (nframes == 0) return 0;
-    hipLaunchKernelGGL(fg_dec_fix_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, d_frames, nframes, d_results, d_pcm);
-    return (int)hipGetLastError();
-}
-
+// (The lane-serial decoders of rounds 1 and 2 -- fg_dec_rice_kernel + fg_dec_restore_kernel, fg_dec_fused_kernel -- left the tree in
+// round 5, their entry points and fg_dec_fix_kernel in round 6; the wave-parallel parser and its restore kernel, flac_dec_wave.hip, replace them.)
 // CRC-16 of every frame; independent of the parse kernel, so the caller may run it on a second stream beside it
 extern "C" int fg_launch_decode_crc(const uint8_t *d_stream, const FgDecFrame *d_frames, uint32_t nframes, FgDecResult *d_results,
                                     const uint16_t *d_crctab, hipStream_t stream, const unsigned long long *d_offsets, unsigned long long stream_len)

@@ -919,7 +919,12 @@ fg_dec_index_resolve_kernel(u64 *offsets, const u64 *alt, uint32_t nframes, u64 
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t *ticket = (uint32_t *)(info + 4) + 1;
-            if (atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1) __hip_atomic_store(gate, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (the last ticket: the acquire fence pairs with the fences the other workgroups' writers took in front of their
+            // tickets, the system-scope release store then carries all of it to the host and to the kernels it queues)
+            if (atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(gate, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -938,13 +943,28 @@ __global__ void fg_dec_index_init_kernel(u64 *offsets, u64 *alt, unsigned long l
 // The join of the decode launch through a word in memory instead of an event (round 5; flacgpu_dec_api.cpp): a one-thread kernel
 // behind the side streams' work raises join[0] to the call's epoch, and the restore kernel looks at it before it reads what that
 // work left (flac_dec_wave.hip).
+// (RELEASE at agent scope: the kernels in front of this one on its stream have ended -- their writes happen-before this kernel's
+// start --, and the restore kernel takes an agent-scope acquire fence behind the load that sees the epoch: release/acquire on this
+// word orders everything header pass, scan and CRC pass wrote before everything the restore kernel reads of it.)
 __global__ void fg_dec_raise_kernel(unsigned long long *word, unsigned long long epoch)
 {
-    if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 extern "C" int fg_launch_dec_raise(unsigned long long *d_word, unsigned long long epoch, hipStream_t stream)
 {
     hipLaunchKernelGGL(fg_dec_raise_kernel, dim3(1), dim3(64), 0, stream, d_word, epoch);
+    return (int)hipGetLastError();
+}
+// One wave that does nothing for `ticks` of the 100 MHz wall clock (at most a second): what a test queues in front of the side
+// streams' kernels to make the restore kernel's wait for its join word turn (flacgpu_dec_api.cpp, test-hooks build only).
+__global__ void fg_dec_spin_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64(), lim = ticks > 100000000ull ? 100000000ull : ticks;
+    while (wall_clock64() - t0 < lim) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int fg_launch_dec_spin(unsigned long long ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fg_dec_spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
     return (int)hipGetLastError();
 }
 

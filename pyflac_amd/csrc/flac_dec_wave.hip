@@ -1155,29 +1155,48 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     int32_t q[16], h[16];
     uint32_t order = 0;
     int shift = 0;
+    bool dead = false;          // (wave 0: the wait for the join word ran out)
     if (wave == 0) {
-        // (join: header pass, scan and CRC pass ran beside the parser on streams of their own and the main stream did not wait for
-        // them -- a wait is 5 us of idle GPU in front of this kernel.  Their last kernel raised join[0] to this call's epoch; it has
-        // by the time the parser ends, so this loop does not turn.  Behind it the frame table and the verdicts are read for the first
-        // time since this kernel's start emptied the caches, and nobody else reads them: what arrives is what those kernels left
-        // when they ended (an acquire fence here -- 220 workgroups emptying the L2 one after the other -- cost the kernel 5 us).
-        // join[-2] collects a timeout.)
+        // Join (round 6, by the rules of the HSA memory model instead of an argument about timing): header pass, scan and CRC pass ran
+        // beside the parser on streams of their own, and the main stream did not wait for them.  The kernel queued behind them
+        // stores this call's epoch into join[0] with RELEASE order at agent scope -- every kernel in front of it on its stream has
+        // ended by then, and the CRC stream's event has been waited for, so everything they wrote happens-before that store.  This
+        // wave reads the word relaxed (one word, every lane the same address) until it holds the epoch, and then -- always, also
+        // when the first look found it raised: the side streams' kernels may have ended between this kernel's start, which
+        // emptied the caches, and that look, and a workgroup of theirs on this CU may have left lines of the tables in its L1 --
+        // takes ONE agent-scope ACQUIRE fence (buffer_inv sc1).  The fence synchronises with the release; the plain loads of
+        // frames[], results[], planeoff[] and subs[] behind it, in this wave and -- behind the __syncthreads() below -- in the
+        // others, see what those kernels left.  (Round 5 had no fence here and argued the loop never turns; 1.7 us of a launch.)
+        // A wait that runs out (a tool that serialises kernels across streams has queued this kernel in front of the one that
+        // raises the word) sets bit 1 of join[-2] and this workgroup does NOTHING: the tables are not final, out_off may be a
+        // previous call's -- no sample is written, no status word touched.  The host repeats the call with events.
+        // join[-2]'s upper half counts the workgroups whose first look found the word not yet raised (flacgpu_decode_stats).
         if (join) {
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-                if (wall_clock64() - t0 > FG_GATE_TICKS) { if (lane == 0) atomicOr(join - 2, 2ull); break; }
-                __builtin_amdgcn_s_sleep(16);
+            unsigned long long seen = __hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = ((unsigned long long)rfl((uint32_t)(seen >> 32)) << 32) | rfl((uint32_t)seen);
+            if (seen < epoch) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    if (wall_clock64() - t0 > FG_GATE_TICKS) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(16);
+                    seen = __hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = ((unsigned long long)rfl((uint32_t)(seen >> 32)) << 32) | rfl((uint32_t)seen);
+                    if (seen >= epoch) break;
+                }
+                // (one add a workgroup: + 1 in the upper half, and + 2 in the lower half for a wait that ran out -- the lower half
+                // stays far below 2^32 and is non-zero exactly when some wait ran out, which is what the host tests)
+                if (lane == 0) atomicAdd(join - 2, (1ull << 32) | (dead ? 2ull : 0ull));
             }
-            asm volatile("" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         // ---- facts of this chain (and the CRC verdict merged into the frame status, as fg_dec_restore_kernel does)
         uint32_t n = 0, status = 1, ca = 0, wasted = 0;
         u64 out_off = 0;
-        if (mine) {
+        if (mine && !dead) {
             const FgDecFrame fr = frames[f];
             if (fr.bytes != 0 && fr.channels == C) {
                 n = fr.n; status = results[f].err; ca = fr.ca; out_off = fr.out_off;
-                // (interleave bit 11: the CRC pass is still running beside this kernel, fg_dec_fix_kernel merges its verdict)
+                // (interleave bit 11, unused since round 6: the CRC verdict is not to be looked at)
                 const uint32_t cw = (interleave & 0x800) ? 0u : results[f].crc;
                 if (status == 0 && (cw & 0x80000000u)) status = 2;          // CRC-16 mismatch (fg_dec_crc_kernel)
             }
@@ -1192,7 +1211,7 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
             for (int j = 0; j < FG_DMAXO; j++) if ((uint32_t)j < order) q[j] = sd->q[j];
         }
         const uint32_t n_in = ok ? n : 0;
-        const uint32_t n_out = (mine && status != 3) ? n : 0;               // status 3: the generic kernel writes the frame
+        const uint32_t n_out = (mine && !dead && status != 3) ? n : 0;      // status 3: the generic kernel writes the frame
         // (planeoff: the parser placed the frames' parts of the plane itself, FgDecSelf)
         const u64 plane = ok ? (planeoff ? (u64)(planeoff[f] >> 2) : out_off * C) + (u64)ch * n : 0;
         uint32_t *fm = fa + lane * WR_FA;
@@ -1215,8 +1234,8 @@ fg_dec_wrestore_kernel(const FgDecFrame *frames, uint32_t nframes, uint32_t C, c
     __syncthreads();
     // (the status merge is written after every wave has read what it needs: only wave 0 reads results[])
     // (host_rows: the status words go to the host's pinned copy from here -- the call then ends with the few words of
-    // fg_signal_kernel instead of a pass over all frames' words, fg_export_kernel: 10 us of a decode launch)
-    if (wave == 0 && mine && ch == 0 && !(interleave & 0x800)) {
+    // fg_signal_kernel instead of a pass over all frames' words -- round 4's fg_export_kernel: 10 us of a decode launch)
+    if (wave == 0 && mine && !dead && ch == 0 && !(interleave & 0x800)) {
         const FgDecFrame fr = frames[f];
         uint32_t status = results[f].err, cw = results[f].crc;
         if (fr.bytes != 0 && fr.channels == C && fr.n != 0) {

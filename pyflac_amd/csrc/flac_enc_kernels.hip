@@ -1126,40 +1126,8 @@ struct Enc {
     }
 };
 
-// x^(32*k) mod P for k = 0..63 and the three CRC tables are generated once per launch by fg_crc_tables.
-__global__ void fg_crc_tables_kernel(uint16_t *tab)
-{
-    const int i = threadIdx.x;   // 256 threads
-    uint32_t c = (uint32_t)i << 8;
-    for (int b = 0; b < 8; b++) c = (c & 0x8000) ? (((c << 1) ^ 0x8005) & 0xFFFF) : ((c << 1) & 0xFFFF);
-    tab[i] = (uint16_t)c;                                       // standard table: (i * x^8) * x^8 ... = crc of byte i
-    // multiply by x^2048: high-byte and low-byte contribution tables
-    tab[256 + i] = (uint16_t)crc16_mulx((uint32_t)i << 8, 2048);
-    tab[512 + i] = (uint16_t)crc16_mulx((uint32_t)i, 2048);
-    if (i < 64) tab[768 + i] = (uint16_t)crc16_mulx(1, 32 * i);  // x^(32 i)
-    // slicing tables: crc of byte i followed by 1, 2, 3 zero bytes (a 32-bit word then needs four independent look-ups)
-    tab[1024 + i] = (uint16_t)crc16_mulx(c, 8);
-    tab[1280 + i] = (uint16_t)crc16_mulx(c, 16);
-    tab[1536 + i] = (uint16_t)crc16_mulx(c, 24);
-    // the direct packing path (fg_pipe_pack_kernel<DIRECT>): a pass of NT threads over 16-byte granules, NT = 256 (set 0, at 2048) and
-    // 128 (set 1, at 2048 + 5632): [0,256) (i x^8) x^(128 NT), [256,512) i x^(128 NT); [512,1536) byte i followed by 3, 2, 1, 0 zero
-    // bytes; [1536 + rem NT + t) x^(128 (NT - 1 - t) + 8 rem) for rem = 0..15
-    for (int set = 0; set < 2; set++) {
-        const int nt = set == 0 ? 256 : 128;
-        uint16_t *x = tab + 2048 + 5632 * set;
-        x[i] = (uint16_t)crc16_mulx((uint32_t)i << 8, 128 * nt);
-        x[256 + i] = (uint16_t)crc16_mulx((uint32_t)i, 128 * nt);
-        x[512 + i] = (uint16_t)crc16_mulx(c, 24);
-        x[768 + i] = (uint16_t)crc16_mulx(c, 16);
-        x[1024 + i] = (uint16_t)crc16_mulx(c, 8);
-        x[1280 + i] = (uint16_t)c;
-        if (i < nt) {
-            uint32_t e = crc16_mulx(1, 128 * (nt - 1 - i));
-            for (int rem = 0; rem < 16; rem++) { x[1536 + rem * nt + i] = (uint16_t)e; e = crc16_mulx(e, 8); }
-        }
-    }
-}
-
+// (the CRC-16 tables -- crctab -- are built on the host and copied at context creation: fg_ctx.cpp fg_crc_tables_host, which also
+// describes their layout)
 __global__ void __launch_bounds__(64)
 fg_encode_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, uint8_t *out,
                  FgBlockResult *results, FgDebugRec *dbg, const uint16_t *crctab)
@@ -1466,50 +1434,6 @@ __global__ void fg_signal_direct_kernel(const u64 *total, const u64 *guard, cons
     fg_signal_tail(nullptr, 0, nullptr, 0, stamp, host, seq, reset);
 }
 
-// the decoder's variant: the per-frame status words travel too (16-byte units, a few workgroups; the last one to finish --
-// counter in stamp[1] -- raises the flag)
-// With `fix_frames` (the decoder's wave path, round 4): the rows are the frames' FgDecResult words and this kernel also does what
-// fg_dec_fix_kernel did in a launch of its own -- the CRC-16 verdict (bit 31 of the crc word, left by fg_dec_crc_kernel beside the
-// parse kernel) becomes status 2, and a frame that failed (not status 3: the generic decoder writes those) is silence.  A failed
-// frame is rare; the thread that meets one zeroes it alone.
-__global__ void __launch_bounds__(1024)
-fg_export_kernel(uint4 *rows, uint32_t nquads, uint4 *host_rows, const u64 *src0, uint32_t n0, const u64 *src1, uint32_t n1,
-                 u64 *stamp, u64 *host, u64 seq, const FgDecFrame *fix_frames, uint32_t fix_nframes, int32_t *fix_out)
-{
-    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < nquads; i += gridDim.x * 1024) {
-        uint4 r = rows[i];
-        if (fix_frames) {
-            uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint32_t f = 2 * i + k;
-                if (f >= fix_nframes) continue;
-                const FgDecFrame fr = fix_frames[f];
-                uint32_t status = 1, crcw = 0;
-                if (fr.bytes != 0) { status = w[2 * k]; crcw = w[2 * k + 1]; if (status == 0 && (crcw & 0x80000000u)) status = 2; }
-                if (fr.n != 0) { w[2 * k] = status; w[2 * k + 1] = crcw & 0xFFFFu; }
-                if (status != 0 && status != 3 && fr.n != 0 && fr.channels != 0 && fr.bytes != 0 && fix_out) {       // (bytes == 0: a slot the scan rejected, out_off means nothing)
-                    int32_t *o = fix_out + fr.out_off * fr.channels;
-                    for (uint32_t j = 0; j < fr.n * fr.channels; j++) o[j] = 0;
-                }
-            }
-            r = make_uint4(w[0], w[1], w[2], w[3]);
-            rows[i] = r;
-        }
-        host_rows[i] = r;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const u64 done = atomicAdd((unsigned long long *)&stamp[1], 1ull);
-        if (done == gridDim.x - 1) {
-            stamp[1] = 0;
-            __threadfence();
-            fg_signal_tail(src0, n0, src1, n1, stamp, host, seq);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ STREAMINFO MD5 of device-resident streams (stage L1, format.h:543)
 // MD5 is a chain over the 64-byte blocks of ONE stream, so the only parallelism is across streams: thread = stream.  The bytes are
 // the samples little-endian at (bits per sample + 7) / 8 bytes each, channels interleaved, exactly what libFLAC hashes; a stream
@@ -1663,25 +1587,6 @@ int fg_launch_md5_streams(const void *d_pcm, uint32_t pcm_i16, uint32_t channels
     if (njobs == 0) return 0;
     hipLaunchKernelGGL(fg_md5_streams_kernel, dim3((njobs + 63) / 64), dim3(64), 0, stream, d_pcm, pcm_i16, channels, bps, (const FgMd5Job *)d_jobs,
                        njobs, d_out);
-    return (int)hipGetLastError();
-}
-
-int fg_launch_export(void *d_rows, uint32_t nrows, void *h_rows, const unsigned long long *src0, uint32_t n0,
-                     const unsigned long long *src1, uint32_t n1, unsigned long long *d_stamp, unsigned long long *h_sig,
-                     unsigned long long seq, hipStream_t stream, const FgDecFrame *fix_frames, int32_t *fix_out)
-{
-    // rows of 8 bytes, moved as 16-byte units (both buffers are padded past nrows)
-    const uint32_t nquads = (nrows + 1) / 2;
-    uint32_t wgs = (nquads + 1023) / 1024;
-    wgs = wgs < 1 ? 1 : wgs > 8 ? 8 : wgs;
-    hipLaunchKernelGGL(fg_export_kernel, dim3(wgs), dim3(1024), 0, stream, (uint4 *)d_rows, nquads, (uint4 *)h_rows, (const u64 *)src0, n0,
-                       (const u64 *)src1, n1, (u64 *)d_stamp, (u64 *)h_sig, (u64)seq, fix_frames, fix_frames ? nrows : 0u, fix_out);
-    return (int)hipGetLastError();
-}
-
-int fg_launch_crc_tables(uint16_t *d_tab, hipStream_t stream)
-{
-    hipLaunchKernelGGL(fg_crc_tables_kernel, dim3(1), dim3(256), 0, stream, d_tab);
     return (int)hipGetLastError();
 }
 

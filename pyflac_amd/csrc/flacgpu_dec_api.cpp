@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <time.h>
 #include <thread>
 
 #include <algorithm>
@@ -398,14 +399,17 @@ struct DecDetail {
 #ifndef FG_NO_DEFER_INIT
 #define FG_NO_DEFER_INIT 0
 #endif
-static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
+// One attempt.  *again = true (with false returned): nothing is wrong with the input, the call is to be made once more under what this
+// attempt left in the context -- events instead of the fork / join words (a wait on one of them ran out), or 32-bit residual planes
+// (a value beyond 16 bits showed up); decode_frames_impl below does that, in a loop.
+static bool decode_frames_once(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
                                uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
                                FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
-                               bool offsets_on_device = false, uint64_t first_number = 0, uint64_t *d_offsets_out = nullptr,
-                               DecDetail *detail = nullptr, uint64_t status_capacity = ~0ull, const FgDecRange *h_ranges = nullptr,
-                               uint32_t nranges = 0)
+                               bool offsets_on_device, uint64_t first_number, uint64_t *d_offsets_out,
+                               DecDetail *detail, uint64_t status_capacity, const FgDecRange *h_ranges,
+                               uint32_t nranges, bool *again)
 {
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    *again = false;
     memset(st, 0, sizeof *st);
     if (!HIPOK(hipSetDevice(c->device))) { fg_set_error("hipSetDevice failed"); return false; }
     const bool index_here = h_offsets == nullptr;
@@ -454,9 +458,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     unsigned long long *d_tot = d_off + nframes + 1;
     // end of call and timing as in the encoder (fg_ctx.cpp): level 0 = stamp kernel in front, export kernel at the end (status
     // words, totals and stamps into pinned memory, the host polls a sequence number), no events; levels 1, 2 = HIP events
-    static const bool want_prof = fg_tune("FLACGPU_DEC_PROF") != nullptr;
     // (level 3: as level 0, plus one event in front of the first kernel and one behind the last -- fg_ctx.cpp)
-    const bool lean = (c->stage_timing == 0 || c->stage_timing == 3) && !h_frames && !detail && !want_prof;
+    const bool lean = (c->stage_timing == 0 || c->stage_timing == 3) && !h_frames && !detail;
     const bool ev2 = lean && c->stage_timing == 3;
     if (ev2 && !HIPOK(hipEventRecord(c->ev[0], c->stream))) return false;
     if (lean) {     // (with the index made here, its first kernel takes the stamp)
@@ -474,8 +477,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     const uint64_t cap_bytes = cap_samples * C * 4 + 256 + 65536ull * C * 4 + (uint64_t)nframes * 16;
     const bool queued = cap_bytes <= c->dec_scratch.cap || cap_bytes <= 32 * len + (1u << 20) + 65536ull * C * 4 + (uint64_t)nframes * 16;
     static const bool self_off = fg_sel("FLACGPU_DEC_SELF") && atoi(fg_sel("FLACGPU_DEC_SELF")) == 0;
-    static const int crc_late_mode = fg_tune("FLACGPU_DEC_CRC_LATE") ? atoi(fg_tune("FLACGPU_DEC_CRC_LATE")) : 0;
-    bool selfstart = lean && queued && index_here && nranges == 0 && !detail && !self_off && crc_late_mode == 0 && c->stream2 != nullptr;
+    bool selfstart = lean && queued && index_here && nranges == 0 && !detail && !self_off && c->stream2 != nullptr;
     uint32_t *d_hrec = nullptr;
     unsigned long long *d_poff = nullptr;
     // (round 5: no event on the main stream between the resolve kernel and the parser, none in front of the restore kernel.  Fork: the
@@ -485,8 +487,11 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     // waits for the word on the side streams slows the index pass beside it by half).  Join: the side streams' last kernel raises a
     // word in device memory that the restore kernel, queued behind all of it, looks at before it reads what they left.
     // FLACGPU_DEC_GATE=0 in a test-hooks build keeps the events; =2 mutes the join word: the restore kernel's bounded wait times out,
-    // the call is repeated with events and the context keeps them)
+    // the call is repeated with events and the context keeps them; FLACGPU_DEC_DELAY_US=n (test-hooks build) queues a wave that idles
+    // for n microseconds in front of the side streams' kernels, so that the restore kernel's wait for the join word does turn --
+    // flacgpu_decode_stats.join_late_workgroups counts the workgroups that waited)
     static const int gate_sel = fg_sel("FLACGPU_DEC_GATE") ? atoi(fg_sel("FLACGPU_DEC_GATE")) : 1;
+    static const long side_delay_us = fg_sel("FLACGPU_DEC_DELAY_US") ? atol(fg_sel("FLACGPU_DEC_DELAY_US")) : 0;
     bool use_gate = selfstart && gate_sel != 0 && !c->gate_off && len != 0;      // (no bytes: no resolve kernel to raise the word)
     if (selfstart) {
         if (!c->dec_poff.ensure((size_t)npad * 8) || !c->dec_hrec.ensure((size_t)npad * 4)) return false;
@@ -559,43 +564,27 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         return false;
     if (!lean && !HIPOK(hipEventRecord(c->ev[1], c->stream))) return false;
     const int wide = (bps_hint == 0 || bps_hint > 16) ? 1 : 0;
-    // FLACGPU_DEC_PROF=1: per-wave clock64() totals of the kernel stages, averaged and printed to stderr (tuning aid)
-    unsigned long long *d_prof = nullptr;
-    if (want_prof && c->dec_prof.ensure((size_t)npad * 2 * 8 * 8)) {
-        d_prof = (unsigned long long *)c->dec_prof.p;
-        (void)hipMemsetAsync(d_prof, 0, (size_t)npad * 2 * 8 * 8, c->stream);
-    }
-    // The CRC-16 pass only needs the stream and the frame table: it runs on the side stream beside the parse kernel.
-    // (the lane-serial decoders of rounds 1 and 2 -- fg_dec_rice_kernel + fg_dec_restore_kernel, fg_dec_fused_kernel -- left the
-    // tree in round 5: the wave parser and its restore kernel decode everything the generic kernel does not; FLACGPU_DEC_WAVE=2 in a
-    // test-hooks build counts the parser's rounds)
-    static const int wave_parse = (fg_sel("FLACGPU_DEC_WAVE") && atoi(fg_sel("FLACGPU_DEC_WAVE")) >= 2) ? 2 : 1;
-    static const bool old_restore = false;
-    const bool fused = false;
-    // (measured: beside the restore kernel the CRC pass slows that kernel's lone recurrence waves down by more than it gave
-    // the parse kernel back -- 136 + 159 us against 123 + 163 --, so it stays beside the parse kernel; FLACGPU_DEC_CRC_LATE=1 tries
-    // the other order)
-    // (round 4, late: the CRC pass lost more than half its instructions and now ends before the parser; waiting for it in front of
-    // the restore kernel is free -- mode 0, the default since --, the restore kernel merges the verdict itself and, in a call
-    // without events, sends the status words to the host on the way)
-    const bool crc_late = crc_late_mode == 1 && wave_parse && !old_restore && !fused;
-    // (mode 2, the default: the CRC pass beside the parse kernel, but the restore kernel does not wait for its last frames -- the
-    // pass lives on the wave slots the parser leaves and ends some 12 us after it --: it ignores the verdict, and
-    // fg_dec_fix_kernel merges it behind both.  0.363 -> 0.348 ms per decode launch.  Mode 0: the restore kernel waits and merges.)
-    const bool crc_join_late = crc_late_mode == 2 && wave_parse && !old_restore && !fused;
+    // The kernels of a decode launch (the lane-serial decoders of rounds 1 and 2 and the fused kernel left the tree in round 5, the
+    // orders of CRC pass and restore kernel tried in round 4 -- FLACGPU_DEC_CRC_LATE -- in round 6): the wave parser
+    // (flac_dec_wave.hip) on the main stream; the CRC-16 pass, which only needs the stream and the frame positions, beside it on a
+    // second stream; the restore kernel behind both, merging the CRC verdict into the frame status and, in a call without events,
+    // sending the status words to the host's pinned copy on the way.  FLACGPU_DEC_WAVE=2 in a test-hooks build counts the parser's
+    // batches and sync rounds.
+    static const bool count_rounds = fg_sel("FLACGPU_DEC_WAVE") && atoi(fg_sel("FLACGPU_DEC_WAVE")) >= 2;
     // 16-bit residual plane between the wave parser and its restore kernel (streams of up to 16 bits; flac_dec_wave.hip P16).  Not
     // when the planes themselves are handed out (subframe detail: FLAC__Frame.subframes[].residual) or read by the warm-up kernel.
     static const bool p16_off = fg_sel("FLACGPU_DEC_P16") && atoi(fg_sel("FLACGPU_DEC_P16")) == 0;
     // A frame with a value beyond 16 bits ends the parse with status 6: the call is repeated with 32-bit planes, and so are the
     // next calls of this context (a stream that does it once does it again: full-scale noise, a side channel at full scale).
-    const int plane16 = (!wide && wave_parse && !old_restore && !fused && !detail && !p16_off && c->dec_p16_hold == 0) ? 1 : 0;
+    const int plane16 = (!wide && !detail && !p16_off && c->dec_p16_hold == 0) ? 1 : 0;
     if (c->dec_p16_hold) c->dec_p16_hold--;
-    bool forked = false, fix_in_export = false, rows_sent = false;
+    bool forked = false;
     FgDecResult *const h_rows_pinned = (FgDecResult *)((char *)c->h_res + 64);
-    if (!crc_late && !selfstart) {
+    if (!selfstart) {
+        // (the frame table is there: the CRC pass starts beside the parser from an event behind the header pass)
         forked = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
         if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
-                                 (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream, selfstart ? d_off : nullptr, len) != 0) {
+                                 (const uint16_t *)c->crctab.p, forked ? c->stream2 : c->stream, nullptr, len) != 0) {
             fg_set_error("decode kernel launch failed"); return false;
         }
         if (forked && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
@@ -607,118 +596,74 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         // (the subframe records of frames the fast decoder does not take stay zero: flags bit 12 = valid)
         if (!HIPOK(hipMemsetAsync(c->dec_subs.p, 0, (size_t)npad * C * sizeof(FgDecSub), c->stream))) return false;
     }
-    // One fused kernel (parse -> residuals -> recurrence -> output through LDS), or, when the residual planes themselves are
-    // wanted (subframe detail level 2) or with FLACGPU_DEC_FUSED=0, the two-kernel version with the plane in HBM.
-    if (fused) {
-        if (fg_launch_decode_fused((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                                   (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams,
-                                   d_rparams ? (int32_t *)c->dec_warm.p : nullptr, (int32_t *)d_pcm, interleave ? 1u : 0u, d_prof, c->stream) != 0) {
+    {
+        // wave-parallel parse (flac_dec_wave.hip): one frame per wavefront
+        unsigned long long *d_cnt = nullptr;
+        FgDecSelf self;
+        self.offsets = d_off; self.hdrrec = d_hrec; self.planeoff = d_poff; self.plane_cap_bytes = c->dec_scratch.cap;
+        self.si_bps = bps_hint; self.reserved = 0;
+        // ([5]: lower half a wait on the join word that ran out, upper half the workgroups that had to wait; [7]: the join word)
+        unsigned long long *const d_gw = (unsigned long long *)c->dec_info.p;
+        if (count_rounds && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
+        if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
+                                    (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16,
+                                    selfstart ? &self : nullptr) != 0) {
             fg_set_error("decode kernel launch failed"); return false;
         }
-        if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-        if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
-            fg_set_error("decode kernel launch failed"); return false;
+        if (selfstart) {
+            // beside the parser, from the index pass's end: header pass + scan on one stream, the CRC pass (from the offsets) on
+            // another; the restore kernel reads the frame table and the verdicts and waits for both
+            // (one wait in front of the restore kernel, not two: the header stream waits for the CRC stream's event before it
+            // records its own -- every wait on the main stream is some 5 us of idle GPU)
+            if (use_gate) {
+                // The fork: wait here, not on the GPU, for the word the resolve kernel's last workgroup raises.  The index pass of
+                // one stream takes some 50 us: the first 250 us are spent looking at the word; behind them (a batch of streams,
+                // a GPU shared with somebody else) the thread sleeps between looks -- a decoder's thread must not keep a core busy
+                // for as long as the GPU takes --, and behind 3 ms the main stream is waited for, which is slower and as good.
+                volatile unsigned long long *const fw = c->h_sig + 1;
+                const auto t0 = std::chrono::steady_clock::now();
+                bool seen = false, sleeping = false;
+                for (unsigned it = 0;; it++) {
+                    if (__atomic_load_n(fw, __ATOMIC_ACQUIRE) == gate_epoch) { seen = true; break; }
+                    if (!sleeping && (it & 63) != 63) continue;
+                    const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                    if (us > 3000) break;
+                    if (us > 250) { sleeping = true; struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+                }
+                if (!seen && !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
+            }
+            if (!(use_gate || HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0))) ||
+                (side_delay_us > 0 && fg_launch_dec_spin((unsigned long long)side_delay_us * 100ull, c->stream2) != 0) ||
+                fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
+                                     (const uint16_t *)c->crctab.p, c->stream2, d_off, len) != 0 ||
+                !HIPOK(hipEventRecord(c->evx[1], c->stream2))) { fg_set_error("decode kernel launch failed"); return false; }
+            if (!(use_gate || HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0))) ||
+                (side_delay_us > 0 && hstream != c->stream2 && fg_launch_dec_spin((unsigned long long)side_delay_us * 100ull, hstream) != 0) ||
+                fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
+                                      (FgDecResult *)c->dec_results.p, d_tot, cap_samples, hstream, 0) != 0 ||
+                (hstream != c->stream2 && !HIPOK(hipStreamWaitEvent(hstream, c->evx[1], 0))) ||
+                !(use_gate ? (gate_sel == 2 || fg_launch_dec_raise(d_gw + 7, gate_epoch, hstream) == 0) : HIPOK(hipEventRecord(c->evx[2], hstream)))) { fg_set_error("header kernel launch failed"); return false; }
+            // (evx[2] stands for both side streams.  With the gate the restore kernel looks at the join word itself: no wait on the main stream)
+            if (!use_gate && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[2], 0))) return false;
+        }
+        if (d_cnt) {
+            unsigned long long hc[3] = {0, 0, 0};
+            if (HIPOK(hipMemcpyAsync(hc, d_cnt, 24, hipMemcpyDeviceToHost, c->stream)) && HIPOK(hipStreamSynchronize(c->stream)))
+                fprintf(stderr, "[flacgpu dec wave] %u frames: %llu batches, %llu sync rounds, %llu long codes\n", nframes, hc[0], hc[1], hc[2]);
         }
     }
-    else {
-        if (wave_parse) {
-            // wave-parallel parse (flac_dec_wave.hip): one frame per wavefront; FLACGPU_DEC_WAVE=2 also counts batches / sync rounds
-            unsigned long long *d_cnt = nullptr;
-            FgDecSelf self;
-            self.offsets = d_off; self.hdrrec = d_hrec; self.planeoff = d_poff; self.plane_cap_bytes = c->dec_scratch.cap;
-            self.si_bps = bps_hint; self.reserved = 0;
-            unsigned long long *const d_gw = (unsigned long long *)c->dec_info.p;       // [5] a timeout of the restore kernel's look at [7], the join word
-            if (wave_parse >= 2 && c->dec_prof.ensure(64)) { d_cnt = (unsigned long long *)c->dec_prof.p; (void)hipMemsetAsync(d_cnt, 0, 64, c->stream); }
-            if (fg_launch_decode_wparse((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                                        (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_rparams, d_cnt, c->stream, plane16,
-                                        selfstart ? &self : nullptr) != 0) {
-                fg_set_error("decode kernel launch failed"); return false;
-            }
-            if (selfstart) {
-                // beside the parser, from the event behind the index pass: header pass + scan on one stream, the CRC pass (from the
-                // offsets) on another; the restore kernel reads the frame table and the verdicts and waits for both
-                // (one wait in front of the restore kernel, not two: the header stream waits for the CRC stream's event before it
-                // records its own -- every wait on the main stream is some 5 us of idle GPU)
-                if (use_gate) {
-                    // (the fork: wait here, not on the GPU -- bounded; behind the bound the stream is waited for, which is slower and as good)
-                    volatile unsigned long long *const fw = c->h_sig + 1;
-                    const auto t0 = std::chrono::steady_clock::now();
-                    bool seen = false;
-                    for (unsigned it = 0; !seen; it++) {
-                        seen = __atomic_load_n(fw, __ATOMIC_ACQUIRE) == gate_epoch;
-                        if (!seen && (it & 63) == 63 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 3000) break;
-                    }
-                    if (!seen && !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
-                }
-                if (!(use_gate || HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0))) ||
-                    fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
-                                         (const uint16_t *)c->crctab.p, c->stream2, d_off, len) != 0 ||
-                    !HIPOK(hipEventRecord(c->evx[1], c->stream2))) { fg_set_error("decode kernel launch failed"); return false; }
-                if (!(use_gate || HIPOK(hipStreamWaitEvent(hstream, c->evx[0], 0))) ||
-                    fg_launch_dec_headers((const uint8_t *)d_stream, len, d_off, nframes, channels_hint, bps_hint, (FgDecFrame *)c->dec_frames.p,
-                                          (FgDecResult *)c->dec_results.p, d_tot, cap_samples, hstream, 0) != 0 ||
-                    (hstream != c->stream2 && !HIPOK(hipStreamWaitEvent(hstream, c->evx[1], 0))) ||
-                    !(use_gate ? (gate_sel == 2 || fg_launch_dec_raise(d_gw + 7, gate_epoch, hstream) == 0) : HIPOK(hipEventRecord(c->evx[2], hstream)))) { fg_set_error("header kernel launch failed"); return false; }
-                forked = false;            // (evx[2] stands for both)
-                // (with the gate the restore kernel looks at the join word itself: no wait on the main stream)
-                if (!use_gate && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[2], 0))) return false;
-            }
-            if (d_cnt) {
-                unsigned long long hc[3] = {0, 0, 0};
-                if (HIPOK(hipMemcpyAsync(hc, d_cnt, 24, hipMemcpyDeviceToHost, c->stream)) && HIPOK(hipStreamSynchronize(c->stream)))
-                    fprintf(stderr, "[flacgpu dec wave] %u frames: %llu batches, %llu sync rounds, %llu long codes\n", nframes, hc[0], hc[1], hc[2]);
-            }
-        }
-        else if (fg_launch_decode_fast((const uint8_t *)d_stream, len, (const FgDecFrame *)c->dec_frames.p, nframes, (int32_t *)c->dec_scratch.p,
-                                  (FgDecSub *)c->dec_subs.p, (FgDecResult *)c->dec_results.p, wide, d_prof, d_rparams, c->stream) != 0) {
-            fg_set_error("decode kernel launch failed"); return false;
-        }
-        if (forked && !crc_join_late && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-        if (wave_parse && !old_restore && !crc_late) {
-            const bool late = crc_join_late && forked;
-            // (the status words straight to the host's pinned copy: when this kernel has the last word on them)
-            rows_sent = lean && !late;
-            if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (late ? 0x800u : 0u), wide, c->stream, plane16,
-                                          rows_sent ? h_rows_pinned : nullptr, selfstart ? d_poff : nullptr,
-                                          use_gate ? (unsigned long long *)c->dec_info.p + 7 : nullptr, gate_epoch) != 0) {
-                fg_set_error("decode kernel launch failed"); return false;
-            }
-            if (late) {
-                if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-                // (without events the call ends with fg_export_kernel, which merges the verdict itself: one launch less)
-                if (lean) fix_in_export = true;
-                else if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
-                    fg_set_error("decode kernel launch failed"); return false;
-                }
-            }
-        }
-        else if (crc_late) {
-            // parse done: the CRC pass starts on the side stream, the restore kernel (told not to look at the verdict) beside it
-            const bool fk = HIPOK(hipEventRecord(c->evx[0], c->stream)) && HIPOK(hipStreamWaitEvent(c->stream2, c->evx[0], 0));
-            if (fg_launch_decode_crc((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p,
-                                     (const uint16_t *)c->crctab.p, fk ? c->stream2 : c->stream, nullptr, len) != 0) { fg_set_error("decode kernel launch failed"); return false; }
-            if (fk && !HIPOK(hipEventRecord(c->evx[1], c->stream2))) return false;
-            if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
-                                          (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, (interleave ? 1u : 0u) | (fk ? 0x800u : 0u), wide, c->stream, plane16, nullptr, selfstart ? d_poff : nullptr) != 0) {
-                fg_set_error("decode kernel launch failed"); return false;
-            }
-            if (fk) {
-                if (!HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
-                if (fg_launch_decode_fix((const FgDecFrame *)c->dec_frames.p, nframes, (FgDecResult *)c->dec_results.p, (int32_t *)d_pcm, c->stream) != 0) {
-                    fg_set_error("decode kernel launch failed"); return false;
-                }
-            }
-        }
-        else if (fg_launch_decode_finish((const uint8_t *)d_stream, (const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p,
-                                    (const FgDecSub *)c->dec_subs.p, (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p,
-                                    (const uint16_t *)c->crctab.p, interleave ? 1u : 0u, wide, d_prof ? d_prof + (size_t)npad * 8 : nullptr, c->stream) != 0) {
-            fg_set_error("decode kernel launch failed"); return false;
-        }
+    if (forked && !HIPOK(hipStreamWaitEvent(c->stream, c->evx[1], 0))) return false;
+    // (the status words straight to the host's pinned copy in a call without events: this kernel has the last word on them)
+    const bool rows_sent = lean;
+    if (fg_launch_decode_wrestore((const FgDecFrame *)c->dec_frames.p, nframes, C, (const int32_t *)c->dec_scratch.p, (const FgDecSub *)c->dec_subs.p,
+                                  (int32_t *)d_pcm, (FgDecResult *)c->dec_results.p, interleave ? 1u : 0u, wide, c->stream, plane16,
+                                  rows_sent ? h_rows_pinned : nullptr, selfstart ? d_poff : nullptr,
+                                  use_gate ? (unsigned long long *)c->dec_info.p + 7 : nullptr, gate_epoch) != 0) {
+        fg_set_error("decode kernel launch failed"); return false;
     }
     if (!lean && !HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
     if (detail && detail->level >= 1) {
-        if (!fused && fg_launch_decode_warmup((const FgDecFrame *)c->dec_frames.p, nframes, C, (const FgDecSub *)c->dec_subs.p, (const int32_t *)c->dec_scratch.p,
+        if (fg_launch_decode_warmup((const FgDecFrame *)c->dec_frames.p, nframes, C, (const FgDecSub *)c->dec_subs.p, (const int32_t *)c->dec_scratch.p,
                                     (int32_t *)c->dec_warm.p, c->stream) != 0) { fg_set_error("decode kernel launch failed"); return false; }
         detail->subs.resize((size_t)nframes * C); detail->rparams.resize((size_t)nframes * C * FG_DEC_RPARAMS); detail->warm.resize((size_t)nframes * C * 32);
         if (!HIPOK(hipMemcpyAsync(detail->subs.data(), c->dec_subs.p, detail->subs.size() * sizeof(FgDecSub), hipMemcpyDeviceToHost, c->stream)) ||
@@ -730,27 +675,30 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (lean) {
         const unsigned long long seq = ++c->sig_seq;
         if (ev2 && !HIPOK(hipEventRecord(c->ev[2], c->stream))) return false;
-        const int lrc = rows_sent
-            ? fg_launch_signal(d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr, index_here ? 6 : 0,
-                               (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream)
-            : fg_launch_export(c->dec_results.p, nframes, res, d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr,
-                               index_here ? 4 : 0, (unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream,
-                               fix_in_export ? (const FgDecFrame *)c->dec_frames.p : nullptr, fix_in_export ? (int32_t *)d_pcm : nullptr);
-        if (lrc != 0 || !c->wait_signal(seq)) { fg_set_error("decode kernel failed"); return false; }
-        // (the index tables for the next call of this shape: emptied behind the signal, while the host is on its way back)
-        if (index_here && !FG_NO_DEFER_INIT && fg_launch_dec_index_init(d_off, (unsigned long long *)c->dec_info.p + 8, (unsigned long long *)c->dec_info.p, nframes, nullptr, c->stream) == 0) {
-            c->idx_clean_n = nframes; c->idx_clean_off = (void *)d_off; c->idx_clean_info = c->dec_info.p;
+        if (fg_launch_signal(d_tot, 2, index_here ? (const unsigned long long *)c->dec_info.p : nullptr, index_here ? 6 : 0,
+                             (const unsigned long long *)c->stamp.p, c->h_sig, seq, c->stream) != 0 || !c->wait_signal(seq)) {
+            fg_set_error("decode kernel failed"); return false;
         }
         tot[0] = c->h_sig[2]; tot[1] = c->h_sig[3];
         for (int k = 0; k < 4; k++) hinfo2[k] = index_here ? c->h_sig[4 + k] : 0;
-        if (use_gate && rows_sent && c->h_sig[9] != 0) {
-            // a wait on the fork or the join word timed out (never seen; a side stream starved for 0.2 s): what this call decoded is
-            // not to be trusted -- once more, and from now on, with events
-            c->gate_off = true;
-            if (HIPOK(hipStreamSynchronize(c->stream2)) && HIPOK(hipStreamSynchronize(hstream)) && HIPOK(hipStreamSynchronize(c->stream)))
-                return decode_frames_impl(c, d_stream, len, h_offsets, nframes, channels_hint, bps_hint, d_pcm, cap_samples, interleave, h_status, h_frames, st,
-                                          offsets_on_device, first_number, d_offsets_out, detail, status_capacity, h_ranges, nranges);
-            fg_set_error("decode kernel failed"); return false;
+        if (use_gate) {
+            st->join_late_workgroups = (uint32_t)(c->h_sig[9] >> 32);
+            if ((c->h_sig[9] & 0xFFFFFFFFull) != 0) {
+                // a wait on the join word ran out (never seen outside tools that serialise kernels across streams): the restore
+                // kernel's workgroups that gave up wrote nothing, the side streams' kernels may still be running -- wait for them
+                // (they read the index tables, which must not be emptied under them), then once more, and from now on, with events
+                c->gate_off = true;
+                if (!HIPOK(hipStreamSynchronize(c->stream2)) || !HIPOK(hipStreamSynchronize(hstream)) || !HIPOK(hipStreamSynchronize(c->stream))) {
+                    fg_set_error("decode kernel failed"); return false;
+                }
+                *again = true;
+                return false;
+            }
+        }
+        // (the index tables for the next call of this shape: emptied behind the signal, while the host is on its way back -- and
+        // behind the look at the timeout word above: the side streams' kernels have ended when the join word was seen)
+        if (index_here && !FG_NO_DEFER_INIT && fg_launch_dec_index_init(d_off, (unsigned long long *)c->dec_info.p + 8, (unsigned long long *)c->dec_info.p, nframes, nullptr, c->stream) == 0) {
+            c->idx_clean_n = nframes; c->idx_clean_off = (void *)d_off; c->idx_clean_info = c->dec_info.p;
         }
     }
     else {
@@ -779,8 +727,8 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
         for (uint32_t i = 0; i < nframes; i++) if (res[i].err == 6) { wide_values = true; break; }
         if (wide_values) {
             c->dec_p16_hold = 256;
-            return decode_frames_impl(c, d_stream, len, h_offsets, nframes, channels_hint, bps_hint, d_pcm, cap_samples, interleave, h_status, h_frames, st,
-                                      offsets_on_device, first_number, d_offsets_out, detail, status_capacity, h_ranges, nranges);
+            *again = true;
+            return false;
         }
     }
     {
@@ -798,23 +746,6 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
                 !HIPOK(hipStreamSynchronize(c->stream))) { fg_set_error("decode kernel failed"); return false; }
         }
     }
-    if (d_prof) {
-        std::vector<unsigned long long> hp((size_t)npad * 16);
-        if (HIPOK(hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost))) {
-            for (int kk = 0; kk < 2; kk++) {
-                double sum[8] = {0}; size_t nw = 0;
-                for (size_t w = 0; w < npad; w++) {
-                    const unsigned long long *r = &hp[((size_t)kk * npad + w) * 8];
-                    unsigned long long tot = 0; for (int i = 0; i < 8; i++) tot += r[i];
-                    if (!tot) continue;
-                    nw++; for (int i = 0; i < 8; i++) sum[i] += (double)r[i];
-                }
-                fprintf(stderr, "[flacgpu dec prof] kernel %d: %zu waves; mean ticks/wave:", kk, nw);
-                for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", nw ? sum[i] / nw : 0.0);
-                fprintf(stderr, "\n");
-            }
-        }
-    }
     if (ev2) { (void)hipEventSynchronize(c->ev[2]); (void)hipEventElapsedTime(&st->total_gpu_ms, c->ev[0], c->ev[2]); }      // (see fg_ctx.cpp)
     else if (lean) st->total_gpu_ms = (float)((double)(c->h_sig[11] - c->h_sig[10]) / c->wall_khz);     // (decode_kernel_ms, index_ms: levels 1, 2)
     else {
@@ -824,7 +755,7 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     uint32_t bad = 0;
     for (uint32_t i = 0; i < nframes; i++) if (res[i].err) bad++;
     st->error_frames = bad;
-    st->plane_bits = (wave_parse && !old_restore && !fused) ? (plane16 ? 16u : 32u) : 0u;
+    st->plane_bits = plane16 ? 16u : 32u;
     if (index_here && bad == nframes && ((unsigned long long *)((char *)c->h_res + 32))[2]) {
         // nothing was found under the fixed-block-size sync code, but headers with the variable-block-size one were
         fg_set_error("variable block size stream: use flacgpu_index_frames"); return false;
@@ -833,6 +764,25 @@ static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t le
     if (h_status) memcpy(h_status, res, (size_t)std::min<uint64_t>(nframes, status_capacity) * sizeof(FgDecResult));
     return true;
 }
+static bool decode_frames_impl(flacgpu_ctx *c, const void *d_stream, uint64_t len, const uint64_t *h_offsets, uint32_t nframes,
+                               uint32_t channels_hint, uint32_t bps_hint, void *d_pcm, uint64_t cap_samples, int interleave,
+                               FgDecResult *h_status, std::vector<FgDecFrame> *h_frames, flacgpu_decode_stats *st,
+                               bool offsets_on_device = false, uint64_t first_number = 0, uint64_t *d_offsets_out = nullptr,
+                               DecDetail *detail = nullptr, uint64_t status_capacity = ~0ull, const FgDecRange *h_ranges = nullptr,
+                               uint32_t nranges = 0)
+{
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    // (at most three attempts: the first, one with events in place of the words in memory, one with 32-bit planes)
+    for (int attempt = 0; attempt < 3; attempt++) {
+        bool again = false;
+        if (decode_frames_once(c, d_stream, len, h_offsets, nframes, channels_hint, bps_hint, d_pcm, cap_samples, interleave, h_status, h_frames, st,
+                               offsets_on_device, first_number, d_offsets_out, detail, status_capacity, h_ranges, nranges, &again)) return true;
+        if (!again) return false;
+    }
+    fg_set_error("decode call did not settle after three attempts");
+    return false;
+}
+
 
 extern "C" int flacgpu_decode_frames_dev(flacgpu_ctx *ctx, const void *d_stream, uint64_t len, const uint64_t *d_frame_offsets,
                                          uint32_t nframes, uint32_t channels_hint, uint32_t bps_hint, void *d_pcm,

@@ -491,6 +491,7 @@ sys.path.insert(0, %r)
 from pyflac_amd import batch, synth
 ctx = batch.Context(0)
 res = []
+late = []
 pcm = synth.config2_stereo16(3.0, 21)
 for level, bs, damage in ((5, 4096, None), (8, 1152, None), (5, 4096, 'header'), (5, 4096, 'payload'), (5, 4096, 'cut'), (3, 4095, None)):
     s = batch.settings(level, 2, 16, 48000, bs, bs != 4095)
@@ -503,7 +504,9 @@ for level, bs, damage in ((5, 4096, None), (8, 1152, None), (5, 4096, 'header'),
     if damage == 'cut': data = data[:int(o[est.nblocks - 1]) + 20].clone()     # the last frame cut short
     dec, status, dst = ctx.decode_stream(data, 2, 16, t.shape[0], nframes=est.nblocks)
     res.append([hashlib.sha256(dec.cpu().numpy().tobytes()).hexdigest(), status[:, 0].tolist(), int(dst.total_samples)])
+    late.append(int(dst.join_late_workgroups))
 print('RESULT ' + json.dumps(res))
+print('LATE ' + json.dumps(late))
 '''
 
 
@@ -541,6 +544,27 @@ def test_fork_and_join_through_words_in_memory_equal_the_events_and_survive_a_ti
         line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
         outs.append(json.loads(line[7:]))
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_the_join_word_arriving_late_is_waited_for_and_the_tables_behind_it_are_the_final_ones():
+    """Round 6: the restore kernel's wait for its join word made to turn.  FLACGPU_DEC_DELAY_US (test-hooks build) queues a wave
+    that idles for 300 us in front of the CRC pass and in front of header pass + scan on their side streams, so that the restore
+    kernel -- queued behind the parser on the main stream, which does not wait for them -- starts while the frame table, the block
+    offsets and the CRC verdicts are not there yet.  Its workgroups must wait (flacgpu_decode_stats.join_late_workgroups > 0), take
+    their acquire fence, and then read final tables: same samples and the same status words, damaged streams included, as a run
+    that joins through events (FLACGPU_DEC_GATE=0).  A run with the delay and events checks the hook itself changes nothing."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs, lates = [], []
+    for gate, delay in (('1', '300'), ('0', '0'), ('0', '300'), ('1', '0')):
+        env = dict(os.environ, FLACGPU_DEC_GATE=gate, FLACGPU_DEC_DELAY_US=delay, PYFLAC_AMD_TESTHOOKS='1')
+        p = subprocess.run([sys.executable, '-c', _SELF_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads([l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1][7:]))
+        lates.append(json.loads([l for l in p.stdout.splitlines() if l.startswith('LATE ')][-1][5:]))
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert all(n > 0 for n in lates[0]), lates[0]          # every call of the delayed run had workgroups that waited
+    assert not any(lates[1]) and not any(lates[2])         # (events: the word is not used)
 
 
 def test_a_fresh_context_whose_first_decode_is_small_after_another_context_left_its_memory_behind():

@@ -55,13 +55,16 @@ for k in sorted(set(fetch) | set(write) | set(valu)):
     if enc(k) or dec(k):
         rows[k] = {'FETCH_SIZE_KiB_raw': round(fetch.get(k, 0.0), 1), 'WRITE_SIZE_KiB_raw': round(write.get(k, 0.0), 1),
                    'traffic_bytes': int(fetch.get(k, 0.0) * 2048 + write.get(k, 0.0) * 1024), 'valu_insts': int(valu.get(k, 0))}
-# the build the passes ran on: the collect run leaves flacgpu_build_id() of the library on the GPU box in build_id.txt (argument 6)
-bid = open(sys.argv[6]).read().strip() if len(sys.argv) > 6 and os.path.exists(sys.argv[6]) else None
-if not bid:
+# the build the passes ran on: the collect run leaves the ids of the library on the GPU box in build_id.txt (argument 6): one line
+# "build kernel host" (round 6; a file with one word is a round-5 build id)
+ids = open(sys.argv[6]).read().split() if len(sys.argv) > 6 and os.path.exists(sys.argv[6]) else []
+if not ids:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from pyflac_amd import _lib
-    bid = _lib.lib().flacgpu_build_id().decode()
+    ids = [_lib.lib().flacgpu_build_id().decode(), _lib.lib().flacgpu_kernel_id().decode(), _lib.lib().flacgpu_host_id().decode()]
+bid = ids[0]
 out = {'workload': workload, 'blocks': blocks, 'level': level, 'fetch_correction': 2.0, 'build_id': bid,
+       'kernel_id': ids[1] if len(ids) > 1 else None, 'host_id': ids[2] if len(ids) > 2 else None,
        'encode_traffic_bytes_per_launch': sum(r['traffic_bytes'] for k, r in rows.items() if enc(k)),
        'decode_traffic_bytes_per_launch': sum(r['traffic_bytes'] for k, r in rows.items() if dec(k)),
        'encode_valu_insts_per_launch': sum(r['valu_insts'] for k, r in rows.items() if enc(k)),
