@@ -143,7 +143,26 @@ def lib():
             import sys
             sys.stderr.write('pyflac_amd: FLACGPU_LIBRARY override: %s (build %s, flags %d)\n' %
                              (LIB_PATH, _lib.flacgpu_build_id().decode(), _lib.flacgpu_build_flags()))
+        ignored = ignored_selectors(os.environ, _lib.flacgpu_build_flags())
+        if ignored:
+            import sys
+            sys.stderr.write('pyflac_amd: %s set, but %s is a release build and reads none of them (FLACGPU_DEVICE only): use the '
+                             'test-hooks library (PYFLAC_AMD_TESTHOOKS=1) for selectors, a `make TUNING=1` build for experiments\n' %
+                             (', '.join(ignored), os.path.basename(LIB_PATH)))
     return _lib
+
+
+# what the release library itself reads, and what this module reads to pick a library
+_READ_BY_EVERY_BUILD = ('FLACGPU_DEVICE', 'FLACGPU_LIBRARY', 'FLACGPU_ALLOW_LIBRARY_OVERRIDE')
+
+
+def ignored_selectors(environ, build_flags):
+    """The FLACGPU_* variables of `environ` that a library with these flacgpu_build_flags() silently ignores: a release build
+    (neither bit 0, tuning, nor bit 2, test hooks) reads FLACGPU_DEVICE and nothing else (csrc/fg_types.h fg_sel / fg_tune).  A script
+    that sets FLACGPU_GROUPS=1 for the release library measures the default path and believes otherwise."""
+    if build_flags & 5:
+        return []
+    return sorted(k for k in environ if k.startswith('FLACGPU_') and k not in _READ_BY_EVERY_BUILD)
 
 
 def testhooks_lib():

@@ -274,3 +274,14 @@ def test_reader_replay_ends_when_a_refill_falls_just_behind_a_damaged_sync_code(
         errs, frames = _refwalk(L, bytes(data), read_size)
         assert (16, 16) not in frames and (0, 16) in frames and (32, 16) in frames, read_size
         assert errs.count(2) in (1, 2) and len(errs) <= 6, (read_size, errs)
+
+
+def test_a_release_build_names_the_selectors_it_ignores():
+    """scripts that set a kernel selector for the release library measured the default path.  pyflac_amd._lib
+    warns on stderr; the rule itself: a build with neither the tuning nor the test-hooks bit reads FLACGPU_DEVICE only."""
+    from pyflac_amd import _lib
+    env = {'FLACGPU_GROUPS': '1', 'FLACGPU_DEVICE': '0', 'FLACGPU_DEC_GATE': '0', 'PATH': '/bin', 'FLACGPU_LIBRARY': 'x'}
+    assert _lib.ignored_selectors(env, 0) == ['FLACGPU_DEC_GATE', 'FLACGPU_GROUPS']
+    assert _lib.ignored_selectors(env, 4) == [] and _lib.ignored_selectors(env, 1) == []
+    assert _lib.ignored_selectors({'FLACGPU_DEVICE': '1'}, 0) == []
+    assert not (_lib.lib().flacgpu_build_flags() & 5)          # (the library in the tree is the release build)
