@@ -5,7 +5,6 @@ import ctypes
 import os
 import subprocess
 import sys
-import types
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -22,17 +21,18 @@ def load():
     if not os.path.exists(SHIM):
         build()
     shim = ctypes.CDLL(SHIM, mode=ctypes.RTLD_GLOBAL)
-    stub = types.ModuleType('torch')
-    stub._gfx950emu_stub = True
-    sys.modules['torch'] = stub
-    if ROOT not in sys.path:
-        sys.path.insert(0, ROOT)
-    from pyflac_amd import _lib
-    L = _lib.lib()
     shim.gfx950emu_stats_json.restype = ctypes.c_char_p
     shim.gfx950emu_last_fault.restype = ctypes.c_char_p
     shim.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     shim.hipFree.argtypes = [ctypes.c_void_p]
     shim.gfx950emu_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     shim.gfx950emu_unregister.argtypes = [ctypes.c_void_p]
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
+    import faketorch
+    faketorch.install(shim)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from pyflac_amd import _lib
+    L = _lib.lib()
     return shim, L

@@ -434,7 +434,8 @@ static bool exec_valu(Wave &w, const Inst &in)
     I1(v_mov_b32, a)
     I1(v_accvgpr_read_b32, a) I1(v_accvgpr_write_b32, a) I1(v_accvgpr_mov_b32, a)
     case OP_v_mov_b64: VLOOP x.W64(l, x.S64(0, l)); break;
-    I2(v_add_u32, a + b) I2(v_sub_u32, a - b) I2(v_subrev_u32, b - a)
+    // (clamp on the unsigned add / subtract saturates: what `x > 1 ? x - 1 : 0` compiles to)
+    I2(v_add_u32, (in.clamp && a + b < a) ? 0xFFFFFFFFu : a + b) I2(v_sub_u32, (in.clamp && b > a) ? 0u : a - b) I2(v_subrev_u32, (in.clamp && a > b) ? 0u : b - a)
     I2(v_mul_lo_u32, a * b) I2(v_mul_hi_u32, ((u64)a * b) >> 32) I2(v_mul_hi_i32, (u64)((i64)(i32)a * (i32)b) >> 32)
     I2(v_mul_i32_i24, (i64)sext24(a) * sext24(b)) I2(v_mul_u32_u24, (u64)(a & 0xFFFFFF) * (b & 0xFFFFFF))
     I2(v_mul_hi_i32_i24, (u64)((i64)sext24(a) * sext24(b)) >> 32) I2(v_mul_hi_u32_u24, ((u64)(a & 0xFFFFFF) * (b & 0xFFFFFF)) >> 32)
@@ -478,8 +479,9 @@ static bool exec_valu(Wave &w, const Inst &in)
                                 for (int k = 0; k < 8; k++) if (in.bitop3 >> k & 1) r |= ((k & 4) ? a : ~a) & ((k & 2) ? b : ~b) & ((k & 1) ? c : ~c);
                                 x.W(l, op == OP_v_bitop3_b16 ? (r & 0xFFFF) : r); } break;
     I3(v_dot2_i32_i16, (u32)((i32)(i16)a * (i32)(i16)b + (i32)(i16)(a >> 16) * (i32)(i16)(b >> 16)) + c)
+    // (v_pk_mov_b32: D.lo = op_sel[0] ? S0.hi : S0.lo, D.hi = op_sel[1] ? S1.hi : S1.lo)
     case OP_v_pk_mov_b32: VLOOP { const u64 a = x.S64(0, l), b = x.S64(1, l);
-                                   const u32 lo = (in.op_sel & 1) ? (u32)(a >> 32) : (u32)a, hi = (in.op_sel_hi & 2) ? (u32)(b >> 32) : (u32)b; x.W64(l, (u64)lo | ((u64)hi << 32)); } break;
+                                   const u32 lo = (in.op_sel & 1) ? (u32)(a >> 32) : (u32)a, hi = (in.op_sel & 2) ? (u32)(b >> 32) : (u32)b; x.W64(l, (u64)lo | ((u64)hi << 32)); } break;
     I2(v_lshlrev_b16, (u16)((u16)b << (a & 15))) I2(v_lshrrev_b16, (u16)((u16)b >> (a & 15))) I2(v_ashrrev_i16, (u16)((i16)b >> (a & 15)))
     I2(v_add_u16, (u16)(a + b)) I2(v_sub_u16, (u16)(a - b)) I2(v_mul_lo_u16, (u16)(a * b)) I3(v_mad_u16, (u16)(a * b + c))
     I2(v_max_u16, std::max((u16)a, (u16)b)) I2(v_min_u16, std::min((u16)a, (u16)b)) I2(v_max_i16, (u16)std::max((i16)a, (i16)b)) I2(v_min_i16, (u16)std::min((i16)a, (i16)b))
@@ -922,6 +924,16 @@ bool emu_step(Wave &w)
     else if (name[0] == 'b') ok = true;         // buffer_inv / buffer_wbl2: memory is one coherent array here
     else { ok = exec_mem(w, in); if (st) st->vmem++; }
     if (!ok || w.state == W_FAULT) { w.state = W_FAULT; return false; }
+    if (w.trace_lane >= 0) {
+        // (GFX950EMU_WATCH: one line per instruction of the watched wave -- what it wrote, for one lane)
+        char b[256]; int n = snprintf(b, sizeof b, "T %6u %-28s exec %016llx vcc %016llx scc %d |", in.line, name, (unsigned long long)w.exec, (unsigned long long)w.vcc, (int)w.scc);
+        if (in.no > 0) {
+            const Opnd &d0 = in.o[0];
+            if (d0.kind == K_VGPR) for (int k = 0; k < d0.n && k < 4; k++) n += snprintf(b + n, sizeof b - n, " v%u=%08x", d0.reg + k, w.v[(size_t)(d0.reg + k) * 64 + w.trace_lane]);
+            else if (d0.kind == K_SGPR) for (int k = 0; k < d0.n && k < 4; k++) n += snprintf(b + n, sizeof b - n, " s%u=%08x", d0.reg + k, w.s[d0.reg + k]);
+        }
+        fprintf(stderr, "%s\n", b);
+    }
     if (!jumped) w.pc++;
     return true;
 }

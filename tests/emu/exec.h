@@ -33,6 +33,7 @@ struct Wave {
     u8 gpr_idx_mode = 0;            // s_set_gpr_idx_on
     u32 gpr_idx = 0;
     u32 nv = 0, na = 0;
+    int trace_lane = -1;            // GFX950EMU_WATCH
 };
 struct KStats {
     u64 wave_insts = 0, valu = 0, valu_lanes = 0, salu = 0, smem = 0, vmem = 0, lds = 0, mfma = 0, branch = 0, waves = 0;
@@ -44,6 +45,7 @@ struct Dispatch {
     u32 grid[3] = {1, 1, 1}, block[3] = {1, 1, 1};      // grid in workgroups
     u32 lds_bytes = 0;
     std::vector<u8> kernarg;
+    std::vector<u8> packet;                              // an hsa_kernel_dispatch_packet_t for kernels that read it
     u64 next_wg = 0, total_wgs = 0, finished_wgs = 0;
     std::vector<std::unique_ptr<WG>> wgs;                // resident
     std::vector<std::unique_ptr<Wave>> waves;            // resident

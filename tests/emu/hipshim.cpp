@@ -50,6 +50,7 @@ struct Global {
     u64 quantum = 128;
     size_t max_waves = 4096;
     bool poison = true, trace = false;
+    std::string watch_kernel; u64 watch_wg = 0; u32 watch_wave = 0; int watch_lane = 0;     // GFX950EMU_WATCH=substring:wg:wave:lane
 };
 Global &G() { static Global *g = new Global; return *g; }
 thread_local int t_last_error = 0;
@@ -104,7 +105,7 @@ static void init_wave(Dispatch &d, WG &wg, Wave &w, u32 wave_idx, u32 threads_in
     u32 s = 0;
     const u32 props = ki.props;
     if (props & 1) s += 4;                                         // private segment buffer (not used with architected scratch)
-    if (props & 2) { w.s[s] = 0; w.s[s + 1] = 0; s += 2; }         // dispatch packet
+    if (props & 2) { const u64 pa = (u64)(uintptr_t)d.packet.data(); w.s[s] = (u32)pa; w.s[s + 1] = (u32)(pa >> 32); s += 2; }         // dispatch packet
     if (props & 4) s += 2;                                         // queue
     if (props & 8) { const u64 ka = (u64)(uintptr_t)d.kernarg.data(); w.s[s] = (u32)ka; w.s[s + 1] = (u32)(ka >> 32); s += 2; }
     if (props & 16) s += 2;
@@ -131,6 +132,7 @@ static void activate(Dispatch &d)
         for (u32 k = 0; k < nw; k++) {
             std::unique_ptr<Wave> w(new Wave);
             init_wave(d, *wg, *w, k, threads);
+            if (!g.watch_kernel.empty() && d.ki->name.find(g.watch_kernel) != std::string::npos && id == g.watch_wg && k == g.watch_wave) w->trace_lane = g.watch_lane;
             wg->members.push_back(w.get());
             d.waves.push_back(std::move(w));
             if (d.stats) d.stats->waves++;
@@ -220,6 +222,7 @@ static void device_main()
                     if (d->failed && !g.sticky_error) { g.sticky_error = hipErrorIllegalAddress; g.sticky_msg = d->error; }
                     if (g.trace) fprintf(stderr, "gfx950emu: done   %s\n", d->ki->name.c_str());
                     a.first->running = nullptr;
+                    del_range(d->kernarg.data()); del_range(d->packet.data());
                     delete d;
                     fin = true;
                 }
@@ -238,6 +241,13 @@ static void ensure_device()
     if (const char *q = getenv("GFX950EMU_MAX_WAVES")) g.max_waves = (size_t)atoll(q);
     if (const char *q = getenv("GFX950EMU_POISON")) g.poison = atoi(q) != 0;
     g.trace = getenv("GFX950EMU_TRACE") != nullptr;
+    if (const char *wv = getenv("GFX950EMU_WATCH")) {
+        std::string t = wv; unsigned long long a = 0; unsigned b = 0; int c = 0;
+        const size_t p1 = t.find(':');
+        g.watch_kernel = t.substr(0, p1);
+        if (p1 != std::string::npos) sscanf(t.c_str() + p1 + 1, "%llu:%u:%d", &a, &b, &c);
+        g.watch_wg = a; g.watch_wave = b; g.watch_lane = c;
+    }
     g.dev = std::thread(device_main);
     g.dev.detach();
 }
@@ -379,8 +389,19 @@ hipError_t hipLaunchKernel(const void *hostFunction, dim3 gridDim, dim3 blockDim
         // (remainders, global offsets, printf / hostcall buffers, queue pointers: zero)
     }
     {
+        // hsa_kernel_dispatch_packet_t: workgroup sizes (u16 at 4, 6, 8), grid sizes in work-items (u32 at 12, 16, 20), segment sizes, kernarg address
+        d->packet.assign(64, 0);
+        u8 *pk = d->packet.data();
+        const u16 wsz[3] = {(u16)blockDim.x, (u16)blockDim.y, (u16)blockDim.z};
+        const u32 gsz[3] = {gridDim.x * blockDim.x, gridDim.y * blockDim.y, gridDim.z * blockDim.z};
+        memcpy(pk + 4, wsz, 6); memcpy(pk + 12, gsz, 12);
+        memcpy(pk + 24, &ki.scratch, 4); memcpy(pk + 28, &d->lds_bytes, 4);
+        const u64 ka = (u64)(uintptr_t)d->kernarg.data(); memcpy(pk + 40, &ka, 8);
+    }
+    {
         std::lock_guard<std::mutex> lk(g.mu);
-        add_range(d->kernarg.data(), d->kernarg.size());      // (stays registered: addresses are not reused while the table is small)
+        add_range(d->packet.data(), d->packet.size());
+        add_range(d->kernarg.data(), d->kernarg.size());      // (until the dispatch retires)
         KStats &st = g.stats[fr.name];
         st.launches++;
         d->stats = &st;
