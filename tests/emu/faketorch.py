@@ -203,6 +203,14 @@ class Tensor:
     def __add__(self, o): return self._bin(o, lambda a, b: a + b)
     def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
     def __and__(self, o): return self._bin(o, lambda a, b: a & b)
+    def __or__(self, o): return self._bin(o, lambda a, b: a | b)
+    def __xor__(self, o): return self._bin(o, lambda a, b: a ^ b)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    def __lshift__(self, o): return self._bin(o, lambda a, b: a << b)
+    def __neg__(self): return Tensor(np.asarray(-self._host()), False)
+    def __invert__(self): return Tensor(np.asarray(~self._host()), False)
+    __radd__ = __add__
+    __rmul__ = __mul__
     def __rshift__(self, o): return self._bin(o, lambda a, b: a >> b)
     __hash__ = object.__hash__
 

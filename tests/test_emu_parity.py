@@ -1,0 +1,69 @@
+"""The compiled gfx950 kernels of libflacgpu.so, executed WITHOUT a GPU on the ISA-level emulator of tests/emu (test infrastructure,
+like oracle/), compared with the CPU oracle: the library's own host code launches the instructions hipcc emitted -- inline assembly,
+matrix-core autocorrelation, the wave-parallel Rice parser, the packed-history restore chain -- on an interpreter that stands in for
+the HIP runtime in a child process.  Not a GPU parity test (tests/test_gpu_*.py, -m gpu, are those; the emulator has no caches, no
+memory model and no timing): what it shows is that the code objects in the tree compute the reference's bytes, on every checkout,
+also when no GPU is at hand -- and it runs the paths a GPU only takes under rare timing (the join word arriving late, its wait running
+out).  Each group is one child process; sizes are chosen so that the whole file takes a minute or two on the build container."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = os.path.join(ROOT, 'tests', 'emu', 'parity_cases.py')
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+pytestmark = pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='the emulator reads the code objects through llvm-objdump')
+
+
+def _run(*args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.pop('PYFLAC_AMD_TESTHOOKS', None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, CASES] + [str(a) for a in args], env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = [l for l in p.stdout.splitlines() if l.startswith('RESULT ')][-1]
+    r = json.loads(line[7:])
+    assert 'fault' not in r, r['fault']
+    return r
+
+
+@pytest.mark.parametrize('level,seconds,channels,bps', [(5, 0.3, 2, 16), (0, 0.3, 1, 16), (8, 0.2, 2, 24), (3, 0.25, 2, 16)])
+def test_drop_in_classes_on_the_emulated_kernels(level, seconds, channels, bps):
+    """StreamEncoder's frames equal the oracle's byte for byte; StreamDecoder (16 bit) / the batch decoder (24 bit) return the input."""
+    r = _run('dropin', level, seconds, channels, bps)
+    assert r['finish'] and r['frames_equal_oracle'] and r['decoded_equals_input'], r
+
+
+def test_batch_entry_points_and_the_join_through_the_word_in_memory():
+    """flacgpu_encode_streams == oracle; flacgpu_decode_stream_dev from the bytes alone == input, twice over (the second call starts
+    from the index tables the first one emptied behind its end)."""
+    r = _run('batch', 5, 1.0, 4096)
+    assert r['encode_equals_oracle'] and r['direct_path'] == 1, r
+    assert all(c['equal'] and c['status_max'] == 0 and c['plane_bits'] == 16 and c['generic'] == 0 for c in r['calls']), r
+
+
+def test_the_join_word_arriving_late_timing_out_and_replaced_by_events_give_the_same_samples():
+    """Round 6's join on paths a GPU takes only under rare timing.  With FLACGPU_DEC_DELAY_US (test-hooks build) a wave idles
+    in front of the side streams' kernels, so the restore kernel starts first and its workgroups WAIT for the word (join_late_workgroups
+    > 0); with FLACGPU_DEC_GATE=2 the word is never raised, the wait runs out, the workgroup writes nothing and the host repeats the call
+    with events; FLACGPU_DEC_GATE=0 joins through events from the start.  Same samples every way."""
+    base = _run('batch', 5, 0.6, 4096, env={'PYFLAC_AMD_TESTHOOKS': '1', 'FLACGPU_DEC_GATE': '0'})
+    late = _run('batch', 5, 0.6, 4096, env={'PYFLAC_AMD_TESTHOOKS': '1', 'FLACGPU_DEC_DELAY_US': '300'})
+    dead = _run('batch', 5, 0.6, 4096, env={'PYFLAC_AMD_TESTHOOKS': '1', 'FLACGPU_DEC_GATE': '2'}, timeout=1800)
+    for r in (base, late, dead):
+        assert r['encode_equals_oracle'] and all(c['equal'] and c['status_max'] == 0 for c in r['calls']), r
+    assert [c['sha'] for c in base['calls']] == [c['sha'] for c in late['calls']] == [c['sha'] for c in dead['calls']]
+    assert all(c['late'] > 0 for c in late['calls']), late          # the wait did turn
+    assert not any(c['late'] for c in base['calls'])                # (events: the word is not looked at)
+
+
+@pytest.mark.parametrize('first', [0, 40])
+def test_seeded_corpus_cases_on_the_emulated_kernels(first):
+    """tests/fuzzgen.py seeds (1-8 channels, 8-32 bit, all levels, odd block sizes, ragged tails, limit_min_bitrate): the batch encoder's
+    bytes equal the oracle's, the decoder returns the input.  Cases above 60 000 samples are left to the GPU runs."""
+    r = _run('fuzz', first, 40)
+    assert r['ran'] >= 20 and r['bad'] == [], r
