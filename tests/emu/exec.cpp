@@ -907,6 +907,7 @@ bool emu_step(Wave &w)
     KStats *st = w.d->stats;
     const char *name = op_name(in.op);
     if (st) st->wave_insts++;
+    if (w.d->pc_hist) (*w.d->pc_hist)[w.pc]++;
     if (in.op == OP_s_endpgm || in.op == OP_s_code_end) { w.state = W_DONE; return false; }
     if (in.op == OP_s_barrier) {
         w.pc++;

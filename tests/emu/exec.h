@@ -52,6 +52,7 @@ struct Dispatch {
     bool failed = false;
     std::string error;
     KStats *stats = nullptr;
+    std::vector<u64> *pc_hist = nullptr;                 // GFX950EMU_PROFILE: executions per instruction of the code object
 };
 
 // one instruction of one wave; false when the wave cannot go on right now (barrier, done, fault)

@@ -304,6 +304,14 @@ cuda.get_device_name = lambda *a, **k: 'gfx950emu (ISA-level emulation of gfx950
 cuda.empty_cache = lambda: None
 
 
+# (pyflac_amd/shard.py imports torch.distributed at the top; a single emulated process never initialises it)
+distributed = types.ModuleType('torch.distributed')
+distributed.is_available = lambda: False
+distributed.is_initialized = lambda: False
+distributed.get_rank = lambda *a, **k: 0
+distributed.get_world_size = lambda *a, **k: 1
+
+
 def install(shim):
     """Make this module `torch` for the process."""
     import sys
@@ -312,4 +320,5 @@ def install(shim):
     mod = sys.modules[__name__]
     sys.modules['torch'] = mod
     sys.modules['torch.cuda'] = cuda
+    sys.modules['torch.distributed'] = distributed
     return mod

@@ -50,6 +50,7 @@ struct Global {
     u64 quantum = 128;
     size_t max_waves = 4096;
     bool poison = true, trace = false;
+    std::string profile_kernel; std::map<std::string, std::pair<CodeObject *, std::vector<u64>>> profiles;     // GFX950EMU_PROFILE=substring
     std::string watch_kernel; u64 watch_wg = 0; u32 watch_wave = 0; int watch_lane = 0;     // GFX950EMU_WATCH=substring:wg:wave:lane
 };
 Global &G() { static Global *g = new Global; return *g; }
@@ -241,6 +242,7 @@ static void ensure_device()
     if (const char *q = getenv("GFX950EMU_MAX_WAVES")) g.max_waves = (size_t)atoll(q);
     if (const char *q = getenv("GFX950EMU_POISON")) g.poison = atoi(q) != 0;
     g.trace = getenv("GFX950EMU_TRACE") != nullptr;
+    if (const char *pk = getenv("GFX950EMU_PROFILE")) g.profile_kernel = pk;
     if (const char *wv = getenv("GFX950EMU_WATCH")) {
         std::string t = wv; unsigned long long a = 0; unsigned b = 0; int c = 0;
         const size_t p1 = t.find(':');
@@ -303,6 +305,24 @@ extern "C" const char *gfx950emu_stats_json(void)
     }
     out += "}";
     return out.c_str();
+}
+// GFX950EMU_PROFILE=<substring of a kernel name>: executions per instruction, written as "count line-of-the-disassembly mnemonic" rows
+// (the disassembly: $GFX950EMU_CACHE/<hash>.s), one file per kernel
+extern "C" int gfx950emu_write_profiles(const char *dir)
+{
+    Global &g = G();
+    std::lock_guard<std::mutex> lk(g.mu);
+    int n = 0;
+    for (auto &p : g.profiles) {
+        char path[512]; snprintf(path, sizeof path, "%s/profile_%d.txt", dir, n++);
+        FILE *f = fopen(path, "w");
+        if (!f) continue;
+        fprintf(f, "# %s\n", p.first.c_str());
+        const auto &h = p.second.second;
+        for (size_t i = 0; i < h.size(); i++) if (h[i]) fprintf(f, "%llu %u %s\n", (unsigned long long)h[i], p.second.first->insts[i].line, op_name(p.second.first->insts[i].op));
+        fclose(f);
+    }
+    return n;
 }
 extern "C" const char *gfx950emu_last_fault(void) { static std::string s; Global &g = G(); std::lock_guard<std::mutex> lk(g.mu); s = g.sticky_msg; return s.c_str(); }
 extern "C" void gfx950emu_clear_fault(void) { Global &g = G(); std::lock_guard<std::mutex> lk(g.mu); g.sticky_error = 0; g.sticky_msg.clear(); }
@@ -405,6 +425,12 @@ hipError_t hipLaunchKernel(const void *hostFunction, dim3 gridDim, dim3 blockDim
         KStats &st = g.stats[fr.name];
         st.launches++;
         d->stats = &st;
+        if (!g.profile_kernel.empty() && fr.name.find(g.profile_kernel) != std::string::npos) {
+            auto &pr = g.profiles[fr.name];
+            pr.first = fr.co;
+            if (pr.second.size() != fr.co->insts.size()) pr.second.assign(fr.co->insts.size(), 0);
+            d->pc_hist = &pr.second;
+        }
         if (g.trace) fprintf(stderr, "gfx950emu: launch %s grid %u block %u lds %u\n", fr.name.c_str(), gridDim.x, blockDim.x, d->lds_bytes);
     }
     QOp op; op.t = QOp::KERNEL; op.d = d;

@@ -1,0 +1,55 @@
+"""Where a kernel's executed instructions are, without a GPU: the headline shape on the ISA-level emulator (tests/emu) with a count
+per instruction, folded into basic blocks of the disassembly and listed by weight.
+usage: python tools/emu_profile.py <substring of the kernel name> [--blocks 8] [--level 5] [--bps 16] [--top 25]"""
+import argparse, collections, os, re, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu')); sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument('kernel'); ap.add_argument('--blocks', type=int, default=8); ap.add_argument('--level', type=int, default=5)
+ap.add_argument('--bps', type=int, default=16); ap.add_argument('--top', type=int, default=25); ap.add_argument('--decode', action='store_true')
+args = ap.parse_args()
+os.environ['GFX950EMU_PROFILE'] = args.kernel
+import emurun
+shim, L = emurun.load()
+import numpy as np, torch
+from pyflac_amd import batch, synth
+sr = 48000 if args.bps == 16 else 96000
+n = args.blocks * 4096
+pcm = (synth.config2_stereo16(n / sr + 0.01, 0, sr) if args.bps == 16 else synth.config4_stereo24(n / sr + 0.01, 1, sr))[:n]
+ctx = batch.Context(0)
+s = batch.settings(args.level, 2, args.bps, sr, 4096, True)
+t = torch.from_numpy(pcm.astype(np.int32)).cuda()
+out, offs, est = ctx.encode(s, t)
+if args.decode:
+    ctx.decode_stream(out[:est.total_bytes].clone(), 2, args.bps, n, nframes=est.nblocks)
+torch.cuda.synchronize()
+d = tempfile.mkdtemp()
+shim.gfx950emu_write_profiles.argtypes = [__import__('ctypes').c_char_p]
+k = shim.gfx950emu_write_profiles(d.encode())
+cache = os.environ.get('GFX950EMU_CACHE', '/tmp/gfx950emu_cache')
+for i in range(k):
+    rows = open(os.path.join(d, 'profile_%d.txt' % i)).read().splitlines()
+    name = rows[0][2:]
+    cnt = {int(r.split()[1]): int(r.split()[0]) for r in rows[1:]}
+    # the disassembly that holds this kernel
+    src = None
+    for f in os.listdir(cache):
+        if f.endswith('.s') and ('<%s>:' % name) in open(os.path.join(cache, f)).read():
+            src = open(os.path.join(cache, f)).read().splitlines()
+            break
+    total = sum(cnt.values())
+    print('== %s\n   %d wave-instructions executed (%d a block)' % (name[:150], total, total // args.blocks))
+    # basic blocks: runs of consecutive lines with the same count
+    lines = sorted(cnt)
+    runs, cur = [], [lines[0]]
+    for a, b in zip(lines, lines[1:]):
+        if b == a + 1 and cnt[b] == cnt[a] and not re.search(r's_cbranch|s_branch|s_endpgm|s_barrier', src[a - 1]):
+            cur.append(b)
+        else:
+            runs.append(cur); cur = [b]
+    runs.append(cur)
+    runs.sort(key=lambda r: -cnt[r[0]] * len(r))
+    for r in runs[:args.top]:
+        w = cnt[r[0]] * len(r)
+        mix = collections.Counter(src[l - 1].split()[0].split('_e32')[0].split('_e64')[0] for l in r)
+        print('%6.2f%%  lines %6d-%-6d  %4d instructions x %8d   %s' % (100.0 * w / total, r[0], r[-1], len(r), cnt[r[0]], ' '.join('%s:%d' % kv for kv in mix.most_common(7))))
