@@ -6,9 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu')); sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument('kernel'); ap.add_argument('--blocks', type=int, default=8); ap.add_argument('--level', type=int, default=5)
-ap.add_argument('--bps', type=int, default=16); ap.add_argument('--top', type=int, default=25); ap.add_argument('--decode', action='store_true')
+ap.add_argument('--bps', type=int, default=16); ap.add_argument('--top', type=int, default=25); ap.add_argument('--decode', action='store_true'); ap.add_argument('--lib', default=None, help='another build of the library (e.g. one with -gline-tables-only: gpurun_exp/libflacgpu_gl.so)'); ap.add_argument('--lines', action='store_true', help='fold the counts by source line (needs a library built with line tables)')
 args = ap.parse_args()
 os.environ['GFX950EMU_PROFILE'] = args.kernel
+if args.lib:
+    os.environ['FLACGPU_ALLOW_LIBRARY_OVERRIDE'] = '1'; os.environ['FLACGPU_LIBRARY'] = os.path.abspath(args.lib)
+    os.environ['GFX950EMU_CACHE'] = '/tmp/gfx950emu_cache_' + os.path.basename(args.lib)      # (its own disassembly cache: kernel names repeat across builds)
 import emurun
 shim, L = emurun.load()
 import numpy as np, torch
@@ -38,6 +41,30 @@ for i in range(k):
             src = open(os.path.join(cache, f)).read().splitlines()
             break
     total = sum(cnt.values())
+    if args.lines:
+        import subprocess
+        elf = None
+        for f in os.listdir(cache):
+            if f.endswith('.s') and ('<%s>:' % name) in open(os.path.join(cache, f)).read():
+                elf = os.path.join(cache, f[:-2] + '.elf')
+        txt = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '-d', '-l', '--mcpu=gfx950', elf], capture_output=True, text=True).stdout.splitlines()
+        # address -> source line from the -l listing; line of the plain listing -> address
+        addr_src, cur = {}, '?'
+        for ln in txt:
+            if ln.startswith('; ') and re.search(r':\d+$', ln.strip()):
+                cur = ln[2:].strip()
+            elif ln.startswith('\t') and '//' in ln:
+                m = re.search(r'// ([0-9A-F]+):', ln)
+                if m:
+                    addr_src[int(m.group(1), 16)] = cur
+        by = collections.Counter()
+        for l, c in cnt.items():
+            m = re.search(r'// ([0-9A-F]+):', src[l - 1])
+            by[addr_src.get(int(m.group(1), 16), '?') if m else '?'] += c
+        print('== %s\n   %d wave-instructions executed (%d a block), by source line:' % (name[:150], total, total // args.blocks))
+        for k2, v in by.most_common(args.top):
+            print('%6.2f%%  %9d  %s' % (100.0 * v / total, v, k2.replace('/tmp/fgvar_gl/', '')))
+        continue
     print('== %s\n   %d wave-instructions executed (%d a block)' % (name[:150], total, total // args.blocks))
     # basic blocks: runs of consecutive lines with the same count
     lines = sorted(cnt)
