@@ -1839,21 +1839,50 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 //     order is chosen from k = 4 down with <=, and every order's estimate comes from the order-0 total.
 //   * LPC: the fp64 FIR of the 24-bit path -- products below 2^46, sums of twelve below 2^50 --, |residual| < 2^31 or the
 //     candidate is dropped (libFLAC's _limit_residual FIR).
-template <bool MS, int NCH, int MAXO>
+// Round 6: the ragged lane geometry too (RAG: tail blocks, odd block sizes -- PipeGeo; 23 % of the fuzz corpus's 32-bit blocks went
+// to the generic kernel for want of it).  As in pipe_eval_cand<..., RAG>: every lane walks the `base` samples all working lanes
+// have, the first `extra` lanes of a group one more (ln.len), idle lanes walk whatever row 0 holds and count for nothing; the
+// samples in front of a lane lie at the end of ONE other lane's row (prv*).  One case stays with the generic kernel: a ragged block
+// of fewer than 28 bits per sample whose length past the warm-up is no multiple of four -- there the reference binary's AVX2
+// routine sums the fixed predictors' errors its own way (pipe_eval_cand has that correction for its integer forms).
+template <bool MS, int NCH, int MAXO, bool RAG>
 FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
-                            FgDebugRec *mydbg, const LDS int32_t *sL, const LDS int32_t *sR, int lane, uint32_t range_err)
+                            FgDebugRec *mydbg, const LDS int32_t *sL, const LDS int32_t *sR, int lane, uint32_t range_err, const PipeGeo &geo)
 {
     constexpr int NC = MS ? 4 : NCH;
     constexpr uint32_t PADE = PipeTypes<true>::PADE;
-    const uint32_t n = d.n, seg = n >> 6, rstr = seg + PADE;
+    const uint32_t n = d.n, seg = RAG ? geo.base : n >> 6, rstr = RAG ? geo.rstr : seg + PADE;
+    (void)PADE;
+    const PipeLane ln = pipe_lane<RAG>(geo, (uint32_t)lane, seg);
     const LDS int32_t *rowL = sL + (uint32_t)lane * rstr, *rowR = sR + (uint32_t)lane * rstr;
+    const LDS int32_t *prvL = sL + ln.prow * rstr + ln.plen, *prvR = sR + ln.prow * rstr + ln.plen;      // one past the samples in front
     const uint32_t wraw = rfl(B.wasted[bi * NC + C]);
     const uint32_t wst = wraw & 0xFFu;
     const uint32_t nominal = P.bps + ((MS && C == 3) ? 1u : 0u);
     const uint32_t sb = nominal - wst;
+    if (RAG && sb < 28 && ((n - 4) & 3u) != 0) {
+        // (the reference binary's AVX2 lane sums: left to the generic kernel -- the record pipe_eval_cand writes for what it does not take)
+        if (lane == 0) {
+            FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
+            dec->bits = 0x80000000u; dec->type = 1; dec->order = 0; dec->prec = 0; dec->shift = 0; dec->porder = 0; dec->method = 0; dec->wasted = wraw;
+            FgBlockResult *r = &results[d.out_slot];
+            r->best_bits[C] = 0;
+            if (C == 0) {
+                r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
+#pragma unroll
+                for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
+                for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)d.out_slot * 4 + w] = 0;
+            }
+        }
+        return;
+    }
     const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);      // 2^-wasted
     auto samp = [&](int s) __attribute__((always_inline)) -> double { return pipe_cdbl(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, C, MS, wscale); };
-    auto hsamp = [&](int k) __attribute__((always_inline)) -> double { return samp((int)seg - k - (int)rstr); };       // k-th sample in front of the lane
+    // the k-th sample in front of this lane's first one (k >= 1)
+    auto hsamp = [&](int k) __attribute__((always_inline)) -> double {
+        if (!RAG) return samp((int)seg - k - (int)rstr);
+        return pipe_cdbl(prvL[-k], (NCH == 2) ? (int32_t)prvR[-k] : 0, C, MS, wscale);
+    };
     auto bcast0 = [&](double v) __attribute__((always_inline)) -> double {
         return __hiloint2double((int)rl((uint32_t)__double2hiint(v), 0), (int)rl((uint32_t)__double2loint(v), 0));
     };
@@ -1897,6 +1926,17 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
 #pragma unroll
             for (int kk = 0; kk < 5; kk++) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
             P0 = v; P1 = e1; P2 = e2; P3 = e3;
+        }
+        if (RAG) {
+            // the one sample more that the first lanes of a group have; idle lanes have walked over whatever row 0 holds
+            const double v = samp((int)seg);
+            const double e1 = v - P0, e2 = e1 - P1, e3 = e2 - P2, e4 = e3 - P3;
+            const double ab[5] = {__builtin_fabs(v), __builtin_fabs(e1), __builtin_fabs(e2), __builtin_fabs(e3), __builtin_fabs(e4)};
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) {
+                if (ln.len > seg) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
+                if (!ln.act) { facc[kk] = 0.0; fwarm[kk] = 0.0; fmx[kk] = 0.0; }
+            }
         }
         bool over[5];
         u64 warm0[5];
@@ -1959,7 +1999,7 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             const double x0 = pipe_cdbl(sL[0], (NCH == 2) ? (int32_t)sR[0] : 0, C, MS, wscale);
             uint32_t ne = 0;
 #pragma unroll 1
-            for (uint32_t s = 0; s < seg; s++) ne |= (samp((int)s) != x0);
+            for (uint32_t s = 0; s < seg + (RAG ? 1u : 0u); s++) ne |= ((!RAG || s < ln.len) && samp((int)s) != x0);
             constant = !__any(ne != 0);
         }
         if (mydbg && lane == 0) {
@@ -1972,7 +2012,7 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
                 const int32_t l0 = sL[0];
                 uint32_t ne = 0;
 #pragma unroll 1
-                for (uint32_t s = 0; s < seg; s++) ne |= ((int32_t)rowL[s] != l0);
+                for (uint32_t s = 0; s < seg + (RAG ? 1u : 0u); s++) ne |= ((!RAG || s < ln.len) && (int32_t)rowL[s] != l0);
                 forbid = !__any(ne != 0);
                 // ("chose CONSTANT", not "is constant": at 28 bits and more only an all-zero left channel does -- see pipe_eval_cand)
                 const uint32_t wl = rfl(B.wasted[(size_t)bi * NC]);
@@ -2048,8 +2088,17 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
 #pragma unroll
                 for (int u = 0; u < MAXO; u++) step(u, s0 + u, false);
             }
+            if (!RAG) {
 #pragma unroll
-            for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+                for (int u = 0; u < MAXO; u++) if (s0 + u < seg) step(u, s0 + u, s0 == 0);
+            }
+            else {
+                // (the rest of the lane: the common `seg` samples and the one more of the first lanes of a group; at most MAXO + 1 of them --
+                // sample s0 + u sits in history slot u mod MAXO)
+#pragma unroll
+                for (int u = 0; u <= MAXO; u++) if (s0 + u < ln.len) step(u % MAXO, s0 + u, s0 == 0);
+                if (!ln.act) { psumd = 0.0; pmaxd = 0.0; }
+            }
             };
             walk(std::false_type());
             if (__any(!(psumd < 2147483648.0))) walk(std::true_type());
@@ -2060,8 +2109,12 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
         const bool dead = __any(ovf != 0);
         uint32_t best_bits, bpo, kb, kpart;
         bool kvalid;
-        if (!pipe_rice_search_tree<true>(psum, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb, kpart, kvalid)) {
-            pipe_rice_search<true>(psum, dead, lane, n, order, sb, pmin0, pmax0, limit, best_bits, bpo, kb);
+        // (a partition must be longer than the predictor order: short blocks of the ragged geometry meet that limit, see pipe_eval_cand)
+        uint32_t pmax_p = pmax0;
+        if (RAG) while (pmax_p > 0 && (n >> pmax_p) <= order) pmax_p--;
+        const uint32_t pmin_p = pmin0 < pmax_p ? pmin0 : pmax_p;
+        if (!pipe_rice_search_tree<true>(psum, lane, n, order, sb, pmin_p, pmax_p, limit, best_bits, bpo, kb, kpart, kvalid)) {
+            pipe_rice_search<true>(psum, dead, lane, n, order, sb, pmin_p, pmax_p, limit, best_bits, bpo, kb);
             kvalid = ((uint32_t)lane & ((64u >> bpo) - 1)) == 0;
             kpart = (uint32_t)lane >> (6 - bpo);
         }
@@ -2152,10 +2205,10 @@ fg_pipe_eval_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const uint32_t range_err = xch[0] ? FG_ERR_RANGE : 0;
     FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
     // (the ragged geometry -- tail blocks, odd block sizes -- is a kernel of its own: the regular one keeps its loops and registers)
-    if constexpr (ACC64 && !RAG) {
+    if constexpr (ACC64) {
         // (32-bit streams: a block whose candidates do not fit the shifted 25-bit forms is evaluated in fp64, pipe_eval_cand_w32)
         if (P.bps == 32 && !pre_ok) {
-            pipe_eval_cand_w32<MS, NCH, MAXO>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, (const LDS int32_t *)sL, (const LDS int32_t *)sR, lane, range_err);
+            pipe_eval_cand_w32<MS, NCH, MAXO, RAG>(NC == 1 ? 0u : wv, d, bi, P, B, results, mydbg, (const LDS int32_t *)sL, (const LDS int32_t *)sR, lane, range_err, geo);
             return;
         }
     }
@@ -2521,7 +2574,7 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
     const LDS samp_t *const rowA = (NCH == 2 && c == 1) ? rowR : rowL, *const rowB = cplain ? rowA : rowR;
     auto cand2 = [&](int32_t a, int32_t b) __attribute__((always_inline)) -> int32_t { return (a + __mul24(b, cvb)) >> csh; };
     // (true 32-bit content, pipe_eval_cand_w32: the candidate's samples as doubles -- up to 33 bits -- instead of 24-bit integer forms)
-    const bool w32 = ACC64 && !RAG && P.bps == 32 && !pre_ok;
+    const bool w32 = ACC64 && P.bps == 32 && !pre_ok;
     const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);
     auto candd = [&](int32_t l, int32_t r) -> double { return pipe_cdbl(l, r, c, MS, wscale); };
     // ---- everything in front of the residual: lane 0 = subframe header byte (+ the unary wasted-bits field), lanes
@@ -2675,7 +2728,10 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
                 double xdh = 0.0;
                 if (Lg > 0) {
                     if (fromg) x = gcand(Lg * seg - 1u - (uint32_t)j);
-                    else if (RAG) x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
+                    else if (RAG) {
+                        x = cand(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
+                        if (ACC64 && w32) xdh = candd(prvL[-1 - j], (NCH == 2) ? (int32_t)prvR[-1 - j] : 0);
+                    }
                     else {
                         x = cand2(rowA[hoff - j], rowB[hoff - j]);
                         if (ACC64 && w32) xdh = candd(rowL[hoff - j], (NCH == 2) ? (int32_t)rowR[hoff - j] : 0);

@@ -125,12 +125,34 @@ def fuzz_cases(first, count):
     return {'ran': ran, 'skipped_long': skipped, 'bad': bad}
 
 
+def ragged_32bit(level):
+    """Round 6: tails of TRUE 32-bit content (33-bit side channel) through the pipeline's fp64 forms in the ragged lane geometry:
+    bytes == oracle, no block handed to the generic kernel."""
+    ctx = batch.Context(0)
+    rng = np.random.default_rng(600 + level)
+    res = []
+    for ch, bs, n, shift in ((2, 4096, 4096 + 777, 0), (1, 4096, 4096 + 2049, 0), (2, 1155, 2 * 1155 + 401, 0), (2, 4096, 4096 + 516, 2)):
+        walk = np.cumsum(rng.integers(-2**26, 2**26, (n, ch)), axis=0)
+        x = ((walk + rng.integers(-2**20, 2**20, (n, ch))) % 2**32 - 2**31).astype(np.int64)
+        x = (x >> shift) << shift
+        arr = np.ascontiguousarray(np.clip(x, -2**31, 2**31 - 1).astype(np.int32))
+        s = batch.settings(level, ch, 32, 48000, bs, bs == 4096)
+        cfg, _ = O.config(level, ch, 32, 48000, bs, bs == 4096)
+        out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+        want, sizes = O.encode_stream(cfg, arr)
+        body = out[:st.total_bytes].cpu().numpy().tobytes()
+        res.append({'equal': body == want[len(want) - int(sizes.sum()):], 'redo': int(st.redo_blocks), 'blocks': int(st.nblocks)})
+    return {'cases': res}
+
+
 if __name__ == '__main__':
     group = sys.argv[1]
     if group == 'dropin':
         r = drop_in_classes(int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     elif group == 'batch':
         r = batch_round_trip(int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]))
+    elif group == 'w32rag':
+        r = ragged_32bit(int(sys.argv[2]))
     elif group == 'fuzz':
         r = fuzz_cases(int(sys.argv[2]), int(sys.argv[3]))
     else:

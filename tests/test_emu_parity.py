@@ -67,3 +67,11 @@ def test_seeded_corpus_cases_on_the_emulated_kernels(first):
     bytes equal the oracle's, the decoder returns the input.  Cases above 60 000 samples are left to the GPU runs."""
     r = _run('fuzz', first, 40)
     assert r['ran'] >= 20 and r['bad'] == [], r
+
+
+@pytest.mark.parametrize('level', [5, 8])
+def test_ragged_blocks_of_true_32_bit_content_on_the_emulated_kernels(level):
+    """Round 6: pipe_eval_cand_w32<..., RAG> and the packing kernel's wide form in the ragged geometry -- written and debugged with no
+    GPU at hand, on this emulator: the oracle's bytes, and no block left to the generic kernel."""
+    r = _run('w32rag', level)
+    assert all(c['equal'] and c['redo'] == 0 for c in r['cases']), r

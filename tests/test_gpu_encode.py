@@ -615,7 +615,7 @@ def test_24_bit_material_in_32_bit_container_stays_in_the_pipeline(ctx, level):
 def test_32_bit_streams_mixed_content(ctx):
     """A 32-bit stereo stream whose blocks differ: 24-bit material (pipeline), one channel silent, both silent, 16-bit material
     (sixteen shared wasted bits), true 32-bit noise (the pipeline's fp64 forms, round 4), L == R (a zero side channel).  Every frame the
-    oracle's; only the ragged tail of true 32-bit content is handed to the generic kernel."""
+    oracle's; round 6: the ragged tail of true 32-bit content stays in the pipeline too (pipe_eval_cand_w32<..., RAG>)."""
     import torch
     from pyflac_amd import batch
     from oracle import oracle as O
@@ -642,7 +642,34 @@ def test_32_bit_streams_mixed_content(ctx):
         want, sizes = O.encode_stream(cfg, arr)
         assert list(np.diff(offs.cpu().numpy())) == list(sizes)
         assert out[:st.total_bytes].cpu().numpy().tobytes() == want[86:]
-        assert st.redo_blocks == 1                       # (the 777-sample tail of true 32-bit content: ragged geometry)
+        assert st.redo_blocks == 0                       # (round 5: 1 -- the 777-sample tail of true 32-bit content, ragged geometry)
+
+
+@pytest.mark.parametrize('level', [2, 5, 8])
+def test_ragged_blocks_of_true_32_bit_content_stay_in_the_pipeline(ctx, level):
+    """Round 6 (the third time asked): tails and odd block sizes of TRUE 32-bit content -- 33-bit side channel, fewer than eight shared
+    wasted bits -- are evaluated and packed by the pipeline's fp64 forms in the ragged lane geometry instead of going to the generic
+    kernel.  Stereo and mono, tails of many lengths (one sample more in some lanes of a group, idle lanes, short partitions), an odd
+    block size, a few wasted bits.  What stays with the generic kernel by design: fewer than 28 bits per sample after the wasted bits
+    AND a length past the warm-up that is no multiple of four (the reference binary's AVX2 lane sums)."""
+    import torch
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    rng = np.random.default_rng(600 + level)
+    for ch, bs, n, shift, redo_want in ((2, 4096, 4096 + 777, 0, 0), (2, 4096, 4096 + 1000, 0, 0), (1, 4096, 4096 + 2049, 0, 0), (2, 1155, 3 * 1155 + 401, 0, 0),
+                                        (2, 4096, 4096 + 516, 2, 0), (2, 4096, 4096 + 35, 0, 0), (2, 4096, 4096 + 777, 6, None)):
+        walk = np.cumsum(rng.integers(-2**26, 2**26, (n, ch)), axis=0)
+        x = ((walk + rng.integers(-2**20, 2**20, (n, ch))) % 2**32 - 2**31).astype(np.int64)
+        x = (x >> shift) << shift                       # `shift` wasted bits
+        arr = np.ascontiguousarray(np.clip(x, -2**31, 2**31 - 1).astype(np.int32))
+        s = batch.settings(level, ch, 32, 48000, bs, bs == 4096)
+        cfg, _ = O.config(level, ch, 32, 48000, bs, bs == 4096)
+        out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
+        want, sizes = O.encode_stream(cfg, arr)
+        assert list(np.diff(offs.cpu().numpy())) == list(sizes), (ch, bs, n, shift)
+        assert out[:st.total_bytes].cpu().numpy().tobytes() == want[len(want) - int(sizes.sum()):], (ch, bs, n, shift)
+        if redo_want is not None:
+            assert st.redo_blocks == redo_want, (ch, bs, n, shift, st.redo_blocks)
 
 
 def test_md5_of_device_resident_streams(ctx):
