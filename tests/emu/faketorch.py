@@ -144,6 +144,10 @@ class Tensor:
 
     def flatten(self): return self.reshape(-1)
 
+    def repeat(self, *reps):
+        r = Tensor(np.tile(self._host(), reps), False)
+        return r.cuda() if self.is_cuda else r
+
     # ---- values (the device is synchronous from the host's point of view once synchronised)
     def _host(self):
         if self.is_cuda:
