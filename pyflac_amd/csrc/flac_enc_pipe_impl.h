@@ -1842,9 +1842,9 @@ FGI void pipe_eval_cand(const uint32_t C, const FgBlockDesc &d, uint32_t bi, con
 // Round 6: the ragged lane geometry too (RAG: tail blocks, odd block sizes -- PipeGeo; 23 % of the fuzz corpus's 32-bit blocks went
 // to the generic kernel for want of it).  As in pipe_eval_cand<..., RAG>: every lane walks the `base` samples all working lanes
 // have, the first `extra` lanes of a group one more (ln.len), idle lanes walk whatever row 0 holds and count for nothing; the
-// samples in front of a lane lie at the end of ONE other lane's row (prv*).  One case stays with the generic kernel: a ragged block
-// of fewer than 28 bits per sample whose length past the warm-up is no multiple of four -- there the reference binary's AVX2
-// routine sums the fixed predictors' errors its own way (pipe_eval_cand has that correction for its integer forms).
+// samples in front of a lane lie at the end of ONE other lane's row (prv*).  Where the block's length past the warm-up is no multiple
+// of four the reference binary's AVX2 routines sum the fixed predictors' errors their own way: reproduced below (the first version
+// of these forms summed exactly, and 33 of 2949 fuzz cases on the emulator came out with another predictor order).
 template <bool MS, int NCH, int MAXO, bool RAG>
 FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi, const FgEncParams &P, const FgPipeBufs &B, FgBlockResult *results,
                             FgDebugRec *mydbg, const LDS int32_t *sL, const LDS int32_t *sR, int lane, uint32_t range_err, const PipeGeo &geo)
@@ -1860,22 +1860,6 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
     const uint32_t wst = wraw & 0xFFu;
     const uint32_t nominal = P.bps + ((MS && C == 3) ? 1u : 0u);
     const uint32_t sb = nominal - wst;
-    if (RAG && sb < 28 && ((n - 4) & 3u) != 0) {
-        // (the reference binary's AVX2 lane sums: left to the generic kernel -- the record pipe_eval_cand writes for what it does not take)
-        if (lane == 0) {
-            FgPipeDec *dec = B.dec + (size_t)bi * NC + C;
-            dec->bits = 0x80000000u; dec->type = 1; dec->order = 0; dec->prec = 0; dec->shift = 0; dec->porder = 0; dec->method = 0; dec->wasted = wraw;
-            FgBlockResult *r = &results[d.out_slot];
-            r->best_bits[C] = 0;
-            if (C == 0) {
-                r->bytes = 0; r->ca = 0; r->err = range_err; r->reserved = 4;
-#pragma unroll
-                for (int c = NC; c < 4; c++) r->best_bits[c] = 0;
-                for (int w = 0; w < 4; w++) B.chunk_bits[(size_t)d.out_slot * 4 + w] = 0;
-            }
-        }
-        return;
-    }
     const double wscale = (wraw & 0x100u) ? 1.0 : __hiloint2double((int)((1023u - wst) << 20), 0);      // 2^-wasted
     auto samp = [&](int s) __attribute__((always_inline)) -> double { return pipe_cdbl(rowL[s], (NCH == 2) ? (int32_t)rowR[s] : 0, C, MS, wscale); };
     // the k-th sample in front of this lane's first one (k >= 1)
@@ -1899,6 +1883,7 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
     float rbg, rb1;
     {
         double facc[5], fwarm[5], fmx[5];
+        uint32_t fov[5] = {0, 0, 0, 0, 0};       // (RAG: how many of the lane's errors lie beyond 31 bits -- the AVX2 correction below needs the count)
 #pragma unroll
         for (int kk = 0; kk < 5; kk++) { facc[kk] = 0.0; fwarm[kk] = 0.0; fmx[kk] = 0.0; }
         double P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
@@ -1912,8 +1897,8 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
                 const double ab[5] = {__builtin_fabs(v), __builtin_fabs(e1), __builtin_fabs(e2), __builtin_fabs(e3), __builtin_fabs(e4)};
 #pragma unroll
                 for (int kk = 0; kk < 5; kk++) {
-                    if (lane > 0) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
-                    else if (s >= kk) { fwarm[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
+                    if (lane > 0) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); if (RAG) fov[kk] += ab[kk] > 2147483647.0 ? 1u : 0u; }
+                    else if (s >= kk) { fwarm[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); if (RAG) fov[kk] += ab[kk] > 2147483647.0 ? 1u : 0u; }
                 }
             }
             P0 = v; P1 = e1; P2 = e2; P3 = e3;
@@ -1924,7 +1909,7 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             const double e1 = v - P0, e2 = e1 - P1, e3 = e2 - P2, e4 = e3 - P3;
             const double ab[5] = {__builtin_fabs(v), __builtin_fabs(e1), __builtin_fabs(e2), __builtin_fabs(e3), __builtin_fabs(e4)};
 #pragma unroll
-            for (int kk = 0; kk < 5; kk++) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
+            for (int kk = 0; kk < 5; kk++) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); if (RAG) fov[kk] += ab[kk] > 2147483647.0 ? 1u : 0u; }
             P0 = v; P1 = e1; P2 = e2; P3 = e3;
         }
         if (RAG) {
@@ -1934,8 +1919,8 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             const double ab[5] = {__builtin_fabs(v), __builtin_fabs(e1), __builtin_fabs(e2), __builtin_fabs(e3), __builtin_fabs(e4)};
 #pragma unroll
             for (int kk = 0; kk < 5; kk++) {
-                if (ln.len > seg) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); }
-                if (!ln.act) { facc[kk] = 0.0; fwarm[kk] = 0.0; fmx[kk] = 0.0; }
+                if (ln.len > seg) { facc[kk] += ab[kk]; fmx[kk] = __builtin_fmax(fmx[kk], ab[kk]); fov[kk] += ab[kk] > 2147483647.0 ? 1u : 0u; }
+                if (!ln.act) { facc[kk] = 0.0; fwarm[kk] = 0.0; fmx[kk] = 0.0; fov[kk] = 0; }
             }
         }
         bool over[5];
@@ -1945,6 +1930,64 @@ FGI void pipe_eval_cand_w32(const uint32_t C, const FgBlockDesc &d, uint32_t bi,
             tot[kk] = wave_sum64((u64)facc[kk]);                   // samples 4 .. n - 1
             warm0[kk] = (u64)bcast0(fwarm[kk]);                    // lane 0: samples kk .. 3
             over[kk] = __any(fmx[kk] > 2147483647.0);
+        }
+        if constexpr (RAG) {
+            // The reference binary's AVX2 routines (oracle/flac_oracle.c avx2_lane_sums; pipe_eval_cand has the same correction for
+            // its integer forms): four lanes of q = len / 4 errors that START at (j len) / 4 but take their history from j q.  With
+            // len % 4 != 0 lanes 2 and 3 start late against their history: a sample or two between the lanes is not counted and
+            // the first four errors of a shifted lane are not the true ones.  Below 28 bits (_wide) the len % 4 samples at the end are
+            // not counted either; from 28 to 32 bits (_limit_residual) a scalar loop adds them -- and the one or two of them the
+            // last lane has reached already count twice.  The 33-bit side channel takes plain C: exact.  The sums above are the
+            // exact ones; every lane computes the same correction from a dozen samples.
+            const uint32_t flen = n - 4, qq = flen >> 2, rr = flen & 3;
+            const bool wide_form = sb < 28 && sb + ilog2_32(flen * 17) >= 32, lim_form = sb >= 28 && sb <= 32;
+            if (rr != 0 && (wide_form || lim_form)) {
+                const uint32_t mS = 0xFFFFFFFFu / geo.S + 1, mB1 = 0xFFFFFFFFu / (geo.base + 1) + 1, mB = 0xFFFFFFFFu / geo.base + 1;
+                auto xat = [&](uint32_t g) -> i64 {          // candidate value of sample g of the block
+                    const uint32_t ad = pipe_rag_addr(geo, g, mS, mB1, mB);
+                    return (i64)pipe_cdbl(sL[ad], (NCH == 2) ? (int32_t)sR[ad] : 0, C, MS, wscale);
+                };
+                auto aabs = [](i64 v) -> u64 { return (u64)(v < 0 ? -v : v); };
+                auto exact = [&](uint32_t i, u64 (&e)[5]) {   // errors of orders 0..4 at d[i] (= sample i + 4 of the block)
+                    const i64 a = xat(i + 4), b = xat(i + 3), c = xat(i + 2), dd = xat(i + 1), ee = xat(i);
+                    e[0] = aabs(a); e[1] = aabs(a - b); e[2] = aabs(a - 2 * b + c); e[3] = aabs(a - 3 * b + 3 * c - dd);
+                    e[4] = aabs(a - 4 * b + 6 * c - 4 * dd + ee);
+                };
+                i64 adj[5] = {0, 0, 0, 0, 0};
+                // (over[]: an order is out when one of the errors the routine COUNTS lies beyond 31 bits -- the lanes counted such errors
+                // among all samples, fov; the ones it skips or replaces go out of the count, the ones it makes come in)
+                int32_t nov[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) nov[k] = (int32_t)wave_sum(fov[k]);
+                const uint32_t st2 = flen >> 1, st3 = (3 * flen) >> 2;
+                auto skip = [&](uint32_t lo, uint32_t hi) {
+                    for (uint32_t i = lo; i < hi; i++) { u64 e[5]; exact(i, e); for (int k = 0; k < 5; k++) { adj[k] -= (i64)e[k]; if (e[k] > 0x7FFFFFFFull) nov[k]--; } }
+                };
+                skip(2 * qq, st2); skip(st2 + qq, st3);
+                if (wide_form) skip(st3 + qq, flen);
+                else for (uint32_t i = 4 * qq; i < st3 + qq; i++) { u64 e[5]; exact(i, e); for (int k = 0; k < 5; k++) adj[k] += (i64)e[k]; }
+                auto shifted = [&](uint32_t j, uint32_t st) {
+                    const uint32_t hb = j * qq;
+                    if (st == hb) return;
+                    const i64 h1 = xat(hb + 3), h2 = xat(hb + 2), h3 = xat(hb + 1), h4 = xat(hb);
+                    i64 p0 = h1, p1 = h1 - h2, p2 = p1 - (h2 - h3), p3 = p2 - (h2 - 2 * h3 + h4);
+                    for (uint32_t i = 0; i < 4 && i < qq; i++) {
+                        const i64 e0 = xat(st + i + 4), e1 = e0 - p0, e2 = e1 - p1, e3 = e2 - p2, e4 = e3 - p3;
+                        const i64 ev[5] = {e0, e1, e2, e3, e4};
+                        u64 ex[5];
+                        exact(st + i, ex);
+                        for (int k = 0; k < 5; k++) {
+                            adj[k] += (i64)aabs(ev[k]) - (i64)ex[k];
+                            if (ex[k] > 0x7FFFFFFFull) nov[k]--;
+                            if (aabs(ev[k]) > 0x7FFFFFFFull) nov[k]++;
+                        }
+                        p3 = e3; p2 = e2; p1 = e1; p0 = e0;
+                    }
+                };
+                shifted(2, st2); shifted(3, st3);
+#pragma unroll
+                for (int kk = 0; kk < 5; kk++) { tot[kk] = (u64)((i64)tot[kk] + adj[kk]); over[kk] = nov[kk] > 0; }
+            }
         }
         const double len = (double)(n - 4);
         if (sb < 28) {

@@ -131,7 +131,8 @@ def ragged_32bit(level):
     ctx = batch.Context(0)
     rng = np.random.default_rng(600 + level)
     res = []
-    for ch, bs, n, shift in ((2, 4096, 4096 + 777, 0), (1, 4096, 4096 + 2049, 0), (2, 1155, 2 * 1155 + 401, 0), (2, 4096, 4096 + 516, 2)):
+    for ch, bs, n, shift in ((2, 4096, 4096 + 777, 0), (1, 4096, 4096 + 2049, 0), (2, 1155, 2 * 1155 + 401, 0), (2, 4096, 4096 + 516, 2),
+                             (2, 4096, 4096 + 778, 0), (2, 4096, 4096 + 779, 5), (1, 4096, 4096 + 778, 6), (2, 256, 66, 0)):
         walk = np.cumsum(rng.integers(-2**26, 2**26, (n, ch)), axis=0)
         x = ((walk + rng.integers(-2**20, 2**20, (n, ch))) % 2**32 - 2**31).astype(np.int64)
         x = (x >> shift) << shift
@@ -141,7 +142,7 @@ def ragged_32bit(level):
         out, offs, st = ctx.encode(s, torch.from_numpy(arr).cuda())
         want, sizes = O.encode_stream(cfg, arr)
         body = out[:st.total_bytes].cpu().numpy().tobytes()
-        res.append({'equal': body == want[len(want) - int(sizes.sum()):], 'redo': int(st.redo_blocks), 'blocks': int(st.nblocks)})
+        res.append({'equal': body == want[len(want) - int(sizes.sum()):], 'redo': int(st.redo_blocks), 'blocks': int(st.nblocks), 'case': [ch, bs, n, shift]})
     return {'cases': res}
 
 
