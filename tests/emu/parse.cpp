@@ -337,12 +337,15 @@ bool parse_text(CodeObject &co)
     char name[64]; snprintf(name, sizeof name, "/%016llx", (unsigned long long)h);
     const std::string base = cache_dir() + name, elfp = base + ".elf", txtp = base + ".s";
     if (access(txtp.c_str(), R_OK) != 0) {
-        FILE *f = fopen(elfp.c_str(), "wb");
-        if (!f) { fprintf(stderr, "gfx950emu: cannot write %s\n", elfp.c_str()); return false; }
+        // (several processes may start on an empty cache at once: each writes files of its own and renames them into place)
+        const std::string pid = std::to_string((long)getpid()), myelf = elfp + ".tmp." + pid, tmp = txtp + ".tmp." + pid;
+        FILE *f = fopen(myelf.c_str(), "wb");
+        if (!f) { fprintf(stderr, "gfx950emu: cannot write %s\n", myelf.c_str()); return false; }
         fwrite(co.elf.data(), 1, co.elf.size(), f); fclose(f);
         const char *od = getenv("GFX950EMU_OBJDUMP");
-        const std::string cmd = std::string(od ? od : "/opt/rocm/lib/llvm/bin/llvm-objdump") + " -d --mcpu=gfx950 " + elfp + " > " + txtp + ".tmp 2>/dev/null && mv " + txtp + ".tmp " + txtp;
-        if (system(cmd.c_str()) != 0) { fprintf(stderr, "gfx950emu: %s failed\n", cmd.c_str()); return false; }
+        const std::string cmd = std::string(od ? od : "/opt/rocm/lib/llvm/bin/llvm-objdump") + " -d --mcpu=gfx950 " + myelf + " > " + tmp + " 2>/dev/null && mv " + myelf + " " + elfp +
+                                " && mv " + tmp + " " + txtp;
+        if (system(cmd.c_str()) != 0 && access(txtp.c_str(), R_OK) != 0) { fprintf(stderr, "gfx950emu: %s failed\n", cmd.c_str()); return false; }
     }
     FILE *f = fopen(txtp.c_str(), "r");
     if (!f) return false;
