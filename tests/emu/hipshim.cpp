@@ -50,6 +50,7 @@ struct Global {
     u64 quantum = 128;
     size_t max_waves = 4096;
     bool poison = true, trace = false;
+    u64 sched_seed = 0;
     std::string profile_kernel; std::map<std::string, std::pair<CodeObject *, std::vector<u64>>> profiles;     // GFX950EMU_PROFILE=substring
     std::string watch_kernel; u64 watch_wg = 0; u32 watch_wave = 0; int watch_lane = 0;     // GFX950EMU_WATCH=substring:wg:wave:lane
 };
@@ -120,6 +121,15 @@ static void init_wave(Dispatch &d, WG &wg, Wave &w, u32 wave_idx, u32 threads_in
     w.state = W_RUN;
 }
 
+static u64 g_sched_state = 0;
+static u64 sched_rand()       // xorshift64*
+{
+    u64 x = g_sched_state;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    g_sched_state = x;
+    return x * 2685821657736338717ull;
+}
+
 static void activate(Dispatch &d)
 {
     Global &g = G();
@@ -156,11 +166,22 @@ static u64 run_slice(Dispatch &d)
     activate(d);
     u64 n = 0;
     bool any_done = false;
-    for (size_t i = 0; i < d.waves.size(); i++) {
+    // GFX950EMU_SCHED=<seed>: an adversarial scheduler -- the waves of a slice in random order, each for a random number of
+    // instructions (1 .. 2 quantum), some skipped altogether: orderings between workgroups (look-back words, tickets, the join) that
+    // the fixed round-robin never produces
+    std::vector<u32> order;
+    if (g.sched_seed) {
+        order.resize(d.waves.size());
+        for (u32 i = 0; i < order.size(); i++) order[i] = i;
+        for (size_t i = order.size(); i > 1; i--) { const size_t j = (size_t)(sched_rand() % i); std::swap(order[i - 1], order[j]); }
+    }
+    for (size_t ii = 0; ii < d.waves.size(); ii++) {
+        const size_t i = g.sched_seed ? order[ii] : ii;
         Wave &w = *d.waves[i];
         if (w.state != W_RUN) continue;
-        u64 q = 0;
-        while (q < g.quantum && emu_step(w)) q++;
+        u64 q = 0, lim = g.quantum;
+        if (g.sched_seed) { const u64 r = sched_rand(); if ((r & 7) == 0) continue; lim = 1 + (r >> 8) % (2 * g.quantum); }
+        while (q < lim && emu_step(w)) q++;
         n += q + 1;
         if (w.state == W_BARRIER) release_barrier(*w.wg);
         else if (w.state == W_DONE || w.state == W_FAULT) { w.wg->done++; any_done = true; release_barrier(*w.wg); }
@@ -212,6 +233,7 @@ static void device_main()
         }
         refresh_ranges();
         u64 n = 0;
+        if (g.sched_seed && active.size() > 1) for (size_t i = active.size(); i > 1; i--) std::swap(active[i - 1], active[(size_t)(sched_rand() % i)]);
         for (auto &a : active) n += run_slice(*a.second);
         g_emu_clock.fetch_add(std::max<u64>(1, n / 64), std::memory_order_relaxed);
         {
@@ -242,6 +264,7 @@ static void ensure_device()
     if (const char *q = getenv("GFX950EMU_MAX_WAVES")) g.max_waves = (size_t)atoll(q);
     if (const char *q = getenv("GFX950EMU_POISON")) g.poison = atoi(q) != 0;
     g.trace = getenv("GFX950EMU_TRACE") != nullptr;
+    if (const char *sd = getenv("GFX950EMU_SCHED")) { g.sched_seed = (u64)atoll(sd); g_sched_state = g.sched_seed * 0x9E3779B97F4A7C15ull + 1; }
     if (const char *pk = getenv("GFX950EMU_PROFILE")) g.profile_kernel = pk;
     if (const char *wv = getenv("GFX950EMU_WATCH")) {
         std::string t = wv; unsigned long long a = 0; unsigned b = 0; int c = 0;

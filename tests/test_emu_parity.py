@@ -75,3 +75,14 @@ def test_ragged_blocks_of_true_32_bit_content_on_the_emulated_kernels(level):
     GPU at hand, on this emulator: the oracle's bytes, and no block left to the generic kernel."""
     r = _run('w32rag', level)
     assert all(c['equal'] and c['redo'] == 0 for c in r['cases']), r
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_batch_round_trip_under_an_adversarial_scheduler(seed):
+    """GFX950EMU_SCHED: the emulator runs the resident waves of every slice in random order, each for a random number of instructions,
+    and skips some -- orderings between workgroups and between kernels of different streams that its round-robin never produces (and
+    a GPU only sometimes): the direct packing path's look-back over the frame sizes of 30 workgroups, the resolve kernel's tickets,
+    the fork through the host, the join word.  The bytes and the samples must not depend on it."""
+    r = _run('batch', 5, 2.5, 4096, env={'GFX950EMU_SCHED': str(seed)})
+    assert r['encode_equals_oracle'] and r['direct_path'] == 1 and r['blocks'] == 30, r
+    assert all(c['equal'] and c['status_max'] == 0 for c in r['calls']), r
