@@ -86,3 +86,11 @@ def test_batch_round_trip_under_an_adversarial_scheduler(seed):
     r = _run('batch', 5, 2.5, 4096, env={'GFX950EMU_SCHED': str(seed)})
     assert r['encode_equals_oracle'] and r['direct_path'] == 1 and r['blocks'] == 30, r
     assert all(c['equal'] and c['status_max'] == 0 for c in r['calls']), r
+
+
+def test_the_five_configurations_of_the_baseline_on_the_emulated_kernels():
+    """BASELINE.json's configs[0..4] at reduced length (tools/emu_configs.py; the full 1024-stream run is profiles/r06_emu_configs.json):
+    the passthrough at full size, single-stream encode + decode from the bytes, 24-bit 96 kHz level 8, and a batch of independent
+    streams dealt to eight ranks by shard.streams_for_rank -- every stream the oracle's, every decode the source."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'emu_configs.py'), '--streams', '64'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2000:])
