@@ -39,7 +39,8 @@ struct Inst {
     u32 target = 0;              // index of the branch target
     u16 dpp = 0xFFFF;            // dpp_ctrl (0xFFFF: none)
     u8 row_mask = 0xF, bank_mask = 0xF;
-    bool bound_ctrl = false, clamp = false, ret = false;   // ret: an atomic that returns the old value
+    bool bound_ctrl = false, clamp = false, ret = false;   // ret (sc0): an atomic that returns the old value
+    bool sc1 = false, nt = false;                           // cache policy bits of memory instructions (the L1 model looks at them)
     u8 dst_sel = SEL_DWORD, dst_unused = UNUSED_PAD, src0_sel = SEL_DWORD, src1_sel = SEL_DWORD;
     u8 bitop3 = 0;               // v_bitop3: the truth table
     u8 op_sel = 0, op_sel_hi = 7;

@@ -698,6 +698,8 @@ static bool exec_mem(Wave &w, const Inst &in)
             u8 *p; if (!address(l, n, &p)) return false;
             const u64 la = (u64)(w.m0 & 0xFFFFF) + (u32)in.off0 + (u64)l * unit;
             if (la + unit > w.wg->lds.size()) { emu_fault(w, "LDS-DMA write at %llu beyond %zu", (unsigned long long)la, w.wg->lds.size()); return false; }
+            u8 linebuf[16];
+            if (g_emu_l1_cus && !in.sc1 && !in.nt && emu_l1_read(w.wg->cu, (u64)(uintptr_t)p, linebuf, n)) p = linebuf;
             if (n < 4) { u32 v = 0; memcpy(&v, p, n); memcpy(&w.wg->lds[la], &v, 4); } else memcpy(&w.wg->lds[la], p, n);
             if (st) st->global_load_bytes += n;
         }
@@ -714,9 +716,14 @@ static bool exec_mem(Wave &w, const Inst &in)
         else { emu_fault(w, "load form not implemented"); return false; }
         // (all lanes read before any lane's destination is written: the address registers may be the destination)
         u32 tmp[64][4];
+        const bool cached = g_emu_l1_cus && !is_scratch && !((in.sc1 || in.nt) && emu_l1_sc1_bypasses());
         MLOOP {
             u8 *p; if (!address(l, n, &p)) return false;
-            tmp[l][0] = 0; memcpy(tmp[l], p, n);
+            tmp[l][0] = 0;
+            if (!(cached && (u64)(uintptr_t)p >> 32 != EMU_SHARED_HI && !(is_flat && (p >= w.wg->lds.data() && p < w.wg->lds.data() + w.wg->lds.size())) &&
+                  !(is_flat && !w.scratch.empty() && p >= w.scratch.data() && p < w.scratch.data() + w.scratch.size()) &&
+                  emu_l1_read(w.wg->cu, (u64)(uintptr_t)p, tmp[l], n)))
+                memcpy(tmp[l], p, n);
             if (sx) tmp[l][0] = n == 1 ? (u32)(i32)(i8)tmp[l][0] : (u32)(i32)(i16)tmp[l][0];
             if (st && !is_scratch) st->global_load_bytes += n;
         }
@@ -742,6 +749,7 @@ static bool exec_mem(Wave &w, const Inst &in)
             if (n == 4) __atomic_store_n((u32 *)p, t4[0], __ATOMIC_RELEASE);          // (a word the host polls must arrive whole and after what precedes it)
             else if (n == 8 && ((uintptr_t)p & 7) == 0) { u64 v; memcpy(&v, t4, 8); __atomic_store_n((u64 *)p, v, __ATOMIC_RELEASE); }
             else memcpy(p, t4, n);
+            if (g_emu_l1_cus && !is_scratch) emu_l1_store(w.wg->cu, (u64)(uintptr_t)p, p, n);
             if (st && !is_scratch) st->global_store_bytes += n;
         }
         return true;
@@ -771,6 +779,7 @@ static bool exec_mem(Wave &w, const Inst &in)
             else { emu_fault(w, "atomic not implemented"); return false; }
             nv &= mask;
             if (n == 4) __atomic_store_n((u32 *)p, (u32)nv, __ATOMIC_SEQ_CST); else __atomic_store_n((u64 *)p, nv, __ATOMIC_SEQ_CST);
+            if (g_emu_l1_cus) emu_l1_drop_line(w.wg->cu, (u64)(uintptr_t)p, n);        // (atomics are done past the L1)
             if (in.ret) { V(vdst, l) = (u32)old; if (x2) V(vdst, l, 1) = (u32)(old >> 32); }
         }
         return true;
@@ -922,7 +931,7 @@ bool emu_step(Wave &w)
         if (st) { if (in.op == OP_v_mfma_f64_4x4x4_4b_f64) st->mfma++; st->valu++; st->valu_lanes += (u64)__builtin_popcountll(w.exec); }
     }
     else if (name[0] == 'd') { ok = exec_ds(w, in); if (st) st->lds++; }
-    else if (name[0] == 'b') ok = true;         // buffer_inv / buffer_wbl2: memory is one coherent array here
+    else if (name[0] == 'b') { ok = true; if (g_emu_l1_cus && in.op == OP_buffer_inv && in.sc1) emu_l1_invalidate(w.wg->cu); }     // (buffer_wbl2: stores are write-through here)
     else { ok = exec_mem(w, in); if (st) st->vmem++; }
     if (!ok || w.state == W_FAULT) { w.state = W_FAULT; return false; }
     if (w.trace_lane >= 0) {

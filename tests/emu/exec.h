@@ -11,6 +11,7 @@ struct Dispatch;
 struct Wave;
 struct WG {
     u32 id[3] = {0, 0, 0};
+    u32 cu = 0;                  // GFX950EMU_L1: which modelled vector L1 this workgroup reads through
     std::vector<u8> lds;
     u32 nwaves = 0, at_barrier = 0, done = 0;
     u64 barrier_gen = 0;
@@ -61,3 +62,13 @@ bool emu_step(Wave &w);
 bool emu_mem_ok(u64 p, u64 n);
 extern std::atomic<u64> g_emu_clock;      // wall clock, 100 MHz ticks (advanced by the scheduler)
 void emu_fault(Wave &w, const char *fmt, ...);
+// GFX950EMU_L1=<n>: a model of the per-CU vector L1 as the weakest thing the hardware may do -- a line a plain load brought in is served
+// from there, whatever other CUs store, until a kernel starts or a wave of that CU executes buffer_inv sc1; sc1 / nt loads and atomics go
+// past it; the CU's own stores update it.  n CUs, workgroups dealt to them round-robin (few CUs: more sharing, more staleness).
+extern u32 g_emu_l1_cus;
+bool emu_l1_read(u32 cu, u64 addr, void *dst, u32 n);        // false: not cacheable here (the line leaves an allocation): read memory
+void emu_l1_store(u32 cu, u64 addr, const void *src, u32 n);
+void emu_l1_drop_line(u32 cu, u64 addr, u32 n);
+void emu_l1_invalidate(u32 cu);
+void emu_l1_invalidate_all();
+bool emu_l1_sc1_bypasses();

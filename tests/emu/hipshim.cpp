@@ -74,6 +74,55 @@ void add_range(const void *p, size_t n) { Global &g = G(); g.ranges[(u64)(uintpt
 void del_range(const void *p) { Global &g = G(); g.ranges.erase((u64)(uintptr_t)p); g.ranges_version.fetch_add(1, std::memory_order_release); }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------- the L1 model
+u32 g_emu_l1_cus = 0;
+bool emu_l1_sc1_bypasses() { extern bool emu_l1_ignore_sc1_flag(); return !emu_l1_ignore_sc1_flag(); }
+namespace {
+struct L1Line { u8 b[64]; };
+std::vector<std::unordered_map<u64, L1Line>> g_l1;
+bool g_l1_ignore_sc1 = false;          // GFX950EMU_L1_IGNORE_SC1=1: sc1 loads are served from the L1 like plain ones (what code WITHOUT agent-scope loads would see)
+bool g_l1_ignore_inv = false;          // GFX950EMU_L1_IGNORE_INV=1: buffer_inv does nothing (what a kernel WITHOUT its acquire fence would see)
+u64 g_l1_wg_counter = 0;
+}
+bool emu_mem_ok(u64 p, u64 n);
+bool emu_l1_read(u32 cu, u64 addr, void *dst, u32 n)
+{
+    u8 *out = (u8 *)dst;
+    u64 a = addr;
+    u32 left = n;
+    while (left) {
+        const u64 line = a & ~63ull;
+        const u32 off = (u32)(a - line), take = std::min<u32>(left, 64 - off);
+        auto &m = g_l1[cu];
+        auto it = m.find(line);
+        if (it == m.end()) {
+            if (!emu_mem_ok(line, 64)) return false;
+            L1Line ln; memcpy(ln.b, (const void *)(uintptr_t)line, 64);
+            it = m.emplace(line, ln).first;
+        }
+        memcpy(out, it->second.b + off, take);
+        out += take; a += take; left -= take;
+    }
+    return true;
+}
+void emu_l1_store(u32 cu, u64 addr, const void *src, u32 n)
+{
+    const u8 *in = (const u8 *)src;
+    u64 a = addr;
+    u32 left = n;
+    while (left) {
+        const u64 line = a & ~63ull;
+        const u32 off = (u32)(a - line), take = std::min<u32>(left, 64 - off);
+        auto it = g_l1[cu].find(line);
+        if (it != g_l1[cu].end()) memcpy(it->second.b + off, in, take);
+        in += take; a += take; left -= take;
+    }
+}
+void emu_l1_drop_line(u32 cu, u64 addr, u32 n) { for (u64 line = addr & ~63ull; line < addr + n; line += 64) g_l1[cu].erase(line); }
+void emu_l1_invalidate(u32 cu) { if (!g_l1_ignore_inv) g_l1[cu].clear(); }
+void emu_l1_invalidate_all() { for (auto &m : g_l1) m.clear(); }
+bool emu_l1_ignore_sc1_flag() { return g_l1_ignore_sc1; }
+
 bool emu_mem_ok(u64 p, u64 n)
 {
     static thread_local size_t last = 0;
@@ -139,6 +188,7 @@ static void activate(Dispatch &d)
         const u64 id = d.next_wg++;
         wg->id[0] = (u32)(id % d.grid[0]); wg->id[1] = (u32)((id / d.grid[0]) % d.grid[1]); wg->id[2] = (u32)(id / ((u64)d.grid[0] * d.grid[1]));
         wg->lds.assign(d.lds_bytes, g.poison ? 0xCD : 0);
+        if (g_emu_l1_cus) wg->cu = (u32)(g_l1_wg_counter++ % g_emu_l1_cus);
         wg->nwaves = nw;
         for (u32 k = 0; k < nw; k++) {
             std::unique_ptr<Wave> w(new Wave);
@@ -215,7 +265,7 @@ static void device_main()
                 for (EmuStream *s : all) {
                     while (!s->running && !s->q.empty()) {
                         QOp &op = s->q.front();
-                        if (op.t == QOp::KERNEL) { s->running = op.d; s->q.pop_front(); progressed = true; break; }
+                        if (op.t == QOp::KERNEL) { s->running = op.d; s->q.pop_front(); progressed = true; if (g_emu_l1_cus) emu_l1_invalidate_all(); break; }
                         if (op.t == QOp::MEMCPY) { if (op.n) memmove(op.dst, op.staged.empty() ? op.src : op.staged.data(), op.n); }
                         else if (op.t == QOp::MEMSET) memset(op.dst, op.value, op.n);
                         else if (op.t == QOp::RECORD) { op.ev->done_seq = std::max(op.ev->done_seq, op.seq); op.ev->stamp = g_emu_clock.load(); }
@@ -266,6 +316,9 @@ static void ensure_device()
     g.trace = getenv("GFX950EMU_TRACE") != nullptr;
     if (const char *sd = getenv("GFX950EMU_SCHED")) { g.sched_seed = (u64)atoll(sd); g_sched_state = g.sched_seed * 0x9E3779B97F4A7C15ull + 1; }
     if (const char *pk = getenv("GFX950EMU_PROFILE")) g.profile_kernel = pk;
+    if (const char *l1 = getenv("GFX950EMU_L1")) { g_emu_l1_cus = (u32)atoi(l1); g_l1.resize(g_emu_l1_cus); }
+    g_l1_ignore_inv = getenv("GFX950EMU_L1_IGNORE_INV") != nullptr;
+    g_l1_ignore_sc1 = getenv("GFX950EMU_L1_IGNORE_SC1") != nullptr;
     if (const char *wv = getenv("GFX950EMU_WATCH")) {
         std::string t = wv; unsigned long long a = 0; unsigned b = 0; int c = 0;
         const size_t p1 = t.find(':');

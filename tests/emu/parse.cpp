@@ -286,7 +286,9 @@ static bool parse_line(const std::string &line, Inst &in, std::string &err)
         else if (key == "offset0") in.off0 = (i32)num(val);
         else if (key == "offset1") in.off1 = (i32)num(val);
         else if (key == "sc0") in.ret = true;          // (on atomics: return the old value; on loads / stores: a cache policy)
-        else if (key == "sc1" || key == "nt" || key == "glc" || key == "slc" || key == "dlc" || key == "gds" || key == "lds") {}
+        else if (key == "sc1") in.sc1 = true;
+        else if (key == "nt") in.nt = true;
+        else if (key == "glc" || key == "slc" || key == "dlc" || key == "gds" || key == "lds") {}
         else if (key == "row_mask") in.row_mask = (u8)num(val);
         else if (key == "bank_mask") in.bank_mask = (u8)num(val);
         else if (key == "bound_ctrl") in.bound_ctrl = true;

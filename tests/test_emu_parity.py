@@ -94,3 +94,25 @@ def test_the_five_configurations_of_the_baseline_on_the_emulated_kernels():
     streams dealt to eight ranks by shard.streams_for_rank -- every stream the oracle's, every decode the source."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'emu_configs.py'), '--streams', '64'], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2000:])
+
+
+def test_under_a_vector_l1_that_is_never_refreshed_the_hand_offs_still_work_and_the_model_has_teeth():
+    """GFX950EMU_L1=<n>: the emulator models the per-CU vector L1 as the weakest thing the hardware may do -- a line a plain load brought
+    in is served from there, whatever other CUs have stored since, until a kernel starts or a wave of that CU executes buffer_inv sc1;
+    sc1 loads and atomics go past it (MI355X_MICROARCH: 'a CU's vector L1 is never refreshed by another CU's stores').  Two CUs for
+    all workgroups (much sharing), the adversarial scheduler on top.  (1) The code in the tree: the direct packing path's look-back,
+    the fork, the late join -- its acquire fence invalidates the modelled L1 -- give the oracle's bytes and the source's samples,
+    direct path taken.  (2) The control: with sc1 loads served from that L1 like plain ones -- what the look-back would see WITHOUT its
+    agent-scope loads -- the chain of frame positions breaks under most seeds (direct_path == 2: the encoder notices a stale word
+    through its time limit and falls back to the chunk form, bytes still right).  The model detects the defect class it is for."""
+    env = {'GFX950EMU_L1': '2', 'PYFLAC_AMD_TESTHOOKS': '1', 'FLACGPU_DEC_DELAY_US': '300'}
+    for seed in (1, 2):
+        r = _run('batch', 5, 1.5, 4096, env=dict(env, GFX950EMU_SCHED=str(seed)))
+        assert r['encode_equals_oracle'] and r['direct_path'] == 1, r
+        assert all(c['equal'] and c['status_max'] == 0 and c['late'] > 0 for c in r['calls']), r
+    broken = 0
+    for seed in (1, 4, 5):
+        r = _run('batch', 5, 1.5, 4096, env={'GFX950EMU_L1': '2', 'GFX950EMU_L1_IGNORE_SC1': '1', 'GFX950EMU_SCHED': str(seed)})
+        assert r['encode_equals_oracle'], r          # (the fallback keeps the bytes right)
+        broken += r['direct_path'] == 2
+    assert broken >= 2
