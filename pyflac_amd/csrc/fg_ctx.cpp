@@ -703,7 +703,11 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // ---- direct packing (round 5): the blocks packed by two waves per subframe assemble their frames in LDS and write them at their
     // final place; no sizes scan, no chunks through HBM, no assembly kernel for them.  <= 16 bit and blocks of up to 4608 samples (the
     // frame buffer beside the staged samples leaves four workgroups a CU), not for one-channel views (the splice wants the chunks).
-    bool direct = use_pipe && c->direct != 0 && d_out != nullptr && view == 0 && s->bits_per_sample <= 16 && s->blocksize <= 4608 &&
+    // Round 6: 17..24-bit input too (the kernel's 64-bit forms; the chunk form's four windows took as much LDS as the one frame buffer
+    // does -- two workgroups a CU either way); FLACGPU_DIRECT24=0 in a test-hooks build keeps the chunk form for them.
+    static const bool direct24_off = fg_sel("FLACGPU_DIRECT24") && atoi(fg_sel("FLACGPU_DIRECT24")) == 0;
+    bool direct = use_pipe && c->direct != 0 && d_out != nullptr && view == 0 && s->blocksize <= 4608 &&
+                  (s->bits_per_sample <= 16 || (s->bits_per_sample <= 24 && !direct24_off)) &&
                   nfast > PL.nblocks_rag && !slow_first && !ws1_only;
     uint32_t direct_fcap = 0;
     bool lb_cleared = false;           // (queued on the main stream: the other streams of the launch wait for it)
