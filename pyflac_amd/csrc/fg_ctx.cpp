@@ -541,7 +541,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     const bool ws1_only = fg_sel("FLACGPU_WS") && atoi(fg_sel("FLACGPU_WS")) == 1;   // tuning aid: never two packing waves per subframe
     const uint32_t nw = 4;                            // chunk slots per frame (channels x packing waves per subframe, <= 4)
     uint32_t chunk_cap_words = 0, fbw_words = s->bits_per_sample <= 16 ? 800 : 1280;   // 16-bit stereo: 5 workgroups per CU
-    if (fg_tune("FLACGPU_FBW")) fbw_words = (uint32_t)atoi(fg_tune("FLACGPU_FBW"));
+    // (FLACGPU_FBW, test-hooks builds: a smaller window -- a lane whose codes do not fit it hands its block to the generic kernel, which
+    // is how the tests reach that path now that every content class stays in the pipeline; the bytes are the same)
+    if (fg_sel("FLACGPU_FBW")) { fbw_words = (uint32_t)atoi(fg_sel("FLACGPU_FBW")); if (fbw_words < 24) fbw_words = 24; }
     if (use_pipe) {
         // a chunk holds at most a whole subframe (all of a subframe's bits may sit in one half) plus the frame header
         const uint64_t per = ((uint64_t)s->blocksize * (s->bits_per_sample + 2)) / 8 + 512 + 64;
@@ -705,7 +707,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // frame buffer beside the staged samples leaves four workgroups a CU), not for one-channel views (the splice wants the chunks).
     // Round 6: 17..24-bit input too (the kernel's 64-bit forms; the chunk form's four windows took as much LDS as the one frame buffer
     // does -- two workgroups a CU either way); FLACGPU_DIRECT24=0 in a test-hooks build keeps the chunk form for them.
-    static const bool direct24_off = fg_sel("FLACGPU_DIRECT24") && atoi(fg_sel("FLACGPU_DIRECT24")) == 0;
+    const bool direct24_off = fg_sel("FLACGPU_DIRECT24") && atoi(fg_sel("FLACGPU_DIRECT24")) == 0;
     bool direct = use_pipe && c->direct != 0 && d_out != nullptr && view == 0 && s->blocksize <= 4608 &&
                   (s->bits_per_sample <= 16 || (s->bits_per_sample <= 24 && !direct24_off)) &&
                   nfast > PL.nblocks_rag && !slow_first && !ws1_only;

@@ -5,12 +5,12 @@
 // ---- environment switches --------------------------------------------------------------------------------------------------------
 // The release library (`make`: libflacgpu.so) reads ONE environment variable: FLACGPU_DEVICE, which GPU the default context uses.
 //   * fg_sel(): the kernel SELECTORS that choose among implementations with identical results and the two TEST HOOKS that alter
-//     results on purpose (FLACGPU_NO_FAST, FLACGPU_WS, FLACGPU_MC, FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_QUICK_START, FLACGPU_DEC_SELF,
+//     results on purpose (FLACGPU_NO_FAST, FLACGPU_WS, FLACGPU_MC, FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_QUICK_START, FLACGPU_FBW, FLACGPU_DIRECT24, FLACGPU_DEC_SELF,
 //     FLACGPU_DEC_GATE, FLACGPU_DEC_P16, FLACGPU_DEC_WAVE; FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST) are read by the test-hooks library only
 //     (libflacgpu_testhooks.so: the same kernel objects, the three host files compiled with -DFG_TESTHOOKS; the cross-check tests
 //     load it explicitly, pyflac_amd/_lib.py testhooks_lib()).
 //   * fg_tune(): everything that skips work, reorders it for an experiment or prints diagnostics (FLACGPU_DEC_SKIP, FLACGPU_STOP,
-//     FLACGPU_DEC_CRC_LATE, FLACGPU_FBW, FLACGPU_LDS_PAD, FLACGPU_FCAP, FLACGPU_ALIAS, FLACGPU_DIRECT_X, FLACGPU_SPIN_US,
+//     FLACGPU_DEC_CRC_LATE, FLACGPU_LDS_PAD, FLACGPU_FCAP, FLACGPU_ALIAS, FLACGPU_DIRECT_X, FLACGPU_SPIN_US,
 //     FLACGPU_DEC_PROF, FLACGPU_API_PROF, FG_REFWALK_DEBUG, FLACGPU_DEC_WPS) is read by `make TUNING=1` builds only.
 // flacgpu_build_flags() says what a library is: bit 0 tuning, bit 2 test hooks.
 #include <stdlib.h>

@@ -146,6 +146,32 @@ def ragged_32bit(level):
     return {'cases': res}
 
 
+def direct_24bit(level):
+    """Round 6: frames of 17..24-bit input packed at their final place (fg_pipe_pack_kernel<ACC64, DIRECT>): bytes and offsets == oracle,
+    direct_path == 1, nothing handed back -- regular blocks, a tail, a short block size, one channel, noise (verbatim: the largest frames)."""
+    from pyflac_amd.encoder import stream_header_bytes
+    ctx = batch.Context(0)
+    res = []
+    for ch, bps, bs, n, noise in ((2, 24, 4096, 4096 * 3 + 300, False), (1, 24, 4096, 4096 * 2 + 17, False), (2, 20, 4608, 4608 * 2 + 100, False),
+                                  (2, 24, 1152, 1152 * 4, False), (2, 24, 4096, 4096 * 2, True)):
+        rng = np.random.default_rng(level * 100 + bs + ch)
+        pcm = synth.config4_stereo24(n / 48000.0 + 0.01, bs + ch)[:n].astype(np.int32) >> (24 - bps)
+        if noise:
+            pcm = rng.integers(-2**23, 2**23, pcm.shape).astype(np.int32)
+        pcm = np.ascontiguousarray(pcm[:, :ch])
+        s = batch.settings(level, ch, bps, 48000, bs, True)
+        cfg, _ = O.config(level, ch, bps, 48000, bs, True)
+        out, offs, st = ctx.encode(s, torch.from_numpy(pcm).cuda())
+        want, sizes = O.encode_stream(cfg, pcm)
+        body = out[:st.total_bytes].cpu().numpy().tobytes()
+        t = torch.from_numpy(pcm).cuda()
+        dec, status, dst = ctx.decode(out[:st.total_bytes].clone(), offs, ch, bps, n)
+        res.append({'case': [ch, bps, bs, n, noise], 'equal': stream_header_bytes(s) + body == want, 'direct': int(st.direct_path), 'redo': int(st.redo_blocks),
+                    'offsets': bool(np.array_equal(np.diff(offs.cpu().numpy().astype(np.int64)), sizes.astype(np.int64))),
+                    'decoded': int(status[:, 0].max()) == 0 and bool(torch.equal(dec.reshape(-1, ch), t))})
+    return {'cases': res}
+
+
 if __name__ == '__main__':
     group = sys.argv[1]
     if group == 'dropin':
@@ -154,6 +180,8 @@ if __name__ == '__main__':
         r = batch_round_trip(int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]))
     elif group == 'w32rag':
         r = ragged_32bit(int(sys.argv[2]))
+    elif group == 'direct24':
+        r = direct_24bit(int(sys.argv[2]))
     elif group == 'fuzz':
         r = fuzz_cases(int(sys.argv[2]), int(sys.argv[3]))
     else:

@@ -378,6 +378,34 @@ def test_window_selfcheck(golden, monkeypatch):
     assert b'committed table is used' in L.flacgpu_window_note(c2._h)
 
 
+def test_frames_of_24_bit_input_are_packed_at_their_final_place(ctx, hctx, monkeypatch):
+    """Round 6: 17..24-bit input takes the direct packing kernel too (its 64-bit forms): direct_path == 1, no
+    block handed back, bytes and offsets the oracle's -- and the chunk form (FLACGPU_DIRECT24=0, test-hooks library) gives the same."""
+    import torch
+    from pyflac_amd import batch, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(24)
+    for level, ch, bps, bs, n, noise in ((8, 2, 24, 4096, 4096 * 6 + 300, False), (5, 1, 24, 4096, 4096 * 3 + 17, False), (5, 2, 20, 4608, 4608 * 3 + 100, False),
+                                         (8, 2, 24, 1152, 1152 * 7, False), (3, 2, 24, 4096, 4096 * 3, True), (0, 2, 24, 2304, 2304 * 3 + 5, False)):
+        pcm = synth.config4_stereo24(n / 48000.0 + 0.01, bs + ch)[:n].astype(np.int32) >> (24 - bps)
+        if noise:
+            pcm = rng.integers(-2**23, 2**23, pcm.shape).astype(np.int32)          # verbatim subframes: the largest frames there are
+        pcm = np.ascontiguousarray(pcm[:, :ch])
+        s = batch.settings(level, ch, bps, 48000, bs, True)
+        cfg, _ = O.config(level, ch, bps, 48000, bs, True)
+        want, sizes = O.encode_stream(cfg, pcm)
+        dev = torch.from_numpy(pcm).cuda()
+        for c, direct in ((ctx, 1), (hctx, 0)):
+            if not direct:
+                monkeypatch.setenv('FLACGPU_DIRECT24', '0')
+            out, offs, st = c.encode(s, dev)
+            monkeypatch.delenv('FLACGPU_DIRECT24', raising=False)
+            assert st.direct_path == direct and st.redo_blocks == 0, (level, ch, bps, bs, st.direct_path, st.redo_blocks)
+            body = out[:st.total_bytes].cpu().numpy().tobytes()
+            assert body == want[len(want) - int(sizes.sum()):], (level, ch, bps, bs, direct)
+            assert np.array_equal(np.diff(offs.cpu().numpy().astype(np.int64)), sizes.astype(np.int64))
+
+
 def test_wasted_bits_stay_in_the_pipeline(ctx):
     """Blocks whose samples share trailing zero bits (16-bit audio in a 24-bit container) are encoded by the pipeline itself
     (no hand-over to the generic kernel) and equal the oracle's bytes."""
@@ -698,26 +726,33 @@ def test_md5_of_device_resident_streams(ctx):
             pos += n
 
 
-def test_guard_statistics_survive_a_redo_pass():
+def test_guard_statistics_survive_a_redo_pass(monkeypatch):
     """a call that hands a block back to the generic kernel (FG_ERR_REDO) ends through a SECOND finish pass, whose
     signal kernel finds the near-tie counters already reset by the first one: the statistics of the call (log_guard_subframes,
     lpc_order_min_margin) must be the first pass's -- equal to what the event-timed form of the same call (stage_timing 1, which
-    reads the counters without resetting them) reports, and not 0 / +inf."""
+    reads the counters without resetting them) reports, and not 0 / +inf.
+    (Round 6: no content class leaves the pipeline any more -- true 32-bit tails included --, so the hand-over is provoked: the
+    test-hooks library with a frame-bit window of 28 words, FLACGPU_FBW, which a lane of 32 verbatim 32-bit samples does not fit.)"""
     import torch
-    from pyflac_amd import batch, _lib
-    L = _lib.lib()
+    from pyflac_amd import batch
+    from oracle import oracle as O
+    monkeypatch.setenv('FLACGPU_FBW', '28')
     rng = np.random.default_rng(11)
     bs = 4096
     t = np.arange(bs)
     tone = lambda a, f, ph: np.round(a * np.sin(2 * np.pi * f * t / 48000 + ph) + rng.normal(0, a / 300, bs)).astype(np.int64)
     blocks = [np.stack([tone(3e6, 440 + 10 * k, 0), tone(2e6, 660, k)], axis=1) << 8 for k in range(6)]
-    blocks.append(rng.integers(-2**31, 2**31, (777, 2)))                         # a true 32-bit ragged tail: the generic kernel's
+    blocks.insert(3, rng.integers(-2**31, 2**31, (bs, 2)))                       # noise over the whole range: verbatim subframes
+    blocks.append(rng.integers(-2**31, 2**31, (777, 2)))                         # a true 32-bit ragged tail (short lanes: it fits)
     arr = np.concatenate(blocks).astype(np.int32)
     s = batch.settings(5, 2, 32, 48000, bs, True)
+    cfg, _ = O.config(5, 2, 32, 48000, bs, True)
+    want, sizes = O.encode_stream(cfg, arr)
     dev = torch.from_numpy(arr).cuda()
     got = []
     for timing in (0, 1, 0):
-        c = batch.Context(0)
+        c = batch.Context(0, testhooks=True)
+        L = c._L
         L.flacgpu_set_log_guard(c._h, 1e30)              # (every order guess counts as a near tie: the counters are busy)
         L.flacgpu_set_stage_timing(c._h, timing)
         for _rep in range(2):                            # (the second call starts from counters the first one's signal kernel left)
@@ -725,6 +760,7 @@ def test_guard_statistics_survive_a_redo_pass():
             assert st.redo_blocks == 1
             got.append((st.log_guard_subframes, st.lpc_order_min_margin, bytes(out[:st.total_bytes].cpu().numpy().tobytes())))
         c.close()
+    assert got[0][2] == want[len(want) - int(sizes.sum()):]
     assert got[0][0] > 0 and np.isfinite(got[0][1])
     assert all(g == got[0] for g in got)
 
