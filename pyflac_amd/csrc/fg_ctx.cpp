@@ -706,10 +706,11 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
     // final place; no sizes scan, no chunks through HBM, no assembly kernel for them.  <= 16 bit and blocks of up to 4608 samples (the
     // frame buffer beside the staged samples leaves four workgroups a CU), not for one-channel views (the splice wants the chunks).
     // Round 6: 17..24-bit input too (the kernel's 64-bit forms; the chunk form's four windows took as much LDS as the one frame buffer
-    // does -- two workgroups a CU either way); FLACGPU_DIRECT24=0 in a test-hooks build keeps the chunk form for them.
+    // does -- two workgroups a CU either way), and 32-bit input in blocks of up to 4096 samples (a frame of 33-bit verbatim samples is
+    // 34 KB: 74 KB a workgroup, still two a CU); FLACGPU_DIRECT24=0 in a test-hooks build keeps the chunk form for all of them.
     const bool direct24_off = fg_sel("FLACGPU_DIRECT24") && atoi(fg_sel("FLACGPU_DIRECT24")) == 0;
     bool direct = use_pipe && c->direct != 0 && d_out != nullptr && view == 0 && s->blocksize <= 4608 &&
-                  (s->bits_per_sample <= 16 || (s->bits_per_sample <= 24 && !direct24_off)) &&
+                  (s->bits_per_sample <= 16 || ((s->bits_per_sample <= 24 || s->blocksize <= 4096) && !direct24_off)) &&
                   nfast > PL.nblocks_rag && !slow_first && !ws1_only;
     uint32_t direct_fcap = 0;
     bool lb_cleared = false;           // (queued on the main stream: the other streams of the launch wait for it)

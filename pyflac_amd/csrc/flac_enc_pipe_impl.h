@@ -2502,10 +2502,14 @@ fg_pipe_pack_kernel(const void *pcm, const FgBlockDesc *descs, FgEncParams P, Fg
         for (int k = 0; k < NC; k++) unsure = unsure || (rfl(B.dec[(size_t)bi * NC + k].bits) >> 31) != 0;
     }
     if (unsure) {
+        // (every wave of the workgroup sees the same flags and leaves here.  Since round 6 the evaluation flags nothing -- a block the
+        // shifted forms cannot hold takes pipe_eval_cand_w32 --; what stays is the hand-over itself, and with DIRECT the word the frames
+        // behind this one would otherwise wait for)
         if (lane == 0) {
             B.chunk_bits[(size_t)d.out_slot * 4 + wv] = 0;
             atomicOr(&results[d.out_slot].err, FG_ERR_REDO);
-            if (B.guard) atomicOr(&B.guard[2], (unsigned long long)FG_ERR_REDO);
+            if (B.guard) atomicOr(&B.guard[2], (unsigned long long)(FG_ERR_REDO | (DIRECT ? FG_ERR_CHAIN : 0u)));
+            if (DIRECT && wv == 0) lb_publish(D.lb, d.out_slot, lb_word(D.epoch, FG_LB_POISON, 0));
         }
         return;
     }

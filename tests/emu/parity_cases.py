@@ -147,17 +147,18 @@ def ragged_32bit(level):
 
 
 def direct_24bit(level):
-    """Round 6: frames of 17..24-bit input packed at their final place (fg_pipe_pack_kernel<ACC64, DIRECT>): bytes and offsets == oracle,
+    """Round 6: frames of 17..24-bit and of 32-bit input packed at their final place (fg_pipe_pack_kernel<ACC64, DIRECT>): bytes and offsets == oracle,
     direct_path == 1, nothing handed back -- regular blocks, a tail, a short block size, one channel, noise (verbatim: the largest frames)."""
     from pyflac_amd.encoder import stream_header_bytes
     ctx = batch.Context(0)
     res = []
     for ch, bps, bs, n, noise in ((2, 24, 4096, 4096 * 3 + 300, False), (1, 24, 4096, 4096 * 2 + 17, False), (2, 20, 4608, 4608 * 2 + 100, False),
-                                  (2, 24, 1152, 1152 * 4, False), (2, 24, 4096, 4096 * 2, True)):
+                                  (2, 24, 1152, 1152 * 4, False), (2, 24, 4096, 4096 * 2, True), (2, 32, 4096, 4096 * 2 + 9, False), (2, 32, 4096, 4096, True)):
         rng = np.random.default_rng(level * 100 + bs + ch)
-        pcm = synth.config4_stereo24(n / 48000.0 + 0.01, bs + ch)[:n].astype(np.int32) >> (24 - bps)
+        pcm = synth.config4_stereo24(n / 48000.0 + 0.01, bs + ch)[:n].astype(np.int32)
+        pcm = pcm >> (24 - bps) if bps <= 24 else pcm * 251 + rng.integers(-90, 90, pcm.shape).astype(np.int32)      # (32 bit: no wasted bits)
         if noise:
-            pcm = rng.integers(-2**23, 2**23, pcm.shape).astype(np.int32)
+            pcm = rng.integers(-2**(bps - 1), 2**(bps - 1), pcm.shape).astype(np.int32)
         pcm = np.ascontiguousarray(pcm[:, :ch])
         s = batch.settings(level, ch, bps, 48000, bs, True)
         cfg, _ = O.config(level, ch, bps, 48000, bs, True)

@@ -77,11 +77,12 @@ def test_ragged_blocks_of_true_32_bit_content_on_the_emulated_kernels(level):
     assert all(c['equal'] and c['redo'] == 0 for c in r['cases']), r
 
 
-@pytest.mark.parametrize('level', [5, 8])
-def test_frames_of_24_bit_input_packed_at_their_final_place_on_the_emulated_kernels(level):
+@pytest.mark.parametrize('level,sched', [(5, None), (8, 21)])
+def test_frames_of_24_bit_input_packed_at_their_final_place_on_the_emulated_kernels(level, sched):
     """Round 6: the direct packing kernel in its 64-bit forms -- no chunks, no sizes scan, no assembly kernel for
-    17..24-bit input either.  Bytes and frame offsets equal the oracle's, the decoder returns the input."""
-    r = _run('direct24', level)
+    17..24-bit input either.  Bytes and frame offsets equal the oracle's, the decoder returns the input; once with the waves in the
+    emulator's usual order, once in random order and random slices (the frame buffer in LDS is shared by four waves)."""
+    r = _run('direct24', level, env={'GFX950EMU_SCHED': str(sched)} if sched else None)
     assert all(c['equal'] and c['offsets'] and c['decoded'] and c['direct'] == 1 and c['redo'] == 0 for c in r['cases']), r
 
 

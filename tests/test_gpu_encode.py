@@ -379,17 +379,20 @@ def test_window_selfcheck(golden, monkeypatch):
 
 
 def test_frames_of_24_bit_input_are_packed_at_their_final_place(ctx, hctx, monkeypatch):
-    """Round 6: 17..24-bit input takes the direct packing kernel too (its 64-bit forms): direct_path == 1, no
-    block handed back, bytes and offsets the oracle's -- and the chunk form (FLACGPU_DIRECT24=0, test-hooks library) gives the same."""
+    """Round 6: 17..24-bit input takes the direct packing kernel too (its 64-bit forms), and so does 32-bit
+    input in blocks of up to 4096 samples: direct_path == 1, no block handed back, bytes and offsets the oracle's -- and the chunk
+    form (FLACGPU_DIRECT24=0, test-hooks library) gives the same."""
     import torch
     from pyflac_amd import batch, synth
     from oracle import oracle as O
     rng = np.random.default_rng(24)
     for level, ch, bps, bs, n, noise in ((8, 2, 24, 4096, 4096 * 6 + 300, False), (5, 1, 24, 4096, 4096 * 3 + 17, False), (5, 2, 20, 4608, 4608 * 3 + 100, False),
-                                         (8, 2, 24, 1152, 1152 * 7, False), (3, 2, 24, 4096, 4096 * 3, True), (0, 2, 24, 2304, 2304 * 3 + 5, False)):
-        pcm = synth.config4_stereo24(n / 48000.0 + 0.01, bs + ch)[:n].astype(np.int32) >> (24 - bps)
+                                         (8, 2, 24, 1152, 1152 * 7, False), (3, 2, 24, 4096, 4096 * 3, True), (0, 2, 24, 2304, 2304 * 3 + 5, False),
+                                         (5, 2, 32, 4096, 4096 * 3 + 9, False), (8, 2, 32, 4096, 4096 * 2, True), (5, 1, 32, 1024, 1024 * 5, True)):
+        pcm = synth.config4_stereo24(n / 48000.0 + 0.01, bs + ch)[:n].astype(np.int32)
+        pcm = pcm >> (24 - bps) if bps <= 24 else pcm * 251 + rng.integers(-90, 90, pcm.shape).astype(np.int32)      # (32 bit: no wasted bits)
         if noise:
-            pcm = rng.integers(-2**23, 2**23, pcm.shape).astype(np.int32)          # verbatim subframes: the largest frames there are
+            pcm = rng.integers(-2**(bps - 1), 2**(bps - 1), pcm.shape).astype(np.int32)     # verbatim subframes: the largest frames there are
         pcm = np.ascontiguousarray(pcm[:, :ch])
         s = batch.settings(level, ch, bps, 48000, bs, True)
         cfg, _ = O.config(level, ch, bps, 48000, bs, True)
@@ -732,11 +735,13 @@ def test_guard_statistics_survive_a_redo_pass(monkeypatch):
     lpc_order_min_margin) must be the first pass's -- equal to what the event-timed form of the same call (stage_timing 1, which
     reads the counters without resetting them) reports, and not 0 / +inf.
     (Round 6: no content class leaves the pipeline any more -- true 32-bit tails included --, so the hand-over is provoked: the
-    test-hooks library with a frame-bit window of 28 words, FLACGPU_FBW, which a lane of 32 verbatim 32-bit samples does not fit.)"""
+    test-hooks library in the chunk form with a frame-bit window of 28 words, FLACGPU_FBW, which a lane of 32 verbatim 32-bit samples
+    does not fit.)"""
     import torch
     from pyflac_amd import batch
     from oracle import oracle as O
     monkeypatch.setenv('FLACGPU_FBW', '28')
+    monkeypatch.setenv('FLACGPU_DIRECT24', '0')          # (the chunk form: the direct form has one frame buffer, no windows)
     rng = np.random.default_rng(11)
     bs = 4096
     t = np.arange(bs)

@@ -24,6 +24,14 @@ if [[ $PH == *b* ]]; then
   # two ranks on the one GPU (gloo): the N > 1 line with its cpu_baseline
   timeout 900 python3 bench.py --gpus 2 --share-gpu --steps 5 --warmup 2 --streams 8 --seconds 20 > $OUT/bench_2ranks.log 2> $OUT/bench_2ranks.err
   grep -v "^[WEI]2026" $OUT/bench_2ranks.log | tail -1 > $OUT/bench_2ranks.json
+  # configs[3], A/B of round 6's direct packing of 24-bit frames against the chunk form (written with no GPU at hand: this run decides)
+  for rep in 1 2; do
+    for ab in direct chunk; do
+      flag=""; [[ $ab == chunk ]] && flag="--no-direct"
+      timeout 600 python3 bench.py --workload stream24 --steps 100 --no-cpu-baseline --no-e2e --no-passes $flag 2> /dev/null | grep -v "^[WEI]2026" | tail -1 > $OUT/bench_stream24_${ab}_$rep.json
+      python3 -c "import json,sys; d=json.load(open('$OUT/bench_stream24_${ab}_$rep.json')); print('stream24 $ab', d.get('ms_per_step'), d.get('encode_gpu_ms'), d.get('value'))" 2>/dev/null
+    done
+  done
 fi
 if [[ $PH == *f* ]]; then
   # (3) the differential fuzzers against the oracle
