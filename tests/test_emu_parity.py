@@ -125,3 +125,21 @@ def test_under_a_vector_l1_that_is_never_refreshed_the_hand_offs_still_work_and_
         assert r['encode_equals_oracle'], r          # (the fallback keeps the bytes right)
         broken += r['direct_path'] == 2
     assert broken >= 2
+
+
+@pytest.mark.parametrize('level,bps,enc_max,dec_max', [(5, 16, 25600, 16700), (8, 24, 98500, 25200)])
+def test_instructions_a_block_stay_where_the_design_document_says_they_are(level, bps, enc_max, dec_max, tmp_path):
+    """tools/emu_counts.py: the VALU wave-instructions the encode and the decode launch execute per block of 4096 stereo samples -- the
+    quantity SQ_INSTS_VALU counts on the MI355X (25 441 a block for the level-5 encode in round 5; the emulator's 25 410 for the same
+    code).  DESIGN.md section 7.x quotes them; a change that adds instructions to the hot path has to move these bounds knowingly.
+    (The tool also checks bytes == oracle and samples == input in the same run.)"""
+    out = tmp_path / 'counts.json'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'emu_counts.py'), '--blocks', '16', '--level', str(level), '--bps', str(bps), '--json', str(out)],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    r = json.loads(out.read_text())
+    assert r['encode']['valu_wave_insts_per_block'] <= enc_max, r['encode']['valu_wave_insts_per_block']
+    assert r['decode']['valu_wave_insts_per_block'] <= dec_max, r['decode']['valu_wave_insts_per_block']
+    if bps == 24:
+        # (round 6: no chunk form left in the configs[3] launch)
+        assert not any('assemble' in k or 'scan_sizes' in k for k in r['encode']['kernels']), sorted(r['encode']['kernels'])
