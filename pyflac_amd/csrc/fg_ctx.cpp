@@ -770,6 +770,7 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         PL.D.reserved = fg_tune("FLACGPU_DIRECT_X") ? (uint32_t)atoi(fg_tune("FLACGPU_DIRECT_X")) : 0u;
     };
     set_direct(direct);
+    PL.no_autoc1 = fg_sel("FLACGPU_AUTOC1") ? (atoi(fg_sel("FLACGPU_AUTOC1")) == 0 ? 1u : (atoi(fg_sel("FLACGPU_AUTOC1")) == 2 ? 2u : 0u)) : 0u;
     if (nfast && use_pipe) {
         PL.nblocks = nfast;
         if (timing) {

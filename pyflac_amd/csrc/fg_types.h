@@ -5,7 +5,7 @@
 // ---- environment switches --------------------------------------------------------------------------------------------------------
 // The release library (`make`: libflacgpu.so) reads ONE environment variable: FLACGPU_DEVICE, which GPU the default context uses.
 //   * fg_sel(): the kernel SELECTORS that choose among implementations with identical results and the two TEST HOOKS that alter
-//     results on purpose (FLACGPU_NO_FAST, FLACGPU_WS, FLACGPU_MC, FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_QUICK_START, FLACGPU_FBW, FLACGPU_DIRECT24, FLACGPU_DEC_SELF,
+//     results on purpose (FLACGPU_NO_FAST, FLACGPU_WS, FLACGPU_MC, FLACGPU_GROUPS, FLACGPU_KEEP, FLACGPU_QUICK_START, FLACGPU_FBW, FLACGPU_DIRECT24, FLACGPU_AUTOC1, FLACGPU_DEC_SELF,
 //     FLACGPU_DEC_GATE, FLACGPU_DEC_P16, FLACGPU_DEC_WAVE; FLACGPU_WINDOW_SELFTEST, FLACGPU_VERIFY_SELFTEST) are read by the test-hooks library only
 //     (libflacgpu_testhooks.so: the same kernel objects, the three host files compiled with -DFG_TESTHOOKS; the cross-check tests
 //     load it explicitly, pyflac_amd/_lib.py testhooks_lib()).
@@ -179,6 +179,7 @@ struct FgPipeLaunch {
     // run beside each other where their ends and starts meet, and nobody's last, half-empty round of workgroups leaves the chip idle
     // (two groups: 0.485 -> 0.474 ms on the headline stream; more groups lose to their synchronisation, pipe_shape.inc).
     uint32_t no_keep;           // packing: the two-walk form for every block (FLACGPU_KEEP=0: cross-check of the kept-residual form)
+    uint32_t no_autoc1;         // autocorrelation: 1 = fg_pipe_autoc_kernel also for launches of a few blocks, 2 = fg_pipe_autoc1_kernel for every launch (FLACGPU_AUTOC1=0 / 2: cross-checks)
     uint32_t ngroups;           // 0, 1: one chain on `stream`
     void *gstream[3];           // streams of groups 1..3
     void *gev_fork, *gev_join[3];

@@ -622,6 +622,325 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
     }
 }
 
+// ================================================================================================ K2': autocorrelation of a FEW blocks
+// (round 6) The call pyFLAC exists for is StreamEncoder.process() with one block: there fg_pipe_autoc_kernel is ONE wave that fetches,
+// converts, windows and stores a chunk and then runs its chain of dependent matrix instructions, with the next chunk's samples
+// requested one chunk (half a microsecond) ahead -- 46 of the call's 70 us of serial GPU work (round 5).  Here a workgroup works on one
+// block.  Wave 0 issues nothing but the chains (the same instructions in the same order: the sums are libFLAC's).  Waves 1 ..
+// FGP_A1S stage: wave s takes the chunks s - 1, s - 1 + FGP_A1S, ... -- requests the samples of its next chunk as soon as it has stored
+// one, i.e. FGP_A1S chunks ahead, with nothing else of its own in flight: the compiler's wait in front of the conversion is for exactly
+// those loads (a queue of chunks in the registers of one wave makes it wait for all or copy registers a load has not reached yet).
+// The chunks go into three slots in LDS, one behind the other, so that the chain's reads of the fifteen values in front of its chunk
+// fall into the slot before (in front of slot 0 a copy of the end of slot 2); the workgroup meets at a barrier a chunk: in phase p
+// chunk p is stored while the chain runs over chunk p - 1, whose history in slot (p - 2) % 3 nobody writes.
+// Used for launches of up to FGP_A1_MAX blocks (pipe_shape.inc): beyond that the chip is full of one-wave blocks anyway.
+#define FGP_A1S 8
+#define FGP_A1_MAX 256
+#define FGP_A1RSTR (FGP_DH + 3 * FGP_CK + FGP_SLK)
+FGI void pipe_a1_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool MS, int NCH, int MAXO>
+__global__ void __launch_bounds__(64 * (1 + FGP_A1S))
+fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, FgPipeBufs B, FgDebugRec *dbg,
+                      uint32_t nblocks, uint32_t bi0)
+{
+    constexpr int NC = MS ? 4 : NCH;
+    constexpr uint32_t RSTR = FGP_A1RSTR;                       // a candidate's row: history of slot 0, three slots, zeros
+    constexpr uint32_t NT = 64 * (1 + FGP_A1S);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t wv = rfl(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t bi = (bi0 & 0x3FFFFFFFu) + blockIdx.x;
+    // (bits 31 / 30 of bi0: as in fg_pipe_autoc_kernel)
+    if ((bi0 >> 30) && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (B.stamp) B.stamp[0] = wall_clock64();
+        if ((bi0 >> 31) && B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }
+    }
+    if (bi >= nblocks) return;
+    const FgBlockDesc d = descs[bi];
+    const uint32_t n = d.n;
+    LDS double *ring = (LDS double *)smem;                      // [NC][FGP_DH | 3 x FGP_CK | FGP_SLK]
+    LDS double *autoc = ring + NC * RSTR;                       // [NC][nvec][MAXO + 1]
+    LDS uint32_t *wl = (LDS uint32_t *)(autoc + NC * P.nvec * (MAXO + 1));   // wasted bits per candidate, then the OR of its samples
+    LDS uint32_t *orx = wl + 4;
+    // (pointers the compiler can still see to be global: its loads then count in vmcnt alone; through uniform_ptr they are generic, a
+    // flat load may be an LDS access, and every wait is for everything)
+    const float *const window = windows + d.win_off;
+    const unsigned char *const pcmb = (const unsigned char *)pcm + (size_t)d.pcm_off * (NCH == 2 ? (P.pcm_i16 ? 4u : 8u) : (P.pcm_i16 ? 2u : 4u));
+    FgDebugRec *mydbg = dbg ? dbg + d.out_slot : nullptr;
+    if (threadIdx.x < 4) orx[threadIdx.x] = 0;
+    pipe_a1_barrier();                  // (the staging waves OR into these words: at the end, which with no LPC to do is at once)
+    uint32_t orv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) orv[c] = 0;
+    // sample g of the block as it lies in memory (a 16-bit pair in one word: taken apart at the point of use), and L, R of it
+    auto ldraw = [&](uint32_t g, int32_t &a, int32_t &b) __attribute__((always_inline)) {
+        b = 0;
+        if (NCH == 2) {
+            if (P.pcm_i16) a = ((const int32_t *)pcmb)[g];
+            else { const int2 v = ((const int2 *)pcmb)[g]; a = v.x; b = v.y; }
+        }
+        else {
+            // (one channel of an interleaved stream of more channels: the block is a view with a stride, see FgBlockDesc)
+            const uint32_t at = g * (d.reserved ? d.reserved : 1u);
+            a = P.pcm_i16 ? (int32_t)((const int16_t *)pcmb)[at] : ((const int32_t *)pcmb)[at];
+        }
+    };
+    auto unraw = [&](int32_t &L, int32_t &R) __attribute__((always_inline)) {
+        if (NCH == 2 && P.pcm_i16) { R = L >> 16; L = (int32_t)(int16_t)L; }
+    };
+    // (candidate c of a sample as the float libFLAC windows, and the bits its wasted-bits count looks at: fg_pipe_autoc_kernel)
+    auto cval = [&](int c, int32_t L, int32_t R, float &fx, uint32_t &ob) __attribute__((always_inline)) {
+        if (MS && P.bps == 32 && c == 2) { const int32_t m_ = (int32_t)(((i64)L + (i64)R) >> 1); fx = (float)m_; ob = (uint32_t)m_; }
+        else if (MS && P.bps == 32 && c == 3) { fx = (float)((double)L - (double)R); ob = (uint32_t)L - (uint32_t)R; }
+        else {
+            const int32_t x = c == 0 ? pcv<MS, 0>(L, R) : c == 1 ? pcv<MS, 1>(L, R) : c == 2 ? pcv<MS, 2>(L, R) : pcv<MS, 3>(L, R);
+            fx = (float)x; ob = (uint32_t)x;
+        }
+    };
+    uint32_t nv = 0;
+    const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+    if (mo == 0) {
+        // no LPC at this level: only the OR of the samples is needed
+        if (wv != 0) {
+            for (uint32_t i = (wv - 1) * 64 + (uint32_t)lane; i < n; i += 64 * FGP_A1S) {
+                int32_t L, R;
+                ldraw(i, L, R);
+                unraw(L, R);
+#pragma unroll
+                for (int c = 0; c < NC; c++) { float fx; uint32_t ob; cval(c, L, R, fx, ob); orv[c] |= ob; }
+            }
+        }
+    }
+    else {
+        const uint32_t mrow = ((lane >> 2) & 3) < (uint32_t)NC ? ((lane >> 2) & 3) : 0;
+        uint32_t vb_ = 1, vc_ = 0;
+        bool more = true;
+        while (more) {
+            uint32_t vec_len = n, part = 0, sh = 0;
+            bool punch = false, skip = false;
+            if (nv > 0) {
+                if (n / vb_ <= 32) skip = true;
+                else if (!(vc_ & 1)) { vec_len = n / vb_; part = n / vb_ / 2; sh = (vc_ / 2 * n) / vb_; }
+                else punch = true;
+            }
+            if (!skip && !punch) {
+                // the history of the first chunk: zeros
+                if (threadIdx.x < (uint32_t)NC * FGP_DH) ring[(threadIdx.x / FGP_DH) * RSTR + (threadIdx.x % FGP_DH)] = 0.0;
+                pipe_a1_barrier();
+                const uint32_t nch = (vec_len + FGP_CK - 1) / FGP_CK;
+                // phase p = 0 .. nch: chunk p is stored (p < nch), the chain runs over chunk p - 1 (p >= 1); a barrier ends it
+                if (wv == 0) {
+                    double acc = 0.0;
+                    for (uint32_t p = 0; p <= nch; p++) {
+                        if (p >= 1) {
+                            const uint32_t k0 = (p - 1) * FGP_CK;
+                            const uint32_t kn = (vec_len - k0) < FGP_CK ? (vec_len - k0) : FGP_CK;
+                            const uint32_t kend = (k0 + kn < vec_len) ? FGP_CK : ((kn + 3) & ~3u) + 4;
+                            const LDS double *pa = ring + mrow * RSTR + FGP_DH + ((p - 1) % 3u) * FGP_CK + (lane >> 4) - (lane & 3);
+                            // (the chain of fg_pipe_autoc_kernel, which explains it)
+                            uint32_t ad = (uint32_t)(size_t)pa;
+                            const uint32_t adb = ad - 8u * (4u + 3u * (lane & 3));
+                            uint32_t n4 = kend >> 4, n1 = (kend >> 2) & 3;
+                            const u64 m0 = 0x1111111111111111ull;
+#define FG_DPPQ " quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+#define FG_STEP(a0, a1, s0, s1, d0, d1) \
+    "v_cndmask_b32_dpp v" #d0 ", v" #s0 ", v" #a0 ", vcc" FG_DPPQ \
+    "v_cndmask_b32_dpp v" #d1 ", v" #s1 ", v" #a1 ", vcc" FG_DPPQ \
+    "s_nop 1\n\t" \
+    "v_mfma_f64_4x4x4_4b_f64 %[acc], v[" #a0 ":" #a1 "], v[" #d0 ":" #d1 "], %[acc]\n\t"
+#define FG_RD2(r0, r1, r2, r3, o) \
+    "ds_read_b64 v[" #r0 ":" #r1 "], %[ad] offset:" #o "\n\tds_read_b64 v[" #r2 ":" #r3 "], %[ad] offset:" #o "+32\n\t"
+#define FG_EVEN(a0, a1) FG_STEP(a0, a1, 56, 57, 58, 59)
+#define FG_ODD(a0, a1) FG_STEP(a0, a1, 58, 59, 56, 57)
+                            asm volatile(
+                                "s_mov_b64 vcc, %[m0]\n\t"
+                                "ds_read_b64 v[56:57], %[adb]\n\t"
+                                "s_cmp_eq_u32 %[n4], 0\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                FG_RD2(40, 41, 42, 43, 0)
+                                "1:\n\t"
+                                FG_RD2(44, 45, 46, 47, 64)
+                                "s_waitcnt lgkmcnt(2)\n\t"
+                                FG_EVEN(40, 41) FG_ODD(42, 43)
+                                "v_add_u32 %[ad], 0x80, %[ad]\n\t"
+                                "s_sub_u32 %[n4], %[n4], 1\n\t"
+                                "s_cmp_eq_u32 %[n4], 0\n\t"
+                                "s_cbranch_scc1 5f\n\t"
+                                FG_RD2(40, 41, 42, 43, 0)
+                                "s_waitcnt lgkmcnt(2)\n\t"
+                                FG_EVEN(44, 45) FG_ODD(46, 47)
+                                "s_branch 1b\n\t"
+                                "5:\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                FG_EVEN(44, 45) FG_ODD(46, 47)
+                                "2:\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "s_cmp_eq_u32 %[n1], 0\n\t"
+                                "s_cbranch_scc1 4f\n\t"
+                                "3:\n\t"
+                                "ds_read_b64 v[40:41], %[ad]\n\t"
+                                "v_add_u32 %[ad], 32, %[ad]\n\t"
+                                "s_sub_u32 %[n1], %[n1], 1\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                FG_EVEN(40, 41)
+                                "v_mov_b32 v56, v58\n\t"
+                                "v_mov_b32 v57, v59\n\t"
+                                "s_nop 1\n\t"
+                                "s_cmp_eq_u32 %[n1], 0\n\t"
+                                "s_cbranch_scc0 3b\n\t"
+                                "4:\n\t"
+                                "s_nop 7\n\t"
+                                "s_nop 3"
+                                : [acc] "+v"(acc), [ad] "+v"(ad), [n4] "+s"(n4), [n1] "+s"(n1)
+                                : [adb] "v"(adb), [m0] "s"(m0)
+                                : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v57", "v58", "v59");
+#undef FG_RD2
+#undef FG_EVEN
+#undef FG_ODD
+#undef FG_STEP
+#undef FG_DPPQ
+                        }
+                        pipe_a1_barrier();
+                    }
+                    {
+                        const uint32_t oc = (lane >> 2) & 3;
+                        const int ol = 4 * (int)(lane & 3) - (int)(lane >> 4);
+                        if (oc < (uint32_t)NC && ol >= 0 && ol <= (int)mo) autoc[(oc * P.nvec + nv) * (MAXO + 1) + ol] = acc;
+                    }
+                    wave_lds_fence();
+                }
+                else {
+                    // samples lane and lane + 64 of the chunk that starts at k0, as they lie in memory, and their window values.  No
+                    // branch around the loads -- behind one the compiler waits for them on the spot --: past the vector's end the last
+                    // valid sample is fetched again, and the conversion below puts a zero in its place.
+                    const uint32_t lim = part ? 2 * part : vec_len;              // (>= 1: a punched or skipped window never comes here)
+                    const uint32_t wjump = part ? n - 2 * part : 0u;             // second half of a partial window: the window's falling end
+                    // (one copy of the loop per sample format: where the two forms of a load meet, the compiler waits for the other's)
+                    auto staging = [&](auto I16) __attribute__((always_inline)) {
+                    constexpr bool i16 = decltype(I16)::value;
+                    float w0, w1;
+                    int32_t l0, r0, l1, r1;
+                    auto ld = [&](uint32_t g, int32_t &a, int32_t &b) __attribute__((always_inline)) {
+                        b = 0;
+                        if (NCH == 2) {
+                            if (i16) a = ((const int32_t *)pcmb)[g];
+                            else { const int2 v = ((const int2 *)pcmb)[g]; a = v.x; b = v.y; }
+                        }
+                        else {
+                            const uint32_t at = g * (d.reserved ? d.reserved : 1u);
+                            a = i16 ? (int32_t)((const int16_t *)pcmb)[at] : ((const int32_t *)pcmb)[at];
+                        }
+                    };
+                    auto fetch = [&](uint32_t k0) __attribute__((always_inline)) {
+                        const uint32_t a0 = k0 + (uint32_t)lane, a1 = a0 + 64;
+                        const uint32_t i0 = a0 < lim ? a0 : lim - 1, i1 = a1 < lim ? a1 : lim - 1;
+                        w0 = window[i0 + ((part != 0 && i0 >= part) ? wjump : 0u)];
+                        w1 = window[i1 + ((part != 0 && i1 >= part) ? wjump : 0u)];
+                        ld(sh + i0, l0, r0);
+                        ld(sh + i1, l1, r1);
+                    };
+                    uint32_t mine = wv - 1;                                      // the next chunk this wave stores
+                    fetch(mine * FGP_CK);
+                    for (uint32_t p = 0; p <= nch; p++) {
+                        if (p == mine && p < nch) {
+                            const uint32_t base = FGP_DH + (p % 3u) * FGP_CK;
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                int32_t L = h ? l1 : l0, R = h ? r1 : r0;
+                                const float w = h ? w1 : w0;
+                                if (NCH == 2 && i16) { R = L >> 16; L = (int32_t)(int16_t)L; }
+                                const uint32_t j = (uint32_t)lane + 64u * h;
+                                const bool zero = (p * FGP_CK + j) >= lim;
+#pragma unroll
+                                for (int c = 0; c < NC; c++) {
+                                    float fx;
+                                    uint32_t ob;
+                                    cval(c, L, R, fx, ob);
+                                    if (nv == 0) orv[c] |= zero ? 0u : ob;
+                                    const float dd = zero ? 0.0f : fx * w;
+                                    const double v = (double)dd;
+                                    ring[c * RSTR + base + j] = v;
+                                    // (the end of slot 2 once more in front of slot 0, where the chain on the next chunk looks for its history)
+                                    if (h == 1 && p % 3u == 2 && j >= FGP_CK - FGP_DH) ring[c * RSTR + (j - (FGP_CK - FGP_DH))] = v;
+                                }
+                            }
+                            // (the vector's last chunk: the chain runs up to seven steps past it -- zeros; in the slot behind, or in the
+                            // slack behind slot 2: nobody stores a chunk there any more)
+                            if (p + 1 == nch && lane < FGP_SLK) {
+#pragma unroll
+                                for (int c = 0; c < NC; c++) ring[c * RSTR + base + FGP_CK + lane] = 0.0;
+                            }
+                            mine += FGP_A1S;
+                            fetch(mine * FGP_CK);
+                        }
+                        pipe_a1_barrier();
+                    }
+                    };
+                    if (P.pcm_i16) staging(std::integral_constant<bool, true>()); else staging(std::integral_constant<bool, false>());
+                }
+            }
+            else if (punch) {
+                // root - previous partial for lags < mo; lag mo keeps the partial (upstream quirk)
+                if (wv == 0) {
+                    const uint32_t total = (uint32_t)NC * (mo + 1);
+                    for (uint32_t j = lane; j < total; j += 64) {
+                        const uint32_t c = j / (mo + 1), ll = j % (mo + 1);
+                        LDS double *base = autoc + c * P.nvec * (MAXO + 1);
+                        const double prev = base[(nv - 1) * (MAXO + 1) + ll];
+                        base[nv * (MAXO + 1) + ll] = (ll < mo) ? base[ll] - prev : prev;
+                    }
+                    wave_lds_fence();
+                }
+            }
+            if (!skip) nv++;
+            if (P.apod_parts < 2) more = false;
+            else if (nv == 1 && vb_ == 1) { vb_ = 2; vc_ = 0; }
+            else {
+                if (vb_ == 2) { if (vc_ == 0) vc_ = 2; else { vc_ = 0; vb_++; } }
+                else if (vc_ < 2 * vb_ - 1) vc_++;
+                else { vc_ = 0; vb_++; }
+                if (vb_ > P.apod_parts) more = false;
+            }
+        }
+    }
+    // ---- the OR of every candidate's samples: from the staging waves to the chain wave, which finishes the block alone
+    if (wv != 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint32_t o = wave_or32(orv[c]);
+            if (lane == 0 && o) __hip_atomic_fetch_or(&orx[c], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    pipe_a1_barrier();
+    if (wv != 0) return;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t o = orx[c];
+        uint32_t w = o ? (uint32_t)__builtin_ctz(o) : 0;
+        const uint32_t nominal = P.bps + ((MS && c == 3) ? 1u : 0u);
+        if (w > nominal) w = nominal;
+        if (MS && c == 3 && P.bps == 32 && o == 0) w = 1;                          // (get_wasted_bits_wide_, see fg_pipe_autoc_kernel)
+        if (lane == 0) { wl[c] = w; B.wasted[bi * NC + c] = w | (o ? 0u : 0x100u); }
+    }
+    if (lane == 0) B.nv[bi] = nv;
+    wave_lds_fence();
+    if (mo > 0) {
+        const uint32_t per = P.nvec * (MAXO + 1);
+        for (uint32_t j = lane; j < (uint32_t)NC * per; j += 64) {
+            const uint32_t c = j / per;
+            double a = autoc[j];
+            const uint32_t w = wl[c];
+            if (w) a = ldexp(a, -2 * (int)w);
+            B.autoc[(size_t)bi * NC * per + j] = a;
+            if (mydbg) {
+                const uint32_t r = j % per, v = r / (MAXO + 1), ll = r % (MAXO + 1);
+                if (v < nv && ll <= mo) mydbg->cand[c].autoc[v][ll] = a;
+            }
+        }
+        if (mydbg && lane < NC) mydbg->cand[lane].nvec = nv;
+    }
+}
+
 // ---- correctly rounded log for the near-ties of the order guess (double-double arithmetic; rare path)
 // libFLAC picks the LPC order by comparing bits = 0.5 * log(scale * err) / ln 2 * (n - o) + o * overhead across orders with a
 // strict <.  glibc's log and the device's differ in the last bit now and then, which can only matter when two orders come

@@ -915,7 +915,7 @@ bool emu_step(Wave &w)
     const Inst &in = w.d->co->insts[w.pc];
     KStats *st = w.d->stats;
     const char *name = op_name(in.op);
-    if (st) st->wave_insts++;
+    if (st) { st->wave_insts++; if (++w.insts > st->max_wave_insts) st->max_wave_insts = w.insts; }
     if (w.d->pc_hist) (*w.d->pc_hist)[w.pc]++;
     if (in.op == OP_s_endpgm || in.op == OP_s_code_end) { w.state = W_DONE; return false; }
     if (in.op == OP_s_barrier) {

@@ -35,10 +35,11 @@ struct Wave {
     u32 gpr_idx = 0;
     u32 nv = 0, na = 0;
     int trace_lane = -1;            // GFX950EMU_WATCH
+    u64 insts = 0;                  // instructions this wave has executed (KStats.max_wave_insts: a launch's longest serial path)
 };
 struct KStats {
     u64 wave_insts = 0, valu = 0, valu_lanes = 0, salu = 0, smem = 0, vmem = 0, lds = 0, mfma = 0, branch = 0, waves = 0;
-    u64 global_load_bytes = 0, global_store_bytes = 0, launches = 0;
+    u64 global_load_bytes = 0, global_store_bytes = 0, launches = 0, max_wave_insts = 0;
 };
 struct Dispatch {
     CodeObject *co = nullptr;

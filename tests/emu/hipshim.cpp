@@ -373,10 +373,10 @@ extern "C" const char *gfx950emu_stats_json(void)
         if (!k.launches) continue;
         char b[1024];
         snprintf(b, sizeof b, "%s\"%s\": {\"launches\": %llu, \"waves\": %llu, \"wave_insts\": %llu, \"valu\": %llu, \"valu_lanes\": %llu, \"salu\": %llu, \"smem\": %llu, "
-                 "\"vmem\": %llu, \"lds\": %llu, \"mfma\": %llu, \"global_load_bytes\": %llu, \"global_store_bytes\": %llu}", first ? "" : ", ", s.first.c_str(),
+                 "\"vmem\": %llu, \"lds\": %llu, \"mfma\": %llu, \"global_load_bytes\": %llu, \"global_store_bytes\": %llu, \"max_wave_insts\": %llu}", first ? "" : ", ", s.first.c_str(),
                  (unsigned long long)k.launches, (unsigned long long)k.waves, (unsigned long long)k.wave_insts, (unsigned long long)k.valu, (unsigned long long)k.valu_lanes,
                  (unsigned long long)k.salu, (unsigned long long)k.smem, (unsigned long long)k.vmem, (unsigned long long)k.lds, (unsigned long long)k.mfma,
-                 (unsigned long long)k.global_load_bytes, (unsigned long long)k.global_store_bytes);
+                 (unsigned long long)k.global_load_bytes, (unsigned long long)k.global_store_bytes, (unsigned long long)k.max_wave_insts);
         out += b; first = false;
     }
     out += "}";

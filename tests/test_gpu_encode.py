@@ -409,6 +409,53 @@ def test_frames_of_24_bit_input_are_packed_at_their_final_place(ctx, hctx, monke
             assert np.array_equal(np.diff(offs.cpu().numpy().astype(np.int64)), sizes.astype(np.int64))
 
 
+def test_the_autocorrelation_of_a_few_blocks_by_a_workgroup_each_equals_the_wave_a_block_form(ctx, hctx, monkeypatch):
+    """Round 6: launches of up to 256 blocks -- StreamEncoder.process() above all -- take fg_pipe_autoc1_kernel (a workgroup a block: one
+    wave on the chains of matrix instructions, eight that stage the chunks ahead of it); larger ones keep fg_pipe_autoc_kernel (a wave
+    a block).  Same sums in the same order: the bytes are the oracle's either way -- every level's windows (partial and punched ones
+    at level 8), one and two channels, 16 / 24 / 32 bit, int16 input, odd block sizes and tails, a single short block -- with the
+    release library's choice, with the old kernel forced on the small launch and the new one on a large one (test-hooks library)."""
+    import torch
+    from pyflac_amd import batch, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(61)
+    cases = [(5, 2, 16, 4096, 4096 * 5 + 1234, False), (8, 2, 24, 4096, 4096 * 3 + 77, False), (8, 2, 16, 1152, 1152 * 6 + 5, True), (0, 1, 16, 4096, 4096 * 2 + 9, False),
+             (3, 2, 16, 4095, 4095 * 3, False), (8, 1, 24, 2304, 2304 * 2 + 130, False), (5, 2, 32, 4096, 4096 * 2 + 300, False), (8, 2, 16, 4608, 4608 + 64, False),
+             (6, 2, 16, 4096, 100, False), (7, 2, 24, 576, 576 * 9, False)]
+    for level, ch, bps, bs, n, i16 in cases:
+        base = synth.config2_stereo16(n / 48000.0 + 0.01, level + bs)[:n].astype(np.int64)
+        if bps == 24:
+            base = base * 211 + rng.integers(-60, 60, base.shape)
+        if bps == 32:
+            base = base * 52001 + rng.integers(-9000, 9000, base.shape)
+        pcm = np.ascontiguousarray(base[:, :ch].astype(np.int32))
+        s = batch.settings(level, ch, bps, 48000, bs, bs != 4095)
+        cfg, _ = O.config(level, ch, bps, 48000, bs, bs != 4095)
+        want, sizes = O.encode_stream(cfg, pcm)
+        dev = torch.from_numpy(pcm.astype(np.int16) if i16 else pcm).cuda()
+        for c, sel in ((ctx, None), (hctx, '0'), (hctx, '2')):
+            if sel is not None:
+                monkeypatch.setenv('FLACGPU_AUTOC1', sel)
+            out, offs, st = c.encode(s, dev)
+            monkeypatch.delenv('FLACGPU_AUTOC1', raising=False)
+            body = out[:st.total_bytes].cpu().numpy().tobytes()
+            assert body == want[len(want) - int(sizes.sum()):], (level, ch, bps, bs, n, sel)
+    # a launch beyond the limit, both ways (300 blocks)
+    pcm = synth.config2_stereo16(300 * 4096 / 48000.0 + 0.01, 3)[:300 * 4096].astype(np.int32)
+    s = batch.settings(5, 2, 16, 48000, 4096, True)
+    dev = torch.from_numpy(pcm).cuda()
+    outs = []
+    for sel in (None, '2'):
+        if sel is not None:
+            monkeypatch.setenv('FLACGPU_AUTOC1', sel)
+        out, offs, st = hctx.encode(s, dev)
+        monkeypatch.delenv('FLACGPU_AUTOC1', raising=False)
+        outs.append(out[:st.total_bytes].cpu().numpy().tobytes())
+    cfg, _ = O.config(5, 2, 16, 48000, 4096, True)
+    want, sizes = O.encode_stream(cfg, pcm)
+    assert outs[0] == outs[1] == want[len(want) - int(sizes.sum()):]
+
+
 def test_wasted_bits_stay_in_the_pipeline(ctx):
     """Blocks whose samples share trailing zero bits (16-bit audio in a 24-bit container) are encoded by the pipeline itself
     (no hand-over to the generic kernel) and equal the oracle's bytes."""
