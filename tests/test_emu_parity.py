@@ -127,6 +127,20 @@ def test_under_a_vector_l1_that_is_never_refreshed_the_hand_offs_still_work_and_
     assert broken >= 2
 
 
+def test_both_autocorrelation_kernels_on_the_emulated_runs():
+    """Round 6: launches of up to 256 blocks -- every other case of this file -- take fg_pipe_autoc1_kernel (a workgroup a block); the
+    headline launch takes fg_pipe_autoc_kernel (a wave a block), which the test-hooks library puts on small launches with
+    FLACGPU_AUTOC1=0.  Same bytes: the drop-in classes at level 8 (partial and punched windows) and the seeded corpus cases on the old
+    kernel, and the corpus cases once more on the new one with the waves in random order (nine waves meet at a barrier a chunk)."""
+    old = {'PYFLAC_AMD_TESTHOOKS': '1', 'FLACGPU_AUTOC1': '0'}
+    r = _run('dropin', 8, 0.2, 2, 24, env=old)
+    assert r['finish'] and r['frames_equal_oracle'] and r['decoded_equals_input'], r
+    r = _run('fuzz', 0, 40, env=old)
+    assert r['ran'] >= 20 and r['bad'] == [], r
+    r = _run('fuzz', 0, 40, env={'GFX950EMU_SCHED': '17'})
+    assert r['ran'] >= 20 and r['bad'] == [], r
+
+
 @pytest.mark.parametrize('level,bps,enc_max,dec_max', [(5, 16, 25600, 16700), (8, 24, 98500, 25200)])
 def test_instructions_a_block_stay_where_the_design_document_says_they_are(level, bps, enc_max, dec_max, tmp_path):
     """tools/emu_counts.py: the VALU wave-instructions the encode and the decode launch execute per block of 4096 stereo samples -- the

@@ -19,7 +19,10 @@ from pyflac_amd import batch, synth
 sr = 48000 if args.bps == 16 else 96000
 n = args.blocks * 4096
 pcm = (synth.config2_stereo16(n / sr + 0.01, 0, sr) if args.bps == 16 else synth.config4_stereo24(n / sr + 0.01, 1, sr))[:n]
-ctx = batch.Context(0)
+# (the headline launch's kernels on a short stream: a launch this small would take fg_pipe_autoc1_kernel -- unless that is what is asked for)
+if 'autoc1' not in args.kernel and not args.lib:
+    os.environ['FLACGPU_AUTOC1'] = '0'
+ctx = batch.Context(0, testhooks='autoc1' not in args.kernel and not args.lib)
 s = batch.settings(args.level, 2, args.bps, sr, 4096, True)
 t = torch.from_numpy(pcm.astype(np.int32)).cuda()
 out, offs, est = ctx.encode(s, t)
