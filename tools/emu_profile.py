@@ -11,7 +11,7 @@ args = ap.parse_args()
 os.environ['GFX950EMU_PROFILE'] = args.kernel
 if args.lib:
     os.environ['FLACGPU_ALLOW_LIBRARY_OVERRIDE'] = '1'; os.environ['FLACGPU_LIBRARY'] = os.path.abspath(args.lib)
-    os.environ['GFX950EMU_CACHE'] = '/tmp/gfx950emu_cache_' + os.path.basename(args.lib)      # (its own disassembly cache: kernel names repeat across builds)
+os.environ['GFX950EMU_CACHE'] = tempfile.mkdtemp(prefix='gfx950emu_prof_')      # (a disassembly cache of this run's own: kernel names repeat across builds, and the listing must be this build's)
 import emurun
 shim, L = emurun.load()
 import numpy as np, torch
