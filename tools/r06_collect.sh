@@ -60,5 +60,8 @@ if [[ $PH == *p* ]]; then
     rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $O3/pmc4 -o pmc4 -- $CMD > $O3/bench_pmc4.log 2>&1
   done
   (python3 tools/exp/process_call_probe.py 4096; python3 tools/exp/process_call_probe.py 1024; python3 tools/exp/process_call_probe.py 16384; python3 tools/exp/small_call_probe.py) > $OUT/small_calls.txt 2>&1
+  # (round 6's fg_pipe_autoc1_kernel against the wave-a-block kernel on the same one-block calls: written with no GPU at hand, this decides)
+  (echo "== FLACGPU_AUTOC1=0: fg_pipe_autoc_kernel on the same calls (test-hooks library)"; PYFLAC_AMD_TESTHOOKS=1 FLACGPU_AUTOC1=0 python3 tools/exp/process_call_probe.py 4096;
+   echo "== release library once more"; python3 tools/exp/process_call_probe.py 4096) >> $OUT/small_calls.txt 2>&1
 fi
 ls -la $OUT
