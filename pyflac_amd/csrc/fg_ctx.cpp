@@ -770,7 +770,9 @@ static bool encode_streams_impl(flacgpu_ctx *c, const flacgpu_settings *s, const
         PL.D.reserved = fg_tune("FLACGPU_DIRECT_X") ? (uint32_t)atoi(fg_tune("FLACGPU_DIRECT_X")) : 0u;
     };
     set_direct(direct);
-    PL.no_autoc1 = fg_sel("FLACGPU_AUTOC1") ? (atoi(fg_sel("FLACGPU_AUTOC1")) == 0 ? 1u : (atoi(fg_sel("FLACGPU_AUTOC1")) == 2 ? 2u : 0u)) : 0u;
+    // (FLACGPU_AUTOC1, test-hooks builds: 0 = the wave-a-block kernel for every launch, 2 = the workgroup-a-block kernel for every launch,
+    // 3 = that kernel with its windows one behind the other also where they would run side by side)
+    PL.no_autoc1 = fg_sel("FLACGPU_AUTOC1") ? (atoi(fg_sel("FLACGPU_AUTOC1")) == 0 ? 1u : (atoi(fg_sel("FLACGPU_AUTOC1")) == 2 ? 2u : (atoi(fg_sel("FLACGPU_AUTOC1")) == 3 ? 3u : 0u))) : 0u;
     if (nfast && use_pipe) {
         PL.nblocks = nfast;
         if (timing) {

@@ -179,7 +179,7 @@ struct FgPipeLaunch {
     // run beside each other where their ends and starts meet, and nobody's last, half-empty round of workgroups leaves the chip idle
     // (two groups: 0.485 -> 0.474 ms on the headline stream; more groups lose to their synchronisation, pipe_shape.inc).
     uint32_t no_keep;           // packing: the two-walk form for every block (FLACGPU_KEEP=0: cross-check of the kept-residual form)
-    uint32_t no_autoc1;         // autocorrelation: 1 = fg_pipe_autoc_kernel also for launches of a few blocks, 2 = fg_pipe_autoc1_kernel for every launch (FLACGPU_AUTOC1=0 / 2: cross-checks)
+    uint32_t no_autoc1;         // autocorrelation: 1 = fg_pipe_autoc_kernel also for launches of a few blocks, 2 = fg_pipe_autoc1_kernel for every launch, 3 = its windows never side by side (FLACGPU_AUTOC1=0 / 2 / 3: cross-checks)
     uint32_t ngroups;           // 0, 1: one chain on `stream`
     void *gstream[3];           // streams of groups 1..3
     void *gev_fork, *gev_join[3];

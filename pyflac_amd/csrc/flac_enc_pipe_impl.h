@@ -634,6 +634,10 @@ fg_pipe_autoc_kernel(const void *pcm, const FgBlockDesc *descs, const float *win
 // fall into the slot before (in front of slot 0 a copy of the end of slot 2); the workgroup meets at a barrier a chunk: in phase p
 // chunk p is stored while the chain runs over chunk p - 1, whose history in slot (p - 2) % 3 nobody writes.
 // Used for launches of up to FGP_A1_MAX blocks (pipe_shape.inc): beyond that the chip is full of one-wave blocks anyway.
+// Windows side by side (wpar, levels 6 - 8: subdivide_tukey): the whole-block window, the half-block and the third-block windows are
+// independent chains, so a launch of very few blocks gives each its own workgroup (blockIdx.y = which of them; up to six), which
+// leaves its vector as it comes out of the chain; fg_pipe_autoc_fix_kernel then makes the punched windows (differences of two
+// vectors) and scales everything by the wasted bits, which only the workgroup of the whole-block window knows.
 #define FGP_A1S 8
 #define FGP_A1_MAX 256
 #define FGP_A1RSTR (FGP_DH + 3 * FGP_CK + FGP_SLK)
@@ -641,7 +645,7 @@ FGI void pipe_a1_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::
 template <bool MS, int NCH, int MAXO>
 __global__ void __launch_bounds__(64 * (1 + FGP_A1S))
 fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *windows, FgEncParams P, FgPipeBufs B, FgDebugRec *dbg,
-                      uint32_t nblocks, uint32_t bi0)
+                      uint32_t nblocks, uint32_t bi0, uint32_t wpar)
 {
     constexpr int NC = MS ? 4 : NCH;
     constexpr uint32_t RSTR = FGP_A1RSTR;                       // a candidate's row: history of slot 0, three slots, zeros
@@ -651,7 +655,7 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     const int lane = threadIdx.x & 63;
     const uint32_t bi = (bi0 & 0x3FFFFFFFu) + blockIdx.x;
     // (bits 31 / 30 of bi0: as in fg_pipe_autoc_kernel)
-    if ((bi0 >> 30) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((bi0 >> 30) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (B.stamp) B.stamp[0] = wall_clock64();
         if ((bi0 >> 31) && B.guard) { B.guard[0] = 0ull; B.guard[1] = 0x7FF0000000000000ull; B.guard[2] = 0ull; }
     }
@@ -699,9 +703,12 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     };
     uint32_t nv = 0;
     const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+    // (wpar: this workgroup's window among those that run a chain, and where its vector went)
+    const uint32_t wsel = wpar ? blockIdx.y : 0xFFFFFFFFu;
+    uint32_t realw = 0, myv = 0xFFFFFFFFu;
     if (mo == 0) {
         // no LPC at this level: only the OR of the samples is needed
-        if (wv != 0) {
+        if (wv != 0 && (!wpar || wsel == 0)) {
             for (uint32_t i = (wv - 1) * 64 + (uint32_t)lane; i < n; i += 64 * FGP_A1S) {
                 int32_t L, R;
                 ldraw(i, L, R);
@@ -723,7 +730,9 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
                 else if (!(vc_ & 1)) { vec_len = n / vb_; part = n / vb_ / 2; sh = (vc_ / 2 * n) / vb_; }
                 else punch = true;
             }
-            if (!skip && !punch) {
+            if (!skip && !punch && wsel != 0xFFFFFFFFu && wsel != realw++) { /* another workgroup's window */ }
+            else if (!skip && !punch) {
+                myv = nv;
                 // the history of the first chunk: zeros
                 if (threadIdx.x < (uint32_t)NC * FGP_DH) ring[(threadIdx.x / FGP_DH) * RSTR + (threadIdx.x % FGP_DH)] = 0.0;
                 pipe_a1_barrier();
@@ -881,7 +890,7 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
             else if (punch) {
                 // root - previous partial for lags < mo; lag mo keeps the partial (upstream quirk)
-                if (wv == 0) {
+                if (wv == 0 && !wpar) {
                     const uint32_t total = (uint32_t)NC * (mo + 1);
                     for (uint32_t j = lane; j < total; j += 64) {
                         const uint32_t c = j / (mo + 1), ll = j % (mo + 1);
@@ -913,6 +922,17 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     }
     pipe_a1_barrier();
     if (wv != 0) return;
+    if (wpar) {
+        // this window's vector as the chain left it (fg_pipe_autoc_fix_kernel does the rest); the whole-block window's workgroup has
+        // seen every sample: the wasted bits and the number of vectors are its to say
+        if (myv != 0xFFFFFFFFu && mo > 0) {
+            for (uint32_t j = lane; j < (uint32_t)NC * (MAXO + 1); j += 64) {
+                const uint32_t c = j / (MAXO + 1), ll = j % (MAXO + 1);
+                B.autoc[((size_t)bi * NC + c) * P.nvec * (MAXO + 1) + (size_t)myv * (MAXO + 1) + ll] = autoc[(c * P.nvec + myv) * (MAXO + 1) + ll];
+            }
+        }
+        if (wsel != 0) return;
+    }
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t o = orx[c];
@@ -924,7 +944,7 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
     }
     if (lane == 0) B.nv[bi] = nv;
     wave_lds_fence();
-    if (mo > 0) {
+    if (mo > 0 && !wpar) {
         const uint32_t per = P.nvec * (MAXO + 1);
         for (uint32_t j = lane; j < (uint32_t)NC * per; j += 64) {
             const uint32_t c = j / per;
@@ -938,6 +958,60 @@ fg_pipe_autoc1_kernel(const void *pcm, const FgBlockDesc *descs, const float *wi
             }
         }
         if (mydbg && lane < NC) mydbg->cand[lane].nvec = nv;
+    }
+}
+
+// (behind fg_pipe_autoc1_kernel with its windows side by side: the punched windows and the scaling by the wasted bits, as the tail of
+// that kernel does them when one workgroup has all the vectors.  One wave a block.)
+template <int MAXO>
+__global__ void __launch_bounds__(64)
+fg_pipe_autoc_fix_kernel(const FgBlockDesc *descs, FgEncParams P, FgPipeBufs B, uint32_t NC, uint32_t nblocks, uint32_t bi0)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LDS double *a = (LDS double *)smem;                 // [NC][nvec][MAXO + 1]
+    const uint32_t bi = bi0 + blockIdx.x;
+    if (bi >= nblocks) return;
+    const uint32_t n = descs[bi].n;
+    const uint32_t mo = P.max_lpc_order >= n ? n - 1 : P.max_lpc_order;
+    if (mo == 0) return;
+    const int lane = threadIdx.x;
+    const uint32_t per = P.nvec * (MAXO + 1), total = NC * per;
+    double *g = B.autoc + (size_t)bi * total;
+    for (uint32_t j = lane; j < total; j += 64) a[j] = g[j];
+    wave_lds_fence();
+    // the windows in the order the autocorrelation kernels count them (fg_pipe_autoc_kernel); the punched ones in place
+    uint32_t nv = 0, vb_ = 1, vc_ = 0;
+    bool more = true;
+    while (more) {
+        bool punch = false, skip = false;
+        if (nv > 0) {
+            if (n / vb_ <= 32) skip = true;
+            else if (vc_ & 1) punch = true;
+        }
+        if (punch) {
+            for (uint32_t j = lane; j < NC * (mo + 1); j += 64) {
+                const uint32_t c = j / (mo + 1), ll = j % (mo + 1);
+                LDS double *base = a + c * per;
+                const double prev = base[(nv - 1) * (MAXO + 1) + ll];
+                base[nv * (MAXO + 1) + ll] = (ll < mo) ? base[ll] - prev : prev;
+            }
+            wave_lds_fence();
+        }
+        if (!skip) nv++;
+        if (P.apod_parts < 2) more = false;
+        else if (nv == 1 && vb_ == 1) { vb_ = 2; vc_ = 0; }
+        else {
+            if (vb_ == 2) { if (vc_ == 0) vc_ = 2; else { vc_ = 0; vb_++; } }
+            else if (vc_ < 2 * vb_ - 1) vc_++;
+            else { vc_ = 0; vb_++; }
+            if (vb_ > P.apod_parts) more = false;
+        }
+    }
+    for (uint32_t c = 0; c < NC; c++) {
+        // (2^-2w: a power of two, exact)
+        const uint32_t w = rfl(B.wasted[bi * NC + c]) & 0xFFu;
+        const double sc = __hiloint2double((int)((1023u - 2u * w) << 20), 0);
+        for (uint32_t j = lane; j < per; j += 64) g[c * per + j] = w ? a[c * per + j] * sc : a[c * per + j];
     }
 }
 

@@ -139,6 +139,9 @@ def test_both_autocorrelation_kernels_on_the_emulated_runs():
     assert r['ran'] >= 20 and r['bad'] == [], r
     r = _run('fuzz', 0, 40, env={'GFX950EMU_SCHED': '17'})
     assert r['ran'] >= 20 and r['bad'] == [], r
+    # (levels 6 - 8, very few blocks: the windows side by side is the release choice; one behind the other with FLACGPU_AUTOC1=3)
+    r = _run('dropin', 8, 0.2, 2, 24, env={'PYFLAC_AMD_TESTHOOKS': '1', 'FLACGPU_AUTOC1': '3'})
+    assert r['finish'] and r['frames_equal_oracle'] and r['decoded_equals_input'], r
 
 
 @pytest.mark.parametrize('level,bps,enc_max,dec_max', [(5, 16, 25600, 16700), (8, 24, 98500, 25200)])

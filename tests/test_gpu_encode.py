@@ -414,14 +414,16 @@ def test_the_autocorrelation_of_a_few_blocks_by_a_workgroup_each_equals_the_wave
     wave on the chains of matrix instructions, eight that stage the chunks ahead of it); larger ones keep fg_pipe_autoc_kernel (a wave
     a block).  Same sums in the same order: the bytes are the oracle's either way -- every level's windows (partial and punched ones
     at level 8), one and two channels, 16 / 24 / 32 bit, int16 input, odd block sizes and tails, a single short block -- with the
-    release library's choice, with the old kernel forced on the small launch and the new one on a large one (test-hooks library)."""
+    release library's choice (at levels 6 - 8 and up to 42 blocks: the windows that run a chain side by side, a workgroup each, and
+    fg_pipe_autoc_fix_kernel behind them), with the old kernel forced on the small launch (FLACGPU_AUTOC1=0), the new one on every
+    launch (2) and with its windows one behind the other (3) -- test-hooks library."""
     import torch
     from pyflac_amd import batch, synth
     from oracle import oracle as O
     rng = np.random.default_rng(61)
     cases = [(5, 2, 16, 4096, 4096 * 5 + 1234, False), (8, 2, 24, 4096, 4096 * 3 + 77, False), (8, 2, 16, 1152, 1152 * 6 + 5, True), (0, 1, 16, 4096, 4096 * 2 + 9, False),
              (3, 2, 16, 4095, 4095 * 3, False), (8, 1, 24, 2304, 2304 * 2 + 130, False), (5, 2, 32, 4096, 4096 * 2 + 300, False), (8, 2, 16, 4608, 4608 + 64, False),
-             (6, 2, 16, 4096, 100, False), (7, 2, 24, 576, 576 * 9, False)]
+             (6, 2, 16, 4096, 100, False), (7, 2, 24, 576, 576 * 9, False), (8, 2, 16, 1024, 1024 * 50 + 3, False), (6, 1, 16, 4096, 4096 * 4, False)]
     for level, ch, bps, bs, n, i16 in cases:
         base = synth.config2_stereo16(n / 48000.0 + 0.01, level + bs)[:n].astype(np.int64)
         if bps == 24:
@@ -433,7 +435,7 @@ def test_the_autocorrelation_of_a_few_blocks_by_a_workgroup_each_equals_the_wave
         cfg, _ = O.config(level, ch, bps, 48000, bs, bs != 4095)
         want, sizes = O.encode_stream(cfg, pcm)
         dev = torch.from_numpy(pcm.astype(np.int16) if i16 else pcm).cuda()
-        for c, sel in ((ctx, None), (hctx, '0'), (hctx, '2')):
+        for c, sel in ((ctx, None), (hctx, '0'), (hctx, '2'), (hctx, '3')):
             if sel is not None:
                 monkeypatch.setenv('FLACGPU_AUTOC1', sel)
             out, offs, st = c.encode(s, dev)
