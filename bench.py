@@ -254,6 +254,8 @@ def api_e2e(seconds, sr):
         dt = time.perf_counter() - t0
         enc.finish()
         lat.sort()
+        if not lat:                         # (a stream shorter than two calls of this size: --seconds below 3)
+            continue
         small[str(frames)] = {'encode_msamples_per_s': round(len(lat) * frames * 2 / dt / 1e6, 1), 'calls': len(lat),
                               'call_ms_median': round(lat[len(lat) // 2] * 1e3, 3), 'call_ms_p95': round(lat[int(len(lat) * 0.95)] * 1e3, 3)}
     out['process_call_size'] = small
