@@ -160,3 +160,18 @@ def test_instructions_a_block_stay_where_the_design_document_says_they_are(level
     if bps == 24:
         # (round 6: no chunk form left in the configs[3] launch)
         assert not any('assemble' in k or 'scan_sizes' in k for k in r['encode']['kernels']), sorted(r['encode']['kernels'])
+
+
+def test_the_serial_path_of_a_one_block_call_stays_where_the_design_document_says_it_is(tmp_path):
+    """tools/emu_oneblock.py: StreamEncoder.process() with one block is the serial work of one wave per kernel; the emulator counts the
+    instructions of every launch's longest wave.  Round 6's fg_pipe_autoc1_kernel against the wave-a-block kernel on
+    the same call: 8 375 instead of 11 470 instructions at level 5, 9 127 (its six chains side by side) instead of 43 218 at level 8."""
+    out = tmp_path / 'oneblock.json'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'emu_oneblock.py'), '--json', str(out)], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    r = json.loads(out.read_text())
+    new5, old5 = r['l5_16bit_release'], r['l5_16bit_autoc1_0']
+    new8, old8 = r['l8_24bit_release'], r['l8_24bit_autoc1_0']
+    assert new5['longest']['pipe_autoc1_kernel'] <= 8500 < 11000 <= old5['longest']['pipe_autoc_kernel']
+    assert new8['longest']['pipe_autoc1_kernel'] <= 9300 and new8['longest']['pipe_autoc_fix_kernel'] <= 1200 and old8['longest']['pipe_autoc_kernel'] >= 40000
+    assert new5['serial_path'] <= 19400 and new8['serial_path'] <= 43000

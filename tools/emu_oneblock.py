@@ -2,7 +2,7 @@
 instructions its LONGEST wave executes (tests/emu counts them per wave), with fg_pipe_autoc1_kernel (round 6: a workgroup a block, one
 wave on the chains, eight staging) and with fg_pipe_autoc_kernel forced on the same call (FLACGPU_AUTOC1=0, test-hooks library: a wave
 a block, which stages its own chunks).  Counts, not times: what they bound is the issue time of the wave everything else waits for.
-usage: python tools/emu_oneblock.py > profiles/r06_emu_oneblock.txt"""
+usage: python tools/emu_oneblock.py [--json file] > profiles/r06_emu_oneblock.txt"""
 import json
 import os
 import sys
@@ -16,6 +16,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from pyflac_amd import batch, synth, _lib  # noqa: E402
 
+res = {}
 print('# kernel id %s; one block of 4096 stereo samples per call; longest = instructions executed by the wave that executes most' % _lib.lib().flacgpu_kernel_id().decode())
 for level, bps in ((5, 16), (8, 24)):
     sr = 48000 if bps == 16 else 96000
@@ -39,3 +40,7 @@ for level, bps in ((5, 16), (8, 24)):
             print('   %-50s waves %3d   all %7d   longest %6d   matrix %5d' % (name, v['waves'], v['wave_insts'], v['max_wave_insts'], v['mfma']))
             tot += v['max_wave_insts']
         print('   sum of the longest waves of the call\'s kernels (they run one behind the other): %d' % tot)
+        res['l%d_%dbit_%s' % (level, bps, 'release' if sel is None else 'autoc1_0')] = {'serial_path': tot, 'longest': {k.split('fg_')[-1].split('IL')[0].split('EP')[0]: v['max_wave_insts'] for k, v in st.items()}}
+if '--json' in sys.argv:
+    with open(sys.argv[sys.argv.index('--json') + 1], 'w') as fh:
+        json.dump(res, fh, indent=1)
