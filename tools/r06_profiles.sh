@@ -11,6 +11,8 @@ for f in fuzz_gpu fuzz_api fuzz_damage fuzz_dec_stream fuzz_batch fuzz32; do [ -
 cp gpurun_out/prof_r06$TAG/trace/*kernel_stats.csv $P/r06_${L}_kernel_stats.csv 2>/dev/null
 cp gpurun_out/prof_r06$TAG/summary.txt $P/r06_${L}_summary.txt 2>/dev/null
 cp $O/small_calls.txt $P/r06_small_calls.txt 2>/dev/null
+# configs[3]: the direct packing form against the chunk form (bench.py --workload stream24 [--no-direct], two runs each)
+for f in $O/bench_stream24_*.json; do [ -f $f ] && echo "$(basename $f .json): $(python3 -c "import json,sys; d=json.load(open('$f')); print('ms_per_step', d.get('ms_per_step'), 'encode_gpu_ms', d.get('encode_gpu_ms'), 'value', d.get('value'), 'kernel_id', d.get('kernel_id'))")"; done > $P/r06_${L}_stream24_direct_vs_chunk.txt
 cp $O/build_id.txt $P/r06_${L}_build_id.txt
 [ -d gpurun_out/prof_r06$TAG/pmc3 ] && python3 tools/rocprof_pmc.py gpurun_out/prof_r06$TAG stream16 7032 5 r06 $O/build_id.txt > /dev/null
 for spec in "stream24 7032 8" "batch 90112 5"; do
